@@ -1,0 +1,446 @@
+#!/usr/bin/env python3
+"""
+Golden-vector generator.  Runs ONLY in the build container, where the read-only
+reference checkout exists at /root/reference: it imports the reference's
+``pygho.backend`` / ``pygho.honn`` (pure Python on torch-CPU), feeds them seeded
+inputs and stores inputs + outputs as small ``.npz`` fixtures next to this
+script.  The fixtures are data (arrays only); no reference source travels.
+
+    python tests/golden/make_golden.py
+
+Index-planner outputs are stored in canonical form (columns lexsorted by
+(b|a, c, d)) because the reference's order inside one output segment is not
+deterministic.
+
+``torch_geometric`` is absent here.  ``pygho.honn.Conv`` imports
+``torch_geometric.nn.HeteroLinear`` at module scope (Conv.py:15) but NGNNConv /
+SSWLConv / I2Conv never use it, so a placeholder module entry is registered to
+let the import succeed; fixtures are only produced for layers that do not touch it.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+# placeholder so that `from torch_geometric.nn import HeteroLinear` resolves
+_tg = types.ModuleType("torch_geometric")
+_tgnn = types.ModuleType("torch_geometric.nn")
+
+
+class _Unavailable(torch.nn.Module):
+    def __init__(self, *a, **k):
+        raise RuntimeError("torch_geometric is not available in this container")
+
+
+_tgnn.HeteroLinear = _Unavailable
+_tg.nn = _tgnn
+sys.modules.setdefault("torch_geometric", _tg)
+sys.modules.setdefault("torch_geometric.nn", _tgnn)
+
+import warnings  # noqa: E402
+
+from pygho import MaskedTensor, SparseTensor  # noqa: E402  (reference)
+from pygho.backend import Mamamm, SpTensor, Spmm, Spspmm  # noqa: E402
+from pygho.backend.utils import torch_scatter_reduce  # noqa: E402
+from pygho.honn import Conv as RefConv  # noqa: E402
+from pygho.honn import SpOperator as RefSpOp  # noqa: E402
+from pygho.honn import TensorOp as RefTensorOp  # noqa: E402
+
+from pygho_amd import synth  # noqa: E402  (host-side generator of this repo)
+
+T = torch.from_numpy
+
+
+def canon(t: torch.Tensor) -> np.ndarray:
+    a = t.numpy()
+    return a[:, np.lexsort((a[2], a[1], a[0]))]
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path)/1024:.1f} KiB, {len(arrays)} arrays")
+
+
+# --------------------------------------------------------------------------
+def gen_hash():
+    rng = np.random.default_rng(11)
+    out = {}
+    for sd, hi in ((2, 2**31 - 1), (3, 2**21 - 1), (4, 2**15 - 1), (5, 4000)):
+        ind = rng.integers(0, hi + 1, size=(sd, 64)).astype(np.int64)
+        ind[:, 0] = hi                                   # boundary value
+        ind[:, 1] = 0
+        h = SpTensor.indicehash(T(ind))
+        out[f"ind{sd}"] = ind
+        out[f"hash{sd}"] = h.numpy()
+        out[f"dec{sd}"] = SpTensor.decodehash(h, sd).numpy()
+    shape = np.array([2, 3, 7, 11, 13], dtype=np.int64)
+    ind = np.stack([rng.integers(0, s, size=40) for s in shape]).astype(np.int64)
+    th = SpTensor.indicehash_tight(T(ind), T(shape))
+    out.update(tight_shape=shape, tight_ind=ind, tight_hash=th.numpy(),
+               tight_dec=SpTensor.decodehash_tight(th, T(shape)).numpy())
+    # coalesce (SpTensor.py:167-197) with duplicates, every reduce
+    ind = rng.integers(0, 4, size=(3, 60)).astype(np.int64)
+    val = rng.standard_normal((60, 5)).astype(np.float32)
+    out.update(co_ind=ind, co_val=val)
+    for red in ("sum", "mean", "max", "min"):
+        ci, cv = SpTensor.coalesce(T(ind), T(val), red)
+        out[f"co_ind_out"] = ci.numpy()
+        out[f"co_val_{red}"] = cv.numpy()
+    save("hash.npz", **out)
+
+
+# --------------------------------------------------------------------------
+def gen_scatter():
+    rng = np.random.default_rng(12)
+    out = {}
+    # the vector observed in SURVEY.md 8(c)-3
+    src = np.array([[1, -2], [4, 5], [7, -8], [9, 10]], dtype=np.float32)
+    ind = np.array([2, 2, 0, 0], dtype=np.int64)
+    out.update(s0_src=src, s0_ind=ind, s0_size=np.int64(4))
+    for ag in ("sum", "mean", "max", "min"):
+        out[f"s0_{ag}"] = torch_scatter_reduce(0, T(src), T(ind), 4, ag).numpy()
+    # random with empty segments, 2-D dense shape, unsorted index
+    src = rng.standard_normal((200, 3, 4)).astype(np.float32)
+    ind = rng.integers(0, 50, size=200).astype(np.int64)
+    ind[ind % 7 == 0] = 1
+    out.update(s1_src=src, s1_ind=ind, s1_size=np.int64(53))
+    for ag in ("sum", "mean", "max", "min"):
+        out[f"s1_{ag}"] = torch_scatter_reduce(0, T(src), T(ind), 53, ag).numpy()
+    # int64 (distance features use reduce="min", hodata/SpTupleSampler.py:126), 1-D src
+    src = rng.integers(-9, 9, size=64).astype(np.int64)
+    ind = rng.integers(0, 10, size=64).astype(np.int64)
+    out.update(s2_src=src, s2_ind=ind, s2_size=np.int64(12))
+    for ag in ("sum", "mean", "max", "min"):
+        out[f"s2_{ag}"] = torch_scatter_reduce(0, T(src), T(ind), 12, ag).numpy()
+    # known-answer vector of the reference's own test (tests/test_backend_sparse.py:94-99)
+    ptr = np.array([0, 4, 4, 7, 8, 11, 11, 11, 16], dtype=np.int64)
+    out.update(ptr=ptr, ptr_batch=Spspmm.ptr2batch(T(ptr), 16).numpy(),
+               ptr_expected=np.array([0, 0, 0, 0, 2, 2, 2, 3, 4, 4, 4, 7, 7, 7, 7, 7], dtype=np.int64))
+    deg = np.array([2, 0, 3, 1, 0], dtype=np.int64)
+    out.update(deg=deg, deg_batch=Spspmm.deg2batch(T(deg), 6).numpy())
+    save("scatter.npz", **out)
+
+
+# --------------------------------------------------------------------------
+def rand_pattern(rng, shape, nnz):
+    ind = np.stack([rng.integers(0, s, size=nnz) for s in shape]).astype(np.int64)
+    h = np.unique(SpTensor.indicehash(T(ind)).numpy())
+    return SpTensor.decodehash(T(h), len(shape)).numpy()
+
+
+def gen_planner():
+    rng = np.random.default_rng(13)
+    out = {}
+    cases = []
+    # docstring toy inputs (Spspmm.py:88-94, 166-170, 207-214)
+    ind1 = np.array([[0, 1, 1, 2], [2, 1, 0, 2]], dtype=np.int64)
+    ind2 = np.array([[2, 1, 0, 1], [1, 0, 2, 2]], dtype=np.int64)
+    cases.append(("doc", ind1, 0, ind2, 1, None))
+    n = 9
+    A2 = rand_pattern(rng, (n, n), 30)
+    B2 = rand_pattern(rng, (n, n), 25)
+    cases.append(("2x2_10", A2, 1, B2, 0, rand_pattern(rng, (n, n), 40)))
+    cases.append(("2x2_01", A2, 0, B2, 1, rand_pattern(rng, (n, n), 40)))
+    A3 = rand_pattern(rng, (n, n, n), 80)
+    cases.append(("3x2_20", A3, 2, B2, 0, A3))
+    B3 = rand_pattern(rng, (n, n, n), 60)
+    cases.append(("3x3_11", A3, 1, B3, 1, rand_pattern(rng, (n, n, n, n), 300)))
+    # one real graph, the keys of the shipped layers
+    g = synth.make_graph(np.random.default_rng(5), "zinc")
+    cases.append(("ngnn", g.tupleid, 1, g.edge_index, 0, g.tupleid))
+    cases.append(("sswl", g.edge_index, 1, g.tupleid, 0, g.tupleid))
+    cases.append(("ppgn", g.tupleid, 1, g.tupleid, 0, g.tupleid))
+    names = []
+    for name, i1, d1, i2, d2, tar in cases:
+        tarind, bcd = Spspmm.spspmm_ind(T(i1), d1, T(i2), d2)
+        out[f"{name}_ind1"], out[f"{name}_ind2"] = i1, i2
+        out[f"{name}_dims"] = np.array([d1, d2], dtype=np.int64)
+        out[f"{name}_tarind"] = tarind.numpy()
+        out[f"{name}_bcd"] = canon(bcd)
+        if tar is not None:
+            out[f"{name}_tar"] = tar
+            out[f"{name}_b2a"] = Spspmm.spsphadamard_ind(T(tar), tarind).numpy()
+            out[f"{name}_acd"] = canon(Spspmm.filterind(T(tar), tarind, bcd))
+        names.append(name)
+    out["names"] = np.array(names)
+    # docstring filterind / hadamard_ind example
+    tar = np.array([[0, 1, 1, 2], [0, 0, 1, 2]], dtype=np.int64)     # sorted variant of the docstring's
+    ind = np.array([[2, 1, 0, 1], [2, 0, 2, 1]], dtype=np.int64)
+    bcd = np.array([[3, 2, 1, 0], [6, 5, 4, 3], [9, 8, 7, 6]], dtype=np.int64)
+    out.update(fdoc_tar=tar, fdoc_ind=ind, fdoc_bcd=bcd,
+               fdoc_b2a=Spspmm.spsphadamard_ind(T(tar), T(ind)).numpy(),
+               fdoc_acd=canon(Spspmm.filterind(T(tar), T(ind), T(bcd))))
+    save("planner.npz", **out)
+
+
+# --------------------------------------------------------------------------
+def ref_grads(fn, tensors):
+    """run fn on leaf copies, return (out, grads wrt each tensor) under a fixed linear loss."""
+    leaves = [None if t is None else t.clone().requires_grad_(True) for t in tensors]
+    out = fn(*leaves)
+    g = torch.Generator().manual_seed(99)
+    w = torch.randn(out.shape, generator=g)
+    (out * w).sum().backward()
+    return out.detach(), w, [None if l is None else l.grad for l in leaves]
+
+
+def gen_sparse_ops():
+    out = {}
+    d = 8
+    hb = synth.make_batch(4, "zinc", seed=21, keys=("X___X___1___A___0", "X___A___1___X___0", "X___X___1___X___0"))
+    g = torch.Generator().manual_seed(7)
+    N, E, nnz = hb.num_nodes, hb.num_edges, hb.num_tuples
+    ei, tid = T(hb.edge_index), T(hb.tupleid)
+    Av = torch.randn((E, d), generator=g)
+    Xv = torch.randn((nnz, d), generator=g)
+    xn = torch.randn((N, d), generator=g)
+    out.update(N=np.int64(N), edge_index=hb.edge_index, tupleid=hb.tupleid, Av=Av.numpy(), Xv=Xv.numpy(), xn=xn.numpy())
+    for k, v in hb.acd.items():
+        out["acd_" + k] = v
+    # the collated acd must equal the reference planner on the whole batch
+    tarind, bcd = Spspmm.spspmm_ind(tid, 1, ei, 0)
+    out["acd_ref_X___X___1___A___0"] = canon(Spspmm.filterind(tid, tarind, bcd))
+
+    def mk(ind, val, n):
+        return SparseTensor(ind, val, [n, n] + ([] if val is None else list(val.shape[1:])), is_coalesced=True)
+
+    key = "X___X___1___A___0"
+    acd = T(hb.acd[key])
+    for ag in ("sum", "mean", "max", "min"):
+        o, w, (gx, ga) = ref_grads(
+            lambda xv, av: Spspmm.spspmm(mk(tid, xv, N), 1, mk(ei, av, N), 0, ag, acd=acd, tar_ind=tid).values, [Xv, Av])
+        out[f"spspmm_{ag}"], out[f"spspmm_{ag}_w"] = o.numpy(), w.numpy()
+        out[f"spspmm_{ag}_gX"], out[f"spspmm_{ag}_gA"] = gx.numpy(), ga.numpy()
+    # pattern-only operands
+    out["spspmm_noA_sum"] = Spspmm.spspmm(mk(tid, Xv, N), 1, mk(ei, None, N), 0, "sum", acd=acd, tar_ind=tid).values.numpy()
+    out["spspmm_noX_max"] = Spspmm.spspmm(mk(tid, None, N), 1, mk(ei, Av, N), 0, "max", acd=acd, tar_ind=tid).values.numpy()
+    # cross-subgraph key (SSWL) and 2-FWL key (PPGN)
+    acd2 = T(hb.acd["X___A___1___X___0"])
+    out["spspmm_cross_sum"] = Spspmm.spspmm(mk(ei, Av, N), 1, mk(tid, Xv, N), 0, "sum", acd=acd2, tar_ind=tid).values.numpy()
+    acd3 = T(hb.acd["X___X___1___X___0"])
+    out["spspmm_fwl_sum"] = Spspmm.spspmm(mk(tid, Xv, N), 1, mk(tid, Xv * 0.5, N), 0, "sum", acd=acd3, tar_ind=tid).values.numpy()
+    # slow path without precomputed acd (Spspmm.py:322-331): full product pattern
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        full = Spspmm.spspmm(mk(tid, Xv, N), 1, mk(ei, Av, N), 0, "sum")
+        filt = Spspmm.spspmm(mk(tid, Xv, N), 1, mk(ei, Av, N), 0, "sum", tar_ind=tid)
+    out["spspmm_slow_ind"], out["spspmm_slow_val"] = full.indices.numpy(), full.values.numpy()
+    out["spspmm_slowtar_val"] = filt.values.numpy()
+    # spspmpnn with a message function using all three operands
+    mf = lambda a, b, c, tarid: a * b + c
+    o, w, (gx, ga) = ref_grads(
+        lambda xv, av: Spspmm.spspmpnn(mk(tid, xv, N), 1, mk(ei, av, N), 0, mk(tid, xv, N), acd, mf, "sum").values, [Xv, Av])
+    out.update(spspmpnn_sum=o.numpy(), spspmpnn_w=w.numpy(), spspmpnn_gX=gx.numpy(), spspmpnn_gA=ga.numpy())
+    # spmm (Spmm.py), both contracted dims, with / without values, broadcast scalar values
+    for dim1 in (0, 1):
+        for ag in ("sum", "mean", "max"):
+            o, w, (ga, gx) = ref_grads(lambda av, x: Spmm.spmm(mk(ei, av, N), dim1, x, ag), [Av, xn])
+            out[f"spmm_{dim1}_{ag}"], out[f"spmm_{dim1}_{ag}_w"] = o.numpy(), w.numpy()
+            out[f"spmm_{dim1}_{ag}_gA"], out[f"spmm_{dim1}_{ag}_gx"] = ga.numpy(), gx.numpy()
+    out["spmm_noval"] = Spmm.spmm(mk(ei, None, N), 1, xn, "sum").numpy()
+    Asc = Av[:, :1].contiguous()
+    out["spmm_scalar"] = Spmm.spmm(SparseTensor(ei, Asc, [N, N, 1], True), 1, xn, "sum").numpy()
+    # hadamard
+    rng = np.random.default_rng(3)
+    P = rand_pattern(rng, (N, N), 400)
+    Pv = torch.randn((P.shape[1], d), generator=g)
+    had = Spspmm.spsphadamard(mk(tid, Xv, N), mk(T(P), Pv, N))
+    out.update(had_P=P, had_Pv=Pv.numpy(), had_ind=had.indices.numpy(), had_val=had.values.numpy())
+    # pooling / diag / unpooling / add / catvalue / diagonalapply (SpTensor.py:304-524)
+    X = mk(tid, Xv, N)
+    for red in ("sum", "mean", "max"):
+        for dims in (0, 1):
+            o, w, (gx,) = ref_grads(lambda xv: getattr(mk(tid, xv, N), red)(dims), [Xv])
+            out[f"pool_{red}_{dims}"], out[f"pool_{red}_{dims}_w"], out[f"pool_{red}_{dims}_g"] = o.numpy(), w.numpy(), gx.numpy()
+    out["diag"] = X.diag([0, 1]).numpy()
+    o, w, (gx,) = ref_grads(lambda v: X.unpooling_fromdense1dim(0, v).values, [xn])
+    out["unpool0"], out["unpool0_w"], out["unpool0_g"] = o.numpy(), w.numpy(), gx.numpy()
+    out["unpool1"] = X.unpooling_fromdense1dim(1, xn).values.numpy()
+    out["add_same"] = X.add(mk(tid, Xv * 2, N), True).values.numpy()
+    addp = X.add(mk(T(P), Pv, N), False)
+    out["add_diff_ind"], out["add_diff_val"] = addp.indices.numpy(), addp.values.numpy()
+    out["cat"] = X.catvalue([mk(tid, Xv * 2, N), mk(tid, Xv * 3, N)], True).values.numpy()
+    out["diagflag"] = X.diagonalapply(lambda v, f: f.unsqueeze(-1).to(v.dtype) * v).values.numpy()
+
+    # 3-tuple batch (I2 shape): spspmm, sparse pooling, sparse->sparse unpooling
+    hb3 = synth.make_batch(2, "i2", seed=22)
+    N3 = hb3.num_nodes
+    d3 = 4
+    ei3, tid3 = T(hb3.edge_index), T(hb3.tupleid)
+    Av3 = torch.randn((hb3.num_edges, d3), generator=g)
+    Xv3 = torch.randn((hb3.num_tuples, d3), generator=g)
+    acd3d = T(hb3.acd["X___X___2___A___0"])
+    X3 = SparseTensor(tid3, Xv3, [N3, N3, N3, d3], True)
+    A3 = SparseTensor(ei3, Av3, [N3, N3, d3], True)
+    out.update(N3=np.int64(N3), edge_index3=hb3.edge_index, tupleid3=hb3.tupleid, Av3=Av3.numpy(), Xv3=Xv3.numpy(),
+               acd3=hb3.acd["X___X___2___A___0"])
+    tarind3, bcd3 = Spspmm.spspmm_ind(tid3, 2, ei3, 0)
+    out["acd3_ref"] = canon(Spspmm.filterind(tid3, tarind3, bcd3))
+    for ag in ("sum", "max"):
+        out[f"spspmm3_{ag}"] = Spspmm.spspmm(X3, 2, A3, 0, ag, acd=acd3d, tar_ind=tid3).values.numpy()
+    for red in ("sum", "mean", "max"):
+        p = getattr(X3, red)([2], return_sparse=True)
+        out[f"pool3_{red}_ind"], out[f"pool3_{red}_val"] = p.indices.numpy(), p.values.numpy()
+    p = X3.sum([2], return_sparse=True)
+    out["unpool3"] = p.unpooling([2], X3).values.numpy()
+    out["pool3_dense_12"] = X3.sum([1, 2]).numpy()
+    out["pool3_dense_2"] = X3.sum([2]).numpy()
+    # constructor-time coalesce of an unsorted duplicate-carrying pattern (KhopSampler uses reduce="min")
+    dup = torch.cat((tid, tid[:, :50]), dim=1)
+    dupv = torch.cat((Xv, Xv[:50] - 1.0), dim=0)
+    perm = torch.randperm(dup.shape[1], generator=g)
+    cs = SparseTensor(dup[:, perm], dupv[perm], [N, N, d], False, "min")
+    out.update(ctor_ind_in=dup[:, perm].numpy(), ctor_val_in=dupv[perm].numpy(),
+               ctor_ind=cs.indices.numpy(), ctor_val=cs.values.numpy())
+    save("sparse_ops.npz", **out)
+
+
+# --------------------------------------------------------------------------
+def gen_masked_ops():
+    out = {}
+    b, n, d = 3, 6, 5
+    dn = synth.make_dense_batch(b, seed=31, hidden=d, clip_nodes=7)
+    n = dn["nodemask"].shape[1]
+    g = torch.Generator().manual_seed(8)
+    Xd, Ad, xd = T(dn["X"]), T(dn["A"]), T(dn["x"])
+    Xm, Am, nm = T(dn["Xmask"]), T(dn["Amask"]), T(dn["nodemask"])
+    out.update(X=dn["X"], A=dn["A"], x=dn["x"], Xmask=dn["Xmask"], Amask=dn["Amask"], nodemask=dn["nodemask"])
+    MX, MA, Mx = MaskedTensor(Xd, Xm), MaskedTensor(Ad, Am), MaskedTensor(xd, nm)
+    # the four contractions the operators issue (MaOperator.py:181,217,258; node-level :36)
+    pairs = {"X2A1": (MX, 2, MA, 1), "A1X1": (MA, 1, MX, 1), "X2X1": (MX, 2, MX, 1)}
+    for name, (P, d1, Q, d2) in pairs.items():
+        o, w, (gp, gq) = ref_grads(
+            lambda p, q: Mamamm.mamamm(MaskedTensor(p, P.mask), d1, MaskedTensor(q, Q.mask), d2, Xm).data, [P.data, Q.data])
+        out[f"mamamm_{name}"], out[f"mamamm_{name}_w"] = o.numpy(), w.numpy()
+        out[f"mamamm_{name}_gP"], out[f"mamamm_{name}_gQ"] = gp.numpy(), gq.numpy()
+    out["mamamm_node"] = Mamamm.mamamm(MaskedTensor(Ad[..., 0], Am), 2, Mx, 1, nm).data.numpy()
+    # 3-D representation x adjacency: einsum("bijkd,bkld->bijld")
+    X3 = torch.randn((b, n, n, n, d), generator=g)
+    m3 = Xm[:, :, :, None] & nm[:, None, None, :]
+    X3 = X3 * m3[..., None]
+    out.update(X3=X3.numpy(), X3mask=m3.numpy())
+    out["mamamm_X3A1"] = Mamamm.mamamm(MaskedTensor(X3, m3), 3, MA, 1, m3).data.numpy()
+    # reductions on PRE-FILLED inputs (where reference behaviour == documented behaviour)
+    for op in ("sum", "mean", "max"):
+        for dims in ([1], [2], [1, 2]):
+            r = getattr(MX, op)(dims)
+            out[f"red_{op}_{''.join(map(str, dims))}"] = r.data.numpy()
+            out[f"red_{op}_{''.join(map(str, dims))}_mask"] = r.mask.numpy()
+    dg = MX.diag([1, 2])
+    out["diag"], out["diag_mask"] = dg.data.numpy(), dg.mask.numpy()
+    up = Mx.unpooling([2], MX)
+    out["unpool2"] = up.data.numpy()
+    up = Mx.unpooling([1], MX)
+    out["unpool1"] = up.data.numpy()
+    out["fill1024"] = MaskedTensor(Xd, Xm, padvalue=torch.inf).fill_masked(1024.).numpy()   # test_fill pattern
+    out["diagapply"] = MX.diagonalapply(lambda v, f: v * f.unsqueeze(-1)).data.numpy()
+    out["cat"] = MX.catvalue([MX, MX], True).data.numpy()
+    out["add_same"] = MX.add(MaskedTensor(Xd * 2, Xm), True).data.numpy()
+    # known-answer vector of the reference's own test (tests/test_backend_masked.py:45-50)
+    from pygho.backend.MaTensor import filterinf
+    fi = torch.tensor([-torch.inf, 0, torch.inf, 1, 2, -torch.inf, 3])
+    out.update(filterinf_in=fi.numpy(), filterinf_out=filterinf(fi).numpy())
+    # DEVIATION fixture: unfilled constructor (MaTensor.py:107-120).  garbage at masked
+    # positions leaks into the reference's sum; the build implements the documented semantics.
+    garbage = Xd + (~Xm)[..., None] * 7.0
+    out["dev_in"] = garbage.numpy()
+    out["dev_ref_sum1"] = MaskedTensor(garbage, Xm).sum([1]).data.numpy()
+    save("masked_ops.npz", **out)
+
+
+# --------------------------------------------------------------------------
+def _randomize_bn(mod: torch.nn.Module, gen):
+    for m in mod.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=gen) * 0.1)
+
+
+def gen_layers():
+    out = {}
+    h = 16
+    mlp = {"numlayer": 1, "tailact": True, "norm": "bn", "act": "silu", "dp": 0.0}
+    keys = ("X___X___1___A___0", "X___A___1___X___0")
+    hb = synth.make_batch(4, "zinc", seed=41, keys=keys)
+    N = hb.num_nodes
+    g = torch.Generator().manual_seed(9)
+    ei, tid = T(hb.edge_index), T(hb.tupleid)
+    Av = torch.randn((hb.num_edges, h), generator=g)
+    Xv = torch.randn((hb.num_tuples, h), generator=g)
+    out.update(N=np.int64(N), edge_index=hb.edge_index, tupleid=hb.tupleid, Av=Av.numpy(), Xv=Xv.numpy())
+    datadict = {}
+    for k in keys:
+        out["acd_" + k] = hb.acd[k]
+        datadict[k + "___acd"] = T(hb.acd[k])
+    A = SparseTensor(ei, Av, [N, N, h], True)
+
+    def run(layer, name, Xvals, Aobj, dd, mkX):
+        torch.manual_seed(100)
+        _randomize_bn(layer, g)
+        layer.eval()
+        for k, v in layer.state_dict().items():
+            out[f"{name}_sd_{k}"] = v.numpy()
+        xv = Xvals.clone().requires_grad_(True)
+        res = layer(Aobj, mkX(xv), dd)
+        vals = res.values if hasattr(res, "values") else res.data
+        w = torch.randn(vals.shape, generator=g)
+        (vals * w).sum().backward()
+        pg = {k: p.grad for k, p in layer.named_parameters()}
+        out[f"{name}_out"], out[f"{name}_w"], out[f"{name}_gX"] = vals.detach().numpy(), w.numpy(), xv.grad.numpy()
+        for k, v in pg.items():
+            out[f"{name}_pg_{k}"] = v.numpy()
+
+    mk2 = lambda xv: SparseTensor(tid, xv, [N, N, h], True)
+    torch.manual_seed(1)
+    run(RefConv.NGNNConv(h, h, "sum", "SS", dict(mlp)), "ngnn", Xv, A, datadict, mk2)
+    torch.manual_seed(2)
+    run(RefConv.NGNNConv(h, h, "max", "SS", dict(mlp)), "ngnnmax", Xv, A, datadict, mk2)
+    torch.manual_seed(3)
+    run(RefConv.SSWLConv(h, h, "sum", "SS", dict(mlp)), "sswl", Xv, A, datadict, mk2)
+    # I2Conv on a 3-tuple batch
+    hb3 = synth.make_batch(2, "i2", seed=42)
+    N3 = hb3.num_nodes
+    ei3, tid3 = T(hb3.edge_index), T(hb3.tupleid)
+    Av3 = torch.randn((hb3.num_edges, h), generator=g)
+    Xv3 = torch.randn((hb3.num_tuples, h), generator=g)
+    out.update(N3=np.int64(N3), edge_index3=hb3.edge_index, tupleid3=hb3.tupleid, Av3=Av3.numpy(), Xv3=Xv3.numpy(),
+               acd3=hb3.acd["X___X___2___A___0"])
+    dd3 = {"X___X___2___A___0___acd": T(hb3.acd["X___X___2___A___0"])}
+    A3 = SparseTensor(ei3, Av3, [N3, N3, h], True)
+    torch.manual_seed(4)
+    run(RefConv.I2Conv(h, h, "sum", "SS", dict(mlp)), "i2", Xv3, A3, dd3, lambda xv: SparseTensor(tid3, xv, [N3, N3, N3, h], True))
+    # NGNNConv on the dense masked path ("DD"); compare at valid positions only
+    dn = synth.make_dense_batch(3, seed=43, hidden=h, clip_nodes=9)
+    Xd, Ad = T(dn["X"]), T(dn["A"])
+    Xm, Am = T(dn["Xmask"]), T(dn["Amask"])
+    out.update(dd_X=dn["X"], dd_A=dn["A"], dd_Xmask=dn["Xmask"], dd_Amask=dn["Amask"])
+    torch.manual_seed(5)
+    run(RefConv.NGNNConv(h, h, "sum", "DD", dict(mlp)), "ngnn_dd", Xd, MaskedTensor(Ad, Am), {}, lambda xv: MaskedTensor(xv, Xm))
+    # operator-level key plumbing (honn/SpOperator.py:135, 15-44)
+    model = torch.nn.ModuleList([RefConv.NGNNConv(h, h, "sum", "SS", dict(mlp)), RefConv.SSWLConv(h, h, "sum", "SS", dict(mlp)),
+                                 RefConv.I2Conv(h, h, "sum", "SS", dict(mlp)), RefConv.PPGNConv(h, h, "sum", "SS", dict(mlp))])
+    out["parsed_keys"] = np.array(RefSpOp.parse_precomputekey(model))
+    save("layers.npz", **out)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    gen_hash()
+    gen_scatter()
+    gen_planner()
+    gen_sparse_ops()
+    gen_masked_ops()
+    gen_layers()
