@@ -1,0 +1,224 @@
+/*
+ * pygho_hip.h -- C ABI of the MI355X (gfx950) backend for PygHO's sparse / masked
+ * operator path.
+ *
+ * The reference (GraphPKU/PygHO) is 100 % Python on ATen and has no FFI of its
+ * own; its "kernels" are the ATen ops its backend calls.  Each entry point below
+ * replaces one such ATen call sequence (file:line cited per function, relative
+ * to the reference checkout) and is what the modules of `pygho/backend` would bind through
+ * ctypes to become MI355X-native (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch allocates);
+ *     nothing is allocated, freed or synchronised inside the library;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - all functions return 0 on success or a PYGHO_ERR_* code;
+ *     `pygho_last_error()` returns a thread-local message for the last failure;
+ *   - re-entrant, no global mutable state besides the error string;
+ *   - row-major, densely packed tensors; index arrays are int32 on the device
+ *     fast path (the int64 arrays of the Python API are narrowed once per batch
+ *     by `pygho_plan_*`).
+ */
+#ifndef PYGHO_HIP_H
+#define PYGHO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYGHO_ABI_VERSION 1
+
+enum pygho_status {
+  PYGHO_OK = 0,
+  PYGHO_ERR_INVALID = 1,     /* bad argument (null pointer, negative size, unknown enum) */
+  PYGHO_ERR_UNSUPPORTED = 2, /* valid but not implemented combination */
+  PYGHO_ERR_LAUNCH = 3       /* HIP reported an error at launch */
+};
+
+enum pygho_dtype {
+  PYGHO_F32 = 0,
+  PYGHO_BF16 = 1,
+  PYGHO_F16 = 2,
+  PYGHO_F64 = 3,
+  PYGHO_I64 = 4,
+  PYGHO_I32 = 5
+};
+
+enum pygho_aggr { PYGHO_SUM = 0, PYGHO_MEAN = 1, PYGHO_MAX = 2, PYGHO_MIN = 3 };
+
+int pygho_abi_version(void);
+const char* pygho_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Fused gather * gather -> segment reduce   (K1+K2+K3 of SURVEY.md 2.1)
+ *
+ *   out[s, :] = (+)_{m in [seg_ptr[s], seg_ptr[s+1])}  scale(m) * L(m) (*) R(m)
+ *     L(m) = lhs[lhs_idx ? lhs_idx[m] : m, :]   (all-ones when lhs == NULL)
+ *     R(m) = rhs[rhs_idx ? rhs_idx[m] : m, :]   (all-ones when rhs == NULL)
+ *     scale(m) = lhs_rowscale ? lhs_rowscale[row of L(m)] : 1
+ *   (+) in {sum, mean, max, min}; segments with no message give 0 for every
+ *   aggregation; mean divides by the segment length.
+ *
+ * Replaces, in one launch and with no (M, d) temporaries:
+ *   pygho/backend/Spspmm.py:309-315   A.values[acd[1]] * B.values[acd[2]] -> torch_scatter_reduce
+ *   pygho/backend/utils.py:44-56      zeros + scatter_reduce_(include_self=False) (sorted index -> seg_ptr)
+ *   pygho/backend/Spmm.py:40-44       val * X[srcind] -> torch_scatter_reduce
+ *   and the autograd of those (index_put_(accumulate) / gather / mul) through
+ *   the transposed plans of pygho_plan_group_by_key.
+ *
+ * lhs_d / rhs_d: dense width of the operand rows, either `d` or 1 (broadcast).
+ * Accumulation: f32 for f32/bf16/f16, f64 for f64, i64 for i64 (mean floors).
+ * Products are rounded before accumulation (no FMA contraction) and summed in
+ * message order, so f32 sums are bit-identical to a sequential CPU loop.
+ */
+int pygho_seg_gather_mul_reduce(void* out, const void* lhs, const void* rhs,
+                                const int32_t* seg_ptr, const int32_t* lhs_idx,
+                                const int32_t* rhs_idx, const float* lhs_rowscale,
+                                int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d,
+                                int dtype, int aggr, void* stream);
+
+/*
+ * Backward of the max / min aggregation (autograd of scatter_reduce_(amax|amin),
+ * pygho/backend/utils.py:50-55): along a plan grouped by the operand being
+ * differentiated,
+ *   gout[s, :] = sum_m  gin[a_m, :] * other(m) * [msg(m) == fwd_out[a_m]] / ties[a_m]
+ * with msg(m) = self[s] * other[o_m] recomputed on the fly and `ties` the number
+ * of messages of segment a_m attaining the extremum (torch shares the gradient
+ * evenly among ties).  `tie_cnt` (n_out, d) f32 is produced by
+ * pygho_seg_extremum_ties.  self / other may be NULL (pattern-only operand).
+ */
+int pygho_seg_extremum_ties(float* tie_cnt, const void* fwd_out, const void* lhs, const void* rhs,
+                            const int32_t* seg_ptr, const int32_t* lhs_idx, const int32_t* rhs_idx,
+                            int64_t n_seg, int64_t d, int dtype, void* stream);
+int pygho_seg_extremum_bwd(void* gout, const void* gin, const void* fwd_out, const float* tie_cnt,
+                           const void* self_vals, const void* other_vals,
+                           const int32_t* seg_ptr, const int32_t* out_idx, const int32_t* other_idx,
+                           int64_t n_seg, int64_t d, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Row gather   out[r, :] = src[idx[r], :]          (K6)
+ *   pygho/backend/SpTensor.py:470-476  X[self.indices[dim]]  (unpooling_fromdense1dim)
+ * `valid` (nullable, int32 per row): rows with valid[r] == 0 are written as 0
+ *   -> SpTensor.py:322-352 (diag) and :447-468 (sparse->sparse unpooling) gathers.
+ */
+int pygho_row_gather(void* out, const void* src, const int32_t* idx, const int32_t* valid,
+                     int64_t n_rows, int64_t d, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Planner (integer, bit-exact)
+ * ---------------------------------------------------------------------- */
+
+/* int64 -> int32 narrowing with range check; *err (device int32) is set to 1 on overflow/negative. */
+int pygho_narrow_i64_i32(int32_t* dst, const int64_t* src, int64_t n, int32_t* err, void* stream);
+
+/* CSR pointer of a SORTED key array: seg_ptr[k] = first m with keys[m] >= k, seg_ptr[n_seg] = m.
+ * *err is set to 1 when keys are not non-decreasing or out of [0, n_seg).
+ * Replaces the (M, d) int64 expanded scatter index of pygho/backend/utils.py:52. */
+int pygho_csr_from_sorted(int32_t* seg_ptr, const int64_t* keys, int64_t m, int64_t n_seg,
+                          int32_t* err, void* stream);
+
+/* Stable grouping of an UNSORTED key array (counting/radix sort): perm lists the
+ * message ids grouped by key (ascending m inside a group), seg_ptr is its CSR
+ * pointer.  Used for the transposed (backward) plans and for scatter-reduce with
+ * an unsorted index.  `workspace` must hold pygho_group_by_key_workspace(m) bytes. */
+size_t pygho_group_by_key_workspace(int64_t m, int64_t n_keys);
+int pygho_group_by_key(int32_t* seg_ptr, int32_t* perm, const int64_t* keys, int64_t m,
+                       int64_t n_keys, void* workspace, size_t workspace_bytes,
+                       int32_t* err, void* stream);
+
+/* out[i] = table[idx[i]] for int32 tables (composition of plan permutations). */
+int pygho_gather_i32(int32_t* out, const int32_t* table, const int32_t* idx, int64_t n, void* stream);
+
+/* out[idx[i]] = vals[i] for int32 arrays (idx must be a permutation / collision free):
+ * the `return_inverse` half of torch.unique (SpTensor.py:190): inverse[perm[i]] = run_id[i]. */
+int pygho_scatter_i32(int32_t* out, const int32_t* idx, const int32_t* vals, int64_t n, void* stream);
+
+/* Order-preserving bit pack of index tuples and its inverse.
+ *   pygho/backend/SpTensor.py:10-44 (indicehash), :47-87 (decodehash): 63 // sparse_dim bits per
+ *   coordinate, most significant first.  ind is (sparse_dim, nnz) row-major with row stride `ld`.
+ *   *err = 1 on a negative coordinate, 2 on a coordinate >= 2^bits. */
+int pygho_hash_pack(int64_t* out, const int64_t* ind, int64_t sparse_dim, int64_t nnz, int64_t ld,
+                    int32_t* err, void* stream);
+int pygho_hash_unpack(int64_t* ind, const int64_t* hash, int64_t sparse_dim, int64_t nnz, void* stream);
+
+/* Sorted match: pos[i] = index of query[i] in the strictly increasing `table`, or -1.
+ *   pygho/backend/Spspmm.py:174-183 (spsphadamard_ind: searchsorted(right=True) - 1, compare),
+ *   SpTensor.py:330-334, :460-467. */
+int pygho_sorted_match(int64_t* pos, const int64_t* table, int64_t n_table, const int64_t* query,
+                       int64_t n_query, void* stream);
+
+/* lower/upper bound of every query in a sorted table (torch.searchsorted, Spspmm.py:114-116). */
+int pygho_search_bounds(int64_t* lower, int64_t* upper, const int64_t* table, int64_t n_table,
+                        const int64_t* query, int64_t n_query, void* stream);
+
+/* Stable sort of int64 keys (bits [0, end_bit)) carrying their original positions:
+ * keys_out sorted ascending, perm_out[i] = position of keys_out[i] in keys_in.
+ *   torch.unique / torch.argsort inside pygho/backend/SpTensor.py:190 (coalesce),
+ *   Spspmm.py:102,136-143 (spspmm_ind). */
+size_t pygho_sort_pairs_i64_workspace(int64_t n);
+int pygho_sort_pairs_i64(int64_t* keys_out, int32_t* perm_out, const int64_t* keys_in, int64_t n,
+                         int end_bit, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Run ids of a SORTED key array: run_id[i] = number of distinct keys before position i's key,
+ * n_runs[0] (device int32) = number of distinct keys.  With pygho_sort_pairs_i64 this is
+ * torch.unique(sorted=True, return_inverse=True) (SpTensor.py:190): unique[run_id[i]] = key[i],
+ * inverse[perm[i]] = run_id[i]. */
+size_t pygho_run_ids_workspace(int64_t n);
+int pygho_run_ids(int32_t* run_id, int32_t* n_runs, const int64_t* sorted_keys, int64_t n,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* Pair expansion of the product planner (Spspmm.py:119-129: cumsum, repeat_interleave, arange):
+ * offsets (nnz1 + 1) is the exclusive prefix sum of the per-row match counts; for every
+ * t in [0, total): c[t] = row whose range contains t, d[t] = lower[c] + (t - offsets[c]). */
+int pygho_expand_pairs(int64_t* c_out, int64_t* d_out, const int64_t* lower, const int64_t* offsets,
+                       int64_t nnz1, int64_t total, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Masked (dense) path
+ * ---------------------------------------------------------------------- */
+
+/* Masked batched contraction (K11):  out[b, i, j, :] = mask[b,i,j] ? sum_k A[b,i,k,:] * B[b,k,j,:] : 0
+ * with A (nb, ni, nk, d), B (nb, nk, nj, d), d innermost, masked-out operand entries
+ * treated as 0 through amask (nb, ni, nk) / bmask (nb, nk, nj) (uint8, nullable = all valid).
+ *   pygho/backend/Mamamm.py:35-64 (movedim/flatten copies + torch.matmul), wrapped by
+ *   MaskedTensor(prod, mask).  transpose flags select which masked dim of each operand is
+ *   contracted: a_kfirst != 0 means A is stored (nb, nk, ni, d); b_kfirst == 0 means B is
+ *   stored (nb, nj, nk, d).  bf16/f16 inputs use MFMA (v_mfma_f32_16x16x32), f32 uses
+ *   v_mfma_f32_16x16x4_f32; accumulation is f32. */
+int pygho_masked_bmm(void* out, const void* A, const void* B, const uint8_t* amask,
+                     const uint8_t* bmask, const uint8_t* omask, int64_t nb, int64_t ni,
+                     int64_t nk, int64_t nj, int64_t d, int a_kfirst, int b_kfirst, int dtype,
+                     void* stream);
+
+/* out = mask ? data : value over (n_rows, d) with a per-row uint8 mask.  MaTensor.py:113-128. */
+int pygho_masked_fill(void* out, const void* data, const uint8_t* mask, double value,
+                      int64_t n_rows, int64_t d, int dtype, void* stream);
+
+/* Reduction over ONE masked dim:  data (outer, r, inner, d), mask (outer, r, inner)
+ *   -> out (outer, inner, d), omask (outer, inner) = any(mask).  sum/mean/max/min with the
+ * documented semantics (masked entries never contribute; all-masked -> 0; mean divides by the
+ * number of valid entries, min 1).  MaTensor.py:175-206. */
+int pygho_masked_reduce(void* out, uint8_t* omask, const void* data, const uint8_t* mask,
+                        int64_t outer, int64_t r, int64_t inner, int64_t d, int dtype, int aggr,
+                        void* stream);
+
+/* Backward of pygho_masked_reduce (autograd of the masked sum / mean / amax / amin of
+ * MaTensor.py:175-206): gdata (outer, r, inner, d) from gout (outer, inner, d); masked entries get 0,
+ * mean divides by the valid count, max/min share the gradient evenly among the entries equal to the
+ * forward result `fwd` (outer, inner, d). */
+int pygho_masked_reduce_bwd(void* gdata, const void* gout, const void* data, const void* fwd,
+                            const uint8_t* mask, int64_t outer, int64_t r, int64_t inner, int64_t d,
+                            int dtype, int aggr, void* stream);
+
+/* Masked broadcast along a new dim: out[o, k, i, :] = mask[o, k, i] ? src[o, i, :] : value.
+ *   MaTensor.py:225-234 (unpooling: unsqueeze + expand, then the lazily applied fill). */
+int pygho_masked_broadcast(void* out, const void* src, const uint8_t* mask, double value,
+                           int64_t outer, int64_t r, int64_t inner, int64_t d, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYGHO_HIP_H */

@@ -1,0 +1,116 @@
+"""
+ctypes binding of the C ABI declared in ``include/pygho_hip.h``.
+
+The shared object ``pygho_amd/_lib/libpygho_hip.so`` is built in-tree by
+``__graft_entry__.build()`` / ``python -m pygho_amd.build`` (hipcc, gfx950).  There is
+NO fallback: if the library is missing every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+from typing import Optional
+
+import torch
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libpygho_hip.so")
+
+# enum pygho_dtype / pygho_aggr (include/pygho_hip.h)
+F32, BF16, F16, F64, I64, I32 = 0, 1, 2, 3, 4, 5
+DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16, torch.float64: F64,
+              torch.int64: I64, torch.int32: I32}
+AGGR_CODE = {"sum": 0, "mean": 1, "max": 2, "min": 3, "amax": 2, "amin": 3}
+
+P, I, L, Z, D = c_void_p, c_int, c_int64, c_size_t, c_double
+
+# name -> (restype, argtypes); mirrors the header one to one (checked by tests/test_cabi.py)
+PROTOTYPES = {
+    "pygho_abi_version": (I, []),
+    "pygho_last_error": (c_char_p, []),
+    "pygho_seg_gather_mul_reduce": (I, [P, P, P, P, P, P, P, L, L, L, L, I, I, P]),
+    "pygho_seg_extremum_ties": (I, [P, P, P, P, P, P, P, L, L, I, P]),
+    "pygho_seg_extremum_bwd": (I, [P, P, P, P, P, P, P, P, P, L, L, I, P]),
+    "pygho_row_gather": (I, [P, P, P, P, L, L, I, P]),
+    "pygho_narrow_i64_i32": (I, [P, P, L, P, P]),
+    "pygho_csr_from_sorted": (I, [P, P, L, L, P, P]),
+    "pygho_group_by_key_workspace": (Z, [L, L]),
+    "pygho_group_by_key": (I, [P, P, P, L, L, P, Z, P, P]),
+    "pygho_gather_i32": (I, [P, P, P, L, P]),
+    "pygho_scatter_i32": (I, [P, P, P, L, P]),
+    "pygho_hash_pack": (I, [P, P, L, L, L, P, P]),
+    "pygho_hash_unpack": (I, [P, P, L, L, P]),
+    "pygho_sorted_match": (I, [P, P, L, P, L, P]),
+    "pygho_search_bounds": (I, [P, P, P, L, P, L, P]),
+    "pygho_sort_pairs_i64_workspace": (Z, [L]),
+    "pygho_sort_pairs_i64": (I, [P, P, P, L, I, P, Z, P]),
+    "pygho_run_ids_workspace": (Z, [L]),
+    "pygho_run_ids": (I, [P, P, P, L, P, Z, P]),
+    "pygho_expand_pairs": (I, [P, P, P, P, L, L, P]),
+    "pygho_masked_bmm": (I, [P, P, P, P, P, P, L, L, L, L, L, I, I, I, P]),
+    "pygho_masked_fill": (I, [P, P, P, D, L, L, I, P]),
+    "pygho_masked_reduce": (I, [P, P, P, P, L, L, L, L, I, I, P]),
+    "pygho_masked_reduce_bwd": (I, [P, P, P, P, P, L, L, L, L, I, I, P]),
+    "pygho_masked_broadcast": (I, [P, P, P, D, L, L, L, L, I, P]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class BackendUnavailable(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """load (once) the HIP extension; loud failure when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BackendUnavailable(
+                f"pygho_amd: HIP extension not built ({LIB_PATH} missing). Run `python -m pygho_amd.build` "
+                "(needs hipcc); there is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.pygho_abi_version() != 1:
+            raise BackendUnavailable("pygho_amd: ABI version mismatch, rebuild the extension")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().pygho_last_error()
+        raise RuntimeError(f"pygho_amd.{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def require_device(*tensors) -> torch.device:
+    """every compute entry point works on ROCm device memory only."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("pygho_amd: the HIP backend needs tensors on a ROCm device (got a CPU tensor); "
+                               "there is no CPU fallback")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"pygho_amd: tensors on different devices ({dev} vs {t.device})")
+    return dev
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr(device: torch.device):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return DTYPE_CODE[t.dtype]
+    except KeyError:
+        raise TypeError(f"pygho_amd: unsupported dtype {t.dtype}") from None

@@ -1,0 +1,760 @@
+"""
+Torch-level wrappers over the C ABI: plan objects (int32 CSR views of the int64 index
+arrays of the Python API, built once per batch and cached) and the autograd Functions
+that launch the HIP kernels.  Everything here runs on ROCm device memory; there is no
+CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _native as N
+from ._native import AGGR_CODE, check, dtype_code, lib, ptr, require_device, stream_ptr
+
+_I32 = torch.int32
+
+
+# --------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------
+def _flag(dev) -> Tensor:
+    return torch.zeros(1, dtype=_I32, device=dev)
+
+
+def narrow_i32(x: Tensor, checked: bool = False) -> Tensor:
+    """int64 -> int32 copy on the device (cached on the source tensor object)."""
+    if x.dtype == _I32:
+        return x.contiguous()
+    cache = getattr(x, "_pygho_i32", None)
+    if cache is not None and cache[0] == x._version:
+        return cache[1]
+    dev = require_device(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=_I32, device=dev)
+    err = _flag(dev) if checked else None
+    check(lib().pygho_narrow_i64_i32(ptr(out), ptr(x), x.numel(), ptr(err), stream_ptr(dev)), "narrow_i64_i32")
+    if checked and int(err.item()) != 0:
+        raise ValueError("pygho_amd: index does not fit int32 or is negative")
+    try:
+        x._pygho_i32 = (x._version, out)
+    except Exception:
+        pass
+    return out
+
+
+def gather_i32(table: Tensor, idx: Tensor) -> Tensor:
+    dev = require_device(table, idx)
+    out = torch.empty(idx.shape, dtype=_I32, device=dev)
+    check(lib().pygho_gather_i32(ptr(out), ptr(table), ptr(idx), idx.numel(), stream_ptr(dev)), "gather_i32")
+    return out
+
+
+class SegPlan:
+    """CSR grouping of `m` messages into `n_seg` segments: ``seg_ptr`` (n_seg+1) int32 and
+    ``perm`` (m) int32 = message ids in grouped order (None when the key array was already
+    sorted, i.e. grouped order == message order)."""
+    __slots__ = ("seg_ptr", "perm", "n_seg", "m", "_inv_cnt", "_unit_ptr")
+
+    def __init__(self, seg_ptr: Tensor, perm: Optional[Tensor], n_seg: int, m: int):
+        self.seg_ptr, self.perm, self.n_seg, self.m = seg_ptr, perm, n_seg, m
+        self._inv_cnt = None
+        self._unit_ptr = None
+
+    @property
+    def inv_count(self) -> Tensor:
+        """1 / max(segment length, 1) as f32 (mean backward)."""
+        if self._inv_cnt is None:
+            cnt = (self.seg_ptr[1:] - self.seg_ptr[:-1]).clamp_min(1)
+            self._inv_cnt = cnt.to(torch.float32).reciprocal()
+        return self._inv_cnt
+
+    def take(self, idx32: Tensor) -> Tensor:
+        """idx32 re-ordered into grouped order."""
+        return idx32 if self.perm is None else gather_i32(idx32, self.perm)
+
+
+def unit_ptr(m: int, dev) -> Tensor:
+    """seg_ptr of the trivial plan (one message per segment)."""
+    return torch.arange(m + 1, dtype=_I32, device=dev)
+
+
+def plan_from_keys(keys: Tensor, n_seg: int, assume_sorted: Optional[bool] = None) -> SegPlan:
+    """Group messages by ``keys`` (int64, values in [0, n_seg)).  Sorted keys give a permutation-free
+    plan (one kernel); otherwise a stable radix sort builds the permutation."""
+    dev = require_device(keys)
+    keys = keys.contiguous()
+    m = keys.numel()
+    st = stream_ptr(dev)
+    seg_ptr = torch.empty(n_seg + 1, dtype=_I32, device=dev)
+    if assume_sorted is not False:
+        err = _flag(dev)
+        check(lib().pygho_csr_from_sorted(ptr(seg_ptr), ptr(keys), m, n_seg, ptr(err), st), "csr_from_sorted")
+        if int(err.item()) == 0:
+            return SegPlan(seg_ptr, None, n_seg, m)
+        if assume_sorted:
+            raise ValueError("pygho_amd: keys are not sorted / out of range")
+    err = _flag(dev)
+    perm = torch.empty(m, dtype=_I32, device=dev)
+    nbytes = int(lib().pygho_group_by_key_workspace(m, n_seg))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib().pygho_group_by_key(ptr(seg_ptr), ptr(perm), ptr(keys), m, n_seg, ptr(ws), nbytes, ptr(err), st),
+          "group_by_key")
+    if int(err.item()) != 0:
+        raise ValueError("pygho_amd: scatter index out of range [0, dim_size)")
+    return SegPlan(seg_ptr, perm, n_seg, m)
+
+
+def cached_plan(keys: Tensor, n_seg: int, tag: str = "") -> SegPlan:
+    """plan cache keyed on the index tensor OBJECT (index tensors are shared by reference between
+    results, SpTensor.py:493) and its in-place version counter."""
+    cache = getattr(keys, "_pygho_plans", None)
+    if cache is None:
+        cache = {}
+        try:
+            keys._pygho_plans = cache
+        except Exception:
+            pass
+    k = (tag, n_seg, keys._version)
+    plan = cache.get(k)
+    if plan is None:
+        plan = plan_from_keys(keys, n_seg)
+        cache[k] = plan
+    return plan
+
+
+# --------------------------------------------------------------------------
+# raw launches
+# --------------------------------------------------------------------------
+def _as2d(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    t = t.contiguous()
+    return t.reshape(t.shape[0], -1) if t.dim() != 2 else t
+
+
+def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr: Tensor,
+            lhs_idx: Optional[Tensor], rhs_idx: Optional[Tensor], aggr: str,
+            lhs_rowscale: Optional[Tensor] = None) -> Tensor:
+    """out[s] = (+)_{m in seg s} scale * lhs[lhs_idx[m]] * rhs[rhs_idx[m]]  (2-D operands)."""
+    ref = lhs if lhs is not None else rhs
+    dev = require_device(lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale)
+    d = ref.shape[1]
+    out = torch.empty((out_rows, d), dtype=ref.dtype, device=dev)
+    check(lib().pygho_seg_gather_mul_reduce(
+        ptr(out), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale),
+        out_rows, d, d if lhs is not None else 0, d if rhs is not None else 0,
+        dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev)), "seg_gather_mul_reduce")
+    return out
+
+
+def row_gather(src: Tensor, idx32: Tensor, valid: Optional[Tensor] = None) -> Tensor:
+    dev = require_device(src, idx32, valid)
+    src = src.contiguous()
+    n = idx32.numel()
+    tail = src.shape[1:]
+    d = 1
+    for s in tail:
+        d *= s
+    out = torch.empty((n,) + tuple(tail), dtype=src.dtype, device=dev)
+    check(lib().pygho_row_gather(ptr(out), ptr(src), ptr(idx32), ptr(valid), n, d, dtype_code(src), stream_ptr(dev)),
+          "row_gather")
+    return out
+
+
+def _ties(fwd: Tensor, lhs, rhs, seg_ptr, lhs_idx, rhs_idx) -> Tensor:
+    dev = fwd.device
+    ties = torch.empty(fwd.shape, dtype=torch.float32, device=dev)
+    check(lib().pygho_seg_extremum_ties(ptr(ties), ptr(fwd), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx),
+                                        ptr(rhs_idx), fwd.shape[0], fwd.shape[1], dtype_code(fwd), stream_ptr(dev)),
+          "seg_extremum_ties")
+    return ties
+
+
+def _extremum_bwd(n_rows, gin, fwd, ties, self_vals, other, seg_ptr, out_idx, other_idx) -> Tensor:
+    dev = gin.device
+    d = gin.shape[1]
+    gout = torch.empty((n_rows, d), dtype=gin.dtype, device=dev)
+    check(lib().pygho_seg_extremum_bwd(ptr(gout), ptr(gin), ptr(fwd), ptr(ties), ptr(self_vals), ptr(other),
+                                       ptr(seg_ptr), ptr(out_idx), ptr(other_idx), n_rows, d, dtype_code(gin),
+                                       stream_ptr(dev)), "seg_extremum_bwd")
+    return gout
+
+
+# --------------------------------------------------------------------------
+# the message-passing plan of one (acd, n_out) pair
+# --------------------------------------------------------------------------
+class MessagePlan:
+    """int32 / CSR view of an ``acd`` triple array (Spspmm.py:186-222): forward grouping by the
+    output slot `a`, and (lazily, for backward) the transposed groupings by `c` and by `d`."""
+
+    def __init__(self, acd: Tensor, n_out: int, n_lhs: int, n_rhs: int):
+        require_device(acd)
+        assert acd.dim() == 2 and acd.shape[0] == 3, "acd must be (3, M)"
+        self.m = acd.shape[1]
+        self.n_out, self.n_lhs, self.n_rhs = n_out, n_lhs, n_rhs
+        self._a64, self._c64, self._d64 = acd[0], acd[1], acd[2]
+        self.fwd = plan_from_keys(acd[0], n_out)
+        a32, c32, d32 = narrow_i32(acd[0]), narrow_i32(acd[1]), narrow_i32(acd[2])
+        self.a32, self.c32, self.d32 = a32, c32, d32                 # message order
+        self.c_fwd, self.d_fwd = self.fwd.take(c32), self.fwd.take(d32)   # grouped-by-a order
+        self._by_c = None
+        self._by_d = None
+
+    def by_c(self):
+        """(plan, a-in-grouped-order, d-in-grouped-order) for the gradient wrt the first operand."""
+        if self._by_c is None:
+            p = plan_from_keys(self._c64, self.n_lhs)
+            self._by_c = (p, p.take(self.a32), p.take(self.d32))
+        return self._by_c
+
+    def by_d(self):
+        if self._by_d is None:
+            p = plan_from_keys(self._d64, self.n_rhs)
+            self._by_d = (p, p.take(self.a32), p.take(self.c32))
+        return self._by_d
+
+
+def message_plan(acd: Tensor, n_out: int, n_lhs: int, n_rhs: int) -> MessagePlan:
+    cache = getattr(acd, "_pygho_plans", None)
+    if cache is None:
+        cache = {}
+        try:
+            acd._pygho_plans = cache
+        except Exception:
+            pass
+    k = ("msg", n_out, n_lhs, n_rhs, acd._version)
+    plan = cache.get(k)
+    if plan is None:
+        plan = MessagePlan(acd, n_out, n_lhs, n_rhs)
+        cache[k] = plan
+    return plan
+
+
+class _MessageReduce(torch.autograd.Function):
+    """out[a] = (+) lhs[c] * rhs[d] over the plan; either operand may be None (pattern only)."""
+
+    @staticmethod
+    def forward(ctx, lhs: Optional[Tensor], rhs: Optional[Tensor], plan: MessagePlan, aggr: str):
+        out = seg_gmr(plan.n_out, lhs, rhs, plan.fwd.seg_ptr, plan.c_fwd if lhs is not None else None,
+                      plan.d_fwd if rhs is not None else None, aggr)
+        ctx.plan, ctx.aggr = plan, aggr
+        ctx.has = (lhs is not None, rhs is not None)
+        ctx.save_for_backward(lhs, rhs, out if aggr in ("max", "min") else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        lhs, rhs, fwd = ctx.saved_tensors
+        plan, aggr = ctx.plan, ctx.aggr
+        gout = gout.contiguous()
+        g_lhs = g_rhs = None
+        scale = plan.fwd.inv_count if aggr == "mean" else None
+        ties = None
+        if aggr in ("max", "min"):
+            ties = _ties(fwd, lhs, rhs, plan.fwd.seg_ptr, plan.c_fwd if lhs is not None else None,
+                         plan.d_fwd if rhs is not None else None)
+        if lhs is not None and ctx.needs_input_grad[0]:
+            p, a_g, d_g = plan.by_c()
+            if ties is None:
+                g_lhs = seg_gmr(plan.n_lhs, gout, rhs, p.seg_ptr, a_g, d_g if rhs is not None else None, "sum", scale)
+            else:
+                g_lhs = _extremum_bwd(plan.n_lhs, gout, fwd, ties, lhs, rhs, p.seg_ptr, a_g, d_g)
+        if rhs is not None and ctx.needs_input_grad[1]:
+            p, a_g, c_g = plan.by_d()
+            if ties is None:
+                g_rhs = seg_gmr(plan.n_rhs, gout, lhs, p.seg_ptr, a_g, c_g if lhs is not None else None, "sum", scale)
+            else:
+                g_rhs = _extremum_bwd(plan.n_rhs, gout, fwd, ties, rhs, lhs, p.seg_ptr, a_g, c_g)
+        return g_lhs, g_rhs, None, None
+
+
+def _broadcast_dense(a: Optional[Tensor], b: Optional[Tensor]) -> Tuple[Optional[Tensor], Optional[Tensor], Tuple[int, ...]]:
+    """broadcast the dense (trailing) shapes of two value tensors and flatten them to 2-D."""
+    if a is None or b is None:
+        t = a if a is not None else b
+        return (None if a is None else _as2d(a)), (None if b is None else _as2d(b)), tuple(t.shape[1:])
+    if a.dtype != b.dtype:
+        dt = torch.promote_types(a.dtype, b.dtype)
+        a, b = a.to(dt), b.to(dt)
+    if a.shape[1:] == b.shape[1:]:
+        return _as2d(a), _as2d(b), tuple(a.shape[1:])
+    nd = max(a.dim(), b.dim()) - 1
+    sa = (1,) * (nd - (a.dim() - 1)) + tuple(a.shape[1:])
+    sb = (1,) * (nd - (b.dim() - 1)) + tuple(b.shape[1:])
+    dense = torch.broadcast_shapes(sa, sb)
+    a = a.reshape((a.shape[0],) + sa).expand((a.shape[0],) + dense)
+    b = b.reshape((b.shape[0],) + sb).expand((b.shape[0],) + dense)
+    return _as2d(a), _as2d(b), tuple(dense)
+
+
+def message_reduce(lhs: Optional[Tensor], rhs: Optional[Tensor], acd: Tensor, n_out: int, n_lhs: int, n_rhs: int,
+                   aggr: str) -> Tensor:
+    """spspmm value computation (Spspmm.py:307-315) on the HIP path."""
+    if lhs is None and rhs is None:
+        raise ValueError("pygho_amd: both operands are pattern-only; nothing to multiply")
+    if aggr not in AGGR_CODE:
+        raise NotImplementedError(f"aggr {aggr!r} is not supported (sum, mean, max, min)")
+    l2, r2, dense = _broadcast_dense(lhs, rhs)
+    plan = message_plan(acd, n_out, n_lhs, n_rhs)
+    out = _MessageReduce.apply(l2, r2, plan, aggr)
+    return out.reshape((n_out,) + dense)
+
+
+# --------------------------------------------------------------------------
+# scatter / segment reduce and gather
+# --------------------------------------------------------------------------
+class _ScatterReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src: Tensor, plan: SegPlan, ind32: Tensor, aggr: str):
+        out = seg_gmr(plan.n_seg, src, None, plan.seg_ptr, plan.perm, None, aggr)
+        ctx.plan, ctx.aggr, ctx.ind32 = plan, aggr, ind32
+        ctx.save_for_backward(*((src, out) if aggr in ("max", "min") else ()))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        plan, aggr, ind32 = ctx.plan, ctx.aggr, ctx.ind32
+        gout = gout.contiguous()
+        if aggr == "sum":
+            return row_gather(gout, ind32), None, None, None
+        if aggr == "mean":
+            scaled = gout * plan.inv_count.to(gout.dtype).unsqueeze(-1)
+            return row_gather(scaled, ind32), None, None, None
+        src, fwd = ctx.saved_tensors
+        ties = _ties(fwd, src, None, plan.seg_ptr, plan.perm, None)
+        up = unit_ptr(src.shape[0], src.device)
+        return _extremum_bwd(src.shape[0], gout, fwd, ties, src, None, up, ind32, None), None, None, None
+
+
+def scatter_reduce(src: Tensor, ind: Tensor, dim_size: int, aggr: str) -> Tensor:
+    """torch_scatter_reduce(dim=0) (utils.py:44-56) on the HIP path."""
+    require_device(src, ind)
+    if aggr not in AGGR_CODE:
+        raise NotImplementedError(f"aggr {aggr!r} is not supported (sum, mean, max, min)")
+    assert ind.dim() == 1, "indice must be 1-d"
+    assert src.shape[0] == ind.shape[0], "src and index length differ"
+    plan = cached_plan(ind, dim_size, "scatter")
+    tail = tuple(src.shape[1:])
+    src2 = _as2d(src) if src.dim() > 1 else src.contiguous().reshape(-1, 1)
+    out = _ScatterReduce.apply(src2, plan, narrow_i32(ind), aggr)
+    return out.reshape((dim_size,) + tail)
+
+
+def scatter_reduce_planned(src: Tensor, plan: SegPlan, ind32: Tensor, aggr: str) -> Tensor:
+    """scatter-reduce along a prebuilt plan (coalesce / sparse pooling)."""
+    if aggr not in AGGR_CODE:
+        raise NotImplementedError(f"aggr {aggr!r} is not supported (sum, mean, max, min)")
+    tail = tuple(src.shape[1:])
+    src2 = _as2d(src) if src.dim() > 1 else src.contiguous().reshape(-1, 1)
+    out = _ScatterReduce.apply(src2, plan, ind32, aggr)
+    return out.reshape((plan.n_seg,) + tail)
+
+
+class _RowGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src: Tensor, ind: Tensor):
+        ctx.ind, ctx.n = ind, src.shape[0]
+        return row_gather(src, narrow_i32(ind))
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        ind = ctx.ind
+        plan = cached_plan(ind, ctx.n, "scatter")
+        g2 = _as2d(gout) if gout.dim() > 1 else gout.contiguous().reshape(-1, 1)
+        g = seg_gmr(ctx.n, g2, None, plan.seg_ptr, plan.perm, None, "sum")
+        return g.reshape((ctx.n,) + tuple(gout.shape[1:])), None
+
+
+def gather_rows(src: Tensor, ind: Tensor) -> Tensor:
+    """src[ind] along dim 0 (SpTensor.py:476) with a segment-reduce backward."""
+    require_device(src, ind)
+    return _RowGather.apply(src, ind)
+
+
+class _MaskedRowGather(torch.autograd.Function):
+    """out[r] = pos[r] >= 0 ? src[pos[r]] : 0   (diag / sparse unpooling)."""
+
+    @staticmethod
+    def forward(ctx, src: Tensor, pos: Tensor):
+        valid = (pos >= 0).to(_I32)
+        idx = narrow_i32(pos.clamp_min(0))
+        ctx.pos, ctx.n = pos, src.shape[0]
+        return row_gather(src, idx, valid)
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        pos, n = ctx.pos, ctx.n
+        keys = torch.where(pos >= 0, pos, torch.full_like(pos, n))      # misses go to a spill segment
+        plan = plan_from_keys(keys, n + 1)
+        g2 = _as2d(gout) if gout.dim() > 1 else gout.contiguous().reshape(-1, 1)
+        g = seg_gmr(n + 1, g2, None, plan.seg_ptr, plan.perm, None, "sum")[:n]
+        return g.reshape((n,) + tuple(gout.shape[1:])), None
+
+
+def gather_rows_matched(src: Tensor, pos: Tensor) -> Tensor:
+    require_device(src, pos)
+    return _MaskedRowGather.apply(src, pos)
+
+
+# --------------------------------------------------------------------------
+# node-level sparse x dense
+# --------------------------------------------------------------------------
+class _Spmm(torch.autograd.Function):
+    """out[t] = (+)_e val[e] * X[src[e]] grouped by tar[e]   (Spmm.py:31-44)."""
+
+    @staticmethod
+    def forward(ctx, val: Optional[Tensor], X: Tensor, src: Tensor, tar: Tensor, n_tar: int, aggr: str):
+        plan = cached_plan(tar, n_tar, "scatter")
+        src32, tar32 = narrow_i32(src), narrow_i32(tar)
+        src_g = plan.take(src32)
+        out = seg_gmr(n_tar, val, X, plan.seg_ptr, plan.perm if val is not None else None, src_g, aggr)
+        ctx.meta = (plan, src, src32, tar32, src_g, n_tar, aggr)
+        ctx.save_for_backward(val, X, out if aggr in ("max", "min") else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        val, X, fwd = ctx.saved_tensors
+        plan, src, src32, tar32, src_g, n_tar, aggr = ctx.meta
+        gout = gout.contiguous()
+        e = src32.numel()
+        g_val = g_x = None
+        scale = plan.inv_count if aggr == "mean" else None
+        ties = None
+        if aggr in ("max", "min"):
+            ties = _ties(fwd, val, X, plan.seg_ptr, plan.perm if val is not None else None, src_g)
+        if val is not None and ctx.needs_input_grad[0]:
+            up = unit_ptr(e, gout.device)
+            if ties is None:
+                g_val = seg_gmr(e, gout, X, up, tar32, src32, "sum", scale)
+            else:
+                g_val = _extremum_bwd(e, gout, fwd, ties, val, X, up, tar32, src32)
+        if ctx.needs_input_grad[1]:
+            p = cached_plan(src, X.shape[0], "scatter")
+            tar_g = p.take(tar32)
+            if ties is None:
+                g_x = seg_gmr(X.shape[0], gout, val, p.seg_ptr, tar_g, p.perm if val is not None else None, "sum", scale)
+            else:
+                eid = p.perm if p.perm is not None else torch.arange(e, dtype=_I32, device=gout.device)
+                g_x = _extremum_bwd(X.shape[0], gout, fwd, ties, X, val, p.seg_ptr, tar_g, eid)
+        return g_val, g_x, None, None, None, None
+
+
+def spmm_values(val: Optional[Tensor], X: Tensor, src: Tensor, tar: Tensor, n_tar: int, aggr: str) -> Tensor:
+    require_device(val, X, src, tar)
+    if aggr not in AGGR_CODE:
+        raise NotImplementedError(f"aggr {aggr!r} is not supported (sum, mean, max, min)")
+    if val is not None:
+        v2, x2, dense = _broadcast_dense(val, X)
+    else:
+        v2, x2, dense = None, _as2d(X) if X.dim() > 1 else X.reshape(-1, 1), tuple(X.shape[1:])
+    out = _Spmm.apply(v2, x2, src, tar, n_tar, aggr)
+    return out.reshape((n_tar,) + dense)
+
+
+# --------------------------------------------------------------------------
+# integer planner primitives
+# --------------------------------------------------------------------------
+def hash_pack(ind: Tensor, validate: bool = True) -> Tensor:
+    """indicehash (SpTensor.py:10-44) on the device."""
+    dev = require_device(ind)
+    assert ind.dim() == 2
+    sd, nnz = ind.shape
+    if sd == 1:
+        return ind[0]
+    ind = ind.contiguous()
+    out = torch.empty(nnz, dtype=torch.int64, device=dev)
+    err = _flag(dev) if validate else None
+    check(lib().pygho_hash_pack(ptr(out), ptr(ind), sd, nnz, nnz, ptr(err), stream_ptr(dev)), "hash_pack")
+    if validate:
+        code = int(err.item())
+        assert code != 1, "indice cannot be negative"
+        assert code != 2, "too large indice, hash is not injective"
+    return out
+
+
+def hash_unpack(h: Tensor, sparse_dim: int) -> Tensor:
+    dev = require_device(h)
+    if sparse_dim == 1:
+        return h.unsqueeze(0)
+    h = h.contiguous()
+    out = torch.empty((sparse_dim, h.numel()), dtype=torch.int64, device=dev)
+    check(lib().pygho_hash_unpack(ptr(out), ptr(h), sparse_dim, h.numel(), stream_ptr(dev)), "hash_unpack")
+    return out
+
+
+def sorted_match(table: Tensor, query: Tensor) -> Tensor:
+    """position of every query in the strictly increasing table, -1 when absent."""
+    dev = require_device(table, query)
+    table, query = table.contiguous(), query.contiguous()
+    pos = torch.empty(query.shape, dtype=torch.int64, device=dev)
+    check(lib().pygho_sorted_match(ptr(pos), ptr(table), table.numel(), ptr(query), query.numel(), stream_ptr(dev)),
+          "sorted_match")
+    return pos
+
+
+def search_bounds(table: Tensor, query: Tensor) -> Tuple[Tensor, Tensor]:
+    dev = require_device(table, query)
+    table, query = table.contiguous(), query.contiguous()
+    lo = torch.empty(query.shape, dtype=torch.int64, device=dev)
+    hi = torch.empty(query.shape, dtype=torch.int64, device=dev)
+    check(lib().pygho_search_bounds(ptr(lo), ptr(hi), ptr(table), table.numel(), ptr(query), query.numel(),
+                                    stream_ptr(dev)), "search_bounds")
+    return lo, hi
+
+
+def sort_with_perm(keys: Tensor, end_bit: int = 63) -> Tuple[Tensor, Tensor]:
+    """stable ascending sort of non-negative int64 keys; returns (sorted keys, int32 permutation)."""
+    dev = require_device(keys)
+    keys = keys.contiguous()
+    n = keys.numel()
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    perm = torch.empty(n, dtype=_I32, device=dev)
+    nbytes = int(lib().pygho_sort_pairs_i64_workspace(n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib().pygho_sort_pairs_i64(ptr(out), ptr(perm), ptr(keys), n, end_bit, ptr(ws), nbytes, stream_ptr(dev)),
+          "sort_pairs_i64")
+    return out, perm
+
+
+def unique_sorted(sorted_keys: Tensor) -> Tuple[Tensor, Tensor, int]:
+    """run ids of a sorted array: (unique keys, run id per position (int32), number of runs)."""
+    dev = require_device(sorted_keys)
+    n = sorted_keys.numel()
+    run = torch.empty(n, dtype=_I32, device=dev)
+    cnt = torch.zeros(1, dtype=_I32, device=dev)
+    nbytes = int(lib().pygho_run_ids_workspace(n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib().pygho_run_ids(ptr(run), ptr(cnt), ptr(sorted_keys), n, ptr(ws), nbytes, stream_ptr(dev)), "run_ids")
+    n_runs = int(cnt.item())
+    if n:
+        plan = plan_from_keys(run.to(torch.int64), n_runs, assume_sorted=True)
+        uniq = row_gather(sorted_keys.reshape(-1, 1), plan.seg_ptr[:-1].contiguous()).reshape(-1)
+    else:
+        uniq = sorted_keys
+    return uniq, run, n_runs
+
+
+def unique_plan(keys: Tensor) -> Tuple[Tensor, SegPlan, Tensor]:
+    """torch.unique(keys, sorted=True, return_inverse=True) as (unique keys, plan grouping the original
+    positions by unique slot, inverse (int32))."""
+    dev = require_device(keys)
+    m = keys.numel()
+    skeys, perm = sort_with_perm(keys)
+    run = torch.empty(m, dtype=_I32, device=dev)
+    cnt = torch.zeros(1, dtype=_I32, device=dev)
+    nbytes = int(lib().pygho_run_ids_workspace(m))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    st = stream_ptr(dev)
+    check(lib().pygho_run_ids(ptr(run), ptr(cnt), ptr(skeys), m, ptr(ws), nbytes, st), "run_ids")
+    n_runs = int(cnt.item())
+    seg_ptr = torch.empty(n_runs + 1, dtype=_I32, device=dev)
+    # run ids are sorted int32: widen once for the CSR builder
+    check(lib().pygho_csr_from_sorted(ptr(seg_ptr), ptr(run.to(torch.int64)), m, n_runs, None, st), "csr_from_sorted")
+    inv = torch.empty(m, dtype=_I32, device=dev)
+    check(lib().pygho_scatter_i32(ptr(inv), ptr(perm), ptr(run), m, st), "scatter_i32")
+    uniq = row_gather(skeys.reshape(-1, 1), seg_ptr[:-1].contiguous()).reshape(-1) if m else skeys
+    return uniq, SegPlan(seg_ptr, perm, n_runs, m), inv
+
+
+def expand_pairs(lower: Tensor, counts: Tensor) -> Tuple[Tensor, Tensor]:
+    """(c, d) pair enumeration of the product planner (Spspmm.py:119-129)."""
+    dev = require_device(lower, counts)
+    nnz1 = counts.numel()
+    offsets = torch.zeros(nnz1 + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=offsets[1:])
+    total = int(offsets[-1].item())
+    c = torch.empty(total, dtype=torch.int64, device=dev)
+    d = torch.empty(total, dtype=torch.int64, device=dev)
+    check(lib().pygho_expand_pairs(ptr(c), ptr(d), ptr(lower.contiguous()), ptr(offsets), nnz1, total, stream_ptr(dev)),
+          "expand_pairs")
+    return c, d
+
+
+# --------------------------------------------------------------------------
+# masked (dense) path
+# --------------------------------------------------------------------------
+def _mask_u8(mask: Tensor) -> Tensor:
+    """bool mask as a uint8 view (no copy), cached on the mask tensor object."""
+    c = getattr(mask, "_pygho_u8", None)
+    if c is None:
+        c = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.contiguous().to(torch.uint8)
+        try:
+            mask._pygho_u8 = c
+        except Exception:
+            pass
+    return c
+
+
+def _rows_d(data: Tensor, masked_dim: int) -> Tuple[int, int]:
+    rows = 1
+    for s in data.shape[:masked_dim]:
+        rows *= s
+    d = 1
+    for s in data.shape[masked_dim:]:
+        d *= s
+    return rows, d
+
+
+class _MaskedFill(torch.autograd.Function):
+    """out = mask ? data : value; gradient flows through the unmasked entries only."""
+
+    @staticmethod
+    def forward(ctx, data: Tensor, mask: Tensor, value: float):
+        dev = require_device(data, mask)
+        data = data.contiguous()
+        rows, d = _rows_d(data, mask.dim())
+        out = torch.empty_like(data)
+        m8 = _mask_u8(mask)
+        check(lib().pygho_masked_fill(ptr(out), ptr(data), ptr(m8), float(value), rows, d, dtype_code(data),
+                                      stream_ptr(dev)), "masked_fill")
+        ctx.mask = mask
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return _MaskedFill.apply(g, ctx.mask, 0.0), None, None
+
+
+def masked_fill(data: Tensor, mask: Tensor, value: float) -> Tensor:
+    return _MaskedFill.apply(data, mask, value)
+
+
+class _MaskedReduce(torch.autograd.Function):
+    """reduce ONE masked dim `dim` of data (masked dims first, dense dims last)."""
+
+    @staticmethod
+    def forward(ctx, data: Tensor, mask: Tensor, dim: int, aggr: str):
+        dev = require_device(data, mask)
+        data = data.contiguous()
+        md = mask.dim()
+        outer = 1
+        for s in data.shape[:dim]:
+            outer *= s
+        r = data.shape[dim]
+        inner = 1
+        for s in data.shape[dim + 1:md]:
+            inner *= s
+        d = 1
+        for s in data.shape[md:]:
+            d *= s
+        oshape = tuple(data.shape[:dim]) + tuple(data.shape[dim + 1:])
+        mshape = tuple(mask.shape[:dim]) + tuple(mask.shape[dim + 1:])
+        out = torch.empty(oshape, dtype=data.dtype, device=dev)
+        omask = torch.empty(mshape, dtype=torch.uint8, device=dev)
+        m8 = _mask_u8(mask)
+        check(lib().pygho_masked_reduce(ptr(out), ptr(omask), ptr(data), ptr(m8), outer, r, inner, d, dtype_code(data),
+                                        AGGR_CODE[aggr], stream_ptr(dev)), "masked_reduce")
+        ctx.meta = (m8, outer, r, inner, d, aggr, tuple(data.shape))
+        ctx.save_for_backward(*((data, out) if aggr in ("max", "min") else ()))
+        ctx.mark_non_differentiable(omask)
+        return out, omask
+
+    @staticmethod
+    def backward(ctx, g: Tensor, _gm):
+        m8, outer, r, inner, d, aggr, shape = ctx.meta
+        g = g.contiguous()
+        data = fwd = None
+        if aggr in ("max", "min"):
+            data, fwd = ctx.saved_tensors
+        gdata = torch.empty(shape, dtype=g.dtype, device=g.device)
+        check(lib().pygho_masked_reduce_bwd(ptr(gdata), ptr(g), ptr(data), ptr(fwd), ptr(m8), outer, r, inner, d,
+                                            dtype_code(g), AGGR_CODE[aggr], stream_ptr(g.device)), "masked_reduce_bwd")
+        return gdata, None, None, None
+
+
+def masked_reduce(data: Tensor, mask: Tensor, dim: int, aggr: str) -> Tuple[Tensor, Tensor]:
+    """(reduced data, reduced mask as bool) over one masked dim."""
+    out, om = _MaskedReduce.apply(data, mask, dim, aggr)
+    return out, om.view(torch.bool)
+
+
+class _MaskedBroadcast(torch.autograd.Function):
+    """out[o, k, i] = mask[o, k, i] ? src[o, i] : value   (unpooling along one new masked dim)."""
+
+    @staticmethod
+    def forward(ctx, src: Tensor, mask: Tensor, dim: int, value: float, src_masked_dim: int):
+        dev = require_device(src, mask)
+        src = src.contiguous()
+        outer = 1
+        for s in src.shape[:dim]:
+            outer *= s
+        inner = 1
+        for s in src.shape[dim:src_masked_dim]:
+            inner *= s
+        d = 1
+        for s in src.shape[src_masked_dim:]:
+            d *= s
+        r = mask.shape[dim]
+        oshape = tuple(src.shape[:dim]) + (r,) + tuple(src.shape[dim:])
+        out = torch.empty(oshape, dtype=src.dtype, device=dev)
+        m8 = _mask_u8(mask)
+        check(lib().pygho_masked_broadcast(ptr(out), ptr(src), ptr(m8), float(value), outer, r, inner, d,
+                                           dtype_code(src), stream_ptr(dev)), "masked_broadcast")
+        ctx.meta = (mask, dim)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        mask, dim = ctx.meta
+        gs, _ = _MaskedReduce.apply(g, mask, dim, "sum")
+        return gs, None, None, None, None
+
+
+def masked_broadcast(src: Tensor, mask: Tensor, dim: int, value: float, src_masked_dim: int) -> Tensor:
+    return _MaskedBroadcast.apply(src, mask, dim, value, src_masked_dim)
+
+
+def _bmm_launch(A: Tensor, B: Tensor, amask, bmask, omask, nb, ni, nk, nj, d, a_kfirst: bool, b_kfirst: bool) -> Tensor:
+    dev = require_device(A, B, amask, bmask, omask)
+    out = torch.empty((nb, ni, nj, d), dtype=A.dtype, device=dev)
+    check(lib().pygho_masked_bmm(ptr(out), ptr(A), ptr(B), ptr(amask), ptr(bmask), ptr(omask), nb, ni, nk, nj, d,
+                                 1 if a_kfirst else 0, 1 if b_kfirst else 0, dtype_code(A), stream_ptr(dev)), "masked_bmm")
+    return out
+
+
+class _MaskedBmm(torch.autograd.Function):
+    """out[b,i,j,:] = omask ? sum_k A[b,i,k,:] * B[b,k,j,:] : 0 on the matrix cores; A stored (b,i,k,d) or
+    k-first (b,k,i,d), B stored (b,k,j,d) (k-first) or (b,j,k,d).  Masks are uint8 or None (= all valid)."""
+
+    @staticmethod
+    def forward(ctx, A, B, amask, bmask, omask, dims, a_kfirst, b_kfirst):
+        nb, ni, nk, nj, d = dims
+        out = _bmm_launch(A, B, amask, bmask, omask, nb, ni, nk, nj, d, a_kfirst, b_kfirst)
+        ctx.save_for_backward(A, B)
+        ctx.meta = (amask, bmask, omask, dims, a_kfirst, b_kfirst)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B = ctx.saved_tensors
+        amask, bmask, omask, (nb, ni, nk, nj, d), akf, bkf = ctx.meta
+        g = g.contiguous()
+        gA = gB = None
+        if ctx.needs_input_grad[0]:
+            if not akf:   # gA[b,i,k] = sum_j g[b,i,j] * B[k,j]
+                gA = _bmm_launch(g, B, omask, bmask, amask, nb, ni, nj, nk, d, False, not bkf)
+            else:         # gA[b,k,i] = sum_j B[k,j] * g[b,i,j]
+                gA = _bmm_launch(B, g, bmask, omask, amask, nb, nk, nj, ni, d, not bkf, False)
+        if ctx.needs_input_grad[1]:
+            if bkf:       # gB[b,k,j] = sum_i A[i,k] * g[b,i,j]
+                gB = _bmm_launch(A, g, amask, omask, bmask, nb, nk, ni, nj, d, not akf, True)
+            else:         # gB[b,j,k] = sum_i g[b,i,j] * A[i,k]
+                gB = _bmm_launch(g, A, omask, amask, bmask, nb, nj, ni, nk, d, True, not akf)
+        return gA, gB, None, None, None, None, None, None
+
+
+def masked_bmm(A, B, amask, bmask, omask, nb, ni, nk, nj, d, a_kfirst, b_kfirst) -> Tensor:
+    """channel-innermost batched contraction; pads d up to the kernel's channel granule when needed."""
+    gran = 8 if A.dtype in (torch.bfloat16, torch.float16) else 4
+    if A.dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        raise TypeError(f"pygho_amd: masked_bmm supports bf16 / f16 / f32, got {A.dtype}")
+    pad = (-d) % gran
+    if pad:
+        A = torch.nn.functional.pad(A, (0, pad))
+        B = torch.nn.functional.pad(B, (0, pad))
+    out = _MaskedBmm.apply(A.contiguous(), B.contiguous(), amask, bmask, omask, (nb, ni, nk, nj, d + pad), a_kfirst, b_kfirst)
+    return out[..., :d] if pad else out

@@ -1,0 +1,338 @@
+// Integer planner kernels: index narrowing, CSR pointers, stable grouping, tuple hashing and
+// sorted matching.  All results are bit-exact functions of their inputs (no atomics whose order
+// could leak into the output).
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace pygho {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+__global__ void narrow_kernel(int32_t* __restrict__ dst, const int64_t* __restrict__ src, int64_t n, int32_t* err) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = src[i];
+    if ((v < 0 || v > INT32_MAX) && err) *err = 1;
+    dst[i] = (int32_t)v;
+  }
+}
+
+template <typename K>
+__global__ void csr_from_sorted_kernel(int32_t* __restrict__ seg_ptr, const K* __restrict__ keys, int64_t m,
+                                       int64_t n_seg, int32_t* err) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= m; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t prev = (i == 0) ? -1 : (int64_t)keys[i - 1];
+    const int64_t cur = (i == m) ? n_seg : (int64_t)keys[i];
+    if (i < m && (cur < 0 || cur >= n_seg || cur < prev)) {
+      if (err) *err = 1;
+      continue;
+    }
+    for (int64_t k = prev + 1; k <= cur; ++k) seg_ptr[k] = (int32_t)i;
+  }
+}
+
+__global__ void group_prepare_kernel(int32_t* __restrict__ k32, int32_t* __restrict__ iota,
+                                     const int64_t* __restrict__ keys, int64_t m, int64_t n_keys, int32_t* err) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = keys[i];
+    if ((v < 0 || v >= n_keys) && err) *err = 1;
+    k32[i] = (int32_t)v;
+    iota[i] = (int32_t)i;
+  }
+}
+
+__global__ void gather_i32_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ table,
+                                  const int32_t* __restrict__ idx, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = table[idx[i]];
+}
+
+__global__ void scatter_i32_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ idx,
+                                   const int32_t* __restrict__ vals, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[idx[i]] = vals[i];
+}
+
+__global__ void hash_pack_kernel(int64_t* __restrict__ out, const int64_t* __restrict__ ind, int sd, int64_t nnz,
+                                 int64_t ld, int bits, int32_t* err) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * blockDim.x) {
+    int64_t h = 0;
+    for (int r = 0; r < sd; ++r) {
+      const int64_t v = ind[(int64_t)r * ld + j];
+      if (v < 0) { if (err) atomicMax(err, 1); }
+      else if (sd > 1 && v >= ((int64_t)1 << bits)) { if (err) atomicMax(err, 2); }
+      h |= v << (bits * (sd - 1 - r));
+    }
+    out[j] = (sd == 1) ? ind[j] : h;
+  }
+}
+
+__global__ void hash_unpack_kernel(int64_t* __restrict__ ind, const int64_t* __restrict__ hash, int sd, int64_t nnz,
+                                   int bits) {
+  const int64_t low = ((int64_t)1 << bits) - 1;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t h = hash[j];
+    if (sd == 1) { ind[j] = h; continue; }
+    for (int r = 0; r < sd; ++r) ind[(int64_t)r * nnz + j] = (h >> (bits * (sd - 1 - r))) & low;
+  }
+}
+
+__device__ __forceinline__ int64_t lower_bound_dev(const int64_t* t, int64_t n, int64_t q) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (t[mid] < q) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ int64_t upper_bound_dev(const int64_t* t, int64_t n, int64_t q) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (t[mid] <= q) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void sorted_match_kernel(int64_t* __restrict__ pos, const int64_t* __restrict__ table, int64_t n_table,
+                                    const int64_t* __restrict__ query, int64_t n_query) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_query; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t q = query[i];
+    const int64_t p = lower_bound_dev(table, n_table, q);
+    pos[i] = (p < n_table && table[p] == q) ? p : -1;
+  }
+}
+
+__global__ void search_bounds_kernel(int64_t* __restrict__ lower, int64_t* __restrict__ upper,
+                                     const int64_t* __restrict__ table, int64_t n_table,
+                                     const int64_t* __restrict__ query, int64_t n_query) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_query; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t q = query[i];
+    if (lower) lower[i] = lower_bound_dev(table, n_table, q);
+    if (upper) upper[i] = upper_bound_dev(table, n_table, q);
+  }
+}
+
+
+__global__ void iota_kernel(int32_t* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (int32_t)i;
+}
+
+__global__ void run_flag_kernel(int32_t* __restrict__ flag, const int64_t* __restrict__ keys, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    flag[i] = (i > 0 && keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+__global__ void run_count_kernel(int32_t* __restrict__ n_runs, const int32_t* __restrict__ run_id, int64_t n) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) n_runs[0] = n > 0 ? run_id[n - 1] + 1 : 0;
+}
+
+__global__ void expand_pairs_kernel(int64_t* __restrict__ c_out, int64_t* __restrict__ d_out,
+                                    const int64_t* __restrict__ lower, const int64_t* __restrict__ offsets,
+                                    int64_t nnz1, int64_t total) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = upper_bound_dev(offsets, nnz1 + 1, t) - 1;
+    c_out[t] = c;
+    d_out[t] = lower[c] + (t - offsets[c]);
+  }
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int key_bits(int64_t n_keys) {
+  int b = 1;
+  while (((int64_t)1 << b) < n_keys && b < 31) ++b;
+  return b;
+}
+
+}  // namespace pygho
+
+using namespace pygho;
+
+extern "C" int pygho_abi_version(void) { return PYGHO_ABI_VERSION; }
+extern "C" const char* pygho_last_error(void) { return g_err; }
+
+extern "C" int pygho_narrow_i64_i32(int32_t* dst, const int64_t* src, int64_t n, int32_t* err, void* stream) {
+  if (n < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n == 0) return PYGHO_OK;
+  if (!dst || !src) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, dst, src, n, err);
+  return check_launch("narrow_i64_i32");
+}
+
+extern "C" int pygho_csr_from_sorted(int32_t* seg_ptr, const int64_t* keys, int64_t m, int64_t n_seg, int32_t* err,
+                                     void* stream) {
+  if (m < 0 || n_seg < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (!seg_ptr || (m > 0 && !keys)) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (m > INT32_MAX) { set_error("more than 2^31 messages"); return PYGHO_ERR_UNSUPPORTED; }
+  hipLaunchKernelGGL((csr_from_sorted_kernel<int64_t>), dim3(grid_for(m + 1, kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, seg_ptr, keys, m, n_seg, err);
+  return check_launch("csr_from_sorted");
+}
+
+extern "C" size_t pygho_group_by_key_workspace(int64_t m, int64_t n_keys) {
+  if (m <= 0) return 256;
+  size_t temp = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const int32_t*)nullptr, (int32_t*)nullptr,
+                                     (const int32_t*)nullptr, (int32_t*)nullptr, (int)m, 0, key_bits(n_keys));
+  return 3 * align256((size_t)m * sizeof(int32_t)) + align256(temp) + 256;
+}
+
+extern "C" int pygho_group_by_key(int32_t* seg_ptr, int32_t* perm, const int64_t* keys, int64_t m, int64_t n_keys,
+                                  void* workspace, size_t workspace_bytes, int32_t* err, void* stream) {
+  if (m < 0 || n_keys < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (!seg_ptr || (m > 0 && (!perm || !keys || !workspace))) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (m > INT32_MAX || n_keys > INT32_MAX) { set_error("size beyond int32"); return PYGHO_ERR_UNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+  if (m == 0) {
+    hipLaunchKernelGGL((csr_from_sorted_kernel<int32_t>), dim3(1), dim3(kBlock), 0, st, seg_ptr, (const int32_t*)nullptr,
+                       (int64_t)0, n_keys, err);
+    return check_launch("group_by_key(empty)");
+  }
+  const size_t need = pygho_group_by_key_workspace(m, n_keys);
+  if (workspace_bytes < need) { set_error("workspace too small: %zu < %zu", workspace_bytes, need); return PYGHO_ERR_INVALID; }
+  char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  const size_t seg = align256((size_t)m * sizeof(int32_t));
+  int32_t* k_in = (int32_t*)ws;
+  int32_t* k_out = (int32_t*)(ws + seg);
+  int32_t* v_in = (int32_t*)(ws + 2 * seg);
+  void* temp = ws + 3 * seg;
+  size_t temp_bytes = workspace_bytes - 3 * seg - (size_t)(ws - (char*)workspace);
+  hipLaunchKernelGGL(group_prepare_kernel, dim3(grid_for(m, kBlock)), dim3(kBlock), 0, st, k_in, v_in, keys, m, n_keys, err);
+  hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const int32_t*)k_in, k_out, (const int32_t*)v_in,
+                                                    perm, (int)m, 0, key_bits(n_keys), st);
+  if (e != hipSuccess) { set_error("radix sort: %s", hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
+  hipLaunchKernelGGL((csr_from_sorted_kernel<int32_t>), dim3(grid_for(m + 1, kBlock)), dim3(kBlock), 0, st, seg_ptr,
+                     (const int32_t*)k_out, m, n_keys, (int32_t*)nullptr);
+  return check_launch("group_by_key");
+}
+
+extern "C" int pygho_gather_i32(int32_t* out, const int32_t* table, const int32_t* idx, int64_t n, void* stream) {
+  if (n < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n == 0) return PYGHO_OK;
+  if (!out || !table || !idx) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(gather_i32_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, table, idx, n);
+  return check_launch("gather_i32");
+}
+
+extern "C" int pygho_hash_pack(int64_t* out, const int64_t* ind, int64_t sparse_dim, int64_t nnz, int64_t ld,
+                               int32_t* err, void* stream) {
+  if (sparse_dim < 1 || sparse_dim > 63 || nnz < 0) { set_error("bad sparse_dim / nnz"); return PYGHO_ERR_INVALID; }
+  if (nnz == 0) return PYGHO_OK;
+  if (!out || !ind) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(hash_pack_kernel, dim3(grid_for(nnz, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, ind,
+                     (int)sparse_dim, nnz, ld, (int)(63 / sparse_dim), err);
+  return check_launch("hash_pack");
+}
+
+extern "C" int pygho_hash_unpack(int64_t* ind, const int64_t* hash, int64_t sparse_dim, int64_t nnz, void* stream) {
+  if (sparse_dim < 1 || sparse_dim > 63 || nnz < 0) { set_error("bad sparse_dim / nnz"); return PYGHO_ERR_INVALID; }
+  if (nnz == 0) return PYGHO_OK;
+  if (!ind || !hash) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(hash_unpack_kernel, dim3(grid_for(nnz, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, ind, hash,
+                     (int)sparse_dim, nnz, (int)(63 / sparse_dim));
+  return check_launch("hash_unpack");
+}
+
+extern "C" int pygho_sorted_match(int64_t* pos, const int64_t* table, int64_t n_table, const int64_t* query,
+                                  int64_t n_query, void* stream) {
+  if (n_table < 0 || n_query < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n_query == 0) return PYGHO_OK;
+  if (!pos || !query || (n_table > 0 && !table)) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(sorted_match_kernel, dim3(grid_for(n_query, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, pos,
+                     table, n_table, query, n_query);
+  return check_launch("sorted_match");
+}
+
+extern "C" int pygho_search_bounds(int64_t* lower, int64_t* upper, const int64_t* table, int64_t n_table,
+                                   const int64_t* query, int64_t n_query, void* stream) {
+  if (n_table < 0 || n_query < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n_query == 0) return PYGHO_OK;
+  if (!query || (n_table > 0 && !table) || (!lower && !upper)) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(search_bounds_kernel, dim3(grid_for(n_query, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, lower,
+                     upper, table, n_table, query, n_query);
+  return check_launch("search_bounds");
+}
+
+extern "C" size_t pygho_sort_pairs_i64_workspace(int64_t n) {
+  if (n <= 0) return 256;
+  size_t temp = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const int64_t*)nullptr, (int64_t*)nullptr,
+                                           (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, 0, 64);
+  return align256((size_t)n * sizeof(int32_t)) + align256(temp) + 256;
+}
+
+extern "C" int pygho_sort_pairs_i64(int64_t* keys_out, int32_t* perm_out, const int64_t* keys_in, int64_t n, int end_bit,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  if (n < 0 || end_bit < 1 || end_bit > 64) { set_error("bad size / end_bit"); return PYGHO_ERR_INVALID; }
+  if (n == 0) return PYGHO_OK;
+  if (!keys_out || !perm_out || !keys_in || !workspace) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (n > INT32_MAX) { set_error("size beyond int32"); return PYGHO_ERR_UNSUPPORTED; }
+  if (workspace_bytes < pygho_sort_pairs_i64_workspace(n)) { set_error("workspace too small"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  const size_t seg = align256((size_t)n * sizeof(int32_t));
+  int32_t* iota = (int32_t*)ws;
+  void* temp = ws + seg;
+  size_t temp_bytes = workspace_bytes - seg - (size_t)(ws - (char*)workspace);
+  hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, st, iota, n);
+  hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, (const int32_t*)iota, perm_out,
+                                                    (int)n, 0, end_bit, st);
+  if (e != hipSuccess) { set_error("radix sort: %s", hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
+  return check_launch("sort_pairs_i64");
+}
+
+extern "C" size_t pygho_run_ids_workspace(int64_t n) {
+  if (n <= 0) return 256;
+  size_t temp = 0;
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, temp, (const int32_t*)nullptr, (int32_t*)nullptr, (int)n);
+  return align256((size_t)n * sizeof(int32_t)) + align256(temp) + 256;
+}
+
+extern "C" int pygho_run_ids(int32_t* run_id, int32_t* n_runs, const int64_t* sorted_keys, int64_t n, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (n < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    if (n_runs) hipLaunchKernelGGL(run_count_kernel, dim3(1), dim3(64), 0, st, n_runs, (const int32_t*)nullptr, (int64_t)0);
+    return check_launch("run_ids(empty)");
+  }
+  if (!run_id || !sorted_keys || !workspace) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (n > INT32_MAX) { set_error("size beyond int32"); return PYGHO_ERR_UNSUPPORTED; }
+  if (workspace_bytes < pygho_run_ids_workspace(n)) { set_error("workspace too small"); return PYGHO_ERR_INVALID; }
+  char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  const size_t seg = align256((size_t)n * sizeof(int32_t));
+  int32_t* flag = (int32_t*)ws;
+  void* temp = ws + seg;
+  size_t temp_bytes = workspace_bytes - seg - (size_t)(ws - (char*)workspace);
+  hipLaunchKernelGGL(run_flag_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, st, flag, sorted_keys, n);
+  hipError_t e = hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, (const int32_t*)flag, run_id, (int)n, st);
+  if (e != hipSuccess) { set_error("scan: %s", hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
+  if (n_runs) hipLaunchKernelGGL(run_count_kernel, dim3(1), dim3(64), 0, st, n_runs, (const int32_t*)run_id, n);
+  return check_launch("run_ids");
+}
+
+extern "C" int pygho_expand_pairs(int64_t* c_out, int64_t* d_out, const int64_t* lower, const int64_t* offsets,
+                                  int64_t nnz1, int64_t total, void* stream) {
+  if (nnz1 < 0 || total < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (total == 0) return PYGHO_OK;
+  if (!c_out || !d_out || !lower || !offsets) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(expand_pairs_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, c_out,
+                     d_out, lower, offsets, nnz1, total);
+  return check_launch("expand_pairs");
+}
+
+extern "C" int pygho_scatter_i32(int32_t* out, const int32_t* idx, const int32_t* vals, int64_t n, void* stream) {
+  if (n < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n == 0) return PYGHO_OK;
+  if (!out || !idx || !vals) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(scatter_i32_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, idx, vals, n);
+  return check_launch("scatter_i32");
+}

@@ -1,0 +1,363 @@
+// Fused gather * gather -> segment reduce, its extremum backward, and the row gather.
+//
+// Roofline: HBM-bound streaming.  Algorithmic bytes of one forward launch
+//   s*d*(rows(lhs) + rows(rhs) + n_seg) + 8*M + 4*(n_seg+1)
+// (every operand row read once, every output row written once, int32 indices once).
+//
+// Mapping (fast path, row bytes a multiple of 16):
+//   * a row is covered by G = next_pow2(row_bytes/16) lanes, 16 B per lane
+//     (d=128 bf16 -> 16 lanes, d=128 f32 / d=256 bf16 -> 32 lanes);
+//   * a wavefront therefore walks 64/G segments side by side, each lane group
+//     looping over its own segment's messages with the partial sums in
+//     registers (f32), and stores the finished row once, 16 B per lane;
+//   * consecutive segments go to the same wave / workgroup, so the reuse the
+//     problem has (tuple (i,k) feeds every (i,j), j in N(k), which are adjacent
+//     output rows; edge rows belong to one graph) is captured by L1/L2;
+//   * products are rounded before accumulation and summed in message order,
+//     so f32 sums are bit-identical to the sequential CPU oracle.
+#include "common.h"
+
+namespace pygho {
+
+enum { MODE_BOTH = 0, MODE_LHS = 1, MODE_RHS = 2 };
+
+template <typename T, int AGGR, int MODE, bool SCALED>
+__global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
+    T* __restrict__ out, const T* __restrict__ lhs, const T* __restrict__ rhs,
+    const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ lhs_idx,
+    const int32_t* __restrict__ rhs_idx, const float* __restrict__ lhs_rowscale,
+    int64_t n_seg, int64_t d, int chunks, int log2g) {
+  using V = Vec16<T>;
+  using R = Reduce<AGGR, float>;
+  constexpr int N = V::N;
+  constexpr int K = 4;  // segments per lane group and pass
+  const int lane = threadIdx.x & (kWave - 1);
+  const int gl = lane & ((1 << log2g) - 1);
+  const int grp = lane >> log2g;
+  const int gw = kWave >> log2g;  // lane groups per wave
+  const int chunk = blockIdx.y * kWave + gl;
+  const bool active = chunk < chunks && gl < kWave;
+  const int64_t col = (int64_t)chunk * N;
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
+  const int64_t span = (int64_t)gw * K;
+
+  for (int64_t base = wave * span; base < n_seg; base += n_waves * span) {
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+      const int64_t s = base + (int64_t)k * gw + grp;
+      if (s >= n_seg || !active) continue;
+      const int beg = seg_ptr[s], end = seg_ptr[s + 1];
+      float acc[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) acc[i] = R::init();
+      for (int m0 = beg; m0 < end; m0 += 2) {
+        const int m1 = (m0 + 1 < end) ? m0 + 1 : m0;
+        uint4 la0, la1, rb0, rb1;
+        float sc0 = 1.f, sc1 = 1.f;
+        if (MODE != MODE_RHS) {
+          const int64_t l0 = lhs_idx ? lhs_idx[m0] : m0, l1 = lhs_idx ? lhs_idx[m1] : m1;
+          la0 = *reinterpret_cast<const uint4*>(lhs + l0 * d + col);
+          la1 = *reinterpret_cast<const uint4*>(lhs + l1 * d + col);
+          if (SCALED) { sc0 = lhs_rowscale[l0]; sc1 = lhs_rowscale[l1]; }
+        }
+        if (MODE != MODE_LHS) {
+          const int64_t r0 = rhs_idx ? rhs_idx[m0] : m0, r1 = rhs_idx ? rhs_idx[m1] : m1;
+          rb0 = *reinterpret_cast<const uint4*>(rhs + r0 * d + col);
+          rb1 = *reinterpret_cast<const uint4*>(rhs + r1 * d + col);
+        }
+        float a[N], b[N];
+        if (MODE != MODE_RHS) V::unpack(la0, a);
+        if (MODE != MODE_LHS) V::unpack(rb0, b);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          float p = (MODE == MODE_BOTH) ? a[i] * b[i] : (MODE == MODE_LHS ? a[i] : b[i]);
+          if (SCALED) p = sc0 * p;
+          acc[i] = R::op(acc[i], p);
+        }
+        if (m0 + 1 < end) {
+          if (MODE != MODE_RHS) V::unpack(la1, a);
+          if (MODE != MODE_LHS) V::unpack(rb1, b);
+#pragma unroll
+          for (int i = 0; i < N; ++i) {
+            float p = (MODE == MODE_BOTH) ? a[i] * b[i] : (MODE == MODE_LHS ? a[i] : b[i]);
+            if (SCALED) p = sc1 * p;
+            acc[i] = R::op(acc[i], p);
+          }
+        }
+      }
+      const int cnt = end - beg;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        if (AGGR == PYGHO_MEAN) acc[i] = cnt > 0 ? mean_div(acc[i], cnt) : 0.f;
+        if (AGGR == PYGHO_MAX || AGGR == PYGHO_MIN) acc[i] = cnt > 0 ? acc[i] : 0.f;
+      }
+      *reinterpret_cast<uint4*>(out + s * d + col) = V::pack(acc);
+    }
+  }
+}
+
+// Generic path: any d, broadcast operands (row width 1), f64 / i64.  One thread per
+// (segment, column); consecutive threads take consecutive columns.
+template <typename T, int AGGR>
+__global__ __launch_bounds__(kBlock) void seg_gmr_generic_kernel(
+    T* __restrict__ out, const T* __restrict__ lhs, const T* __restrict__ rhs,
+    const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ lhs_idx,
+    const int32_t* __restrict__ rhs_idx, const float* __restrict__ lhs_rowscale,
+    int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d) {
+  using A = typename Acc<T>::type;
+  using R = Reduce<AGGR, A>;
+  const int64_t total = n_seg * d;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = t / d, c = t - s * d;
+    const int beg = seg_ptr[s], end = seg_ptr[s + 1];
+    A acc = R::init();
+    for (int m = beg; m < end; ++m) {
+      A p = (A)1;
+      if (lhs) {
+        const int64_t l = lhs_idx ? lhs_idx[m] : m;
+        p = load_as_acc<T>(lhs + l * lhs_d + (lhs_d == 1 ? 0 : c));
+        if (lhs_rowscale) p = (A)(lhs_rowscale[l] * (float)p);
+      }
+      if (rhs) {
+        const int64_t r = rhs_idx ? rhs_idx[m] : m;
+        const A q = load_as_acc<T>(rhs + r * rhs_d + (rhs_d == 1 ? 0 : c));
+        p = lhs ? p * q : q;
+      }
+      acc = R::op(acc, p);
+    }
+    const int cnt = end - beg;
+    if (AGGR == PYGHO_MEAN) acc = cnt > 0 ? mean_div(acc, cnt) : (A)0;
+    if (AGGR == PYGHO_MAX || AGGR == PYGHO_MIN) acc = cnt > 0 ? acc : (A)0;
+    store_from_acc<T>(out + t, acc);
+  }
+}
+
+// ties[a, c] = #messages of segment a whose value equals the forward extremum
+template <typename T>
+__global__ __launch_bounds__(kBlock) void seg_ties_kernel(
+    float* __restrict__ ties, const T* __restrict__ fwd, const T* __restrict__ lhs, const T* __restrict__ rhs,
+    const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ lhs_idx, const int32_t* __restrict__ rhs_idx,
+    int64_t n_seg, int64_t d) {
+  using A = typename Acc<T>::type;
+  const int64_t total = n_seg * d;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = t / d, c = t - s * d;
+    const A ext = load_as_acc<T>(fwd + t);
+    float n = 0.f;
+    for (int m = seg_ptr[s]; m < seg_ptr[s + 1]; ++m) {
+      A p = (A)1;
+      if (lhs) p = load_as_acc<T>(lhs + (int64_t)(lhs_idx ? lhs_idx[m] : m) * d + c);
+      if (rhs) {
+        const A q = load_as_acc<T>(rhs + (int64_t)(rhs_idx ? rhs_idx[m] : m) * d + c);
+        p = lhs ? p * q : q;
+      }
+      // the forward stored the extremum rounded to T: compare after the same rounding
+      T tmp; store_from_acc<T>(&tmp, p);
+      n += (load_as_acc<T>(&tmp) == ext) ? 1.f : 0.f;
+    }
+    ties[t] = n;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void seg_extremum_bwd_kernel(
+    T* __restrict__ gout, const T* __restrict__ gin, const T* __restrict__ fwd, const float* __restrict__ ties,
+    const T* __restrict__ self_vals, const T* __restrict__ other, const int32_t* __restrict__ seg_ptr,
+    const int32_t* __restrict__ out_idx, const int32_t* __restrict__ other_idx, int64_t n_seg, int64_t d) {
+  using A = typename Acc<T>::type;
+  const int64_t total = n_seg * d;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = t / d, c = t - s * d;
+    const A sv = self_vals ? load_as_acc<T>(self_vals + t) : (A)1;
+    A acc = (A)0;
+    for (int m = seg_ptr[s]; m < seg_ptr[s + 1]; ++m) {
+      const int64_t a = out_idx[m];
+      const A ov = other ? load_as_acc<T>(other + (int64_t)(other_idx ? other_idx[m] : m) * d + c) : (A)1;
+      const A msg = self_vals ? (other ? sv * ov : sv) : ov;
+      T tmp; store_from_acc<T>(&tmp, msg);
+      if (load_as_acc<T>(&tmp) == load_as_acc<T>(fwd + a * d + c)) {
+        const A g = load_as_acc<T>(gin + a * d + c) / (A)ties[a * d + c];
+        acc += other ? g * ov : g;
+      }
+    }
+    store_from_acc<T>(gout + t, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void row_gather_fast_kernel(
+    T* __restrict__ out, const T* __restrict__ src, const int32_t* __restrict__ idx,
+    const int32_t* __restrict__ valid, int64_t n_rows, int64_t d, int chunks) {
+  constexpr int N = Vec16<T>::N;
+  const int64_t total = n_rows * chunks;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / chunks;
+    const int c = (int)(t - r * chunks);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (!valid || valid[r]) v = *reinterpret_cast<const uint4*>(src + (int64_t)idx[r] * d + (int64_t)c * N);
+    *reinterpret_cast<uint4*>(out + r * d + (int64_t)c * N) = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void row_gather_generic_kernel(
+    T* __restrict__ out, const T* __restrict__ src, const int32_t* __restrict__ idx,
+    const int32_t* __restrict__ valid, int64_t n_rows, int64_t d) {
+  const int64_t total = n_rows * d;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / d, c = t - r * d;
+    T v;
+    if (!valid || valid[r]) v = src[(int64_t)idx[r] * d + c];
+    else memset(&v, 0, sizeof(T));
+    out[t] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+template <typename T, int AGGR>
+int launch_fast(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
+                const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, hipStream_t st) {
+  const int chunks = (int)(d * sizeof(T) / 16);
+  int log2g = 0;
+  while ((1 << log2g) < chunks && log2g < 6) ++log2g;
+  const int gw = kWave >> log2g;
+  const int64_t per_block = (int64_t)(kBlock / kWave) * gw * 4;
+  dim3 grid(grid_for(n_seg, (int)per_block), (unsigned)ceil_div(chunks, kWave));
+#define PYGHO_LAUNCH(MODE, SC)                                                                                   \
+  hipLaunchKernelGGL((seg_gmr_fast_kernel<T, AGGR, MODE, SC>), grid, dim3(kBlock), 0, st, (T*)out, (const T*)lhs, \
+                     (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, chunks, log2g)
+  if (lhs && rhs) { if (scale) PYGHO_LAUNCH(MODE_BOTH, true); else PYGHO_LAUNCH(MODE_BOTH, false); }
+  else if (lhs)   { if (scale) PYGHO_LAUNCH(MODE_LHS, true);  else PYGHO_LAUNCH(MODE_LHS, false); }
+  else            { PYGHO_LAUNCH(MODE_RHS, false); }
+#undef PYGHO_LAUNCH
+  return check_launch("seg_gather_mul_reduce");
+}
+
+template <typename T, int AGGR>
+int launch_generic(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
+                   const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d,
+                   hipStream_t st) {
+  hipLaunchKernelGGL((seg_gmr_generic_kernel<T, AGGR>), dim3(grid_for(n_seg * d, kBlock)), dim3(kBlock), 0, st, (T*)out,
+                     (const T*)lhs, (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, lhs_d, rhs_d);
+  return check_launch("seg_gather_mul_reduce(generic)");
+}
+
+template <typename T, bool FAST_OK>
+int dispatch_aggr(int aggr, void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
+                  const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d,
+                  hipStream_t st) {
+  bool fast = FAST_OK && (d * sizeof(T)) % 16 == 0 && (!lhs || lhs_d == d) && (!rhs || rhs_d == d) && (lhs || rhs) &&
+              ((uintptr_t)out % 16 == 0) && ((uintptr_t)lhs % 16 == 0) && ((uintptr_t)rhs % 16 == 0) && !(scale && !lhs);
+#define PYGHO_CASE(AG)                                                                                              \
+  case AG:                                                                                                         \
+    if constexpr (FAST_OK) {                                                                                       \
+      if (fast) return launch_fast<T, AG>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, st);          \
+    }                                                                                                              \
+    return launch_generic<T, AG>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, lhs_d, rhs_d, st);
+  switch (aggr) {
+    PYGHO_CASE(PYGHO_SUM)
+    PYGHO_CASE(PYGHO_MEAN)
+    PYGHO_CASE(PYGHO_MAX)
+    PYGHO_CASE(PYGHO_MIN)
+    default:
+      set_error("unknown aggr %d", aggr);
+      return PYGHO_ERR_INVALID;
+  }
+#undef PYGHO_CASE
+}
+
+}  // namespace pygho
+
+using namespace pygho;
+
+extern "C" int pygho_seg_gather_mul_reduce(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr,
+                                           const int32_t* lhs_idx, const int32_t* rhs_idx, const float* lhs_rowscale,
+                                           int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d, int dtype, int aggr,
+                                           void* stream) {
+  if (n_seg < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n_seg == 0 || d == 0) return PYGHO_OK;
+  if (!out || !seg_ptr) { set_error("null out / seg_ptr"); return PYGHO_ERR_INVALID; }
+  if ((lhs && lhs_d != d && lhs_d != 1) || (rhs && rhs_d != d && rhs_d != 1)) {
+    set_error("operand row width must be d or 1");
+    return PYGHO_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case PYGHO_F32: return dispatch_aggr<float, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, st);
+    case PYGHO_BF16: return dispatch_aggr<bf16, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, st);
+    case PYGHO_F16: return dispatch_aggr<f16, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, st);
+    case PYGHO_F64: return dispatch_aggr<double, false>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, st);
+    case PYGHO_I64: return dispatch_aggr<int64_t, false>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, st);
+    default: set_error("unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED;
+  }
+}
+
+#define PYGHO_FLOAT_DISPATCH(dtype, CALL)                           \
+  switch (dtype) {                                                  \
+    case PYGHO_F32: { using T = float; CALL; break; }               \
+    case PYGHO_BF16: { using T = bf16; CALL; break; }               \
+    case PYGHO_F16: { using T = f16; CALL; break; }                 \
+    case PYGHO_F64: { using T = double; CALL; break; }              \
+    default: set_error("unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED; \
+  }
+
+extern "C" int pygho_seg_extremum_ties(float* tie_cnt, const void* fwd_out, const void* lhs, const void* rhs,
+                                       const int32_t* seg_ptr, const int32_t* lhs_idx, const int32_t* rhs_idx,
+                                       int64_t n_seg, int64_t d, int dtype, void* stream) {
+  if (n_seg < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n_seg == 0 || d == 0) return PYGHO_OK;
+  if (!tie_cnt || !fwd_out || !seg_ptr) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  PYGHO_FLOAT_DISPATCH(dtype, hipLaunchKernelGGL((seg_ties_kernel<T>), dim3(grid_for(n_seg * d, kBlock)), dim3(kBlock), 0, st,
+                                                  tie_cnt, (const T*)fwd_out, (const T*)lhs, (const T*)rhs, seg_ptr, lhs_idx,
+                                                  rhs_idx, n_seg, d));
+  return check_launch("seg_extremum_ties");
+}
+
+extern "C" int pygho_seg_extremum_bwd(void* gout, const void* gin, const void* fwd_out, const float* tie_cnt,
+                                      const void* self_vals, const void* other_vals, const int32_t* seg_ptr,
+                                      const int32_t* out_idx, const int32_t* other_idx, int64_t n_seg, int64_t d,
+                                      int dtype, void* stream) {
+  if (n_seg < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n_seg == 0 || d == 0) return PYGHO_OK;
+  if (!gout || !gin || !fwd_out || !tie_cnt || !seg_ptr || !out_idx) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  PYGHO_FLOAT_DISPATCH(dtype, hipLaunchKernelGGL((seg_extremum_bwd_kernel<T>), dim3(grid_for(n_seg * d, kBlock)), dim3(kBlock), 0,
+                                                  st, (T*)gout, (const T*)gin, (const T*)fwd_out, tie_cnt, (const T*)self_vals,
+                                                  (const T*)other_vals, seg_ptr, out_idx, other_idx, n_seg, d));
+  return check_launch("seg_extremum_bwd");
+}
+
+extern "C" int pygho_row_gather(void* out, const void* src, const int32_t* idx, const int32_t* valid, int64_t n_rows,
+                                int64_t d, int dtype, void* stream) {
+  if (n_rows < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n_rows == 0 || d == 0) return PYGHO_OK;
+  if (!out || !src || !idx) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  size_t es = 0;
+  switch (dtype) {
+    case PYGHO_F32: case PYGHO_I32: es = 4; break;
+    case PYGHO_BF16: case PYGHO_F16: es = 2; break;
+    case PYGHO_F64: case PYGHO_I64: es = 8; break;
+    default: set_error("unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED;
+  }
+  const bool fast = (d * es) % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)src % 16 == 0;
+  if (fast) {
+    // byte-wise copy: treat every row as (d*es/4) floats
+    const int64_t d4 = d * es / 4;
+    const int chunks = (int)(d4 / 4);
+    hipLaunchKernelGGL((row_gather_fast_kernel<float>), dim3(grid_for(n_rows * chunks, kBlock)), dim3(kBlock), 0, st,
+                       (float*)out, (const float*)src, idx, valid, n_rows, d4, chunks);
+  } else if (es == 2) {
+    hipLaunchKernelGGL((row_gather_generic_kernel<uint16_t>), dim3(grid_for(n_rows * d, kBlock)), dim3(kBlock), 0, st,
+                       (uint16_t*)out, (const uint16_t*)src, idx, valid, n_rows, d);
+  } else if (es == 4) {
+    hipLaunchKernelGGL((row_gather_generic_kernel<uint32_t>), dim3(grid_for(n_rows * d, kBlock)), dim3(kBlock), 0, st,
+                       (uint32_t*)out, (const uint32_t*)src, idx, valid, n_rows, d);
+  } else {
+    hipLaunchKernelGGL((row_gather_generic_kernel<uint64_t>), dim3(grid_for(n_rows * d, kBlock)), dim3(kBlock), 0, st,
+                       (uint64_t*)out, (const uint64_t*)src, idx, valid, n_rows, d);
+  }
+  return check_launch("row_gather");
+}
