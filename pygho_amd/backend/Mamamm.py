@@ -19,7 +19,8 @@ def _as_bik(X: MaskedTensor, dim: int):
     """view X as (b, rows, k) or k-first (b, k, rows): returns (data4d, mask3d|None, rows, k, kfirst, rest_shape)."""
     md = X.masked_dim
     data, mask = X.raw, X.mask
-    if md == 2:                       # (b, k, *dense): a single masked dim besides batch
+    vector = md == 2                  # (b, k, *dense): a single masked dim besides batch
+    if vector:
         assert dim == 1
         data, mask, md = data.unsqueeze(2), mask.unsqueeze(2), 3      # (b, k, 1)
     if dim not in (1, md - 1):        # contracted dim in the middle: bring it to the end (copy)
@@ -33,6 +34,8 @@ def _as_bik(X: MaskedTensor, dim: int):
     else:
         rest = tuple(data.shape[2:md])
         kfirst = True
+    if vector:
+        rest = ()
     k = data.shape[dim]
     rows = 1
     for s in rest:

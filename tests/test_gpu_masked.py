@@ -1,0 +1,172 @@
+"""
+GPU parity tests of the masked (dense) path: MaskedTensor methods and the MFMA batched contraction against
+the golden fixtures generated from the reference (pre-filled inputs, where the reference's behaviour equals
+its documented behaviour) and against the numpy oracle / einsum on seeded inputs.
+Tolerances: f32 1e-5 (exact-f32 MFMA, different summation order than einsum); bf16/f16 one output rounding.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from pygho_amd import _native
+    _native.lib()
+    return torch.device("cuda:0")
+
+
+def T(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t if dtype is None else t.to(dtype)
+
+
+def N(t):
+    return t.detach().float().cpu().numpy() if t.dtype in (torch.bfloat16, torch.float16) else t.detach().cpu().numpy()
+
+
+def test_mamamm_golden_forward_backward(dev):
+    from pygho_amd import MaskedTensor
+    from pygho_amd.backend.Mamamm import mamamm
+    g = load_golden("masked_ops.npz")
+    Xm, Am, nm = T(g["Xmask"], dev), T(g["Amask"], dev), T(g["nodemask"], dev)
+    cases = {"X2A1": ("X", Xm, 2, "A", Am, 1), "A1X1": ("A", Am, 1, "X", Xm, 1), "X2X1": ("X", Xm, 2, "X", Xm, 1)}
+    for name, (pn, pm, d1, qn, qm, d2) in cases.items():
+        P = T(g[pn], dev).requires_grad_(True)
+        Q = T(g[qn], dev).requires_grad_(True)
+        out = mamamm(MaskedTensor(P, pm), d1, MaskedTensor(Q, qm), d2, Xm)
+        valid = g["Xmask"][..., None]
+        np.testing.assert_allclose(N(out.data) * valid, g[f"mamamm_{name}"] * valid, **TOL)
+        assert float(N(out.data)[~g["Xmask"]].__abs__().sum()) == 0.0           # documented: masked entries = padvalue
+        w = T(g[f"mamamm_{name}_w"] * valid, dev)                                  # gradient only through valid outputs
+        (out.data * w).sum().backward()
+        # reference gradients were taken with the same weights on ALL outputs; its masked outputs are 0 * inputs
+        # only where inputs are zero-filled, so recompute the expectation with the oracle on the masked weights
+        Pn, Qn = g[pn], g[qn]
+        wm = g[f"mamamm_{name}_w"] * valid
+        Pz, Qz = Pn * g[pn + "mask"][..., None], Qn * g[qn + "mask"][..., None]
+        if name == "A1X1":      # out[bij] = sum_k P[bki] Q[bkj]
+            gP = np.einsum("bijd,bkjd->bkid", wm, Qz)
+            gQ = np.einsum("bijd,bkid->bkjd", wm, Pz)
+        else:                   # out[bij] = sum_k P[bik] Q[bkj]
+            gP = np.einsum("bijd,bkjd->bikd", wm, Qz)
+            gQ = np.einsum("bijd,bikd->bkjd", wm, Pz)
+        np.testing.assert_allclose(N(P.grad), gP * g[pn + "mask"][..., None], **TOL)
+        np.testing.assert_allclose(N(Q.grad), gQ * g[qn + "mask"][..., None], **TOL)
+    # node level: A (b,n,n) without dense dims x x (b,n,d)
+    out = mamamm(MaskedTensor(T(g["A"][..., 0].copy(), dev), Am), 2, MaskedTensor(T(g["x"], dev), nm), 1, nm)
+    np.testing.assert_allclose(N(out.data) * g["nodemask"][..., None], g["mamamm_node"] * g["nodemask"][..., None], **TOL)
+    # 3-D representation x adjacency
+    m3 = T(g["X3mask"], dev)
+    out = mamamm(MaskedTensor(T(g["X3"], dev), m3), 3, MaskedTensor(T(g["A"], dev), Am), 1, m3)
+    v3 = g["X3mask"][..., None]
+    np.testing.assert_allclose(N(out.data) * v3, g["mamamm_X3A1"] * v3, **TOL)
+
+
+def test_masked_tensor_methods_golden(dev):
+    from pygho_amd import MaskedTensor
+    from pygho_amd.backend.MaTensor import filterinf
+    g = load_golden("masked_ops.npz")
+    X, Xm = T(g["X"], dev), T(g["Xmask"], dev)
+    MX = MaskedTensor(X, Xm)
+    Mx = MaskedTensor(T(g["x"], dev), T(g["nodemask"], dev))
+    for op in ("sum", "mean", "max"):
+        for dims in ([1], [2], [1, 2]):
+            tag = f"red_{op}_{''.join(map(str, dims))}"
+            r = getattr(MX, op)(dims)
+            np.testing.assert_allclose(N(r.data), g[tag], **TOL)
+            assert np.array_equal(N(r.mask), g[tag + "_mask"])
+            rk = getattr(MX, op)(dims, keepdim=True)
+            assert rk.data.shape[:3] == tuple(1 if i in dims else s for i, s in enumerate(X.shape[:3]))
+    dg = MX.diag([1, 2])
+    assert np.array_equal(N(dg.data), g["diag"]) and np.array_equal(N(dg.mask), g["diag_mask"])
+    valid = g["Xmask"][..., None]
+    assert np.array_equal(N(Mx.unpooling([2], MX).data), g["unpool2"] * valid)      # documented: masked entries read padvalue
+    assert np.array_equal(N(Mx.unpooling([1], MX).data), g["unpool1"] * valid)
+    assert np.array_equal(N(MaskedTensor(X, Xm, padvalue=float("inf")).fill_masked(1024.)), g["fill1024"])
+    np.testing.assert_allclose(N(MX.diagonalapply(lambda v, f: v * f.unsqueeze(-1)).data), g["diagapply"], **TOL)
+    assert np.array_equal(N(MX.catvalue([MX, MX], True).data), g["cat"])
+    np.testing.assert_allclose(N(MX.add(MaskedTensor(X * 2, Xm), True).data), g["add_same"], **TOL)
+    assert np.array_equal(N(filterinf(T(g["filterinf_in"], dev))), g["filterinf_out"])
+    # deviation fixture: garbage at masked positions must not leak (the reference leaks it)
+    r = MaskedTensor(T(g["dev_in"], dev), Xm).sum([1])
+    np.testing.assert_allclose(N(r.data), g["red_sum_1"], **TOL)
+    assert not np.allclose(g["dev_ref_sum1"], g["red_sum_1"])
+    # true minimum (the reference calls amax here)
+    r = MX.min([2])
+    exp, _ = O.ma_reduce(g["X"], g["Xmask"], [2], "min")
+    np.testing.assert_allclose(N(r.data), exp, **TOL)
+
+
+def test_masked_reduce_grads(dev):
+    from pygho_amd import MaskedTensor
+    rng = np.random.default_rng(0)
+    b, n, d = 3, 7, 12
+    X = rng.standard_normal((b, n, n, d)).astype(np.float32)
+    mask = rng.random((b, n, n)) > 0.4
+    mask[0, 2] = False
+    for op in ("sum", "mean", "max", "min"):
+        for dim in (1, 2):
+            xt = T(X, dev).requires_grad_(True)
+            out = getattr(MaskedTensor(xt, T(mask, dev)), op)([dim]).data
+            w = torch.randn_like(out)
+            (out * w).sum().backward()
+            xr = torch.from_numpy(X).requires_grad_(True)
+            m = torch.from_numpy(mask)[..., None]
+            if op == "sum":
+                ref = (xr * m).sum(dim)
+            elif op == "mean":
+                ref = (xr * m).sum(dim) / m.sum(dim).clamp_min(1)
+            else:
+                fill = float("-inf") if op == "max" else float("inf")
+                t = xr.masked_fill(~m, fill)
+                ref = t.amax(dim) if op == "max" else t.amin(dim)
+                ref = torch.where(torch.isinf(ref), torch.zeros_like(ref), ref)
+            np.testing.assert_allclose(N(out), ref.detach().numpy(), **TOL)
+            (ref * w.cpu()).sum().backward()
+            np.testing.assert_allclose(N(xt.grad), xr.grad.numpy(), **TOL)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(4, 37, 37, 37, 128), (2, 50, 70, 9, 16), (3, 16, 16, 16, 8), (2, 5, 130, 33, 24)])
+@pytest.mark.parametrize("layout", [(False, True), (True, True), (False, False), (True, False)])
+def test_masked_bmm_vs_einsum(dev, dtype, shape, layout):
+    """every storage layout / ragged tile / k-block combination against a float64 einsum."""
+    from pygho_amd import _ops
+    nb, ni, nk, nj, d = shape
+    akf, bkf = layout
+    rng = np.random.default_rng(hash((shape, layout)) % (2 ** 31))
+    A = rng.standard_normal((nb, ni, nk, d)).astype(np.float32)
+    B = rng.standard_normal((nb, nk, nj, d)).astype(np.float32)
+    am, bm, om = rng.random((nb, ni, nk)) > 0.3, rng.random((nb, nk, nj)) > 0.3, rng.random((nb, ni, nj)) > 0.2
+    At, Bt = T(A, dev, dtype), T(B, dev, dtype)
+    Aq, Bq = N(At).astype(np.float64), N(Bt).astype(np.float64)
+    exp = np.einsum("bikd,bkjd->bijd", Aq * am[..., None], Bq * bm[..., None]) * om[..., None]
+    a_st = At.permute(0, 2, 1, 3).contiguous() if akf else At
+    b_st = Bt if bkf else Bt.permute(0, 2, 1, 3).contiguous()
+    am_st = T(am, dev).permute(0, 2, 1).contiguous() if akf else T(am, dev)
+    bm_st = T(bm, dev) if bkf else T(bm, dev).permute(0, 2, 1).contiguous()
+    got = _ops.masked_bmm(a_st, b_st, _ops._mask_u8(am_st), _ops._mask_u8(bm_st), _ops._mask_u8(T(om, dev)),
+                          nb, ni, nk, nj, d, akf, bkf)
+    eps = {torch.float32: 1e-5, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    scale = np.abs(exp).max()
+    np.testing.assert_allclose(N(got), exp, rtol=eps, atol=eps * scale)
+
+
+def test_masked_bmm_transpose_detecting(dev):
+    """A = I with an asymmetric B: a swapped output layout cannot pass."""
+    from pygho_amd import _ops
+    nb, n, d = 2, 20, 8
+    A = torch.eye(n, device=dev).reshape(1, n, n, 1).expand(nb, n, n, d).contiguous()
+    B = (torch.arange(n, device=dev).reshape(n, 1) * 100 + torch.arange(n, device=dev).reshape(1, n)).float()
+    B = B.reshape(1, n, n, 1) + torch.arange(d, device=dev).float().reshape(1, 1, 1, d) * 0.25
+    B = B.expand(nb, n, n, d).contiguous()
+    got = _ops.masked_bmm(A, B, None, None, None, nb, n, n, n, d, False, True)
+    assert torch.equal(got, B)
