@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark: BASELINE.json metric "graphs/sec + 2-tuple msg-edges/sec, ZINC NGNN; HBM GB/s fraction of
+roofline" on config[1] "NGNNConv 2-tuple sparse spspmm on ZINC, hidden=128 bf16, 1xMI355X".
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one full training step (forward, backward, gradient all-reduce when N > 1, AdamW) of the 6-layer NGNN
+of example/minimal.py (hidden 128, bf16 activations / f32 master weights) over one synthetic ZINC-shape batch
+that is already resident in HBM.  Every rank owns its own batch of --graphs graphs (weak scaling, graphs shard
+with no data-path collective); value = graphs of all ranks / max-over-ranks time.
+
+Alongside: msg-edges/s and the HBM roofline fraction of the dominant kernel (the fused gather*gather->segment
+reduce of spspmm, forward and both backward plans), measured live with HIP events around every launch in the
+timed region; and the CPU baseline = the reference's ATen op sequence (oracle/aten_port.py) on the host cores
+for a bounded sample of the same workload (rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+KEY = "X___X___1___A___0"
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--graphs", type=int, default=8192, help="graphs per GPU per step")
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--distinct", type=int, default=1024, help="distinct graphs generated per rank (tiled up to --graphs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-graphs", type=int, default=128)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, seed):
+    """reference op sequence on the host cores: same 6-layer NGNN train step, f32, bounded sample."""
+    from oracle import aten_port as P
+    from pygho_amd import synth
+    hb = synth.make_batch(args.cpu_graphs, "zinc", seed=seed)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    x, ea, tid, tf = t(hb.x), t(hb.edge_attr), t(hb.tupleid), t(hb.tuplefeat)
+    acd, batch, y = t(hb.acd[KEY]), t(hb.batch), t(hb.y)
+    torch.manual_seed(0)
+    model = P.NGNNPort(args.hidden, args.layers)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+
+    def step():
+        opt.zero_grad()
+        pred = model(x, ea, tid, tf, acd, batch, hb.num_graphs)
+        loss = torch.nn.functional.l1_loss(y.unsqueeze(-1), pred)
+        loss.backward()
+        opt.step()
+
+    # ATen's intra-op threading does not scale on these small scatter-heavy ops (the survey container was
+    # slower with 8 threads than with 1): time 1 thread and a moderate pool, report the faster.
+    avail = os.cpu_count() or 1
+    results = []
+    for threads in sorted({1, min(16, avail)}):
+        torch.set_num_threads(threads)
+        step()                               # warm-up
+        n, t0 = 0, time.perf_counter()
+        while n < 2 or (time.perf_counter() - t0 < args.cpu_seconds / 2 and n < 200):
+            step()
+            n += 1
+        results.append((hb.num_graphs * n / (time.perf_counter() - t0), threads, n, time.perf_counter() - t0))
+    rate, cores, n, dt = max(results)
+    torch.set_num_threads(cores)
+    # forward-only spspmm rate for the msg-edges figure
+    Xv, Av = torch.randn(hb.num_tuples, args.hidden), torch.randn(hb.num_edges, args.hidden)
+    P.spspmm_values(Xv, Av, acd, hb.num_tuples)
+    reps, t1 = 0, time.perf_counter()
+    while reps < 3 or time.perf_counter() - t1 < 3.0:
+        P.spspmm_values(Xv, Av, acd, hb.num_tuples)
+        reps += 1
+    dts = time.perf_counter() - t1
+    return {"value": rate, "unit": "graphs/s", "cores": cores, "kind": "port",
+            "all_thread_counts": {str(t): r for r, t, _, _ in results},
+            "sample": f"{n} train steps of the same {args.layers}-layer NGNN (h={args.hidden}, f32) on a "
+                      f"{hb.num_graphs}-graph ZINC-shape batch ({hb.num_messages(KEY)} msg-edges), torch-CPU ATen op "
+                      f"sequence of pygho/backend/Spspmm.py:307-321 (oracle/aten_port.py), {cores} threads, {dt:.1f} s",
+            "spspmm_fwd_msg_edges_per_sec": hb.num_messages(KEY) * reps / dts}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pygho_amd import _native, _ops, synth
+    from pygho_amd.ngnn import SpModel
+    from pygho_amd.parallel import FlatGradSync
+    _native.lib()
+
+    # ---- synthetic ZINC-shape batch of this rank, resident in HBM before timing ------------------------
+    distinct = min(args.distinct, args.graphs)
+    times = max(1, args.graphs // distinct)
+    hb = synth.replicate(synth.make_batch(distinct, "zinc", seed=1000 + rank), times)
+    datadict = synth.to_datadict(hb, dev)
+    act_dtype = torch.bfloat16 if args.dtype == "bf16" else None
+    torch.manual_seed(0)
+    model = SpModel(1, args.layers, args.hidden, act_dtype=act_dtype).to(dev)
+    sync = FlatGradSync(model.parameters())
+    sync.broadcast_params(0)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    y = datadict["y"].unsqueeze(-1)
+
+    def step():
+        sync.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=act_dtype is not None):
+            pred = model(datadict)
+        loss = torch.nn.functional.l1_loss(y, pred.float())
+        loss.backward()
+        sync.sync()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer = _ops.LaunchTimer()
+    t0 = time.perf_counter()
+    with timer:
+        for _ in range(args.steps):
+            loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        gg = torch.tensor([hb.num_graphs, hb.num_messages(KEY)], dtype=torch.float64, device=dev)
+        dist.all_reduce(gg, op=dist.ReduceOp.SUM)
+        total_graphs, total_msgs = float(gg[0].item()), float(gg[1].item())
+    else:
+        total_graphs, total_msgs = float(hb.num_graphs), float(hb.num_messages(KEY))
+
+    if rank == 0:
+        assert bool(torch.isfinite(loss)), "loss is not finite"
+        summ = timer.summary()
+        dom = f"seg_gmr[{'bfloat16' if act_dtype is not None else 'float32'},sum,both]"
+        launches, ms, nbytes = summ[dom]
+        achieved = nbytes / (ms * 1e-3) / 1e9
+        es = 2 if act_dtype is not None else 4
+        fwd_bytes = es * args.hidden * (2 * hb.num_tuples + hb.num_edges) + 8 * hb.num_messages(KEY) + 4 * (hb.num_tuples + 1)
+        line = {
+            "metric": "graphs/sec, ZINC-shape NGNN train step (+ 2-tuple msg-edges/sec and HBM roofline fraction of the spspmm kernel)",
+            "value": total_graphs * args.steps / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype if args.dtype == "f32" else "bf16", "data": "synthetic",
+            "config": {"workload": "NGNNConv 2-tuple sparse spspmm on ZINC-shape synthetic batches, hidden=128 bf16 "
+                                   "(6-layer NGNN of example/minimal.py, full train step)",
+                       "graphs_per_gpu": hb.num_graphs, "nodes": hb.num_nodes, "edges": hb.num_edges,
+                       "tuples": hb.num_tuples, "msg_edges": hb.num_messages(KEY), "hidden": args.hidden,
+                       "layers": args.layers, "parallelism": f"graph-sharded data parallel x{world}"},
+            "msg_edges_per_sec_train": total_msgs * args.layers * args.steps / elapsed,
+            "msg_edges_per_sec_kernel": hb.num_messages(KEY) / (ms * 1e-3),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "seg_gmr_fast_kernel<bf16,SUM,BOTH>"
+                         if act_dtype is not None else "seg_gmr_fast_kernel<float,SUM,BOTH>",
+                         "launches": launches, "avg_ms": ms, "algorithmic_bytes_per_launch": nbytes,
+                         "forward_bytes_per_msg_edge": fwd_bytes / hb.num_messages(KEY)},
+            "kernels": {k: {"launches": v[0], "avg_ms": v[1], "GBps": v[2] / (v[1] * 1e-3) / 1e9} for k, v in summ.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, 1000)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+"""
+CPU port of the reference's hot path as the SAME ATen op sequence it issues  --  TEST / BASELINE
+INFRASTRUCTURE ONLY (nothing under pygho_amd/ may import this).
+
+The reference's "kernels" are ATen calls from Python; its CPU performance is therefore the performance of
+this op sequence on torch-CPU.  ``bench.py``'s ``cpu_baseline`` leg times it on the GPU box's host cores
+(kind "port").  Every function is pinned against the golden fixtures in tests/test_oracle_golden.py.
+
+  scatter_reduce   pygho/backend/utils.py:44-56     zeros + scatter_reduce_(expanded int64 index, include_self=False)
+  spspmm_values    pygho/backend/Spspmm.py:309-315  index, index, mul, scatter_reduce
+  spmm_values      pygho/backend/Spmm.py:40-44      mul, index, scatter_reduce
+  NGNNPort         example/minimal.py:37-85 + honn/Conv.py:53-58 (6 x [MLP, spspmm] + residual, pooling, readout)
+"""
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+
+def scatter_reduce(src: Tensor, ind: Tensor, dim_size: int, aggr: str) -> Tensor:
+    red = {"sum": "sum", "mean": "mean", "max": "amax", "min": "amin"}[aggr]
+    out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
+    index = ind.reshape((-1,) + (1,) * (src.dim() - 1)).expand_as(src)
+    return out.scatter_reduce_(0, index, src, red, include_self=False)
+
+
+def spspmm_values(valA, valB, acd: Tensor, n_out: int, aggr: str = "sum") -> Tensor:
+    if valA is None:
+        msg = valB[acd[2]]
+    elif valB is None:
+        msg = valA[acd[1]]
+    else:
+        msg = valA[acd[1]] * valB[acd[2]]
+    return scatter_reduce(msg, acd[0], n_out, aggr)
+
+
+def spmm_values(valA, X: Tensor, src: Tensor, tar: Tensor, n_tar: int, aggr: str = "sum") -> Tensor:
+    msg = X[src] if valA is None else valA * X[src]
+    return scatter_reduce(msg, tar, n_tar, aggr)
+
+
+def _mlp(h_in, h_out, tailact=True):
+    layers = [nn.Linear(h_in, h_out)]
+    if tailact:
+        layers += [nn.BatchNorm1d(h_out), nn.SiLU(inplace=True)]
+    return nn.Sequential(*layers)
+
+
+class NGNNPort(nn.Module):
+    """functional twin of pygho_amd.ngnn.SpModel on plain CPU tensors (same layer stack and sizes)."""
+
+    def __init__(self, hiddim: int = 128, num_layer: int = 6):
+        super().__init__()
+        self.x_encoder = nn.Embedding(32, hiddim)
+        self.ea_encoder = nn.Embedding(16, hiddim)
+        self.tuplefeat_encoder = nn.Embedding(16, hiddim)
+        self.lin_tupleinit0 = nn.Linear(hiddim, hiddim)
+        self.lin_tupleinit1 = nn.Linear(hiddim, hiddim)
+        self.convs = nn.ModuleList([_mlp(hiddim, hiddim) for _ in range(num_layer)])
+        self.poolmlp = _mlp(hiddim, hiddim)
+        self.pred = nn.Sequential(nn.Linear(hiddim, hiddim), nn.BatchNorm1d(hiddim), nn.SiLU(inplace=True), nn.Linear(hiddim, 1))
+
+    def forward(self, x, edge_attr, tupleid, tuplefeat, acd, batch, num_graphs):
+        n, nnz = x.shape[0], tupleid.shape[1]
+        xh = self.x_encoder(x)
+        Av = self.ea_encoder(edge_attr)
+        Xv = self.tuplefeat_encoder(tuplefeat)
+        Xv = self.lin_tupleinit0(xh)[tupleid[0]] * self.lin_tupleinit1(xh)[tupleid[1]] * Xv
+        for mlp in self.convs:
+            Xv = Xv + spspmm_values(mlp(Xv), Av, acd, nnz, "sum")
+        xn = scatter_reduce(Xv, tupleid[0], n, "mean")
+        hg = scatter_reduce(self.poolmlp(xn), batch, num_graphs, "sum")
+        return self.pred(hg)

@@ -135,6 +135,33 @@ def _as2d(t: Optional[Tensor]) -> Optional[Tensor]:
     return t.reshape(t.shape[0], -1) if t.dim() != 2 else t
 
 
+class LaunchTimer:
+    """Opt-in per-launch timing of the fused segment kernel with HIP events recorded on the stream the
+    kernel is launched on (torch's current stream is the one handed to the C ABI).  Used by bench.py for the
+    roofline figure; `records` holds (kernel variant, algorithmic bytes, start event, end event)."""
+    active: Optional["LaunchTimer"] = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        LaunchTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        LaunchTimer.active = None
+
+    def summary(self):
+        """{variant: (launches, mean ms, mean algorithmic bytes)} -- call after a device synchronize."""
+        agg = {}
+        for name, nbytes, e0, e1 in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+            a[2] += nbytes
+        return {k: (v[0], v[1] / v[0], v[2] / v[0]) for k, v in agg.items()}
+
+
 def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr: Tensor,
             lhs_idx: Optional[Tensor], rhs_idx: Optional[Tensor], aggr: str,
             lhs_rowscale: Optional[Tensor] = None) -> Tensor:
@@ -143,10 +170,26 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
     dev = require_device(lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale)
     d = ref.shape[1]
     out = torch.empty((out_rows, d), dtype=ref.dtype, device=dev)
+    timer = LaunchTimer.active
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(dev))
     check(lib().pygho_seg_gather_mul_reduce(
         ptr(out), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale),
         out_rows, d, d if lhs is not None else 0, d if rhs is not None else 0,
         dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev)), "seg_gather_mul_reduce")
+    if timer is not None:
+        e1.record(torch.cuda.current_stream(dev))
+        # algorithmic bytes: every operand row once, every output row once, int32 indices once
+        es = ref.element_size()
+        m = lhs_idx.numel() if lhs_idx is not None else (rhs_idx.numel() if rhs_idx is not None else ref.shape[0])
+        rows = (lhs.shape[0] if lhs is not None else 0) + (rhs.shape[0] if rhs is not None else 0) + out_rows
+        nbytes = es * d * rows + 4 * m * ((lhs_idx is not None) + (rhs_idx is not None)) + 4 * (out_rows + 1)
+        if lhs_rowscale is not None:
+            nbytes += 4 * lhs_rowscale.numel()
+        mode = "both" if (lhs is not None and rhs is not None) else ("lhs" if lhs is not None else "rhs")
+        timer.records.append((f"seg_gmr[{str(ref.dtype).split('.')[-1]},{aggr},{mode}{',scaled' if lhs_rowscale is not None else ''}]",
+                              nbytes, e0, e1))
     return out
 
 

@@ -15,13 +15,18 @@
 //     output rows; edge rows belong to one graph) is captured by L1/L2;
 //   * products are rounded before accumulation and summed in message order,
 //     so f32 sums are bit-identical to the sequential CPU oracle.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace pygho {
 
 enum { MODE_BOTH = 0, MODE_LHS = 1, MODE_RHS = 2 };
 
-template <typename T, int AGGR, int MODE, bool SCALED>
+constexpr int kSegsPerPass = 64;   // segments a wavefront stages and reduces per pass
+constexpr int kMsgCap = 256;       // message indices staged in LDS per pass (longer passes read the rest from global)
+
+template <typename T, int AGGR, int MODE, bool SCALED, int CPL>
 __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
     T* __restrict__ out, const T* __restrict__ lhs, const T* __restrict__ rhs,
     const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ lhs_idx,
@@ -30,70 +35,114 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
   using V = Vec16<T>;
   using R = Reduce<AGGR, float>;
   constexpr int N = V::N;
-  constexpr int K = 4;  // segments per lane group and pass
+  // per-wave staging of the control data (CSR pointers and message indices): ONE coalesced load each
+  // instead of a dependent pointer -> index -> row chain per segment
+  __shared__ int32_t s_ptr[kBlock / kWave][kSegsPerPass + 1];
+  __shared__ int32_t s_li[kBlock / kWave][kMsgCap];
+  __shared__ int32_t s_ri[kBlock / kWave][kMsgCap];
   const int lane = threadIdx.x & (kWave - 1);
-  const int gl = lane & ((1 << log2g) - 1);
+  const int wv = threadIdx.x >> 6;
+  const int G = 1 << log2g;       // lanes per row; lane gl covers 16-B chunks gl, gl + G, ... (CPL of them)
+  const int gl = lane & (G - 1);
   const int grp = lane >> log2g;
   const int gw = kWave >> log2g;  // lane groups per wave
-  const int chunk = blockIdx.y * kWave + gl;
-  const bool active = chunk < chunks && gl < kWave;
-  const int64_t col = (int64_t)chunk * N;
-  const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-  const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
-  const int64_t span = (int64_t)gw * K;
-
-  for (int64_t base = wave * span; base < n_seg; base += n_waves * span) {
-#pragma unroll 1
-    for (int k = 0; k < K; ++k) {
-      const int64_t s = base + (int64_t)k * gw + grp;
-      if (s >= n_seg || !active) continue;
-      const int beg = seg_ptr[s], end = seg_ptr[s + 1];
-      float acc[N];
+  const int chunk0 = blockIdx.y * kWave * CPL + gl;
+  bool act[CPL];
+  int64_t col[CPL];
 #pragma unroll
-      for (int i = 0; i < N; ++i) acc[i] = R::init();
+  for (int c = 0; c < CPL; ++c) {
+    act[c] = chunk0 + c * G < chunks;
+    col[c] = (int64_t)(act[c] ? chunk0 + c * G : 0) * N;
+  }
+  const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + wv;
+
+  for (int64_t base = wave * kSegsPerPass; base < n_seg; base += n_waves * kSegsPerPass) {
+    // ---- stage: 65 CSR pointers, then the pass's message indices, coalesced ---------------------------
+    const int64_t sp = min(base + lane, n_seg);
+    const int pv = seg_ptr[sp];
+    s_ptr[wv][lane] = pv;
+    const int pend = seg_ptr[min(base + kSegsPerPass, n_seg)];
+    if (lane == 0) s_ptr[wv][kSegsPerPass] = pend;
+    const int mbeg = __builtin_amdgcn_readfirstlane(pv);
+    const int staged = min(pend - mbeg, kMsgCap);
+    for (int j = lane; j < staged; j += kWave) {
+      if (MODE != MODE_RHS && lhs_idx) s_li[wv][j] = lhs_idx[mbeg + j];
+      if (MODE != MODE_LHS && rhs_idx) s_ri[wv][j] = rhs_idx[mbeg + j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- reduce: lane group `grp` takes segments grp, grp + gw, ... of the pass ------------------------
+    const int nloc = (int)min((int64_t)kSegsPerPass, n_seg - base);
+    for (int i = grp; i < nloc; i += gw) {
+      const int beg = s_ptr[wv][i], end = s_ptr[wv][i + 1];
+      float acc[CPL][N];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c)
+#pragma unroll
+        for (int q = 0; q < N; ++q) acc[c][q] = R::init();
       for (int m0 = beg; m0 < end; m0 += 2) {
-        const int m1 = (m0 + 1 < end) ? m0 + 1 : m0;
-        uint4 la0, la1, rb0, rb1;
+        const bool two = m0 + 1 < end;
+        const int m1 = two ? m0 + 1 : m0;
+        const int j0 = m0 - mbeg, j1 = m1 - mbeg;
+        uint4 la[2][CPL], rb[2][CPL];
         float sc0 = 1.f, sc1 = 1.f;
         if (MODE != MODE_RHS) {
-          const int64_t l0 = lhs_idx ? lhs_idx[m0] : m0, l1 = lhs_idx ? lhs_idx[m1] : m1;
-          la0 = *reinterpret_cast<const uint4*>(lhs + l0 * d + col);
-          la1 = *reinterpret_cast<const uint4*>(lhs + l1 * d + col);
+          int64_t l0 = m0, l1 = m1;
+          if (lhs_idx) {
+            l0 = j0 < kMsgCap ? s_li[wv][j0] : lhs_idx[m0];
+            l1 = j1 < kMsgCap ? s_li[wv][j1] : lhs_idx[m1];
+          }
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            la[0][c] = *reinterpret_cast<const uint4*>(lhs + l0 * d + col[c]);
+            la[1][c] = *reinterpret_cast<const uint4*>(lhs + l1 * d + col[c]);
+          }
           if (SCALED) { sc0 = lhs_rowscale[l0]; sc1 = lhs_rowscale[l1]; }
         }
         if (MODE != MODE_LHS) {
-          const int64_t r0 = rhs_idx ? rhs_idx[m0] : m0, r1 = rhs_idx ? rhs_idx[m1] : m1;
-          rb0 = *reinterpret_cast<const uint4*>(rhs + r0 * d + col);
-          rb1 = *reinterpret_cast<const uint4*>(rhs + r1 * d + col);
-        }
-        float a[N], b[N];
-        if (MODE != MODE_RHS) V::unpack(la0, a);
-        if (MODE != MODE_LHS) V::unpack(rb0, b);
+          int64_t r0 = m0, r1 = m1;
+          if (rhs_idx) {
+            r0 = j0 < kMsgCap ? s_ri[wv][j0] : rhs_idx[m0];
+            r1 = j1 < kMsgCap ? s_ri[wv][j1] : rhs_idx[m1];
+          }
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-          float p = (MODE == MODE_BOTH) ? a[i] * b[i] : (MODE == MODE_LHS ? a[i] : b[i]);
-          if (SCALED) p = sc0 * p;
-          acc[i] = R::op(acc[i], p);
+          for (int c = 0; c < CPL; ++c) {
+            rb[0][c] = *reinterpret_cast<const uint4*>(rhs + r0 * d + col[c]);
+            rb[1][c] = *reinterpret_cast<const uint4*>(rhs + r1 * d + col[c]);
+          }
         }
-        if (m0 + 1 < end) {
-          if (MODE != MODE_RHS) V::unpack(la1, a);
-          if (MODE != MODE_LHS) V::unpack(rb1, b);
 #pragma unroll
-          for (int i = 0; i < N; ++i) {
-            float p = (MODE == MODE_BOTH) ? a[i] * b[i] : (MODE == MODE_LHS ? a[i] : b[i]);
-            if (SCALED) p = sc1 * p;
-            acc[i] = R::op(acc[i], p);
+        for (int u = 0; u < 2; ++u) {
+          if (u == 1 && !two) break;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            float a[N], b[N];
+            if (MODE != MODE_RHS) V::unpack(la[u][c], a);
+            if (MODE != MODE_LHS) V::unpack(rb[u][c], b);
+#pragma unroll
+            for (int q = 0; q < N; ++q) {
+              float p = (MODE == MODE_BOTH) ? a[q] * b[q] : (MODE == MODE_LHS ? a[q] : b[q]);
+              if (SCALED) p = (u == 0 ? sc0 : sc1) * p;
+              acc[c][q] = R::op(acc[c][q], p);
+            }
           }
         }
       }
       const int cnt = end - beg;
 #pragma unroll
-      for (int i = 0; i < N; ++i) {
-        if (AGGR == PYGHO_MEAN) acc[i] = cnt > 0 ? mean_div(acc[i], cnt) : 0.f;
-        if (AGGR == PYGHO_MAX || AGGR == PYGHO_MIN) acc[i] = cnt > 0 ? acc[i] : 0.f;
+      for (int c = 0; c < CPL; ++c) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+          if (AGGR == PYGHO_MEAN) acc[c][q] = cnt > 0 ? mean_div(acc[c][q], cnt) : 0.f;
+          if (AGGR == PYGHO_MAX || AGGR == PYGHO_MIN) acc[c][q] = cnt > 0 ? acc[c][q] : 0.f;
+        }
+        if (act[c]) *reinterpret_cast<uint4*>(out + (base + i) * d + col[c]) = V::pack(acc[c]);
       }
-      *reinterpret_cast<uint4*>(out + s * d + col) = V::pack(acc);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -215,23 +264,36 @@ __global__ __launch_bounds__(kBlock) void row_gather_generic_kernel(
 }
 
 // ---------------------------------------------------------------------------
-template <typename T, int AGGR>
-int launch_fast(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
-                const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, hipStream_t st) {
+template <typename T, int AGGR, int CPL>
+int launch_fast_cpl(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
+                    const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, hipStream_t st) {
   const int chunks = (int)(d * sizeof(T) / 16);
+  const int per_lane_groups = (chunks + CPL - 1) / CPL;      // lanes needed per row
   int log2g = 0;
-  while ((1 << log2g) < chunks && log2g < 6) ++log2g;
-  const int gw = kWave >> log2g;
-  const int64_t per_block = (int64_t)(kBlock / kWave) * gw * 4;
-  dim3 grid(grid_for(n_seg, (int)per_block), (unsigned)ceil_div(chunks, kWave));
-#define PYGHO_LAUNCH(MODE, SC)                                                                                   \
-  hipLaunchKernelGGL((seg_gmr_fast_kernel<T, AGGR, MODE, SC>), grid, dim3(kBlock), 0, st, (T*)out, (const T*)lhs, \
+  while ((1 << log2g) < per_lane_groups && log2g < 6) ++log2g;
+  const int gx = grid_for(n_seg, (kBlock / kWave) * kSegsPerPass);
+  dim3 grid(gx, (unsigned)ceil_div(chunks, kWave * CPL));
+#define PYGHO_LAUNCH(MODE, SC)                                                                                        \
+  hipLaunchKernelGGL((seg_gmr_fast_kernel<T, AGGR, MODE, SC, CPL>), grid, dim3(kBlock), 0, st, (T*)out, (const T*)lhs, \
                      (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, chunks, log2g)
   if (lhs && rhs) { if (scale) PYGHO_LAUNCH(MODE_BOTH, true); else PYGHO_LAUNCH(MODE_BOTH, false); }
   else if (lhs)   { if (scale) PYGHO_LAUNCH(MODE_LHS, true);  else PYGHO_LAUNCH(MODE_LHS, false); }
   else            { PYGHO_LAUNCH(MODE_RHS, false); }
 #undef PYGHO_LAUNCH
   return check_launch("seg_gather_mul_reduce");
+}
+
+template <typename T, int AGGR>
+int launch_fast(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
+                const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, hipStream_t st) {
+  // chunks of 16 B per lane: more chunks per lane = more loads in flight per wavefront and a shorter
+  // sequential chain of segments per lane group (the kernel is latency x parallelism bound, not ALU bound)
+  static const int forced = getenv("PYGHO_SEG_CPL") ? atoi(getenv("PYGHO_SEG_CPL")) : 0;
+  const int chunks = (int)(d * sizeof(T) / 16);
+  int cpl = forced ? forced : (chunks >= 16 ? 2 : 1);
+  if (cpl == 4 && chunks >= 4) return launch_fast_cpl<T, AGGR, 4>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, st);
+  if (cpl == 2 && chunks >= 2) return launch_fast_cpl<T, AGGR, 2>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, st);
+  return launch_fast_cpl<T, AGGR, 1>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, st);
 }
 
 template <typename T, int AGGR>

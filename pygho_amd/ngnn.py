@@ -1,0 +1,73 @@
+"""
+The end-to-end NGNN model of the reference's minimal example (example/minimal.py:22-85), restated on
+the pygho_amd operators.  It defines the shapes the headline benchmark is quoted on (BASELINE.json
+configs 1, 2, 4): InputEncoder (3 embeddings) -> tuple init -> 6 x [NGNNConv + residual] -> subgraph
+mean pooling -> MLP -> per-graph sum -> prediction MLP.  175 489 parameters at hidden = 128.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .backend.SpTensor import SparseTensor
+from .backend.utils import torch_scatter_reduce
+from .honn.Conv import NGNNConv
+from .honn.TensorOp import OpPoolingSubg2D
+from .honn.utils import MLP
+
+
+class InputEncoderSp(nn.Module):
+    """integer node / edge / tuple features -> hidden vectors (example/minimal.py:22-34)."""
+
+    def __init__(self, hiddim: int, act_dtype: Optional[torch.dtype] = None) -> None:
+        super().__init__()
+        self.x_encoder = nn.Embedding(32, hiddim)
+        self.ea_encoder = nn.Embedding(16, hiddim)
+        self.tuplefeat_encoder = nn.Embedding(16, hiddim)
+        self.act_dtype = act_dtype
+
+    def _cast(self, t: Tensor) -> Tensor:
+        return t if self.act_dtype is None else t.to(self.act_dtype)
+
+    def forward(self, datadict: dict) -> dict:
+        out = dict(datadict)
+        out["x"] = self._cast(self.x_encoder(datadict["x"].flatten()))
+        out["A"] = datadict["A"].tuplewiseapply(lambda v: self._cast(self.ea_encoder(v)))
+        out["X"] = datadict["X"].tuplewiseapply(lambda v: self._cast(self.tuplefeat_encoder(v)))
+        return out
+
+
+class SpModel(nn.Module):
+    """example/minimal.py:37-85 (sparse NGNN for graph regression)."""
+
+    def __init__(self, num_tasks: int = 1, num_layer: int = 6, hiddim: int = 128, mlp: Optional[dict] = None,
+                 act_dtype: Optional[torch.dtype] = None):
+        super().__init__()
+        mlp = dict(mlp or {"norm": "bn", "act": "silu", "dp": 0.0})
+        self.lin_tupleinit0 = nn.Linear(hiddim, hiddim)
+        self.lin_tupleinit1 = nn.Linear(hiddim, hiddim)
+        self.npool = "sum"
+        self.lpool = OpPoolingSubg2D("S", "mean")
+        self.poolmlp = MLP(hiddim, hiddim, 1, tailact=True, **mlp)
+        self.data_encoder = InputEncoderSp(hiddim, act_dtype)
+        self.pred_lin = MLP(hiddim, num_tasks, 2, tailact=False, **mlp)
+        conv_mlp = dict(mlp, numlayer=1, tailact=True)
+        self.subggnns = nn.ModuleList([NGNNConv(hiddim, hiddim, "sum", "SS", conv_mlp) for _ in range(num_layer)])
+
+    def tupleinit(self, X: SparseTensor, x: Tensor) -> SparseTensor:
+        subgx0 = X.unpooling_fromdense1dim(0, self.lin_tupleinit0(x))
+        subgx1 = X.unpooling_fromdense1dim(1, self.lin_tupleinit1(x))
+        return X.tuplewiseapply(lambda val: subgx0.values * subgx1.values * val)
+
+    def forward(self, datadict: dict) -> Tensor:
+        datadict = self.data_encoder(datadict)
+        A, X, x = datadict["A"], datadict["X"], datadict["x"]
+        X = self.tupleinit(X, x)
+        for conv in self.subggnns:
+            tX = conv.forward(A, X, datadict)
+            X = X.add(tX, True)
+        x = self.lpool(X)
+        x = self.poolmlp(x)
+        h_graph = torch_scatter_reduce(0, x, datadict["batch"], datadict["num_graphs"], self.npool)
+        return self.pred_lin(h_graph)

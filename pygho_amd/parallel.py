@@ -1,0 +1,55 @@
+"""
+Data parallelism over graphs.  A batch is a block-diagonal union of graphs, so the whole
+operator path shards by graph with no data-path collective; the only exchange is the gradient
+all-reduce.  The reference has no distributed code at all; this is new work.
+
+``FlatGradSync`` keeps every parameter gradient as a view into ONE flat buffer so that the step's
+gradient exchange is a single RCCL all-reduce over xGMI (0.70 MB for the minimal NGNN: latency- not
+bandwidth-bound, so one bucket is optimal) issued right after backward.
+"""
+from typing import Iterable, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class FlatGradSync:
+    def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional["dist.ProcessGroup"] = None,
+                 dtype: torch.dtype = torch.float32):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.group = group
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, dtype=dtype, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)      # autograd accumulates in place into the view
+            off += n
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+    def zero_grad(self) -> None:
+        self.flat.zero_()
+
+    def sync(self) -> None:
+        """average the flat gradient over all ranks (one collective)."""
+        if self.world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(self.world)
+
+    def broadcast_params(self, src: int = 0) -> None:
+        if self.world > 1:
+            for p in self.params:
+                dist.broadcast(p.data, src=src, group=self.group)
+
+
+def shard_ranges(weights, world_size: int) -> List[Tuple[int, int]]:
+    """contiguous graph ranges per rank, balanced by cumulative weight (per-graph message count)."""
+    w = np.asarray(weights, dtype=np.float64)
+    cum = np.concatenate(([0.0], np.cumsum(w)))
+    cuts = [0]
+    for r in range(1, world_size):
+        cuts.append(max(cuts[-1], int(np.searchsorted(cum, cum[-1] * r / world_size, side="left"))))
+    cuts.append(len(w))
+    return [(cuts[i], cuts[i + 1]) for i in range(world_size)]
