@@ -70,6 +70,8 @@ const char* pygho_last_error(void);
  *   the transposed plans of pygho_plan_group_by_key.
  *
  * lhs_d / rhs_d: dense width of the operand rows, either `d` or 1 (broadcast).
+ * lhs_rows / rhs_rows: number of rows of the operand arrays (0 = unknown); operands below 4 GiB are
+ *   addressed with 32-bit byte offsets.
  * Accumulation: f32 for f32/bf16/f16, f64 for f64, i64 for i64 (mean floors).
  * Products are rounded before accumulation (no FMA contraction) and summed in
  * message order, so f32 sums are bit-identical to a sequential CPU loop.
@@ -78,7 +80,7 @@ int pygho_seg_gather_mul_reduce(void* out, const void* lhs, const void* rhs,
                                 const int32_t* seg_ptr, const int32_t* lhs_idx,
                                 const int32_t* rhs_idx, const float* lhs_rowscale,
                                 int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d,
-                                int dtype, int aggr, void* stream);
+                                int64_t lhs_rows, int64_t rhs_rows, int dtype, int aggr, void* stream);
 
 /*
  * Backward of the max / min aggregation (autograd of scatter_reduce_(amax|amin),

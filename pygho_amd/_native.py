@@ -28,7 +28,7 @@ P, I, L, Z, D = c_void_p, c_int, c_int64, c_size_t, c_double
 PROTOTYPES = {
     "pygho_abi_version": (I, []),
     "pygho_last_error": (c_char_p, []),
-    "pygho_seg_gather_mul_reduce": (I, [P, P, P, P, P, P, P, L, L, L, L, I, I, P]),
+    "pygho_seg_gather_mul_reduce": (I, [P, P, P, P, P, P, P, L, L, L, L, L, L, I, I, P]),
     "pygho_seg_extremum_ties": (I, [P, P, P, P, P, P, P, L, L, I, P]),
     "pygho_seg_extremum_bwd": (I, [P, P, P, P, P, P, P, P, P, L, L, I, P]),
     "pygho_row_gather": (I, [P, P, P, P, L, L, I, P]),

@@ -177,6 +177,7 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
     check(lib().pygho_seg_gather_mul_reduce(
         ptr(out), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale),
         out_rows, d, d if lhs is not None else 0, d if rhs is not None else 0,
+        lhs.shape[0] if lhs is not None else 0, rhs.shape[0] if rhs is not None else 0,
         dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev)), "seg_gather_mul_reduce")
     if timer is not None:
         e1.record(torch.cuda.current_stream(dev))

@@ -59,6 +59,11 @@ template <> __device__ __forceinline__ void store_from_acc<bf16>(bf16* p, float 
 template <> __device__ __forceinline__ void store_from_acc<f16>(f16* p, float v) { p->v = (_Float16)v; }
 
 // ---- 16-byte vectors: N elements of T per lane ------------------------------
+// 16-bit inputs: the f32 product of two bf16/f16 values is exact, so fma(a, b, acc) == acc + a*b bit for bit
+template <typename T> struct ExactProduct { static constexpr bool value = false; };
+template <> struct ExactProduct<bf16> { static constexpr bool value = true; };
+template <> struct ExactProduct<f16> { static constexpr bool value = true; };
+
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
   static constexpr int N = 4;
@@ -80,9 +85,15 @@ template <> struct Vec16<bf16> {
     }
   }
   static __device__ __forceinline__ uint4 pack(const float (&v)[8]) {
+    // v_cvt_pk_bf16_f32: hardware round-to-nearest-even pair conversion (gfx950)
+    typedef __attribute__((ext_vector_type(2))) float f2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) {
+      const f2_t f = {v[2 * i], v[2 * i + 1]};
+      w[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf2_t));
+    }
     return make_uint4(w[0], w[1], w[2], w[3]);
   }
 };

@@ -26,12 +26,43 @@ enum { MODE_BOTH = 0, MODE_LHS = 1, MODE_RHS = 2 };
 constexpr int kSegsPerPass = 64;   // segments a wavefront stages and reduces per pass
 constexpr int kMsgCap = 256;       // message indices staged in LDS per pass (longer passes read the rest from global)
 
-template <typename T, int AGGR, int MODE, bool SCALED, int CPL>
+// row address: 32-bit byte offsets off a uniform base when the operand is < 4 GiB (one v_mad_u32 instead
+// of a 64-bit multiply-add chain; the kernel is VALU-issue sensitive), 64-bit otherwise
+template <bool OFF32>
+__device__ __forceinline__ uint4 load_row16(const char* __restrict__ base, int idx, uint32_t row_bytes, uint32_t col_bytes) {
+  if (OFF32) {
+    const uint32_t off = (uint32_t)idx * row_bytes + col_bytes;
+    return *reinterpret_cast<const uint4*>(base + off);
+  }
+  return *reinterpret_cast<const uint4*>(base + ((int64_t)idx * (int64_t)row_bytes + col_bytes));
+}
+
+template <typename T, int AGGR, int MODE, bool SCALED>
+__device__ __forceinline__ void accumulate16(float (&acc)[Vec16<T>::N], const uint4& la, const uint4& rb, float sc) {
+  using V = Vec16<T>;
+  using R = Reduce<AGGR, float>;
+  constexpr int N = V::N;
+  float a[N], b[N];
+  if (MODE != MODE_RHS) V::unpack(la, a);
+  if (MODE != MODE_LHS) V::unpack(rb, b);
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    if (MODE == MODE_BOTH && !SCALED && (AGGR == PYGHO_SUM || AGGR == PYGHO_MEAN) && ExactProduct<T>::value) {
+      acc[q] = __builtin_fmaf(a[q], b[q], acc[q]);      // exact product: identical to mul then add
+    } else {
+      float p = (MODE == MODE_BOTH) ? a[q] * b[q] : (MODE == MODE_LHS ? a[q] : b[q]);
+      if (SCALED) p = sc * p;
+      acc[q] = R::op(acc[q], p);
+    }
+  }
+}
+
+template <typename T, int AGGR, int MODE, bool SCALED, bool OFF32>
 __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
     T* __restrict__ out, const T* __restrict__ lhs, const T* __restrict__ rhs,
     const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ lhs_idx,
     const int32_t* __restrict__ rhs_idx, const float* __restrict__ lhs_rowscale,
-    int64_t n_seg, int64_t d, int chunks, int log2g) {
+    int64_t n_seg, int d, int chunks, int log2g) {
   using V = Vec16<T>;
   using R = Reduce<AGGR, float>;
   constexpr int N = V::N;
@@ -42,33 +73,34 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
   __shared__ int32_t s_ri[kBlock / kWave][kMsgCap];
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = threadIdx.x >> 6;
-  const int G = 1 << log2g;       // lanes per row; lane gl covers 16-B chunks gl, gl + G, ... (CPL of them)
-  const int gl = lane & (G - 1);
+  const int gl = lane & ((1 << log2g) - 1);   // lane within the row group: 16-B chunk of the row
   const int grp = lane >> log2g;
-  const int gw = kWave >> log2g;  // lane groups per wave
-  const int chunk0 = blockIdx.y * kWave * CPL + gl;
-  bool act[CPL];
-  int64_t col[CPL];
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) {
-    act[c] = chunk0 + c * G < chunks;
-    col[c] = (int64_t)(act[c] ? chunk0 + c * G : 0) * N;
-  }
+  const int gw = kWave >> log2g;              // lane groups (= segments in flight) per wave
+  const int chunk = blockIdx.y * kWave + gl;
+  const bool active = chunk < chunks;
+  const uint32_t row_bytes = (uint32_t)d * sizeof(T);
+  const uint32_t col_bytes = (uint32_t)(active ? chunk : 0) * 16u;
+  const char* lbase = reinterpret_cast<const char*>(lhs);
+  const char* rbase = reinterpret_cast<const char*>(rhs);
+  char* obase = reinterpret_cast<char*>(out);
+  const bool has_li = lhs_idx != nullptr, has_ri = rhs_idx != nullptr;
   const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
   const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + wv;
 
   for (int64_t base = wave * kSegsPerPass; base < n_seg; base += n_waves * kSegsPerPass) {
     // ---- stage: 65 CSR pointers, then the pass's message indices, coalesced ---------------------------
-    const int64_t sp = min(base + lane, n_seg);
-    const int pv = seg_ptr[sp];
-    s_ptr[wv][lane] = pv;
+    const int pv = seg_ptr[min(base + lane, n_seg)];
     const int pend = seg_ptr[min(base + kSegsPerPass, n_seg)];
+    s_ptr[wv][lane] = pv;
     if (lane == 0) s_ptr[wv][kSegsPerPass] = pend;
     const int mbeg = __builtin_amdgcn_readfirstlane(pv);
-    const int staged = min(pend - mbeg, kMsgCap);
-    for (int j = lane; j < staged; j += kWave) {
-      if (MODE != MODE_RHS && lhs_idx) s_li[wv][j] = lhs_idx[mbeg + j];
-      if (MODE != MODE_LHS && rhs_idx) s_ri[wv][j] = rhs_idx[mbeg + j];
+    const int nmsg = __builtin_amdgcn_readfirstlane(pend) - mbeg;
+    const bool staged = nmsg <= kMsgCap;              // wave-uniform
+    if (staged) {
+      for (int j = lane; j < nmsg; j += kWave) {
+        if (MODE != MODE_RHS && has_li) s_li[wv][j] = lhs_idx[mbeg + j];
+        if (MODE != MODE_LHS && has_ri) s_ri[wv][j] = rhs_idx[mbeg + j];
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -77,68 +109,37 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
     const int nloc = (int)min((int64_t)kSegsPerPass, n_seg - base);
     for (int i = grp; i < nloc; i += gw) {
       const int beg = s_ptr[wv][i], end = s_ptr[wv][i + 1];
-      float acc[CPL][N];
+      float acc[N];
 #pragma unroll
-      for (int c = 0; c < CPL; ++c)
-#pragma unroll
-        for (int q = 0; q < N; ++q) acc[c][q] = R::init();
+      for (int q = 0; q < N; ++q) acc[q] = R::init();
       for (int m0 = beg; m0 < end; m0 += 2) {
         const bool two = m0 + 1 < end;
         const int m1 = two ? m0 + 1 : m0;
-        const int j0 = m0 - mbeg, j1 = m1 - mbeg;
-        uint4 la[2][CPL], rb[2][CPL];
+        int l0 = m0, l1 = m1, r0 = m0, r1 = m1;
+        if (staged) {
+          if (MODE != MODE_RHS && has_li) { l0 = s_li[wv][m0 - mbeg]; l1 = s_li[wv][m1 - mbeg]; }
+          if (MODE != MODE_LHS && has_ri) { r0 = s_ri[wv][m0 - mbeg]; r1 = s_ri[wv][m1 - mbeg]; }
+        } else {
+          if (MODE != MODE_RHS && has_li) { l0 = lhs_idx[m0]; l1 = lhs_idx[m1]; }
+          if (MODE != MODE_LHS && has_ri) { r0 = rhs_idx[m0]; r1 = rhs_idx[m1]; }
+        }
+        uint4 la0, la1, rb0, rb1;
         float sc0 = 1.f, sc1 = 1.f;
-        if (MODE != MODE_RHS) {
-          int64_t l0 = m0, l1 = m1;
-          if (lhs_idx) {
-            l0 = j0 < kMsgCap ? s_li[wv][j0] : lhs_idx[m0];
-            l1 = j1 < kMsgCap ? s_li[wv][j1] : lhs_idx[m1];
-          }
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) {
-            la[0][c] = *reinterpret_cast<const uint4*>(lhs + l0 * d + col[c]);
-            la[1][c] = *reinterpret_cast<const uint4*>(lhs + l1 * d + col[c]);
-          }
-          if (SCALED) { sc0 = lhs_rowscale[l0]; sc1 = lhs_rowscale[l1]; }
-        }
-        if (MODE != MODE_LHS) {
-          int64_t r0 = m0, r1 = m1;
-          if (rhs_idx) {
-            r0 = j0 < kMsgCap ? s_ri[wv][j0] : rhs_idx[m0];
-            r1 = j1 < kMsgCap ? s_ri[wv][j1] : rhs_idx[m1];
-          }
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) {
-            rb[0][c] = *reinterpret_cast<const uint4*>(rhs + r0 * d + col[c]);
-            rb[1][c] = *reinterpret_cast<const uint4*>(rhs + r1 * d + col[c]);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (u == 1 && !two) break;
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) {
-            float a[N], b[N];
-            if (MODE != MODE_RHS) V::unpack(la[u][c], a);
-            if (MODE != MODE_LHS) V::unpack(rb[u][c], b);
-#pragma unroll
-            for (int q = 0; q < N; ++q) {
-              float p = (MODE == MODE_BOTH) ? a[q] * b[q] : (MODE == MODE_LHS ? a[q] : b[q]);
-              if (SCALED) p = (u == 0 ? sc0 : sc1) * p;
-              acc[c][q] = R::op(acc[c][q], p);
-            }
-          }
-        }
+        if (MODE != MODE_RHS) { la0 = load_row16<OFF32>(lbase, l0, row_bytes, col_bytes); la1 = load_row16<OFF32>(lbase, l1, row_bytes, col_bytes); }
+        if (MODE != MODE_LHS) { rb0 = load_row16<OFF32>(rbase, r0, row_bytes, col_bytes); rb1 = load_row16<OFF32>(rbase, r1, row_bytes, col_bytes); }
+        if (SCALED) { sc0 = lhs_rowscale[l0]; sc1 = lhs_rowscale[l1]; }
+        accumulate16<T, AGGR, MODE, SCALED>(acc, la0, rb0, sc0);
+        if (two) accumulate16<T, AGGR, MODE, SCALED>(acc, la1, rb1, sc1);
       }
       const int cnt = end - beg;
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-#pragma unroll
-        for (int q = 0; q < N; ++q) {
-          if (AGGR == PYGHO_MEAN) acc[c][q] = cnt > 0 ? mean_div(acc[c][q], cnt) : 0.f;
-          if (AGGR == PYGHO_MAX || AGGR == PYGHO_MIN) acc[c][q] = cnt > 0 ? acc[c][q] : 0.f;
-        }
-        if (act[c]) *reinterpret_cast<uint4*>(out + (base + i) * d + col[c]) = V::pack(acc[c]);
+      for (int q = 0; q < N; ++q) {
+        if (AGGR == PYGHO_MEAN) acc[q] = cnt > 0 ? mean_div(acc[q], cnt) : 0.f;
+        if (AGGR == PYGHO_MAX || AGGR == PYGHO_MIN) acc[q] = cnt > 0 ? acc[q] : 0.f;
+      }
+      if (active) {
+        if (OFF32) *reinterpret_cast<uint4*>(obase + ((uint32_t)(base + i) * row_bytes + col_bytes)) = V::pack(acc);
+        else *reinterpret_cast<uint4*>(obase + ((int64_t)(base + i) * (int64_t)row_bytes + col_bytes)) = V::pack(acc);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -264,18 +265,18 @@ __global__ __launch_bounds__(kBlock) void row_gather_generic_kernel(
 }
 
 // ---------------------------------------------------------------------------
-template <typename T, int AGGR, int CPL>
-int launch_fast_cpl(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
+template <typename T, int AGGR, bool OFF32>
+int launch_fast_off(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
                     const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, hipStream_t st) {
   const int chunks = (int)(d * sizeof(T) / 16);
-  const int per_lane_groups = (chunks + CPL - 1) / CPL;      // lanes needed per row
   int log2g = 0;
-  while ((1 << log2g) < per_lane_groups && log2g < 6) ++log2g;
-  const int gx = grid_for(n_seg, (kBlock / kWave) * kSegsPerPass);
-  dim3 grid(gx, (unsigned)ceil_div(chunks, kWave * CPL));
-#define PYGHO_LAUNCH(MODE, SC)                                                                                        \
-  hipLaunchKernelGGL((seg_gmr_fast_kernel<T, AGGR, MODE, SC, CPL>), grid, dim3(kBlock), 0, st, (T*)out, (const T*)lhs, \
-                     (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, chunks, log2g)
+  while ((1 << log2g) < chunks && log2g < 6) ++log2g;
+  static const int cap = getenv("PYGHO_SEG_GRID") ? atoi(getenv("PYGHO_SEG_GRID")) : kMaxGrid;
+  const int gx = grid_for(n_seg, (kBlock / kWave) * kSegsPerPass, cap);
+  dim3 grid(gx, (unsigned)ceil_div(chunks, kWave));
+#define PYGHO_LAUNCH(MODE, SC)                                                                                          \
+  hipLaunchKernelGGL((seg_gmr_fast_kernel<T, AGGR, MODE, SC, OFF32>), grid, dim3(kBlock), 0, st, (T*)out, (const T*)lhs, \
+                     (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, (int)d, chunks, log2g)
   if (lhs && rhs) { if (scale) PYGHO_LAUNCH(MODE_BOTH, true); else PYGHO_LAUNCH(MODE_BOTH, false); }
   else if (lhs)   { if (scale) PYGHO_LAUNCH(MODE_LHS, true);  else PYGHO_LAUNCH(MODE_LHS, false); }
   else            { PYGHO_LAUNCH(MODE_RHS, false); }
@@ -285,15 +286,13 @@ int launch_fast_cpl(void* out, const void* lhs, const void* rhs, const int32_t* 
 
 template <typename T, int AGGR>
 int launch_fast(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
-                const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, hipStream_t st) {
-  // chunks of 16 B per lane: more chunks per lane = more loads in flight per wavefront and a shorter
-  // sequential chain of segments per lane group (the kernel is latency x parallelism bound, not ALU bound)
-  static const int forced = getenv("PYGHO_SEG_CPL") ? atoi(getenv("PYGHO_SEG_CPL")) : 0;
-  const int chunks = (int)(d * sizeof(T) / 16);
-  int cpl = forced ? forced : (chunks >= 16 ? 2 : 1);
-  if (cpl == 4 && chunks >= 4) return launch_fast_cpl<T, AGGR, 4>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, st);
-  if (cpl == 2 && chunks >= 2) return launch_fast_cpl<T, AGGR, 2>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, st);
-  return launch_fast_cpl<T, AGGR, 1>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, st);
+                const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, int64_t lhs_rows, int64_t rhs_rows,
+                hipStream_t st) {
+  const int64_t rb = d * (int64_t)sizeof(T);
+  const int64_t lim = (int64_t)1 << 32;
+  const bool off32 = n_seg * rb < lim && (!lhs || (lhs_rows > 0 && lhs_rows * rb < lim)) && (!rhs || (rhs_rows > 0 && rhs_rows * rb < lim));
+  if (off32) return launch_fast_off<T, AGGR, true>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, st);
+  return launch_fast_off<T, AGGR, false>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, st);
 }
 
 template <typename T, int AGGR>
@@ -308,13 +307,13 @@ int launch_generic(void* out, const void* lhs, const void* rhs, const int32_t* s
 template <typename T, bool FAST_OK>
 int dispatch_aggr(int aggr, void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
                   const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d,
-                  hipStream_t st) {
+                  int64_t lhs_rows, int64_t rhs_rows, hipStream_t st) {
   bool fast = FAST_OK && (d * sizeof(T)) % 16 == 0 && (!lhs || lhs_d == d) && (!rhs || rhs_d == d) && (lhs || rhs) &&
               ((uintptr_t)out % 16 == 0) && ((uintptr_t)lhs % 16 == 0) && ((uintptr_t)rhs % 16 == 0) && !(scale && !lhs);
 #define PYGHO_CASE(AG)                                                                                              \
   case AG:                                                                                                         \
     if constexpr (FAST_OK) {                                                                                       \
-      if (fast) return launch_fast<T, AG>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, st);          \
+      if (fast) return launch_fast<T, AG>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, lhs_rows, rhs_rows, st); \
     }                                                                                                              \
     return launch_generic<T, AG>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, lhs_d, rhs_d, st);
   switch (aggr) {
@@ -335,8 +334,8 @@ using namespace pygho;
 
 extern "C" int pygho_seg_gather_mul_reduce(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr,
                                            const int32_t* lhs_idx, const int32_t* rhs_idx, const float* lhs_rowscale,
-                                           int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d, int dtype, int aggr,
-                                           void* stream) {
+                                           int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d, int64_t lhs_rows,
+                                           int64_t rhs_rows, int dtype, int aggr, void* stream) {
   if (n_seg < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
   if (n_seg == 0 || d == 0) return PYGHO_OK;
   if (!out || !seg_ptr) { set_error("null out / seg_ptr"); return PYGHO_ERR_INVALID; }
@@ -346,11 +345,11 @@ extern "C" int pygho_seg_gather_mul_reduce(void* out, const void* lhs, const voi
   }
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {
-    case PYGHO_F32: return dispatch_aggr<float, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, st);
-    case PYGHO_BF16: return dispatch_aggr<bf16, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, st);
-    case PYGHO_F16: return dispatch_aggr<f16, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, st);
-    case PYGHO_F64: return dispatch_aggr<double, false>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, st);
-    case PYGHO_I64: return dispatch_aggr<int64_t, false>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, st);
+    case PYGHO_F32: return dispatch_aggr<float, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
+    case PYGHO_BF16: return dispatch_aggr<bf16, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
+    case PYGHO_F16: return dispatch_aggr<f16, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
+    case PYGHO_F64: return dispatch_aggr<double, false>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
+    case PYGHO_I64: return dispatch_aggr<int64_t, false>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
     default: set_error("unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED;
   }
 }
