@@ -100,6 +100,13 @@ int pygho_seg_extremum_bwd(void* gout, const void* gin, const void* fwd_out, con
                            const int32_t* seg_ptr, const int32_t* out_idx, const int32_t* other_idx,
                            int64_t n_seg, int64_t d, int dtype, void* stream);
 
+/* f32 row sums of a 16-bit (or f32) operand: out[s, :] = sum_{m in seg s} src[idx ? idx[m] : m, :].
+ * First level of the hierarchical reduction of LONG segments (e.g. the backward of a row gather from a
+ * table with a handful of rows -- nn.Embedding's index_put_(accumulate) over 10^6 messages per row):
+ * segments are split into chunks of bounded length whose partial sums stay in f32 until the last level. */
+int pygho_seg_sum_f32out(float* out, const void* src, const int32_t* seg_ptr, const int32_t* idx,
+                         int64_t n_seg, int64_t d, int64_t src_rows, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------
  * Row gather   out[r, :] = src[idx[r], :]          (K6)
  *   pygho/backend/SpTensor.py:470-476  X[self.indices[dim]]  (unpooling_fromdense1dim)

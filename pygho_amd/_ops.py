@@ -56,12 +56,12 @@ class SegPlan:
     """CSR grouping of `m` messages into `n_seg` segments: ``seg_ptr`` (n_seg+1) int32 and
     ``perm`` (m) int32 = message ids in grouped order (None when the key array was already
     sorted, i.e. grouped order == message order)."""
-    __slots__ = ("seg_ptr", "perm", "n_seg", "m", "_inv_cnt", "_unit_ptr")
+    __slots__ = ("seg_ptr", "perm", "n_seg", "m", "_inv_cnt", "_memo")
 
     def __init__(self, seg_ptr: Tensor, perm: Optional[Tensor], n_seg: int, m: int):
         self.seg_ptr, self.perm, self.n_seg, self.m = seg_ptr, perm, n_seg, m
         self._inv_cnt = None
-        self._unit_ptr = None
+        self._memo = None
 
     @property
     def inv_count(self) -> Tensor:
@@ -74,6 +74,45 @@ class SegPlan:
     def take(self, idx32: Tensor) -> Tensor:
         """idx32 re-ordered into grouped order."""
         return idx32 if self.perm is None else gather_i32(idx32, self.perm)
+
+    @property
+    def max_len(self) -> int:
+        """longest segment (one host sync, cached)."""
+        if self._memo is None:
+            self._memo = {}
+        if "max_len" not in self._memo:
+            self._memo["max_len"] = int((self.seg_ptr[1:] - self.seg_ptr[:-1]).max().item()) if self.n_seg > 0 else 0
+        return self._memo["max_len"]
+
+    def levels(self, limit: int):
+        """CSR pointers of a hierarchical reduction whose segments never exceed `limit` items: level 0
+        groups the messages into bounded chunks, every further level groups the previous level's partial
+        rows, the last one into the n_seg output segments.  A lane group walks its segment sequentially, so
+        an unbounded segment (a 4-row embedding table receiving 10^6 gradient rows) would serialise."""
+        if self._memo is None:
+            self._memo = {}
+        key = ("levels", limit)
+        if key not in self._memo:
+            out = []
+            cur = self.seg_ptr.to(torch.int64)
+            n_seg = self.n_seg
+            dev = cur.device
+            while True:
+                lens = cur[1:] - cur[:-1]
+                if n_seg == 0 or int(lens.max().item()) <= limit:
+                    out.append(cur.to(_I32))
+                    break
+                nch = (lens + (limit - 1)) // limit
+                ends = torch.cumsum(nch, 0)
+                first = ends - nch
+                n_sub = int(ends[-1].item())
+                seg_of_sub = torch.repeat_interleave(torch.arange(n_seg, device=dev), nch, output_size=n_sub)
+                q = torch.arange(n_sub, device=dev) - first[seg_of_sub]
+                start = cur[seg_of_sub] + q * limit
+                out.append(torch.cat((start, cur[-1:])).to(_I32))
+                cur = torch.cat((torch.zeros(1, dtype=torch.int64, device=dev), ends))
+            self._memo[key] = out
+        return self._memo[key]
 
 
 def unit_ptr(m: int, dev) -> Tensor:
@@ -192,6 +231,39 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
         timer.records.append((f"seg_gmr[{str(ref.dtype).split('.')[-1]},{aggr},{mode}{',scaled' if lhs_rowscale is not None else ''}]",
                               nbytes, e0, e1))
     return out
+
+
+LONG_SEGMENT = 256      # segments longer than this are reduced hierarchically ...
+LONG_CHUNK = 32         # ... in chunks of this many rows (a lane group walks its chunk sequentially)
+
+
+def seg_sum_f32out(src: Tensor, seg_ptr: Tensor, idx: Optional[Tensor], n_seg: int) -> Tensor:
+    dev = require_device(src, seg_ptr, idx)
+    d = src.shape[1]
+    out = torch.empty((n_seg, d), dtype=torch.float32, device=dev)
+    check(lib().pygho_seg_sum_f32out(ptr(out), ptr(src), ptr(seg_ptr), ptr(idx), n_seg, d, src.shape[0], dtype_code(src),
+                                     stream_ptr(dev)), "seg_sum_f32out")
+    return out
+
+
+def seg_reduce_rows(src: Tensor, plan: SegPlan, aggr: str) -> Tensor:
+    """out[s] = (+)_{m in segment s} src[perm[m]] for a 2-D `src`; long segments go through a hierarchy of
+    bounded chunks (f32 partial sums for 16-bit inputs)."""
+    if plan.m == 0 or plan.max_len <= LONG_SEGMENT:
+        return seg_gmr(plan.n_seg, src, None, plan.seg_ptr, plan.perm, None, aggr)
+    levels = plan.levels(LONG_CHUNK)
+    red = "sum" if aggr == "mean" else aggr
+    sixteen = src.dtype in (torch.bfloat16, torch.float16) and red == "sum" and (src.shape[1] * 2) % 16 == 0
+    n0 = levels[0].numel() - 1
+    if sixteen:
+        cur = seg_sum_f32out(src, levels[0], plan.perm, n0)
+    else:
+        cur = seg_gmr(n0, src, None, levels[0], plan.perm, None, red)
+    for lv in levels[1:]:
+        cur = seg_gmr(lv.numel() - 1, cur, None, lv, None, None, red)
+    if aggr == "mean":
+        cur = cur * plan.inv_count.to(cur.dtype).unsqueeze(-1)
+    return cur.to(src.dtype)
 
 
 def row_gather(src: Tensor, idx32: Tensor, valid: Optional[Tensor] = None) -> Tensor:
@@ -353,7 +425,7 @@ def message_reduce(lhs: Optional[Tensor], rhs: Optional[Tensor], acd: Tensor, n_
 class _ScatterReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src: Tensor, plan: SegPlan, ind32: Tensor, aggr: str):
-        out = seg_gmr(plan.n_seg, src, None, plan.seg_ptr, plan.perm, None, aggr)
+        out = seg_reduce_rows(src, plan, aggr)
         ctx.plan, ctx.aggr, ctx.ind32 = plan, aggr, ind32
         ctx.save_for_backward(*((src, out) if aggr in ("max", "min") else ()))
         return out
@@ -408,7 +480,7 @@ class _RowGather(torch.autograd.Function):
         ind = ctx.ind
         plan = cached_plan(ind, ctx.n, "scatter")
         g2 = _as2d(gout) if gout.dim() > 1 else gout.contiguous().reshape(-1, 1)
-        g = seg_gmr(ctx.n, g2, None, plan.seg_ptr, plan.perm, None, "sum")
+        g = seg_reduce_rows(g2, plan, "sum")
         return g.reshape((ctx.n,) + tuple(gout.shape[1:])), None
 
 
@@ -431,10 +503,20 @@ class _MaskedRowGather(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout: Tensor):
         pos, n = ctx.pos, ctx.n
-        keys = torch.where(pos >= 0, pos, torch.full_like(pos, n))      # misses go to a spill segment
-        plan = plan_from_keys(keys, n + 1)
+        cache = getattr(pos, "_pygho_plans", None)
+        if cache is None:
+            cache = {}
+            try:
+                pos._pygho_plans = cache
+            except Exception:
+                pass
+        k = ("spill", n, pos._version)
+        if k not in cache:
+            keys = torch.where(pos >= 0, pos, torch.full_like(pos, n))      # misses go to a spill segment
+            cache[k] = plan_from_keys(keys, n + 1)
+        plan = cache[k]
         g2 = _as2d(gout) if gout.dim() > 1 else gout.contiguous().reshape(-1, 1)
-        g = seg_gmr(n + 1, g2, None, plan.seg_ptr, plan.perm, None, "sum")[:n]
+        g = seg_reduce_rows(g2, plan, "sum")[:n]
         return g.reshape((n,) + tuple(gout.shape[1:])), None
 
 

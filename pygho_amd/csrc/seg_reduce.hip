@@ -15,8 +15,6 @@
 //     output rows; edge rows belong to one graph) is captured by L1/L2;
 //   * products are rounded before accumulation and summed in message order,
 //     so f32 sums are bit-identical to the sequential CPU oracle.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace pygho {
@@ -57,12 +55,12 @@ __device__ __forceinline__ void accumulate16(float (&acc)[Vec16<T>::N], const ui
   }
 }
 
-template <typename T, int AGGR, int MODE, bool SCALED, bool OFF32>
+template <typename T, int AGGR, int MODE, bool SCALED, bool OFF32, bool OUTF32 = false>
 __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
     T* __restrict__ out, const T* __restrict__ lhs, const T* __restrict__ rhs,
     const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ lhs_idx,
     const int32_t* __restrict__ rhs_idx, const float* __restrict__ lhs_rowscale,
-    int64_t n_seg, int d, int chunks, int log2g) {
+    int64_t n_seg, int d, int chunks, int log2g, int spp) {
   using V = Vec16<T>;
   using R = Reduce<AGGR, float>;
   constexpr int N = V::N;
@@ -87,10 +85,12 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
   const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
   const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + wv;
 
-  for (int64_t base = wave * kSegsPerPass; base < n_seg; base += n_waves * kSegsPerPass) {
+  // spp = segments per wave and pass (<= kSegsPerPass): small when there are few segments so that they
+  // still spread over the whole chip (a lane group walks its segments sequentially)
+  for (int64_t base = wave * spp; base < n_seg; base += n_waves * spp) {
     // ---- stage: 65 CSR pointers, then the pass's message indices, coalesced ---------------------------
-    const int pv = seg_ptr[min(base + lane, n_seg)];
-    const int pend = seg_ptr[min(base + kSegsPerPass, n_seg)];
+    const int pv = seg_ptr[min(base + min(lane, spp), n_seg)];
+    const int pend = seg_ptr[min(base + spp, n_seg)];
     s_ptr[wv][lane] = pv;
     if (lane == 0) s_ptr[wv][kSegsPerPass] = pend;
     const int mbeg = __builtin_amdgcn_readfirstlane(pv);
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- reduce: lane group `grp` takes segments grp, grp + gw, ... of the pass ------------------------
-    const int nloc = (int)min((int64_t)kSegsPerPass, n_seg - base);
+    const int nloc = (int)min((int64_t)spp, n_seg - base);
     for (int i = grp; i < nloc; i += gw) {
       const int beg = s_ptr[wv][i], end = s_ptr[wv][i + 1];
       float acc[N];
@@ -138,7 +138,12 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
         if (AGGR == PYGHO_MAX || AGGR == PYGHO_MIN) acc[q] = cnt > 0 ? acc[q] : 0.f;
       }
       if (active) {
-        if (OFF32) *reinterpret_cast<uint4*>(obase + ((uint32_t)(base + i) * row_bytes + col_bytes)) = V::pack(acc);
+        if (OUTF32) {   // f32 partial sums of a 16-bit operand (first level of a long-segment reduction)
+          float* orow = reinterpret_cast<float*>(obase) + ((int64_t)(base + i) * d + (int64_t)chunk * N);
+#pragma unroll
+          for (int q = 0; q < N; q += 4)
+            *reinterpret_cast<float4*>(orow + q) = make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
+        } else if (OFF32) *reinterpret_cast<uint4*>(obase + ((uint32_t)(base + i) * row_bytes + col_bytes)) = V::pack(acc);
         else *reinterpret_cast<uint4*>(obase + ((int64_t)(base + i) * (int64_t)row_bytes + col_bytes)) = V::pack(acc);
       }
     }
@@ -265,18 +270,32 @@ __global__ __launch_bounds__(kBlock) void row_gather_generic_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// segments per wave and pass: enough to amortise the staging when segments are plentiful, as few as one
+// per lane group when they are scarce (so that few long segments still spread over all CUs)
+static inline int segs_per_pass(int64_t n_seg, int log2g) {
+  const int gw = kWave >> log2g;
+  // measured on MI355X (ZINC-shape d=128 bf16 and I2-shape d=256 bf16): 4 segments per lane group and pass
+  // is the sweet spot between staging overhead and the sequential chain a lane group walks
+  int64_t spp = 4 * gw;
+  const int64_t even = ceil_div(ceil_div(n_seg, (int64_t)kMaxGrid * (kBlock / kWave)), gw) * gw;
+  if (even < spp) spp = even;        // scarce segments: spread them over the whole chip
+  if (spp < gw) spp = gw;
+  if (spp > kSegsPerPass) spp = kSegsPerPass;
+  return (int)spp;
+}
+
 template <typename T, int AGGR, bool OFF32>
 int launch_fast_off(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
                     const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, hipStream_t st) {
   const int chunks = (int)(d * sizeof(T) / 16);
   int log2g = 0;
   while ((1 << log2g) < chunks && log2g < 6) ++log2g;
-  static const int cap = getenv("PYGHO_SEG_GRID") ? atoi(getenv("PYGHO_SEG_GRID")) : kMaxGrid;
-  const int gx = grid_for(n_seg, (kBlock / kWave) * kSegsPerPass, cap);
+  const int spp = segs_per_pass(n_seg, log2g);
+  const int gx = grid_for(n_seg, (kBlock / kWave) * spp);
   dim3 grid(gx, (unsigned)ceil_div(chunks, kWave));
 #define PYGHO_LAUNCH(MODE, SC)                                                                                          \
   hipLaunchKernelGGL((seg_gmr_fast_kernel<T, AGGR, MODE, SC, OFF32>), grid, dim3(kBlock), 0, st, (T*)out, (const T*)lhs, \
-                     (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, (int)d, chunks, log2g)
+                     (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, (int)d, chunks, log2g, spp)
   if (lhs && rhs) { if (scale) PYGHO_LAUNCH(MODE_BOTH, true); else PYGHO_LAUNCH(MODE_BOTH, false); }
   else if (lhs)   { if (scale) PYGHO_LAUNCH(MODE_LHS, true);  else PYGHO_LAUNCH(MODE_LHS, false); }
   else            { PYGHO_LAUNCH(MODE_RHS, false); }
@@ -421,4 +440,34 @@ extern "C" int pygho_row_gather(void* out, const void* src, const int32_t* idx, 
                        (uint64_t*)out, (const uint64_t*)src, idx, valid, n_rows, d);
   }
   return check_launch("row_gather");
+}
+
+// f32 row sums of a 16-bit (or f32) operand: out_f32[s, :] = sum_{m in seg s} src[idx ? idx[m] : m, :]
+extern "C" int pygho_seg_sum_f32out(float* out, const void* src, const int32_t* seg_ptr, const int32_t* idx,
+                                    int64_t n_seg, int64_t d, int64_t src_rows, int dtype, void* stream) {
+  if (n_seg < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n_seg == 0 || d == 0) return PYGHO_OK;
+  if (!out || !src || !seg_ptr) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PYGHO_F32)
+    return dispatch_aggr<float, true>(PYGHO_SUM, out, src, nullptr, seg_ptr, idx, nullptr, nullptr, n_seg, d, d, 0, src_rows, 0, st);
+  if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("seg_sum_f32out: unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED; }
+  if ((d * 2) % 16 != 0 || (uintptr_t)src % 16 != 0 || (uintptr_t)out % 16 != 0) {
+    set_error("seg_sum_f32out: rows must be 16-byte multiples");
+    return PYGHO_ERR_UNSUPPORTED;
+  }
+  const int chunks = (int)(d * 2 / 16);
+  int log2g = 0;
+  while ((1 << log2g) < chunks && log2g < 6) ++log2g;
+  const int spp = segs_per_pass(n_seg, log2g);
+  dim3 grid(grid_for(n_seg, (kBlock / kWave) * spp), (unsigned)ceil_div(chunks, kWave));
+  const bool off32 = src_rows > 0 && src_rows * d * 2 < ((int64_t)1 << 32);
+#define PYGHO_L(T, O32)                                                                                                 \
+  hipLaunchKernelGGL((seg_gmr_fast_kernel<T, PYGHO_SUM, MODE_LHS, false, O32, true>), grid, dim3(kBlock), 0, st, (T*)out, \
+                     (const T*)src, (const T*)nullptr, seg_ptr, idx, (const int32_t*)nullptr, (const float*)nullptr,      \
+                     n_seg, (int)d, chunks, log2g, spp)
+  if (dtype == PYGHO_BF16) { if (off32) PYGHO_L(bf16, true); else PYGHO_L(bf16, false); }
+  else { if (off32) PYGHO_L(f16, true); else PYGHO_L(f16, false); }
+#undef PYGHO_L
+  return check_launch("seg_sum_f32out");
 }

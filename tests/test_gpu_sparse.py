@@ -323,3 +323,55 @@ def test_i2_shape_and_large_linearity(dev):
     direct = (x1.double()[c] * a1.double()[dd]).sum(0)
     torch.testing.assert_close(f(x1, a1).double().sum(0), direct, rtol=1e-6, atol=1e-6)
     assert bool((torch.diff(acd_b[0]) >= 0).all())                            # collated plan stays sorted
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_long_segments_hierarchical(dev, dtype):
+    """a 4-row table receiving 300k rows (the embedding-backward shape): hierarchical chunks, f32 partials"""
+    from pygho_amd.backend.utils import torch_scatter_reduce
+    rng = np.random.default_rng(0)
+    m, d, n = 300_000, 64, 6
+    ind = rng.integers(0, 4, size=m).astype(np.int64)           # segments 4, 5 stay empty
+    ind[:5] = [3, 0, 2, 1, 0]
+    src = rng.standard_normal((m, d)).astype(np.float32)
+    st = T(src, dev, dtype)
+    ref_in = N(st).astype(np.float64)
+    for ag in ("sum", "mean", "max", "min"):
+        got = N(torch_scatter_reduce(0, st, T(ind, dev), n, ag)).astype(np.float64)
+        exp = O.scatter_reduce(ref_in, ind, n, ag)
+        tol = 1e-4 if dtype == torch.float32 else 2.0 ** -7
+        np.testing.assert_allclose(got, exp, rtol=tol, atol=tol * max(1.0, np.abs(exp).max()))
+    # gradient of a gather from the tiny table == sum over the long segments
+    table = torch.randn(4, d, device=dev, dtype=dtype, requires_grad=True)
+    from pygho_amd import _ops
+    out = _ops.gather_rows(table, T(ind, dev))
+    w = T(src, dev, dtype)
+    (out.float() * w.float()).sum().backward()
+    exp = O.scatter_reduce(N(w).astype(np.float64), ind, 4, "sum")
+    np.testing.assert_allclose(N(table.grad).astype(np.float64), exp, rtol=2e-2 if dtype == torch.bfloat16 else 1e-4, atol=1.0 if dtype == torch.bfloat16 else 1e-2)
+
+
+def test_model_building_blocks_match_torch(dev):
+    """IndexEmbedding / split-K Linear keep nn.Embedding / nn.Linear semantics (forward and gradients)"""
+    from pygho_amd.honn.utils import Linear
+    from pygho_amd.ngnn import IndexEmbedding
+    torch.manual_seed(0)
+    idx = torch.randint(0, 16, (50_000,), device=dev)
+    e1, e2 = IndexEmbedding(16, 32).to(dev), torch.nn.Embedding(16, 32).to(dev)
+    e2.load_state_dict(e1.state_dict())
+    w = torch.randn(50_000, 32, device=dev)
+    (e1(idx) * w).sum().backward()
+    (e2(idx) * w).sum().backward()
+    assert torch.equal(e1(idx), e2(idx))
+    torch.testing.assert_close(e1.weight.grad, e2.weight.grad, rtol=1e-4, atol=1e-3)
+    l1, l2 = Linear(64, 48).to(dev), torch.nn.Linear(64, 48).to(dev)
+    l2.load_state_dict(l1.state_dict())
+    x1 = torch.randn(40_000, 64, device=dev, requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    g = torch.randn(40_000, 48, device=dev)
+    (l1(x1) * g).sum().backward()
+    (l2(x2) * g).sum().backward()
+    torch.testing.assert_close(l1(x1), l2(x2), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(l1.weight.grad, l2.weight.grad, rtol=1e-3, atol=2e-2)
+    torch.testing.assert_close(l1.bias.grad, l2.bias.grad, rtol=1e-3, atol=1e-2)
