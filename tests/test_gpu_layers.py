@@ -83,6 +83,3 @@ def test_dense_ngnn_matches_reference_on_valid_entries(dev):
     _check(layer, g, "ngnn_dd", MaskedTensor(T(g["dd_A"], dev), Am), lambda xv: MaskedTensor(xv, Xm), T(g["dd_X"], dev), {}, dev,
            valid=g["dd_Xmask"][..., None].astype(np.float32))
 
-
-def test_key_plumbing_matches_reference():
-    pass
