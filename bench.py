@@ -176,6 +176,16 @@ def main():
         achieved = nbytes / (ms * 1e-3) / 1e9
         es = 2 if act_dtype is not None else 4
         fwd_bytes = es * args.hidden * (2 * hb.num_tuples + hb.num_edges) + 8 * hb.num_messages(KEY) + 4 * (hb.num_tuples + 1)
+        # HBM traffic of the dominant kernel: collected OUTSIDE this process in separate rocprofv3 --pmc passes of
+        # this very command (FETCH_SIZE corrected by the calibrated gfx950 factor, WRITE_SIZE as is) and committed
+        # under profiles/; reported only when the configuration matches, otherwise null.
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "r01_final_traffic.json")))
+            if tj["config"] == {"graphs_per_gpu": hb.num_graphs, "hidden": args.hidden, "dtype": args.dtype}:
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         line = {
             "metric": "graphs/sec, ZINC-shape NGNN train step (+ 2-tuple msg-edges/sec and HBM roofline fraction of the spspmm kernel)",
             "value": total_graphs * args.steps / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
@@ -189,7 +199,7 @@ def main():
             "msg_edges_per_sec_train": total_msgs * args.layers * args.steps / elapsed,
             "msg_edges_per_sec_kernel": hb.num_messages(KEY) / (ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "seg_gmr_fast_kernel<bf16,SUM,BOTH>"
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "seg_gmr_fast_kernel<bf16,SUM,BOTH>"
                          if act_dtype is not None else "seg_gmr_fast_kernel<float,SUM,BOTH>",
                          "launches": launches, "avg_ms": ms, "algorithmic_bytes_per_launch": nbytes,
                          "forward_bytes_per_msg_edge": fwd_bytes / hb.num_messages(KEY)},
