@@ -428,6 +428,28 @@ def gen_layers():
     out.update(dd_X=dn["X"], dd_A=dn["A"], dd_Xmask=dn["Xmask"], dd_Amask=dn["Amask"])
     torch.manual_seed(5)
     run(RefConv.NGNNConv(h, h, "sum", "DD", dict(mlp)), "ngnn_dd", Xd, MaskedTensor(Ad, Am), {}, lambda xv: MaskedTensor(xv, Xm))
+    # the remaining shipped sparse layers that do not touch torch_geometric (Conv.py:151-297)
+    keys2 = ("X___X___1___A___0", "X___X___1___X___0")
+    hbp = synth.make_batch(3, "zinc", seed=44, keys=keys2)
+    Np = hbp.num_nodes
+    eip, tidp = T(hbp.edge_index), T(hbp.tupleid)
+    Avp = torch.randn((hbp.num_edges, h), generator=g)
+    Xvp = torch.randn((hbp.num_tuples, h), generator=g) * 0.5
+    out.update(Np=np.int64(Np), edge_indexp=hbp.edge_index, tupleidp=hbp.tupleid, Avp=Avp.numpy(), Xvp=Xvp.numpy())
+    ddp = {}
+    for k in keys2:
+        out["acdp_" + k] = hbp.acd[k]
+        ddp[k + "___acd"] = T(hbp.acd[k])
+    Ap = SparseTensor(eip, Avp, [Np, Np, h], True)
+    mkp = lambda xv: SparseTensor(tidp, xv, [Np, Np, h], True)
+    torch.manual_seed(6)
+    run(RefConv.PPGNConv(h, h, "sum", "SS", dict(mlp)), "ppgn", Xvp, Ap, ddp, mkp)
+    torch.manual_seed(7)
+    run(RefConv.GNNAKConv(h, h, "sum", "mean", "SS", dict(mlp), dict(mlp)), "gnnak", Xvp, Ap, ddp, mkp)
+    torch.manual_seed(8)
+    # DSSGNN's global branch multiplies edge values with node features: scalar adjacency values (reference Spmm.py:40)
+    Asc = SparseTensor(eip, None, [Np, Np], True)
+    run(RefConv.DSSGNNConv(h, h, "sum", "sum", "mean", "SS", dict(mlp)), "dssgnn", Xvp, Asc, ddp, mkp)
     # operator-level key plumbing (honn/SpOperator.py:135, 15-44)
     model = torch.nn.ModuleList([RefConv.NGNNConv(h, h, "sum", "SS", dict(mlp)), RefConv.SSWLConv(h, h, "sum", "SS", dict(mlp)),
                                  RefConv.I2Conv(h, h, "sum", "SS", dict(mlp)), RefConv.PPGNConv(h, h, "sum", "SS", dict(mlp))])

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""
+Operator-level micro-benchmarks for the other BASELINE.json configs (not the headline line of bench.py):
+  config 2  spspmm forward, ZINC-shape 2-tuples, d=128 (bf16 / f32)
+  config 5  spspmm forward, I2-shape 3-tuples, d=256 bf16
+  config 3  masked batched einsum mamamm(X,2,A,1) on the MFMA kernel, (b, 37, 37, 128) bf16 / f32, and its backward
+Each line: median kernel time (HIP events), algorithmic bytes, GB/s and fraction of the 8 TB/s HBM peak.
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pygho_amd import _ops, synth  # noqa: E402
+
+PEAK = 8000.0
+
+
+def timed(fn, reps=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in ev:
+        e0.record()
+        fn()
+        e1.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    return ts[len(ts) // 2]
+
+
+def spspmm_case(kind, graphs, d, dtype, dev):
+    base = 1024 if kind == "zinc" else 128
+    key = "X___X___1___A___0" if kind == "zinc" else "X___X___2___A___0"
+    hb = synth.replicate(synth.make_batch(min(graphs, base), kind, seed=1), max(1, graphs // base))
+    acd = torch.from_numpy(hb.acd[key]).to(dev)
+    nt, ne, m = hb.num_tuples, hb.num_edges, acd.shape[1]
+    X = torch.randn(nt, d, device=dev).to(dtype)
+    A = torch.randn(ne, d, device=dev).to(dtype)
+    plan = _ops.message_plan(acd, nt, nt, ne)
+    ms = timed(lambda: _ops.seg_gmr(nt, X, A, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, "sum"))
+    nbytes = X.element_size() * d * (2 * nt + ne) + 8 * m + 4 * (nt + 1)
+    return {"op": f"spspmm fwd {kind}", "graphs": hb.num_graphs, "d": d, "dtype": str(dtype).split(".")[-1], "msg_edges": m,
+            "ms": ms, "alg_MB": nbytes / 1e6, "GBps": nbytes / ms / 1e6, "frac_hbm": nbytes / ms / 1e6 / PEAK,
+            "G_msg_edges_per_s": m / ms / 1e6}
+
+
+def mamamm_case(b, n, d, dtype, dev):
+    from pygho_amd import MaskedTensor
+    from pygho_amd.backend.Mamamm import mamamm
+    dn = synth.make_dense_batch(min(b, 256), seed=2, hidden=d, nmax=n)
+    rep = max(1, b // min(b, 256))
+    t = lambda a, dt=None: torch.from_numpy(a).to(dev).repeat((rep,) + (1,) * (a.ndim - 1)).to(dt) if dt else torch.from_numpy(a).to(dev).repeat((rep,) + (1,) * (a.ndim - 1))
+    X = MaskedTensor(t(dn["X"], dtype), t(dn["Xmask"]), 0.0, True)
+    A = MaskedTensor(t(dn["A"], dtype), t(dn["Amask"]), 0.0, True)
+    ms = timed(lambda: mamamm(X, 2, A, 1, X.mask))
+    bb = X.shape[0]
+    es = X.raw.element_size()
+    nbytes = 3 * bb * n * n * d * es + bb * n * n
+    flops = 2 * bb * d * n ** 3
+    Xg = MaskedTensor(X.raw.clone().requires_grad_(True), X.mask, 0.0, True)
+    Ag = MaskedTensor(A.raw.clone().requires_grad_(True), A.mask, 0.0, True)
+    out = mamamm(Xg, 2, Ag, 1, X.mask).data
+    g = torch.randn_like(out)
+    msb = timed(lambda: torch.autograd.grad(out, (Xg.raw, Ag.raw), g, retain_graph=True), reps=10)
+    return {"op": "mamamm(X,2,A,1) fwd", "b": bb, "n": n, "d": d, "dtype": str(dtype).split(".")[-1], "ms": ms, "alg_MB": nbytes / 1e6,
+            "GBps": nbytes / ms / 1e6, "frac_hbm": nbytes / ms / 1e6 / PEAK, "TFLOPs": flops / ms / 1e9, "bwd_ms": msb}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    out = []
+    out.append(spspmm_case("zinc", 1024 if args.quick else 8192, 128, torch.bfloat16, dev))
+    out.append(spspmm_case("zinc", 1024 if args.quick else 8192, 128, torch.float32, dev))
+    out.append(spspmm_case("zinc", 128, 128, torch.bfloat16, dev))
+    out.append(spspmm_case("i2", 256 if args.quick else 2048, 256, torch.bfloat16, dev))
+    out.append(mamamm_case(128, 37, 128, torch.bfloat16, dev))
+    out.append(mamamm_case(128 if args.quick else 1024, 37, 128, torch.bfloat16, dev))
+    out.append(mamamm_case(128 if args.quick else 1024, 37, 128, torch.float32, dev))
+    for r in out:
+        print(json.dumps(r))
+
+
+if __name__ == "__main__":
+    main()
