@@ -83,7 +83,13 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
   char* obase = reinterpret_cast<char*>(out);
   const bool has_li = lhs_idx != nullptr, has_ri = rhs_idx != nullptr;
   const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
-  const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + wv;
+  // XCD-aware sweep: workgroup b runs on XCD b % 8 (observed dispatch order).  Remap so that the workgroups of
+  // ONE XCD cover a contiguous stretch of segments in every sweep step: the ~4 workgroups that share the edge
+  // rows of one graph then hit in one L2 instead of fetching them into four (measured: edge rows were read
+  // 4.5x from HBM with the plain order).
+  int64_t lb = blockIdx.x;
+  if ((gridDim.x & 7) == 0) lb = (lb & 7) * (gridDim.x >> 3) + (lb >> 3);
+  const int64_t wave = lb * (kBlock / kWave) + wv;
 
   // spp = segments per wave and pass (<= kSegsPerPass): small when there are few segments so that they
   // still spread over the whole chip (a lane group walks its segments sequentially)
@@ -291,7 +297,8 @@ int launch_fast_off(void* out, const void* lhs, const void* rhs, const int32_t* 
   int log2g = 0;
   while ((1 << log2g) < chunks && log2g < 6) ++log2g;
   const int spp = segs_per_pass(n_seg, log2g);
-  const int gx = grid_for(n_seg, (kBlock / kWave) * spp);
+  int gx = grid_for(n_seg, (kBlock / kWave) * spp);
+  if (gx > 8) gx = (gx + 7) & ~7;      // multiple of 8: the XCD remap is a bijection
   dim3 grid(gx, (unsigned)ceil_div(chunks, kWave));
 #define PYGHO_LAUNCH(MODE, SC)                                                                                          \
   hipLaunchKernelGGL((seg_gmr_fast_kernel<T, AGGR, MODE, SC, OFF32>), grid, dim3(kBlock), 0, st, (T*)out, (const T*)lhs, \
@@ -460,7 +467,9 @@ extern "C" int pygho_seg_sum_f32out(float* out, const void* src, const int32_t* 
   int log2g = 0;
   while ((1 << log2g) < chunks && log2g < 6) ++log2g;
   const int spp = segs_per_pass(n_seg, log2g);
-  dim3 grid(grid_for(n_seg, (kBlock / kWave) * spp), (unsigned)ceil_div(chunks, kWave));
+  int gx = grid_for(n_seg, (kBlock / kWave) * spp);
+  if (gx > 8) gx = (gx + 7) & ~7;
+  dim3 grid(gx, (unsigned)ceil_div(chunks, kWave));
   const bool off32 = src_rows > 0 && src_rows * d * 2 < ((int64_t)1 << 32);
 #define PYGHO_L(T, O32)                                                                                                 \
   hipLaunchKernelGGL((seg_gmr_fast_kernel<T, PYGHO_SUM, MODE_LHS, false, O32, true>), grid, dim3(kBlock), 0, st, (T*)out, \
