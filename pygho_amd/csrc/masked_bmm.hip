@@ -39,9 +39,9 @@ struct BmmArgs {
   const uint8_t* amask;
   const uint8_t* bmask;
   const uint8_t* omask;
-  int64_t ni, nk, nj, d;
+  int ni, nk, nj, d;
   // position strides (in positions; multiply by d for elements)
-  int64_t a_si, a_sk, b_sj, b_sk;
+  int a_si, a_sk, b_sj, b_sk;
   int n_itiles, n_jtiles, n_chunks;
 };
 
@@ -60,49 +60,76 @@ __host__ __device__ inline int bmm_pitch(int kvalid, int elem_size) {
   return kp + 2;
 }
 
-// stage rows x kblk positions of one operand into per-channel planes plane[c][row][k]
+// Staging of one operand's (rows x k-block) positions into per-channel planes plane[c][row][k].
+// The item space is FIXED (kTile rows x kKBlock/KG k-groups, invalid items predicated off) so that the
+// item -> (row, k-group) map needs no runtime division, and every address is a 32-bit offset from a
+// per-workgroup scalar base (one batch element is far below 4 GiB): the first version spent 2300 VALU
+// instructions per wavefront on index arithmetic around 36 MFMAs.
+//   stage_load  : 16-B global loads (the CH channels of one position) of KG consecutive k into registers
+//   stage_write : registers byte-permuted into per-channel k-contiguous 8-B words and written to LDS
+template <typename T> struct StageRegs {
+  static constexpr int KG = BmmTraits<T>::KG;
+  static constexpr int KGROUPS = kKBlock / KG;
+  static constexpr int ITEMS = (kTile * KGROUPS + kBlock - 1) / kBlock;   // items per thread
+  uint4 v[KG];
+};
+
 template <typename T>
-__device__ __forceinline__ void stage_operand(char* lds, const T* __restrict__ g, const uint8_t* __restrict__ mask,
-                                              int64_t base_pos, int64_t s_row, int64_t s_k, int64_t d, int c0,
-                                              int row0, int rows, int64_t nrows_total, int k0, int kvalid, int64_t nk,
-                                              int kp) {
+__device__ __forceinline__ void item_coords(int it, bool k_fast, int& r, int& g4) {
+  constexpr int KGROUPS = StageRegs<T>::KGROUPS;
+  if (k_fast) { r = it / KGROUPS; g4 = it % KGROUPS; } else { g4 = it / kTile; r = it % kTile; }
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_load(StageRegs<T>& regs, int it, const char* __restrict__ gbase,
+                                           const uint8_t* __restrict__ mbase, bool k_fast, uint32_t s_row_b,
+                                           uint32_t s_k_b, uint32_t s_row_p, uint32_t s_k_p, int row0, int rows, int k0,
+                                           int nk) {
+  constexpr int KG = BmmTraits<T>::KG;
+  int r, g4;
+  item_coords<T>(it, k_fast, r, g4);
+#pragma unroll
+  for (int kk = 0; kk < KG; ++kk) {
+    const int k = k0 + g4 * KG + kk;
+    regs.v[kk] = make_uint4(0, 0, 0, 0);
+    if (r < rows && k < nk) {
+      const uint32_t row = (uint32_t)(row0 + r);
+      bool ok = true;
+      if (mbase) ok = mbase[row * s_row_p + (uint32_t)k * s_k_p] != 0;
+      if (ok) regs.v[kk] = *reinterpret_cast<const uint4*>(gbase + (row * s_row_b + (uint32_t)k * s_k_b));
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_write(char* lds, const StageRegs<T>& regs, int it, bool k_fast, int rows, int kround,
+                                            int kp) {
   using TR = BmmTraits<T>;
   constexpr int CH = TR::CH, KG = TR::KG;
-  const int kgroups = ((kvalid + (TR::KSTEP >= 8 ? 7 : 3)) & ~(TR::KSTEP >= 8 ? 7 : 3)) / KG;
-  const int items = rows * kgroups;
-  const bool k_fast = s_k < s_row;     // which position axis is contiguous in memory
-  for (int it = threadIdx.x; it < items; it += kBlock) {
-    int r, g4;
-    if (k_fast) { r = it / kgroups; g4 = it - r * kgroups; } else { g4 = it / rows; r = it - g4 * rows; }
-    uint4 v[KG];
+  int r, g4;
+  item_coords<T>(it, k_fast, r, g4);
+  const int koff = g4 * KG;
+  if (r >= rows || koff >= kround) return;
+  const uint4* v = regs.v;
+  if constexpr (sizeof(T) == 2) {
+    // 4 k x 8 channels of 16-bit -> per channel one 8-byte word (k..k+3)
+    const uint32_t w[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
+                              {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
+    char* dst = lds + (uint32_t)(r * kp + koff) * 2u;
+    const uint32_t plane = (uint32_t)(rows * kp) * 2u;
 #pragma unroll
-    for (int kk = 0; kk < KG; ++kk) {
-      const int64_t k = (int64_t)k0 + g4 * KG + kk;
-      const int64_t row = (int64_t)row0 + r;
-      v[kk] = make_uint4(0, 0, 0, 0);
-      if (k < nk && row < nrows_total) {
-        const int64_t pos = base_pos + row * s_row + k * s_k;
-        if (!mask || mask[pos]) v[kk] = *reinterpret_cast<const uint4*>(g + pos * d + c0);
-      }
+    for (int c = 0; c < CH; ++c) {
+      const uint32_t sel = (c & 1) ? 0x7632u : 0x5410u;
+      const uint32_t lo = __byte_perm(w[0][c >> 1], w[1][c >> 1], sel);
+      const uint32_t hi = __byte_perm(w[2][c >> 1], w[3][c >> 1], sel);
+      *reinterpret_cast<uint2*>(dst + c * plane) = make_uint2(lo, hi);
     }
-    const int koff = g4 * KG;
-    if constexpr (sizeof(T) == 2) {
-      // 4 k x 8 channels of 16-bit -> per channel one 8-byte word (k..k+3)
-      const uint32_t w[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
-                                {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
+  } else {
+    const uint32_t w[2][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w}};
+    char* dst = lds + (uint32_t)(r * kp + koff) * 4u;
+    const uint32_t plane = (uint32_t)(rows * kp) * 4u;
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const uint32_t sel = (c & 1) ? 0x7632u : 0x5410u;
-        const uint32_t lo = __byte_perm(w[0][c >> 1], w[1][c >> 1], sel);
-        const uint32_t hi = __byte_perm(w[2][c >> 1], w[3][c >> 1], sel);
-        *reinterpret_cast<uint2*>(lds + ((size_t)(c * rows + r) * kp + koff) * 2) = make_uint2(lo, hi);
-      }
-    } else {
-      const uint32_t w[2][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w}};
-#pragma unroll
-      for (int c = 0; c < CH; ++c)
-        *reinterpret_cast<uint2*>(lds + ((size_t)(c * rows + r) * kp + koff) * 4) = make_uint2(w[0][c], w[1][c]);
-    }
+    for (int c = 0; c < CH; ++c) *reinterpret_cast<uint2*>(dst + c * plane) = make_uint2(w[0][c], w[1][c]);
   }
 }
 
@@ -124,10 +151,10 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
   const int64_t b = rest / (p.n_itiles * p.n_jtiles);
   const int it = tile / p.n_jtiles, jt = tile - it * p.n_jtiles;
   const int i0 = it * kTile, j0 = jt * kTile;
-  const int rows_i = (int)min((int64_t)kTile, p.ni - i0), rows_j = (int)min((int64_t)kTile, p.nj - j0);
+  const int rows_i = min(kTile, p.ni - i0), rows_j = min(kTile, p.nj - j0);
   const int c0 = chunk * CH;
   const int nti = (rows_i + 15) >> 4, ntj = (rows_j + 15) >> 4;
-  const int kmax = (int)min((int64_t)kKBlock, p.nk);
+  const int kmax = min(kKBlock, p.nk);
   const int kp = bmm_pitch(kmax, sizeof(T));
   char* ldsA = smem;
   char* ldsB = smem + (size_t)CH * rows_i * kp * sizeof(T);
@@ -140,12 +167,30 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
 #pragma unroll
       for (int u = 0; u < 3; ++u) acc[c][t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int64_t a_base = b * p.ni * p.nk, b_base = b * p.nk * p.nj;
+  const int64_t a_base = b * (int64_t)p.ni * p.nk, b_base = b * (int64_t)p.nk * p.nj;
   for (int k0 = 0; k0 < p.nk; k0 += kKBlock) {
-    const int kvalid = (int)min((int64_t)kKBlock, p.nk - k0);
+    const int kvalid = min(kKBlock, p.nk - k0);
     if (k0 > 0) __syncthreads();
-    stage_operand<T>(ldsA, (const T*)p.A, p.amask, a_base, p.a_si, p.a_sk, p.d, c0, i0, rows_i, p.ni, k0, kvalid, p.nk, kp);
-    stage_operand<T>(ldsB, (const T*)p.B, p.bmask, b_base, p.b_sj, p.b_sk, p.d, c0, j0, rows_j, p.nj, k0, kvalid, p.nk, kp);
+    {
+      const int kround = (kvalid + (TR::KSTEP >= 8 ? 7 : 3)) & ~(TR::KSTEP >= 8 ? 7 : 3);
+      const uint32_t es = sizeof(T), db = (uint32_t)p.d * es;
+      const char* abase = reinterpret_cast<const char*>(p.A) + ((a_base * p.d + c0) * (int64_t)es);
+      const char* bbase = reinterpret_cast<const char*>(p.B) + ((b_base * p.d + c0) * (int64_t)es);
+      const uint8_t* amb = p.amask ? p.amask + a_base : nullptr;
+      const uint8_t* bmb = p.bmask ? p.bmask + b_base : nullptr;
+      const bool a_kfast = p.a_sk < p.a_si, b_kfast = p.b_sk < p.b_sj;
+#pragma unroll
+      for (int t = 0; t < StageRegs<T>::ITEMS; ++t) {
+        const int item = threadIdx.x + t * kBlock;
+        StageRegs<T> ra, rb;
+        stage_load<T>(ra, item, abase, amb, a_kfast, (uint32_t)p.a_si * db, (uint32_t)p.a_sk * db, (uint32_t)p.a_si,
+                      (uint32_t)p.a_sk, i0, rows_i, k0, (int)p.nk);
+        stage_load<T>(rb, item, bbase, bmb, b_kfast, (uint32_t)p.b_sj * db, (uint32_t)p.b_sk * db, (uint32_t)p.b_sj,
+                      (uint32_t)p.b_sk, j0, rows_j, k0, (int)p.nk);
+        stage_write<T>(ldsA, ra, item, a_kfast, rows_i, kround, kp);
+        stage_write<T>(ldsB, rb, item, b_kfast, rows_j, kround, kp);
+      }
+    }
     __syncthreads();
     const int r16 = lane & 15, q = lane >> 4;
     if constexpr (sizeof(T) == 2) {
@@ -156,30 +201,30 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
           const int ch = wave * CW + c;
+          // all 3 x 3 tiles are always issued (MFMA time is negligible here); rows / k beyond the tile are
+          // read from a clamped address and zeroed by a select, so the loop has no divergent control flow
           uint4 fa[3], fb[3];
+          const int kc = kok ? kk : 0;
 #pragma unroll
           for (int t = 0; t < 3; ++t) {
             const int row = t * 16 + r16;
-            fa[t] = make_uint4(0, 0, 0, 0);
-            if (t < nti && kok && row < rows_i)
-              fa[t] = *reinterpret_cast<const uint4*>(ldsA + ((size_t)(ch * rows_i + row) * kp + kk) * 2);
-            const int col = t * 16 + r16;
-            fb[t] = make_uint4(0, 0, 0, 0);
-            if (t < ntj && kok && col < rows_j)
-              fb[t] = *reinterpret_cast<const uint4*>(ldsB + ((size_t)(ch * rows_j + col) * kp + kk) * 2);
+            const uint4 va = *reinterpret_cast<const uint4*>(ldsA + ((uint32_t)(ch * rows_i + min(row, rows_i - 1)) * kp + kc) * 2u);
+            const uint4 vb = *reinterpret_cast<const uint4*>(ldsB + ((uint32_t)(ch * rows_j + min(row, rows_j - 1)) * kp + kc) * 2u);
+            const bool oka = kok && row < rows_i, okb = kok && row < rows_j;
+            fa[t] = make_uint4(oka ? va.x : 0u, oka ? va.y : 0u, oka ? va.z : 0u, oka ? va.w : 0u);
+            fb[t] = make_uint4(okb ? vb.x : 0u, okb ? vb.y : 0u, okb ? vb.z : 0u, okb ? vb.w : 0u);
           }
 #pragma unroll
           for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int u = 0; u < 3; ++u)
-              if (t < nti && u < ntj) {
-                if constexpr (std::is_same<T, bf16>::value)
-                  acc[c][t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[t]),
-                                                                         __builtin_bit_cast(bf16x8_t, fb[u]), acc[c][t][u], 0, 0, 0);
-                else
-                  acc[c][t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fa[t]),
-                                                                        __builtin_bit_cast(f16x8_t, fb[u]), acc[c][t][u], 0, 0, 0);
-              }
+            for (int u = 0; u < 3; ++u) {
+              if constexpr (std::is_same<T, bf16>::value)
+                acc[c][t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[t]),
+                                                                       __builtin_bit_cast(bf16x8_t, fb[u]), acc[c][t][u], 0, 0, 0);
+              else
+                acc[c][t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fa[t]),
+                                                                      __builtin_bit_cast(f16x8_t, fb[u]), acc[c][t][u], 0, 0, 0);
+            }
         }
       }
     } else {
@@ -191,14 +236,15 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
           const int row = t * 16 + r16;
-          fa[t] = (t < nti && row < rows_i) ? *reinterpret_cast<const float*>(ldsA + ((size_t)(ch * rows_i + row) * kp + kk) * 4) : 0.f;
-          fb[t] = (t < ntj && row < rows_j) ? *reinterpret_cast<const float*>(ldsB + ((size_t)(ch * rows_j + row) * kp + kk) * 4) : 0.f;
+          const float va = *reinterpret_cast<const float*>(ldsA + ((uint32_t)(ch * rows_i + min(row, rows_i - 1)) * kp + kk) * 4u);
+          const float vb = *reinterpret_cast<const float*>(ldsB + ((uint32_t)(ch * rows_j + min(row, rows_j - 1)) * kp + kk) * 4u);
+          fa[t] = row < rows_i ? va : 0.f;
+          fb[t] = row < rows_j ? vb : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-          for (int u = 0; u < 3; ++u)
-            if (t < nti && u < ntj) acc[0][t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t], fb[u], acc[0][t][u], 0, 0, 0);
+          for (int u = 0; u < 3; ++u) acc[0][t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t], fb[u], acc[0][t][u], 0, 0, 0);
       }
     }
   }
@@ -211,7 +257,6 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
-        if (t >= nti || u >= ntj) continue;
         const int j = u * 16 + colj;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -277,9 +322,13 @@ extern "C" int pygho_masked_bmm(void* out, const void* A, const void* B, const u
   if (!out || (nk > 0 && (!A || !B))) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   BmmArgs p;
   p.out = out; p.A = A; p.B = B; p.amask = amask; p.bmask = bmask; p.omask = omask;
-  p.ni = ni; p.nk = nk; p.nj = nj; p.d = d;
-  if (a_kfirst) { p.a_sk = ni; p.a_si = 1; } else { p.a_si = nk; p.a_sk = 1; }     // A stored (nk, ni) or (ni, nk)
-  if (b_kfirst) { p.b_sk = nj; p.b_sj = 1; } else { p.b_sj = nk; p.b_sk = 1; }     // B stored (nk, nj) or (nj, nk)
+  if (ni > INT32_MAX / 4 || nk > INT32_MAX / 4 || nj > INT32_MAX / 4 || d > 65536 || ni * nk * d > INT32_MAX / 8 || nk * nj * d > INT32_MAX / 8) {
+    set_error("masked_bmm: one batch element must stay below 2^28 elements");
+    return PYGHO_ERR_UNSUPPORTED;
+  }
+  p.ni = (int)ni; p.nk = (int)nk; p.nj = (int)nj; p.d = (int)d;
+  if (a_kfirst) { p.a_sk = (int)ni; p.a_si = 1; } else { p.a_si = (int)nk; p.a_sk = 1; }     // A stored (nk, ni) or (ni, nk)
+  if (b_kfirst) { p.b_sk = (int)nj; p.b_sj = 1; } else { p.b_sj = (int)nk; p.b_sk = 1; }     // B stored (nk, nj) or (nj, nk)
   p.n_itiles = (int)ceil_div(ni, kTile);
   p.n_jtiles = (int)ceil_div(nj, kTile);
   hipStream_t st = (hipStream_t)stream;
