@@ -227,6 +227,29 @@ int pygho_masked_reduce_bwd(void* gdata, const void* gout, const void* data, con
 int pygho_masked_broadcast(void* out, const void* src, const uint8_t* mask, double value,
                            int64_t outer, int64_t r, int64_t inner, int64_t d, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Dense neighbours of the aggregation
+ * ---------------------------------------------------------------------- */
+
+/* Fused BatchNorm1d (+ activation) over (m rows, c channels) row-major activations:
+ *   pygho/honn/utils.py:46-61,126-138 (Linear -> BatchNorm1d -> SiLU/ReLU inside every MLP; called per layer
+ *   through X.tuplewiseapply(self.lin), honn/Conv.py:56).  act: 0 none, 1 relu, 2 silu.
+ * pygho_bn_stats: per-channel mean and BIASED variance of x (two deterministic reduction stages).
+ * pygho_bn_act_fwd: y = act(x * scale + bias) with scale = weight * invstd, bias = bn_bias - mean * scale.
+ * pygho_bn_act_bwd: dx and the per-channel sums sum_dz (= grad of bn bias) and sum_dz_xhat (= grad of bn
+ *   weight); the normalised value is recomputed from x, so the BatchNorm output is never stored.
+ *   training != 0 uses batch statistics in the input gradient, 0 treats mean / invstd as constants (eval).
+ * workspace: pygho_bn_workspace(m, c, dtype) bytes (0 = unsupported geometry: row bytes must be a multiple
+ *   of 16 and the 16-byte chunks per row must divide 256). */
+size_t pygho_bn_workspace(int64_t m, int64_t c, int dtype);
+int pygho_bn_stats(float* mean, float* var, const void* x, int64_t m, int64_t c, void* workspace, int dtype,
+                   void* stream);
+int pygho_bn_act_fwd(void* y, const void* x, const float* scale, const float* bias, int64_t m, int64_t c,
+                     int act, int dtype, void* stream);
+int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy,
+                     const float* mean, const float* invstd, const float* w, const float* b, int64_t m,
+                     int64_t c, int act, int training, void* workspace, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

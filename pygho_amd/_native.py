@@ -53,6 +53,10 @@ PROTOTYPES = {
     "pygho_masked_reduce": (I, [P, P, P, P, L, L, L, L, I, I, P]),
     "pygho_masked_reduce_bwd": (I, [P, P, P, P, P, L, L, L, L, I, I, P]),
     "pygho_masked_broadcast": (I, [P, P, P, D, L, L, L, L, I, P]),
+    "pygho_bn_workspace": (Z, [L, L, I]),
+    "pygho_bn_stats": (I, [P, P, P, L, L, P, I, P]),
+    "pygho_bn_act_fwd": (I, [P, P, P, P, L, L, I, I, P]),
+    "pygho_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, P, I, P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

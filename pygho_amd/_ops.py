@@ -884,3 +884,75 @@ def masked_bmm(A, B, amask, bmask, omask, nb, ni, nk, nj, d, a_kfirst, b_kfirst)
         B = torch.nn.functional.pad(B, (0, pad))
     out = _MaskedBmm.apply(A.contiguous(), B.contiguous(), amask, bmask, omask, (nb, ni, nk, nj, d + pad), a_kfirst, b_kfirst)
     return out[..., :d] if pad else out
+
+
+# --------------------------------------------------------------------------
+# fused BatchNorm + activation (dense neighbour of the aggregation)
+# --------------------------------------------------------------------------
+ACT_CODE = {"none": 0, "relu": 1, "silu": 2}
+
+
+def bn_act_supported(x: Tensor) -> bool:
+    return (x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and x.shape[0] > 1
+            and int(lib().pygho_bn_workspace(x.shape[0], x.shape[1], dtype_code(x))) > 0)
+
+
+class _BNAct(torch.autograd.Function):
+    """y = act(batch_norm(x)); training uses batch statistics (and returns them for the running averages)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act):
+        dev = require_device(x)
+        x = x.contiguous()
+        m, c = x.shape
+        dt = dtype_code(x)
+        st = stream_ptr(dev)
+        nbytes = int(lib().pygho_bn_workspace(m, c, dt))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if training:
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            var = torch.empty(c, dtype=torch.float32, device=dev)
+            check(lib().pygho_bn_stats(ptr(mean), ptr(var), ptr(x), m, c, ptr(ws), dt, st), "bn_stats")
+        else:
+            mean, var = running_mean.float().clone(), running_var.float().clone()
+        invstd = torch.rsqrt(var + eps)
+        w32 = weight.float() if weight is not None else torch.ones(c, dtype=torch.float32, device=dev)
+        b32 = bias.float() if bias is not None else torch.zeros(c, dtype=torch.float32, device=dev)
+        scale = (w32 * invstd).contiguous()
+        shift = (b32 - mean * scale).contiguous()
+        y = torch.empty_like(x)
+        check(lib().pygho_bn_act_fwd(ptr(y), ptr(x), ptr(scale), ptr(shift), m, c, ACT_CODE[act], dt, st), "bn_act_fwd")
+        ctx.save_for_backward(x, mean, invstd, w32, b32)
+        ctx.meta = (training, act, ws, weight is not None, bias is not None)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv):
+        x, mean, invstd, w32, b32 = ctx.saved_tensors
+        training, act, ws, has_w, has_b = ctx.meta
+        gy = gy.contiguous()
+        m, c = x.shape
+        dev = x.device
+        dx = torch.empty_like(x)
+        s1 = torch.empty(c, dtype=torch.float32, device=dev)
+        s2 = torch.empty(c, dtype=torch.float32, device=dev)
+        check(lib().pygho_bn_act_bwd(ptr(dx), ptr(s1), ptr(s2), ptr(x), ptr(gy), ptr(mean), ptr(invstd), ptr(w32), ptr(b32),
+                                     m, c, ACT_CODE[act], 1 if training else 0, ptr(ws), dtype_code(x), stream_ptr(dev)),
+              "bn_act_bwd")
+        return dx, (s2 if has_w else None), (s1 if has_b else None), None, None, None, None, None
+
+
+def batch_norm_act(x: Tensor, bn: "torch.nn.BatchNorm1d", act: str) -> Tensor:
+    """BatchNorm1d(x) followed by `act`, with torch's semantics (batch statistics + running-average update in
+    training mode, running statistics in eval mode)."""
+    training = bn.training or bn.running_mean is None
+    y, mean, var = _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, act)
+    if bn.training and bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            n = x.shape[0]
+            bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var.to(bn.running_var.dtype), alpha=mom * n / max(n - 1, 1))
+    return y

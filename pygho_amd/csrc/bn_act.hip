@@ -1,0 +1,287 @@
+// Fused BatchNorm (+ SiLU / ReLU / identity) over (M rows, C channels) row-major activations -- the dense step
+// that brackets every aggregation in the shipped layers (reference honn/utils.py:126-138: Linear -> BatchNorm1d
+// -> act; honn/Conv.py:56 `X.tuplewiseapply(self.lin)`), SURVEY.md 8 row f3.  HBM-bound streaming:
+//   forward   stats pass (read x) + apply pass (read x, write y)                      = 3 passes of M*C*s
+//   backward  reduce pass (read x, gy) + apply pass (read x, gy, write dx)            = 5 passes
+// against 5 + 8 passes for ATen's batch_norm / silu / their backward kernels (BN output never materialised,
+// recomputed from x in the backward).  Channel sums are reduced without atomics: per-thread f32 partials over a
+// fixed set of channels -> per-workgroup LDS tree -> per-channel double-precision finalisation, so results are
+// run-to-run bit-identical.
+#include "common.h"
+
+namespace pygho {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+
+template <typename T> struct Row16 {                      // 16-B vector <-> N floats
+  static constexpr int N = Vec16<T>::N;
+};
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float z) {
+  if (ACT == ACT_RELU) return z > 0.f ? z : 0.f;
+  if (ACT == ACT_SILU) return z / (1.f + __expf(-z));
+  return z;
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad(float z) {      // d act(z) / dz
+  if (ACT == ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (ACT == ACT_SILU) { const float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
+  return 1.f;
+}
+
+// ---- per-channel shifted sums: ws[blk][0][c] = sum(x - shift), ws[blk][1][c] = sum((x - shift)^2) -------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bn_stats_partial_kernel(float* __restrict__ ws, const T* __restrict__ x,
+                                                                  int64_t m, int c, int chunks) {
+  constexpr int N = Vec16<T>::N;
+  __shared__ float red[2][kBlock][Vec16<T>::N];
+  const int tpr = chunks;                       // threads per row (divides kBlock)
+  const int rows_per_it = kBlock / tpr;
+  const int chunk = threadIdx.x % tpr, rlane = threadIdx.x / tpr;
+  float shift[N], s1[N], s2[N];
+  {
+    float tmp[N];
+    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(x + (int64_t)chunk * N), tmp);     // row 0 as the shift
+#pragma unroll
+    for (int q = 0; q < N; ++q) { shift[q] = tmp[q]; s1[q] = 0.f; s2[q] = 0.f; }
+  }
+  for (int64_t r = (int64_t)blockIdx.x * rows_per_it + rlane; r < m; r += (int64_t)gridDim.x * rows_per_it) {
+    float v[N];
+    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(x + r * c + (int64_t)chunk * N), v);
+#pragma unroll
+    for (int q = 0; q < N; ++q) { const float dlt = v[q] - shift[q]; s1[q] += dlt; s2[q] += dlt * dlt; }
+  }
+#pragma unroll
+  for (int q = 0; q < N; ++q) { red[0][threadIdx.x][q] = s1[q]; red[1][threadIdx.x][q] = s2[q]; }
+  __syncthreads();
+  if (rlane == 0) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      float a = 0.f, b = 0.f;
+      for (int j = 0; j < rows_per_it; ++j) { a += red[0][j * tpr + chunk][q]; b += red[1][j * tpr + chunk][q]; }
+      ws[((int64_t)blockIdx.x * 2 + 0) * c + chunk * N + q] = a;
+      ws[((int64_t)blockIdx.x * 2 + 1) * c + chunk * N + q] = b;
+    }
+  }
+}
+
+// second reduction stage: 64 partial-sum lanes x 4 channels per workgroup, double-precision tree in LDS
+constexpr int kFinParts = 64, kFinCh = 4;
+
+__device__ __forceinline__ void final_sums(double& a, double& b, const float* __restrict__ ws, int c, int nblk, int ch0) {
+  __shared__ double red[2][kFinParts][kFinCh];
+  const int part = threadIdx.x / kFinCh, cl = threadIdx.x % kFinCh;
+  const int ch = ch0 + cl;
+  double sa = 0.0, sb = 0.0;
+  if (ch < c)
+    for (int k = part; k < nblk; k += kFinParts) { sa += ws[((int64_t)k * 2 + 0) * c + ch]; sb += ws[((int64_t)k * 2 + 1) * c + ch]; }
+  red[0][part][cl] = sa; red[1][part][cl] = sb;
+  __syncthreads();
+  for (int s = kFinParts / 2; s > 0; s >>= 1) {
+    if (part < s) { red[0][part][cl] += red[0][part + s][cl]; red[1][part][cl] += red[1][part + s][cl]; }
+    __syncthreads();
+  }
+  a = red[0][0][cl]; b = red[1][0][cl];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kFinParts * kFinCh) void bn_stats_final_kernel(float* __restrict__ mean, float* __restrict__ var,
+                                                                            const float* __restrict__ ws, const T* __restrict__ x,
+                                                                            int64_t m, int c, int nblk) {
+  double a, b;
+  final_sums(a, b, ws, c, nblk, blockIdx.x * kFinCh);
+  const int ch = blockIdx.x * kFinCh + threadIdx.x % kFinCh;
+  if (threadIdx.x >= kFinCh || ch >= c) return;
+  const double shift = (double)load_as_acc<T>(x + ch);
+  const double md = a / (double)m;
+  mean[ch] = (float)(shift + md);
+  const double v = b / (double)m - md * md;
+  var[ch] = (float)(v > 0.0 ? v : 0.0);        // biased variance
+}
+
+// ---- y = act((x - mean) * invstd * w + b) ------------------------------------------------------------------------
+template <typename T, int ACT>
+__global__ __launch_bounds__(kBlock) void bn_act_fwd_kernel(T* __restrict__ y, const T* __restrict__ x,
+                                                            const float* __restrict__ scale, const float* __restrict__ bias,
+                                                            int64_t m, int c, int chunks) {
+  constexpr int N = Vec16<T>::N;
+  const int tpr = chunks, rows_per_it = kBlock / tpr;
+  const int chunk = threadIdx.x % tpr, rlane = threadIdx.x / tpr;
+  float sc[N], bi[N];                          // scale = invstd * w, bias = b - mean * scale
+#pragma unroll
+  for (int q = 0; q < N; ++q) { sc[q] = scale[chunk * N + q]; bi[q] = bias[chunk * N + q]; }
+  for (int64_t r = (int64_t)blockIdx.x * rows_per_it + rlane; r < m; r += (int64_t)gridDim.x * rows_per_it) {
+    float v[N];
+    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(x + r * c + (int64_t)chunk * N), v);
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = act_fwd<ACT>(v[q] * sc[q] + bi[q]);
+    *reinterpret_cast<uint4*>(y + r * c + (int64_t)chunk * N) = Vec16<T>::pack(v);
+  }
+}
+
+// ---- backward reductions: ws[blk][0][c] = sum dz, ws[blk][1][c] = sum dz * xhat ------------------------------------
+template <typename T, int ACT>
+__global__ __launch_bounds__(kBlock) void bn_act_bwd_reduce_kernel(float* __restrict__ ws, const T* __restrict__ x,
+                                                                   const T* __restrict__ gy, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, const float* __restrict__ w,
+                                                                   const float* __restrict__ b, int64_t m, int c, int chunks) {
+  constexpr int N = Vec16<T>::N;
+  __shared__ float red[2][kBlock][Vec16<T>::N];
+  const int tpr = chunks, rows_per_it = kBlock / tpr;
+  const int chunk = threadIdx.x % tpr, rlane = threadIdx.x / tpr;
+  float mu[N], is[N], ww[N], bb[N], s1[N], s2[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    mu[q] = mean[chunk * N + q]; is[q] = invstd[chunk * N + q]; ww[q] = w ? w[chunk * N + q] : 1.f; bb[q] = b ? b[chunk * N + q] : 0.f;
+    s1[q] = 0.f; s2[q] = 0.f;
+  }
+  for (int64_t r = (int64_t)blockIdx.x * rows_per_it + rlane; r < m; r += (int64_t)gridDim.x * rows_per_it) {
+    float v[N], g[N];
+    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(x + r * c + (int64_t)chunk * N), v);
+    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(gy + r * c + (int64_t)chunk * N), g);
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const float xh = (v[q] - mu[q]) * is[q];
+      const float dz = g[q] * act_grad<ACT>(xh * ww[q] + bb[q]);
+      s1[q] += dz; s2[q] += dz * xh;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < N; ++q) { red[0][threadIdx.x][q] = s1[q]; red[1][threadIdx.x][q] = s2[q]; }
+  __syncthreads();
+  if (rlane == 0) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      float a = 0.f, bsum = 0.f;
+      for (int j = 0; j < rows_per_it; ++j) { a += red[0][j * tpr + chunk][q]; bsum += red[1][j * tpr + chunk][q]; }
+      ws[((int64_t)blockIdx.x * 2 + 0) * c + chunk * N + q] = a;
+      ws[((int64_t)blockIdx.x * 2 + 1) * c + chunk * N + q] = bsum;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kFinParts * kFinCh) void bn_bwd_final_kernel(float* __restrict__ sum_dz, float* __restrict__ sum_dz_xhat,
+                                                                          const float* __restrict__ ws, int c, int nblk) {
+  double a, b;
+  final_sums(a, b, ws, c, nblk, blockIdx.x * kFinCh);
+  const int ch = blockIdx.x * kFinCh + threadIdx.x % kFinCh;
+  if (threadIdx.x >= kFinCh || ch >= c) return;
+  sum_dz[ch] = (float)a;
+  sum_dz_xhat[ch] = (float)b;
+}
+
+// ---- dx = w * invstd * (dz - (sum_dz + xhat * sum_dz_xhat) / M)   (training)   |   w * invstd * dz   (eval) -------
+template <typename T, int ACT>
+__global__ __launch_bounds__(kBlock) void bn_act_bwd_kernel(T* __restrict__ dx, const T* __restrict__ x, const T* __restrict__ gy,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            const float* __restrict__ sum_dz, const float* __restrict__ sum_dz_xhat,
+                                                            int64_t m, int c, int chunks, int training) {
+  constexpr int N = Vec16<T>::N;
+  const int tpr = chunks, rows_per_it = kBlock / tpr;
+  const int chunk = threadIdx.x % tpr, rlane = threadIdx.x / tpr;
+  const float inv_m = 1.f / (float)m;
+  float mu[N], is[N], ww[N], bb[N], k1[N], k2[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    mu[q] = mean[chunk * N + q]; is[q] = invstd[chunk * N + q]; ww[q] = w ? w[chunk * N + q] : 1.f; bb[q] = b ? b[chunk * N + q] : 0.f;
+    k1[q] = training ? sum_dz[chunk * N + q] * inv_m : 0.f;
+    k2[q] = training ? sum_dz_xhat[chunk * N + q] * inv_m : 0.f;
+  }
+  for (int64_t r = (int64_t)blockIdx.x * rows_per_it + rlane; r < m; r += (int64_t)gridDim.x * rows_per_it) {
+    float v[N], g[N];
+    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(x + r * c + (int64_t)chunk * N), v);
+    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(gy + r * c + (int64_t)chunk * N), g);
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const float xh = (v[q] - mu[q]) * is[q];
+      const float dz = g[q] * act_grad<ACT>(xh * ww[q] + bb[q]);
+      v[q] = ww[q] * is[q] * (dz - k1[q] - xh * k2[q]);
+    }
+    *reinterpret_cast<uint4*>(dx + r * c + (int64_t)chunk * N) = Vec16<T>::pack(v);
+  }
+}
+
+static int bn_geometry(int64_t m, int64_t c, int dtype, int* chunks, int* grid) {
+  const int es = dtype == PYGHO_F32 ? 4 : 2;
+  if (dtype != PYGHO_F32 && dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("bn_act: unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED; }
+  if ((c * es) % 16 != 0) { set_error("bn_act: channel bytes must be a multiple of 16"); return PYGHO_ERR_UNSUPPORTED; }
+  const int ch = (int)(c * es / 16);
+  if (ch < 1 || ch > kBlock || (kBlock % ch) != 0) { set_error("bn_act: %d 16-byte chunks per row must divide %d", ch, kBlock); return PYGHO_ERR_UNSUPPORTED; }
+  *chunks = ch;
+  const int rows_per_it = kBlock / ch;
+  *grid = grid_for(m, rows_per_it * 8);
+  return PYGHO_OK;
+}
+
+}  // namespace pygho
+
+using namespace pygho;
+
+#define PYGHO_BN_T(dtype, CALL)                                     \
+  switch (dtype) {                                                  \
+    case PYGHO_F32: { using T = float; CALL; break; }               \
+    case PYGHO_BF16: { using T = bf16; CALL; break; }               \
+    default: { using T = f16; CALL; break; }                        \
+  }
+#define PYGHO_BN_ACT(act, CALL)                                     \
+  switch (act) {                                                    \
+    case ACT_NONE: { constexpr int A = ACT_NONE; CALL; break; }     \
+    case ACT_RELU: { constexpr int A = ACT_RELU; CALL; break; }     \
+    case ACT_SILU: { constexpr int A = ACT_SILU; CALL; break; }     \
+    default: set_error("bn_act: unknown activation %d", act); return PYGHO_ERR_INVALID; \
+  }
+
+extern "C" size_t pygho_bn_workspace(int64_t m, int64_t c, int dtype) {
+  int chunks = 0, grid = 0;
+  if (bn_geometry(m, c, dtype, &chunks, &grid) != PYGHO_OK) return 0;
+  return (size_t)grid * 2 * (size_t)c * sizeof(float);
+}
+
+extern "C" int pygho_bn_stats(float* mean, float* var, const void* x, int64_t m, int64_t c, void* workspace, int dtype,
+                              void* stream) {
+  if (m <= 0 || c <= 0) { set_error("bn_stats: empty input"); return PYGHO_ERR_INVALID; }
+  if (!mean || !var || !x || !workspace) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  int chunks, grid;
+  if (int rc = bn_geometry(m, c, dtype, &chunks, &grid)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  PYGHO_BN_T(dtype, {
+    hipLaunchKernelGGL((bn_stats_partial_kernel<T>), dim3(grid), dim3(kBlock), 0, st, (float*)workspace, (const T*)x, m, (int)c, chunks);
+    hipLaunchKernelGGL((bn_stats_final_kernel<T>), dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, st, mean, var,
+                       (const float*)workspace, (const T*)x, m, (int)c, grid);
+  });
+  return check_launch("bn_stats");
+}
+
+extern "C" int pygho_bn_act_fwd(void* y, const void* x, const float* scale, const float* bias, int64_t m, int64_t c, int act,
+                                int dtype, void* stream) {
+  if (m < 0 || c <= 0) { set_error("bad size"); return PYGHO_ERR_INVALID; }
+  if (m == 0) return PYGHO_OK;
+  if (!y || !x || !scale || !bias) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  int chunks, grid;
+  if (int rc = bn_geometry(m, c, dtype, &chunks, &grid)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  PYGHO_BN_T(dtype, PYGHO_BN_ACT(act, hipLaunchKernelGGL((bn_act_fwd_kernel<T, A>), dim3(grid), dim3(kBlock), 0, st, (T*)y,
+                                                         (const T*)x, scale, bias, m, (int)c, chunks)));
+  return check_launch("bn_act_fwd");
+}
+
+extern "C" int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
+                                const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act, int training,
+                                void* workspace, int dtype, void* stream) {
+  if (m <= 0 || c <= 0) { set_error("bn_act_bwd: empty input"); return PYGHO_ERR_INVALID; }
+  if (!dx || !sum_dz || !sum_dz_xhat || !x || !gy || !mean || !invstd || !workspace) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  int chunks, grid;
+  if (int rc = bn_geometry(m, c, dtype, &chunks, &grid)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  PYGHO_BN_T(dtype, PYGHO_BN_ACT(act, {
+    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, A>), dim3(grid), dim3(kBlock), 0, st, (float*)workspace, (const T*)x,
+                       (const T*)gy, mean, invstd, w, b, m, (int)c, chunks);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, st, sum_dz, sum_dz_xhat,
+                       (const float*)workspace, (int)c, grid);
+    hipLaunchKernelGGL((bn_act_bwd_kernel<T, A>), dim3(grid), dim3(kBlock), 0, st, (T*)dx, (const T*)x, (const T*)gy, mean, invstd,
+                       w, b, (const float*)sum_dz, (const float*)sum_dz_xhat, m, (int)c, chunks, training);
+  }));
+  return check_launch("bn_act_bwd");
+}

@@ -10,6 +10,8 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from .. import _ops
+
 
 class _SplitKLinearFn(torch.autograd.Function):
     """y = x W^T + b with the weight gradient computed as a batched split-K product.
@@ -154,4 +156,23 @@ class MLP(nn.Module):
         self.lins = nn.Sequential(*blocks)
 
     def forward(self, x: Tensor):
-        return self.lins(x)
+        if not isinstance(self.lins, nn.Sequential):
+            return self.lins(x)
+        # same module sequence as the reference; [BatchNorm, act] pairs on device tensors run as ONE fused HIP
+        # kernel pair (the BatchNorm output is never materialised), everything else is the stock module
+        mods = list(self.lins)
+        i = 0
+        while i < len(mods):
+            mod = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            act = {nn.SiLU: "silu", nn.ReLU: "relu"}.get(type(nxt)) if nxt is not None else None
+            if type(mod) is BatchNorm and x.is_cuda and x.dim() >= 2:
+                x2 = x.flatten(0, -2) if x.dim() > 2 else x
+                if _ops.bn_act_supported(x2):
+                    y = _ops.batch_norm_act(x2, mod.norm, act or "none")
+                    x = y.reshape(x.shape)
+                    i += 2 if act is not None else 1
+                    continue
+            x = mod(x)
+            i += 1
+        return x

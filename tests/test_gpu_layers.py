@@ -133,3 +133,39 @@ def test_sunconv_sparse_and_dense_agree(dev):
     acd = synth.host_plan_acd(tid, tid, 1, eidx, 0)
     out_ss = ss(As, Xs, {"X___X___1___A___0___acd": T(acd, dev)}).values
     np.testing.assert_allclose(N(out_ss), N(out_dd)[bi, ii, jj], rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["silu", "relu", "none"])
+def test_fused_batchnorm_act_matches_torch(dev, dtype, act):
+    """fused BatchNorm+activation kernels vs torch's batch_norm -> activation in f32 (training and eval mode,
+    input / weight / bias gradients, running statistics)."""
+    from pygho_amd import _ops
+    torch.manual_seed(0)
+    m, c = 20_011, 128
+    x32 = torch.randn(m, c, device=dev) * 1.7 + 0.6
+    x = x32.to(dtype)
+    g = torch.randn(m, c, device=dev).to(dtype)
+    actf = {"silu": torch.nn.functional.silu, "relu": torch.relu, "none": lambda t: t}[act]
+    for training in (True, False):
+        bn1, bn2 = torch.nn.BatchNorm1d(c).to(dev), torch.nn.BatchNorm1d(c).to(dev)
+        with torch.no_grad():
+            bn1.weight.uniform_(0.5, 1.5); bn1.bias.normal_(0, 0.3)
+            bn1.running_mean.normal_(0, 0.2); bn1.running_var.uniform_(0.5, 2.0)
+        bn2.load_state_dict(bn1.state_dict())
+        bn1.train(training); bn2.train(training)
+        xa = x.clone().requires_grad_(True)
+        ya = _ops.batch_norm_act(xa, bn1, act)
+        (ya.float() * g.float()).sum().backward()
+        xb = x.float().clone().requires_grad_(True)
+        yb = actf(bn2(xb))
+        (yb * g.float()).sum().backward()
+        tol = 2e-5 if dtype == torch.float32 else 2.0 ** -7
+        torch.testing.assert_close(ya.float(), yb, rtol=tol, atol=tol)
+        gtol = 1e-4 if dtype == torch.float32 else 3e-2
+        torch.testing.assert_close(xa.grad.float(), xb.grad, rtol=gtol, atol=gtol)
+        torch.testing.assert_close(bn1.weight.grad, bn2.weight.grad, rtol=1e-3 if dtype == torch.float32 else 2e-2, atol=0.5 if dtype != torch.float32 else 1e-2)
+        torch.testing.assert_close(bn1.bias.grad, bn2.bias.grad, rtol=1e-3 if dtype == torch.float32 else 2e-2, atol=0.5 if dtype != torch.float32 else 1e-2)
+        torch.testing.assert_close(bn1.running_mean, bn2.running_mean, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(bn1.running_var, bn2.running_var, rtol=1e-4, atol=1e-4)
+        assert int(bn1.num_batches_tracked) == int(bn2.num_batches_tracked)
