@@ -34,12 +34,13 @@ class FlatGradSync:
 
     def sync(self) -> None:
         """average the flat gradient over all ranks (one collective)."""
-        if self.world > 1:
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(self.world)
+            if self.world > 1:
+                self.flat.div_(self.world)
 
     def broadcast_params(self, src: int = 0) -> None:
-        if self.world > 1:
+        if dist.is_available() and dist.is_initialized():
             for p in self.params:
                 dist.broadcast(p.data, src=src, group=self.group)
 
