@@ -47,9 +47,20 @@ class HeteroLinear(Module):
         return out
 
 
+def _views(mode: str, pool: str):
+    """the parameter-free pooling / broadcast operators a layer needs for representation layout mode[1]"""
+    layout = mode[1]
+    return {
+        "diag": TensorOp.OpDiag2D(layout),
+        "pool_subg": TensorOp.OpPoolingSubg2D(layout, pool),          # over the nodes of a subgraph
+        "pool_node": TensorOp.OpPoolingCrossSubg2D(layout, pool),     # over the subgraphs a node appears in
+        "to_subg_nodes": TensorOp.OpUnpoolingSubgNodes2D(layout),
+        "to_root": TensorOp.OpUnpoolingRootNodes2D(layout),
+    }
+
+
 class NGNNConv(Module):
-    """nested GNN layer: MLP on every tuple, then message passing inside each subgraph
-    (reference Conv.py:20-58)."""
+    """nested GNN layer (reference Conv.py:20-58): tuple-wise MLP, then message passing inside each subgraph."""
 
     def __init__(self, indim: int, outdim: int, aggr: str = "sum", mode: Literal["SD", "DD", "SS"] = "SS",
                  mlp: dict = {}, optuplefeat: str = "X", opadj: str = "A", message_func: Optional[Callable] = None):
@@ -58,12 +69,12 @@ class NGNNConv(Module):
         self.lin = MLP(indim, outdim, **mlp)
 
     def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
-        tX = X.tuplewiseapply(self.lin)
-        return self.aggr.forward(A, tX, datadict, tX)
+        H = X.tuplewiseapply(self.lin)
+        return self.aggr.forward(A, H, datadict, H)
 
 
 class SSWLConv(Module):
-    """subgraph-WL layer: in-subgraph and cross-subgraph aggregation, concatenated (reference Conv.py:62-103)."""
+    """subgraph-WL layer (reference Conv.py:62-103): [X, X A (in-subgraph), A X (cross-subgraph)] -> MLP."""
 
     def __init__(self, indim: int, outdim: int, aggr: str = "sum", mode: Literal["SD", "DD", "SS"] = "SS",
                  mlp: dict = {}, optuplefeat: str = "X", opadj: str = "A"):
@@ -73,9 +84,8 @@ class SSWLConv(Module):
         self.lin = MLP(3 * indim, outdim, **mlp)
 
     def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
-        X1 = self.aggr1.forward(A, X, datadict, X)
-        X2 = self.aggr2.forward(A, X, datadict, X)
-        return X.catvalue([X1, X2], True).tuplewiseapply(self.lin)
+        neighbours = [op.forward(A, X, datadict, X) for op in (self.aggr1, self.aggr2)]
+        return X.catvalue(neighbours, True).tuplewiseapply(self.lin)
 
 
 class I2Conv(Module):
@@ -88,13 +98,13 @@ class I2Conv(Module):
         self.lin = MLP(indim, outdim, **mlp)
 
     def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
-        tX = X.tuplewiseapply(self.lin)
-        return self.aggr.forward(A, tX, datadict, tX)
+        H = X.tuplewiseapply(self.lin)
+        return self.aggr.forward(A, H, datadict, H)
 
 
 class DSSGNNConv(Module):
-    """DSS-GNN layer: subgraph aggregation plus a global (cross-subgraph pooled) aggregation
-    (reference Conv.py:151-196)."""
+    """DSS-GNN layer (reference Conv.py:151-196): in-subgraph aggregation next to a global aggregation of the
+    cross-subgraph pooled node features, broadcast back to the roots."""
 
     def __init__(self, indim: int, outdim: int, aggr_subg: str = "sum", aggr_global: str = "sum", pool: str = "mean",
                  mode: Literal["SD", "DD", "SS"] = "SS", mlp: dict = {}, optuplefeat: str = "X", opadj: str = "A"):
@@ -106,13 +116,14 @@ class DSSGNNConv(Module):
         self.lin = MLP(2 * indim, outdim, **mlp)
 
     def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
-        X1 = self.unpooling2subg.forward(self.aggr_global.forward(A, self.pool2global.forward(X)), X)
-        X2 = self.aggr_subg.forward(A, X, datadict, X)
-        return X2.catvalue(X1, True).tuplewiseapply(self.lin)
+        node_level = self.aggr_global.forward(A, self.pool2global.forward(X))
+        shared = self.unpooling2subg.forward(node_level, X)
+        local = self.aggr_subg.forward(A, X, datadict, X)
+        return local.catvalue(shared, True).tuplewiseapply(self.lin)
 
 
 class PPGNConv(Module):
-    """PPGN layer: product of two transformed copies of X (reference Conv.py:200-232)."""
+    """PPGN layer (reference Conv.py:200-232): product of two transformed copies of X."""
 
     def __init__(self, indim: int, outdim: int, aggr: str = "sum", mode: Literal["DD", "SS"] = "SS", mlp: dict = {},
                  optuplefeat: str = "X"):
@@ -122,64 +133,63 @@ class PPGNConv(Module):
         self.lin2 = MLP(indim, outdim, **mlp)
 
     def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
-        return self.op.forward(X.tuplewiseapply(self.lin1), X.tuplewiseapply(self.lin2), datadict, X)
+        left, right = (X.tuplewiseapply(f) for f in (self.lin1, self.lin2))
+        return self.op.forward(left, right, datadict, X)
 
 
 class GNNAKConv(Module):
-    """GNN-AK layer (reference Conv.py:236-297)."""
+    """GNN-AK layer (reference Conv.py:236-297): aggregate, then concatenate the subgraph-pooled view, the
+    centroid (diagonal) view and optionally the context (cross-subgraph pooled) view."""
 
     def __init__(self, indim: int, outdim: int, aggr: str = "sum", pool: str = "mean",
                  mode: Literal["SD", "DD", "SS"] = "SS", mlp0: dict = {}, mlp1: dict = {}, ctx: bool = True,
                  optuplefeat: str = "X", opadj: str = "A"):
         super().__init__()
+        v = _views(mode, pool)
         self.lin0 = MLP(indim, indim, **mlp0)
         self.aggr = TensorOp.OpMessagePassingOnSubg2D(mode, aggr, optuplefeat, opadj)
-        self.diag = TensorOp.OpDiag2D(mode[1])
-        self.pool2subg = TensorOp.OpPoolingSubg2D(mode[1], pool)
-        self.unpool4subg = TensorOp.OpUnpoolingSubgNodes2D(mode[1])
+        self.diag, self.pool2subg, self.unpool4subg = v["diag"], v["pool_subg"], v["to_subg_nodes"]
         self.ctx = ctx
         if ctx:
-            self.pool2node = TensorOp.OpPoolingCrossSubg2D(mode[1], pool)
-            self.unpool4rootnode = TensorOp.OpUnpoolingRootNodes2D(mode[1])
-        self.lin = MLP(3 * indim if ctx else 2 * indim, outdim, **mlp1)
+            self.pool2node, self.unpool4rootnode = v["pool_node"], v["to_root"]
+        self.lin = MLP((3 if ctx else 2) * indim, outdim, **mlp1)
 
     def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
-        X = self.aggr.forward(A, X.tuplewiseapply(self.lin0), datadict, X)
-        X1 = self.unpool4subg.forward(self.diag.forward(X), X)
-        X2 = self.unpool4subg.forward(self.pool2subg.forward(X), X)
+        H = self.aggr.forward(A, X.tuplewiseapply(self.lin0), datadict, X)
+        centroid = self.unpool4subg.forward(self.diag.forward(H), H)
+        pooled = self.unpool4subg.forward(self.pool2subg.forward(H), H)
+        extra = [centroid]
         if self.ctx:
-            X3 = self.unpool4rootnode.forward(self.pool2node.forward(X), X)
-            return X2.catvalue([X1, X3], True).tuplewiseapply(self.lin)
-        return X2.catvalue(X1, True).tuplewiseapply(self.lin)
+            extra.append(self.unpool4rootnode.forward(self.pool2node.forward(H), H))
+        return pooled.catvalue(extra if self.ctx else centroid, True).tuplewiseapply(self.lin)
 
 
 class SUNConv(Module):
-    """SUN layer: seven tuple-wise views concatenated, a per-(diagonal / off-diagonal) linear map, an MLP
-    (reference Conv.py:301-362)."""
+    """SUN layer (reference Conv.py:301-362): seven tuple-wise views of X concatenated, one linear map for
+    diagonal and one for off-diagonal tuples (``HeteroLinear``), then an MLP."""
 
     def __init__(self, indim: int, outdim: int, aggr: str = "sum", pool: str = "mean",
                  mode: Literal["SD", "DD", "SS"] = "SS", mlp0: dict = {}, mlp1: dict = {}, optuplefeat: str = "X",
                  opadj: str = "A"):
         super().__init__()
+        v = _views(mode, pool)
         self.lin0 = MLP(indim, indim, **mlp0)
         self.aggr = TensorOp.OpMessagePassingOnSubg2D(mode, aggr, optuplefeat, opadj)
-        self.diag = TensorOp.OpDiag2D(mode[1])
-        self.pool2subg = TensorOp.OpPoolingSubg2D(mode[1], pool)
-        self.unpool4subg = TensorOp.OpUnpoolingSubgNodes2D(mode[1])
-        self.pool2node = TensorOp.OpPoolingCrossSubg2D(mode[1], pool)
-        self.unpool4rootnode = TensorOp.OpUnpoolingRootNodes2D(mode[1])
+        self.diag, self.pool2subg, self.unpool4subg = v["diag"], v["pool_subg"], v["to_subg_nodes"]
+        self.pool2node, self.unpool4rootnode = v["pool_node"], v["to_root"]
         self.lin1_0 = HeteroLinear(7 * indim, indim, 2, False)
         self.lin1_1 = MLP(indim, outdim, **mlp1)
 
     def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
-        X4 = self.aggr.forward(A, X.tuplewiseapply(self.lin0), datadict, X)
-        Xdiag = self.diag.forward(X)
-        X2 = self.unpool4subg.forward(Xdiag, X)
-        X3 = self.unpool4rootnode.forward(Xdiag, X)
-        X5 = self.unpool4rootnode.forward(self.pool2node(X), X)
-        X6 = self.unpool4subg.forward(self.pool2subg(X), X)
-        X7 = self.unpool4rootnode.forward(self.pool2node(X4), X)
-        X = X.catvalue([X2, X3, X4, X5, X6, X7], True)
-        X = X.diagonalapply(
-            lambda val, ind: self.lin1_0(val.flatten(0, -2), ind.flatten()).unflatten(0, val.shape[0:-1]))
-        return X.tuplewiseapply(self.lin1_1)
+        to_nodes, to_root = self.unpool4subg.forward, self.unpool4rootnode.forward
+        agg = self.aggr.forward(A, X.tuplewiseapply(self.lin0), datadict, X)
+        centre = self.diag.forward(X)
+        views = [to_nodes(centre, X), to_root(centre, X), agg, to_root(self.pool2node(X), X),
+                 to_nodes(self.pool2subg(X), X), to_root(self.pool2node(agg), X)]     # X2 .. X7 of the reference
+        stacked = X.catvalue(views, True)
+
+        def per_type(val, is_diag):
+            flat = self.lin1_0(val.flatten(0, -2), is_diag.flatten())
+            return flat.unflatten(0, val.shape[0:-1])
+
+        return stacked.diagonalapply(per_type).tuplewiseapply(self.lin1_1)

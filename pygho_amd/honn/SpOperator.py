@@ -1,8 +1,11 @@
 """
-Graph operators on ``SparseTensor`` (parameter-free ``nn.Module`` shims).  Mirror of
-``pygho/honn/SpOperator.py``: same class names, constructor / forward signatures and the ``datadict``
-key convention (reference SpOperator.py:12, :135, :165-183); the work is done by the HIP-backed
-``pygho_amd.backend`` functions.
+Graph operators on ``SparseTensor`` (parameter-free ``nn.Module`` shims).
+
+Same public names, constructor arguments, ``forward`` signatures and ``datadict`` key convention as
+``pygho/honn/SpOperator.py`` (KEYSEP :12, key format :135, lookups :165-183).  ``OpMessagePassing`` carries the
+logic; its named specialisations only fix the operand roles, so they are generated from a table instead of being
+written out one class at a time (reference: Op2FWL :185-227, OnSubg2D :230-277, OnSubg3D :280-327,
+CrossSubg2D :330-372, pooling :470-545, unpooling :586-601).
 """
 from typing import Callable, Dict, Iterable, List, Optional, Union
 
@@ -17,13 +20,16 @@ KEYSEP = "___"
 
 
 def parse_precomputekey(model: Module) -> List[str]:
-    """sorted unique precompute keys of every message-passing operator inside ``model``
-    (reference SpOperator.py:15-44)."""
+    """sorted unique precompute keys of every message-passing operator inside ``model`` (reference :15-44)."""
     return sorted({m.precomputekey for m in model.modules() if isinstance(m, OpMessagePassing)})
 
 
+def _as_dims(dims: Union[int, Iterable[int]]):
+    return sorted(set([dims] if isinstance(dims, int) else dims))
+
+
 class OpNodeMessagePassing(Module):
-    """node-level message passing ``A X`` (reference SpOperator.py:47-85)."""
+    """node-level message passing ``A X`` with a 2-D sparse adjacency."""
 
     def __init__(self, aggr: str = "sum") -> None:
         super().__init__()
@@ -36,173 +42,130 @@ class OpNodeMessagePassing(Module):
 
 class OpMessagePassing(Module):
     """
-    Generalised message passing ``out = A (x)_{dim1,dim2} B`` restricted to the pattern of ``tarX``.
-    ``precomputekey = f"{op0}___{op1}___{dim1}___{op2}___{dim2}"`` names the plan
-    (``datadict[key + "___acd"]``) produced off-line (reference SpOperator.py:88-183).
+    Generalised message passing ``out = A (x)_{dim1, dim2} B`` restricted to the pattern of ``tarX``.
+    The plan is looked up in ``datadict`` under ``f"{op0}___{op1}___{dim1}___{op2}___{dim2}___acd"`` (also
+    ``___bcd`` / ``___tarind``), exactly the keys the reference's pre-transform produces.
     """
 
     def __init__(self, op0: str = "X", op1: str = "X", dim1: int = 1, op2: str = "A", dim2: int = 0,
                  aggr: str = "sum", message_func: Optional[Callable] = None) -> None:
         super().__init__()
-        self.dim1 = dim1
-        self.dim2 = dim2
+        self.dim1, self.dim2, self.aggr = dim1, dim2, aggr
         self.precomputekey = KEYSEP.join((op0, op1, str(dim1), op2, str(dim2)))
-        self.aggr = aggr
         self.message_func = message_func
         self.use_mpnn = message_func is not None
 
+    def _plan(self, datadict: Dict, which: str):
+        return datadict.get(self.precomputekey + KEYSEP + which, None)
+
     def forward(self, A: SparseTensor, B: SparseTensor, datadict: Dict, tarX: Optional[SparseTensor] = None) -> SparseTensor:
-        key = self.precomputekey + KEYSEP
         if self.use_mpnn:
             assert tarX is not None, "target representation is a must when message func is not None"
-            return spspmpnn(A, self.dim1, B, self.dim2, tarX, datadict.get(key + "acd", None), self.message_func, self.aggr)
-        return spspmm(A, self.dim1, B, self.dim2, self.aggr,
-                      acd=datadict.get(key + "acd", None), bcd=datadict.get(key + "bcd", None),
-                      tar_ind=datadict.get(key + "tarind", None) if tarX is None else tarX.indices)
+            return spspmpnn(A, self.dim1, B, self.dim2, tarX, self._plan(datadict, "acd"), self.message_func, self.aggr)
+        tar_ind = self._plan(datadict, "tarind") if tarX is None else tarX.indices
+        return spspmm(A, self.dim1, B, self.dim2, self.aggr, acd=self._plan(datadict, "acd"),
+                      bcd=self._plan(datadict, "bcd"), tar_ind=tar_ind)
+
+
+def _variant(name: str, roles: str, dim1: int, x_sd: int, doc: str):
+    """`roles`: which of (tuple feature X, adjacency A) is op1 / op2 of the product, e.g. "XA" = X (x) A."""
+
+    def __init__(self, aggr: str = "sum", optuplefeat: str = "X", opadj: str = "A",
+                 message_func: Optional[Callable] = None) -> None:
+        ops = {"X": optuplefeat, "A": opadj}
+        OpMessagePassing.__init__(self, optuplefeat, ops[roles[0]], dim1, ops[roles[1]], 0, aggr, message_func)
+
+    def forward(self, A: SparseTensor, X: SparseTensor, datadict: Dict, tarX: Optional[SparseTensor] = None) -> SparseTensor:
+        assert A.sparse_dim == 2, "A should be nxn adjacency matrix "
+        assert X.sparse_dim == x_sd, f"X should be {x_sd}d representations"
+        operands = {"X": X, "A": A}
+        return OpMessagePassing.forward(self, operands[roles[0]], operands[roles[1]], datadict, tarX)
+
+    return type(name, (OpMessagePassing,), {"__init__": __init__, "forward": forward, "__doc__": doc})
+
+
+OpMessagePassingOnSubg2D = _variant("OpMessagePassingOnSubg2D", "XA", 1, 2,
+                                    "message passing inside every subgraph of a 2-D representation: X A")
+OpMessagePassingOnSubg3D = _variant("OpMessagePassingOnSubg3D", "XA", 2, 3,
+                                    "message passing inside every subgraph of a 3-D representation: X A over the last dim")
+OpMessagePassingCrossSubg2D = _variant("OpMessagePassingCrossSubg2D", "AX", 1, 2,
+                                       "message passing across subgraphs: A X")
 
 
 class Op2FWL(OpMessagePassing):
-    """2-FWL style product of two 2-D representations, X <- X1 X2 (reference SpOperator.py:185-227)."""
+    """2-FWL style product of two 2-D representations, X <- X1 X2."""
 
     def __init__(self, aggr: str = "sum", optuplefeat: str = "X") -> None:
         super().__init__(optuplefeat, optuplefeat, 1, optuplefeat, 0, aggr)
 
     def forward(self, X1: SparseTensor, X2: SparseTensor, datadict: Dict, tarX: Optional[SparseTensor] = None) -> SparseTensor:
-        assert X1.sparse_dim == 2, "X1 should be 2d representations "
-        assert X2.sparse_dim == 2, "X2 should be 2d representations"
+        assert X1.sparse_dim == 2 and X2.sparse_dim == 2, "X1, X2 should be 2d representations"
         return super().forward(X1, X2, datadict, tarX)
 
 
-class OpMessagePassingOnSubg2D(OpMessagePassing):
-    """message passing inside every subgraph, 2-D representations: X A (reference SpOperator.py:230-277)."""
-
-    def __init__(self, aggr: str = "sum", optuplefeat: str = "X", opadj: str = "A",
-                 message_func: Optional[Callable] = None) -> None:
-        super().__init__(optuplefeat, optuplefeat, 1, opadj, 0, aggr, message_func)
-
-    def forward(self, A: SparseTensor, X: SparseTensor, datadict: Dict, tarX: Optional[SparseTensor] = None) -> SparseTensor:
-        assert A.sparse_dim == 2, "A should be nxn adjacency matrix "
-        assert X.sparse_dim == 2, "X should be 2d representations"
-        return super().forward(X, A, datadict, tarX)
-
-
-class OpMessagePassingOnSubg3D(OpMessagePassing):
-    """message passing inside every subgraph, 3-D representations (reference SpOperator.py:280-327)."""
-
-    def __init__(self, aggr: str = "sum", optuplefeat: str = "X", opadj: str = "A",
-                 message_func: Optional[Callable] = None) -> None:
-        super().__init__(optuplefeat, optuplefeat, 2, opadj, 0, aggr, message_func)
-
-    def forward(self, A: SparseTensor, X: SparseTensor, datadict: Dict, tarX: Optional[SparseTensor] = None) -> SparseTensor:
-        assert A.sparse_dim == 2, "A should be nxn adjacency matrix "
-        assert X.sparse_dim == 3, "X should be 3d representations"
-        return super().forward(X, A, datadict, tarX)
-
-
-class OpMessagePassingCrossSubg2D(OpMessagePassing):
-    """message passing across subgraphs: A X (reference SpOperator.py:330-372)."""
-
-    def __init__(self, aggr: str = "sum", optuplefeat: str = "X", opadj: str = "A",
-                 message_func: Optional[Callable] = None) -> None:
-        super().__init__(optuplefeat, opadj, 1, optuplefeat, 0, aggr, message_func)
-
-    def forward(self, A: SparseTensor, X: SparseTensor, datadict: Dict, tarX: Optional[SparseTensor] = None) -> SparseTensor:
-        assert A.sparse_dim == 2, "A should be nxn adjacency matrix "
-        assert X.sparse_dim == 2, "X should be 2d representations"
-        return super().forward(A, X, datadict, tarX)
-
-
 class OpDiag(Module):
-    """diagonal extraction (reference SpOperator.py:375-403)."""
-
     def __init__(self, dims: Iterable[int], return_sparse: bool = False) -> None:
         super().__init__()
-        self.dims = sorted(set(dims))
-        self.return_sparse = return_sparse
+        self.dims, self.return_sparse = _as_dims(dims), return_sparse
 
     def forward(self, A: SparseTensor) -> Union[Tensor, SparseTensor]:
         return A.diag(self.dims, return_sparse=self.return_sparse)
 
 
 class OpDiag2D(OpDiag):
-
     def __init__(self) -> None:
         super().__init__([0, 1], False)
 
     def forward(self, X: SparseTensor) -> Tensor:
         assert X.sparse_dim == 2, "X should be 2d representations"
-        return X.diag(self.dims, return_sparse=self.return_sparse)
+        return super().forward(X)
 
 
 class OpPooling(Module):
-    """pool tuple representations over sparse dims (reference SpOperator.py:427-467)."""
-
     def __init__(self, dims: Union[int, Iterable[int]], pool: str = "sum", return_sparse: bool = False) -> None:
         super().__init__()
-        self.dims = sorted(set([dims] if isinstance(dims, int) else dims))
-        self.pool = pool
-        self.return_sparse = return_sparse
+        self.dims, self.pool, self.return_sparse = _as_dims(dims), pool, return_sparse
 
     def forward(self, X: SparseTensor) -> Union[SparseTensor, Tensor]:
         return getattr(X, self.pool)(self.dims, return_sparse=self.return_sparse)
 
 
-class OpPoolingSubg2D(OpPooling):
-    """pool the nodes of each subgraph -> dense (n, d) (reference SpOperator.py:470-493)."""
-
+def _pooling(name: str, dim: int, sparse_out: bool, x_sd: int, doc: str):
     def __init__(self, pool) -> None:
-        super().__init__(1, pool, False)
+        OpPooling.__init__(self, dim, pool, sparse_out)
 
-    def forward(self, X: SparseTensor) -> Tensor:
-        assert X.sparse_dim == 2, "X should be 2d representations"
-        return super().forward(X)
+    def forward(self, X: SparseTensor):
+        assert X.sparse_dim == x_sd, f"X should be {x_sd}d representations"
+        return OpPooling.forward(self, X)
 
-
-class OpPoolingSubg3D(OpPooling):
-    """pool the last dim of 3-D representations -> sparse 2-D (reference SpOperator.py:496-519)."""
-
-    def __init__(self, pool) -> None:
-        super().__init__(2, pool, True)
-
-    def forward(self, X: SparseTensor) -> SparseTensor:
-        assert X.sparse_dim == 3, "X should be 3d representations"
-        return super().forward(X)
+    return type(name, (OpPooling,), {"__init__": __init__, "forward": forward, "__doc__": doc})
 
 
-class OpPoolingCrossSubg2D(OpPooling):
-    """pool the same node across subgraphs -> dense (reference SpOperator.py:522-545)."""
-
-    def __init__(self, pool) -> None:
-        super().__init__(0, pool, False)
-
-    def forward(self, X: SparseTensor) -> Tensor:
-        assert X.sparse_dim == 2, "X should be 2d representations"
-        return super().forward(X)
+OpPoolingSubg2D = _pooling("OpPoolingSubg2D", 1, False, 2, "pool the nodes of each subgraph -> dense (n, d)")
+OpPoolingSubg3D = _pooling("OpPoolingSubg3D", 2, True, 3, "pool the last dim of 3-D representations -> sparse 2-D")
+OpPoolingCrossSubg2D = _pooling("OpPoolingCrossSubg2D", 0, False, 2, "pool the same node across subgraphs -> dense (n, d)")
 
 
 class OpUnpooling(Module):
-    """broadcast lower-order representations to a tuple pattern (reference SpOperator.py:548-583)."""
+    """broadcast a dense per-node tensor or a lower-order sparse tensor to the pattern of ``tarX``."""
 
     def __init__(self, dims: Union[int, Iterable[int]], fromdense1dim: bool = True) -> None:
         super().__init__()
-        self.dims = sorted(set([dims] if isinstance(dims, int) else dims))
-        self.fromdense1dim = fromdense1dim
+        self.dims, self.fromdense1dim = _as_dims(dims), fromdense1dim
 
     def forward(self, X: Union[Tensor, SparseTensor], tarX: SparseTensor) -> SparseTensor:
-        if isinstance(X, Tensor):
-            leftdim = list(set(range(tarX.sparse_dim)) - set(self.dims))
-            assert len(leftdim) == 1, "canonly pooling from 1 dim"
-            return tarX.unpooling_fromdense1dim(leftdim[0], X)
-        return X.unpooling(self.dims, tarX)
+        if not isinstance(X, Tensor):
+            return X.unpooling(self.dims, tarX)
+        kept = [d for d in range(tarX.sparse_dim) if d not in self.dims]
+        assert len(kept) == 1, "canonly pooling from 1 dim"
+        return tarX.unpooling_fromdense1dim(kept[0], X)
 
 
 class OpUnpoolingSubgNodes2D(OpUnpooling):
-
     def __init__(self) -> None:
         super().__init__(1, True)
 
 
 class OpUnpoolingRootNodes2D(OpUnpooling):
-
     def __init__(self) -> None:
         super().__init__(0, True)

@@ -1,25 +1,87 @@
 """
-Sparse / dense dispatch of the graph operators.  Mirror of ``pygho/honn/TensorOp.py``: every class picks
-the ``SpOperator`` or ``MaOperator`` implementation from ``mode`` in {"SS", "SD", "DD"} (first letter =
-adjacency, second = tuple representation; "S" sparse, "D" dense/masked) or {"S", "D"}.
-"""
-from typing import Callable, Dict, Literal, Optional, Union
+Sparse / dense dispatch of the graph operators.
 
-from torch import Tensor
+Same class names, constructor arguments and ``forward`` signatures as ``pygho/honn/TensorOp.py``: each class
+picks the ``SpOperator`` or ``MaOperator`` implementation from ``mode`` -- "SS" / "SD" / "DD" (first letter =
+adjacency, second = tuple representation; S sparse, D dense) for the message-passing operators, "S" / "D" for
+pooling, diagonal and unpooling -- and forwards to it as ``self.mod``.  The dispatch rules are one table here
+(reference TensorOp.py:14-500).
+"""
+from typing import Callable, Dict, Optional, Union
+
 from torch.nn import Module
 
 from . import MaOperator, SpOperator
 from ..backend.MaTensor import MaskedTensor
 from ..backend.SpTensor import SparseTensor
 
+Rep = Union[SparseTensor, MaskedTensor]
 _DENSE_MSG = "general message passing with message_func is not implemented for Dense"
 _DENSE_AGGR = "only sum aggragation implemented for Dense adjacency"
 
 
-class OpNodeMessagePassing(Module):
-    """node-level message passing (reference TensorOp.py:14-62)."""
+def _pick_tuple_operator(kind: str, mode: str, aggr: str, optuplefeat: str, opadj: str, message_func):
+    """SS -> sparse operator (keeps aggr, names, message function); SD -> sparse adjacency on masked X (aggr
+    only); DD -> masked contraction on the matrix cores (sum only)."""
+    if mode == "SS":
+        cls = getattr(SpOperator, kind)
+        return cls(aggr, optuplefeat) if kind == "Op2FWL" else cls(aggr, optuplefeat, opadj, message_func)
+    if mode == "SD" and kind != "Op2FWL":
+        assert message_func is None, _DENSE_MSG
+        # (the reference's CrossSubg2D "SD" branch passes aggr to a 0-argument constructor -> TypeError,
+        #  TensorOp.py:287; the sparse-adjacency operator is what the mode means)
+        return getattr(MaOperator, kind.replace("OpMessagePassing", "OpSpMessagePassing"))(aggr)
+    if mode == "DD":
+        assert message_func is None, _DENSE_MSG
+        assert aggr == "sum", _DENSE_AGGR
+        return getattr(MaOperator, kind)()
+    raise NotImplementedError
 
-    def __init__(self, mode: Literal["SS", "SD", "DD"] = "SS", aggr: str = "sum") -> None:
+
+class _TupleOperator(Module):
+    """forward(A, X, datadict, tarX) -> self.mod.forward(...)"""
+    _kind = ""
+
+    def __init__(self, mode: str = "SS", aggr: str = "sum", optuplefeat: str = "X", opadj: str = "A",
+                 message_func: Optional[Callable] = None) -> None:
+        super().__init__()
+        self.mod = _pick_tuple_operator(self._kind, mode, aggr, optuplefeat, opadj, message_func)
+
+    def forward(self, A: Rep, X: Rep, datadict: Optional[Dict] = None, tarX: Optional[Rep] = None) -> Rep:
+        return self.mod.forward(A, X, datadict, tarX)
+
+
+class OpMessagePassingOnSubg2D(_TupleOperator):
+    """message passing within each subgraph, 2-D representations"""
+    _kind = "OpMessagePassingOnSubg2D"
+
+
+class OpMessagePassingOnSubg3D(_TupleOperator):
+    """message passing within each subgraph, 3-D representations (the reference drops `message_func` in SS mode,
+    TensorOp.py:219-220; it is forwarded here)"""
+    _kind = "OpMessagePassingOnSubg3D"
+
+
+class OpMessagePassingCrossSubg2D(_TupleOperator):
+    """message passing across subgraphs"""
+    _kind = "OpMessagePassingCrossSubg2D"
+
+
+class Op2FWL(Module):
+    """2-FWL product X1 X2"""
+
+    def __init__(self, mode: str = "SS", aggr: str = "sum", optuplefeat: str = "X") -> None:
+        super().__init__()
+        self.mod = _pick_tuple_operator("Op2FWL", mode, aggr, optuplefeat, "A", None)
+
+    def forward(self, X1: Rep, X2: Rep, datadict: Optional[Dict] = None, tarX: Optional[Rep] = None) -> Rep:
+        return self.mod.forward(X1, X2, datadict, tarX)
+
+
+class OpNodeMessagePassing(Module):
+    """node-level message passing A x"""
+
+    def __init__(self, mode: str = "SS", aggr: str = "sum") -> None:
         super().__init__()
         if mode == "SS":
             self.mod = SpOperator.OpNodeMessagePassing(aggr)
@@ -33,158 +95,65 @@ class OpNodeMessagePassing(Module):
         return self.mod.forward(A, X, X)
 
 
-class _Dispatch4(Module):
-    """shared forward(A, X, datadict, tarX) of the tuple message-passing operators."""
-
-    def forward(self, A: Union[SparseTensor, MaskedTensor], X: Union[SparseTensor, MaskedTensor],
-                datadict: Optional[Dict] = None, tarX: Optional[Union[SparseTensor, MaskedTensor]] = None):
-        return self.mod.forward(A, X, datadict, tarX)
+def _by_layout(kind: str, mode: str, *args):
+    if mode not in ("S", "D"):
+        raise NotImplementedError
+    return getattr(SpOperator if mode == "S" else MaOperator, kind)(*args)
 
 
-class Op2FWL(_Dispatch4):
-    """2-FWL product X1 X2 (reference TensorOp.py:65-113)."""
+class _UnaryOperator(Module):
+    _kind = ""
 
-    def __init__(self, mode: Literal["SS", "DD"] = "SS", aggr: Literal["sum", "mean", "max"] = "sum",
-                 optuplefeat: str = "X") -> None:
-        super().__init__()
-        if mode == "SS":
-            self.mod = SpOperator.Op2FWL(aggr, optuplefeat)
-        elif mode == "DD":
-            assert aggr == "sum", _DENSE_AGGR
-            self.mod = MaOperator.Op2FWL()
-        else:
-            raise NotImplementedError
-
-
-class OpMessagePassingOnSubg2D(_Dispatch4):
-    """message passing within each subgraph, 2-D (reference TensorOp.py:116-187)."""
-
-    def __init__(self, mode: Literal["SD", "SS", "DD"] = "SS", aggr: Literal["sum", "mean", "max"] = "sum",
-                 optuplefeat: str = "X", opadj: str = "A", message_func: Optional[Callable] = None) -> None:
-        super().__init__()
-        if mode == "SS":
-            self.mod = SpOperator.OpMessagePassingOnSubg2D(aggr, optuplefeat, opadj, message_func)
-        elif mode == "SD":
-            assert message_func is None, _DENSE_MSG
-            self.mod = MaOperator.OpSpMessagePassingOnSubg2D(aggr)
-        elif mode == "DD":
-            assert message_func is None, _DENSE_MSG
-            assert aggr == "sum", _DENSE_AGGR
-            self.mod = MaOperator.OpMessagePassingOnSubg2D()
-        else:
-            raise NotImplementedError
-
-
-class OpMessagePassingOnSubg3D(_Dispatch4):
-    """message passing within each subgraph, 3-D (reference TensorOp.py:190-256)."""
-
-    def __init__(self, mode: Literal["SD", "SS", "DD"] = "SS", aggr: Literal["sum", "mean", "max"] = "sum",
-                 optuplefeat: str = "X", opadj: str = "A", message_func: Optional[Callable] = None) -> None:
-        super().__init__()
-        if mode == "SS":
-            # the reference drops message_func here (TensorOp.py:219-220); it is forwarded instead
-            self.mod = SpOperator.OpMessagePassingOnSubg3D(aggr, optuplefeat, opadj, message_func)
-        elif mode == "SD":
-            assert message_func is None, _DENSE_MSG
-            self.mod = MaOperator.OpSpMessagePassingOnSubg3D(aggr)
-        elif mode == "DD":
-            assert message_func is None, _DENSE_MSG
-            assert aggr == "sum", _DENSE_AGGR
-            self.mod = MaOperator.OpMessagePassingOnSubg3D()
-        else:
-            raise NotImplementedError
-
-
-class OpMessagePassingCrossSubg2D(_Dispatch4):
-    """message passing across subgraphs (reference TensorOp.py:259-329)."""
-
-    def __init__(self, mode: Literal["SD", "SS", "DD"] = "SS", aggr: Literal["sum", "mean", "max"] = "sum",
-                 optuplefeat: str = "X", opadj: str = "A", message_func: Optional[Callable] = None) -> None:
-        super().__init__()
-        if mode == "SS":
-            self.mod = SpOperator.OpMessagePassingCrossSubg2D(aggr, optuplefeat, opadj, message_func)
-        elif mode == "SD":
-            assert message_func is None, _DENSE_MSG
-            # the reference passes `aggr` to a 0-argument constructor here (TensorOp.py:287 -> TypeError);
-            # the sparse-adjacency operator is what the mode means
-            self.mod = MaOperator.OpSpMessagePassingCrossSubg2D(aggr)
-        elif mode == "DD":
-            assert message_func is None, _DENSE_MSG
-            assert aggr == "sum", _DENSE_AGGR
-            self.mod = MaOperator.OpMessagePassingCrossSubg2D()
-        else:
-            raise NotImplementedError
-
-
-def _pick(mode: str, sp_cls, ma_cls, *args):
-    if mode == "S":
-        return sp_cls(*args)
-    if mode == "D":
-        return ma_cls(*args)
-    raise NotImplementedError
-
-
-class OpDiag2D(Module):
-    """diagonal of 2-D representations (reference TensorOp.py:332-365)."""
-
-    def __init__(self, mode: Literal["D", "S"] = "S") -> None:
-        super().__init__()
-        self.mod = _pick(mode, SpOperator.OpDiag2D, MaOperator.OpDiag2D)
-
-    def forward(self, X: Union[MaskedTensor, SparseTensor]) -> Union[MaskedTensor, Tensor]:
+    def forward(self, X: Rep):
         return self.mod.forward(X)
 
 
-class OpPoolingSubg2D(Module):
-    """pool nodes within each subgraph (reference TensorOp.py:368-395)."""
+class OpDiag2D(_UnaryOperator):
+    """diagonal of 2-D representations"""
+    _kind = "OpDiag2D"
 
-    def __init__(self, mode: Literal["S", "D"] = "S", pool: str = "sum") -> None:
+    def __init__(self, mode: str = "S") -> None:
         super().__init__()
-        self.mod = _pick(mode, SpOperator.OpPoolingSubg2D, MaOperator.OpPoolingSubg2D, pool)
-
-    def forward(self, X):
-        return self.mod(X)
+        self.mod = _by_layout(self._kind, mode)
 
 
-class OpPoolingSubg3D(Module):
-    """pool the last tuple dim of 3-D representations (reference TensorOp.py:398-425)."""
-
-    def __init__(self, mode: Literal["S", "D"] = "S", pool: str = "sum") -> None:
+class _Pooling(_UnaryOperator):
+    def __init__(self, mode: str = "S", pool: str = "sum") -> None:
         super().__init__()
-        self.mod = _pick(mode, SpOperator.OpPoolingSubg3D, MaOperator.OpPoolingSubg3D, pool)
-
-    def forward(self, X):
-        return self.mod(X)
+        self.mod = _by_layout(self._kind, mode, pool)
 
 
-class OpPoolingCrossSubg2D(Module):
-    """pool the same node over all subgraphs (reference TensorOp.py:428-451)."""
+class OpPoolingSubg2D(_Pooling):
+    """pool nodes within each subgraph"""
+    _kind = "OpPoolingSubg2D"
 
-    def __init__(self, mode: Literal["S", "D"] = "S", pool: str = "sum") -> None:
+
+class OpPoolingSubg3D(_Pooling):
+    """pool the last tuple dim of 3-D representations"""
+    _kind = "OpPoolingSubg3D"
+
+
+class OpPoolingCrossSubg2D(_Pooling):
+    """pool the same node over all subgraphs"""
+    _kind = "OpPoolingCrossSubg2D"
+
+
+class _Unpooling(Module):
+    _kind = ""
+
+    def __init__(self, mode: str = "S") -> None:
         super().__init__()
-        self.mod = _pick(mode, SpOperator.OpPoolingCrossSubg2D, MaOperator.OpPoolingCrossSubg2D, pool)
+        self.mod = _by_layout(self._kind, mode)
 
-    def forward(self, X):
-        return self.mod(X)
-
-
-class OpUnpoolingSubgNodes2D(Module):
-    """node representations -> every subgraph (reference TensorOp.py:454-476)."""
-
-    def __init__(self, mode: Literal["S", "D"] = "S") -> None:
-        super().__init__()
-        self.mod = _pick(mode, SpOperator.OpUnpoolingSubgNodes2D, MaOperator.OpUnpoolingSubgNodes2D)
-
-    def forward(self, X, tarX):
+    def forward(self, X, tarX: Rep) -> Rep:
         return self.mod.forward(X, tarX)
 
 
-class OpUnpoolingRootNodes2D(Module):
-    """root-node representations -> their subgraph (reference TensorOp.py:479-500)."""
+class OpUnpoolingSubgNodes2D(_Unpooling):
+    """node representations -> every subgraph"""
+    _kind = "OpUnpoolingSubgNodes2D"
 
-    def __init__(self, mode: Literal["S", "D"] = "S") -> None:
-        super().__init__()
-        self.mod = _pick(mode, SpOperator.OpUnpoolingRootNodes2D, MaOperator.OpUnpoolingRootNodes2D)
 
-    def forward(self, X, tarX):
-        return self.mod.forward(X, tarX)
+class OpUnpoolingRootNodes2D(_Unpooling):
+    """root-node representations -> their subgraph"""
+    _kind = "OpUnpoolingRootNodes2D"
