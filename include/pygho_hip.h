@@ -185,6 +185,39 @@ int pygho_run_ids(int32_t* run_id, int32_t* n_runs, const int64_t* sorted_keys, 
 int pygho_expand_pairs(int64_t* c_out, int64_t* d_out, const int64_t* lower, const int64_t* offsets,
                        int64_t nnz1, int64_t total, void* stream);
 
+/* Exclusive prefix sum: out (n + 1) with out[0] = 0, out[i+1] = out[i] + in[i]   (Spspmm.py:119-123 cumsum).
+ * Workspace: pygho_exclusive_scan_i64_workspace(n) bytes. */
+size_t pygho_exclusive_scan_i64_workspace(int64_t n);
+int pygho_exclusive_scan_i64(int64_t* out, const int64_t* in, int64_t n, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
+/* Hash of the product pattern without materialising the concatenated coordinates (Spspmm.py:132-135):
+ * out[t] = pack(ind1[r, c[t]] for r != dim1, ind2[r, d[t]] for r != dim2), 63 // (sd1 + sd2 - 2) bits per
+ * coordinate, most significant first.  *err as in pygho_hash_pack. */
+int pygho_product_hash(int64_t* out, const int64_t* ind1, int64_t sd1, int64_t nnz1, int64_t dim1,
+                       const int64_t* ind2, int64_t sd2, int64_t nnz2, int64_t dim2, const int64_t* c,
+                       const int64_t* d, int64_t total, int32_t* err, void* stream);
+
+/* Column gather of an int64 matrix: out[r, t] = src[r * ld + idx[t]] for r < rows, t < m; idx is int64, or
+ * int32 when idx_is_i32 != 0 (index glue of the planner: ind[:, c], bcd[:, order], perm[d]). */
+int pygho_gather_cols_i64(int64_t* out, const int64_t* src, int64_t rows, int64_t ld, const void* idx,
+                          int idx_is_i32, int64_t m, void* stream);
+/* out[t] = (int64) table[idx[t]] for an int32 table indexed by int64 positions (Spspmm.py:104 perm[bcd[2]]). */
+int pygho_gather_i32_to_i64(int64_t* out, const int32_t* table, const int64_t* idx, int64_t n, void* stream);
+
+/* Assemble the product plan in segment order (Spspmm.py:136-143): for t < m and p = perm[t]
+ *   out[0, t] = slot[p], out[1, t] = c[p], out[2, t] = d[p]      (out is (3, m) row-major, slot/perm int32). */
+int pygho_plan_triples(int64_t* out, const int32_t* slot, const int64_t* c, const int64_t* d, const int32_t* perm,
+                       int64_t m, void* stream);
+
+/* Stream compaction of the non-negative entries (boolean-mask indexing of Spspmm.py:219-221, :256-263):
+ * offsets (n + 1) = exclusive scan of [v_i >= 0] with v_i = via ? vals[via[i]] : vals[i];
+ * pygho_compact_positions then writes the kept positions in order: pos[offsets[i]] = i.
+ * Workspace: pygho_exclusive_scan_i64_workspace(n). */
+int pygho_flag_scan_nonneg(int64_t* offsets, const int64_t* vals, const int64_t* via, int64_t n, void* workspace,
+                           size_t workspace_bytes, void* stream);
+int pygho_compact_positions(int64_t* pos, const int64_t* offsets, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------------
  * Masked (dense) path
  * ---------------------------------------------------------------------- */

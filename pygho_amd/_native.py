@@ -48,6 +48,14 @@ PROTOTYPES = {
     "pygho_run_ids_workspace": (Z, [L]),
     "pygho_run_ids": (I, [P, P, P, L, P, Z, P]),
     "pygho_expand_pairs": (I, [P, P, P, P, L, L, P]),
+    "pygho_exclusive_scan_i64_workspace": (Z, [L]),
+    "pygho_exclusive_scan_i64": (I, [P, P, L, P, Z, P]),
+    "pygho_product_hash": (I, [P, P, L, L, L, P, L, L, L, P, P, L, P, P]),
+    "pygho_gather_cols_i64": (I, [P, P, L, L, P, I, L, P]),
+    "pygho_gather_i32_to_i64": (I, [P, P, P, L, P]),
+    "pygho_plan_triples": (I, [P, P, P, P, P, L, P]),
+    "pygho_flag_scan_nonneg": (I, [P, P, P, L, P, Z, P]),
+    "pygho_compact_positions": (I, [P, P, L, P]),
     "pygho_masked_bmm": (I, [P, P, P, P, P, P, L, L, L, L, L, I, I, I, P]),
     "pygho_masked_fill": (I, [P, P, P, D, L, L, I, P]),
     "pygho_masked_reduce": (I, [P, P, P, P, L, L, L, L, I, I, P]),

@@ -686,18 +686,99 @@ def unique_plan(keys: Tensor) -> Tuple[Tensor, SegPlan, Tensor]:
     return uniq, SegPlan(seg_ptr, perm, n_runs, m), inv
 
 
+def exclusive_scan(counts: Tensor) -> Tensor:
+    """(n + 1) int64 offsets with offsets[0] = 0 (Spspmm.py:119-123)."""
+    dev = require_device(counts)
+    counts = counts.contiguous()
+    n = counts.numel()
+    out = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    nbytes = int(lib().pygho_exclusive_scan_i64_workspace(n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib().pygho_exclusive_scan_i64(ptr(out), ptr(counts), n, ptr(ws), nbytes, stream_ptr(dev)), "exclusive_scan_i64")
+    return out
+
+
 def expand_pairs(lower: Tensor, counts: Tensor) -> Tuple[Tensor, Tensor]:
     """(c, d) pair enumeration of the product planner (Spspmm.py:119-129)."""
     dev = require_device(lower, counts)
     nnz1 = counts.numel()
-    offsets = torch.zeros(nnz1 + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(counts, 0, out=offsets[1:])
+    offsets = exclusive_scan(counts)
     total = int(offsets[-1].item())
     c = torch.empty(total, dtype=torch.int64, device=dev)
     d = torch.empty(total, dtype=torch.int64, device=dev)
     check(lib().pygho_expand_pairs(ptr(c), ptr(d), ptr(lower.contiguous()), ptr(offsets), nnz1, total, stream_ptr(dev)),
           "expand_pairs")
     return c, d
+
+
+def product_hash(ind1: Tensor, dim1: int, ind2: Tensor, dim2: int, c: Tensor, d: Tensor) -> Tensor:
+    """hash of (ind1 rows != dim1 at c, ind2 rows != dim2 at d), Spspmm.py:132-135, without the (sd, M)
+    concatenated coordinate temporaries."""
+    dev = require_device(ind1, ind2, c, d)
+    ind1, ind2, c, d = ind1.contiguous(), ind2.contiguous(), c.contiguous(), d.contiguous()
+    total = c.numel()
+    out = torch.empty(total, dtype=torch.int64, device=dev)
+    err = _flag(dev)
+    check(lib().pygho_product_hash(ptr(out), ptr(ind1), ind1.shape[0], ind1.shape[1], dim1, ptr(ind2), ind2.shape[0],
+                                   ind2.shape[1], dim2, ptr(c), ptr(d), total, ptr(err), stream_ptr(dev)), "product_hash")
+    code = int(err.item())
+    assert code != 1, "indice cannot be negative"
+    assert code != 2, "too large indice, hash is not injective"
+    return out
+
+
+def gather_cols(src: Tensor, idx: Tensor) -> Tensor:
+    """``src[:, idx]`` (or ``src[idx]`` for a vector) of an int64 array, idx int64 or int32."""
+    dev = require_device(src, idx)
+    assert src.dtype == torch.int64 and idx.dtype in (torch.int64, _I32)
+    vec = src.dim() == 1
+    src2 = src.reshape(1, -1) if vec else src
+    src2, idx = src2.contiguous(), idx.contiguous()
+    rows, ld = src2.shape
+    m = idx.numel()
+    out = torch.empty((rows, m), dtype=torch.int64, device=dev)
+    check(lib().pygho_gather_cols_i64(ptr(out), ptr(src2), rows, ld, ptr(idx), int(idx.dtype == _I32), m, stream_ptr(dev)),
+          "gather_cols_i64")
+    return out.reshape(-1) if vec else out
+
+
+def widen_gather(table: Tensor, idx: Tensor) -> Tensor:
+    """``table[idx]`` for an int32 table and int64 positions, int64 result (Spspmm.py:104)."""
+    dev = require_device(table, idx)
+    assert table.dtype == _I32 and idx.dtype == torch.int64
+    table, idx = table.contiguous(), idx.contiguous()
+    out = torch.empty(idx.numel(), dtype=torch.int64, device=dev)
+    check(lib().pygho_gather_i32_to_i64(ptr(out), ptr(table), ptr(idx), idx.numel(), stream_ptr(dev)), "gather_i32_to_i64")
+    return out
+
+
+def plan_triples(slot: Tensor, c: Tensor, d: Tensor, perm: Tensor) -> Tensor:
+    """(3, M) int64 plan ``(slot[perm], c[perm], d[perm])`` in one pass (Spspmm.py:136-143)."""
+    dev = require_device(slot, c, d, perm)
+    assert slot.dtype == _I32 and perm.dtype == _I32
+    m = perm.numel()
+    out = torch.empty((3, m), dtype=torch.int64, device=dev)
+    check(lib().pygho_plan_triples(ptr(out), ptr(slot.contiguous()), ptr(c.contiguous()), ptr(d.contiguous()),
+                                   ptr(perm.contiguous()), m, stream_ptr(dev)), "plan_triples")
+    return out
+
+
+def nonneg_positions(vals: Tensor, via: Optional[Tensor] = None) -> Tensor:
+    """ordered positions i with ``(vals[via[i]] if via is given else vals[i]) >= 0``: the boolean-mask
+    compaction of Spspmm.py:219-221 / :256-263 as flag -> scan -> scatter."""
+    dev = require_device(vals, via)
+    vals = vals.contiguous()
+    via = None if via is None else via.contiguous()
+    n = vals.numel() if via is None else via.numel()
+    offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    nbytes = int(lib().pygho_exclusive_scan_i64_workspace(n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    st = stream_ptr(dev)
+    check(lib().pygho_flag_scan_nonneg(ptr(offsets), ptr(vals), ptr(via), n, ptr(ws), nbytes, st), "flag_scan_nonneg")
+    kept = int(offsets[-1].item())
+    pos = torch.empty(kept, dtype=torch.int64, device=dev)
+    check(lib().pygho_compact_positions(ptr(pos), ptr(offsets), n, st), "compact_positions")
+    return pos
 
 
 # --------------------------------------------------------------------------

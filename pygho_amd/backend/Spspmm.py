@@ -57,16 +57,13 @@ def spspmm_ind(ind1: LongTensor, dim1: int, ind2: LongTensor, dim2: int,
     lower, upper = _ops.search_bounds(k2s, k1)                       # Spspmm.py:114-116
     c, d = _ops.expand_pairs(lower, upper - lower)                   # Spspmm.py:119-129
     if perm2 is not None:
-        d = perm2.to(torch.int64)[d]
-    rest1 = torch.cat((ind1[:dim1], ind1[dim1 + 1:]))[:, c]
-    rest2 = torch.cat((ind2[:dim2], ind2[dim2 + 1:]))[:, d]
-    combined = indicehash(torch.cat((rest1, rest2)).contiguous())    # Spspmm.py:132-135
+        d = _ops.widen_gather(perm2, d)                              # Spspmm.py:104
+    combined = _ops.product_hash(ind1, dim1, ind2, dim2, c, d)       # Spspmm.py:132-135
     uniq, plan, inv = _ops.unique_plan(combined)                      # Spspmm.py:136-140
     tarind = decodehash(uniq, sd1 + sd2 - 2)
     # stable grouping by b keeps the (c, d) enumeration order inside a segment: c ascending, and for
     # equal c ascending position in the sorted k2 run -> canonical once d is ascending too
-    order = plan.perm.to(torch.int64)
-    bcd = torch.stack((inv.to(torch.int64)[order], c[order], d[order]))
+    bcd = _ops.plan_triples(inv, c, d, plan.perm)
     if perm2 is not None:
         bcd = _canonical(bcd)
     return tarind, bcd
@@ -77,8 +74,8 @@ def _canonical(t: LongTensor) -> LongTensor:
     if t.shape[1] == 0:
         return t
     for r in (2, 1, 0):                          # LSD passes of a stable sort
-        _, p = _ops.sort_with_perm(t[r].contiguous())
-        t = t[:, p.to(torch.int64)]
+        _, p = _ops.sort_with_perm(t[r])
+        t = _ops.gather_cols(t, p)
     return t
 
 
@@ -97,9 +94,10 @@ def filterind(tar_ind: LongTensor, ind: LongTensor, bcd: LongTensor) -> LongTens
     ``tar_ind`` dropped; column order preserved (so ``acd[0]`` stays sorted).
     Reference: Spspmm.py:186-222."""
     b2a = spsphadamard_ind(tar_ind, ind)
-    a = b2a[bcd[0]]
-    keep = torch.nonzero(a >= 0).flatten()
-    return torch.stack((a[keep], bcd[1][keep], bcd[2][keep]))
+    keep = _ops.nonneg_positions(b2a, via=bcd[0])
+    acd = _ops.gather_cols(bcd, keep)
+    acd[0] = _ops.gather_cols(b2a, acd[0])
+    return acd
 
 
 def spsphadamard(A: SparseTensor, B: SparseTensor, b2a: Optional[LongTensor] = None) -> SparseTensor:
@@ -109,14 +107,14 @@ def spsphadamard(A: SparseTensor, B: SparseTensor, b2a: Optional[LongTensor] = N
     assert A.sparseshape == B.sparseshape, "A, B should be of the same sparse shape"
     if b2a is None:
         b2a = spsphadamard_ind(A.indices, B.indices)
-    sel = torch.nonzero(b2a >= 0).flatten()
+    sel = _ops.nonneg_positions(b2a)
     if A.values is None:
         retval = _ops.gather_rows(B.values, sel)
     elif B.values is None:
-        retval = _ops.gather_rows(A.values, b2a[sel])
+        retval = _ops.gather_rows(A.values, _ops.gather_cols(b2a, sel))
     else:
-        retval = _ops.gather_rows(A.values, b2a[sel]) * _ops.gather_rows(B.values, sel)
-    return SparseTensor(B.indices[:, sel], retval, shape=A.sparseshape + retval.shape[1:], is_coalesced=True)
+        retval = _ops.gather_rows(A.values, _ops.gather_cols(b2a, sel)) * _ops.gather_rows(B.values, sel)
+    return SparseTensor(_ops.gather_cols(B.indices, sel), retval, shape=A.sparseshape + retval.shape[1:], is_coalesced=True)
 
 
 def _product_shape(A: SparseTensor, dim1: int, B: SparseTensor, dim2: int, retval: Tensor):

@@ -144,6 +144,72 @@ __global__ void expand_pairs_kernel(int64_t* __restrict__ c_out, int64_t* __rest
   }
 }
 
+__global__ void product_hash_kernel(int64_t* __restrict__ out, const int64_t* __restrict__ ind1, int sd1, int64_t nnz1, int dim1,
+                                    const int64_t* __restrict__ ind2, int sd2, int64_t nnz2, int dim2,
+                                    const int64_t* __restrict__ c, const int64_t* __restrict__ d, int64_t total, int bits,
+                                    int32_t* err) {
+  const int sd = sd1 + sd2 - 2;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t ci = c[t], di = d[t];
+    int64_t h = 0;
+    int slot = 0;
+    for (int r = 0; r < sd1; ++r) {
+      if (r == dim1) continue;
+      const int64_t v = ind1[(int64_t)r * nnz1 + ci];
+      if (v < 0) { if (err) atomicMax(err, 1); } else if (sd > 1 && v >= ((int64_t)1 << bits)) { if (err) atomicMax(err, 2); }
+      h |= v << (bits * (sd - 1 - slot));
+      ++slot;
+    }
+    for (int r = 0; r < sd2; ++r) {
+      if (r == dim2) continue;
+      const int64_t v = ind2[(int64_t)r * nnz2 + di];
+      if (v < 0) { if (err) atomicMax(err, 1); } else if (sd > 1 && v >= ((int64_t)1 << bits)) { if (err) atomicMax(err, 2); }
+      h |= v << (bits * (sd - 1 - slot));
+      ++slot;
+    }
+    out[t] = h;
+  }
+}
+
+template <typename I>
+__global__ void gather_cols_kernel(int64_t* __restrict__ out, const int64_t* __restrict__ src, int64_t rows, int64_t ld,
+                                   const I* __restrict__ idx, int64_t m) {
+  const int64_t total = rows * m;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / m, j = t - r * m;
+    out[t] = src[r * ld + (int64_t)idx[j]];
+  }
+}
+
+__global__ void gather_i32_to_i64_kernel(int64_t* __restrict__ out, const int32_t* __restrict__ table,
+                                         const int64_t* __restrict__ idx, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (int64_t)table[idx[i]];
+}
+
+__global__ void flag_nonneg_kernel(int64_t* __restrict__ flag, const int64_t* __restrict__ vals,
+                                   const int64_t* __restrict__ via, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    flag[i] = (via ? vals[via[i]] : vals[i]) >= 0 ? 1 : 0;
+}
+
+__global__ void compact_positions_kernel(int64_t* __restrict__ pos, const int64_t* __restrict__ offsets, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (offsets[i + 1] > offsets[i]) pos[offsets[i]] = i;
+}
+
+__global__ void set_zero_i64_kernel(int64_t* p) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = 0; }
+
+__global__ void plan_triples_kernel(int64_t* __restrict__ out, const int32_t* __restrict__ slot, const int64_t* __restrict__ c,
+                                    const int64_t* __restrict__ d, const int32_t* __restrict__ perm, int64_t m) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m; t += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t p = perm[t];
+    out[t] = (int64_t)slot[p];
+    out[m + t] = c[p];
+    out[2 * m + t] = d[p];
+  }
+}
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int key_bits(int64_t n_keys) {
@@ -335,4 +401,103 @@ extern "C" int pygho_scatter_i32(int32_t* out, const int32_t* idx, const int32_t
   if (!out || !idx || !vals) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   hipLaunchKernelGGL(scatter_i32_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, idx, vals, n);
   return check_launch("scatter_i32");
+}
+
+extern "C" size_t pygho_exclusive_scan_i64_workspace(int64_t n) {
+  if (n <= 0) return 256;
+  size_t temp = 0;
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, temp, (const int64_t*)nullptr, (int64_t*)nullptr, (int)n);
+  return align256((size_t)n * sizeof(int64_t)) + align256(temp) + 256;
+}
+
+extern "C" int pygho_exclusive_scan_i64(int64_t* out, const int64_t* in, int64_t n, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+  if (n < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (!out) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(set_zero_i64_kernel, dim3(1), dim3(64), 0, st, out);
+  if (n == 0) return check_launch("exclusive_scan(empty)");
+  if (!in || !workspace) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (n > INT32_MAX) { set_error("size beyond int32"); return PYGHO_ERR_UNSUPPORTED; }
+  if (workspace_bytes < pygho_exclusive_scan_i64_workspace(n)) { set_error("workspace too small"); return PYGHO_ERR_INVALID; }
+  char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  void* temp = ws + align256((size_t)n * sizeof(int64_t));
+  size_t temp_bytes = workspace_bytes - align256((size_t)n * sizeof(int64_t)) - (size_t)(ws - (char*)workspace);
+  hipError_t e = hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, in, out + 1, (int)n, st);
+  if (e != hipSuccess) { set_error("scan: %s", hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
+  return check_launch("exclusive_scan_i64");
+}
+
+extern "C" int pygho_product_hash(int64_t* out, const int64_t* ind1, int64_t sd1, int64_t nnz1, int64_t dim1,
+                                  const int64_t* ind2, int64_t sd2, int64_t nnz2, int64_t dim2, const int64_t* c,
+                                  const int64_t* d, int64_t total, int32_t* err, void* stream) {
+  if (sd1 < 1 || sd2 < 1 || dim1 < 0 || dim1 >= sd1 || dim2 < 0 || dim2 >= sd2 || total < 0 || sd1 + sd2 - 2 < 1 || sd1 + sd2 - 2 > 63) {
+    set_error("product_hash: bad dims");
+    return PYGHO_ERR_INVALID;
+  }
+  if (total == 0) return PYGHO_OK;
+  if (!out || !ind1 || !ind2 || !c || !d) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  const int sd = (int)(sd1 + sd2 - 2);
+  hipLaunchKernelGGL(product_hash_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, ind1,
+                     (int)sd1, nnz1, (int)dim1, ind2, (int)sd2, nnz2, (int)dim2, c, d, total, sd == 1 ? 62 : 63 / sd, err);
+  return check_launch("product_hash");
+}
+
+extern "C" int pygho_gather_cols_i64(int64_t* out, const int64_t* src, int64_t rows, int64_t ld, const void* idx,
+                                     int idx_is_i32, int64_t m, void* stream) {
+  if (rows < 0 || m < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (rows == 0 || m == 0) return PYGHO_OK;
+  if (!out || !src || !idx) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  if (idx_is_i32)
+    hipLaunchKernelGGL((gather_cols_kernel<int32_t>), dim3(grid_for(rows * m, kBlock)), dim3(kBlock), 0, st, out, src, rows, ld,
+                       (const int32_t*)idx, m);
+  else
+    hipLaunchKernelGGL((gather_cols_kernel<int64_t>), dim3(grid_for(rows * m, kBlock)), dim3(kBlock), 0, st, out, src, rows, ld,
+                       (const int64_t*)idx, m);
+  return check_launch("gather_cols_i64");
+}
+
+extern "C" int pygho_gather_i32_to_i64(int64_t* out, const int32_t* table, const int64_t* idx, int64_t n, void* stream) {
+  if (n < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n == 0) return PYGHO_OK;
+  if (!out || !table || !idx) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(gather_i32_to_i64_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, table, idx, n);
+  return check_launch("gather_i32_to_i64");
+}
+
+extern "C" int pygho_flag_scan_nonneg(int64_t* offsets, const int64_t* vals, const int64_t* via, int64_t n, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  if (n < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (!offsets) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) { hipLaunchKernelGGL(set_zero_i64_kernel, dim3(1), dim3(64), 0, st, offsets); return check_launch("flag_scan(empty)"); }
+  if (!vals || !workspace) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (workspace_bytes < pygho_exclusive_scan_i64_workspace(n)) { set_error("workspace too small"); return PYGHO_ERR_INVALID; }
+  char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  int64_t* flag = (int64_t*)ws;
+  hipLaunchKernelGGL(flag_nonneg_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, st, flag, vals, via, n);
+  hipLaunchKernelGGL(set_zero_i64_kernel, dim3(1), dim3(64), 0, st, offsets);
+  void* temp = ws + align256((size_t)n * sizeof(int64_t));
+  size_t temp_bytes = workspace_bytes - align256((size_t)n * sizeof(int64_t)) - (size_t)(ws - (char*)workspace);
+  hipError_t e = hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, (const int64_t*)flag, offsets + 1, (int)n, st);
+  if (e != hipSuccess) { set_error("scan: %s", hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
+  return check_launch("flag_scan_nonneg");
+}
+
+extern "C" int pygho_compact_positions(int64_t* pos, const int64_t* offsets, int64_t n, void* stream) {
+  if (n < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n == 0) return PYGHO_OK;
+  if (!offsets) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(compact_positions_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, pos, offsets, n);
+  return check_launch("compact_positions");
+}
+
+extern "C" int pygho_plan_triples(int64_t* out, const int32_t* slot, const int64_t* c, const int64_t* d, const int32_t* perm,
+                                  int64_t m, void* stream) {
+  if (m < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (m == 0) return PYGHO_OK;
+  if (!out || !slot || !c || !d || !perm) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(plan_triples_kernel, dim3(grid_for(m, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, slot, c, d, perm, m);
+  return check_launch("plan_triples");
 }

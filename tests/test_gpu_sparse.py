@@ -71,6 +71,43 @@ def test_hash_and_planner_bit_exact(dev):
     assert np.array_equal(N(Spspmm.deg2batch(T(s["deg"], dev), 6)), s["deg_batch"])
 
 
+def test_planner_primitives_bit_exact(dev):
+    """the integer glue kernels of the planner against numpy on seeded inputs, incl. empty inputs."""
+    from pygho_amd import _ops
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 63, 1000, 70001):
+        cnt = rng.integers(0, 5, n).astype(np.int64)
+        assert np.array_equal(N(_ops.exclusive_scan(T(cnt, dev))), np.concatenate(([0], np.cumsum(cnt))))
+        vals = rng.integers(-1, 3, max(n, 1)).astype(np.int64)
+        assert np.array_equal(N(_ops.nonneg_positions(T(vals[:n], dev))), np.nonzero(vals[:n] >= 0)[0])
+        via = rng.integers(0, max(n, 1), 2 * n).astype(np.int64)
+        assert np.array_equal(N(_ops.nonneg_positions(T(vals, dev), via=T(via, dev))), np.nonzero(vals[via] >= 0)[0])
+        src = rng.integers(0, 1 << 40, (3, max(n, 1))).astype(np.int64)
+        for idt in (np.int64, np.int32):
+            idx = rng.integers(0, max(n, 1), n).astype(idt)
+            assert np.array_equal(N(_ops.gather_cols(T(src, dev), T(idx, dev))), src[:, idx])
+            assert np.array_equal(N(_ops.gather_cols(T(src[1], dev), T(idx, dev))), src[1][idx])
+        tab = rng.integers(0, 1 << 30, max(n, 1)).astype(np.int32)
+        idx = rng.integers(0, max(n, 1), n).astype(np.int64)
+        assert np.array_equal(N(_ops.widen_gather(T(tab, dev), T(idx, dev))), tab[idx].astype(np.int64))
+        perm = rng.permutation(n).astype(np.int32)
+        slot = rng.integers(0, 9, n).astype(np.int32)
+        c, d = rng.integers(0, 99, n).astype(np.int64), rng.integers(0, 99, n).astype(np.int64)
+        assert np.array_equal(N(_ops.plan_triples(T(slot, dev), T(c, dev), T(d, dev), T(perm, dev))),
+                              np.stack((slot[perm].astype(np.int64), c[perm], d[perm])))
+    # product hash == indicehash of the concatenated remaining coordinates (Spspmm.py:132-135)
+    for sd1, dim1, sd2, dim2 in ((2, 1, 2, 0), (2, 0, 2, 1), (3, 1, 2, 0), (3, 2, 3, 1), (2, 1, 1, 0)):
+        ind1 = rng.integers(0, 500, (sd1, 300)).astype(np.int64)
+        ind2 = rng.integers(0, 500, (sd2, 200)).astype(np.int64)
+        c, d = rng.integers(0, 300, 4000).astype(np.int64), rng.integers(0, 200, 4000).astype(np.int64)
+        rest = np.concatenate((np.delete(ind1, dim1, 0)[:, c], np.delete(ind2, dim2, 0)[:, d]))
+        got = _ops.product_hash(T(ind1, dev), dim1, T(ind2, dev), dim2, T(c, dev), T(d, dev))
+        assert np.array_equal(N(got), O.indicehash(rest))
+    with pytest.raises(AssertionError):
+        _ops.product_hash(T(np.array([[0], [1 << 33]], dtype=np.int64), dev), 0, T(np.array([[0], [1]], dtype=np.int64), dev), 0,
+                          T(np.array([0], dtype=np.int64), dev), T(np.array([0], dtype=np.int64), dev))
+
+
 def test_scatter_reduce_golden(dev):
     from pygho_amd.backend.utils import torch_scatter_reduce
     g = load_golden("scatter.npz")

@@ -49,6 +49,33 @@ def spspmm_case(kind, graphs, d, dtype, dev):
             "G_msg_edges_per_s": m / ms / 1e6}
 
 
+def planner_case(kind, graphs, dev):
+    """device planner (Spspmm.py:57-222): tuple pattern x adjacency -> (tarind, bcd) -> acd on the tuple pattern.
+    Wall time per batch (includes the two host syncs that size the outputs)."""
+    import time
+    from pygho_amd.backend import Spspmm
+    base = 1024 if kind == "zinc" else 128
+    hb = synth.replicate(synth.make_batch(min(graphs, base), kind, seed=1), max(1, graphs // base))
+    tup = torch.from_numpy(hb.tupleid).to(dev)
+    adj = torch.from_numpy(hb.edge_index).to(dev)
+    dim1 = tup.shape[0] - 1
+
+    def run():
+        ind, bcd = Spspmm.spspmm_ind(tup, dim1, adj, 0, is_k2_sorted=True)
+        return Spspmm.filterind(tup, ind, bcd)
+    acd = run()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ms = sorted(ts)[len(ts) // 2]
+    return {"op": f"planner spspmm_ind+filterind {kind}", "graphs": hb.num_graphs, "tuples": int(tup.shape[1]),
+            "msg_edges": int(acd.shape[1]), "ms": ms, "M_msg_edges_per_s": acd.shape[1] / ms / 1e3}
+
+
 def mamamm_case(b, n, d, dtype, dev):
     from pygho_amd import MaskedTensor
     from pygho_amd.backend.Mamamm import mamamm
@@ -84,6 +111,7 @@ def main():
     out.append(mamamm_case(128, 37, 128, torch.bfloat16, dev))
     out.append(mamamm_case(128 if args.quick else 1024, 37, 128, torch.bfloat16, dev))
     out.append(mamamm_case(128 if args.quick else 1024, 37, 128, torch.float32, dev))
+    out.append(planner_case("zinc", 1024 if args.quick else 8192, dev))
     for r in out:
         print(json.dumps(r))
 
