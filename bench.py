@@ -174,8 +174,13 @@ def main():
     if rank == 0:
         assert bool(torch.isfinite(loss)), "loss is not finite"
         summ = timer.summary()
-        dom = f"seg_gmr[{'bfloat16' if act_dtype is not None else 'float32'},sum,both]"
-        launches, ms, nbytes = summ[dom]
+        # the dominant kernel is ONE template instance (seg_gmr_fast_kernel<T, SUM, BOTH>): the forward launches carry
+        # the residual row in their epilogue (",res"), the two backward launches per layer do not
+        dom = f"seg_gmr[{'bfloat16' if act_dtype is not None else 'float32'},sum,both"
+        parts = [v for k, v in summ.items() if k.startswith(dom)]
+        launches = sum(v[0] for v in parts)
+        ms = sum(v[0] * v[1] for v in parts) / launches
+        nbytes = sum(v[0] * v[2] for v in parts) / launches
         achieved = nbytes / (ms * 1e-3) / 1e9
         es = 2 if act_dtype is not None else 4
         fwd_bytes = es * args.hidden * (2 * hb.num_tuples + hb.num_edges) + 8 * hb.num_messages(KEY) + 4 * (hb.num_tuples + 1)

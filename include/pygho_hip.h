@@ -82,6 +82,15 @@ int pygho_seg_gather_mul_reduce(void* out, const void* lhs, const void* rhs,
                                 int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d,
                                 int64_t lhs_rows, int64_t rhs_rows, int dtype, int aggr, void* stream);
 
+/* Same reduction with a residual connection fused into the epilogue:
+ *   out[s, :] = addend[s, :] + (+)_{m in segment s} ...            (addend: n_seg x d, dtype of out)
+ * replaces `X.add(conv(A, X))` of the model loop (example/minimal.py:76-79, SpTensor.py `add`): the aggregate
+ * is added in the accumulation type and rounded once.  f32 results are bit-identical to reduce-then-add. */
+int pygho_seg_gather_mul_reduce_add(void* out, const void* addend, const void* lhs, const void* rhs,
+                                    const int32_t* seg_ptr, const int32_t* lhs_idx, const int32_t* rhs_idx,
+                                    const float* lhs_rowscale, int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d,
+                                    int64_t lhs_rows, int64_t rhs_rows, int dtype, int aggr, void* stream);
+
 /*
  * Backward of the max / min aggregation (autograd of scatter_reduce_(amax|amin),
  * pygho/backend/utils.py:50-55): along a plan grouped by the operand being
@@ -272,6 +281,8 @@ int pygho_masked_broadcast(void* out, const void* src, const uint8_t* mask, doub
  * pygho_bn_act_bwd: dx and the per-channel sums sum_dz (= grad of bn bias) and sum_dz_xhat (= grad of bn
  *   weight); the normalised value is recomputed from x, so the BatchNorm output is never stored.
  *   training != 0 uses batch statistics in the input gradient, 0 treats mean / invstd as constants (eval).
+ *   sum_dx (nullable, c floats): column sums of the rounded dx, i.e. the bias gradient of the Linear that
+ *   produced x (honn/utils.py:126-131), taken inside the same pass instead of a separate reduction over dx.
  * workspace: pygho_bn_workspace(m, c, dtype) bytes (0 = unsupported geometry: row bytes must be a multiple
  *   of 16 and the 16-byte chunks per row must divide 256). */
 size_t pygho_bn_workspace(int64_t m, int64_t c, int dtype);
@@ -281,7 +292,7 @@ int pygho_bn_act_fwd(void* y, const void* x, const float* scale, const float* bi
                      int act, int dtype, void* stream);
 int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy,
                      const float* mean, const float* invstd, const float* w, const float* b, int64_t m,
-                     int64_t c, int act, int training, void* workspace, int dtype, void* stream);
+                     int64_t c, int act, int training, void* workspace, int dtype, float* sum_dx, void* stream);
 
 #ifdef __cplusplus
 }

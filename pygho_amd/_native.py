@@ -29,6 +29,7 @@ PROTOTYPES = {
     "pygho_abi_version": (I, []),
     "pygho_last_error": (c_char_p, []),
     "pygho_seg_gather_mul_reduce": (I, [P, P, P, P, P, P, P, L, L, L, L, L, L, I, I, P]),
+    "pygho_seg_gather_mul_reduce_add": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, L, I, I, P]),
     "pygho_seg_sum_f32out": (I, [P, P, P, P, L, L, L, I, P]),
     "pygho_seg_extremum_ties": (I, [P, P, P, P, P, P, P, L, L, I, P]),
     "pygho_seg_extremum_bwd": (I, [P, P, P, P, P, P, P, P, P, L, L, I, P]),
@@ -64,7 +65,7 @@ PROTOTYPES = {
     "pygho_bn_workspace": (Z, [L, L, I]),
     "pygho_bn_stats": (I, [P, P, P, L, L, P, I, P]),
     "pygho_bn_act_fwd": (I, [P, P, P, P, L, L, I, I, P]),
-    "pygho_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, P, I, P]),
+    "pygho_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, P, I, P, P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -12,7 +12,7 @@ import torch
 from torch import Tensor
 
 from . import _native as N
-from ._native import AGGR_CODE, check, dtype_code, lib, ptr, require_device, stream_ptr
+from ._native import AGGR_CODE, DTYPE_CODE, check, dtype_code, lib, ptr, require_device, stream_ptr
 
 _I32 = torch.int32
 
@@ -203,21 +203,28 @@ class LaunchTimer:
 
 def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr: Tensor,
             lhs_idx: Optional[Tensor], rhs_idx: Optional[Tensor], aggr: str,
-            lhs_rowscale: Optional[Tensor] = None) -> Tensor:
-    """out[s] = (+)_{m in seg s} scale * lhs[lhs_idx[m]] * rhs[rhs_idx[m]]  (2-D operands)."""
+            lhs_rowscale: Optional[Tensor] = None, addend: Optional[Tensor] = None) -> Tensor:
+    """out[s] = [addend[s] +] (+)_{m in seg s} scale * lhs[lhs_idx[m]] * rhs[rhs_idx[m]]  (2-D operands)."""
     ref = lhs if lhs is not None else rhs
-    dev = require_device(lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale)
+    dev = require_device(lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, addend)
     d = ref.shape[1]
     out = torch.empty((out_rows, d), dtype=ref.dtype, device=dev)
     timer = LaunchTimer.active
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(dev))
-    check(lib().pygho_seg_gather_mul_reduce(
-        ptr(out), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale),
-        out_rows, d, d if lhs is not None else 0, d if rhs is not None else 0,
-        lhs.shape[0] if lhs is not None else 0, rhs.shape[0] if rhs is not None else 0,
-        dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev)), "seg_gather_mul_reduce")
+    dims = (out_rows, d, d if lhs is not None else 0, d if rhs is not None else 0,
+            lhs.shape[0] if lhs is not None else 0, rhs.shape[0] if rhs is not None else 0,
+            dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev))
+    if addend is None:
+        check(lib().pygho_seg_gather_mul_reduce(
+            ptr(out), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale), *dims),
+            "seg_gather_mul_reduce")
+    else:
+        assert addend.shape == out.shape and addend.dtype == out.dtype and addend.is_contiguous()
+        check(lib().pygho_seg_gather_mul_reduce_add(
+            ptr(out), ptr(addend), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale), *dims),
+            "seg_gather_mul_reduce_add")
     if timer is not None:
         e1.record(torch.cuda.current_stream(dev))
         # algorithmic bytes (SURVEY.md 8d): every operand row once, every output row once, int32 indices once
@@ -227,8 +234,10 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
         nbytes = es * d * rows + 4 * m * ((lhs_idx is not None) + (rhs_idx is not None)) + 4 * (out_rows + 1)
         if lhs_rowscale is not None:
             nbytes += 4 * lhs_rowscale.numel()
+        if addend is not None:
+            nbytes += es * d * out_rows
         mode = "both" if (lhs is not None and rhs is not None) else ("lhs" if lhs is not None else "rhs")
-        timer.records.append((f"seg_gmr[{str(ref.dtype).split('.')[-1]},{aggr},{mode}{',scaled' if lhs_rowscale is not None else ''}]",
+        timer.records.append((f"seg_gmr[{str(ref.dtype).split('.')[-1]},{aggr},{mode}{',scaled' if lhs_rowscale is not None else ''}{',res' if addend is not None else ''}]",
                               nbytes, e0, e1))
     return out
 
@@ -978,50 +987,78 @@ def bn_act_supported(x: Tensor) -> bool:
             and int(lib().pygho_bn_workspace(x.shape[0], x.shape[1], dtype_code(x))) > 0)
 
 
+def _bn_forward(x: Tensor, weight, bias, running_mean, running_var, training: bool, eps: float, act: str):
+    """(y, mean, var, saved) of act(batch_norm(x)) for a contiguous 2-D x."""
+    dev = x.device
+    m, c = x.shape
+    dt = dtype_code(x)
+    st = stream_ptr(dev)
+    nbytes = int(lib().pygho_bn_workspace(m, c, dt))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if training:
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        var = torch.empty(c, dtype=torch.float32, device=dev)
+        check(lib().pygho_bn_stats(ptr(mean), ptr(var), ptr(x), m, c, ptr(ws), dt, st), "bn_stats")
+    else:
+        mean, var = running_mean.float().clone(), running_var.float().clone()
+    invstd = torch.rsqrt(var + eps)
+    w32 = weight.float() if weight is not None else torch.ones(c, dtype=torch.float32, device=dev)
+    b32 = bias.float() if bias is not None else torch.zeros(c, dtype=torch.float32, device=dev)
+    scale = (w32 * invstd).contiguous()
+    shift = (b32 - mean * scale).contiguous()
+    y = torch.empty_like(x)
+    check(lib().pygho_bn_act_fwd(ptr(y), ptr(x), ptr(scale), ptr(shift), m, c, ACT_CODE[act], dt, st), "bn_act_fwd")
+    return y, mean, var, (mean, invstd, w32, b32, ws)
+
+
+def _bn_backward(x: Tensor, gy: Tensor, saved, training: bool, act: str, want_colsum: bool = False):
+    """(dx, d bn.bias, d bn.weight, column sums of dx or None)."""
+    mean, invstd, w32, b32, ws = saved
+    m, c = x.shape
+    dev = x.device
+    dx = torch.empty_like(x)
+    s1 = torch.empty(c, dtype=torch.float32, device=dev)
+    s2 = torch.empty(c, dtype=torch.float32, device=dev)
+    sdx = torch.empty(c, dtype=torch.float32, device=dev) if want_colsum else None
+    check(lib().pygho_bn_act_bwd(ptr(dx), ptr(s1), ptr(s2), ptr(x), ptr(gy), ptr(mean), ptr(invstd), ptr(w32), ptr(b32),
+                                 m, c, ACT_CODE[act], 1 if training else 0, ptr(ws), dtype_code(x), ptr(sdx),
+                                 stream_ptr(dev)), "bn_act_bwd")
+    return dx, s1, s2, sdx
+
+
+def bn_act_supported_shape(m: int, c: int, dtype: torch.dtype) -> bool:
+    return (dtype in (torch.float32, torch.bfloat16, torch.float16) and m > 1
+            and int(lib().pygho_bn_workspace(m, c, DTYPE_CODE[dtype])) > 0)
+
+
 class _BNAct(torch.autograd.Function):
     """y = act(batch_norm(x)); training uses batch statistics (and returns them for the running averages)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act):
-        dev = require_device(x)
+        require_device(x)
         x = x.contiguous()
-        m, c = x.shape
-        dt = dtype_code(x)
-        st = stream_ptr(dev)
-        nbytes = int(lib().pygho_bn_workspace(m, c, dt))
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        if training:
-            mean = torch.empty(c, dtype=torch.float32, device=dev)
-            var = torch.empty(c, dtype=torch.float32, device=dev)
-            check(lib().pygho_bn_stats(ptr(mean), ptr(var), ptr(x), m, c, ptr(ws), dt, st), "bn_stats")
-        else:
-            mean, var = running_mean.float().clone(), running_var.float().clone()
-        invstd = torch.rsqrt(var + eps)
-        w32 = weight.float() if weight is not None else torch.ones(c, dtype=torch.float32, device=dev)
-        b32 = bias.float() if bias is not None else torch.zeros(c, dtype=torch.float32, device=dev)
-        scale = (w32 * invstd).contiguous()
-        shift = (b32 - mean * scale).contiguous()
-        y = torch.empty_like(x)
-        check(lib().pygho_bn_act_fwd(ptr(y), ptr(x), ptr(scale), ptr(shift), m, c, ACT_CODE[act], dt, st), "bn_act_fwd")
-        ctx.save_for_backward(x, mean, invstd, w32, b32)
-        ctx.meta = (training, act, ws, weight is not None, bias is not None)
+        y, mean, var, saved = _bn_forward(x, weight, bias, running_mean, running_var, training, eps, act)
+        ctx.save_for_backward(x, *saved)
+        ctx.meta = (training, act, weight is not None, bias is not None)
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, gy, _gm, _gv):
-        x, mean, invstd, w32, b32 = ctx.saved_tensors
-        training, act, ws, has_w, has_b = ctx.meta
-        gy = gy.contiguous()
-        m, c = x.shape
-        dev = x.device
-        dx = torch.empty_like(x)
-        s1 = torch.empty(c, dtype=torch.float32, device=dev)
-        s2 = torch.empty(c, dtype=torch.float32, device=dev)
-        check(lib().pygho_bn_act_bwd(ptr(dx), ptr(s1), ptr(s2), ptr(x), ptr(gy), ptr(mean), ptr(invstd), ptr(w32), ptr(b32),
-                                     m, c, ACT_CODE[act], 1 if training else 0, ptr(ws), dtype_code(x), stream_ptr(dev)),
-              "bn_act_bwd")
+        x, *saved = ctx.saved_tensors
+        training, act, has_w, has_b = ctx.meta
+        dx, s1, s2, _ = _bn_backward(x, gy.contiguous(), saved, training, act)
         return dx, (s2 if has_w else None), (s1 if has_b else None), None, None, None, None, None
+
+
+def _update_running(bn, mean: Tensor, var: Tensor, n: int) -> None:
+    if bn.training and bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var.to(bn.running_var.dtype), alpha=mom * n / max(n - 1, 1))
 
 
 def batch_norm_act(x: Tensor, bn: "torch.nn.BatchNorm1d", act: str) -> Tensor:
@@ -1029,11 +1066,90 @@ def batch_norm_act(x: Tensor, bn: "torch.nn.BatchNorm1d", act: str) -> Tensor:
     training mode, running statistics in eval mode)."""
     training = bn.training or bn.running_mean is None
     y, mean, var = _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, act)
-    if bn.training and bn.track_running_stats and bn.running_mean is not None:
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
-            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            n = x.shape[0]
-            bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
-            bn.running_var.mul_(1 - mom).add_(var.to(bn.running_var.dtype), alpha=mom * n / max(n - 1, 1))
+    _update_running(bn, mean, var, x.shape[0])
     return y
+
+
+# --------------------------------------------------------------------------
+# one tuple-wise block: Linear -> BatchNorm -> act [-> message passing [+ residual]]   (SURVEY.md 8 row f3)
+# --------------------------------------------------------------------------
+def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype) -> Tensor:
+    """dW = g^T x for tall (nnz ~ 10^6) operands as a batched split-K product: the reduction dim is the long
+    one and the BLAS heuristics pick a kernel without split-K for it (2.9 ms vs 0.19 ms at nnz = 1.8 M)."""
+    m, n, k = g.shape[0], g.shape[1], x.shape[1]
+    slabs = min(256, m // 2048)
+    if slabs < 4:
+        return (g.t() @ x).to(out_dtype)
+    rows = m // slabs
+    main = rows * slabs
+    part = torch.bmm(g[:main].view(slabs, rows, n).transpose(1, 2), x[:main].view(slabs, rows, k))
+    gw = part.float().sum(0)
+    if main < m:
+        gw = gw + (g[main:].t() @ x[main:]).float()
+    return gw.to(out_dtype)
+
+
+class _TupleBlock(torch.autograd.Function):
+    """H = act(bn(x W^T + b));  out = H                                  (plan is None)
+                                  out = [x +] (+)_{(a,c,d)} H[c] * rhs[d]   (plan given; `residual` adds x)
+    One autograd node for the whole block so that (i) the Linear's bias gradient comes out of the BatchNorm
+    backward pass, (ii) the residual add runs in the aggregation epilogue and (iii) the residual gradient is the
+    `beta = 1` accumulator of the input-gradient GEMM: no stand-alone elementwise or column-reduction pass
+    over the (nnz, d) activations is left."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, eps, act, rhs, plan, aggr, residual):
+        require_device(x, w, rhs)
+        x = x.contiguous()
+        pre = torch.nn.functional.linear(x, w, b)
+        h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act)
+        if plan is None:
+            out = h
+        else:
+            out = seg_gmr(plan.n_out, h, rhs, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd if rhs is not None else None, aggr,
+                          addend=x if residual else None)
+        ctx.save_for_backward(x, w, pre, h if plan is not None else None, rhs, *saved)
+        ctx.meta = (training, act, b is not None, gamma is not None, beta is not None, plan, aggr, residual)
+        ctx.mark_non_differentiable(mean, var)
+        return out, mean, var
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv):
+        x, w, pre, h, rhs, *saved = ctx.saved_tensors
+        training, act, has_b, has_gamma, has_beta, plan, aggr, residual = ctx.meta
+        g = g.contiguous()
+        g_rhs = None
+        gh = g
+        if plan is not None:
+            scale = plan.fwd.inv_count if aggr == "mean" else None
+            p, a_g, d_g = plan.by_c()
+            gh = seg_gmr(plan.n_lhs, g, rhs, p.seg_ptr, a_g, d_g if rhs is not None else None, "sum", scale)
+            if rhs is not None and ctx.needs_input_grad[10]:
+                p, a_g, c_g = plan.by_d()
+                g_rhs = seg_gmr(plan.n_rhs, g, h, p.seg_ptr, a_g, c_g, "sum", scale)
+        gpre, s1, s2, sdx = _bn_backward(pre, gh, saved, training, act, want_colsum=has_b and ctx.needs_input_grad[2])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.addmm(g, gpre, w) if residual else gpre @ w
+        if ctx.needs_input_grad[1]:
+            gw = weight_grad_splitk(gpre, x, w.dtype)
+        if sdx is not None:
+            gb = sdx.to(w.dtype)
+        return (gx, gw, gb, (s2 if has_gamma else None), (s1 if has_beta else None), None, None, None, None, None,
+                g_rhs, None, None, None)
+
+
+def tuple_block(x: Tensor, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", act: str, rhs: Optional[Tensor] = None,
+                plan: Optional[MessagePlan] = None, aggr: str = "sum", residual: bool = False) -> Tensor:
+    """fused Linear -> BatchNorm1d -> act (-> aggregation over `plan` with `rhs` (-> + x)); parameters are read
+    from the stock modules (f32 master weights are cast to the activation dtype like autocast would)."""
+    dt = x.dtype
+    w = lin.weight if lin.weight.dtype == dt else lin.weight.to(dt)
+    b = None if lin.bias is None else (lin.bias if lin.bias.dtype == dt else lin.bias.to(dt))
+    training = bn.training or bn.running_mean is None
+    if residual:
+        assert plan is not None and plan.n_out == x.shape[0] and lin.out_features == x.shape[1]
+    out, mean, var = _TupleBlock.apply(x, w, b, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, act,
+                                       rhs, plan, aggr, residual)
+    _update_running(bn, mean, var, x.shape[0])
+    return out

@@ -177,15 +177,17 @@ __global__ __launch_bounds__(kBlock) void bn_act_bwd_kernel(T* __restrict__ dx, 
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             const float* __restrict__ sum_dz, const float* __restrict__ sum_dz_xhat,
-                                                            int64_t m, int c, int chunks, int training) {
+                                                            float* __restrict__ colsum_ws, int64_t m, int c, int chunks, int training) {
   constexpr int N = Vec16<T>::N;
+  __shared__ float red[kBlock][Vec16<T>::N];
   const int tpr = chunks, rows_per_it = kBlock / tpr;
   const int chunk = threadIdx.x % tpr, rlane = threadIdx.x / tpr;
   const float inv_m = 1.f / (float)m;
-  float mu[N], is[N], ww[N], bb[N], k1[N], k2[N];
+  float mu[N], is[N], ww[N], bb[N], k1[N], k2[N], cs[N];
 #pragma unroll
   for (int q = 0; q < N; ++q) {
     mu[q] = mean[chunk * N + q]; is[q] = invstd[chunk * N + q]; ww[q] = w ? w[chunk * N + q] : 1.f; bb[q] = b ? b[chunk * N + q] : 0.f;
+    cs[q] = 0.f;
     k1[q] = training ? sum_dz[chunk * N + q] * inv_m : 0.f;
     k2[q] = training ? sum_dz_xhat[chunk * N + q] * inv_m : 0.f;
   }
@@ -199,8 +201,37 @@ __global__ __launch_bounds__(kBlock) void bn_act_bwd_kernel(T* __restrict__ dx, 
       const float dz = g[q] * act_grad<ACT>(xh * ww[q] + bb[q]);
       v[q] = ww[q] * is[q] * (dz - k1[q] - xh * k2[q]);
     }
-    *reinterpret_cast<uint4*>(dx + r * c + (int64_t)chunk * N) = Vec16<T>::pack(v);
+    const uint4 packed = Vec16<T>::pack(v);
+    *reinterpret_cast<uint4*>(dx + r * c + (int64_t)chunk * N) = packed;
+    if (colsum_ws) {                            // column sums of the ROUNDED dx: bias gradient of the producing Linear
+      Vec16<T>::unpack(packed, v);
+#pragma unroll
+      for (int q = 0; q < N; ++q) cs[q] += v[q];
+    }
   }
+  if (colsum_ws) {                              // wave-uniform
+#pragma unroll
+    for (int q = 0; q < N; ++q) red[threadIdx.x][q] = cs[q];
+    __syncthreads();
+    if (rlane == 0) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        float a = 0.f;
+        for (int j = 0; j < rows_per_it; ++j) a += red[j * tpr + chunk][q];
+        colsum_ws[((int64_t)blockIdx.x * 2 + 0) * c + chunk * N + q] = a;
+        colsum_ws[((int64_t)blockIdx.x * 2 + 1) * c + chunk * N + q] = 0.f;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kFinParts * kFinCh) void bn_colsum_final_kernel(float* __restrict__ sum_dx, const float* __restrict__ ws,
+                                                                             int c, int nblk) {
+  double a, b;
+  final_sums(a, b, ws, c, nblk, blockIdx.x * kFinCh);
+  const int ch = blockIdx.x * kFinCh + threadIdx.x % kFinCh;
+  if (threadIdx.x >= kFinCh || ch >= c) return;
+  sum_dx[ch] = (float)a;
 }
 
 static int bn_geometry(int64_t m, int64_t c, int dtype, int* chunks, int* grid) {
@@ -269,7 +300,7 @@ extern "C" int pygho_bn_act_fwd(void* y, const void* x, const float* scale, cons
 
 extern "C" int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
                                 const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act, int training,
-                                void* workspace, int dtype, void* stream) {
+                                void* workspace, int dtype, float* sum_dx, void* stream) {
   if (m <= 0 || c <= 0) { set_error("bn_act_bwd: empty input"); return PYGHO_ERR_INVALID; }
   if (!dx || !sum_dz || !sum_dz_xhat || !x || !gy || !mean || !invstd || !workspace) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   int chunks, grid;
@@ -281,7 +312,11 @@ extern "C" int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, con
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, st, sum_dz, sum_dz_xhat,
                        (const float*)workspace, (int)c, grid);
     hipLaunchKernelGGL((bn_act_bwd_kernel<T, A>), dim3(grid), dim3(kBlock), 0, st, (T*)dx, (const T*)x, (const T*)gy, mean, invstd,
-                       w, b, (const float*)sum_dz, (const float*)sum_dz_xhat, m, (int)c, chunks, training);
+                       w, b, (const float*)sum_dz, (const float*)sum_dz_xhat, sum_dx ? (float*)workspace : (float*)nullptr, m, (int)c,
+                       chunks, training);
+    if (sum_dx)
+      hipLaunchKernelGGL(bn_colsum_final_kernel, dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, st, sum_dx,
+                         (const float*)workspace, (int)c, grid);
   }));
   return check_launch("bn_act_bwd");
 }

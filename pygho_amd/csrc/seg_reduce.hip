@@ -59,7 +59,7 @@ template <typename T, int AGGR, int MODE, bool SCALED, bool OFF32, bool OUTF32 =
 __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
     T* __restrict__ out, const T* __restrict__ lhs, const T* __restrict__ rhs,
     const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ lhs_idx,
-    const int32_t* __restrict__ rhs_idx, const float* __restrict__ lhs_rowscale,
+    const int32_t* __restrict__ rhs_idx, const float* __restrict__ lhs_rowscale, const T* __restrict__ addend,
     int64_t n_seg, int d, int chunks, int log2g, int spp) {
   using V = Vec16<T>;
   using R = Reduce<AGGR, float>;
@@ -118,6 +118,8 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
       float acc[N];
 #pragma unroll
       for (int q = 0; q < N; ++q) acc[q] = R::init();
+      uint4 res;                                   // residual row (wave-uniform branch), in flight during the reduction
+      if (addend) res = load_row16<OFF32>(reinterpret_cast<const char*>(addend), (int)(base + i), row_bytes, col_bytes);
       for (int m0 = beg; m0 < end; m0 += 2) {
         const bool two = m0 + 1 < end;
         const int m1 = two ? m0 + 1 : m0;
@@ -143,6 +145,12 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
         if (AGGR == PYGHO_MEAN) acc[q] = cnt > 0 ? mean_div(acc[q], cnt) : 0.f;
         if (AGGR == PYGHO_MAX || AGGR == PYGHO_MIN) acc[q] = cnt > 0 ? acc[q] : 0.f;
       }
+      if (addend) {                                // out = addend + reduction (the layer's residual connection)
+        float rv[N];
+        V::unpack(res, rv);
+#pragma unroll
+        for (int q = 0; q < N; ++q) acc[q] = rv[q] + acc[q];
+      }
       if (active) {
         if (OUTF32) {   // f32 partial sums of a 16-bit operand (first level of a long-segment reduction)
           float* orow = reinterpret_cast<float*>(obase) + ((int64_t)(base + i) * d + (int64_t)chunk * N);
@@ -164,7 +172,7 @@ template <typename T, int AGGR>
 __global__ __launch_bounds__(kBlock) void seg_gmr_generic_kernel(
     T* __restrict__ out, const T* __restrict__ lhs, const T* __restrict__ rhs,
     const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ lhs_idx,
-    const int32_t* __restrict__ rhs_idx, const float* __restrict__ lhs_rowscale,
+    const int32_t* __restrict__ rhs_idx, const float* __restrict__ lhs_rowscale, const T* __restrict__ addend,
     int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d) {
   using A = typename Acc<T>::type;
   using R = Reduce<AGGR, A>;
@@ -190,6 +198,7 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_generic_kernel(
     const int cnt = end - beg;
     if (AGGR == PYGHO_MEAN) acc = cnt > 0 ? mean_div(acc, cnt) : (A)0;
     if (AGGR == PYGHO_MAX || AGGR == PYGHO_MIN) acc = cnt > 0 ? acc : (A)0;
+    if (addend) acc = load_as_acc<T>(addend + t) + acc;
     store_from_acc<T>(out + t, acc);
   }
 }
@@ -292,7 +301,7 @@ static inline int segs_per_pass(int64_t n_seg, int log2g) {
 
 template <typename T, int AGGR, bool OFF32>
 int launch_fast_off(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
-                    const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, hipStream_t st) {
+                    const int32_t* rhs_idx, const float* scale, const void* addend, int64_t n_seg, int64_t d, hipStream_t st) {
   const int chunks = (int)(d * sizeof(T) / 16);
   int log2g = 0;
   while ((1 << log2g) < chunks && log2g < 6) ++log2g;
@@ -302,7 +311,7 @@ int launch_fast_off(void* out, const void* lhs, const void* rhs, const int32_t* 
   dim3 grid(gx, (unsigned)ceil_div(chunks, kWave));
 #define PYGHO_LAUNCH(MODE, SC)                                                                                          \
   hipLaunchKernelGGL((seg_gmr_fast_kernel<T, AGGR, MODE, SC, OFF32>), grid, dim3(kBlock), 0, st, (T*)out, (const T*)lhs, \
-                     (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, (int)d, chunks, log2g, spp)
+                     (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, (const T*)addend, n_seg, (int)d, chunks, log2g, spp)
   if (lhs && rhs) { if (scale) PYGHO_LAUNCH(MODE_BOTH, true); else PYGHO_LAUNCH(MODE_BOTH, false); }
   else if (lhs)   { if (scale) PYGHO_LAUNCH(MODE_LHS, true);  else PYGHO_LAUNCH(MODE_LHS, false); }
   else            { PYGHO_LAUNCH(MODE_RHS, false); }
@@ -312,36 +321,37 @@ int launch_fast_off(void* out, const void* lhs, const void* rhs, const int32_t* 
 
 template <typename T, int AGGR>
 int launch_fast(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
-                const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, int64_t lhs_rows, int64_t rhs_rows,
-                hipStream_t st) {
+                const int32_t* rhs_idx, const float* scale, const void* addend, int64_t n_seg, int64_t d, int64_t lhs_rows,
+                int64_t rhs_rows, hipStream_t st) {
   const int64_t rb = d * (int64_t)sizeof(T);
   const int64_t lim = (int64_t)1 << 32;
   const bool off32 = n_seg * rb < lim && (!lhs || (lhs_rows > 0 && lhs_rows * rb < lim)) && (!rhs || (rhs_rows > 0 && rhs_rows * rb < lim));
-  if (off32) return launch_fast_off<T, AGGR, true>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, st);
-  return launch_fast_off<T, AGGR, false>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, st);
+  if (off32) return launch_fast_off<T, AGGR, true>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, addend, n_seg, d, st);
+  return launch_fast_off<T, AGGR, false>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, addend, n_seg, d, st);
 }
 
 template <typename T, int AGGR>
 int launch_generic(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
-                   const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d,
-                   hipStream_t st) {
+                   const int32_t* rhs_idx, const float* scale, const void* addend, int64_t n_seg, int64_t d, int64_t lhs_d,
+                   int64_t rhs_d, hipStream_t st) {
   hipLaunchKernelGGL((seg_gmr_generic_kernel<T, AGGR>), dim3(grid_for(n_seg * d, kBlock)), dim3(kBlock), 0, st, (T*)out,
-                     (const T*)lhs, (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, lhs_d, rhs_d);
+                     (const T*)lhs, (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, (const T*)addend, n_seg, d, lhs_d, rhs_d);
   return check_launch("seg_gather_mul_reduce(generic)");
 }
 
 template <typename T, bool FAST_OK>
 int dispatch_aggr(int aggr, void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
-                  const int32_t* rhs_idx, const float* scale, int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d,
+                  const int32_t* rhs_idx, const float* scale, const void* addend, int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d,
                   int64_t lhs_rows, int64_t rhs_rows, hipStream_t st) {
   bool fast = FAST_OK && (d * sizeof(T)) % 16 == 0 && (!lhs || lhs_d == d) && (!rhs || rhs_d == d) && (lhs || rhs) &&
-              ((uintptr_t)out % 16 == 0) && ((uintptr_t)lhs % 16 == 0) && ((uintptr_t)rhs % 16 == 0) && !(scale && !lhs);
+              ((uintptr_t)out % 16 == 0) && ((uintptr_t)lhs % 16 == 0) && ((uintptr_t)rhs % 16 == 0) && ((uintptr_t)addend % 16 == 0) &&
+              !(scale && !lhs);
 #define PYGHO_CASE(AG)                                                                                              \
   case AG:                                                                                                         \
     if constexpr (FAST_OK) {                                                                                       \
-      if (fast) return launch_fast<T, AG>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, lhs_rows, rhs_rows, st); \
+      if (fast) return launch_fast<T, AG>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, addend, n_seg, d, lhs_rows, rhs_rows, st); \
     }                                                                                                              \
-    return launch_generic<T, AG>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, n_seg, d, lhs_d, rhs_d, st);
+    return launch_generic<T, AG>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, addend, n_seg, d, lhs_d, rhs_d, st);
   switch (aggr) {
     PYGHO_CASE(PYGHO_SUM)
     PYGHO_CASE(PYGHO_MEAN)
@@ -358,10 +368,10 @@ int dispatch_aggr(int aggr, void* out, const void* lhs, const void* rhs, const i
 
 using namespace pygho;
 
-extern "C" int pygho_seg_gather_mul_reduce(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr,
+static int seg_gmr_entry(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr,
                                            const int32_t* lhs_idx, const int32_t* rhs_idx, const float* lhs_rowscale,
                                            int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d, int64_t lhs_rows,
-                                           int64_t rhs_rows, int dtype, int aggr, void* stream) {
+                                           int64_t rhs_rows, int dtype, int aggr, const void* addend, void* stream) {
   if (n_seg < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
   if (n_seg == 0 || d == 0) return PYGHO_OK;
   if (!out || !seg_ptr) { set_error("null out / seg_ptr"); return PYGHO_ERR_INVALID; }
@@ -371,13 +381,30 @@ extern "C" int pygho_seg_gather_mul_reduce(void* out, const void* lhs, const voi
   }
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {
-    case PYGHO_F32: return dispatch_aggr<float, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
-    case PYGHO_BF16: return dispatch_aggr<bf16, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
-    case PYGHO_F16: return dispatch_aggr<f16, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
-    case PYGHO_F64: return dispatch_aggr<double, false>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
-    case PYGHO_I64: return dispatch_aggr<int64_t, false>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
+    case PYGHO_F32: return dispatch_aggr<float, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, addend, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
+    case PYGHO_BF16: return dispatch_aggr<bf16, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, addend, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
+    case PYGHO_F16: return dispatch_aggr<f16, true>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, addend, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
+    case PYGHO_F64: return dispatch_aggr<double, false>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, addend, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
+    case PYGHO_I64: return dispatch_aggr<int64_t, false>(aggr, out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, addend, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, st);
     default: set_error("unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED;
   }
+}
+
+extern "C" int pygho_seg_gather_mul_reduce(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr,
+                                           const int32_t* lhs_idx, const int32_t* rhs_idx, const float* lhs_rowscale,
+                                           int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d, int64_t lhs_rows,
+                                           int64_t rhs_rows, int dtype, int aggr, void* stream) {
+  return seg_gmr_entry(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, dtype, aggr,
+                       nullptr, stream);
+}
+
+extern "C" int pygho_seg_gather_mul_reduce_add(void* out, const void* addend, const void* lhs, const void* rhs,
+                                               const int32_t* seg_ptr, const int32_t* lhs_idx, const int32_t* rhs_idx,
+                                               const float* lhs_rowscale, int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d,
+                                               int64_t lhs_rows, int64_t rhs_rows, int dtype, int aggr, void* stream) {
+  if (!addend && n_seg > 0 && d > 0) { set_error("null addend"); return PYGHO_ERR_INVALID; }
+  return seg_gmr_entry(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, n_seg, d, lhs_d, rhs_d, lhs_rows, rhs_rows, dtype, aggr,
+                       addend, stream);
 }
 
 #define PYGHO_FLOAT_DISPATCH(dtype, CALL)                           \
@@ -457,7 +484,7 @@ extern "C" int pygho_seg_sum_f32out(float* out, const void* src, const int32_t* 
   if (!out || !src || !seg_ptr) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   if (dtype == PYGHO_F32)
-    return dispatch_aggr<float, true>(PYGHO_SUM, out, src, nullptr, seg_ptr, idx, nullptr, nullptr, n_seg, d, d, 0, src_rows, 0, st);
+    return dispatch_aggr<float, true>(PYGHO_SUM, out, src, nullptr, seg_ptr, idx, nullptr, nullptr, nullptr, n_seg, d, d, 0, src_rows, 0, st);
   if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("seg_sum_f32out: unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED; }
   if ((d * 2) % 16 != 0 || (uintptr_t)src % 16 != 0 || (uintptr_t)out % 16 != 0) {
     set_error("seg_sum_f32out: rows must be 16-byte multiples");
@@ -474,7 +501,7 @@ extern "C" int pygho_seg_sum_f32out(float* out, const void* src, const int32_t* 
 #define PYGHO_L(T, O32)                                                                                                 \
   hipLaunchKernelGGL((seg_gmr_fast_kernel<T, PYGHO_SUM, MODE_LHS, false, O32, true>), grid, dim3(kBlock), 0, st, (T*)out, \
                      (const T*)src, (const T*)nullptr, seg_ptr, idx, (const int32_t*)nullptr, (const float*)nullptr,      \
-                     n_seg, (int)d, chunks, log2g, spp)
+                     (const T*)nullptr, n_seg, (int)d, chunks, log2g, spp)
   if (dtype == PYGHO_BF16) { if (off32) PYGHO_L(bf16, true); else PYGHO_L(bf16, false); }
   else { if (off32) PYGHO_L(f16, true); else PYGHO_L(f16, false); }
 #undef PYGHO_L

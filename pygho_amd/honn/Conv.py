@@ -16,7 +16,9 @@ from torch import Tensor
 from torch.nn import Module
 
 from . import TensorOp
+from .SpOperator import KEYSEP, OpMessagePassing
 from .utils import MLP
+from .. import _ops
 from ..backend.MaTensor import MaskedTensor
 from ..backend.SpTensor import SparseTensor
 
@@ -59,6 +61,29 @@ def _views(mode: str, pool: str):
     }
 
 
+def _residual_update(layer, A: Rep, X: Rep, datadict: dict) -> Rep:
+    """X + aggr(lin(X), A) for the layers whose update is `tuple-wise MLP, then X A inside the subgraph`.  Fused
+    path (sparse X and A on the device, single-block MLP with square weight, sum / mean, precomputed acd):
+    GEMM -> BatchNorm+act kernels -> aggregation kernel with the residual row added in its epilogue, one
+    autograd node (``_ops.tuple_block``)."""
+    op = getattr(layer.aggr, "mod", None)
+    block = layer.lin.single_block() if isinstance(layer.lin, MLP) else None
+    acd = None if op is None or datadict is None else datadict.get(getattr(op, "precomputekey", "") + KEYSEP + "acd")
+    ok = (isinstance(X, SparseTensor) and isinstance(A, SparseTensor) and isinstance(op, OpMessagePassing)
+          and not op.use_mpnn and op.aggr in ("sum", "mean") and block is not None and acd is not None
+          and X.values is not None and A.values is not None and X.values.is_cuda and X.values.dim() == 2
+          and A.values.dim() == 2 and A.values.shape[1] == X.values.shape[1] and A.values.dtype == X.values.dtype
+          and block[0].in_features == block[0].out_features == X.values.shape[1]
+          and _ops.bn_act_supported_shape(X.nnz, X.values.shape[1], X.values.dtype))
+    if not ok:
+        return X.add(layer.forward(A, X, datadict), True)
+    lin, bn, act = block
+    plan = _ops.message_plan(acd, X.nnz, X.nnz, A.nnz)
+    with torch.autocast("cuda", enabled=False):
+        vals = _ops.tuple_block(X.values, lin, bn, act, rhs=A.values, plan=plan, aggr=op.aggr, residual=True)
+    return X.tuplewiseapply(lambda _: vals)
+
+
 class NGNNConv(Module):
     """nested GNN layer (reference Conv.py:20-58): tuple-wise MLP, then message passing inside each subgraph."""
 
@@ -71,6 +96,11 @@ class NGNNConv(Module):
     def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
         H = X.tuplewiseapply(self.lin)
         return self.aggr.forward(A, H, datadict, H)
+
+    def forward_residual(self, A: Rep, X: Rep, datadict: dict) -> Rep:
+        """``X.add(self.forward(A, X, datadict), True)`` (the model loop of example/minimal.py:76-79) as one fused
+        block when the layer is sparse with a single Linear -> BatchNorm -> act update; otherwise exactly that."""
+        return _residual_update(self, A, X, datadict)
 
 
 class SSWLConv(Module):
@@ -100,6 +130,10 @@ class I2Conv(Module):
     def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
         H = X.tuplewiseapply(self.lin)
         return self.aggr.forward(A, H, datadict, H)
+
+    def forward_residual(self, A: Rep, X: Rep, datadict: dict) -> Rep:
+        """``X.add(self.forward(A, X, datadict), True)``, fused when possible (see NGNNConv.forward_residual)."""
+        return _residual_update(self, A, X, datadict)
 
 
 class DSSGNNConv(Module):

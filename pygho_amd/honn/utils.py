@@ -17,9 +17,7 @@ class _SplitKLinearFn(torch.autograd.Function):
     """y = x W^T + b with the weight gradient computed as a batched split-K product.
 
     The tuple-wise MLPs see (nnz ~ 10^6, d = 128) activations, so dW = g^T x is a (d x nnz) @ (nnz x d)
-    GEMM whose reduction dim is the long one; the BLAS heuristics pick a kernel without split-K for it
-    (2.9 ms vs 0.19 ms on MI355X at nnz = 1.8 M).  Slicing nnz into S slabs turns it into S independent
-    small GEMMs plus one tiny sum."""
+    GEMM whose reduction dim is the long one (``_ops.weight_grad_splitk``)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -31,24 +29,9 @@ class _SplitKLinearFn(torch.autograd.Function):
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         g = g.contiguous()
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = g @ w
-        if ctx.needs_input_grad[1]:
-            m, n, k = g.shape[0], g.shape[1], x.shape[1]
-            slabs = min(256, m // 2048)
-            if slabs >= 4:
-                rows = m // slabs
-                main = rows * slabs
-                part = torch.bmm(g[:main].view(slabs, rows, n).transpose(1, 2), x[:main].view(slabs, rows, k))
-                gw = part.float().sum(0)
-                if main < m:
-                    gw = gw + (g[main:].t() @ x[main:]).float()
-                gw = gw.to(w.dtype)
-            else:
-                gw = g.t() @ x
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(0)
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = _ops.weight_grad_splitk(g, x, w.dtype) if ctx.needs_input_grad[1] else None
+        gb = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb
 
 
@@ -155,18 +138,38 @@ class MLP(nn.Module):
             blocks.append(act_dict[act])
         self.lins = nn.Sequential(*blocks)
 
+    def single_block(self):
+        """(Linear, BatchNorm1d, act name) when this MLP is exactly one Linear -> BatchNorm -> SiLU/ReLU block
+        (the shape every shipped layer uses for its tuple-wise update), else None."""
+        if not isinstance(self.lins, nn.Sequential) or len(self.lins) != 3:
+            return None
+        lin, norm, act = self.lins
+        name = _ACT_NAMES.get(type(act))
+        if isinstance(lin, nn.Linear) and type(norm) is BatchNorm and name is not None:
+            return lin, norm.norm, name
+        return None
+
     def forward(self, x: Tensor):
         if not isinstance(self.lins, nn.Sequential):
             return self.lins(x)
-        # same module sequence as the reference; [BatchNorm, act] pairs on device tensors run as ONE fused HIP
-        # kernel pair (the BatchNorm output is never materialised), everything else is the stock module
+        # same module sequence as the reference.  On device tensors a [Linear, BatchNorm, act] run is ONE autograd
+        # node (GEMM + fused BatchNorm/activation kernels; the bias gradient falls out of the BatchNorm backward
+        # pass) and a [BatchNorm, act] pair is one fused kernel pair; everything else is the stock module.
         mods = list(self.lins)
         i = 0
         while i < len(mods):
             mod = mods[i]
-            nxt = mods[i + 1] if i + 1 < len(mods) else None
-            act = {nn.SiLU: "silu", nn.ReLU: "relu"}.get(type(nxt)) if nxt is not None else None
+            if isinstance(mod, nn.Linear) and i + 1 < len(mods) and type(mods[i + 1]) is BatchNorm and x.is_cuda and x.dim() >= 2:
+                act = _ACT_NAMES.get(type(mods[i + 2])) if i + 2 < len(mods) else None
+                x2 = _autocast_input(x.flatten(0, -2) if x.dim() > 2 else x)
+                if x2.shape[0] >= 8192 and _ops.bn_act_supported_shape(x2.shape[0], mod.out_features, x2.dtype):
+                    with torch.autocast("cuda", enabled=False):
+                        y = _ops.tuple_block(x2, mod, mods[i + 1].norm, act or "none")
+                    x = y.reshape(tuple(x.shape[:-1]) + (mod.out_features,))
+                    i += 3 if act is not None else 2
+                    continue
             if type(mod) is BatchNorm and x.is_cuda and x.dim() >= 2:
+                act = _ACT_NAMES.get(type(mods[i + 1])) if i + 1 < len(mods) else None
                 x2 = x.flatten(0, -2) if x.dim() > 2 else x
                 if _ops.bn_act_supported(x2):
                     y = _ops.batch_norm_act(x2, mod.norm, act or "none")
@@ -176,3 +179,13 @@ class MLP(nn.Module):
             x = mod(x)
             i += 1
         return x
+
+
+_ACT_NAMES = {nn.SiLU: "silu", nn.ReLU: "relu"}
+
+
+def _autocast_input(x: Tensor) -> Tensor:
+    if torch.is_autocast_enabled("cuda") and x.is_floating_point():
+        dt = torch.get_autocast_dtype("cuda")
+        return x if x.dtype == dt else x.to(dt)
+    return x

@@ -86,8 +86,7 @@ class SpModel(nn.Module):
         A, X, x = datadict["A"], datadict["X"], datadict["x"]
         X = self.tupleinit(X, x)
         for conv in self.subggnns:
-            tX = conv.forward(A, X, datadict)
-            X = X.add(tX, True)
+            X = conv.forward_residual(A, X, datadict)      # == X.add(conv.forward(A, X, datadict), True), fused
         x = self.lpool(X)
         x = self.poolmlp(x)
         h_graph = torch_scatter_reduce(0, x, datadict["batch"], datadict["num_graphs"], self.npool)

@@ -169,3 +169,108 @@ def test_fused_batchnorm_act_matches_torch(dev, dtype, act):
         torch.testing.assert_close(bn1.running_mean, bn2.running_mean, rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(bn1.running_var, bn2.running_var, rtol=1e-4, atol=1e-4)
         assert int(bn1.num_batches_tracked) == int(bn2.num_batches_tracked)
+
+
+def _ngnn_inputs(dev, dtype, graphs=64, h=128, seed=5):
+    from pygho_amd import SparseTensor, synth
+    hb = synth.make_batch(graphs, "zinc", seed=seed)
+    n = hb.num_nodes
+    torch.manual_seed(seed)
+    A = SparseTensor(T(hb.edge_index, dev), (torch.randn(hb.num_edges, h, device=dev) * 0.3).to(dtype), [n, n, h], True)
+    xv = (torch.randn(hb.num_tuples, h, device=dev)).to(dtype)
+    tid = T(hb.tupleid, dev)
+    dd = {k + "___acd": T(v, dev) for k, v in hb.acd.items()}
+    return A, tid, xv, dd, n
+
+
+def test_residual_aggregation_epilogue_bit_exact(dev):
+    """out = addend + segment reduction in ONE launch is bit-identical (f32) to reduce, then add; bf16 rounds once."""
+    from pygho_amd import _ops
+    A, tid, xv, dd, n = _ngnn_inputs(dev, torch.float32)
+    acd = dd["X___X___1___A___0___acd"]
+    plan = _ops.message_plan(acd, xv.shape[0], xv.shape[0], A.nnz)
+    for aggr in ("sum", "mean", "max"):
+        plain = _ops.seg_gmr(plan.n_out, xv, A.values, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, aggr)
+        fused = _ops.seg_gmr(plan.n_out, xv, A.values, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, aggr, addend=xv)
+        assert torch.equal(fused, xv + plain), aggr
+    xb, ab = xv.bfloat16(), A.values.bfloat16()
+    fused = _ops.seg_gmr(plan.n_out, xb, ab, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, "sum", addend=xb)
+    exact = xb.float() + _ops.seg_gmr(plan.n_out, xb.float(), ab.float(), plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, "sum")
+    assert torch.equal(fused, exact.bfloat16())        # f32 accumulate of exact products, one rounding
+    # generic path (d not a multiple of the 16-byte vector)
+    x5, a5 = xv[:, :5].contiguous(), A.values[:, :5].contiguous()
+    plain = _ops.seg_gmr(plan.n_out, x5, a5, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, "sum")
+    assert torch.equal(_ops.seg_gmr(plan.n_out, x5, a5, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, "sum", addend=x5), x5 + plain)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("aggr", ["sum", "mean"])
+def test_fused_residual_layer_matches_unfused(dev, dtype, aggr):
+    """NGNNConv.forward_residual (one autograd node: GEMM, fused BatchNorm+act, aggregation with residual epilogue,
+    bias gradient from the BatchNorm backward, residual gradient as the GEMM accumulator) against
+    X.add(conv.forward(A, X, datadict), True) built from the separately tested operators: values, input / adjacency /
+    parameter gradients and BatchNorm running statistics, training and eval mode."""
+    import copy
+    from pygho_amd import SparseTensor
+    from pygho_amd.honn import Conv
+    h = 128
+    A, tid, xv, dd, n = _ngnn_inputs(dev, dtype, graphs=700)      # nnz > 8192: the MLP's fused Linear path too
+    torch.manual_seed(1)
+    w = torch.randn(xv.shape, device=dev)
+    f32 = dtype == torch.float32
+    for training in (True, False):
+        la = Conv.NGNNConv(h, h, aggr, "SS", dict(MLP)).to(dev)
+        with torch.no_grad():
+            la.lin.lins[1].norm.weight.uniform_(0.5, 1.5)
+            la.lin.lins[1].norm.bias.normal_(0, 0.3)
+        lb = copy.deepcopy(la)
+        la.train(training); lb.train(training)
+        res = {}
+        for name, layer in (("fused", la), ("plain", lb)):
+            x = xv.clone().requires_grad_(True)
+            av = A.values.clone().requires_grad_(True)
+            Ax = SparseTensor(A.indices, av, A.shape, True)
+            X = SparseTensor(tid, x, [n, n, h], True)
+            if name == "fused":
+                out = layer.forward_residual(Ax, X, dd)
+            else:
+                H = layer.lin.lins[2](layer.lin.lins[1](torch.nn.functional.linear(x, layer.lin.lins[0].weight.to(dtype),
+                                                                                   layer.lin.lins[0].bias.to(dtype))))
+                out = X.add(layer.aggr.forward(Ax, SparseTensor(tid, H, [n, n, h], True), dd, X), True)
+            (out.values.float() * w).sum().backward()
+            res[name] = (out.values.float(), x.grad.float(), av.grad.float(), {k: p.grad.float() for k, p in layer.named_parameters()},
+                         layer.lin.lins[1].norm.running_mean.clone(), layer.lin.lins[1].norm.running_var.clone())
+        fa, fb = res["fused"], res["plain"]
+        tol = dict(rtol=2e-4, atol=2e-4) if f32 else dict(rtol=3e-2, atol=6e-2)
+        torch.testing.assert_close(fa[0], fb[0], **tol)
+        torch.testing.assert_close(fa[1], fb[1], **tol)
+        scale = float(fb[2].abs().max())
+        torch.testing.assert_close(fa[2] / scale, fb[2] / scale, rtol=0, atol=1e-4 if f32 else 2e-2)
+        for k in fa[3]:
+            ref = fb[3][k]
+            s = float(ref.abs().max()) + 1e-6
+            if k.endswith("lins.0.bias") and training:
+                # mathematically zero (a bias before BatchNorm): both sides are rounding noise around 0
+                assert float(fa[3][k].abs().max()) <= 1e-3 * float(fb[3]["lin.lins.0.weight"].abs().max()) * (1 if f32 else 200), k
+                continue
+            torch.testing.assert_close(fa[3][k] / s, ref / s, rtol=0, atol=2e-4 if f32 else 3e-2, msg=k)
+        torch.testing.assert_close(fa[4], fb[4], rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(fa[5], fb[5], rtol=1e-3, atol=1e-3)
+
+
+def test_bn_backward_column_sums(dev):
+    """the bias gradient of the Linear in front of a BatchNorm = column sums of the (rounded) BatchNorm input gradient,
+    produced by the BatchNorm backward pass itself (eval mode, where it is not degenerate)."""
+    from pygho_amd import _ops
+    torch.manual_seed(3)
+    for dtype in (torch.float32, torch.bfloat16):
+        m, c = 30_001, 128
+        x = (torch.randn(m, c, device=dev) * 1.3).to(dtype)
+        g = torch.randn(m, c, device=dev).to(dtype)
+        bn = torch.nn.BatchNorm1d(c).to(dev).eval()
+        with torch.no_grad():
+            bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 2.0); bn.weight.uniform_(0.5, 1.5)
+        _, _, _, saved = _ops._bn_forward(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, False, bn.eps, "silu")
+        dx, s1, s2, sdx = _ops._bn_backward(x, g, saved, False, "silu", want_colsum=True)
+        ref = dx.double().sum(0)
+        torch.testing.assert_close(sdx.double(), ref, rtol=1e-5, atol=1e-3)
