@@ -91,6 +91,17 @@ int pygho_seg_gather_mul_reduce_add(void* out, const void* addend, const void* l
                                     const float* lhs_rowscale, int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d,
                                     int64_t lhs_rows, int64_t rhs_rows, int dtype, int aggr, void* stream);
 
+/* Three-operand gather-multiply-segment-sum:
+ *   out[s, :] = sum_{m in [seg_ptr[s], seg_ptr[s+1])} a[a_idx[m], :] * b[b_idx[m], :] * c[c_idx[m], :]
+ * (an index array may be NULL = identity m).  Replaces the tuple initialisation of the model
+ *   example/minimal.py:62-67   X.unpooling_fromdense1dim(0, .) * X.unpooling_fromdense1dim(1, .) * X.values
+ * (two (nnz, d) gathers + two elementwise products -> one pass) and its three operand gradients, which are the
+ * same kernel over the unit / by-root / by-node groupings.  Products are formed as (a * b) * c and summed in
+ * message order (f32 bit-identical to the elementwise chain followed by a sequential sum). */
+int pygho_seg_triple_product(void* out, const void* a, const void* b, const void* c, const int32_t* seg_ptr,
+                             const int32_t* a_idx, const int32_t* b_idx, const int32_t* c_idx, int64_t n_seg,
+                             int64_t d, int64_t a_rows, int64_t b_rows, int64_t c_rows, int dtype, void* stream);
+
 /*
  * Backward of the max / min aggregation (autograd of scatter_reduce_(amax|amin),
  * pygho/backend/utils.py:50-55): along a plan grouped by the operand being

@@ -35,17 +35,23 @@ __device__ __forceinline__ uint4 load_row16(const char* __restrict__ base, int i
   return *reinterpret_cast<const uint4*>(base + ((int64_t)idx * (int64_t)row_bytes + col_bytes));
 }
 
-template <typename T, int AGGR, int MODE, bool SCALED>
-__device__ __forceinline__ void accumulate16(float (&acc)[Vec16<T>::N], const uint4& la, const uint4& rb, float sc) {
+template <typename T, int AGGR, int MODE, bool SCALED, bool THIRD = false>
+__device__ __forceinline__ void accumulate16(float (&acc)[Vec16<T>::N], const uint4& la, const uint4& rb, float sc,
+                                             const uint4& tc = uint4{}) {
   using V = Vec16<T>;
   using R = Reduce<AGGR, float>;
   constexpr int N = V::N;
-  float a[N], b[N];
+  float a[N], b[N], c[N];
   if (MODE != MODE_RHS) V::unpack(la, a);
   if (MODE != MODE_LHS) V::unpack(rb, b);
+  if (THIRD) V::unpack(tc, c);
 #pragma unroll
   for (int q = 0; q < N; ++q) {
-    if (MODE == MODE_BOTH && !SCALED && (AGGR == PYGHO_SUM || AGGR == PYGHO_MEAN) && ExactProduct<T>::value) {
+    if (THIRD) {                                   // (a * b) * c, rounded like the sequential elementwise chain
+      float p = a[q] * b[q];
+      p = p * c[q];
+      acc[q] = R::op(acc[q], p);
+    } else if (MODE == MODE_BOTH && !SCALED && (AGGR == PYGHO_SUM || AGGR == PYGHO_MEAN) && ExactProduct<T>::value) {
       acc[q] = __builtin_fmaf(a[q], b[q], acc[q]);      // exact product: identical to mul then add
     } else {
       float p = (MODE == MODE_BOTH) ? a[q] * b[q] : (MODE == MODE_LHS ? a[q] : b[q]);
@@ -55,12 +61,13 @@ __device__ __forceinline__ void accumulate16(float (&acc)[Vec16<T>::N], const ui
   }
 }
 
-template <typename T, int AGGR, int MODE, bool SCALED, bool OFF32, bool OUTF32 = false>
+template <typename T, int AGGR, int MODE, bool SCALED, bool OFF32, bool OUTF32 = false, bool THIRD = false>
 __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
     T* __restrict__ out, const T* __restrict__ lhs, const T* __restrict__ rhs,
     const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ lhs_idx,
     const int32_t* __restrict__ rhs_idx, const float* __restrict__ lhs_rowscale, const T* __restrict__ addend,
-    int64_t n_seg, int d, int chunks, int log2g, int spp) {
+    int64_t n_seg, int d, int chunks, int log2g, int spp,
+    const T* __restrict__ third = nullptr, const int32_t* __restrict__ third_idx = nullptr) {
   using V = Vec16<T>;
   using R = Reduce<AGGR, float>;
   constexpr int N = V::N;
@@ -69,6 +76,7 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
   __shared__ int32_t s_ptr[kBlock / kWave][kSegsPerPass + 1];
   __shared__ int32_t s_li[kBlock / kWave][kMsgCap];
   __shared__ int32_t s_ri[kBlock / kWave][kMsgCap];
+  __shared__ int32_t s_ti[THIRD ? kBlock / kWave : 1][THIRD ? kMsgCap : 1];
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = threadIdx.x >> 6;
   const int gl = lane & ((1 << log2g) - 1);   // lane within the row group: 16-B chunk of the row
@@ -81,7 +89,8 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
   const char* lbase = reinterpret_cast<const char*>(lhs);
   const char* rbase = reinterpret_cast<const char*>(rhs);
   char* obase = reinterpret_cast<char*>(out);
-  const bool has_li = lhs_idx != nullptr, has_ri = rhs_idx != nullptr;
+  const bool has_li = lhs_idx != nullptr, has_ri = rhs_idx != nullptr, has_ti = THIRD && third_idx != nullptr;
+  const char* tbase = reinterpret_cast<const char*>(third);
   const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
   // XCD-aware sweep: workgroup b runs on XCD b % 8 (observed dispatch order).  Remap so that the workgroups of
   // ONE XCD cover a contiguous stretch of segments in every sweep step: the ~4 workgroups that share the edge
@@ -106,6 +115,7 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
       for (int j = lane; j < nmsg; j += kWave) {
         if (MODE != MODE_RHS && has_li) s_li[wv][j] = lhs_idx[mbeg + j];
         if (MODE != MODE_LHS && has_ri) s_ri[wv][j] = rhs_idx[mbeg + j];
+        if (THIRD && has_ti) s_ti[wv][j] = third_idx[mbeg + j];
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -123,21 +133,24 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
       for (int m0 = beg; m0 < end; m0 += 2) {
         const bool two = m0 + 1 < end;
         const int m1 = two ? m0 + 1 : m0;
-        int l0 = m0, l1 = m1, r0 = m0, r1 = m1;
+        int l0 = m0, l1 = m1, r0 = m0, r1 = m1, t0 = m0, t1 = m1;
         if (staged) {
           if (MODE != MODE_RHS && has_li) { l0 = s_li[wv][m0 - mbeg]; l1 = s_li[wv][m1 - mbeg]; }
           if (MODE != MODE_LHS && has_ri) { r0 = s_ri[wv][m0 - mbeg]; r1 = s_ri[wv][m1 - mbeg]; }
+          if (THIRD && has_ti) { t0 = s_ti[wv][m0 - mbeg]; t1 = s_ti[wv][m1 - mbeg]; }
         } else {
           if (MODE != MODE_RHS && has_li) { l0 = lhs_idx[m0]; l1 = lhs_idx[m1]; }
           if (MODE != MODE_LHS && has_ri) { r0 = rhs_idx[m0]; r1 = rhs_idx[m1]; }
+          if (THIRD && has_ti) { t0 = third_idx[m0]; t1 = third_idx[m1]; }
         }
-        uint4 la0, la1, rb0, rb1;
+        uint4 la0, la1, rb0, rb1, tc0 = uint4{}, tc1 = uint4{};
+        if (THIRD) { tc0 = load_row16<OFF32>(tbase, t0, row_bytes, col_bytes); tc1 = load_row16<OFF32>(tbase, t1, row_bytes, col_bytes); }
         float sc0 = 1.f, sc1 = 1.f;
         if (MODE != MODE_RHS) { la0 = load_row16<OFF32>(lbase, l0, row_bytes, col_bytes); la1 = load_row16<OFF32>(lbase, l1, row_bytes, col_bytes); }
         if (MODE != MODE_LHS) { rb0 = load_row16<OFF32>(rbase, r0, row_bytes, col_bytes); rb1 = load_row16<OFF32>(rbase, r1, row_bytes, col_bytes); }
         if (SCALED) { sc0 = lhs_rowscale[l0]; sc1 = lhs_rowscale[l1]; }
-        accumulate16<T, AGGR, MODE, SCALED>(acc, la0, rb0, sc0);
-        if (two) accumulate16<T, AGGR, MODE, SCALED>(acc, la1, rb1, sc1);
+        accumulate16<T, AGGR, MODE, SCALED, THIRD>(acc, la0, rb0, sc0, tc0);
+        if (two) accumulate16<T, AGGR, MODE, SCALED, THIRD>(acc, la1, rb1, sc1, tc1);
       }
       const int cnt = end - beg;
 #pragma unroll
@@ -364,6 +377,62 @@ int dispatch_aggr(int aggr, void* out, const void* lhs, const void* rhs, const i
 #undef PYGHO_CASE
 }
 
+
+// out[s] = sum_{m in segment s} a[ai[m]] * b[bi[m]] * c[ci[m]] for any row width (one thread per (segment, column))
+template <typename T>
+__global__ __launch_bounds__(kBlock) void seg_triple_generic_kernel(
+    T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
+    const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ ai, const int32_t* __restrict__ bi,
+    const int32_t* __restrict__ ci, int64_t n_seg, int64_t d) {
+  using A = typename Acc<T>::type;
+  const int64_t total = n_seg * d;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = t / d, col = t - s * d;
+    A acc = (A)0;
+    for (int m = seg_ptr[s]; m < seg_ptr[s + 1]; ++m) {
+      A p = load_as_acc<T>(a + (int64_t)(ai ? ai[m] : m) * d + col) * load_as_acc<T>(b + (int64_t)(bi ? bi[m] : m) * d + col);
+      p = p * load_as_acc<T>(c + (int64_t)(ci ? ci[m] : m) * d + col);
+      acc = acc + p;
+    }
+    store_from_acc<T>(out + t, acc);
+  }
+}
+
+template <typename T, bool OFF32>
+int launch_triple_fast(void* out, const void* a, const void* b, const void* c, const int32_t* seg_ptr, const int32_t* ai,
+                       const int32_t* bi, const int32_t* ci, int64_t n_seg, int64_t d, hipStream_t st) {
+  const int chunks = (int)(d * sizeof(T) / 16);
+  int log2g = 0;
+  while ((1 << log2g) < chunks && log2g < 6) ++log2g;
+  const int spp = segs_per_pass(n_seg, log2g);
+  int gx = grid_for(n_seg, (kBlock / kWave) * spp);
+  if (gx > 8) gx = (gx + 7) & ~7;
+  dim3 grid(gx, (unsigned)ceil_div(chunks, kWave));
+  hipLaunchKernelGGL((seg_gmr_fast_kernel<T, PYGHO_SUM, MODE_BOTH, false, OFF32, false, true>), grid, dim3(kBlock), 0, st, (T*)out,
+                     (const T*)a, (const T*)b, seg_ptr, ai, bi, (const float*)nullptr, (const T*)nullptr, n_seg, (int)d, chunks, log2g,
+                     spp, (const T*)c, ci);
+  return check_launch("seg_triple_product");
+}
+
+template <typename T, bool FAST_OK>
+int dispatch_triple(void* out, const void* a, const void* b, const void* c, const int32_t* seg_ptr, const int32_t* ai,
+                    const int32_t* bi, const int32_t* ci, int64_t n_seg, int64_t d, int64_t a_rows, int64_t b_rows, int64_t c_rows,
+                    hipStream_t st) {
+  if constexpr (FAST_OK) {
+    const bool aligned = (((uintptr_t)out | (uintptr_t)a | (uintptr_t)b | (uintptr_t)c) % 16) == 0;
+    if ((d * sizeof(T)) % 16 == 0 && aligned) {
+      const int64_t rb = d * (int64_t)sizeof(T), lim = (int64_t)1 << 32;
+      const bool off32 = n_seg * rb < lim && a_rows > 0 && a_rows * rb < lim && b_rows > 0 && b_rows * rb < lim && c_rows > 0 &&
+                         c_rows * rb < lim;
+      if (off32) return launch_triple_fast<T, true>(out, a, b, c, seg_ptr, ai, bi, ci, n_seg, d, st);
+      return launch_triple_fast<T, false>(out, a, b, c, seg_ptr, ai, bi, ci, n_seg, d, st);
+    }
+  }
+  hipLaunchKernelGGL((seg_triple_generic_kernel<T>), dim3(grid_for(n_seg * d, kBlock)), dim3(kBlock), 0, st, (T*)out, (const T*)a,
+                     (const T*)b, (const T*)c, seg_ptr, ai, bi, ci, n_seg, d);
+  return check_launch("seg_triple_product(generic)");
+}
+
 }  // namespace pygho
 
 using namespace pygho;
@@ -506,4 +575,20 @@ extern "C" int pygho_seg_sum_f32out(float* out, const void* src, const int32_t* 
   else { if (off32) PYGHO_L(f16, true); else PYGHO_L(f16, false); }
 #undef PYGHO_L
   return check_launch("seg_sum_f32out");
+}
+
+extern "C" int pygho_seg_triple_product(void* out, const void* a, const void* b, const void* c, const int32_t* seg_ptr,
+                                        const int32_t* a_idx, const int32_t* b_idx, const int32_t* c_idx, int64_t n_seg, int64_t d,
+                                        int64_t a_rows, int64_t b_rows, int64_t c_rows, int dtype, void* stream) {
+  if (n_seg < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n_seg == 0 || d == 0) return PYGHO_OK;
+  if (!out || !a || !b || !c || !seg_ptr) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case PYGHO_F32: return dispatch_triple<float, true>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, st);
+    case PYGHO_BF16: return dispatch_triple<bf16, true>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, st);
+    case PYGHO_F16: return dispatch_triple<f16, true>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, st);
+    case PYGHO_F64: return dispatch_triple<double, false>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, st);
+    default: set_error("unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED;
+  }
 }

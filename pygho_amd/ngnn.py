@@ -77,9 +77,14 @@ class SpModel(nn.Module):
         self.subggnns = nn.ModuleList([NGNNConv(hiddim, hiddim, "sum", "SS", conv_mlp) for _ in range(num_layer)])
 
     def tupleinit(self, X: SparseTensor, x: Tensor) -> SparseTensor:
-        subgx0 = X.unpooling_fromdense1dim(0, self.lin_tupleinit0(x))
-        subgx1 = X.unpooling_fromdense1dim(1, self.lin_tupleinit1(x))
-        return X.tuplewiseapply(lambda val: subgx0.values * subgx1.values * val)
+        """X.values * lin0(x)[root] * lin1(x)[node] (example/minimal.py:62-67)."""
+        left, right = self.lin_tupleinit0(x), self.lin_tupleinit1(x)
+        val = X.values
+        if val.is_cuda and val.dim() == 2 and left.dtype == right.dtype == val.dtype:
+            return X.tuplewiseapply(lambda v: _ops.pair_product(left, right, v, X._row(0), X._row(1)))
+        subgx0 = X.unpooling_fromdense1dim(0, left)
+        subgx1 = X.unpooling_fromdense1dim(1, right)
+        return X.tuplewiseapply(lambda v: subgx0.values * subgx1.values * v)
 
     def forward(self, datadict: dict) -> Tensor:
         datadict = self.data_encoder(datadict)

@@ -412,3 +412,35 @@ def test_model_building_blocks_match_torch(dev):
     torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(l1.weight.grad, l2.weight.grad, rtol=1e-3, atol=2e-2)
     torch.testing.assert_close(l1.bias.grad, l2.bias.grad, rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pair_product_matches_elementwise_chain(dev, dtype):
+    """tuple initialisation left[root] * right[node] * val as one three-operand kernel vs the unpooling + elementwise
+    chain of example/minimal.py:62-67: forward bit-exact in f32, gradients against torch autograd of the chain."""
+    from pygho_amd import _ops, synth
+    hb = synth.make_batch(96, "zinc", seed=4)
+    n, d = hb.num_nodes, 128
+    row, col = T(hb.tupleid[0], dev), T(hb.tupleid[1], dev)
+    torch.manual_seed(2)
+    mk = lambda r: torch.randn(r, d, device=dev).to(dtype)
+    left, right, val, w = mk(n), mk(n), mk(hb.num_tuples), torch.randn(hb.num_tuples, d, device=dev)
+    a = [t.clone().requires_grad_(True) for t in (left, right, val)]
+    out = _ops.pair_product(a[0], a[1], a[2], row, col)
+    (out.float() * w).sum().backward()
+    b = [t.double().clone().requires_grad_(True) for t in (left, right, val)]
+    ref = b[0][row] * b[1][col] * b[2]
+    (ref * w.double()).sum().backward()
+    if dtype == torch.float32:
+        assert torch.equal(out, left[row] * right[col] * val)
+        for x, y in zip(a, b):
+            s = float(y.grad.abs().max())
+            torch.testing.assert_close(x.grad.double() / s, y.grad / s, rtol=0, atol=1e-6)
+    else:
+        torch.testing.assert_close(out.double(), ref, rtol=2.0 ** -7, atol=1e-6)
+        for x, y in zip(a, b):
+            s = float(y.grad.abs().max())
+            torch.testing.assert_close(x.grad.double() / s, y.grad / s, rtol=0, atol=2.0 ** -7)
+    # generic width (d = 5), f32
+    l5, r5, v5 = left.float()[:, :5].contiguous(), right.float()[:, :5].contiguous(), val.float()[:, :5].contiguous()
+    assert torch.equal(_ops.pair_product(l5, r5, v5, row, col), l5[row] * r5[col] * v5)
