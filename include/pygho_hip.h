@@ -299,6 +299,13 @@ int pygho_masked_broadcast(void* out, const void* src, const uint8_t* mask, doub
 size_t pygho_bn_workspace(int64_t m, int64_t c, int dtype);
 int pygho_bn_stats(float* mean, float* var, const void* x, int64_t m, int64_t c, void* workspace, int dtype,
                    void* stream);
+/* pygho_bn_prepare: pygho_bn_stats plus everything derived from the statistics in the same finalisation kernel:
+ *   invstd = 1/sqrt(var + eps), scale = weight * invstd, shift = bias - mean * scale (weight / bias nullable = 1 / 0)
+ *   and, when running_mean / running_var are given, torch's momentum update with the unbiased variance
+ *   (torch.nn.BatchNorm1d semantics as used by honn/utils.py:46-61).  x == NULL: mean / var are inputs (eval mode). */
+int pygho_bn_prepare(float* mean, float* var, float* invstd, float* scale, float* shift, const void* x, int64_t m,
+                     int64_t c, const float* weight, const float* bias, double eps, float* running_mean,
+                     float* running_var, double momentum, void* workspace, int dtype, void* stream);
 int pygho_bn_act_fwd(void* y, const void* x, const float* scale, const float* bias, int64_t m, int64_t c,
                      int act, int dtype, void* stream);
 int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy,

@@ -1056,25 +1056,28 @@ def bn_act_supported(x: Tensor) -> bool:
             and int(lib().pygho_bn_workspace(x.shape[0], x.shape[1], dtype_code(x))) > 0)
 
 
-def _bn_forward(x: Tensor, weight, bias, running_mean, running_var, training: bool, eps: float, act: str):
-    """(y, mean, var, saved) of act(batch_norm(x)) for a contiguous 2-D x."""
+def _bn_forward(x: Tensor, weight, bias, running_mean, running_var, training: bool, eps: float, act: str,
+                fold_momentum: Optional[float] = None):
+    """(y, mean, var, saved) of act(batch_norm(x)) for a contiguous 2-D x.  Statistics, 1/sqrt(var + eps), the fused
+    scale / shift and (with `fold_momentum`) the running-average update all come out of ONE finalisation kernel."""
     dev = x.device
     m, c = x.shape
     dt = dtype_code(x)
     st = stream_ptr(dev)
     nbytes = int(lib().pygho_bn_workspace(m, c, dt))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    w32 = None if weight is None else weight.detach().float().contiguous()
+    b32 = None if bias is None else bias.detach().float().contiguous()
     if training:
         mean = torch.empty(c, dtype=torch.float32, device=dev)
         var = torch.empty(c, dtype=torch.float32, device=dev)
-        check(lib().pygho_bn_stats(ptr(mean), ptr(var), ptr(x), m, c, ptr(ws), dt, st), "bn_stats")
     else:
         mean, var = running_mean.float().clone(), running_var.float().clone()
-    invstd = torch.rsqrt(var + eps)
-    w32 = weight.float() if weight is not None else torch.ones(c, dtype=torch.float32, device=dev)
-    b32 = bias.float() if bias is not None else torch.zeros(c, dtype=torch.float32, device=dev)
-    scale = (w32 * invstd).contiguous()
-    shift = (b32 - mean * scale).contiguous()
+    invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(3))
+    fold = training and fold_momentum is not None
+    check(lib().pygho_bn_prepare(ptr(mean), ptr(var), ptr(invstd), ptr(scale), ptr(shift), ptr(x) if training else None, m, c,
+                                 ptr(w32), ptr(b32), float(eps), ptr(running_mean) if fold else None,
+                                 ptr(running_var) if fold else None, float(fold_momentum or 0.0), ptr(ws), dt, st), "bn_prepare")
     y = torch.empty_like(x)
     check(lib().pygho_bn_act_fwd(ptr(y), ptr(x), ptr(scale), ptr(shift), m, c, ACT_CODE[act], dt, st), "bn_act_fwd")
     return y, mean, var, (mean, invstd, w32, b32, ws)
@@ -1104,10 +1107,10 @@ class _BNAct(torch.autograd.Function):
     """y = act(batch_norm(x)); training uses batch statistics (and returns them for the running averages)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act, fold_momentum=None):
         require_device(x)
         x = x.contiguous()
-        y, mean, var, saved = _bn_forward(x, weight, bias, running_mean, running_var, training, eps, act)
+        y, mean, var, saved = _bn_forward(x, weight, bias, running_mean, running_var, training, eps, act, fold_momentum)
         ctx.save_for_backward(x, *saved)
         ctx.meta = (training, act, weight is not None, bias is not None)
         ctx.mark_non_differentiable(mean, var)
@@ -1118,13 +1121,25 @@ class _BNAct(torch.autograd.Function):
         x, *saved = ctx.saved_tensors
         training, act, has_w, has_b = ctx.meta
         dx, s1, s2, _ = _bn_backward(x, gy.contiguous(), saved, training, act)
-        return dx, (s2 if has_w else None), (s1 if has_b else None), None, None, None, None, None
+        return dx, (s2 if has_w else None), (s1 if has_b else None), None, None, None, None, None, None
 
 
-def _update_running(bn, mean: Tensor, var: Tensor, n: int) -> None:
+def _fold_momentum(bn) -> Optional[float]:
+    """momentum when the running-average update can run inside the statistics kernel (f32 contiguous buffers and a
+    fixed momentum; the cumulative-average mode needs the batch counter on the host and takes the torch path)."""
+    if (bn.training and bn.track_running_stats and bn.running_mean is not None and bn.momentum is not None
+            and bn.running_mean.dtype == torch.float32 and bn.running_var.dtype == torch.float32
+            and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous()):
+        return float(bn.momentum)
+    return None
+
+
+def _update_running(bn, mean: Tensor, var: Tensor, n: int, folded: bool = False) -> None:
     if bn.training and bn.track_running_stats and bn.running_mean is not None:
         with torch.no_grad():
             bn.num_batches_tracked += 1
+            if folded:
+                return
             mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
             bn.running_var.mul_(1 - mom).add_(var.to(bn.running_var.dtype), alpha=mom * n / max(n - 1, 1))
@@ -1134,8 +1149,9 @@ def batch_norm_act(x: Tensor, bn: "torch.nn.BatchNorm1d", act: str) -> Tensor:
     """BatchNorm1d(x) followed by `act`, with torch's semantics (batch statistics + running-average update in
     training mode, running statistics in eval mode)."""
     training = bn.training or bn.running_mean is None
-    y, mean, var = _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, act)
-    _update_running(bn, mean, var, x.shape[0])
+    fold = _fold_momentum(bn)
+    y, mean, var = _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, act, fold)
+    _update_running(bn, mean, var, x.shape[0], folded=fold is not None)
     return y
 
 
@@ -1166,25 +1182,30 @@ class _TupleBlock(torch.autograd.Function):
     added in place into the fresh input-gradient GEMM output."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, eps, act, rhs, plan, aggr, residual):
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, eps, act, rhs, plan, aggr, residual,
+                fold_momentum=None):
         require_device(x, w, rhs)
         x = x.contiguous()
-        pre = torch.nn.functional.linear(x, w, b)
-        h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act)
+        # master weights (usually f32) are cast to the activation dtype here, outside the autograd graph; their
+        # gradients are returned in the master dtype straight from the f32 split-K / column sums
+        wc = w if w.dtype == x.dtype else w.to(x.dtype)
+        bc = None if b is None else (b if b.dtype == x.dtype else b.to(x.dtype))
+        pre = torch.nn.functional.linear(x, wc, bc)
+        h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum)
         if plan is None:
             out = h
         else:
             out = seg_gmr(plan.n_out, h, rhs, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd if rhs is not None else None, aggr,
                           addend=x if residual else None)
-        ctx.save_for_backward(x, w, pre, h if plan is not None else None, rhs, *saved)
-        ctx.meta = (training, act, b is not None, gamma is not None, beta is not None, plan, aggr, residual)
+        ctx.save_for_backward(x, wc, pre, h if plan is not None else None, rhs, *saved)
+        ctx.meta = (training, act, None if b is None else b.dtype, gamma is not None, beta is not None, plan, aggr, residual, w.dtype)
         ctx.mark_non_differentiable(mean, var)
         return out, mean, var
 
     @staticmethod
     def backward(ctx, g, _gm, _gv):
         x, w, pre, h, rhs, *saved = ctx.saved_tensors
-        training, act, has_b, has_gamma, has_beta, plan, aggr, residual = ctx.meta
+        training, act, b_dtype, has_gamma, has_beta, plan, aggr, residual, w_dtype = ctx.meta
         g = g.contiguous()
         g_rhs = None
         gh = g
@@ -1195,7 +1216,7 @@ class _TupleBlock(torch.autograd.Function):
             if rhs is not None and ctx.needs_input_grad[10]:
                 p, a_g, c_g = plan.by_d()
                 g_rhs = seg_gmr(plan.n_rhs, g, h, p.seg_ptr, a_g, c_g, "sum", scale)
-        gpre, s1, s2, sdx = _bn_backward(pre, gh, saved, training, act, want_colsum=has_b and ctx.needs_input_grad[2])
+        gpre, s1, s2, sdx = _bn_backward(pre, gh, saved, training, act, want_colsum=b_dtype is not None and ctx.needs_input_grad[2])
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             # (addmm(g, gpre, w) copies g into the output first and then runs a slower beta = 1 GEMM: 0.52 ms against
@@ -1204,24 +1225,22 @@ class _TupleBlock(torch.autograd.Function):
             if residual:
                 gx = gx.add_(g)
         if ctx.needs_input_grad[1]:
-            gw = weight_grad_splitk(gpre, x, w.dtype)
+            gw = weight_grad_splitk(gpre, x, w_dtype)
         if sdx is not None:
-            gb = sdx.to(w.dtype)
+            gb = sdx.to(b_dtype)
         return (gx, gw, gb, (s2 if has_gamma else None), (s1 if has_beta else None), None, None, None, None, None,
-                g_rhs, None, None, None)
+                g_rhs, None, None, None, None)
 
 
 def tuple_block(x: Tensor, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", act: str, rhs: Optional[Tensor] = None,
                 plan: Optional[MessagePlan] = None, aggr: str = "sum", residual: bool = False) -> Tensor:
     """fused Linear -> BatchNorm1d -> act (-> aggregation over `plan` with `rhs` (-> + x)); parameters are read
     from the stock modules (f32 master weights are cast to the activation dtype like autocast would)."""
-    dt = x.dtype
-    w = lin.weight if lin.weight.dtype == dt else lin.weight.to(dt)
-    b = None if lin.bias is None else (lin.bias if lin.bias.dtype == dt else lin.bias.to(dt))
     training = bn.training or bn.running_mean is None
     if residual:
         assert plan is not None and plan.n_out == x.shape[0] and lin.out_features == x.shape[1]
-    out, mean, var = _TupleBlock.apply(x, w, b, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, act,
-                                       rhs, plan, aggr, residual)
-    _update_running(bn, mean, var, x.shape[0])
+    fold = _fold_momentum(bn)
+    out, mean, var = _TupleBlock.apply(x, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                                       bn.eps, act, rhs, plan, aggr, residual, fold)
+    _update_running(bn, mean, var, x.shape[0], folded=fold is not None)
     return out

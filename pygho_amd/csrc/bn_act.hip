@@ -85,19 +85,50 @@ __device__ __forceinline__ void final_sums(double& a, double& b, const float* __
   a = red[0][0][cl]; b = red[1][0][cl];
 }
 
+struct BnDerived {                         // everything the forward / backward passes need besides x, per channel
+  float* invstd; float* scale; float* shift;       // 1/sqrt(var + eps), w * invstd, b - mean * scale   (nullable as a group)
+  const float* weight; const float* bias;          // nullable: 1 / 0
+  float* running_mean; float* running_var;         // nullable: momentum update with the UNBIASED variance
+  double eps, momentum;
+};
+
+__device__ __forceinline__ void bn_derive(const BnDerived& dv, int ch, float mean, float var, int64_t m, bool update_running) {
+  if (dv.invstd) {
+    const float is = (float)(1.0 / sqrt((double)var + dv.eps));
+    const float sc = (dv.weight ? dv.weight[ch] : 1.f) * is;
+    dv.invstd[ch] = is;
+    dv.scale[ch] = sc;
+    dv.shift[ch] = (dv.bias ? dv.bias[ch] : 0.f) - mean * sc;
+  }
+  if (update_running && dv.running_mean) {
+    const double mom = dv.momentum;
+    const double unbiased = (double)var * ((double)m / (double)(m > 1 ? m - 1 : 1));
+    dv.running_mean[ch] = (float)((1.0 - mom) * (double)dv.running_mean[ch] + mom * (double)mean);
+    dv.running_var[ch] = (float)((1.0 - mom) * (double)dv.running_var[ch] + mom * unbiased);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kFinParts * kFinCh) void bn_stats_final_kernel(float* __restrict__ mean, float* __restrict__ var,
                                                                             const float* __restrict__ ws, const T* __restrict__ x,
-                                                                            int64_t m, int c, int nblk) {
+                                                                            int64_t m, int c, int nblk, BnDerived dv) {
   double a, b;
   final_sums(a, b, ws, c, nblk, blockIdx.x * kFinCh);
   const int ch = blockIdx.x * kFinCh + threadIdx.x % kFinCh;
   if (threadIdx.x >= kFinCh || ch >= c) return;
   const double shift = (double)load_as_acc<T>(x + ch);
   const double md = a / (double)m;
-  mean[ch] = (float)(shift + md);
+  const float mu = (float)(shift + md);
   const double v = b / (double)m - md * md;
-  var[ch] = (float)(v > 0.0 ? v : 0.0);        // biased variance
+  const float vr = (float)(v > 0.0 ? v : 0.0);        // biased variance
+  mean[ch] = mu;
+  var[ch] = vr;
+  bn_derive(dv, ch, mu, vr, m, true);
+}
+
+__global__ void bn_derive_kernel(const float* __restrict__ mean, const float* __restrict__ var, int c, BnDerived dv) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch < c) bn_derive(dv, ch, mean[ch], var[ch], 2, false);
 }
 
 // ---- y = act((x - mean) * invstd * w + b) ------------------------------------------------------------------------
@@ -280,9 +311,33 @@ extern "C" int pygho_bn_stats(float* mean, float* var, const void* x, int64_t m,
   PYGHO_BN_T(dtype, {
     hipLaunchKernelGGL((bn_stats_partial_kernel<T>), dim3(grid), dim3(kBlock), 0, st, (float*)workspace, (const T*)x, m, (int)c, chunks);
     hipLaunchKernelGGL((bn_stats_final_kernel<T>), dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, st, mean, var,
-                       (const float*)workspace, (const T*)x, m, (int)c, grid);
+                       (const float*)workspace, (const T*)x, m, (int)c, grid, BnDerived{});
   });
   return check_launch("bn_stats");
+}
+
+extern "C" int pygho_bn_prepare(float* mean, float* var, float* invstd, float* scale, float* shift, const void* x, int64_t m,
+                                int64_t c, const float* weight, const float* bias, double eps, float* running_mean,
+                                float* running_var, double momentum, void* workspace, int dtype, void* stream) {
+  if (c <= 0) { set_error("bn_prepare: empty input"); return PYGHO_ERR_INVALID; }
+  if (!mean || !var || !invstd || !scale || !shift) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if ((running_mean == nullptr) != (running_var == nullptr)) { set_error("bn_prepare: running_mean / running_var go together"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  BnDerived dv{invstd, scale, shift, weight, bias, running_mean, running_var, eps, momentum};
+  if (!x) {                                      // statistics given (eval mode): derived quantities only
+    hipLaunchKernelGGL(bn_derive_kernel, dim3((unsigned)ceil_div(c, (int64_t)kBlock)), dim3(kBlock), 0, st, (const float*)mean,
+                       (const float*)var, (int)c, dv);
+    return check_launch("bn_prepare(eval)");
+  }
+  if (m <= 0 || !workspace) { set_error("bn_prepare: empty input / null workspace"); return PYGHO_ERR_INVALID; }
+  int chunks, grid;
+  if (int rc = bn_geometry(m, c, dtype, &chunks, &grid)) return rc;
+  PYGHO_BN_T(dtype, {
+    hipLaunchKernelGGL((bn_stats_partial_kernel<T>), dim3(grid), dim3(kBlock), 0, st, (float*)workspace, (const T*)x, m, (int)c, chunks);
+    hipLaunchKernelGGL((bn_stats_final_kernel<T>), dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, st, mean, var,
+                       (const float*)workspace, (const T*)x, m, (int)c, grid, dv);
+  });
+  return check_launch("bn_prepare");
 }
 
 extern "C" int pygho_bn_act_fwd(void* y, const void* x, const float* scale, const float* bias, int64_t m, int64_t c, int act,

@@ -3,9 +3,9 @@ Data parallelism over graphs.  A batch is a block-diagonal union 
 operator path shards by graph with no data-path collective; the only exchange is the gradient
 all-reduce.  The reference has no distributed code at all; this is new work.
 
-``FlatGradSync`` keeps every parameter gradient as a view into ONE flat buffer so that the step's
-gradient exchange is a single RCCL all-reduce over xGMI (0.70 MB for the minimal NGNN: latency- not
-bandwidth-bound, so one bucket is optimal) issued right after backward.
+``FlatGradSync`` packs every parameter gradient into ONE flat buffer so that the step's gradient exchange is
+a single RCCL all-reduce over xGMI (0.70 MB for the minimal NGNN: latency- not bandwidth-bound, so one bucket
+is optimal) issued right after backward.
 """
 from typing import Iterable, List, Optional, Tuple
 
@@ -15,6 +15,13 @@ import torch.distributed as dist
 
 
 class FlatGradSync:
+    """gradient exchange of one data-parallel step.
+
+    ``zero_grad()`` drops the gradients (autograd then hands its freshly produced tensors over instead of launching
+    one accumulate kernel per parameter); ``sync()`` packs them into ONE flat buffer with a multi-tensor copy,
+    averages it over the ranks with a single all-reduce and re-points every ``param.grad`` at its slice (without a
+    process group only the packing happens)."""
+
     def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional["dist.ProcessGroup"] = None,
                  dtype: torch.dtype = torch.float32):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -22,18 +29,32 @@ class FlatGradSync:
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=dtype, device=dev)
+        self.views: List[torch.Tensor] = []
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)      # autograd accumulates in place into the view
+            self.views.append(self.flat[off:off + n].view_as(p))
             off += n
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
     def zero_grad(self) -> None:
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
+
+    def pack(self) -> None:
+        """flat <- gradients (parameters without a gradient contribute zeros), then param.grad = its flat slice."""
+        missing = [v for v, p in zip(self.views, self.params) if p.grad is None]
+        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        if missing:
+            torch._foreach_zero_(missing)
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, p in zip(self.views, self.params):
+            p.grad = v
 
     def sync(self) -> None:
-        """average the flat gradient over all ranks (one collective)."""
+        """average the gradient over all ranks (one collective over the flat buffer)."""
+        self.pack()
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.world > 1:

@@ -73,7 +73,13 @@ def test_flat_views_alias_parameter_grads():
     model = _model()
     sync = FlatGradSync(model.parameters())
     model(torch.ones(2, 6)).sum().backward()
-    assert all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in model.parameters())
-    assert float(sync.flat.abs().sum()) > 0
+    expect = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    sync.sync()                                  # no process group: pack only
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(model.parameters(), sync.views))
+    assert torch.equal(sync.flat, expect) and float(sync.flat.abs().sum()) > 0
     sync.zero_grad()
-    assert all(float(p.grad.abs().sum()) == 0 for p in model.parameters())
+    assert all(p.grad is None for p in model.parameters())
+    model[0](torch.ones(2, 6)).sum().backward()   # second Linear unused: its slice must read zero after packing
+    sync.sync()
+    n0 = sum(p.numel() for p in model[0].parameters())
+    assert float(sync.flat[:n0].abs().sum()) > 0 and float(sync.flat[n0:].abs().sum()) == 0
