@@ -306,11 +306,30 @@ int pygho_bn_stats(float* mean, float* var, const void* x, int64_t m, int64_t c,
 int pygho_bn_prepare(float* mean, float* var, float* invstd, float* scale, float* shift, const void* x, int64_t m,
                      int64_t c, const float* weight, const float* bias, double eps, float* running_mean,
                      float* running_var, double momentum, void* workspace, int dtype, void* stream);
+/* pygho_bn_finalize: the finalisation half of pygho_bn_prepare for per-block partial sums produced elsewhere
+ * (the epilogue of pygho_rowblock_linear): partial_sums[blk][0][c] = sum(y - sum_shift[c]),
+ * partial_sums[blk][1][c] = sum((y - sum_shift[c])^2) over the rows of block blk, n_blocks blocks, m rows in total. */
+int pygho_bn_finalize(float* mean, float* var, float* invstd, float* scale, float* shift, const float* partial_sums,
+                      int64_t n_blocks, const float* sum_shift, int64_t m, int64_t c, const float* weight,
+                      const float* bias, double eps, float* running_mean, float* running_var, double momentum,
+                      void* stream);
 int pygho_bn_act_fwd(void* y, const void* x, const float* scale, const float* bias, int64_t m, int64_t c,
                      int act, int dtype, void* stream);
 int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy,
                      const float* mean, const float* invstd, const float* w, const float* b, int64_t m,
                      int64_t c, int act, int training, void* workspace, int dtype, float* sum_dx, void* stream);
+
+/* Tuple-wise linear map with the neighbouring passes fused into its epilogue (bf16 / f16, d = 64 or 128):
+ *   out[m, d] = in[m, d] . wl[d, d]^T (+ bias[d]) (+ addend[m, d])            wl row-major, row = output channel
+ *   pygho/honn/utils.py:126-131 (the Linear of every MLP, applied per tuple, Conv.py:56) and its input gradient
+ *   (wl = W^T, addend = the residual gradient of example/minimal.py:76-79).
+ * stats_ws (nullable): pygho_rowblock_linear_blocks(m) x 2 x d floats receive the per-block sums of (out - shift) and
+ *   (out - shift)^2 of the rounded output, to be finalised by pygho_bn_finalize -- the BatchNorm statistics pass is
+ *   folded into the GEMM epilogue.  f32 accumulation on the matrix cores, one rounding of acc + bias; the addend is
+ *   added to the rounded product (as product-then-add would). */
+int pygho_rowblock_linear_blocks(int64_t m);
+int pygho_rowblock_linear(void* out, const void* in, const void* wl, const void* bias, const void* addend,
+                          float* stats_ws, const float* shift, int64_t m, int64_t d, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

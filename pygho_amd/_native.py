@@ -66,8 +66,11 @@ PROTOTYPES = {
     "pygho_bn_workspace": (Z, [L, L, I]),
     "pygho_bn_stats": (I, [P, P, P, L, L, P, I, P]),
     "pygho_bn_prepare": (I, [P, P, P, P, P, P, L, L, P, P, D, P, P, D, P, I, P]),
+    "pygho_bn_finalize": (I, [P, P, P, P, P, P, L, P, L, L, P, P, D, P, P, D, P]),
     "pygho_bn_act_fwd": (I, [P, P, P, P, L, L, I, I, P]),
     "pygho_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, P, I, P, P]),
+    "pygho_rowblock_linear_blocks": (I, [L]),
+    "pygho_rowblock_linear": (I, [P, P, P, P, P, P, P, L, L, I, P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

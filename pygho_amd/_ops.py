@@ -1057,9 +1057,10 @@ def bn_act_supported(x: Tensor) -> bool:
 
 
 def _bn_forward(x: Tensor, weight, bias, running_mean, running_var, training: bool, eps: float, act: str,
-                fold_momentum: Optional[float] = None):
+                fold_momentum: Optional[float] = None, partial: Optional[Tuple[Tensor, Tensor]] = None):
     """(y, mean, var, saved) of act(batch_norm(x)) for a contiguous 2-D x.  Statistics, 1/sqrt(var + eps), the fused
-    scale / shift and (with `fold_momentum`) the running-average update all come out of ONE finalisation kernel."""
+    scale / shift and (with `fold_momentum`) the running-average update all come out of ONE finalisation kernel;
+    `partial` = (per-block shifted sums, their shift) when the producer of x already took the sums (rowblock_linear)."""
     dev = x.device
     m, c = x.shape
     dt = dtype_code(x)
@@ -1075,9 +1076,16 @@ def _bn_forward(x: Tensor, weight, bias, running_mean, running_var, training: bo
         mean, var = running_mean.float().clone(), running_var.float().clone()
     invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(3))
     fold = training and fold_momentum is not None
-    check(lib().pygho_bn_prepare(ptr(mean), ptr(var), ptr(invstd), ptr(scale), ptr(shift), ptr(x) if training else None, m, c,
-                                 ptr(w32), ptr(b32), float(eps), ptr(running_mean) if fold else None,
-                                 ptr(running_var) if fold else None, float(fold_momentum or 0.0), ptr(ws), dt, st), "bn_prepare")
+    if training and partial is not None:
+        sums, sum_shift = partial
+        check(lib().pygho_bn_finalize(ptr(mean), ptr(var), ptr(invstd), ptr(scale), ptr(shift), ptr(sums), sums.shape[0],
+                                      ptr(sum_shift), m, c, ptr(w32), ptr(b32), float(eps), ptr(running_mean) if fold else None,
+                                      ptr(running_var) if fold else None, float(fold_momentum or 0.0), st), "bn_finalize")
+    else:
+        check(lib().pygho_bn_prepare(ptr(mean), ptr(var), ptr(invstd), ptr(scale), ptr(shift), ptr(x) if training else None, m, c,
+                                     ptr(w32), ptr(b32), float(eps), ptr(running_mean) if fold else None,
+                                     ptr(running_var) if fold else None, float(fold_momentum or 0.0), ptr(ws), dt, st),
+              "bn_prepare")
     y = torch.empty_like(x)
     check(lib().pygho_bn_act_fwd(ptr(y), ptr(x), ptr(scale), ptr(shift), m, c, ACT_CODE[act], dt, st), "bn_act_fwd")
     return y, mean, var, (mean, invstd, w32, b32, ws)
@@ -1174,6 +1182,34 @@ def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype) -> Tensor:
     return gw.to(out_dtype)
 
 
+USE_ROWBLOCK_LINEAR = True      # module switch for A/B measurements (the library GEMM + separate passes otherwise)
+
+
+def rowblock_linear_supported(x: Tensor, out_features: int) -> bool:
+    return (USE_ROWBLOCK_LINEAR and x.is_cuda and x.dim() == 2 and x.dtype in (torch.bfloat16, torch.float16) and x.shape[1] == out_features
+            and out_features in (64, 128) and x.shape[0] >= 8192)
+
+
+def rowblock_linear(x: Tensor, wl: Tensor, bias: Optional[Tensor] = None, addend: Optional[Tensor] = None,
+                    stats_shift: Optional[Tensor] = None):
+    """out = x @ wl^T (+ bias) (+ addend) on the skinny-GEMM kernel; with `stats_shift` (f32, d) also returns the per-block
+    partial sums of (out - shift), (out - shift)^2 for pygho_bn_finalize: (out, partial_sums or None)."""
+    dev = require_device(x, wl, bias, addend, stats_shift)
+    x, wl = x.contiguous(), wl.contiguous()
+    m, d = x.shape
+    assert wl.shape == (d, d) and wl.dtype == x.dtype
+    out = torch.empty_like(x)
+    ws = None
+    if stats_shift is not None:
+        nblk = int(lib().pygho_rowblock_linear_blocks(m))
+        ws = torch.empty((nblk, 2, d), dtype=torch.float32, device=dev)
+    if addend is not None:
+        addend = addend.contiguous()
+    check(lib().pygho_rowblock_linear(ptr(out), ptr(x), ptr(wl), ptr(bias), ptr(addend), ptr(ws), ptr(stats_shift), m, d,
+                                      dtype_code(x), stream_ptr(dev)), "rowblock_linear")
+    return out, ws
+
+
 class _TupleBlock(torch.autograd.Function):
     """H = act(bn(x W^T + b));  out = H                                  (plan is None)
                                   out = [x +] (+)_{(a,c,d)} H[c] * rhs[d]   (plan given; `residual` adds x)
@@ -1190,22 +1226,31 @@ class _TupleBlock(torch.autograd.Function):
         # gradients are returned in the master dtype straight from the f32 split-K / column sums
         wc = w if w.dtype == x.dtype else w.to(x.dtype)
         bc = None if b is None else (b if b.dtype == x.dtype else b.to(x.dtype))
-        pre = torch.nn.functional.linear(x, wc, bc)
-        h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum)
+        skinny = rowblock_linear_supported(x, w.shape[0]) and w.shape[0] == w.shape[1]
+        partial = None
+        if skinny:
+            # hand-written streaming GEMM: the BatchNorm statistics of its output ride in the epilogue
+            sum_shift = torch.nn.functional.linear(x[:1], wc, bc).float().reshape(-1) if training else None
+            pre, sums = rowblock_linear(x, wc, bc, stats_shift=sum_shift)
+            partial = (sums, sum_shift) if training else None
+        else:
+            pre = torch.nn.functional.linear(x, wc, bc)
+        h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum, partial)
         if plan is None:
             out = h
         else:
             out = seg_gmr(plan.n_out, h, rhs, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd if rhs is not None else None, aggr,
                           addend=x if residual else None)
         ctx.save_for_backward(x, wc, pre, h if plan is not None else None, rhs, *saved)
-        ctx.meta = (training, act, None if b is None else b.dtype, gamma is not None, beta is not None, plan, aggr, residual, w.dtype)
+        ctx.meta = (training, act, None if b is None else b.dtype, gamma is not None, beta is not None, plan, aggr, residual, w.dtype,
+                    skinny)
         ctx.mark_non_differentiable(mean, var)
         return out, mean, var
 
     @staticmethod
     def backward(ctx, g, _gm, _gv):
         x, w, pre, h, rhs, *saved = ctx.saved_tensors
-        training, act, b_dtype, has_gamma, has_beta, plan, aggr, residual, w_dtype = ctx.meta
+        training, act, b_dtype, has_gamma, has_beta, plan, aggr, residual, w_dtype, skinny = ctx.meta
         g = g.contiguous()
         g_rhs = None
         gh = g
@@ -1219,11 +1264,14 @@ class _TupleBlock(torch.autograd.Function):
         gpre, s1, s2, sdx = _bn_backward(pre, gh, saved, training, act, want_colsum=b_dtype is not None and ctx.needs_input_grad[2])
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            # (addmm(g, gpre, w) copies g into the output first and then runs a slower beta = 1 GEMM: 0.52 ms against
-            #  0.39 ms for product + add at nnz = 1.8 M, so the residual gradient stays a separate add for now)
-            gx = gpre @ w
-            if residual:
-                gx = gx.add_(g)
+            if skinny:
+                # dX = gpre . W (+ g): the residual gradient is added in the GEMM epilogue
+                gx, _ = rowblock_linear(gpre, w.t().contiguous(), None, addend=g if residual else None)
+            else:
+                # (addmm(g, gpre, w) copies g first and then runs a slower beta = 1 GEMM: product + add is faster)
+                gx = gpre @ w
+                if residual:
+                    gx = gx.add_(g)
         if ctx.needs_input_grad[1]:
             gw = weight_grad_splitk(gpre, x, w_dtype)
         if sdx is not None:

@@ -111,12 +111,13 @@ __device__ __forceinline__ void bn_derive(const BnDerived& dv, int ch, float mea
 template <typename T>
 __global__ __launch_bounds__(kFinParts * kFinCh) void bn_stats_final_kernel(float* __restrict__ mean, float* __restrict__ var,
                                                                             const float* __restrict__ ws, const T* __restrict__ x,
-                                                                            int64_t m, int c, int nblk, BnDerived dv) {
+                                                                            int64_t m, int c, int nblk, BnDerived dv,
+                                                                            const float* __restrict__ shiftf = nullptr) {
   double a, b;
   final_sums(a, b, ws, c, nblk, blockIdx.x * kFinCh);
   const int ch = blockIdx.x * kFinCh + threadIdx.x % kFinCh;
   if (threadIdx.x >= kFinCh || ch >= c) return;
-  const double shift = (double)load_as_acc<T>(x + ch);
+  const double shift = shiftf ? (double)shiftf[ch] : (double)load_as_acc<T>(x + ch);   // the shift the partial sums were taken around
   const double md = a / (double)m;
   const float mu = (float)(shift + md);
   const double v = b / (double)m - md * md;
@@ -374,4 +375,17 @@ extern "C" int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, con
                          (const float*)workspace, (int)c, grid);
   }));
   return check_launch("bn_act_bwd");
+}
+
+extern "C" int pygho_bn_finalize(float* mean, float* var, float* invstd, float* scale, float* shift, const float* partial_sums,
+                                 int64_t n_blocks, const float* sum_shift, int64_t m, int64_t c, const float* weight,
+                                 const float* bias, double eps, float* running_mean, float* running_var, double momentum,
+                                 void* stream) {
+  if (m <= 0 || c <= 0 || n_blocks <= 0) { set_error("bn_finalize: empty input"); return PYGHO_ERR_INVALID; }
+  if (!mean || !var || !invstd || !scale || !shift || !partial_sums || !sum_shift) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if ((running_mean == nullptr) != (running_var == nullptr)) { set_error("bn_finalize: running_mean / running_var go together"); return PYGHO_ERR_INVALID; }
+  BnDerived dv{invstd, scale, shift, weight, bias, running_mean, running_var, eps, momentum};
+  hipLaunchKernelGGL((bn_stats_final_kernel<float>), dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, (hipStream_t)stream,
+                     mean, var, partial_sums, (const float*)nullptr, m, (int)c, (int)n_blocks, dv, sum_shift);
+  return check_launch("bn_finalize");
 }

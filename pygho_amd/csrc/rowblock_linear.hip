@@ -1,0 +1,219 @@
+// Tuple-wise linear map of the layer MLPs: out[M, D] = in[M, D] . Wl[D, D]^T (+ bias) (+ addend), M ~ 10^6, D = 64 / 128
+// (reference honn/utils.py:126-131: Linear inside every MLP, applied per tuple through X.tuplewiseapply, Conv.py:56).
+// With K = N = D tiny and M huge the product streams `in` once and `out` once: it is HBM-bound (43 flop/B at D = 128),
+// so the kernel is organised around the stream and what can ride on it for free:
+//   * forward:  the per-channel shifted sums of the ROUNDED output (BatchNorm statistics) are taken in the epilogue,
+//               which removes the separate statistics pass over `out`;
+//   * backward: the residual gradient is added in the epilogue (dX = gY . W + g), which removes the elementwise add pass.
+// Mapping: persistent workgroups (4 waves) walk 128-row tiles; Wl sits in LDS for the whole kernel (k-contiguous rows,
+// padded pitch); a wave owns 32 rows.  MFMA v_mfma_f32_16x16x32_{bf16,f16} in the swapped form D[n][m] = sum_k Wl[n][k] in[m][k]:
+// the `in` fragments (lane = row m, 8 consecutive k) are 16-B global loads straight into registers, prefetched one tile
+// ahead; the accumulator (lane = row m, 4 consecutive n) goes through a per-wave LDS stage so that the epilogue works on
+// row-contiguous 16-B chunks (coalesced stores, one fixed channel chunk per lane for the statistics).
+#include "common.h"
+
+namespace pygho {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 rl_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 rl_f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float rl_f32x4_t;
+
+constexpr int kRlRowsPerWave = 32;
+constexpr int kRlTile = kRlRowsPerWave * (kBlock / kWave);      // 128 rows per workgroup tile
+
+template <typename T>
+__device__ __forceinline__ rl_f32x4_t rl_mfma(const uint4& a, const uint4& b, rl_f32x4_t c) {
+  if constexpr (std::is_same<T, bf16>::value)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(rl_bf16x8_t, a), __builtin_bit_cast(rl_bf16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rl_f16x8_t, a), __builtin_bit_cast(rl_f16x8_t, b), c, 0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ uint2 rl_pack4(const rl_f32x4_t& v);
+template <> __device__ __forceinline__ uint2 rl_pack4<bf16>(const rl_f32x4_t& v) {
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+  const f2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+  return make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf2_t)),
+                    __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf2_t)));
+}
+template <> __device__ __forceinline__ uint2 rl_pack4<f16>(const rl_f32x4_t& v) {
+  union { uint32_t u; _Float16 h[2]; } a, b;
+  a.h[0] = (_Float16)v[0]; a.h[1] = (_Float16)v[1]; b.h[0] = (_Float16)v[2]; b.h[1] = (_Float16)v[3];
+  return make_uint2(a.u, b.u);
+}
+
+template <int D> struct RlGeom {
+  static constexpr int KS = D / 32;            // k steps of the MFMA
+  static constexpr int NB = D / 16;            // 16-column output blocks
+  static constexpr int PITCH = D + 8;          // elements; +16 B per row: fragment reads and stage writes spread over the banks
+  static constexpr int CH = D / 8;             // 16-B chunks per row
+  static constexpr size_t w_bytes = (size_t)D * PITCH * 2;
+  static constexpr size_t stage_bytes = (size_t)kRlTile * PITCH * 2;
+  static constexpr size_t lds_bytes = w_bytes + stage_bytes + (size_t)D * 4;
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ wl,
+                                                                    const T* __restrict__ bias, const T* __restrict__ addend,
+                                                                    float* __restrict__ stats_ws, const float* __restrict__ shift,
+                                                                    int64_t m_rows) {
+  using G = RlGeom<D>;
+  using V = Vec16<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_w = smem;
+  char* lds_stage = smem + G::w_bytes;
+  float* lds_bias = reinterpret_cast<float*>(smem + G::w_bytes + G::stage_bytes);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+
+  // ---- Wl[n][k] (row-major, k contiguous) -> LDS with padded pitch; bias as f32 -------------------------------
+  for (int item = threadIdx.x; item < D * G::CH; item += kBlock) {
+    const int n = item / G::CH, ch = item - n * G::CH;
+    *reinterpret_cast<uint4*>(lds_w + ((size_t)n * G::PITCH + ch * 8) * 2) = *reinterpret_cast<const uint4*>(wl + (size_t)n * D + ch * 8);
+  }
+  for (int n = threadIdx.x; n < D; n += kBlock) lds_bias[n] = bias ? load_as_acc<T>(bias + n) : 0.f;
+  __syncthreads();
+
+  char* my_stage = lds_stage + (size_t)wave * kRlRowsPerWave * G::PITCH * 2;
+  const int64_t n_tiles = (m_rows + kRlTile - 1) / kRlTile;
+  const int ech = lane % G::CH;                          // epilogue: this lane's 16-B channel chunk (fixed: 64 % CH == 0)
+  const int erow0 = lane / G::CH;                        // ... and its first row inside the wave's 32
+  constexpr int EROWS = 64 / G::CH;                      // rows covered per epilogue iteration
+  float sh[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sh[j] = (stats_ws && shift) ? shift[ech * 8 + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+
+  uint4 fb[2][G::KS];                                    // `in` fragments of the current tile
+  auto load_tile = [&](int64_t tile, uint4 (&dst)[2][G::KS]) {
+    const int64_t base = tile * kRlTile + wave * kRlRowsPerWave;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      int64_t row = base + mb * 16 + r16;
+      if (row >= m_rows) row = m_rows - 1;               // clamped; never stored
+      const T* p = in + row * D + q * 8;
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) dst[mb][ks] = *reinterpret_cast<const uint4*>(p + ks * 32);
+    }
+  };
+  int64_t tile = blockIdx.x;
+  if (tile < n_tiles) load_tile(tile, fb);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    uint4 nxt[2][G::KS];
+    const int64_t tn = tile + gridDim.x;
+    if (tn < n_tiles) load_tile(tn, nxt);                // prefetch: in flight during this tile's MFMAs and epilogue
+
+    rl_f32x4_t acc[2][G::NB];
+#pragma unroll
+    for (int nb = 0; nb < G::NB; ++nb) {
+      const rl_f32x4_t b4 = *reinterpret_cast<const rl_f32x4_t*>(lds_bias + nb * 16 + q * 4);
+      acc[0][nb] = b4; acc[1][nb] = b4;
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+      for (int nb = 0; nb < G::NB; ++nb) {
+        const uint4 fa = *reinterpret_cast<const uint4*>(lds_w + ((size_t)(nb * 16 + r16) * G::PITCH + ks * 32 + q * 8) * 2);
+        acc[0][nb] = rl_mfma<T>(fa, fb[0][ks], acc[0][nb]);
+        acc[1][nb] = rl_mfma<T>(fa, fb[1][ks], acc[1][nb]);
+      }
+    // ---- accumulators (lane: row m = mb*16 + r16, columns nb*16 + q*4 .. +3) -> per-wave stage, rounded to T -------
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < G::NB; ++nb)
+        *reinterpret_cast<uint2*>(my_stage + ((size_t)(mb * 16 + r16) * G::PITCH + nb * 16 + q * 4) * 2) = rl_pack4<T>(acc[mb][nb]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- epilogue on row-contiguous 16-B chunks ----------------------------------------------------------------
+    const int64_t base = tile * kRlTile + wave * kRlRowsPerWave;
+#pragma unroll
+    for (int it = 0; it < kRlRowsPerWave / EROWS; ++it) {
+      const int rl = it * EROWS + erow0;
+      const int64_t row = base + rl;
+      uint4 v = *reinterpret_cast<const uint4*>(my_stage + ((size_t)rl * G::PITCH + ech * 8) * 2);
+      if (row < m_rows) {
+        if (addend) {
+          float a[8], b[8];
+          V::unpack(v, a);
+          V::unpack(*reinterpret_cast<const uint4*>(addend + row * D + ech * 8), b);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] += b[j];
+          v = V::pack(a);
+        }
+        *reinterpret_cast<uint4*>(out + row * D + ech * 8) = v;
+        if (stats_ws) {
+          float a[8];
+          V::unpack(v, a);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float dlt = a[j] - sh[j]; s1[j] += dlt; s2[j] += dlt * dlt; }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) fb[mb][ks] = nxt[mb][ks];
+  }
+
+  // ---- per-workgroup partial sums: ws[blk][0][c] = sum(y - shift), ws[blk][1][c] = sum((y - shift)^2) -------------
+  if (stats_ws) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds_stage);       // [2][kBlock][8] floats = 16 KB (stage is >= 34 KB)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[(0 * kBlock + threadIdx.x) * 8 + j] = s1[j]; red[(1 * kBlock + threadIdx.x) * 8 + j] = s2[j]; }
+    __syncthreads();
+    for (int item = threadIdx.x; item < 2 * D; item += kBlock) {
+      const int which = item / D, c = item - which * D;
+      const int ch = c / 8, j = c - ch * 8;
+      float a = 0.f;
+      for (int t = ch; t < kBlock; t += G::CH) a += red[(which * kBlock + t) * 8 + j];     // fixed order: deterministic
+      stats_ws[((size_t)blockIdx.x * 2 + which) * D + c] = a;
+    }
+  }
+}
+
+template <typename T, int D>
+int launch_rowblock(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws, const float* shift,
+                    int64_t m, int grid, hipStream_t st) {
+  using G = RlGeom<D>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_linear_kernel<T, D>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
+    if (e != hipSuccess) { set_error("rowblock_linear: cannot reserve %zu B of LDS: %s", G::lds_bytes, hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((rowblock_linear_kernel<T, D>), dim3(grid), dim3(kBlock), G::lds_bytes, st, (T*)out, (const T*)in, (const T*)wl,
+                     (const T*)bias, (const T*)addend, stats_ws, shift, m);
+  return check_launch("rowblock_linear");
+}
+
+}  // namespace pygho
+
+using namespace pygho;
+
+extern "C" int pygho_rowblock_linear_blocks(int64_t m) {
+  if (m <= 0) return 0;
+  return grid_for(m, kRlTile, 512);          // 2 resident workgroups per CU (70 KB of LDS each)
+}
+
+extern "C" int pygho_rowblock_linear(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws,
+                                     const float* shift, int64_t m, int64_t d, int dtype, void* stream) {
+  if (m < 0 || d <= 0) { set_error("rowblock_linear: bad size"); return PYGHO_ERR_INVALID; }
+  if (m == 0) return PYGHO_OK;
+  if (!out || !in || !wl) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("rowblock_linear: bf16 / f16 only (f32 takes the library GEMM)"); return PYGHO_ERR_UNSUPPORTED; }
+  if (d != 64 && d != 128) { set_error("rowblock_linear: width %lld not supported (64, 128)", (long long)d); return PYGHO_ERR_UNSUPPORTED; }
+  if ((((uintptr_t)out | (uintptr_t)in | (uintptr_t)wl | (uintptr_t)addend) % 16) != 0) { set_error("rowblock_linear: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
+  const int grid = pygho_rowblock_linear_blocks(m);
+  hipStream_t st = (hipStream_t)stream;
+#define PYGHO_RL(T)                                                                                               \
+  (d == 128 ? launch_rowblock<T, 128>(out, in, wl, bias, addend, stats_ws, shift, m, grid, st)                     \
+            : launch_rowblock<T, 64>(out, in, wl, bias, addend, stats_ws, shift, m, grid, st))
+  return dtype == PYGHO_BF16 ? PYGHO_RL(bf16) : PYGHO_RL(f16);
+#undef PYGHO_RL
+}

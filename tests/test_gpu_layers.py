@@ -274,3 +274,32 @@ def test_bn_backward_column_sums(dev):
         dx, s1, s2, sdx = _ops._bn_backward(x, g, saved, False, "silu", want_colsum=True)
         ref = dx.double().sum(0)
         torch.testing.assert_close(sdx.double(), ref, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d", [128, 64])
+def test_rowblock_linear_matches_f32_reference(dev, dtype, d):
+    """the streaming tuple-wise GEMM (MFMA) against an f32 torch reference: product (+ bias) within one output rounding,
+    the residual-add epilogue equal to product-rounded-then-added, and the BatchNorm partial sums of its epilogue
+    equal to sums over the rounded output; ragged row counts exercise the tail tile."""
+    from pygho_amd import _ops
+    torch.manual_seed(7)
+    for m in (8192, 100_003, 300_000):
+        x = torch.randn(m, d, device=dev).to(dtype)
+        w = (torch.randn(d, d, device=dev) / d ** 0.5).to(dtype)       # asymmetric: a transposed operand would show
+        b = torch.randn(d, device=dev).to(dtype)
+        g = torch.randn(m, d, device=dev).to(dtype)
+        ref = torch.nn.functional.linear(x.float(), w.float(), b.float())
+        out, none = _ops.rowblock_linear(x, w, b)
+        assert none is None
+        ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        torch.testing.assert_close(out.float(), ref, rtol=ulp, atol=ulp)
+        shift = ref[0].contiguous()
+        out2, sums = _ops.rowblock_linear(x, w, b, stats_shift=shift)
+        assert torch.equal(out, out2)
+        o = out.double() - shift.double()
+        torch.testing.assert_close(sums[:, 0].double().sum(0), o.sum(0), rtol=1e-5, atol=1e-3 * m ** 0.5)
+        torch.testing.assert_close(sums[:, 1].double().sum(0), (o * o).sum(0), rtol=1e-5, atol=1e-3)
+        out3, _ = _ops.rowblock_linear(x, w, None, addend=g)
+        prod, _ = _ops.rowblock_linear(x, w, None)
+        assert torch.equal(out3, (prod.float() + g.float()).to(dtype))
