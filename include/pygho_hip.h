@@ -331,6 +331,21 @@ int pygho_rowblock_linear_blocks(int64_t m);
 int pygho_rowblock_linear(void* out, const void* in, const void* wl, const void* bias, const void* addend,
                           float* stats_ws, const float* shift, int64_t m, int64_t d, int dtype, void* stream);
 
+/* Backward of Linear -> BatchNorm -> act in one streaming pass (bf16 / f16, d = 64 or 128):
+ *   gpre = the input gradient of pygho_bn_act_bwd for (pre, gh) given the finished sums (same formula, same rounding),
+ *   gx   = gpre . W (+ addend)                    wl = W^T row-major
+ * gpre is written once (the weight-gradient GEMM reads it) and reaches the matrix cores through LDS, not HBM.
+ * colsum_ws (nullable): pygho_rowblock_linear_blocks(m) x 2 x d floats, [blk][0][c] = column sums of the rounded gpre
+ * over block blk (bias gradient; finalise with any per-block sum, e.g. a (blocks, 2, d) tensor summed over blocks). */
+int pygho_bn_bwd_linear(void* gx, void* gpre, const void* pre, const void* gh, const void* wl, const void* addend,
+                        float* colsum_ws, const float* mean, const float* invstd, const float* w, const float* b,
+                        const float* sum_dz, const float* sum_dz_xhat, int64_t m, int64_t d, int act, int training,
+                        int dtype, void* stream);
+/* the reduction half of pygho_bn_act_bwd alone: sum_dz, sum_dz_xhat (c floats each). */
+int pygho_bn_act_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
+                          const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act,
+                          void* workspace, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,8 @@ PROTOTYPES = {
     "pygho_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, P, I, P, P]),
     "pygho_rowblock_linear_blocks": (I, [L]),
     "pygho_rowblock_linear": (I, [P, P, P, P, P, P, P, L, L, I, P]),
+    "pygho_bn_bwd_linear": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, P]),
+    "pygho_bn_act_bwd_sums": (I, [P, P, P, P, P, P, P, P, L, L, I, P, I, P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

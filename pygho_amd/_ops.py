@@ -1182,6 +1182,7 @@ def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype) -> Tensor:
     return gw.to(out_dtype)
 
 
+USE_BN_BWD_LINEAR = True
 USE_ROWBLOCK_LINEAR = True      # module switch for A/B measurements (the library GEMM + separate passes otherwise)
 
 
@@ -1208,6 +1209,38 @@ def rowblock_linear(x: Tensor, wl: Tensor, bias: Optional[Tensor] = None, addend
     check(lib().pygho_rowblock_linear(ptr(out), ptr(x), ptr(wl), ptr(bias), ptr(addend), ptr(ws), ptr(stats_shift), m, d,
                                       dtype_code(x), stream_ptr(dev)), "rowblock_linear")
     return out, ws
+
+
+def bn_bwd_linear(pre: Tensor, gh: Tensor, saved, training: bool, act: str, w: Tensor, addend: Optional[Tensor],
+                  want_colsum: bool):
+    """(gx, gpre, d bn.bias, d bn.weight, column sums of gpre or None): BatchNorm/act backward and the input-gradient GEMM
+    gx = gpre @ w (+ addend) in one streaming kernel after the two-stage channel reduction."""
+    mean, invstd, w32, b32, ws = saved
+    m, c = pre.shape
+    dev = pre.device
+    st = stream_ptr(dev)
+    dt = dtype_code(pre)
+    s1 = torch.empty(c, dtype=torch.float32, device=dev)
+    s2 = torch.empty(c, dtype=torch.float32, device=dev)
+    if training:
+        check(lib().pygho_bn_act_bwd_sums(ptr(s1), ptr(s2), ptr(pre), ptr(gh), ptr(mean), ptr(invstd), ptr(w32), ptr(b32), m, c,
+                                          ACT_CODE[act], ptr(ws), dt, st), "bn_act_bwd_sums")
+    gx, gpre = torch.empty_like(pre), torch.empty_like(pre)
+    cws = None
+    if want_colsum or not training:
+        cws = torch.empty((int(lib().pygho_rowblock_linear_blocks(m)), 2, c), dtype=torch.float32, device=dev)
+    wl = w.t().contiguous()
+    if addend is not None:
+        addend = addend.contiguous()
+    check(lib().pygho_bn_bwd_linear(ptr(gx), ptr(gpre), ptr(pre), ptr(gh), ptr(wl), ptr(addend), ptr(cws), ptr(mean), ptr(invstd),
+                                    ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act], 1 if training else 0, dt, st),
+          "bn_bwd_linear")
+    sdx = cws[:, 0].sum(0) if cws is not None and want_colsum else None
+    if not training:
+        # eval mode: the sums are not part of the input gradient; take them with the two-pass kernel for the parameter grads
+        check(lib().pygho_bn_act_bwd_sums(ptr(s1), ptr(s2), ptr(pre), ptr(gh), ptr(mean), ptr(invstd), ptr(w32), ptr(b32), m, c,
+                                          ACT_CODE[act], ptr(ws), dt, st), "bn_act_bwd_sums")
+    return gx, gpre, s1, s2, sdx
 
 
 class _TupleBlock(torch.autograd.Function):
@@ -1261,9 +1294,13 @@ class _TupleBlock(torch.autograd.Function):
             if rhs is not None and ctx.needs_input_grad[10]:
                 p, a_g, c_g = plan.by_d()
                 g_rhs = seg_gmr(plan.n_rhs, g, h, p.seg_ptr, a_g, c_g, "sum", scale)
-        gpre, s1, s2, sdx = _bn_backward(pre, gh, saved, training, act, want_colsum=b_dtype is not None and ctx.needs_input_grad[2])
+        want_cs = b_dtype is not None and ctx.needs_input_grad[2]
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
+        if skinny and USE_BN_BWD_LINEAR:
+            gx, gpre, s1, s2, sdx = bn_bwd_linear(pre, gh.contiguous(), saved, training, act, w, g if residual else None, want_cs)
+        else:
+            gpre, s1, s2, sdx = _bn_backward(pre, gh, saved, training, act, want_colsum=want_cs)
+        if gx is None and ctx.needs_input_grad[0]:
             if skinny:
                 # dX = gpre . W (+ g): the residual gradient is added in the GEMM epilogue
                 gx, _ = rowblock_linear(gpre, w.t().contiguous(), None, addend=g if residual else None)

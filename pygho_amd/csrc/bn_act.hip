@@ -389,3 +389,20 @@ extern "C" int pygho_bn_finalize(float* mean, float* var, float* invstd, float* 
                      mean, var, partial_sums, (const float*)nullptr, m, (int)c, (int)n_blocks, dv, sum_shift);
   return check_launch("bn_finalize");
 }
+
+extern "C" int pygho_bn_act_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
+                                     const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act,
+                                     void* workspace, int dtype, void* stream) {
+  if (m <= 0 || c <= 0) { set_error("bn_act_bwd_sums: empty input"); return PYGHO_ERR_INVALID; }
+  if (!sum_dz || !sum_dz_xhat || !x || !gy || !mean || !invstd || !workspace) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  int chunks, grid;
+  if (int rc = bn_geometry(m, c, dtype, &chunks, &grid)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  PYGHO_BN_T(dtype, PYGHO_BN_ACT(act, {
+    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, A>), dim3(grid), dim3(kBlock), 0, st, (float*)workspace, (const T*)x,
+                       (const T*)gy, mean, invstd, w, b, m, (int)c, chunks);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, st, sum_dz, sum_dz_xhat,
+                       (const float*)workspace, (int)c, grid);
+  }));
+  return check_launch("bn_act_bwd_sums");
+}

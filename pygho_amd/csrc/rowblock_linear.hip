@@ -176,6 +176,188 @@ __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restric
   }
 }
 
+// ---- backward of Linear -> BatchNorm -> act in one streaming pass -----------------------------------------------------
+//   gpre = BatchNorm/act backward of (pre, gh)      (the apply half of pygho_bn_act_bwd, same formula and rounding)
+//   gx   = gpre . W (+ addend)                      (wl = W^T)
+// The BatchNorm input gradient is formed in the prologue on row-contiguous chunks, written once to HBM (the weight
+// gradient GEMM still reads it) and handed to the MFMAs through the wave's LDS stage instead of being re-read.
+struct BnBwdArgs {
+  const float* mean; const float* invstd; const float* w; const float* b;    // w / b nullable (1 / 0)
+  const float* sum_dz; const float* sum_dz_xhat;
+  int act; int training;
+};
+
+template <int ACT> __device__ __forceinline__ float rl_act_grad(float z) {
+  if (ACT == 1) return z > 0.f ? 1.f : 0.f;
+  if (ACT == 2) { const float sg = 1.f / (1.f + __expf(-z)); return sg * (1.f + z * (1.f - sg)); }
+  return 1.f;
+}
+
+template <typename T, int D, int ACT>
+__global__ __launch_bounds__(kBlock, 2) void bn_bwd_linear_kernel(T* __restrict__ gx, T* __restrict__ gpre, const T* __restrict__ pre,
+                                                                  const T* __restrict__ gh, const T* __restrict__ wl,
+                                                                  const T* __restrict__ addend, float* __restrict__ colsum_ws,
+                                                                  BnBwdArgs bn, int64_t m_rows) {
+  using G = RlGeom<D>;
+  using V = Vec16<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_w = smem;
+  char* lds_stage = smem + G::w_bytes;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  for (int item = threadIdx.x; item < D * G::CH; item += kBlock) {
+    const int n = item / G::CH, ch = item - n * G::CH;
+    *reinterpret_cast<uint4*>(lds_w + ((size_t)n * G::PITCH + ch * 8) * 2) = *reinterpret_cast<const uint4*>(wl + (size_t)n * D + ch * 8);
+  }
+  __syncthreads();
+
+  char* my_stage = lds_stage + (size_t)wave * kRlRowsPerWave * G::PITCH * 2;
+  const int64_t n_tiles = (m_rows + kRlTile - 1) / kRlTile;
+  const int ech = lane % G::CH, erow0 = lane / G::CH;
+  constexpr int EROWS = 64 / G::CH;
+  constexpr int EIT = kRlRowsPerWave / EROWS;
+  // per-channel constants of this lane's 8 columns:  xh = (x - mu) * is,  z = xh * ww + bb,
+  // gpre = ww * is * (dz - k1 - xh * k2)   with k1 = sum_dz / M, k2 = sum_dz_xhat / M (0 in eval mode)
+  float mu[8], is[8], ww[8], bb[8], k1[8], k2[8], cs[8];
+  {
+    const float inv_m = 1.f / (float)m_rows;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = ech * 8 + j;
+      mu[j] = bn.mean[c]; is[j] = bn.invstd[c]; ww[j] = bn.w ? bn.w[c] : 1.f; bb[j] = bn.b ? bn.b[c] : 0.f;
+      k1[j] = bn.training ? bn.sum_dz[c] * inv_m : 0.f;
+      k2[j] = bn.training ? bn.sum_dz_xhat[c] * inv_m : 0.f;
+      cs[j] = 0.f;
+    }
+  }
+  uint4 cy[EIT], cg[EIT];                                // current tile's (pre, gh) chunks, row-contiguous
+  auto load_tile = [&](int64_t tile, uint4 (&y)[EIT], uint4 (&g)[EIT]) {
+    const int64_t base = tile * kRlTile + wave * kRlRowsPerWave;
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      int64_t row = base + it * EROWS + erow0;
+      if (row >= m_rows) row = m_rows - 1;
+      y[it] = *reinterpret_cast<const uint4*>(pre + row * D + ech * 8);
+      g[it] = *reinterpret_cast<const uint4*>(gh + row * D + ech * 8);
+    }
+  };
+  int64_t tile = blockIdx.x;
+  if (tile < n_tiles) load_tile(tile, cy, cg);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    uint4 ny[EIT], ng[EIT];
+    const int64_t tn = tile + gridDim.x;
+    if (tn < n_tiles) load_tile(tn, ny, ng);
+    const int64_t base = tile * kRlTile + wave * kRlRowsPerWave;
+    // ---- prologue: BatchNorm / activation backward on this wave's 32 rows -> HBM (gpre) and LDS stage ---------------
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      const int rl = it * EROWS + erow0;
+      const int64_t row = base + rl;
+      float v[8], g[8];
+      V::unpack(cy[it], v);
+      V::unpack(cg[it], g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (v[j] - mu[j]) * is[j];
+        const float dz = g[j] * rl_act_grad<ACT>(xh * ww[j] + bb[j]);
+        v[j] = ww[j] * is[j] * (dz - k1[j] - xh * k2[j]);
+      }
+      const uint4 packed = V::pack(v);
+      *reinterpret_cast<uint4*>(my_stage + ((size_t)rl * G::PITCH + ech * 8) * 2) = packed;
+      if (row < m_rows) {
+        *reinterpret_cast<uint4*>(gpre + row * D + ech * 8) = packed;
+        if (colsum_ws) {
+          V::unpack(packed, v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cs[j] += v[j];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- gx tile = gpre tile . W  (fragments of gpre from the stage) ----------------------------------------------------
+    uint4 fb[2][G::KS];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks)
+        fb[mb][ks] = *reinterpret_cast<const uint4*>(my_stage + ((size_t)(mb * 16 + r16) * G::PITCH + ks * 32 + q * 8) * 2);
+    rl_f32x4_t acc[2][G::NB];
+#pragma unroll
+    for (int nb = 0; nb < G::NB; ++nb) { acc[0][nb] = rl_f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[1][nb] = rl_f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+      for (int nb = 0; nb < G::NB; ++nb) {
+        const uint4 fa = *reinterpret_cast<const uint4*>(lds_w + ((size_t)(nb * 16 + r16) * G::PITCH + ks * 32 + q * 8) * 2);
+        acc[0][nb] = rl_mfma<T>(fa, fb[0][ks], acc[0][nb]);
+        acc[1][nb] = rl_mfma<T>(fa, fb[1][ks], acc[1][nb]);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // all fragment reads of the stage are done (program order within
+    __builtin_amdgcn_wave_barrier();                            // the wave; the MFMAs above consumed them) before it is overwritten
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < G::NB; ++nb)
+        *reinterpret_cast<uint2*>(my_stage + ((size_t)(mb * 16 + r16) * G::PITCH + nb * 16 + q * 4) * 2) = rl_pack4<T>(acc[mb][nb]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      const int rl = it * EROWS + erow0;
+      const int64_t row = base + rl;
+      uint4 v = *reinterpret_cast<const uint4*>(my_stage + ((size_t)rl * G::PITCH + ech * 8) * 2);
+      if (row < m_rows) {
+        if (addend) {
+          float a[8], b[8];
+          V::unpack(v, a);
+          V::unpack(*reinterpret_cast<const uint4*>(addend + row * D + ech * 8), b);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] += b[j];
+          v = V::pack(a);
+        }
+        *reinterpret_cast<uint4*>(gx + row * D + ech * 8) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) { cy[it] = ny[it]; cg[it] = ng[it]; }
+  }
+  if (colsum_ws) {                                       // per-workgroup column sums of the rounded gpre (bias gradient)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds_stage);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = cs[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += kBlock) {
+      const int ch = c / 8, j = c - ch * 8;
+      float a = 0.f;
+      for (int t = ch; t < kBlock; t += G::CH) a += red[t * 8 + j];
+      colsum_ws[((size_t)blockIdx.x * 2 + 0) * D + c] = a;
+      colsum_ws[((size_t)blockIdx.x * 2 + 1) * D + c] = 0.f;
+    }
+  }
+}
+
+template <typename T, int D, int ACT>
+int launch_bn_bwd_linear(void* gx, void* gpre, const void* pre, const void* gh, const void* wl, const void* addend, float* colsum_ws,
+                         const BnBwdArgs& bn, int64_t m, int grid, hipStream_t st) {
+  using G = RlGeom<D>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_linear_kernel<T, D, ACT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
+    if (e != hipSuccess) { set_error("bn_bwd_linear: cannot reserve %zu B of LDS: %s", G::lds_bytes, hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bn_bwd_linear_kernel<T, D, ACT>), dim3(grid), dim3(kBlock), G::lds_bytes, st, (T*)gx, (T*)gpre, (const T*)pre,
+                     (const T*)gh, (const T*)wl, (const T*)addend, colsum_ws, bn, m);
+  return check_launch("bn_bwd_linear");
+}
+
 template <typename T, int D>
 int launch_rowblock(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws, const float* shift,
                     int64_t m, int grid, hipStream_t st) {
@@ -216,4 +398,26 @@ extern "C" int pygho_rowblock_linear(void* out, const void* in, const void* wl, 
             : launch_rowblock<T, 64>(out, in, wl, bias, addend, stats_ws, shift, m, grid, st))
   return dtype == PYGHO_BF16 ? PYGHO_RL(bf16) : PYGHO_RL(f16);
 #undef PYGHO_RL
+}
+
+extern "C" int pygho_bn_bwd_linear(void* gx, void* gpre, const void* pre, const void* gh, const void* wl, const void* addend,
+                                   float* colsum_ws, const float* mean, const float* invstd, const float* w, const float* b,
+                                   const float* sum_dz, const float* sum_dz_xhat, int64_t m, int64_t d, int act, int training,
+                                   int dtype, void* stream) {
+  if (m <= 0 || d <= 0) { set_error("bn_bwd_linear: empty input"); return PYGHO_ERR_INVALID; }
+  if (!gx || !gpre || !pre || !gh || !wl || !mean || !invstd || (training && (!sum_dz || !sum_dz_xhat))) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("bn_bwd_linear: bf16 / f16 only"); return PYGHO_ERR_UNSUPPORTED; }
+  if (d != 64 && d != 128) { set_error("bn_bwd_linear: width %lld not supported (64, 128)", (long long)d); return PYGHO_ERR_UNSUPPORTED; }
+  if (act < 0 || act > 2) { set_error("bn_bwd_linear: unknown activation %d", act); return PYGHO_ERR_INVALID; }
+  if ((((uintptr_t)gx | (uintptr_t)gpre | (uintptr_t)pre | (uintptr_t)gh | (uintptr_t)wl | (uintptr_t)addend) % 16) != 0) { set_error("bn_bwd_linear: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
+  const int grid = pygho_rowblock_linear_blocks(m);
+  hipStream_t st = (hipStream_t)stream;
+  const BnBwdArgs bn{mean, invstd, w, b, sum_dz, sum_dz_xhat, act, training};
+#define PYGHO_BL(T, DD)                                                                                                  \
+  (act == 0 ? launch_bn_bwd_linear<T, DD, 0>(gx, gpre, pre, gh, wl, addend, colsum_ws, bn, m, grid, st)                   \
+   : act == 1 ? launch_bn_bwd_linear<T, DD, 1>(gx, gpre, pre, gh, wl, addend, colsum_ws, bn, m, grid, st)                 \
+              : launch_bn_bwd_linear<T, DD, 2>(gx, gpre, pre, gh, wl, addend, colsum_ws, bn, m, grid, st))
+  if (dtype == PYGHO_BF16) return d == 128 ? PYGHO_BL(bf16, 128) : PYGHO_BL(bf16, 64);
+  return d == 128 ? PYGHO_BL(f16, 128) : PYGHO_BL(f16, 64);
+#undef PYGHO_BL
 }

@@ -303,3 +303,32 @@ def test_rowblock_linear_matches_f32_reference(dev, dtype, d):
         out3, _ = _ops.rowblock_linear(x, w, None, addend=g)
         prod, _ = _ops.rowblock_linear(x, w, None)
         assert torch.equal(out3, (prod.float() + g.float()).to(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("act", ["silu", "relu", "none"])
+def test_bn_bwd_linear_equals_two_kernel_path(dev, dtype, act):
+    """the one-pass backward of Linear -> BatchNorm -> act (BatchNorm input gradient formed in the GEMM prologue) is
+    bit-identical to pygho_bn_act_bwd followed by the streaming GEMM with the residual epilogue."""
+    from pygho_amd import _ops
+    torch.manual_seed(11)
+    d = 128
+    for m, training in ((100_003, True), (40_000, False)):
+        pre = (torch.randn(m, d, device=dev) * 1.2 + 0.3).to(dtype)
+        gh = torch.randn(m, d, device=dev).to(dtype)
+        g = torch.randn(m, d, device=dev).to(dtype)
+        w = (torch.randn(d, d, device=dev) / d ** 0.5).to(dtype)
+        bn = torch.nn.BatchNorm1d(d).to(dev).train(training)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3); bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 2.0)
+        _, _, _, saved = _ops._bn_forward(pre, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, act)
+        gpre0, s1, s2, sdx0 = _ops._bn_backward(pre, gh, saved, training, act, want_colsum=True)
+        gx0, _ = _ops.rowblock_linear(gpre0, w.t().contiguous(), None, addend=g)
+        gx1, gpre1, t1, t2, sdx1 = _ops.bn_bwd_linear(pre, gh, saved, training, act, w, g, True)
+        assert torch.equal(gpre0, gpre1) and torch.equal(gx0, gx1)
+        assert torch.equal(s1, t1) and torch.equal(s2, t2)
+        torch.testing.assert_close(sdx0, sdx1, rtol=1e-5, atol=1e-3)
+        gx2, _, _, _, none = _ops.bn_bwd_linear(pre, gh, saved, training, act, w, None, False)
+        assert none is None
+        ref, _ = _ops.rowblock_linear(gpre0, w.t().contiguous(), None)
+        assert torch.equal(gx2, ref)
