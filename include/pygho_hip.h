@@ -97,10 +97,12 @@ int pygho_seg_gather_mul_reduce_add(void* out, const void* addend, const void* l
  *   example/minimal.py:62-67   X.unpooling_fromdense1dim(0, .) * X.unpooling_fromdense1dim(1, .) * X.values
  * (two (nnz, d) gathers + two elementwise products -> one pass) and its three operand gradients, which are the
  * same kernel over the unit / by-root / by-node groupings.  Products are formed as (a * b) * c and summed in
- * message order (f32 bit-identical to the elementwise chain followed by a sequential sum). */
+ * message order (f32 bit-identical to the elementwise chain followed by a sequential sum).
+ * out_f32 != 0 (bf16 / f16 operands only): `out` is float -- the first level of a long-segment hierarchy. */
 int pygho_seg_triple_product(void* out, const void* a, const void* b, const void* c, const int32_t* seg_ptr,
                              const int32_t* a_idx, const int32_t* b_idx, const int32_t* c_idx, int64_t n_seg,
-                             int64_t d, int64_t a_rows, int64_t b_rows, int64_t c_rows, int dtype, void* stream);
+                             int64_t d, int64_t a_rows, int64_t b_rows, int64_t c_rows, int dtype, int out_f32,
+                             void* stream);
 
 /*
  * Backward of the max / min aggregation (autograd of scatter_reduce_(amax|amin),

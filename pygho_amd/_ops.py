@@ -62,7 +62,7 @@ class SegPlan:
         self.seg_ptr, self.perm, self.n_seg, self.m = seg_ptr, perm, n_seg, m
         self._inv_cnt = None
         self._memo = None
-        self._partner = None         # (index array, the same array in grouped order) of the last three-operand user
+        self._partner = None         # (key, index arrays in grouped order) of the last three-operand user
 
     @property
     def inv_count(self) -> Tensor:
@@ -244,19 +244,21 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
 
 
 def seg_triple(out_rows: int, a: Tensor, b: Tensor, c: Tensor, seg_ptr: Tensor, a_idx: Optional[Tensor],
-               b_idx: Optional[Tensor], c_idx: Optional[Tensor]) -> Tensor:
-    """out[s] = sum_{m in seg s} a[a_idx[m]] * b[b_idx[m]] * c[c_idx[m]]  (2-D operands of one dtype and width)."""
+               b_idx: Optional[Tensor], c_idx: Optional[Tensor], out_f32: bool = False) -> Tensor:
+    """out[s] = sum_{m in seg s} a[a_idx[m]] * b[b_idx[m]] * c[c_idx[m]]  (2-D operands of one dtype and width);
+    `out_f32`: f32 result for 16-bit operands (first level of a long-segment hierarchy)."""
     dev = require_device(a, b, c, seg_ptr, a_idx, b_idx, c_idx)
     assert a.dim() == b.dim() == c.dim() == 2 and a.shape[1] == b.shape[1] == c.shape[1] and a.dtype == b.dtype == c.dtype
     a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
     d = a.shape[1]
-    out = torch.empty((out_rows, d), dtype=a.dtype, device=dev)
+    out = torch.empty((out_rows, d), dtype=torch.float32 if out_f32 else a.dtype, device=dev)
     timer = LaunchTimer.active
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(dev))
     check(lib().pygho_seg_triple_product(ptr(out), ptr(a), ptr(b), ptr(c), ptr(seg_ptr), ptr(a_idx), ptr(b_idx), ptr(c_idx),
-                                         out_rows, d, a.shape[0], b.shape[0], c.shape[0], dtype_code(a), stream_ptr(dev)),
+                                         out_rows, d, a.shape[0], b.shape[0], c.shape[0], dtype_code(a),
+                                         1 if out_f32 and a.dtype != torch.float32 else 0, stream_ptr(dev)),
           "seg_triple_product")
     if timer is not None:
         e1.record(torch.cuda.current_stream(dev))
@@ -616,47 +618,73 @@ def spmm_values(val: Optional[Tensor], X: Tensor, src: Tensor, tar: Tensor, n_ta
 
 
 class _PairProduct(torch.autograd.Function):
-    """out[t] = (left[row[t]] * right[col[t]]) * val[t]: the tuple initialisation of example/minimal.py:62-67 (two
-    unpoolings of node features onto the tuple pattern and two elementwise products) as ONE pass; the three operand
-    gradients are the same three-operand kernel over the unit / by-row / by-col groupings of the tuples."""
+    """out[t] = (left[row[t]] * right[col[t]]) * val[vidx[t]] (vidx None = t): the tuple initialisation of
+    example/minimal.py:62-67 (two unpoolings of node features onto the tuple pattern and two elementwise products; with
+    `vidx` also the embedding lookup of the tuple feature, example/minimal.py:30-33) as ONE pass; the three operand
+    gradients are the same three-operand kernel over the unit / by-row / by-col / by-feature groupings of the tuples."""
 
     @staticmethod
-    def forward(ctx, left, right, val, row32, col32, by_row: SegPlan, by_col: SegPlan, col_by_row, row_by_col):
-        n = val.shape[0]
-        out = seg_triple(n, left, right, val, unit_ptr(n, val.device), row32, col32, None)
+    def forward(ctx, left, right, val, row32, col32, vidx32, by_row, by_col, by_val):
+        n = row32.numel()
+        out = seg_triple(n, left, right, val, unit_ptr(n, val.device), row32, col32, vidx32)
         ctx.save_for_backward(left, right, val)
-        ctx.idx = (row32, col32, by_row, by_col, col_by_row, row_by_col)
+        ctx.idx = (row32, col32, vidx32, by_row, by_col, by_val)
         return out
 
     @staticmethod
     def backward(ctx, g):
         left, right, val = ctx.saved_tensors
-        row32, col32, by_row, by_col, col_by_row, row_by_col = ctx.idx
+        row32, col32, vidx32, by_row, by_col, by_val = ctx.idx
         g = g.contiguous()
-        n = val.shape[0]
+        n = row32.numel()
         g_left = g_right = g_val = None
         if ctx.needs_input_grad[0]:
-            g_left = seg_triple(by_row.n_seg, g, val, right, by_row.seg_ptr, by_row.perm, by_row.perm, col_by_row)
+            p, col_p, v_p = by_row
+            g_left = seg_triple(p.n_seg, g, val, right, p.seg_ptr, p.perm, v_p if vidx32 is not None else p.perm, col_p)
         if ctx.needs_input_grad[1]:
-            g_right = seg_triple(by_col.n_seg, g, val, left, by_col.seg_ptr, by_col.perm, by_col.perm, row_by_col)
+            p, row_p, v_p = by_col
+            g_right = seg_triple(p.n_seg, g, val, left, p.seg_ptr, p.perm, v_p if vidx32 is not None else p.perm, row_p)
         if ctx.needs_input_grad[2]:
-            g_val = seg_triple(n, g, left, right, unit_ptr(n, g.device), None, row32, col32)
+            if vidx32 is None:
+                g_val = seg_triple(n, g, left, right, unit_ptr(n, g.device), None, row32, col32)
+            else:
+                # gradient of the (small) table: a handful of very long segments -> chunked f32 partial sums, then a tree
+                p, row_p, col_p = by_val
+                levels = p.levels(LONG_CHUNK) if p.max_len > LONG_SEGMENT else [p.seg_ptr]
+                cur = seg_triple(levels[0].numel() - 1, g, left, right, levels[0], p.perm, row_p, col_p, out_f32=len(levels) > 1)
+                for lv in levels[1:]:
+                    cur = seg_gmr(lv.numel() - 1, cur, None, lv, None, None, "sum")
+                g_val = cur.to(val.dtype)
         return g_left, g_right, g_val, None, None, None, None, None, None
 
 
-def pair_product(left: Tensor, right: Tensor, val: Tensor, row: Tensor, col: Tensor) -> Tensor:
-    """``left[row] * right[col] * val`` for (n_rows, d) / (n_cols, d) node features and (nnz, d) tuple values; `row` /
-    `col` are the persistent int64 index rows of the tuple pattern (plans are cached on them)."""
-    require_device(left, right, val, row, col)
+def _grouped(plan: SegPlan, key, *idx32):
+    """index arrays re-ordered into the plan's grouped order, memoised on the plan object."""
+    memo = plan._partner
+    if memo is None or memo[0] != key:
+        memo = (key, tuple(None if i is None else plan.take(i) for i in idx32))
+        plan._partner = memo
+    return memo[1]
+
+
+def pair_product(left: Tensor, right: Tensor, val: Tensor, row: Tensor, col: Tensor, val_index: Optional[Tensor] = None) -> Tensor:
+    """``left[row] * right[col] * val`` for (n_rows, d) / (n_cols, d) node features and (nnz, d) tuple values -- or, with
+    `val_index`, ``... * val[val_index]`` for a small (n_types, d) table.  `row` / `col` / `val_index` are persistent
+    int64 index arrays of the tuple pattern (plans are cached on them)."""
+    require_device(left, right, val, row, col, val_index)
     assert left.dim() == right.dim() == val.dim() == 2
-    by_row = cached_plan(row, left.shape[0], "pair-row")
-    by_col = cached_plan(col, right.shape[0], "pair-col")
     row32, col32 = narrow_i32(row), narrow_i32(col)
-    if by_row._partner is None or by_row._partner[0] is not col32:
-        by_row._partner = (col32, by_row.take(col32))
-    if by_col._partner is None or by_col._partner[0] is not row32:
-        by_col._partner = (row32, by_col.take(row32))
-    return _PairProduct.apply(left, right, val, row32, col32, by_row, by_col, by_row._partner[1], by_col._partner[1])
+    vidx32 = None if val_index is None else narrow_i32(val_index)
+    key = (id(row32), id(col32), id(vidx32))
+    p_row = cached_plan(row, left.shape[0], "pair-row")
+    p_col = cached_plan(col, right.shape[0], "pair-col")
+    by_row = (p_row,) + _grouped(p_row, key, col32, vidx32)
+    by_col = (p_col,) + _grouped(p_col, key, row32, vidx32)
+    by_val = None
+    if val_index is not None:
+        p_val = cached_plan(val_index, val.shape[0], "pair-val")
+        by_val = (p_val,) + _grouped(p_val, key, row32, col32)
+    return _PairProduct.apply(left, right, val, row32, col32, vidx32, by_row, by_col, by_val)
 
 
 # --------------------------------------------------------------------------
@@ -1182,6 +1210,7 @@ def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype) -> Tensor:
     return gw.to(out_dtype)
 
 
+USE_TABLE_PRODUCT = True
 USE_BN_BWD_LINEAR = True
 USE_ROWBLOCK_LINEAR = True      # module switch for A/B measurements (the library GEMM + separate passes otherwise)
 

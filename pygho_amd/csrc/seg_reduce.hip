@@ -398,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void seg_triple_generic_kernel(
   }
 }
 
-template <typename T, bool OFF32>
+template <typename T, bool OFF32, bool OUTF32>
 int launch_triple_fast(void* out, const void* a, const void* b, const void* c, const int32_t* seg_ptr, const int32_t* ai,
                        const int32_t* bi, const int32_t* ci, int64_t n_seg, int64_t d, hipStream_t st) {
   const int chunks = (int)(d * sizeof(T) / 16);
@@ -408,7 +408,7 @@ int launch_triple_fast(void* out, const void* a, const void* b, const void* c, c
   int gx = grid_for(n_seg, (kBlock / kWave) * spp);
   if (gx > 8) gx = (gx + 7) & ~7;
   dim3 grid(gx, (unsigned)ceil_div(chunks, kWave));
-  hipLaunchKernelGGL((seg_gmr_fast_kernel<T, PYGHO_SUM, MODE_BOTH, false, OFF32, false, true>), grid, dim3(kBlock), 0, st, (T*)out,
+  hipLaunchKernelGGL((seg_gmr_fast_kernel<T, PYGHO_SUM, MODE_BOTH, false, OFF32, OUTF32, true>), grid, dim3(kBlock), 0, st, (T*)out,
                      (const T*)a, (const T*)b, seg_ptr, ai, bi, (const float*)nullptr, (const T*)nullptr, n_seg, (int)d, chunks, log2g,
                      spp, (const T*)c, ci);
   return check_launch("seg_triple_product");
@@ -417,15 +417,25 @@ int launch_triple_fast(void* out, const void* a, const void* b, const void* c, c
 template <typename T, bool FAST_OK>
 int dispatch_triple(void* out, const void* a, const void* b, const void* c, const int32_t* seg_ptr, const int32_t* ai,
                     const int32_t* bi, const int32_t* ci, int64_t n_seg, int64_t d, int64_t a_rows, int64_t b_rows, int64_t c_rows,
-                    hipStream_t st) {
+                    bool out_f32, hipStream_t st) {
+  if (out_f32 && !(FAST_OK && sizeof(T) == 2 && (d * sizeof(T)) % 16 == 0)) {
+    set_error("seg_triple_product: f32 output needs bf16 / f16 rows of a multiple of 16 bytes");
+    return PYGHO_ERR_UNSUPPORTED;
+  }
   if constexpr (FAST_OK) {
     const bool aligned = (((uintptr_t)out | (uintptr_t)a | (uintptr_t)b | (uintptr_t)c) % 16) == 0;
     if ((d * sizeof(T)) % 16 == 0 && aligned) {
       const int64_t rb = d * (int64_t)sizeof(T), lim = (int64_t)1 << 32;
-      const bool off32 = n_seg * rb < lim && a_rows > 0 && a_rows * rb < lim && b_rows > 0 && b_rows * rb < lim && c_rows > 0 &&
-                         c_rows * rb < lim;
-      if (off32) return launch_triple_fast<T, true>(out, a, b, c, seg_ptr, ai, bi, ci, n_seg, d, st);
-      return launch_triple_fast<T, false>(out, a, b, c, seg_ptr, ai, bi, ci, n_seg, d, st);
+      const bool off32 = n_seg * rb * (out_f32 ? 2 : 1) < lim && a_rows > 0 && a_rows * rb < lim && b_rows > 0 && b_rows * rb < lim &&
+                         c_rows > 0 && c_rows * rb < lim;
+      if constexpr (sizeof(T) == 2) {
+        if (out_f32) {
+          if (off32) return launch_triple_fast<T, true, true>(out, a, b, c, seg_ptr, ai, bi, ci, n_seg, d, st);
+          return launch_triple_fast<T, false, true>(out, a, b, c, seg_ptr, ai, bi, ci, n_seg, d, st);
+        }
+      }
+      if (off32) return launch_triple_fast<T, true, false>(out, a, b, c, seg_ptr, ai, bi, ci, n_seg, d, st);
+      return launch_triple_fast<T, false, false>(out, a, b, c, seg_ptr, ai, bi, ci, n_seg, d, st);
     }
   }
   hipLaunchKernelGGL((seg_triple_generic_kernel<T>), dim3(grid_for(n_seg * d, kBlock)), dim3(kBlock), 0, st, (T*)out, (const T*)a,
@@ -579,16 +589,16 @@ extern "C" int pygho_seg_sum_f32out(float* out, const void* src, const int32_t* 
 
 extern "C" int pygho_seg_triple_product(void* out, const void* a, const void* b, const void* c, const int32_t* seg_ptr,
                                         const int32_t* a_idx, const int32_t* b_idx, const int32_t* c_idx, int64_t n_seg, int64_t d,
-                                        int64_t a_rows, int64_t b_rows, int64_t c_rows, int dtype, void* stream) {
+                                        int64_t a_rows, int64_t b_rows, int64_t c_rows, int dtype, int out_f32, void* stream) {
   if (n_seg < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
   if (n_seg == 0 || d == 0) return PYGHO_OK;
   if (!out || !a || !b || !c || !seg_ptr) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {
-    case PYGHO_F32: return dispatch_triple<float, true>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, st);
-    case PYGHO_BF16: return dispatch_triple<bf16, true>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, st);
-    case PYGHO_F16: return dispatch_triple<f16, true>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, st);
-    case PYGHO_F64: return dispatch_triple<double, false>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, st);
+    case PYGHO_F32: return dispatch_triple<float, true>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, out_f32 != 0, st);
+    case PYGHO_BF16: return dispatch_triple<bf16, true>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, out_f32 != 0, st);
+    case PYGHO_F16: return dispatch_triple<f16, true>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, out_f32 != 0, st);
+    case PYGHO_F64: return dispatch_triple<double, false>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, out_f32 != 0, st);
     default: set_error("unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED;
   }
 }

@@ -51,11 +51,16 @@ class InputEncoderSp(nn.Module):
     def _cast(self, t: Tensor) -> Tensor:
         return t if self.act_dtype is None or t.dtype == self.act_dtype else t.to(self.act_dtype)
 
-    def forward(self, datadict: dict) -> dict:
+    def forward(self, datadict: dict, defer_tuplefeat: bool = False) -> dict:
+        """`defer_tuplefeat`: leave X's integer feature in place and hand its embedding TABLE on as "X_table" -- the
+        consumer (SpModel.tupleinit) performs the lookup inside its fused product kernel."""
         out = dict(datadict)
         out["x"] = self._cast(self.x_encoder(datadict["x"].flatten()))
         out["A"] = datadict["A"].tuplewiseapply(lambda v: self._cast(self.ea_encoder(v)))
-        out["X"] = datadict["X"].tuplewiseapply(lambda v: self._cast(self.tuplefeat_encoder(v)))
+        if defer_tuplefeat:
+            out["X_table"] = self._cast(self.tuplefeat_encoder.weight)
+        else:
+            out["X"] = datadict["X"].tuplewiseapply(lambda v: self._cast(self.tuplefeat_encoder(v)))
         return out
 
 
@@ -76,9 +81,16 @@ class SpModel(nn.Module):
         conv_mlp = dict(mlp, numlayer=1, tailact=True)
         self.subggnns = nn.ModuleList([NGNNConv(hiddim, hiddim, "sum", "SS", conv_mlp) for _ in range(num_layer)])
 
-    def tupleinit(self, X: SparseTensor, x: Tensor) -> SparseTensor:
-        """X.values * lin0(x)[root] * lin1(x)[node] (example/minimal.py:62-67)."""
+    def tupleinit(self, X: SparseTensor, x: Tensor, table: Optional[Tensor] = None) -> SparseTensor:
+        """X.values * lin0(x)[root] * lin1(x)[node] (example/minimal.py:62-67); with `table`, X.values are still the
+        integer tuple features and the embedding lookup table[X.values] happens inside the same kernel."""
         left, right = self.lin_tupleinit0(x), self.lin_tupleinit1(x)
+        if table is not None:
+            vals = X.values
+            if not hasattr(vals, "_pygho_flat") or vals._pygho_flat[0] != vals._version:
+                vals._pygho_flat = (vals._version, vals.reshape(-1).contiguous())   # persistent object: plans are cached on it
+            feat = vals._pygho_flat[1]
+            return X.tuplewiseapply(lambda _: _ops.pair_product(left, right, table, X._row(0), X._row(1), feat))
         val = X.values
         if val.is_cuda and val.dim() == 2 and left.dtype == right.dtype == val.dtype:
             return X.tuplewiseapply(lambda v: _ops.pair_product(left, right, v, X._row(0), X._row(1)))
@@ -87,9 +99,12 @@ class SpModel(nn.Module):
         return X.tuplewiseapply(lambda v: subgx0.values * subgx1.values * v)
 
     def forward(self, datadict: dict) -> Tensor:
-        datadict = self.data_encoder(datadict)
+        raw = datadict["X"]
+        fuse = (_ops.USE_TABLE_PRODUCT and isinstance(raw, SparseTensor) and raw.values is not None and raw.values.is_cuda
+                and raw.values.dtype == torch.int64 and raw.values.numel() == raw.nnz)
+        datadict = self.data_encoder(datadict, defer_tuplefeat=fuse)
         A, X, x = datadict["A"], datadict["X"], datadict["x"]
-        X = self.tupleinit(X, x)
+        X = self.tupleinit(X, x, datadict.get("X_table"))
         for conv in self.subggnns:
             X = conv.forward_residual(A, X, datadict)      # == X.add(conv.forward(A, X, datadict), True), fused
         x = self.lpool(X)

@@ -444,3 +444,32 @@ def test_pair_product_matches_elementwise_chain(dev, dtype):
     # generic width (d = 5), f32
     l5, r5, v5 = left.float()[:, :5].contiguous(), right.float()[:, :5].contiguous(), val.float()[:, :5].contiguous()
     assert torch.equal(_ops.pair_product(l5, r5, v5, row, col), l5[row] * r5[col] * v5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pair_product_with_embedding_table(dev, dtype):
+    """left[root] * right[node] * table[feature]: the embedding lookup of the tuple feature inside the product kernel;
+    the table gradient (16 very long segments) goes through the chunked f32 hierarchy."""
+    from pygho_amd import _ops, synth
+    hb = synth.make_batch(96, "zinc", seed=4)
+    n, d = hb.num_nodes, 128
+    row, col = T(hb.tupleid[0], dev), T(hb.tupleid[1], dev)
+    feat = T(hb.tuplefeat.reshape(-1), dev)
+    torch.manual_seed(3)
+    mk = lambda r: torch.randn(r, d, device=dev).to(dtype)
+    left, right, table, w = mk(n), mk(n), mk(16), torch.randn(hb.num_tuples, d, device=dev)
+    a = [t.clone().requires_grad_(True) for t in (left, right, table)]
+    out = _ops.pair_product(a[0], a[1], a[2], row, col, feat)
+    (out.float() * w).sum().backward()
+    b = [t.double().clone().requires_grad_(True) for t in (left, right, table)]
+    ref = b[0][row] * b[1][col] * b[2][feat]
+    (ref * w.double()).sum().backward()
+    if dtype == torch.float32:
+        assert torch.equal(out, left[row] * right[col] * table[feat])
+    else:
+        torch.testing.assert_close(out.double(), ref, rtol=2.0 ** -7, atol=1e-6)
+    for x, y, name in zip(a, b, ("left", "right", "table")):
+        s = float(y.grad.abs().max())
+        tol = 1e-5 if dtype == torch.float32 else 2.0 ** -7
+        torch.testing.assert_close(x.grad.double() / s, y.grad / s, rtol=0, atol=tol, msg=name)
+    assert torch.equal(out, _ops.pair_product(left, right, table[feat].contiguous(), row, col))   # same kernel, same rounding
