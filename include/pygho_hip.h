@@ -343,6 +343,15 @@ int pygho_bn_bwd_linear(void* gx, void* gpre, const void* pre, const void* gh, c
                         float* colsum_ws, const float* mean, const float* invstd, const float* w, const float* b,
                         const float* sum_dz, const float* sum_dz_xhat, int64_t m, int64_t d, int act, int training,
                         int dtype, void* stream);
+/* pygho_bn_bwd_linear with the weight gradient folded in and gpre kept on chip:
+ *   gx = gpre . W (+ addend),   dw_ws[blk] = sum over the rows of block blk of gpre^T . x     (x = the Linear's input)
+ * dw_ws: pygho_bn_bwd_linear_dw_blocks(m) x d x d floats, to be summed over blocks ([n][k] = weight layout of
+ * torch.nn.Linear); colsum_ws as above with the same block count.  HBM traffic per row: pre, gh, x, addend in, gx out. */
+int pygho_bn_bwd_linear_dw_blocks(int64_t m);
+int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, const void* gh, const void* x, const void* wl,
+                           const void* addend, float* colsum_ws, const float* mean, const float* invstd, const float* w,
+                           const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m, int64_t d, int act,
+                           int training, int dtype, void* stream);
 /* the reduction half of pygho_bn_act_bwd alone: sum_dz, sum_dz_xhat (c floats each). */
 int pygho_bn_act_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
                           const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act,

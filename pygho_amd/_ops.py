@@ -1210,6 +1210,8 @@ def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype) -> Tensor:
     return gw.to(out_dtype)
 
 
+USE_FUSED_DW = False     # weight gradient inside the backward kernel: correct, but its one-workgroup-per-CU form measures
+                         # 0.80 ms against 0.45 + 0.19 ms for bn_bwd_linear + split-K GEMM at nnz = 1.8 M
 USE_TABLE_PRODUCT = True
 USE_BN_BWD_LINEAR = True
 USE_ROWBLOCK_LINEAR = True      # module switch for A/B measurements (the library GEMM + separate passes otherwise)
@@ -1241,9 +1243,11 @@ def rowblock_linear(x: Tensor, wl: Tensor, bias: Optional[Tensor] = None, addend
 
 
 def bn_bwd_linear(pre: Tensor, gh: Tensor, saved, training: bool, act: str, w: Tensor, addend: Optional[Tensor],
-                  want_colsum: bool):
-    """(gx, gpre, d bn.bias, d bn.weight, column sums of gpre or None): BatchNorm/act backward and the input-gradient GEMM
-    gx = gpre @ w (+ addend) in one streaming kernel after the two-stage channel reduction."""
+                  want_colsum: bool, x: Optional[Tensor] = None):
+    """(gx, gpre or dW, d bn.bias, d bn.weight, column sums of gpre or None): BatchNorm/act backward and the
+    input-gradient GEMM gx = gpre @ w (+ addend) in one streaming kernel after the two-stage channel reduction.
+    With `x` (the Linear's input) the weight gradient gpre^T @ x (f32) is accumulated in the same pass and returned in
+    place of gpre, which then never reaches HBM."""
     mean, invstd, w32, b32, ws = saved
     m, c = pre.shape
     dev = pre.device
@@ -1251,25 +1255,27 @@ def bn_bwd_linear(pre: Tensor, gh: Tensor, saved, training: bool, act: str, w: T
     dt = dtype_code(pre)
     s1 = torch.empty(c, dtype=torch.float32, device=dev)
     s2 = torch.empty(c, dtype=torch.float32, device=dev)
-    if training:
-        check(lib().pygho_bn_act_bwd_sums(ptr(s1), ptr(s2), ptr(pre), ptr(gh), ptr(mean), ptr(invstd), ptr(w32), ptr(b32), m, c,
-                                          ACT_CODE[act], ptr(ws), dt, st), "bn_act_bwd_sums")
-    gx, gpre = torch.empty_like(pre), torch.empty_like(pre)
-    cws = None
-    if want_colsum or not training:
-        cws = torch.empty((int(lib().pygho_rowblock_linear_blocks(m)), 2, c), dtype=torch.float32, device=dev)
+    check(lib().pygho_bn_act_bwd_sums(ptr(s1), ptr(s2), ptr(pre), ptr(gh), ptr(mean), ptr(invstd), ptr(w32), ptr(b32), m, c,
+                                      ACT_CODE[act], ptr(ws), dt, st), "bn_act_bwd_sums")
+    gx = torch.empty_like(pre)
     wl = w.t().contiguous()
     if addend is not None:
         addend = addend.contiguous()
-    check(lib().pygho_bn_bwd_linear(ptr(gx), ptr(gpre), ptr(pre), ptr(gh), ptr(wl), ptr(addend), ptr(cws), ptr(mean), ptr(invstd),
-                                    ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act], 1 if training else 0, dt, st),
-          "bn_bwd_linear")
-    sdx = cws[:, 0].sum(0) if cws is not None and want_colsum else None
-    if not training:
-        # eval mode: the sums are not part of the input gradient; take them with the two-pass kernel for the parameter grads
-        check(lib().pygho_bn_act_bwd_sums(ptr(s1), ptr(s2), ptr(pre), ptr(gh), ptr(mean), ptr(invstd), ptr(w32), ptr(b32), m, c,
-                                          ACT_CODE[act], ptr(ws), dt, st), "bn_act_bwd_sums")
-    return gx, gpre, s1, s2, sdx
+    nblk = int(lib().pygho_bn_bwd_linear_dw_blocks(m) if x is not None else lib().pygho_rowblock_linear_blocks(m))
+    cws = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev) if want_colsum else None
+    if x is not None:
+        second = torch.empty((nblk, c, c), dtype=torch.float32, device=dev)
+        check(lib().pygho_bn_bwd_linear_dw(ptr(gx), ptr(second), ptr(pre), ptr(gh), ptr(x), ptr(wl), ptr(addend), ptr(cws), ptr(mean),
+                                           ptr(invstd), ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act],
+                                           1 if training else 0, dt, st), "bn_bwd_linear_dw")
+        second = second.sum(0)
+    else:
+        second = torch.empty_like(pre)
+        check(lib().pygho_bn_bwd_linear(ptr(gx), ptr(second), ptr(pre), ptr(gh), ptr(wl), ptr(addend), ptr(cws), ptr(mean), ptr(invstd),
+                                        ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act], 1 if training else 0, dt, st),
+              "bn_bwd_linear")
+    sdx = cws[:, 0].sum(0) if cws is not None else None
+    return gx, second, s1, s2, sdx
 
 
 class _TupleBlock(torch.autograd.Function):
@@ -1325,7 +1331,10 @@ class _TupleBlock(torch.autograd.Function):
                 g_rhs = seg_gmr(plan.n_rhs, g, h, p.seg_ptr, a_g, c_g, "sum", scale)
         want_cs = b_dtype is not None and ctx.needs_input_grad[2]
         gx = gw = gb = None
-        if skinny and USE_BN_BWD_LINEAR:
+        if skinny and USE_BN_BWD_LINEAR and USE_FUSED_DW and ctx.needs_input_grad[1]:
+            gx, gw32, s1, s2, sdx = bn_bwd_linear(pre, gh.contiguous(), saved, training, act, w, g if residual else None, want_cs, x=x)
+            gw = gw32.to(w_dtype)
+        elif skinny and USE_BN_BWD_LINEAR:
             gx, gpre, s1, s2, sdx = bn_bwd_linear(pre, gh.contiguous(), saved, training, act, w, g if residual else None, want_cs)
         else:
             gpre, s1, s2, sdx = _bn_backward(pre, gh, saved, training, act, want_colsum=want_cs)
@@ -1338,7 +1347,7 @@ class _TupleBlock(torch.autograd.Function):
                 gx = gpre @ w
                 if residual:
                     gx = gx.add_(g)
-        if ctx.needs_input_grad[1]:
+        if gw is None and ctx.needs_input_grad[1]:
             gw = weight_grad_splitk(gpre, x, w_dtype)
         if sdx is not None:
             gb = sdx.to(b_dtype)

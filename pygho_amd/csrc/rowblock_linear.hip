@@ -358,6 +358,227 @@ int launch_bn_bwd_linear(void* gx, void* gpre, const void* pre, const void* gh, 
   return check_launch("bn_bwd_linear");
 }
 
+// ---- the same backward pass with the WEIGHT gradient folded in -------------------------------------------------------
+//   gpre (never written to HBM) = BatchNorm/act backward of (pre, gh);  gx = gpre . W (+ addend);  dW = gpre^T . x
+// One 512-thread workgroup per CU walks 128-row tiles.  Every wave forms gpre for its 16 rows and stages it next to the
+// matching x rows in LDS; after a barrier it multiplies its own rows with W (gx) and accumulates ONE 16-row slab of
+// dW[n][k] = sum_m gpre[m][n] x[m][k] over all 128 rows of the tile: both operands of that product are needed with the
+// reduction index m along the lanes' 8-element fragments, i.e. as COLUMNS of the row-major staged tiles, which is what
+// the LDS transpose read ds_read_b64_tr_b16 delivers (two reads per fragment).  Per-workgroup dW partials are summed by
+// the caller.  HBM traffic per row: pre, gh, x, addend in, gx out -- 5 streams instead of 8 for the three-kernel path.
+typedef __attribute__((ext_vector_type(4))) short rl_s4_t;
+constexpr int kDwThreads = 512, kDwWaves = 8, kDwRowsPerWave = 16, kDwTile = 128;
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the outstanding GLOBAL loads (vmcnt(0)),
+// i.e. the next tile's prefetch, twice per tile
+__device__ __forceinline__ void rl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int D> struct DwGeom {
+  static constexpr int PBX = (RlGeom<D>::PITCH + 8) * 2;   // x tile: 32 B past a multiple of 256 B -> the transpose reads of
+                                                           // 8 consecutive rows (one 32-lane half) cover all 64 banks once
+  static constexpr size_t tile_bytes = (size_t)kDwTile * RlGeom<D>::PITCH * 2;
+  static constexpr size_t xtile_bytes = (size_t)kDwTile * PBX;
+  static constexpr size_t lds_bytes = RlGeom<D>::w_bytes + 2 * tile_bytes + xtile_bytes;
+};
+
+template <typename T, int D, int ACT>
+__global__ __launch_bounds__(kDwThreads, 1) void bn_bwd_linear_dw_kernel(T* __restrict__ gx, const T* __restrict__ pre,
+                                                                         const T* __restrict__ gh, const T* __restrict__ x,
+                                                                         const T* __restrict__ wl, const T* __restrict__ addend,
+                                                                         float* __restrict__ colsum_ws, float* __restrict__ dw_ws,
+                                                                         BnBwdArgs bn, int64_t m_rows) {
+  using G = RlGeom<D>;
+  using V = Vec16<T>;
+  constexpr int PB = G::PITCH * 2;                       // LDS row pitch in bytes (W^T, gpre and output tiles)
+  constexpr int PBX = DwGeom<D>::PBX;                    // ... of the x tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_w = smem;
+  char* stage_g = smem + G::w_bytes;
+  char* stage_x = stage_g + DwGeom<D>::tile_bytes;
+  char* stage_o = stage_x + DwGeom<D>::xtile_bytes;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  for (int item = threadIdx.x; item < D * G::CH; item += kDwThreads) {
+    const int n = item / G::CH, ch = item - n * G::CH;
+    *reinterpret_cast<uint4*>(lds_w + (size_t)n * PB + ch * 16) = *reinterpret_cast<const uint4*>(wl + (size_t)n * D + ch * 8);
+  }
+  const int64_t n_tiles = (m_rows + kDwTile - 1) / kDwTile;
+  const int ech = lane % G::CH, erow0 = lane / G::CH;
+  constexpr int EROWS = 64 / G::CH;
+  constexpr int EIT = kDwRowsPerWave / EROWS;
+  float mu[8], is[8], ww[8], bb[8], k1[8], k2[8], cs[8];
+  {
+    const float inv_m = 1.f / (float)m_rows;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = ech * 8 + j;
+      mu[j] = bn.mean[c]; is[j] = bn.invstd[c]; ww[j] = bn.w ? bn.w[c] : 1.f; bb[j] = bn.b ? bn.b[c] : 0.f;
+      k1[j] = bn.training ? bn.sum_dz[c] * inv_m : 0.f;
+      k2[j] = bn.training ? bn.sum_dz_xhat[c] * inv_m : 0.f;
+      cs[j] = 0.f;
+    }
+  }
+  rl_f32x4_t acc_w[G::NB];                               // dW slab of this wave: rows n0 + q*4 + r, columns kb*16 + r16
+#pragma unroll
+  for (int kb = 0; kb < G::NB; ++kb) acc_w[kb] = rl_f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const bool dw_wave = wave < G::NB;
+  const int n0 = wave * 16;
+
+  uint4 cy[EIT], cg[EIT], cx[EIT], ca[EIT];
+  auto load_tile = [&](int64_t tile, uint4 (&y)[EIT], uint4 (&g)[EIT], uint4 (&xx)[EIT], uint4 (&aa)[EIT]) {
+    const int64_t base = tile * kDwTile + wave * kDwRowsPerWave;
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      int64_t row = base + it * EROWS + erow0;
+      if (row >= m_rows) row = m_rows - 1;
+      const int64_t off = row * D + ech * 8;
+      y[it] = *reinterpret_cast<const uint4*>(pre + off);
+      g[it] = *reinterpret_cast<const uint4*>(gh + off);
+      xx[it] = *reinterpret_cast<const uint4*>(x + off);
+      if (addend) aa[it] = *reinterpret_cast<const uint4*>(addend + off);
+    }
+  };
+  int64_t tile = blockIdx.x;
+  if (tile < n_tiles) load_tile(tile, cy, cg, cx, ca);
+  __syncthreads();                                       // W^T staged
+  for (; tile < n_tiles; tile += gridDim.x) {
+    uint4 ny[EIT], ng[EIT], nx[EIT], na[EIT];
+    const int64_t tn = tile + gridDim.x;
+    if (tn < n_tiles) load_tile(tn, ny, ng, nx, na);
+    const int64_t base = tile * kDwTile + wave * kDwRowsPerWave;
+    // ---- prologue: gpre of this wave's 16 rows and the matching x rows -> LDS (rows past the end as zeros) ---------------
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      const int rl = wave * kDwRowsPerWave + it * EROWS + erow0;
+      const bool valid = base + it * EROWS + erow0 < m_rows;
+      float v[8], g[8];
+      V::unpack(cy[it], v);
+      V::unpack(cg[it], g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (v[j] - mu[j]) * is[j];
+        const float dz = g[j] * rl_act_grad<ACT>(xh * ww[j] + bb[j]);
+        v[j] = ww[j] * is[j] * (dz - k1[j] - xh * k2[j]);
+      }
+      uint4 packed = V::pack(v);
+      if (!valid) packed = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(stage_g + (size_t)rl * PB + ech * 16) = packed;
+      *reinterpret_cast<uint4*>(stage_x + (size_t)rl * PBX + ech * 16) = cx[it];
+      if (colsum_ws) {
+        V::unpack(packed, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] += v[j];
+      }
+    }
+    rl_lds_barrier();
+    // ---- gx rows of this wave: gpre . W ------------------------------------------------------------------------------------
+    rl_f32x4_t acc[G::NB];
+#pragma unroll
+    for (int nb = 0; nb < G::NB; ++nb) acc[nb] = rl_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const uint4 fb = *reinterpret_cast<const uint4*>(stage_g + (size_t)(wave * kDwRowsPerWave + r16) * PB + (ks * 32 + q * 8) * 2);
+#pragma unroll
+      for (int nb = 0; nb < G::NB; ++nb) {
+        const uint4 fa = *reinterpret_cast<const uint4*>(lds_w + (size_t)(nb * 16 + r16) * PB + (ks * 32 + q * 8) * 2);
+        acc[nb] = rl_mfma<T>(fa, fb, acc[nb]);
+      }
+    }
+    // ---- dW slab: sum over the tile's 128 rows, operands read as columns of the staged tiles -------------------------------
+    if (dw_wave) {
+      // the reduction index of an MFMA may be permuted freely as long as both operands use the same permutation: lane
+      // group q takes rows {0-3, 8-11} + 4 (q & 1) + 16 (q >> 1) of each 32-row step, so that the two groups of a 32-lane
+      // half read 8 CONSECUTIVE rows per transpose read (conflict-free with the x tile's pitch)
+      const int rsel = (q & 1) * 4 + (q >> 1) * 16 + (r16 >> 2);
+#pragma unroll
+      for (int ms = 0; ms < kDwTile / 32; ++ms) {
+        const int row = ms * 32 + rsel;
+        const char* ga = stage_g + (size_t)row * PB + (r16 & 3) * 8 + n0 * 2;
+        const uint4 fa = [&] {
+          const rl_s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(ga));
+          const rl_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(ga + 8 * PB));
+          const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+          return make_uint4(a.x, a.y, b.x, b.y);
+        }();
+        const char* xa = stage_x + (size_t)row * PBX + (r16 & 3) * 8;
+#pragma unroll
+        for (int kb = 0; kb < G::NB; ++kb) {
+          const rl_s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(xa + kb * 32));
+          const rl_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(xa + kb * 32 + 8 * PBX));
+          const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+          acc_w[kb] = rl_mfma<T>(fa, make_uint4(a.x, a.y, b.x, b.y), acc_w[kb]);
+        }
+      }
+    }
+    rl_lds_barrier();                                    // every wave is done with stage_g / stage_x of this tile
+    // ---- epilogue: accumulators -> own rows of stage_o -> row-contiguous chunks (+ addend) -> HBM ---------------------------
+#pragma unroll
+    for (int nb = 0; nb < G::NB; ++nb)
+      *reinterpret_cast<uint2*>(stage_o + (size_t)(wave * kDwRowsPerWave + r16) * PB + (nb * 16 + q * 4) * 2) = rl_pack4<T>(acc[nb]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      const int rl = wave * kDwRowsPerWave + it * EROWS + erow0;
+      const int64_t row = base + it * EROWS + erow0;
+      uint4 v = *reinterpret_cast<const uint4*>(stage_o + (size_t)rl * PB + ech * 16);
+      if (row < m_rows) {
+        if (addend) {
+          float a[8], b[8];
+          V::unpack(v, a);
+          V::unpack(ca[it], b);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] += b[j];
+          v = V::pack(a);
+        }
+        *reinterpret_cast<uint4*>(gx + row * D + ech * 8) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) { cy[it] = ny[it]; cg[it] = ng[it]; cx[it] = nx[it]; ca[it] = na[it]; }
+  }
+  // ---- per-workgroup results: dW partial (D x D f32) and the column sums of gpre ------------------------------------------
+  if (dw_wave) {
+#pragma unroll
+    for (int kb = 0; kb < G::NB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dw_ws[((size_t)blockIdx.x * D + n0 + q * 4 + r) * D + kb * 16 + r16] = acc_w[kb][r];
+  }
+  if (colsum_ws) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(stage_o);      // [512][8] floats = 16 KB
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = cs[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += kDwThreads) {
+      const int ch = c / 8, j = c - ch * 8;
+      float a = 0.f;
+      for (int t = ch; t < kDwThreads; t += G::CH) a += red[t * 8 + j];
+      colsum_ws[((size_t)blockIdx.x * 2 + 0) * D + c] = a;
+      colsum_ws[((size_t)blockIdx.x * 2 + 1) * D + c] = 0.f;
+    }
+  }
+}
+
+template <typename T, int D, int ACT>
+int launch_bn_bwd_linear_dw(void* gx, const void* pre, const void* gh, const void* x, const void* wl, const void* addend,
+                            float* colsum_ws, float* dw_ws, const BnBwdArgs& bn, int64_t m, int grid, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_linear_dw_kernel<T, D, ACT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)DwGeom<D>::lds_bytes);
+    if (e != hipSuccess) { set_error("bn_bwd_linear_dw: cannot reserve %zu B of LDS: %s", DwGeom<D>::lds_bytes, hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bn_bwd_linear_dw_kernel<T, D, ACT>), dim3(grid), dim3(kDwThreads), DwGeom<D>::lds_bytes, st, (T*)gx, (const T*)pre,
+                     (const T*)gh, (const T*)x, (const T*)wl, (const T*)addend, colsum_ws, dw_ws, bn, m);
+  return check_launch("bn_bwd_linear_dw");
+}
+
 template <typename T, int D>
 int launch_rowblock(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws, const float* shift,
                     int64_t m, int grid, hipStream_t st) {
@@ -420,4 +641,31 @@ extern "C" int pygho_bn_bwd_linear(void* gx, void* gpre, const void* pre, const 
   if (dtype == PYGHO_BF16) return d == 128 ? PYGHO_BL(bf16, 128) : PYGHO_BL(bf16, 64);
   return d == 128 ? PYGHO_BL(f16, 128) : PYGHO_BL(f16, 64);
 #undef PYGHO_BL
+}
+
+extern "C" int pygho_bn_bwd_linear_dw_blocks(int64_t m) {
+  if (m <= 0) return 0;
+  return grid_for(m, kDwTile, 256);          // one resident 512-thread workgroup per CU (139 KB of LDS at d = 128)
+}
+
+extern "C" int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, const void* gh, const void* x, const void* wl,
+                                      const void* addend, float* colsum_ws, const float* mean, const float* invstd, const float* w,
+                                      const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m, int64_t d, int act,
+                                      int training, int dtype, void* stream) {
+  if (m <= 0 || d <= 0) { set_error("bn_bwd_linear_dw: empty input"); return PYGHO_ERR_INVALID; }
+  if (!gx || !dw_ws || !pre || !gh || !x || !wl || !mean || !invstd || (training && (!sum_dz || !sum_dz_xhat))) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("bn_bwd_linear_dw: bf16 / f16 only"); return PYGHO_ERR_UNSUPPORTED; }
+  if (d != 64 && d != 128) { set_error("bn_bwd_linear_dw: width %lld not supported (64, 128)", (long long)d); return PYGHO_ERR_UNSUPPORTED; }
+  if (act < 0 || act > 2) { set_error("bn_bwd_linear_dw: unknown activation %d", act); return PYGHO_ERR_INVALID; }
+  if ((((uintptr_t)gx | (uintptr_t)pre | (uintptr_t)gh | (uintptr_t)x | (uintptr_t)wl | (uintptr_t)addend) % 16) != 0) { set_error("bn_bwd_linear_dw: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
+  const int grid = pygho_bn_bwd_linear_dw_blocks(m);
+  hipStream_t st = (hipStream_t)stream;
+  const BnBwdArgs bn{mean, invstd, w, b, sum_dz, sum_dz_xhat, act, training};
+#define PYGHO_BLW(T, DD)                                                                                                        \
+  (act == 0 ? launch_bn_bwd_linear_dw<T, DD, 0>(gx, pre, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, st)                   \
+   : act == 1 ? launch_bn_bwd_linear_dw<T, DD, 1>(gx, pre, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, st)                 \
+              : launch_bn_bwd_linear_dw<T, DD, 2>(gx, pre, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, st))
+  if (dtype == PYGHO_BF16) return d == 128 ? PYGHO_BLW(bf16, 128) : PYGHO_BLW(bf16, 64);
+  return d == 128 ? PYGHO_BLW(f16, 128) : PYGHO_BLW(f16, 64);
+#undef PYGHO_BLW
 }

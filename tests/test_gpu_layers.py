@@ -332,3 +332,11 @@ def test_bn_bwd_linear_equals_two_kernel_path(dev, dtype, act):
         assert none is None
         ref, _ = _ops.rowblock_linear(gpre0, w.t().contiguous(), None)
         assert torch.equal(gx2, ref)
+        # weight gradient folded in (gpre never written): same gx bits, dW = gpre^T x against an f64 product of the rounded gpre
+        x = torch.randn(m, d, device=dev).to(dtype)
+        gx3, dw, u1, u2, sdx3 = _ops.bn_bwd_linear(pre, gh, saved, training, act, w, g, True, x=x)
+        assert torch.equal(gx3, gx0) and torch.equal(u1, s1) and torch.equal(u2, s2)
+        torch.testing.assert_close(sdx3, sdx0, rtol=1e-5, atol=1e-3)
+        dw_ref = gpre0.double().t() @ x.double()
+        scale = float(dw_ref.abs().max())
+        torch.testing.assert_close(dw.double() / scale, dw_ref / scale, rtol=0, atol=2e-6)
