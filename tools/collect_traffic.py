@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""
+Turn the two rocprofv3 --pmc passes of the bench command (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) into
+profiles/<tag>_traffic.json: HBM bytes per launch of the dominant kernel (seg_gmr_fast_kernel<bf16, SUM, BOTH>), corrected
+as MI355X_MICROARCH.md prescribes (counters are in KiB; FETCH_SIZE is half-counted on gfx950 for coalesced 16-B reads:
+x1.97 from the calibration in profiles/r01_pmc_seg_gmr.md; WRITE_SIZE is exact).
+
+usage: collect_traffic.py <fetch_dir> <write_dir> <kernel_stats.csv> <out.json> [graphs hidden dtype]
+"""
+import csv
+import glob
+import json
+import sys
+
+KERNEL = "seg_gmr_fast_kernel<pygho::bf16, 0, 0, false, true, false, false>"
+FETCH_CORRECTION = 1.97
+
+
+def mean_counter(directory, name):
+    f = glob.glob(directory + "/**/*counter_collection.csv", recursive=True)[0]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+            if r["Counter_Name"] == name and KERNEL in r["Kernel_Name"] and int(r["Grid_Size"]) > 100000]
+    return sum(vals) / len(vals) * 1024.0, len(vals)
+
+
+def main():
+    fetch_dir, write_dir, stats_csv, out = sys.argv[1:5]
+    graphs, hidden, dtype = (int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]) if len(sys.argv) > 7 else (8192, 128, "bf16")
+    fetch, n = mean_counter(fetch_dir, "FETCH_SIZE")
+    write, _ = mean_counter(write_dir, "WRITE_SIZE")
+    row = next(r for r in csv.DictReader(open(stats_csv)) if KERNEL in r["Name"])
+    json.dump({
+        "kernel": "seg_gmr_fast_kernel<bf16,SUM,BOTH>",
+        "config": {"graphs_per_gpu": graphs, "hidden": hidden, "dtype": dtype},
+        "launches_profiled": n,
+        "FETCH_SIZE_bytes_raw": fetch, "FETCH_SIZE_correction": FETCH_CORRECTION, "WRITE_SIZE_bytes": write,
+        "traffic_bytes_per_launch": fetch * FETCH_CORRECTION + write,
+        "rocprof_avg_us": float(row["AverageNs"]) / 1e3, "rocprof_calls": int(row["Calls"]),
+        "note": "separate --pmc passes of `rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 3 "
+                "--warmup 1 --no-cpu-baseline`; launches with grid > 100k threads only (the 8192-graph aggregation: forward with "
+                "the residual row + both backward launches per layer); FETCH_SIZE x1.97 per profiles/r01_pmc_seg_gmr.md",
+    }, open(out, "w"), indent=1)
+    print(open(out).read())
+
+
+if __name__ == "__main__":
+    main()
