@@ -189,7 +189,7 @@ struct BnBwdArgs {
 
 template <int ACT> __device__ __forceinline__ float rl_act_grad(float z) {
   if (ACT == 1) return z > 0.f ? 1.f : 0.f;
-  if (ACT == 2) { const float sg = 1.f / (1.f + __expf(-z)); return sg * (1.f + z * (1.f - sg)); }
+  if (ACT == 2) { const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-z)); return sg * (1.f + z * (1.f - sg)); }   // = bn_act.hip
   return 1.f;
 }
 
@@ -360,14 +360,14 @@ int launch_bn_bwd_linear(void* gx, void* gpre, const void* pre, const void* gh, 
 
 // ---- the same backward pass with the WEIGHT gradient folded in -------------------------------------------------------
 //   gpre (never written to HBM) = BatchNorm/act backward of (pre, gh);  gx = gpre . W (+ addend);  dW = gpre^T . x
-// One 512-thread workgroup per CU walks 128-row tiles.  Every wave forms gpre for its 16 rows and stages it next to the
-// matching x rows in LDS; after a barrier it multiplies its own rows with W (gx) and accumulates ONE 16-row slab of
-// dW[n][k] = sum_m gpre[m][n] x[m][k] over all 128 rows of the tile: both operands of that product are needed with the
+// Two 256-thread workgroups per CU walk 64-row tiles.  Every wave forms gpre for its 16 rows and stages it next to the
+// matching x rows in LDS; after a barrier it multiplies its own rows with W (gx) and accumulates its slab of
+// dW[n][k] = sum_m gpre[m][n] x[m][k] over all 64 rows of the tile: both operands of that product are needed with the
 // reduction index m along the lanes' 8-element fragments, i.e. as COLUMNS of the row-major staged tiles, which is what
 // the LDS transpose read ds_read_b64_tr_b16 delivers (two reads per fragment).  Per-workgroup dW partials are summed by
 // the caller.  HBM traffic per row: pre, gh, x, addend in, gx out -- 5 streams instead of 8 for the three-kernel path.
 typedef __attribute__((ext_vector_type(4))) short rl_s4_t;
-constexpr int kDwThreads = 512, kDwWaves = 8, kDwRowsPerWave = 16, kDwTile = 128;
+constexpr int kDwThreads = 256, kDwWaves = 4, kDwRowsPerWave = 16, kDwTile = 64;
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains the outstanding GLOBAL loads (vmcnt(0)),
 // i.e. the next tile's prefetch, twice per tile
@@ -378,11 +378,13 @@ template <int D> struct DwGeom {
                                                            // 8 consecutive rows (one 32-lane half) cover all 64 banks once
   static constexpr size_t tile_bytes = (size_t)kDwTile * RlGeom<D>::PITCH * 2;
   static constexpr size_t xtile_bytes = (size_t)kDwTile * PBX;
-  static constexpr size_t lds_bytes = RlGeom<D>::w_bytes + 2 * tile_bytes + xtile_bytes;
+  static constexpr size_t const_bytes = 6 * (size_t)D * 4;                                   // per-channel BatchNorm constants
+  static constexpr size_t lds_bytes = RlGeom<D>::w_bytes + tile_bytes + xtile_bytes + const_bytes;   // 73.7 KB at d = 128: 2 per CU
+  static constexpr int NBW = (RlGeom<D>::NB + kDwWaves - 1) / kDwWaves;                      // dW row blocks per wave
 };
 
 template <typename T, int D, int ACT>
-__global__ __launch_bounds__(kDwThreads, 1) void bn_bwd_linear_dw_kernel(T* __restrict__ gx, const T* __restrict__ pre,
+__global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __restrict__ gx, const T* __restrict__ pre,
                                                                          const T* __restrict__ gh, const T* __restrict__ x,
                                                                          const T* __restrict__ wl, const T* __restrict__ addend,
                                                                          float* __restrict__ colsum_ws, float* __restrict__ dw_ws,
@@ -395,7 +397,10 @@ __global__ __launch_bounds__(kDwThreads, 1) void bn_bwd_linear_dw_kernel(T* __re
   char* lds_w = smem;
   char* stage_g = smem + G::w_bytes;
   char* stage_x = stage_g + DwGeom<D>::tile_bytes;
-  char* stage_o = stage_x + DwGeom<D>::xtile_bytes;
+  char* stage_o = stage_g;                               // a wave's output rows reuse ITS OWN gpre rows once every wave is past
+                                                         // the tile's dW phase (second barrier)
+  float* lds_c = reinterpret_cast<float*>(stage_x + DwGeom<D>::xtile_bytes);   // [6][D]: mu, is, ww, bb, k1, k2 (registers are
+                                                                               // needed for the two accumulator sets)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
   for (int item = threadIdx.x; item < D * G::CH; item += kDwThreads) {
@@ -406,26 +411,31 @@ __global__ __launch_bounds__(kDwThreads, 1) void bn_bwd_linear_dw_kernel(T* __re
   const int ech = lane % G::CH, erow0 = lane / G::CH;
   constexpr int EROWS = 64 / G::CH;
   constexpr int EIT = kDwRowsPerWave / EROWS;
-  float mu[8], is[8], ww[8], bb[8], k1[8], k2[8], cs[8];
   {
     const float inv_m = 1.f / (float)m_rows;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = ech * 8 + j;
-      mu[j] = bn.mean[c]; is[j] = bn.invstd[c]; ww[j] = bn.w ? bn.w[c] : 1.f; bb[j] = bn.b ? bn.b[c] : 0.f;
-      k1[j] = bn.training ? bn.sum_dz[c] * inv_m : 0.f;
-      k2[j] = bn.training ? bn.sum_dz_xhat[c] * inv_m : 0.f;
-      cs[j] = 0.f;
+    for (int c = threadIdx.x; c < D; c += kDwThreads) {
+      lds_c[0 * D + c] = bn.mean[c];
+      lds_c[1 * D + c] = bn.invstd[c];
+      lds_c[2 * D + c] = bn.w ? bn.w[c] : 1.f;
+      lds_c[3 * D + c] = bn.b ? bn.b[c] : 0.f;
+      lds_c[4 * D + c] = bn.training ? bn.sum_dz[c] * inv_m : 0.f;
+      lds_c[5 * D + c] = bn.training ? bn.sum_dz_xhat[c] * inv_m : 0.f;
     }
   }
-  rl_f32x4_t acc_w[G::NB];                               // dW slab of this wave: rows n0 + q*4 + r, columns kb*16 + r16
+  float cs[8];
 #pragma unroll
-  for (int kb = 0; kb < G::NB; ++kb) acc_w[kb] = rl_f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const bool dw_wave = wave < G::NB;
-  const int n0 = wave * 16;
+  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+  constexpr int NBW = DwGeom<D>::NBW;
+  rl_f32x4_t acc_w[NBW][G::NB];                          // dW slab of this wave: rows n0 + u*16 + q*4 + r, columns kb*16 + r16
+#pragma unroll
+  for (int u = 0; u < NBW; ++u)
+#pragma unroll
+    for (int kb = 0; kb < G::NB; ++kb) acc_w[u][kb] = rl_f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int n0 = wave * 16 * NBW;
+  const bool dw_wave = n0 < D;
 
-  uint4 cy[EIT], cg[EIT], cx[EIT], ca[EIT];
-  auto load_tile = [&](int64_t tile, uint4 (&y)[EIT], uint4 (&g)[EIT], uint4 (&xx)[EIT], uint4 (&aa)[EIT]) {
+  uint4 cy[EIT], cg[EIT];
+  auto load_tile = [&](int64_t tile, uint4 (&y)[EIT], uint4 (&g)[EIT]) {
     const int64_t base = tile * kDwTile + wave * kDwRowsPerWave;
 #pragma unroll
     for (int it = 0; it < EIT; ++it) {
@@ -434,19 +444,35 @@ __global__ __launch_bounds__(kDwThreads, 1) void bn_bwd_linear_dw_kernel(T* __re
       const int64_t off = row * D + ech * 8;
       y[it] = *reinterpret_cast<const uint4*>(pre + off);
       g[it] = *reinterpret_cast<const uint4*>(gh + off);
-      xx[it] = *reinterpret_cast<const uint4*>(x + off);
-      if (addend) aa[it] = *reinterpret_cast<const uint4*>(addend + off);
     }
   };
   int64_t tile = blockIdx.x;
-  if (tile < n_tiles) load_tile(tile, cy, cg, cx, ca);
+  if (tile < n_tiles) load_tile(tile, cy, cg);
   __syncthreads();                                       // W^T staged
   for (; tile < n_tiles; tile += gridDim.x) {
-    uint4 ny[EIT], ng[EIT], nx[EIT], na[EIT];
-    const int64_t tn = tile + gridDim.x;
-    if (tn < n_tiles) load_tile(tn, ny, ng, nx, na);
     const int64_t base = tile * kDwTile + wave * kDwRowsPerWave;
+    uint4 cx[EIT];                                       // x rows of THIS tile: only pass through (HBM -> registers -> LDS), so
+#pragma unroll                                           // they are not carried across the MFMA phases like the (pre, gh) prefetch
+    for (int it = 0; it < EIT; ++it) {
+      int64_t row = base + it * EROWS + erow0;
+      if (row >= m_rows) row = m_rows - 1;
+      cx[it] = *reinterpret_cast<const uint4*>(x + row * D + ech * 8);
+    }
+    uint4 ny[EIT], ng[EIT];
+    const int64_t tn = tile + gridDim.x;
+    if (tn < n_tiles) load_tile(tn, ny, ng);
     // ---- prologue: gpre of this wave's 16 rows and the matching x rows -> LDS (rows past the end as zeros) ---------------
+    float mu[8], is[8], ww[8], bb[8], k1[8], k2[8];        // re-read per tile: live only here
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c4 = ech * 8 + h * 4;
+      *reinterpret_cast<float4*>(mu + h * 4) = *reinterpret_cast<const float4*>(lds_c + 0 * D + c4);
+      *reinterpret_cast<float4*>(is + h * 4) = *reinterpret_cast<const float4*>(lds_c + 1 * D + c4);
+      *reinterpret_cast<float4*>(ww + h * 4) = *reinterpret_cast<const float4*>(lds_c + 2 * D + c4);
+      *reinterpret_cast<float4*>(bb + h * 4) = *reinterpret_cast<const float4*>(lds_c + 3 * D + c4);
+      *reinterpret_cast<float4*>(k1 + h * 4) = *reinterpret_cast<const float4*>(lds_c + 4 * D + c4);
+      *reinterpret_cast<float4*>(k2 + h * 4) = *reinterpret_cast<const float4*>(lds_c + 5 * D + c4);
+    }
 #pragma unroll
     for (int it = 0; it < EIT; ++it) {
       const int rl = wave * kDwRowsPerWave + it * EROWS + erow0;
@@ -463,13 +489,15 @@ __global__ __launch_bounds__(kDwThreads, 1) void bn_bwd_linear_dw_kernel(T* __re
       uint4 packed = V::pack(v);
       if (!valid) packed = make_uint4(0u, 0u, 0u, 0u);
       *reinterpret_cast<uint4*>(stage_g + (size_t)rl * PB + ech * 16) = packed;
-      *reinterpret_cast<uint4*>(stage_x + (size_t)rl * PBX + ech * 16) = cx[it];
       if (colsum_ws) {
         V::unpack(packed, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) cs[j] += v[j];
       }
     }
+#pragma unroll
+    for (int it = 0; it < EIT; ++it)
+      *reinterpret_cast<uint4*>(stage_x + (size_t)(wave * kDwRowsPerWave + it * EROWS + erow0) * PBX + ech * 16) = cx[it];
     rl_lds_barrier();
     // ---- gx rows of this wave: gpre . W ------------------------------------------------------------------------------------
     rl_f32x4_t acc[G::NB];
@@ -484,7 +512,7 @@ __global__ __launch_bounds__(kDwThreads, 1) void bn_bwd_linear_dw_kernel(T* __re
         acc[nb] = rl_mfma<T>(fa, fb, acc[nb]);
       }
     }
-    // ---- dW slab: sum over the tile's 128 rows, operands read as columns of the staged tiles -------------------------------
+    // ---- dW slab: sum over the tile's 64 rows, operands read as columns of the staged tiles --------------------------------
     if (dw_wave) {
       // the reduction index of an MFMA may be permuted freely as long as both operands use the same permutation: lane
       // group q takes rows {0-3, 8-11} + 4 (q & 1) + 16 (q >> 1) of each 32-row step, so that the two groups of a 32-lane
@@ -494,19 +522,23 @@ __global__ __launch_bounds__(kDwThreads, 1) void bn_bwd_linear_dw_kernel(T* __re
       for (int ms = 0; ms < kDwTile / 32; ++ms) {
         const int row = ms * 32 + rsel;
         const char* ga = stage_g + (size_t)row * PB + (r16 & 3) * 8 + n0 * 2;
-        const uint4 fa = [&] {
-          const rl_s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(ga));
-          const rl_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(ga + 8 * PB));
+        uint4 fa[NBW];
+#pragma unroll
+        for (int u = 0; u < NBW; ++u) {
+          const rl_s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(ga + u * 32));
+          const rl_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(ga + u * 32 + 8 * PB));
           const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
-          return make_uint4(a.x, a.y, b.x, b.y);
-        }();
+          fa[u] = make_uint4(a.x, a.y, b.x, b.y);
+        }
         const char* xa = stage_x + (size_t)row * PBX + (r16 & 3) * 8;
 #pragma unroll
         for (int kb = 0; kb < G::NB; ++kb) {
           const rl_s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(xa + kb * 32));
           const rl_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(xa + kb * 32 + 8 * PBX));
           const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
-          acc_w[kb] = rl_mfma<T>(fa, make_uint4(a.x, a.y, b.x, b.y), acc_w[kb]);
+          const uint4 fk = make_uint4(a.x, a.y, b.x, b.y);
+#pragma unroll
+          for (int u = 0; u < NBW; ++u) acc_w[u][kb] = rl_mfma<T>(fa[u], fk, acc_w[u][kb]);
         }
       }
     }
@@ -527,7 +559,7 @@ __global__ __launch_bounds__(kDwThreads, 1) void bn_bwd_linear_dw_kernel(T* __re
         if (addend) {
           float a[8], b[8];
           V::unpack(v, a);
-          V::unpack(ca[it], b);
+          V::unpack(*reinterpret_cast<const uint4*>(addend + row * D + ech * 8), b);
 #pragma unroll
           for (int j = 0; j < 8; ++j) a[j] += b[j];
           v = V::pack(a);
@@ -538,19 +570,21 @@ __global__ __launch_bounds__(kDwThreads, 1) void bn_bwd_linear_dw_kernel(T* __re
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < EIT; ++it) { cy[it] = ny[it]; cg[it] = ng[it]; cx[it] = nx[it]; ca[it] = na[it]; }
+    for (int it = 0; it < EIT; ++it) { cy[it] = ny[it]; cg[it] = ng[it]; }
   }
   // ---- per-workgroup results: dW partial (D x D f32) and the column sums of gpre ------------------------------------------
   if (dw_wave) {
 #pragma unroll
-    for (int kb = 0; kb < G::NB; ++kb)
+    for (int u = 0; u < NBW; ++u)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        dw_ws[((size_t)blockIdx.x * D + n0 + q * 4 + r) * D + kb * 16 + r16] = acc_w[kb][r];
+      for (int kb = 0; kb < G::NB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dw_ws[((size_t)blockIdx.x * D + n0 + u * 16 + q * 4 + r) * D + kb * 16 + r16] = acc_w[u][kb][r];
   }
   if (colsum_ws) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(stage_o);      // [512][8] floats = 16 KB
+    float* red = reinterpret_cast<float*>(stage_g);      // [256][8] floats = 8 KB
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = cs[j];
     __syncthreads();
@@ -645,7 +679,7 @@ extern "C" int pygho_bn_bwd_linear(void* gx, void* gpre, const void* pre, const 
 
 extern "C" int pygho_bn_bwd_linear_dw_blocks(int64_t m) {
   if (m <= 0) return 0;
-  return grid_for(m, kDwTile, 256);          // one resident 512-thread workgroup per CU (139 KB of LDS at d = 128)
+  return grid_for(m, kDwTile, 512);          // two resident 256-thread workgroups per CU (70.6 KB of LDS each at d = 128)
 }
 
 extern "C" int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, const void* gh, const void* x, const void* wl,
