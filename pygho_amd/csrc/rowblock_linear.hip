@@ -50,7 +50,7 @@ template <int D> struct RlGeom {
   static constexpr int CH = D / 8;             // 16-B chunks per row
   static constexpr size_t w_bytes = (size_t)D * PITCH * 2;
   static constexpr size_t stage_bytes = (size_t)kRlTile * PITCH * 2;
-  static constexpr size_t lds_bytes = w_bytes + stage_bytes + (size_t)D * 4;
+  static constexpr size_t lds_bytes = w_bytes + stage_bytes + 6 * (size_t)D * 4;   // + bias (forward) / BatchNorm constants (backward)
 };
 
 template <typename T, int D>
@@ -216,20 +216,25 @@ __global__ __launch_bounds__(kBlock, 2) void bn_bwd_linear_kernel(T* __restrict_
   const int ech = lane % G::CH, erow0 = lane / G::CH;
   constexpr int EROWS = 64 / G::CH;
   constexpr int EIT = kRlRowsPerWave / EROWS;
-  // per-channel constants of this lane's 8 columns:  xh = (x - mu) * is,  z = xh * ww + bb,
-  // gpre = ww * is * (dz - k1 - xh * k2)   with k1 = sum_dz / M, k2 = sum_dz_xhat / M (0 in eval mode)
-  float mu[8], is[8], ww[8], bb[8], k1[8], k2[8], cs[8];
+  // per-channel constants:  xh = (x - mu) * is,  z = xh * ww + bb,  gpre = ww * is * (dz - k1 - xh * k2)  with
+  // k1 = sum_dz / M, k2 = sum_dz_xhat / M (0 in eval mode).  Kept in LDS and re-read per tile: holding them in registers next
+  // to the accumulators and the prefetch spilled to scratch.
+  float* lds_c = reinterpret_cast<float*>(smem + G::w_bytes + G::stage_bytes);        // [6][D] (slot of the forward kernel's bias + 5 D)
   {
     const float inv_m = 1.f / (float)m_rows;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = ech * 8 + j;
-      mu[j] = bn.mean[c]; is[j] = bn.invstd[c]; ww[j] = bn.w ? bn.w[c] : 1.f; bb[j] = bn.b ? bn.b[c] : 0.f;
-      k1[j] = bn.training ? bn.sum_dz[c] * inv_m : 0.f;
-      k2[j] = bn.training ? bn.sum_dz_xhat[c] * inv_m : 0.f;
-      cs[j] = 0.f;
+    for (int c = threadIdx.x; c < D; c += kBlock) {
+      lds_c[0 * D + c] = bn.mean[c];
+      lds_c[1 * D + c] = bn.invstd[c];
+      lds_c[2 * D + c] = bn.w ? bn.w[c] : 1.f;
+      lds_c[3 * D + c] = bn.b ? bn.b[c] : 0.f;
+      lds_c[4 * D + c] = bn.training ? bn.sum_dz[c] * inv_m : 0.f;
+      lds_c[5 * D + c] = bn.training ? bn.sum_dz_xhat[c] * inv_m : 0.f;
     }
   }
+  __syncthreads();
+  float cs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
   uint4 cy[EIT], cg[EIT];                                // current tile's (pre, gh) chunks, row-contiguous
   auto load_tile = [&](int64_t tile, uint4 (&y)[EIT], uint4 (&g)[EIT]) {
     const int64_t base = tile * kRlTile + wave * kRlRowsPerWave;
@@ -249,6 +254,17 @@ __global__ __launch_bounds__(kBlock, 2) void bn_bwd_linear_kernel(T* __restrict_
     if (tn < n_tiles) load_tile(tn, ny, ng);
     const int64_t base = tile * kRlTile + wave * kRlRowsPerWave;
     // ---- prologue: BatchNorm / activation backward on this wave's 32 rows -> HBM (gpre) and LDS stage ---------------
+    float mu[8], is[8], ww[8], bb[8], k1[8], k2[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c4 = ech * 8 + h * 4;
+      *reinterpret_cast<float4*>(mu + h * 4) = *reinterpret_cast<const float4*>(lds_c + 0 * D + c4);
+      *reinterpret_cast<float4*>(is + h * 4) = *reinterpret_cast<const float4*>(lds_c + 1 * D + c4);
+      *reinterpret_cast<float4*>(ww + h * 4) = *reinterpret_cast<const float4*>(lds_c + 2 * D + c4);
+      *reinterpret_cast<float4*>(bb + h * 4) = *reinterpret_cast<const float4*>(lds_c + 3 * D + c4);
+      *reinterpret_cast<float4*>(k1 + h * 4) = *reinterpret_cast<const float4*>(lds_c + 4 * D + c4);
+      *reinterpret_cast<float4*>(k2 + h * 4) = *reinterpret_cast<const float4*>(lds_c + 5 * D + c4);
+    }
 #pragma unroll
     for (int it = 0; it < EIT; ++it) {
       const int rl = it * EROWS + erow0;

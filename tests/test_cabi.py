@@ -57,6 +57,23 @@ def test_argument_validation_without_gpu(lib):
     assert lib.pygho_row_gather(None, None, None, None, 5, 4, 0, None) == 1
     assert lib.pygho_hash_pack(None, None, 0, 5, 5, None, None) == 1          # sparse_dim out of range
     assert lib.pygho_masked_bmm(None, None, None, None, None, None, -1, 1, 1, 1, 8, 0, 1, 1, None) == 1
+    # entry points of the fused tuple-wise block: shape / dtype / null checks happen before any launch
+    assert lib.pygho_seg_gather_mul_reduce_add(None, None, None, None, None, None, None, None, 3, 4, 4, 4, 0, 0, 0, 0, None) == 1
+    assert lib.pygho_seg_triple_product(None, None, None, None, None, None, None, None, 0, 4, 0, 0, 0, 0, 0, None) == 0      # empty
+    assert lib.pygho_seg_triple_product(None, None, None, None, None, None, None, None, 3, 4, 1, 1, 1, 0, 0, None) == 1
+    assert lib.pygho_rowblock_linear_blocks(0) == 0 and lib.pygho_rowblock_linear_blocks(129) == 2
+    assert lib.pygho_rowblock_linear_blocks(10 ** 8) == 512 and lib.pygho_bn_bwd_linear_dw_blocks(10 ** 8) == 512
+    assert lib.pygho_rowblock_linear(None, None, None, None, None, None, None, 0, 128, 1, None) == 0                          # empty
+    assert lib.pygho_rowblock_linear(None, None, None, None, None, None, None, 5, 128, 1, None) == 1 and b"null" in lib.pygho_last_error()
+    one = ctypes.c_void_p(16)       # never dereferenced: the checks below fail first
+    assert lib.pygho_rowblock_linear(one, one, one, None, None, None, None, 5, 128, 0, None) == 2 and b"bf16" in lib.pygho_last_error()
+    assert lib.pygho_rowblock_linear(one, one, one, None, None, None, None, 5, 96, 1, None) == 2 and b"width" in lib.pygho_last_error()
+    assert lib.pygho_bn_bwd_linear(one, one, one, one, one, None, None, one, one, None, None, None, None, 5, 128, 2, 1, 1, None) == 1
+    assert lib.pygho_bn_bwd_linear_dw(one, one, one, one, one, one, None, None, one, one, None, None, one, one, 5, 128, 7, 1, 1, None) == 1
+    assert lib.pygho_bn_prepare(None, None, None, None, None, None, 5, 8, None, None, 1e-5, None, None, 0.1, None, 0, None) == 1
+    assert lib.pygho_exclusive_scan_i64(None, None, -1, None, 0, None) == 1
+    assert lib.pygho_product_hash(None, None, 1, 0, 0, None, 1, 0, 0, None, None, 0, None, None) == 1                          # no remaining coordinate
+    assert lib.pygho_gather_cols_i64(None, None, 0, 0, None, 0, 5, None) == 0
 
 
 def test_product_path_refuses_cpu_tensors():

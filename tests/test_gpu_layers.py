@@ -340,3 +340,43 @@ def test_bn_bwd_linear_equals_two_kernel_path(dev, dtype, act):
         dw_ref = gpre0.double().t() @ x.double()
         scale = float(dw_ref.abs().max())
         torch.testing.assert_close(dw.double() / scale, dw_ref / scale, rtol=0, atol=2e-6)
+
+
+def test_fused_residual_i2conv_3tuples(dev):
+    """the same fused block on 3-tuples (I2Conv, BASELINE config 5 shape, d = 64 -> the d = 64 instantiation of the MFMA
+    kernels): forward_residual against the unfused composition, values and input / parameter gradients, bf16."""
+    import copy
+    from pygho_amd import SparseTensor, synth
+    from pygho_amd.honn import Conv
+    h, dtype = 64, torch.bfloat16
+    hb = synth.make_batch(48, "i2", seed=9)
+    n = hb.num_nodes
+    assert hb.tupleid.shape[0] == 3 and hb.num_tuples >= 8192
+    torch.manual_seed(4)
+    A = SparseTensor(T(hb.edge_index, dev), (torch.randn(hb.num_edges, h, device=dev) * 0.3).to(dtype), [n, n, h], True)
+    xv = torch.randn(hb.num_tuples, h, device=dev).to(dtype)
+    tid = T(hb.tupleid, dev)
+    dd = {k + "___acd": T(v, dev) for k, v in hb.acd.items()}
+    w = torch.randn(xv.shape, device=dev)
+    la = Conv.I2Conv(h, h, "sum", "SS", dict(MLP)).to(dev).train()
+    lb = copy.deepcopy(la)
+    res = {}
+    for name, layer in (("fused", la), ("plain", lb)):
+        x = xv.clone().requires_grad_(True)
+        X = SparseTensor(tid, x, [n, n, n, h], True)
+        if name == "fused":
+            out = layer.forward_residual(A, X, dd)
+        else:
+            H = layer.lin.lins[2](layer.lin.lins[1](torch.nn.functional.linear(x, layer.lin.lins[0].weight.to(dtype),
+                                                                               layer.lin.lins[0].bias.to(dtype))))
+            out = X.add(layer.aggr.forward(A, SparseTensor(tid, H, [n, n, n, h], True), dd, X), True)
+        (out.values.float() * w).sum().backward()
+        res[name] = (out.values.float(), x.grad.float(), {k: p.grad.float() for k, p in layer.named_parameters()})
+    fa, fb = res["fused"], res["plain"]
+    torch.testing.assert_close(fa[0], fb[0], rtol=3e-2, atol=6e-2)
+    torch.testing.assert_close(fa[1], fb[1], rtol=3e-2, atol=6e-2)
+    for k in fa[2]:
+        if k.endswith("lins.0.bias"):
+            continue                                   # zero up to rounding noise in front of a BatchNorm
+        s = float(fb[2][k].abs().max()) + 1e-6
+        torch.testing.assert_close(fa[2][k] / s, fb[2][k] / s, rtol=0, atol=3e-2, msg=k)
