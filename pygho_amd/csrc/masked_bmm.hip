@@ -80,34 +80,67 @@ __device__ __forceinline__ void item_coords(int it, bool k_fast, int& r, int& g4
   if (k_fast) { r = it / KGROUPS; g4 = it % KGROUPS; } else { g4 = it / kTile; r = it % kTile; }
 }
 
+// All mask bytes of the item are loaded first (clamped, unconditional), then every 16-B load is issued back to back
+// through a buffer descriptor whose bounds check does the predication: a masked / out-of-tile position gets an
+// out-of-range offset, reads as zero and costs no memory traffic.  (With `if (mask) load` the compiler emitted one
+// mask-load -> wait -> branch -> data-load round trip per position: 16-24 serialised memory latencies per work item.)
+typedef __attribute__((ext_vector_type(4))) unsigned int bmm_u4_t;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bmm_rsrc(const char* base, uint32_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0,
+                                           (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 template <typename T>
-__device__ __forceinline__ void stage_load(StageRegs<T>& regs, int it, const char* __restrict__ gbase,
-                                           const uint8_t* __restrict__ mbase, bool k_fast, uint32_t s_row_b,
-                                           uint32_t s_k_b, uint32_t s_row_p, uint32_t s_k_p, int row0, int rows, int k0,
-                                           int nk) {
+__device__ __forceinline__ void stage_load_at(StageRegs<T>& regs, int r, int g4, __amdgpu_buffer_rsrc_t rsrc,
+                                              const uint8_t* __restrict__ mbase, uint32_t s_row_b, uint32_t s_k_b,
+                                              uint32_t s_row_p, uint32_t s_k_p, int row0, int rows, int k0, int nk) {
   constexpr int KG = BmmTraits<T>::KG;
-  int r, g4;
-  item_coords<T>(it, k_fast, r, g4);
+  uint32_t off[KG];
+  bool ok[KG];
+  uint8_t m[KG];
 #pragma unroll
   for (int kk = 0; kk < KG; ++kk) {
     const int k = k0 + g4 * KG + kk;
-    regs.v[kk] = make_uint4(0, 0, 0, 0);
-    if (r < rows && k < nk) {
-      const uint32_t row = (uint32_t)(row0 + r);
-      bool ok = true;
-      if (mbase) ok = mbase[row * s_row_p + (uint32_t)k * s_k_p] != 0;
-      if (ok) regs.v[kk] = *reinterpret_cast<const uint4*>(gbase + (row * s_row_b + (uint32_t)k * s_k_b));
-    }
+    ok[kk] = r < rows && k < nk;
+    const uint32_t row = ok[kk] ? (uint32_t)(row0 + r) : 0u, kc = ok[kk] ? (uint32_t)k : 0u;
+    off[kk] = row * s_row_b + kc * s_k_b;
+    m[kk] = mbase ? mbase[row * s_row_p + kc * s_k_p] : (uint8_t)1;
+  }
+#pragma unroll
+  for (int kk = 0; kk < KG; ++kk) {
+    const bmm_u4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (ok[kk] && m[kk] != 0) ? (int)off[kk] : (int)0x80000000, 0, 0);
+    regs.v[kk] = make_uint4(v[0], v[1], v[2], v[3]);
   }
 }
 
 template <typename T>
-__device__ __forceinline__ void stage_write(char* lds, const StageRegs<T>& regs, int it, bool k_fast, int rows, int kround,
-                                            int kp) {
-  using TR = BmmTraits<T>;
-  constexpr int CH = TR::CH, KG = TR::KG;
+__device__ __forceinline__ void stage_load(StageRegs<T>& regs, int it, __amdgpu_buffer_rsrc_t gbase,
+                                           const uint8_t* __restrict__ mbase, bool k_fast, uint32_t s_row_b,
+                                           uint32_t s_k_b, uint32_t s_row_p, uint32_t s_k_p, int row0, int rows, int k0,
+                                           int nk) {
   int r, g4;
   item_coords<T>(it, k_fast, r, g4);
+  stage_load_at<T>(regs, r, g4, gbase, mbase, s_row_b, s_k_b, s_row_p, s_k_p, row0, rows, k0, nk);
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_write_at(char* lds, const StageRegs<T>& regs, int r, int g4, int rows, int kround, int kp);
+
+template <typename T>
+__device__ __forceinline__ void stage_write(char* lds, const StageRegs<T>& regs, int it, bool k_fast, int rows, int kround,
+                                            int kp) {
+  int r, g4;
+  item_coords<T>(it, k_fast, r, g4);
+  stage_write_at<T>(lds, regs, r, g4, rows, kround, kp);
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_write_at(char* lds, const StageRegs<T>& regs, int r, int g4, int rows, int kround, int kp) {
+  using TR = BmmTraits<T>;
+  constexpr int CH = TR::CH, KG = TR::KG;
   const int koff = g4 * KG;
   if (r >= rows || koff >= kround) return;
   const uint4* v = regs.v;
@@ -174,21 +207,32 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
     {
       const int kround = (kvalid + (TR::KSTEP >= 8 ? 7 : 3)) & ~(TR::KSTEP >= 8 ? 7 : 3);
       const uint32_t es = sizeof(T), db = (uint32_t)p.d * es;
-      const char* abase = reinterpret_cast<const char*>(p.A) + ((a_base * p.d + c0) * (int64_t)es);
-      const char* bbase = reinterpret_cast<const char*>(p.B) + ((b_base * p.d + c0) * (int64_t)es);
+      const __amdgpu_buffer_rsrc_t abase = bmm_rsrc(reinterpret_cast<const char*>(p.A) + ((a_base * p.d + c0) * (int64_t)es),
+                                                    (uint32_t)p.ni * (uint32_t)p.nk * db);
+      const __amdgpu_buffer_rsrc_t bbase = bmm_rsrc(reinterpret_cast<const char*>(p.B) + ((b_base * p.d + c0) * (int64_t)es),
+                                                    (uint32_t)p.nk * (uint32_t)p.nj * db);
       const uint8_t* amb = p.amask ? p.amask + a_base : nullptr;
       const uint8_t* bmb = p.bmask ? p.bmask + b_base : nullptr;
       const bool a_kfast = p.a_sk < p.a_si, b_kfast = p.b_sk < p.b_sj;
-#pragma unroll
-      for (int t = 0; t < StageRegs<T>::ITEMS; ++t) {
-        const int item = threadIdx.x + t * kBlock;
+      // tight staging map: item -> (row, k-group) over rows x (kround / KG) positions only (37 x 10 of the 48 x 16 slots at
+      // n = 37), the faster coordinate being the one contiguous in memory; the divisions are exact float reciprocals
+      // (items < 2^10).  Padded k-groups (k >= nk) are written as zeros by the bounds-checked loads.
+      const int kgroups = kround / TR::KG;
+      const int n_items = max(rows_i, rows_j) * kgroups;
+      const float inv_kg = 1.0f / (float)kgroups, inv_ri = 1.0f / (float)rows_i, inv_rj = 1.0f / (float)rows_j;
+      for (int item = threadIdx.x; item < n_items; item += kBlock) {
+        int ar, ag, br, bg;
+        if (a_kfast) { ar = (int)(((float)item + 0.5f) * inv_kg); ag = item - ar * kgroups; }
+        else { ag = (int)(((float)item + 0.5f) * inv_ri); ar = item - ag * rows_i; if (ag >= kgroups) ar = rows_i; }
+        if (b_kfast) { br = (int)(((float)item + 0.5f) * inv_kg); bg = item - br * kgroups; }
+        else { bg = (int)(((float)item + 0.5f) * inv_rj); br = item - bg * rows_j; if (bg >= kgroups) br = rows_j; }
         StageRegs<T> ra, rb;
-        stage_load<T>(ra, item, abase, amb, a_kfast, (uint32_t)p.a_si * db, (uint32_t)p.a_sk * db, (uint32_t)p.a_si,
-                      (uint32_t)p.a_sk, i0, rows_i, k0, (int)p.nk);
-        stage_load<T>(rb, item, bbase, bmb, b_kfast, (uint32_t)p.b_sj * db, (uint32_t)p.b_sk * db, (uint32_t)p.b_sj,
-                      (uint32_t)p.b_sk, j0, rows_j, k0, (int)p.nk);
-        stage_write<T>(ldsA, ra, item, a_kfast, rows_i, kround, kp);
-        stage_write<T>(ldsB, rb, item, b_kfast, rows_j, kround, kp);
+        stage_load_at<T>(ra, ar, ag, abase, amb, (uint32_t)p.a_si * db, (uint32_t)p.a_sk * db, (uint32_t)p.a_si, (uint32_t)p.a_sk,
+                         i0, rows_i, k0, (int)p.nk);
+        stage_load_at<T>(rb, br, bg, bbase, bmb, (uint32_t)p.b_sj * db, (uint32_t)p.b_sk * db, (uint32_t)p.b_sj, (uint32_t)p.b_sk,
+                         j0, rows_j, k0, (int)p.nk);
+        stage_write_at<T>(ldsA, ra, ar, ag, rows_i, kround, kp);
+        stage_write_at<T>(ldsB, rb, br, bg, rows_j, kround, kp);
       }
     }
     __syncthreads();
@@ -261,10 +305,15 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = t * 16 + rowq + r;
-          if (i < rows_i && j < rows_j) {
-            char* dst = smem + ((size_t)(i * rows_j + j)) * 16 + wave * 4;
-            if constexpr (std::is_same<T, bf16>::value)
-              *reinterpret_cast<uint32_t*>(dst) = (uint32_t)f32_to_bf16(acc[0][t][u][r]) | ((uint32_t)f32_to_bf16(acc[CW - 1][t][u][r]) << 16);
+          {   // unconditional: the LDS image is the padded 48 x 48 position grid (one base address + immediates, no
+              // per-element bounds branches); the ragged edge is dropped by the store loop below
+            char* dst = smem + ((uint32_t)(i * kTile + j)) * 16u + wave * 4;
+            if constexpr (std::is_same<T, bf16>::value) {
+              typedef __attribute__((ext_vector_type(2))) float f2_t;      // v_cvt_pk_bf16_f32: one instruction per channel pair
+              typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+              const f2_t pr = {acc[0][t][u][r], acc[CW - 1][t][u][r]};
+              *reinterpret_cast<uint32_t*>(dst) = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf2_t));
+            }
             else if constexpr (std::is_same<T, f16>::value) {
               union { uint32_t u32; _Float16 h[2]; } cv;
               cv.h[0] = (_Float16)acc[0][t][u][r]; cv.h[1] = (_Float16)acc[CW - 1][t][u][r];
@@ -277,10 +326,11 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
   }
   __syncthreads();
   const int npos = rows_i * rows_j;
+  const float inv_rows_j = 1.0f / (float)rows_j;
   for (int ps = threadIdx.x; ps < npos; ps += kBlock) {
-    const int i = ps / rows_j, j = ps - i * rows_j;
+    const int i = (int)(((float)ps + 0.5f) * inv_rows_j), j = ps - i * rows_j;     // exact: ps < 2^12
     const int64_t opos = (b * p.ni + i0 + i) * p.nj + j0 + j;
-    uint4 v = *reinterpret_cast<const uint4*>(smem + (size_t)ps * 16);
+    uint4 v = *reinterpret_cast<const uint4*>(smem + (uint32_t)(i * kTile + j) * 16u);
     if (p.omask && !p.omask[opos]) v = make_uint4(0, 0, 0, 0);
     *reinterpret_cast<uint4*>((T*)p.out + opos * p.d + c0) = v;
   }
@@ -294,7 +344,7 @@ int launch_bmm(const BmmArgs& p, int64_t nb, hipStream_t st) {
   const int kp = bmm_pitch(kmax, sizeof(T));
   const int ri = (int)(p.ni < kTile ? p.ni : kTile), rj = (int)(p.nj < kTile ? p.nj : kTile);
   size_t lds = (size_t)TR::CH * (ri + rj) * kp * sizeof(T);
-  const size_t lds_out = (size_t)ri * rj * 16;
+  const size_t lds_out = (size_t)kTile * kTile * 16;      // padded position grid of the epilogue
   if (lds_out > lds) lds = lds_out;
   lds = (lds + 15) & ~(size_t)15;
   if (lds > 160 * 1024) { set_error("masked_bmm: LDS budget exceeded"); return PYGHO_ERR_UNSUPPORTED; }
