@@ -8,14 +8,16 @@
 //
 //   * workgroup = (batch b, chunk of CH channels = 16 B per (i,k) position, i-tile <= 48, j-tile <= 48),
 //     4 waves, each wave owning CH/4 channels;
-//   * staging: 16-B global loads (the channels of one position) of KG consecutive k, byte-permuted in
-//     registers into per-channel k-contiguous 8-B words and written to per-channel LDS planes
-//     A_c[i][k], Bt_c[j][k] (k contiguous, row pitch chosen so that MFMA fragment reads are
-//     bank-conflict free); operand masks and the ragged tile edges are zero-filled here;
+//   * staging: the mask bytes of a thread's positions are loaded first, then the 16-B pieces (the channels of one
+//     position) of KG consecutive k through a buffer descriptor whose bounds check predicates masked / ragged
+//     positions (zero, no traffic, no branches); byte-permuted in registers into per-channel k-contiguous 8-B
+//     words and written to per-channel LDS planes A_c[i][k], Bt_c[j][k] (k contiguous, row pitch chosen so
+//     that MFMA fragment reads are bank-conflict free; lanes walk k first so the writes are contiguous too);
 //   * compute: v_mfma_f32_16x16x32_bf16 / _f16 (8 k per lane, ds_read_b128) or v_mfma_f32_16x16x4_f32
 //     (exact f32), up to 3x3 output tiles per channel accumulated in f32 registers over k blocks of 64;
-//   * epilogue: accumulators go back through LDS as [position][channel] so that the masked output is
-//     written with 16-B coalesced stores.
+//   * epilogue: accumulators go back through LDS (one padded plane per wave = per 4-B channel group, pitch 50
+//     dwords: 2-way = minimal conflicts) and are gathered into 16-B pieces so that the masked output is written
+//     with coalesced stores.
 //
 // Roofline: HBM-bound (arithmetic intensity ~ n/3 flop/B); algorithmic bytes
 //   s*d*nb*(ni*nk + nk*nj + ni*nj) + mask bytes.
@@ -31,6 +33,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int kTile = 48;     // max rows of an i- / j-tile (3 MFMA tiles of 16)
 constexpr int kKBlock = 64;   // k elements staged per pass
+constexpr int kOutPitch = 50; // dwords per row of an epilogue plane: a wavefront's 4 row groups land 8 banks apart (2-way =
+                              // the minimum for 64 x 4 B) instead of on the same 16 banks
 
 struct BmmArgs {
   void* out;
@@ -213,19 +217,18 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
                                                     (uint32_t)p.nk * (uint32_t)p.nj * db);
       const uint8_t* amb = p.amask ? p.amask + a_base : nullptr;
       const uint8_t* bmb = p.bmask ? p.bmask + b_base : nullptr;
-      const bool a_kfast = p.a_sk < p.a_si, b_kfast = p.b_sk < p.b_sj;
       // tight staging map: item -> (row, k-group) over rows x (kround / KG) positions only (37 x 10 of the 48 x 16 slots at
       // n = 37), the faster coordinate being the one contiguous in memory; the divisions are exact float reciprocals
       // (items < 2^10).  Padded k-groups (k >= nk) are written as zeros by the bounds-checked loads.
       const int kgroups = kround / TR::KG;
       const int n_items = max(rows_i, rows_j) * kgroups;
-      const float inv_kg = 1.0f / (float)kgroups, inv_ri = 1.0f / (float)rows_i, inv_rj = 1.0f / (float)rows_j;
+      const float inv_kg = 1.0f / (float)kgroups;
       for (int item = threadIdx.x; item < n_items; item += kBlock) {
-        int ar, ag, br, bg;
-        if (a_kfast) { ar = (int)(((float)item + 0.5f) * inv_kg); ag = item - ar * kgroups; }
-        else { ag = (int)(((float)item + 0.5f) * inv_ri); ar = item - ag * rows_i; if (ag >= kgroups) ar = rows_i; }
-        if (b_kfast) { br = (int)(((float)item + 0.5f) * inv_kg); bg = item - br * kgroups; }
-        else { bg = (int)(((float)item + 0.5f) * inv_rj); br = item - bg * rows_j; if (bg >= kgroups) br = rows_j; }
+        // consecutive lanes take consecutive k-groups of one row for BOTH operands, whatever their storage order: the LDS
+        // writes of a wavefront are then contiguous 8-B words (row-fastest lanes hit the planes at an 80-B stride: 8-way bank
+        // conflicts), and the global side does not care -- a position only contributes 16 B of its line to this workgroup
+        const int ar = (int)(((float)item + 0.5f) * inv_kg), ag = item - ar * kgroups;
+        const int br = ar, bg = ag;
         StageRegs<T> ra, rb;
         stage_load_at<T>(ra, ar, ag, abase, amb, (uint32_t)p.a_si * db, (uint32_t)p.a_sk * db, (uint32_t)p.a_si, (uint32_t)p.a_sk,
                          i0, rows_i, k0, (int)p.nk);
@@ -305,9 +308,10 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = t * 16 + rowq + r;
-          {   // unconditional: the LDS image is the padded 48 x 48 position grid (one base address + immediates, no
-              // per-element bounds branches); the ragged edge is dropped by the store loop below
-            char* dst = smem + ((uint32_t)(i * kTile + j)) * 16u + wave * 4;
+          {   // unconditional: the LDS image is one padded 48-row plane per wave (= per 4-byte channel group; one base address
+              // + immediates, no per-element bounds branches, no 8-way conflicts of a [position][wave] layout); the ragged
+              // edge is dropped by the store loop below, which gathers the four planes back into 16-B pieces
+            char* dst = smem + ((uint32_t)(wave * kTile * kOutPitch + i * kOutPitch + j)) * 4u;
             if constexpr (std::is_same<T, bf16>::value) {
               typedef __attribute__((ext_vector_type(2))) float f2_t;      // v_cvt_pk_bf16_f32: one instruction per channel pair
               typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
@@ -330,7 +334,8 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
   for (int ps = threadIdx.x; ps < npos; ps += kBlock) {
     const int i = (int)(((float)ps + 0.5f) * inv_rows_j), j = ps - i * rows_j;     // exact: ps < 2^12
     const int64_t opos = (b * p.ni + i0 + i) * p.nj + j0 + j;
-    uint4 v = *reinterpret_cast<const uint4*>(smem + (uint32_t)(i * kTile + j) * 16u);
+    const uint32_t* lp = reinterpret_cast<const uint32_t*>(smem) + (uint32_t)(i * kOutPitch + j);
+    uint4 v = make_uint4(lp[0], lp[kTile * kOutPitch], lp[2 * kTile * kOutPitch], lp[3 * kTile * kOutPitch]);
     if (p.omask && !p.omask[opos]) v = make_uint4(0, 0, 0, 0);
     *reinterpret_cast<uint4*>((T*)p.out + opos * p.d + c0) = v;
   }
@@ -344,7 +349,7 @@ int launch_bmm(const BmmArgs& p, int64_t nb, hipStream_t st) {
   const int kp = bmm_pitch(kmax, sizeof(T));
   const int ri = (int)(p.ni < kTile ? p.ni : kTile), rj = (int)(p.nj < kTile ? p.nj : kTile);
   size_t lds = (size_t)TR::CH * (ri + rj) * kp * sizeof(T);
-  const size_t lds_out = (size_t)kTile * kTile * 16;      // padded position grid of the epilogue
+  const size_t lds_out = (size_t)4 * kTile * kOutPitch * 4;      // padded per-wave position planes of the epilogue
   if (lds_out > lds) lds = lds_out;
   lds = (lds + 15) & ~(size_t)15;
   if (lds > 160 * 1024) { set_error("masked_bmm: LDS budget exceeded"); return PYGHO_ERR_UNSUPPORTED; }
