@@ -380,3 +380,38 @@ def test_fused_residual_i2conv_3tuples(dev):
             continue                                   # zero up to rounding noise in front of a BatchNorm
         s = float(fb[2][k].abs().max()) + 1e-6
         torch.testing.assert_close(fa[2][k] / s, fb[2][k] / s, rtol=0, atol=3e-2, msg=k)
+
+
+def test_model_fused_paths_match_plain_composition(dev):
+    """the whole NGNN model (example/minimal.py) with every fused path on (table-indexed tuple initialisation, fused tuple
+    block with MFMA GEMMs, one-pass backward with the weight gradient) against the same model with the paths switched off
+    one level down: loss and all parameter gradients, bf16 activations."""
+    from pygho_amd import _ops, synth
+    from pygho_amd.ngnn import SpModel
+    hb = synth.make_batch(512, "zinc", seed=21)
+    dd = synth.to_datadict(hb, dev)
+    y = dd["y"].unsqueeze(-1)
+    flags = ("USE_TABLE_PRODUCT", "USE_FUSED_DW", "USE_BN_BWD_LINEAR", "USE_ROWBLOCK_LINEAR")
+    saved = {f: getattr(_ops, f) for f in flags}
+    res = {}
+    try:
+        for mode in (True, False):
+            for f in flags:
+                setattr(_ops, f, mode)
+            torch.manual_seed(0)
+            model = SpModel(1, 3, 128, act_dtype=torch.bfloat16).to(dev)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                pred = model(dd)
+            loss = torch.nn.functional.l1_loss(y, pred.float())
+            loss.backward()
+            res[mode] = (float(loss.detach()), {k: p.grad.float().clone() for k, p in model.named_parameters() if p.grad is not None})
+    finally:
+        for f, v in saved.items():
+            setattr(_ops, f, v)
+    assert abs(res[True][0] - res[False][0]) <= 2e-2 * abs(res[False][0]) + 1e-3
+    assert res[True][1].keys() == res[False][1].keys()
+    for k, ref in res[False][1].items():
+        if k.endswith(".lins.0.bias"):
+            continue                                       # bias in front of a BatchNorm: zero up to rounding noise
+        s = float(ref.abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][1][k] / s, ref / s, rtol=0, atol=8e-2, msg=k)
