@@ -240,6 +240,16 @@ int pygho_flag_scan_nonneg(int64_t* offsets, const int64_t* vals, const int64_t*
                            size_t workspace_bytes, void* stream);
 int pygho_compact_positions(int64_t* pos, const int64_t* offsets, int64_t n, void* stream);
 
+/* Block-diagonal batch collation on the device (hodata/SpData.py:56-112: concatenate the selected graphs and add the
+ * running node / tuple / edge offsets), from int32 per-graph-local storage to the int64 arrays of the API:
+ *   out[r, out_ptr[s] + t] = (int64) src[r, src_start[s] + t] + inc[r, s]        t < out_ptr[s+1] - out_ptr[s]
+ * for rows r < rows and selected graphs s < n_sel.  src is (rows, src_ld) int32, out (rows, out_ld) int64, src_start (n_sel)
+ * the first column of each selected graph in src, out_ptr (n_sel + 1) the exclusive scan of the selected lengths,
+ * inc (rows, n_sel) int64 or NULL. */
+int pygho_collate_rows(int64_t* out, const int32_t* src, int64_t rows, int64_t src_ld, int64_t out_ld,
+                       const int64_t* src_start, const int64_t* out_ptr, const int64_t* inc, int64_t n_sel,
+                       int64_t total, void* stream);
+
 /* ------------------------------------------------------------------------
  * Masked (dense) path
  * ---------------------------------------------------------------------- */

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "pygho_gather_cols_i64": (I, [P, P, L, L, P, I, L, P]),
     "pygho_gather_i32_to_i64": (I, [P, P, P, L, P]),
     "pygho_plan_triples": (I, [P, P, P, P, P, L, P]),
+    "pygho_collate_rows": (I, [P, P, L, L, L, P, P, P, L, L, P]),
     "pygho_flag_scan_nonneg": (I, [P, P, P, L, P, Z, P]),
     "pygho_compact_positions": (I, [P, P, L, P]),
     "pygho_masked_bmm": (I, [P, P, P, P, P, P, L, L, L, L, L, I, I, I, P]),

@@ -1,0 +1,96 @@
+"""
+Device-resident graph store and on-device mini-batch collation.
+
+The reference collates on the host with PyG's ``Batch.from_data_list`` (``hodata/SpData.py:56-112``: concatenate the graphs
+block-diagonally, ``__inc__`` adds the running node offset to ``edge_index`` / ``tupleid`` and the running tuple / edge
+offsets to the rows of every ``*___acd`` plan) and ships int64 triples to the device for every batch.  Here the whole
+dataset lives on the device once, graph-local and in **int32**; a mini-batch is a handful of integer kernels
+(``pygho_collate_rows``: gather the selected graphs' columns, widen to the API's int64 and add the offsets) -- no H2D
+traffic per batch (an 8192-graph batch is ~150 MB of int64 indices).  The output is the ``datadict`` of ``synth.to_datadict``.
+"""
+from typing import Dict, List, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _ops
+from ._native import check, lib, ptr, require_device, stream_ptr
+from .backend.SpTensor import SparseTensor
+from .synth import KEYSEP, GraphRecord, parse_key
+
+
+def _cat32(arrs: List[np.ndarray], axis: int, device) -> torch.Tensor:
+    a = np.concatenate(arrs, axis=axis)
+    assert a.size == 0 or (a.min() >= 0 and a.max() < 2 ** 31)
+    return torch.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(device)
+
+
+def _ptr64(lengths: Sequence[int], device) -> torch.Tensor:
+    return torch.from_numpy(np.concatenate(([0], np.cumsum(np.asarray(lengths, dtype=np.int64))))).to(device)
+
+
+class DeviceGraphStore:
+    """all graphs of a dataset on the device: graph-local int32 indices + int64 segment pointers per graph."""
+
+    def __init__(self, records: List[GraphRecord], device):
+        self.device = torch.device(device)
+        self.num_graphs = len(records)
+        self.keys = list(records[0].acd.keys())
+        self.sd = records[0].tupleid.shape[0]
+        d = self.device
+        self.node_ptr = _ptr64([r.num_nodes for r in records], d)
+        self.edge_ptr = _ptr64([r.edge_index.shape[1] for r in records], d)
+        self.tup_ptr = _ptr64([r.tupleid.shape[1] for r in records], d)
+        self.x = _cat32([r.x.reshape(1, -1) for r in records], 1, d)
+        self.edge_index = _cat32([r.edge_index for r in records], 1, d)
+        self.edge_attr = _cat32([r.edge_attr.reshape(1, -1) for r in records], 1, d)
+        self.tupleid = _cat32([r.tupleid for r in records], 1, d)
+        tf = [r.tuplefeat.reshape(r.tuplefeat.shape[0], -1).T for r in records]          # (f, t)
+        self.tuplefeat = _cat32(tf, 1, d)
+        self.feat_shape = tuple(records[0].tuplefeat.shape[1:])
+        self.acd = {k: _cat32([r.acd[k] for r in records], 1, d) for k in self.keys}
+        self.acd_ptr = {k: _ptr64([r.acd[k].shape[1] for r in records], d) for k in self.keys}
+        self.y = torch.tensor([r.y for r in records], dtype=torch.float32, device=d)
+
+    # ------------------------------------------------------------------
+    def _rows(self, src: torch.Tensor, seg_ptr: torch.Tensor, ids: torch.Tensor, out_ptr: torch.Tensor, total: int,
+              inc: Union[torch.Tensor, None]) -> torch.Tensor:
+        rows = src.shape[0]
+        out = torch.empty((rows, total), dtype=torch.int64, device=self.device)
+        start = _ops.gather_cols(seg_ptr, ids)
+        check(lib().pygho_collate_rows(ptr(out), ptr(src), rows, src.shape[1], total, ptr(start), ptr(out_ptr),
+                                       ptr(None if inc is None else inc.contiguous()), ids.numel(), total,
+                                       stream_ptr(self.device)), "collate_rows")
+        return out
+
+    def collate(self, graph_ids: Union[Sequence[int], torch.Tensor]) -> Dict:
+        """datadict of the block-diagonal batch of ``graph_ids`` (any order, repeats allowed)."""
+        ids = torch.as_tensor(graph_ids, dtype=torch.int64).to(self.device).contiguous()
+        require_device(ids)
+        g = ids.numel()
+        lens = {"node": self.node_ptr, "edge": self.edge_ptr, "tup": self.tup_ptr, **{("acd", k): v for k, v in self.acd_ptr.items()}}
+        ptrs = {}
+        for name, sp in lens.items():
+            ptrs[name] = _ops.exclusive_scan(_ops.gather_cols(sp, ids + 1) - _ops.gather_cols(sp, ids))
+        totals = torch.stack([p[-1] for p in ptrs.values()]).tolist()                   # ONE host sync sizes every output
+        total = dict(zip(ptrs.keys(), (int(t) for t in totals)))
+        off = {name: ptrs[name][:-1] for name in ("node", "edge", "tup")}                # running offsets per selected graph
+        n = total["node"]
+        ei = self._rows(self.edge_index, self.edge_ptr, ids, ptrs["edge"], total["edge"], off["node"].repeat(2, 1))
+        ea = self._rows(self.edge_attr, self.edge_ptr, ids, ptrs["edge"], total["edge"], None).reshape(-1)
+        tid = self._rows(self.tupleid, self.tup_ptr, ids, ptrs["tup"], total["tup"], off["node"].repeat(self.sd, 1))
+        tf = self._rows(self.tuplefeat, self.tup_ptr, ids, ptrs["tup"], total["tup"], None)
+        tf = tf.reshape(-1) if not self.feat_shape else tf.t().contiguous().reshape((total["tup"],) + self.feat_shape)
+        x = self._rows(self.x, self.node_ptr, ids, ptrs["node"], n, None).reshape(-1)
+        counts = ptrs["node"][1:] - ptrs["node"][:-1]
+        batch, _ = _ops.expand_pairs(torch.zeros_like(counts), counts)
+        dd = {
+            "x": x, "batch": batch, "num_graphs": g, "y": self.y[ids], "num_nodes": n,
+            "A": SparseTensor(ei, ea, [n, n], is_coalesced=True),
+            "X": SparseTensor(tid, tf, [n] * self.sd + list(self.feat_shape), is_coalesced=True),
+        }
+        for k in self.keys:
+            roles = parse_key(k)
+            inc = torch.stack([off["tup"] if roles[i][0] == "X" else off["edge"] for i in (0, 1, 3)])
+            dd[k + KEYSEP + "acd"] = self._rows(self.acd[k], self.acd_ptr[k], ids, ptrs[("acd", k)], total[("acd", k)], inc)
+        return dd

@@ -210,6 +210,21 @@ __global__ void plan_triples_kernel(int64_t* __restrict__ out, const int32_t* __
   }
 }
 
+__global__ void collate_rows_kernel(int64_t* __restrict__ out, const int32_t* __restrict__ src, int rows, int64_t src_ld,
+                                    int64_t out_ld, const int64_t* __restrict__ src_start, const int64_t* __restrict__ out_ptr,
+                                    const int64_t* __restrict__ inc, int64_t n_sel, int64_t total) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = n_sel;                  // last s with out_ptr[s] <= j
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (out_ptr[mid] <= j) lo = mid; else hi = mid;
+    }
+    const int64_t col = src_start[lo] + (j - out_ptr[lo]);
+    for (int r = 0; r < rows; ++r)
+      out[(int64_t)r * out_ld + j] = (int64_t)src[(int64_t)r * src_ld + col] + (inc ? inc[(int64_t)r * n_sel + lo] : 0);
+  }
+}
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int key_bits(int64_t n_keys) {
@@ -500,4 +515,15 @@ extern "C" int pygho_plan_triples(int64_t* out, const int32_t* slot, const int64
   if (!out || !slot || !c || !d || !perm) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   hipLaunchKernelGGL(plan_triples_kernel, dim3(grid_for(m, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, slot, c, d, perm, m);
   return check_launch("plan_triples");
+}
+
+extern "C" int pygho_collate_rows(int64_t* out, const int32_t* src, int64_t rows, int64_t src_ld, int64_t out_ld,
+                                  const int64_t* src_start, const int64_t* out_ptr, const int64_t* inc, int64_t n_sel,
+                                  int64_t total, void* stream) {
+  if (rows < 0 || n_sel < 0 || total < 0 || rows > 64) { set_error("collate_rows: bad size"); return PYGHO_ERR_INVALID; }
+  if (rows == 0 || n_sel == 0 || total == 0) return PYGHO_OK;
+  if (!out || !src || !src_start || !out_ptr) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(collate_rows_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, src, (int)rows,
+                     src_ld, out_ld, src_start, out_ptr, inc, n_sel, total);
+  return check_launch("collate_rows");
 }

@@ -473,3 +473,26 @@ def test_pair_product_with_embedding_table(dev, dtype):
         tol = 1e-5 if dtype == torch.float32 else 2.0 ** -7
         torch.testing.assert_close(x.grad.double() / s, y.grad / s, rtol=0, atol=tol, msg=name)
     assert torch.equal(out, _ops.pair_product(left, right, table[feat].contiguous(), row, col))   # same kernel, same rounding
+
+
+@pytest.mark.parametrize("kind", ["zinc", "i2"])
+def test_device_collate_bit_exact(dev, kind):
+    """on-device mini-batch collation from the int32 graph store == host block-diagonal collate (hodata/SpData.py:56-112
+    increments) for an arbitrary selection with repeats; the collated plan drives the same spspmm result."""
+    from pygho_amd import SparseTensor, synth
+    from pygho_amd.collate import DeviceGraphStore
+    rng = np.random.default_rng(5)
+    recs = [synth.make_graph(rng, kind) for _ in range(24 if kind == "zinc" else 10)]
+    store = DeviceGraphStore(recs, dev)
+    for sel in ([3, 0, 7, 7, 1], list(range(len(recs))), [len(recs) - 1]):
+        got = store.collate(sel)
+        ref = synth.to_datadict(synth.collate([recs[i] for i in sel]), dev, kind)
+        for k, v in ref.items():
+            g = got[k]
+            if isinstance(v, SparseTensor):
+                assert torch.equal(g.indices, v.indices) and torch.equal(g.values, v.values) and tuple(g.shape) == tuple(v.shape), k
+            elif torch.is_tensor(v):
+                assert v.dtype == g.dtype and torch.equal(g, v), k
+            else:
+                assert g == v, k
+        assert set(got.keys()) == set(ref.keys())

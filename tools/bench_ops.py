@@ -76,6 +76,29 @@ def planner_case(kind, graphs, dev):
             "msg_edges": int(acd.shape[1]), "ms": ms, "M_msg_edges_per_s": acd.shape[1] / ms / 1e3}
 
 
+def collate_case(graphs, dev):
+    """on-device mini-batch collation (hodata/SpData.py:56-112) from the int32 graph store: wall time per batch."""
+    import time
+    import numpy as np
+    from pygho_amd.collate import DeviceGraphStore
+    rng = np.random.default_rng(3)
+    recs = [synth.make_graph(rng, "zinc") for _ in range(1024)]
+    store = DeviceGraphStore(recs, dev)
+    sel = torch.from_numpy(rng.integers(0, len(recs), graphs)).to(dev)
+    dd = store.collate(sel)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        dd = store.collate(sel)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    key = next(k for k in dd if k.endswith("acd"))
+    out_bytes = 8 * (dd["A"].indices.numel() + dd["X"].indices.numel() + dd[key].numel() + dd["X"].nnz + dd["A"].nnz + 2 * dd["num_nodes"])
+    return {"op": "device collate zinc", "graphs": graphs, "tuples": dd["X"].nnz, "msg_edges": int(dd[key].shape[1]),
+            "ms": sorted(ts)[len(ts) // 2], "int64_MB_not_shipped_over_PCIe": out_bytes / 1e6}
+
+
 def mamamm_case(b, n, d, dtype, dev):
     from pygho_amd import MaskedTensor
     from pygho_amd.backend.Mamamm import mamamm
@@ -112,6 +135,7 @@ def main():
     out.append(mamamm_case(128 if args.quick else 1024, 37, 128, torch.bfloat16, dev))
     out.append(mamamm_case(128 if args.quick else 1024, 37, 128, torch.float32, dev))
     out.append(planner_case("zinc", 1024 if args.quick else 8192, dev))
+    out.append(collate_case(1024 if args.quick else 8192, dev))
     for r in out:
         print(json.dumps(r))
 
