@@ -91,6 +91,21 @@ int pygho_seg_gather_mul_reduce_add(void* out, const void* addend, const void* l
                                     const float* lhs_rowscale, int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d,
                                     int64_t lhs_rows, int64_t rhs_rows, int dtype, int aggr, void* stream);
 
+/* The same reduction with the layer MLP's BatchNorm + activation applied to one operand AS IT IS LOADED:
+ *   act_side 1:  out[s] = [addend[s] +] (+) act(lhs[li] * act_scale + act_shift) * rhs[ri]
+ *   act_side 2:  out[s] = [addend[s] +] (+) lhs[li] * act(rhs[ri] * act_scale + act_shift)
+ * (act_scale / act_shift: d floats, = weight * invstd and bias - mean * weight * invstd of pygho_bn_prepare; act 0 none,
+ * 1 relu, 2 silu; sum / mean; addend and lhs_rowscale nullable).  Replaces honn/utils.py:126-138 (BatchNorm1d -> act on
+ * the (nnz, d) values, Conv.py:56) FOLLOWED by Spspmm.py:309-315: the activated tensor is never written to or read from
+ * HBM, neither in the forward nor in the backward pass that needs it again (the gradient of the second operand).
+ * The activated value is rounded to the storage type before the product, so results are bit-identical to
+ * pygho_bn_act_fwd + pygho_seg_gather_mul_reduce(_add). */
+int pygho_seg_gather_mul_reduce_act(void* out, const void* addend, const void* lhs, const void* rhs,
+                                    const int32_t* seg_ptr, const int32_t* lhs_idx, const int32_t* rhs_idx,
+                                    const float* lhs_rowscale, const float* act_scale, const float* act_shift, int act,
+                                    int act_side, int64_t n_seg, int64_t d, int64_t lhs_rows, int64_t rhs_rows, int dtype,
+                                    int aggr, void* stream);
+
 /* Three-operand gather-multiply-segment-sum:
  *   out[s, :] = sum_{m in [seg_ptr[s], seg_ptr[s+1])} a[a_idx[m], :] * b[b_idx[m], :] * c[c_idx[m], :]
  * (an index array may be NULL = identity m).  Replaces the tuple initialisation of the model

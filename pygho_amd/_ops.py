@@ -204,8 +204,11 @@ class LaunchTimer:
 
 def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr: Tensor,
             lhs_idx: Optional[Tensor], rhs_idx: Optional[Tensor], aggr: str,
-            lhs_rowscale: Optional[Tensor] = None, addend: Optional[Tensor] = None) -> Tensor:
-    """out[s] = [addend[s] +] (+)_{m in seg s} scale * lhs[lhs_idx[m]] * rhs[rhs_idx[m]]  (2-D operands)."""
+            lhs_rowscale: Optional[Tensor] = None, addend: Optional[Tensor] = None,
+            act: Optional[Tuple[Tensor, Tensor, str, int]] = None) -> Tensor:
+    """out[s] = [addend[s] +] (+)_{m in seg s} scale * lhs[lhs_idx[m]] * rhs[rhs_idx[m]]  (2-D operands).
+    `act` = (scale, shift, name, side): operand `side` (1 lhs, 2 rhs) holds pre-activations and
+    act(x * scale + shift) is applied to its rows as they are loaded."""
     ref = lhs if lhs is not None else rhs
     dev = require_device(lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, addend)
     d = ref.shape[1]
@@ -217,7 +220,16 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
     dims = (out_rows, d, d if lhs is not None else 0, d if rhs is not None else 0,
             lhs.shape[0] if lhs is not None else 0, rhs.shape[0] if rhs is not None else 0,
             dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev))
-    if addend is None:
+    if act is not None:
+        a_scale, a_shift, a_name, a_side = act
+        assert lhs is not None and rhs is not None and a_scale.dtype == torch.float32 and a_shift.dtype == torch.float32
+        if addend is not None:
+            assert addend.shape == out.shape and addend.dtype == out.dtype and addend.is_contiguous()
+        check(lib().pygho_seg_gather_mul_reduce_act(
+            ptr(out), ptr(addend), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale),
+            ptr(a_scale.contiguous()), ptr(a_shift.contiguous()), ACT_CODE[a_name], a_side, out_rows, d, lhs.shape[0], rhs.shape[0],
+            dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev)), "seg_gather_mul_reduce_act")
+    elif addend is None:
         check(lib().pygho_seg_gather_mul_reduce(
             ptr(out), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale), *dims),
             "seg_gather_mul_reduce")
@@ -238,7 +250,7 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
         if addend is not None:
             nbytes += es * d * out_rows
         mode = "both" if (lhs is not None and rhs is not None) else ("lhs" if lhs is not None else "rhs")
-        timer.records.append((f"seg_gmr[{str(ref.dtype).split('.')[-1]},{aggr},{mode}{',scaled' if lhs_rowscale is not None else ''}{',res' if addend is not None else ''}]",
+        timer.records.append((f"seg_gmr[{str(ref.dtype).split('.')[-1]},{aggr},{mode}{',scaled' if lhs_rowscale is not None else ''}{',res' if addend is not None else ''}{',act' if act is not None else ''}]",
                               nbytes, e0, e1))
     return out
 
@@ -1085,10 +1097,12 @@ def bn_act_supported(x: Tensor) -> bool:
 
 
 def _bn_forward(x: Tensor, weight, bias, running_mean, running_var, training: bool, eps: float, act: str,
-                fold_momentum: Optional[float] = None, partial: Optional[Tuple[Tensor, Tensor]] = None):
+                fold_momentum: Optional[float] = None, partial: Optional[Tuple[Tensor, Tensor]] = None,
+                apply: bool = True):
     """(y, mean, var, saved) of act(batch_norm(x)) for a contiguous 2-D x.  Statistics, 1/sqrt(var + eps), the fused
     scale / shift and (with `fold_momentum`) the running-average update all come out of ONE finalisation kernel;
-    `partial` = (per-block shifted sums, their shift) when the producer of x already took the sums (rowblock_linear)."""
+    `partial` = (per-block shifted sums, their shift) when the producer of x already took the sums (rowblock_linear).
+    `apply=False`: y is not formed; (scale, shift) are returned in its place for a consumer that applies them on load."""
     dev = x.device
     m, c = x.shape
     dt = dtype_code(x)
@@ -1114,6 +1128,8 @@ def _bn_forward(x: Tensor, weight, bias, running_mean, running_var, training: bo
                                      ptr(w32), ptr(b32), float(eps), ptr(running_mean) if fold else None,
                                      ptr(running_var) if fold else None, float(fold_momentum or 0.0), ptr(ws), dt, st),
               "bn_prepare")
+    if not apply:
+        return (scale, shift), mean, var, (mean, invstd, w32, b32, ws)
     y = torch.empty_like(x)
     check(lib().pygho_bn_act_fwd(ptr(y), ptr(x), ptr(scale), ptr(shift), m, c, ACT_CODE[act], dt, st), "bn_act_fwd")
     return y, mean, var, (mean, invstd, w32, b32, ws)
@@ -1212,6 +1228,7 @@ def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype) -> Tensor:
 
 USE_FUSED_DW = True      # weight gradient inside the backward kernel (gpre never reaches HBM)
 USE_TABLE_PRODUCT = True
+USE_ACT_ON_LOAD = True   # f32 blocks: BatchNorm + activation applied inside the aggregation kernel's loads
 USE_BN_BWD_LINEAR = True
 USE_ROWBLOCK_LINEAR = True      # module switch for A/B measurements (the library GEMM + separate passes otherwise)
 
@@ -1302,12 +1319,24 @@ class _TupleBlock(torch.autograd.Function):
             partial = (sums, sum_shift) if training else None
         else:
             pre = torch.nn.functional.linear(x, wc, bc)
-        h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum, partial)
+        # f32 rows carry half the elements per byte: there the BatchNorm + activation can ride on the aggregation's loads
+        # (act-on-load: 0.61 vs 0.35 + 0.62 ms) and the activated tensor is never formed; with 16-bit rows the two
+        # transcendentals per element make that kernel VALU-bound (0.52 vs 0.50 ms forward, 0.41 vs 0.30 ms backward)
+        on_load = (USE_ACT_ON_LOAD and plan is not None and rhs is not None and x.dtype == torch.float32 and aggr in ("sum", "mean")
+                   and (x.shape[1] * 4) % 16 == 0 and rhs.dtype == x.dtype and rhs.shape[1] == x.shape[1])
+        h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum, partial,
+                                          apply=not on_load)
+        affine = None
         if plan is None:
             out = h
+        elif on_load:
+            affine, h = h, None
+            out = seg_gmr(plan.n_out, pre, rhs, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, aggr, addend=x if residual else None,
+                          act=(affine[0], affine[1], act, 1))
         else:
             out = seg_gmr(plan.n_out, h, rhs, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd if rhs is not None else None, aggr,
                           addend=x if residual else None)
+        ctx.affine = affine
         ctx.save_for_backward(x, wc, pre, h if plan is not None else None, rhs, *saved)
         ctx.meta = (training, act, None if b is None else b.dtype, gamma is not None, beta is not None, plan, aggr, residual, w.dtype,
                     skinny)
@@ -1327,7 +1356,11 @@ class _TupleBlock(torch.autograd.Function):
             gh = seg_gmr(plan.n_lhs, g, rhs, p.seg_ptr, a_g, d_g if rhs is not None else None, "sum", scale)
             if rhs is not None and ctx.needs_input_grad[10]:
                 p, a_g, c_g = plan.by_d()
-                g_rhs = seg_gmr(plan.n_rhs, g, h, p.seg_ptr, a_g, c_g, "sum", scale)
+                if ctx.affine is not None:
+                    g_rhs = seg_gmr(plan.n_rhs, g, pre, p.seg_ptr, a_g, c_g, "sum", scale,
+                                    act=(ctx.affine[0], ctx.affine[1], act, 2))
+                else:
+                    g_rhs = seg_gmr(plan.n_rhs, g, h, p.seg_ptr, a_g, c_g, "sum", scale)
         want_cs = b_dtype is not None and ctx.needs_input_grad[2]
         gx = gw = gb = None
         if skinny and USE_BN_BWD_LINEAR and USE_FUSED_DW and ctx.needs_input_grad[1]:

@@ -20,7 +20,7 @@ template <typename T> struct Row16 {                      // 16-B vector <-> N f
 template <int ACT>
 __device__ __forceinline__ float act_fwd(float z) {
   if (ACT == ACT_RELU) return z > 0.f ? z : 0.f;
-  if (ACT == ACT_SILU) return z / (1.f + __expf(-z));
+  if (ACT == ACT_SILU) return z * __builtin_amdgcn_rcpf(1.f + __expf(-z));      // same formula as the activation-on-load of seg_reduce.hip
   return z;
 }
 template <int ACT>

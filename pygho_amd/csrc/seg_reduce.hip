@@ -35,9 +35,24 @@ __device__ __forceinline__ uint4 load_row16(const char* __restrict__ base, int i
   return *reinterpret_cast<const uint4*>(base + ((int64_t)idx * (int64_t)row_bytes + col_bytes));
 }
 
-template <typename T, int AGGR, int MODE, bool SCALED, bool THIRD = false>
+// act(x * scale + shift) of a freshly loaded row, rounded to T like the materialised tensor it replaces (so the fused
+// result is bit-identical to bn_act_fwd followed by the plain kernel); act: 0 affine only, 1 relu, 2 silu
+template <typename T>
+__device__ __forceinline__ void act_on_load(float (&v)[Vec16<T>::N], const float (&asc)[Vec16<T>::N],
+                                            const float (&ash)[Vec16<T>::N], int act) {
+  constexpr int N = Vec16<T>::N;
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    const float z = v[q] * asc[q] + ash[q];
+    v[q] = act == 2 ? z * __builtin_amdgcn_rcpf(1.f + __expf(-z)) : (act == 1 ? (z > 0.f ? z : 0.f) : z);
+  }
+  if (sizeof(T) == 2) Vec16<T>::unpack(Vec16<T>::pack(v), v);
+}
+
+template <typename T, int AGGR, int MODE, bool SCALED, bool THIRD = false, int ACTSIDE = 0>
 __device__ __forceinline__ void accumulate16(float (&acc)[Vec16<T>::N], const uint4& la, const uint4& rb, float sc,
-                                             const uint4& tc = uint4{}) {
+                                             const uint4& tc = uint4{}, const float (*asc)[Vec16<T>::N] = nullptr,
+                                             const float (*ash)[Vec16<T>::N] = nullptr, int act = 0) {
   using V = Vec16<T>;
   using R = Reduce<AGGR, float>;
   constexpr int N = V::N;
@@ -45,6 +60,8 @@ __device__ __forceinline__ void accumulate16(float (&acc)[Vec16<T>::N], const ui
   if (MODE != MODE_RHS) V::unpack(la, a);
   if (MODE != MODE_LHS) V::unpack(rb, b);
   if (THIRD) V::unpack(tc, c);
+  if (ACTSIDE == 1) act_on_load<T>(a, *asc, *ash, act);
+  if (ACTSIDE == 2) act_on_load<T>(b, *asc, *ash, act);
 #pragma unroll
   for (int q = 0; q < N; ++q) {
     if (THIRD) {                                   // (a * b) * c, rounded like the sequential elementwise chain
@@ -61,13 +78,14 @@ __device__ __forceinline__ void accumulate16(float (&acc)[Vec16<T>::N], const ui
   }
 }
 
-template <typename T, int AGGR, int MODE, bool SCALED, bool OFF32, bool OUTF32 = false, bool THIRD = false>
+template <typename T, int AGGR, int MODE, bool SCALED, bool OFF32, bool OUTF32 = false, bool THIRD = false, int ACTSIDE = 0>
 __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
     T* __restrict__ out, const T* __restrict__ lhs, const T* __restrict__ rhs,
     const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ lhs_idx,
     const int32_t* __restrict__ rhs_idx, const float* __restrict__ lhs_rowscale, const T* __restrict__ addend,
     int64_t n_seg, int d, int chunks, int log2g, int spp,
-    const T* __restrict__ third = nullptr, const int32_t* __restrict__ third_idx = nullptr) {
+    const T* __restrict__ third = nullptr, const int32_t* __restrict__ third_idx = nullptr,
+    const float* __restrict__ act_scale = nullptr, const float* __restrict__ act_shift = nullptr, int act = 0) {
   using V = Vec16<T>;
   using R = Reduce<AGGR, float>;
   constexpr int N = V::N;
@@ -90,6 +108,16 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
   const char* rbase = reinterpret_cast<const char*>(rhs);
   char* obase = reinterpret_cast<char*>(out);
   const bool has_li = lhs_idx != nullptr, has_ri = rhs_idx != nullptr, has_ti = THIRD && third_idx != nullptr;
+  // ACTSIDE: that operand holds PRE-activations; act(x * scale + shift) (the BatchNorm + activation of the layer MLP) is
+  // applied to every row as it is loaded, so the activated tensor never exists in HBM.  Per-lane constants of its 16-B chunk.
+  float asc[ACTSIDE ? N : 1], ash[ACTSIDE ? N : 1];
+  if (ACTSIDE) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      asc[q] = active ? act_scale[chunk * N + q] : 0.f;
+      ash[q] = active ? act_shift[chunk * N + q] : 0.f;
+    }
+  }
   const char* tbase = reinterpret_cast<const char*>(third);
   const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
   // XCD-aware sweep: workgroup b runs on XCD b % 8 (observed dispatch order).  Remap so that the workgroups of
@@ -149,8 +177,16 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
         if (MODE != MODE_RHS) { la0 = load_row16<OFF32>(lbase, l0, row_bytes, col_bytes); la1 = load_row16<OFF32>(lbase, l1, row_bytes, col_bytes); }
         if (MODE != MODE_LHS) { rb0 = load_row16<OFF32>(rbase, r0, row_bytes, col_bytes); rb1 = load_row16<OFF32>(rbase, r1, row_bytes, col_bytes); }
         if (SCALED) { sc0 = lhs_rowscale[l0]; sc1 = lhs_rowscale[l1]; }
-        accumulate16<T, AGGR, MODE, SCALED, THIRD>(acc, la0, rb0, sc0, tc0);
-        if (two) accumulate16<T, AGGR, MODE, SCALED, THIRD>(acc, la1, rb1, sc1, tc1);
+        if (ACTSIDE) {
+          accumulate16<T, AGGR, MODE, SCALED, THIRD, ACTSIDE>(acc, la0, rb0, sc0, tc0, reinterpret_cast<const float(*)[N]>(&asc),
+                                                              reinterpret_cast<const float(*)[N]>(&ash), act);
+          if (two)
+            accumulate16<T, AGGR, MODE, SCALED, THIRD, ACTSIDE>(acc, la1, rb1, sc1, tc1, reinterpret_cast<const float(*)[N]>(&asc),
+                                                                reinterpret_cast<const float(*)[N]>(&ash), act);
+        } else {
+          accumulate16<T, AGGR, MODE, SCALED, THIRD>(acc, la0, rb0, sc0, tc0);
+          if (two) accumulate16<T, AGGR, MODE, SCALED, THIRD>(acc, la1, rb1, sc1, tc1);
+        }
       }
       const int cnt = end - beg;
 #pragma unroll
@@ -378,6 +414,42 @@ int dispatch_aggr(int aggr, void* out, const void* lhs, const void* rhs, const i
 }
 
 
+template <typename T, int AGGR, bool OFF32, int ACTSIDE>
+int launch_act_fast(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
+                    const int32_t* rhs_idx, const float* scale, const void* addend, const float* act_scale, const float* act_shift,
+                    int act, int64_t n_seg, int64_t d, hipStream_t st) {
+  const int chunks = (int)(d * sizeof(T) / 16);
+  int log2g = 0;
+  while ((1 << log2g) < chunks && log2g < 6) ++log2g;
+  const int spp = segs_per_pass(n_seg, log2g);
+  int gx = grid_for(n_seg, (kBlock / kWave) * spp);
+  if (gx > 8) gx = (gx + 7) & ~7;
+  dim3 grid(gx, (unsigned)ceil_div(chunks, kWave));
+#define PYGHO_LAUNCH_ACT(SC)                                                                                                        \
+  hipLaunchKernelGGL((seg_gmr_fast_kernel<T, AGGR, MODE_BOTH, SC, OFF32, false, false, ACTSIDE>), grid, dim3(kBlock), 0, st, (T*)out, \
+                     (const T*)lhs, (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, (const T*)addend, n_seg, (int)d, chunks, log2g, \
+                     spp, (const T*)nullptr, (const int32_t*)nullptr, act_scale, act_shift, act)
+  if (scale) PYGHO_LAUNCH_ACT(true); else PYGHO_LAUNCH_ACT(false);
+#undef PYGHO_LAUNCH_ACT
+  return check_launch("seg_gather_mul_reduce_act");
+}
+
+template <typename T>
+int dispatch_act(void* out, const void* addend, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
+                 const int32_t* rhs_idx, const float* scale, const float* act_scale, const float* act_shift, int act, int act_side,
+                 int64_t n_seg, int64_t d, int64_t lhs_rows, int64_t rhs_rows, int aggr, hipStream_t st) {
+  const int64_t rb = d * (int64_t)sizeof(T), lim = (int64_t)1 << 32;
+  const bool off32 = n_seg * rb < lim && lhs_rows > 0 && lhs_rows * rb < lim && rhs_rows > 0 && rhs_rows * rb < lim;
+#define PYGHO_ACT_CASE(AG, O32)                                                                                                  \
+  return act_side == 1 ? launch_act_fast<T, AG, O32, 1>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, addend, act_scale,        \
+                                                        act_shift, act, n_seg, d, st)                                            \
+                       : launch_act_fast<T, AG, O32, 2>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, addend, act_scale,        \
+                                                        act_shift, act, n_seg, d, st)
+  if (aggr == PYGHO_SUM) { if (off32) { PYGHO_ACT_CASE(PYGHO_SUM, true); } else { PYGHO_ACT_CASE(PYGHO_SUM, false); } }
+  if (off32) { PYGHO_ACT_CASE(PYGHO_MEAN, true); } else { PYGHO_ACT_CASE(PYGHO_MEAN, false); }
+#undef PYGHO_ACT_CASE
+}
+
 // out[s] = sum_{m in segment s} a[ai[m]] * b[bi[m]] * c[ci[m]] for any row width (one thread per (segment, column))
 template <typename T>
 __global__ __launch_bounds__(kBlock) void seg_triple_generic_kernel(
@@ -600,5 +672,30 @@ extern "C" int pygho_seg_triple_product(void* out, const void* a, const void* b,
     case PYGHO_F16: return dispatch_triple<f16, true>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, out_f32 != 0, st);
     case PYGHO_F64: return dispatch_triple<double, false>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, out_f32 != 0, st);
     default: set_error("unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED;
+  }
+}
+
+extern "C" int pygho_seg_gather_mul_reduce_act(void* out, const void* addend, const void* lhs, const void* rhs,
+                                               const int32_t* seg_ptr, const int32_t* lhs_idx, const int32_t* rhs_idx,
+                                               const float* lhs_rowscale, const float* act_scale, const float* act_shift, int act,
+                                               int act_side, int64_t n_seg, int64_t d, int64_t lhs_rows, int64_t rhs_rows, int dtype,
+                                               int aggr, void* stream) {
+  if (n_seg < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n_seg == 0 || d == 0) return PYGHO_OK;
+  if (!out || !seg_ptr || !lhs || !rhs || !act_scale || !act_shift) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (act_side != 1 && act_side != 2) { set_error("act_side must be 1 (lhs) or 2 (rhs)"); return PYGHO_ERR_INVALID; }
+  if (act < 0 || act > 2) { set_error("unknown activation %d", act); return PYGHO_ERR_INVALID; }
+  if (aggr != PYGHO_SUM && aggr != PYGHO_MEAN) { set_error("seg_gather_mul_reduce_act: sum / mean only"); return PYGHO_ERR_UNSUPPORTED; }
+  const int es = dtype == PYGHO_F32 ? 4 : 2;
+  if ((dtype != PYGHO_F32 && dtype != PYGHO_BF16 && dtype != PYGHO_F16) || (d * es) % 16 != 0 ||
+      (((uintptr_t)out | (uintptr_t)lhs | (uintptr_t)rhs | (uintptr_t)addend) % 16) != 0) {
+    set_error("seg_gather_mul_reduce_act: f32 / bf16 / f16 rows of a multiple of 16 bytes, 16-byte aligned");
+    return PYGHO_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case PYGHO_F32: return dispatch_act<float>(out, addend, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, act_scale, act_shift, act, act_side, n_seg, d, lhs_rows, rhs_rows, aggr, st);
+    case PYGHO_BF16: return dispatch_act<bf16>(out, addend, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, act_scale, act_shift, act, act_side, n_seg, d, lhs_rows, rhs_rows, aggr, st);
+    default: return dispatch_act<f16>(out, addend, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, act_scale, act_shift, act, act_side, n_seg, d, lhs_rows, rhs_rows, aggr, st);
   }
 }

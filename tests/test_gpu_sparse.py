@@ -496,3 +496,33 @@ def test_device_collate_bit_exact(dev, kind):
             else:
                 assert g == v, k
         assert set(got.keys()) == set(ref.keys())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("act", ["silu", "relu", "none"])
+def test_activation_on_load_bit_identical(dev, dtype, act):
+    """aggregation with BatchNorm scale / shift + activation applied to one operand as it is loaded == fused BatchNorm+act
+    kernel followed by the plain aggregation, bit for bit, on either operand side, with residual and mean scaling."""
+    from pygho_amd import _ops, synth
+    from pygho_amd._native import check, dtype_code, lib, ptr, stream_ptr
+    hb = synth.make_batch(64, "zinc", seed=8)
+    acd = T(hb.acd["X___X___1___A___0"], dev)
+    nt, ne, d = hb.num_tuples, hb.num_edges, 64
+    torch.manual_seed(6)
+    Y = (torch.randn(nt, d, device=dev) * 1.3).to(dtype)
+    R, G = torch.randn(nt, d, device=dev).to(dtype), torch.randn(nt, d, device=dev).to(dtype)
+    A = torch.randn(ne, d, device=dev).to(dtype)
+    scale, shift = torch.rand(d, device=dev) + 0.5, torch.randn(d, device=dev) * 0.3
+    H = torch.empty_like(Y)
+    check(lib().pygho_bn_act_fwd(ptr(H), ptr(Y), ptr(scale), ptr(shift), nt, d, _ops.ACT_CODE[act], dtype_code(Y), stream_ptr(dev)), "bn_act_fwd")
+    plan = _ops.message_plan(acd, nt, nt, ne)
+    for aggr in ("sum", "mean"):
+        ref = _ops.seg_gmr(nt, H, A, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, aggr, addend=R)
+        got = _ops.seg_gmr(nt, Y, A, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, aggr, addend=R, act=(scale, shift, act, 1))
+        assert torch.equal(ref, got), aggr
+    p, a_g, c_g = plan.by_d()
+    inv = plan.fwd.inv_count
+    for rs in (None, inv):
+        ref = _ops.seg_gmr(ne, G, H, p.seg_ptr, a_g, c_g, "sum", rs)
+        got = _ops.seg_gmr(ne, G, Y, p.seg_ptr, a_g, c_g, "sum", rs, act=(scale, shift, act, 2))
+        assert torch.equal(ref, got)
