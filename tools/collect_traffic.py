@@ -12,7 +12,7 @@ import glob
 import json
 import sys
 
-KERNEL = "seg_gmr_fast_kernel<pygho::bf16, 0, 0, false, true, false, false>"
+KERNEL = "seg_gmr_fast_kernel<pygho::bf16, 0, 0, false, true, false, false, 0>"     # <T, SUM, BOTH, !SCALED, OFF32, !OUTF32, !THIRD, no act>
 FETCH_CORRECTION = 1.97
 
 
