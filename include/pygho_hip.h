@@ -377,6 +377,9 @@ int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, const void* 
                            const void* addend, float* colsum_ws, const float* mean, const float* invstd, const float* w,
                            const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m, int64_t d, int act,
                            int training, int dtype, void* stream);
+/* out[j] = sum over b < n_blocks of in[b * n + j]: folds the per-workgroup partial results of the kernels above (weight
+ * gradient slabs, column sums) deterministically. */
+int pygho_sum_blocks(float* out, const float* in, int64_t n_blocks, int64_t n, void* stream);
 /* the reduction half of pygho_bn_act_bwd alone: sum_dz, sum_dz_xhat (c floats each). */
 int pygho_bn_act_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
                           const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act,

@@ -1258,6 +1258,15 @@ def rowblock_linear(x: Tensor, wl: Tensor, bias: Optional[Tensor] = None, addend
     return out, ws
 
 
+def sum_blocks(partials: Tensor) -> Tensor:
+    """(n_blocks, ...) f32 per-workgroup partial results -> their sum over the first dim (one deterministic kernel)."""
+    dev = require_device(partials)
+    assert partials.dtype == torch.float32 and partials.is_contiguous()
+    out = torch.empty(partials.shape[1:], dtype=torch.float32, device=dev)
+    check(lib().pygho_sum_blocks(ptr(out), ptr(partials), partials.shape[0], out.numel(), stream_ptr(dev)), "sum_blocks")
+    return out
+
+
 def bn_bwd_linear(pre: Tensor, gh: Tensor, saved, training: bool, act: str, w: Tensor, addend: Optional[Tensor],
                   want_colsum: bool, x: Optional[Tensor] = None):
     """(gx, gpre or dW, d bn.bias, d bn.weight, column sums of gpre or None): BatchNorm/act backward and the
@@ -1284,13 +1293,13 @@ def bn_bwd_linear(pre: Tensor, gh: Tensor, saved, training: bool, act: str, w: T
         check(lib().pygho_bn_bwd_linear_dw(ptr(gx), ptr(second), ptr(pre), ptr(gh), ptr(x), ptr(wl), ptr(addend), ptr(cws), ptr(mean),
                                            ptr(invstd), ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act],
                                            1 if training else 0, dt, st), "bn_bwd_linear_dw")
-        second = second.sum(0)
+        second = sum_blocks(second)
     else:
         second = torch.empty_like(pre)
         check(lib().pygho_bn_bwd_linear(ptr(gx), ptr(second), ptr(pre), ptr(gh), ptr(wl), ptr(addend), ptr(cws), ptr(mean), ptr(invstd),
                                         ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act], 1 if training else 0, dt, st),
               "bn_bwd_linear")
-    sdx = cws[:, 0].sum(0) if cws is not None else None
+    sdx = sum_blocks(cws)[0] if cws is not None else None
     return gx, second, s1, s2, sdx
 
 

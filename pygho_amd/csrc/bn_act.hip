@@ -407,3 +407,34 @@ extern "C" int pygho_bn_act_bwd_sums(float* sum_dz, float* sum_dz_xhat, const vo
   }));
   return check_launch("bn_act_bwd_sums");
 }
+
+// out[j] = sum_b in[b * n + j]: per-workgroup partial results (weight-gradient slabs, column sums) -> one.  Coalesced along j,
+// the block range split over the 4 waves of a workgroup and combined through LDS in a fixed order (deterministic).
+namespace pygho {
+__global__ __launch_bounds__(kBlock) void sum_blocks_kernel(float* __restrict__ out, const float* __restrict__ in, int64_t nblk,
+                                                            int64_t n) {
+  __shared__ float red[kBlock / kWave][kWave];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * kWave + lane;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (j < n) {
+    int64_t b = wave;
+    for (; b + 3 * (kBlock / kWave) < nblk; b += 4 * (kBlock / kWave)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] += in[(b + u * (kBlock / kWave)) * n + j];
+    }
+    for (; b < nblk; b += kBlock / kWave) acc[0] += in[b * n + j];
+  }
+  red[wave][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (wave == 0 && j < n) out[j] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+}  // namespace pygho
+
+extern "C" int pygho_sum_blocks(float* out, const float* in, int64_t n_blocks, int64_t n, void* stream) {
+  if (n_blocks < 0 || n < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n == 0) return PYGHO_OK;
+  if (!out || (n_blocks > 0 && !in)) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(pygho::sum_blocks_kernel, dim3((unsigned)ceil_div(n, kWave)), dim3(kBlock), 0, (hipStream_t)stream, out, in, n_blocks, n);
+  return check_launch("sum_blocks");
+}
