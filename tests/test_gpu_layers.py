@@ -415,3 +415,46 @@ def test_model_fused_paths_match_plain_composition(dev):
             continue                                       # bias in front of a BatchNorm: zero up to rounding noise
         s = float(ref.abs().max()) + 1e-6
         torch.testing.assert_close(res[True][1][k] / s, ref / s, rtol=0, atol=8e-2, msg=k)
+
+
+@pytest.mark.parametrize("mode", ["SS", "DD"])
+def test_sunconv_restructured_equals_reference_wiring(dev, mode):
+    """SUNConv.forward (per-type linear map pulled through the unpooling broadcasts, no (nnz, 7 d) concatenation) against
+    SUNConv.forward_concat (the reference's literal wiring, Conv.py:338-362): outputs, input and parameter gradients."""
+    import copy
+    from pygho_amd import MaskedTensor, SparseTensor, synth
+    from pygho_amd.honn import Conv
+    h = 16
+    dn = synth.make_dense_batch(5, seed=6, hidden=h, clip_nodes=9)
+    torch.manual_seed(1)
+    mlp = dict(MLP, norm="none")
+    la = Conv.SUNConv(h, h, "sum", "mean", mode, dict(mlp), dict(mlp)).to(dev)
+    lb = copy.deepcopy(la)
+    if mode == "DD":
+        xraw = T(dn["X"], dev)
+        mk = lambda v: (MaskedTensor(T(dn["A"], dev), T(dn["Amask"], dev)), MaskedTensor(v, T(dn["Xmask"], dev)), {})
+        vals_of = lambda r: r.data * T(dn["Xmask"], dev)[..., None]
+    else:
+        off = np.concatenate(([0], np.cumsum(dn["nodemask"].sum(1))))
+        bi, ii, jj = np.nonzero(dn["Xmask"])
+        tid = np.stack((ii + off[bi], jj + off[bi]))
+        eb, ei_, ej = np.nonzero(dn["Amask"])
+        eidx = np.stack((ei_ + off[eb], ej + off[eb]))
+        n = int(off[-1])
+        xraw = T(dn["X"][bi, ii, jj], dev)
+        acd = T(synth.host_plan_acd(tid, tid, 1, eidx, 0), dev)
+        As = SparseTensor(T(eidx, dev), T(dn["A"][eb, ei_, ej], dev), [n, n, h], True)
+        mk = lambda v: (As, SparseTensor(T(tid, dev), v, [n, n, h], True), {"X___X___1___A___0___acd": acd})
+        vals_of = lambda r: r.values
+    w = torch.randn(xraw.shape, device=dev)
+    res = []
+    for layer, fn in ((la, "forward"), (lb, "forward_concat")):
+        x = xraw.clone().requires_grad_(True)
+        A, X, dd = mk(x)
+        out = vals_of(getattr(layer, fn)(A, X, dd))
+        (out * w).sum().backward()
+        res.append((out.detach(), x.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()}))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-4, atol=2e-4)
+    for k in res[1][2]:
+        torch.testing.assert_close(res[0][2][k], res[1][2][k], rtol=5e-4, atol=5e-4, msg=k)

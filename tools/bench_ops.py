@@ -76,6 +76,36 @@ def planner_case(kind, graphs, dev):
             "msg_edges": int(acd.shape[1]), "ms": ms, "M_msg_edges_per_s": acd.shape[1] / ms / 1e3}
 
 
+def sunconv_case(b, n, d, dtype, dev):
+    """BASELINE config 3, second half: one SUNConv layer on the dense MaskedTensor path (mode "DD": masked bmm on the matrix
+    cores, masked pooling / broadcast kernels, fused BatchNorm MLPs), forward + backward, padded ZINC-shape batch."""
+    from pygho_amd import MaskedTensor
+    from pygho_amd.honn import Conv
+    dn = synth.make_dense_batch(min(b, 256), seed=2, hidden=d, nmax=n)
+    rep = max(1, b // min(b, 256))
+    t = lambda a, dt=None: (torch.from_numpy(a).to(dev).repeat((rep,) + (1,) * (a.ndim - 1)).to(dt) if dt
+                            else torch.from_numpy(a).to(dev).repeat((rep,) + (1,) * (a.ndim - 1)))
+    mlp = {"numlayer": 1, "tailact": True, "norm": "bn", "act": "silu", "dp": 0.0}
+    torch.manual_seed(0)
+    layer = Conv.SUNConv(d, d, "sum", "mean", "DD", dict(mlp), dict(mlp)).to(dev)
+    Xraw = t(dn["X"], dtype).requires_grad_(True)
+    X = MaskedTensor(Xraw, t(dn["Xmask"]), 0.0, True)
+    A = MaskedTensor(t(dn["A"], dtype), t(dn["Amask"]), 0.0, True)
+    w = torch.randn_like(Xraw)
+
+    def step():
+        Xraw.grad = None
+        for p in layer.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            out = layer(A, X, {})
+        (out.data.float() * w.float()).sum().backward()
+    ms = timed(step, reps=10)
+    bb = Xraw.shape[0]
+    return {"op": "SUNConv DD layer fwd+bwd", "b": bb, "n": n, "d": d, "dtype": str(dtype).split(".")[-1], "ms": ms,
+            "graphs_per_s": bb / ms * 1e3}
+
+
 def collate_case(graphs, dev):
     """on-device mini-batch collation (hodata/SpData.py:56-112) from the int32 graph store: wall time per batch."""
     import time
@@ -134,6 +164,8 @@ def main():
     out.append(mamamm_case(128, 37, 128, torch.bfloat16, dev))
     out.append(mamamm_case(128 if args.quick else 1024, 37, 128, torch.bfloat16, dev))
     out.append(mamamm_case(128 if args.quick else 1024, 37, 128, torch.float32, dev))
+    out.append(sunconv_case(128, 37, 128, torch.bfloat16, dev))
+    out.append(sunconv_case(128 if args.quick else 1024, 37, 128, torch.bfloat16, dev))
     out.append(planner_case("zinc", 1024 if args.quick else 8192, dev))
     out.append(collate_case(1024 if args.quick else 8192, dev))
     for r in out:
