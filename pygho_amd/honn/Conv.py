@@ -258,8 +258,11 @@ class SUNConv(Module):
                 return _SplitKLinearFn.apply(flat, w.to(val.dtype).t(), None).reshape(val.shape[:-1] + (w.shape[1],))
             return val @ w.to(val.dtype)
 
-        lin = lambda rep, w: (rep.tuplewiseapply(lambda val: mm(val, w)) if isinstance(rep, (SparseTensor, MaskedTensor))
-                              else mm(rep, w))
+        def lin(rep, w):                     # a bias-free linear map needs no fill of the masked entries (they stay don't-care)
+            if isinstance(rep, MaskedTensor):
+                return MaskedTensor(mm(rep.raw, w), rep.mask)
+            return rep.tuplewiseapply(lambda val: mm(val, w)) if isinstance(rep, SparseTensor) else mm(rep, w)
+
         add = lambda a, b: a.add(b, True) if isinstance(a, (SparseTensor, MaskedTensor)) else a + b
 
         agg = self.aggr.forward(A, X.tuplewiseapply(self.lin0), datadict, X)
@@ -272,9 +275,9 @@ class SUNConv(Module):
         dg = add(lin(centre, blk(1, 0) + blk(1, 1) + blk(1, 2)), lin(self.diag.forward(agg), blk(1, 3)))
         dg = add(add(add(dg, lin(n5, blk(1, 4))), lin(n6, blk(1, 5))), lin(n7, blk(1, 6)))
         dg_t = to_root(dg, X)
-        dg_vals = dg_t.values if isinstance(dg_t, SparseTensor) else dg_t.raw
-
-        def select(val, is_diag):
-            return torch.where(is_diag.bool().unsqueeze(-1), dg_vals.to(val.dtype), val)
-
-        return off.diagonalapply(select).tuplewiseapply(self.lin1_1)
+        if isinstance(off, MaskedTensor):
+            eye = torch.eye(off.shape[1], off.shape[2], dtype=torch.bool, device=off.raw.device).reshape(1, off.shape[1], off.shape[2], 1)
+            picked = MaskedTensor(torch.where(eye, dg_t.raw.to(off.raw.dtype), off.raw), off.mask)
+        else:
+            picked = off.diagonalapply(lambda val, is_diag: torch.where(is_diag.bool().unsqueeze(-1), dg_t.values.to(val.dtype), val))
+        return picked.tuplewiseapply(self.lin1_1)
