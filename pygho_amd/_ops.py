@@ -1210,20 +1210,38 @@ def batch_norm_act(x: Tensor, bn: "torch.nn.BatchNorm1d", act: str) -> Tensor:
 # --------------------------------------------------------------------------
 # one tuple-wise block: Linear -> BatchNorm -> act [-> message passing [+ residual]]   
 # --------------------------------------------------------------------------
-def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype) -> Tensor:
-    """dW = g^T x for tall (nnz ~ 10^6) operands as a batched split-K product: the reduction dim is the long
-    one and the BLAS heuristics pick a kernel without split-K for it (2.9 ms vs 0.19 ms at nnz = 1.8 M)."""
+def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype, want_colsum: bool = False):
+    """dW = g^T x for tall (nnz ~ 10^5..10^6) operands; with `want_colsum` returns (dW, g.sum(0)).
+    Square 16-bit Linears of width 64 / 128 run on the transpose-read MFMA kernel (`pygho_weight_grad`); the rest falls back
+    to the library: a plain GEMM below 2^19 rows, a batched split-K product above (the BLAS heuristics pick no split-K for a
+    128 x 128 output, 2.9 ms at 1.8 M rows, but the batched call costs ~3.7 ms of host time, so it only pays for huge m)."""
     m, n, k = g.shape[0], g.shape[1], x.shape[1]
-    slabs = min(256, m // 2048)
-    if slabs < 4:
-        return (g.t() @ x).to(out_dtype)
-    rows = m // slabs
-    main = rows * slabs
-    part = torch.bmm(g[:main].view(slabs, rows, n).transpose(1, 2), x[:main].view(slabs, rows, k))
-    gw = part.float().sum(0)
-    if main < m:
-        gw = gw + (g[main:].t() @ x[main:]).float()
-    return gw.to(out_dtype)
+    cs = None
+    if (g.is_cuda and g.dtype in (torch.bfloat16, torch.float16) and x.dtype == g.dtype and n == k and n in (64, 128) and m >= 8192):
+        g, x = g.contiguous(), x.contiguous()
+        dev = g.device
+        nblk = int(lib().pygho_bn_bwd_linear_dw_blocks(m))
+        ws = torch.empty((nblk, n, k), dtype=torch.float32, device=dev)
+        cws = torch.empty((nblk, 2, n), dtype=torch.float32, device=dev) if want_colsum else None
+        check(lib().pygho_weight_grad(ptr(ws), ptr(cws), ptr(g), ptr(x), m, n, dtype_code(g), stream_ptr(dev)), "weight_grad")
+        gw = sum_blocks(ws).to(out_dtype)
+        if want_colsum:
+            cs = sum_blocks(cws)[0]
+    else:
+        slabs = min(256, m // 2048)
+        if slabs < 4 or m < (1 << 19):
+            gw = (g.t() @ x).to(out_dtype)
+        else:
+            rows = m // slabs
+            main = rows * slabs
+            part = torch.bmm(g[:main].view(slabs, rows, n).transpose(1, 2), x[:main].view(slabs, rows, k))
+            gw = part.float().sum(0)
+            if main < m:
+                gw = gw + (g[main:].t() @ x[main:]).float()
+            gw = gw.to(out_dtype)
+        if want_colsum:
+            cs = g.sum(0, dtype=torch.float32)
+    return (gw, cs) if want_colsum else gw
 
 
 USE_FUSED_DW = True      # weight gradient inside the backward kernel (gpre never reaches HBM)

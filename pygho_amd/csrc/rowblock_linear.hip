@@ -629,6 +629,142 @@ int launch_bn_bwd_linear_dw(void* gx, const void* pre, const void* gh, const voi
   return check_launch("bn_bwd_linear_dw");
 }
 
+// ---- stand-alone weight gradient of a tall Linear: dW[n][k] = sum_m g[m][n] x[m][k]  (+ column sums of g = bias gradient) -----
+// The dW half of the kernel above for Linears outside a fused block (node-level maps, SUNConv's block products): the library
+// GEMM has no split-K for a 128 x 128 output with K = 10^5..10^6 (2.9 ms at 1.8 M rows) and the batched split-K workaround
+// costs 3.7 ms of HOST time per call in the BLAS front end, which stalled the whole training step.  Two 256-thread
+// workgroups per CU walk 64-row tiles; g and x rows go HBM -> registers -> LDS, every wave accumulates its slab with
+// operands read as columns of the staged tiles (ds_read_b64_tr_b16, same reduction-index permutation as above).
+template <typename T, int D>
+__global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                                    float* __restrict__ dw_ws, float* __restrict__ colsum_ws,
+                                                                    int64_t m_rows) {
+  using G = RlGeom<D>;
+  using V = Vec16<T>;
+  constexpr int PB = G::PITCH * 2, PBX = DwGeom<D>::PBX;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* stage_g = smem;
+  char* stage_x = smem + DwGeom<D>::tile_bytes;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int64_t n_tiles = (m_rows + kDwTile - 1) / kDwTile;
+  const int ech = lane % G::CH, erow0 = lane / G::CH;
+  constexpr int EROWS = 64 / G::CH;
+  constexpr int EIT = kDwRowsPerWave / EROWS;
+  constexpr int NBW = DwGeom<D>::NBW;
+  rl_f32x4_t acc_w[NBW][G::NB];
+#pragma unroll
+  for (int u = 0; u < NBW; ++u)
+#pragma unroll
+    for (int kb = 0; kb < G::NB; ++kb) acc_w[u][kb] = rl_f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int n0 = wave * 16 * NBW;
+  const bool dw_wave = n0 < D;
+  float cs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+
+  uint4 cg[EIT], cx[EIT];
+  auto load_tile = [&](int64_t tile, uint4 (&gg)[EIT], uint4 (&xx)[EIT]) {
+    const int64_t base = tile * kDwTile + wave * kDwRowsPerWave;
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      int64_t row = base + it * EROWS + erow0;
+      if (row >= m_rows) row = m_rows - 1;
+      gg[it] = *reinterpret_cast<const uint4*>(g + row * D + ech * 8);
+      xx[it] = *reinterpret_cast<const uint4*>(x + row * D + ech * 8);
+    }
+  };
+  int64_t tile = blockIdx.x;
+  if (tile < n_tiles) load_tile(tile, cg, cx);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    uint4 ng[EIT], nx[EIT];
+    const int64_t tn = tile + gridDim.x;
+    if (tn < n_tiles) load_tile(tn, ng, nx);
+    const int64_t base = tile * kDwTile + wave * kDwRowsPerWave;
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      const int rl = wave * kDwRowsPerWave + it * EROWS + erow0;
+      const bool valid = base + it * EROWS + erow0 < m_rows;
+      uint4 gv = cg[it];
+      if (!valid) gv = make_uint4(0u, 0u, 0u, 0u);      // rows past the end contribute nothing
+      *reinterpret_cast<uint4*>(stage_g + (size_t)rl * PB + ech * 16) = gv;
+      *reinterpret_cast<uint4*>(stage_x + (size_t)rl * PBX + ech * 16) = cx[it];
+      if (colsum_ws) {
+        float v[8];
+        V::unpack(gv, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] += v[j];
+      }
+    }
+    rl_lds_barrier();
+    if (dw_wave) {
+      const int rsel = (q & 1) * 4 + (q >> 1) * 16 + (r16 >> 2);
+#pragma unroll
+      for (int ms = 0; ms < kDwTile / 32; ++ms) {
+        const int row = ms * 32 + rsel;
+        const char* ga = stage_g + (size_t)row * PB + (r16 & 3) * 8 + n0 * 2;
+        uint4 fa[NBW];
+#pragma unroll
+        for (int u = 0; u < NBW; ++u) {
+          const rl_s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(ga + u * 32));
+          const rl_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(ga + u * 32 + 8 * PB));
+          const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+          fa[u] = make_uint4(a.x, a.y, b.x, b.y);
+        }
+        const char* xa = stage_x + (size_t)row * PBX + (r16 & 3) * 8;
+#pragma unroll
+        for (int kb = 0; kb < G::NB; ++kb) {
+          const rl_s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(xa + kb * 32));
+          const rl_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(xa + kb * 32 + 8 * PBX));
+          const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+          const uint4 fk = make_uint4(a.x, a.y, b.x, b.y);
+#pragma unroll
+          for (int u = 0; u < NBW; ++u) acc_w[u][kb] = rl_mfma<T>(fa[u], fk, acc_w[u][kb]);
+        }
+      }
+    }
+    rl_lds_barrier();
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) { cg[it] = ng[it]; cx[it] = nx[it]; }
+  }
+  if (dw_wave) {
+#pragma unroll
+    for (int u = 0; u < NBW; ++u)
+#pragma unroll
+      for (int kb = 0; kb < G::NB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dw_ws[((size_t)blockIdx.x * D + n0 + u * 16 + q * 4 + r) * D + kb * 16 + r16] = acc_w[u][kb][r];
+  }
+  if (colsum_ws) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(stage_g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = cs[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += kDwThreads) {
+      const int ch = c / 8, j = c - ch * 8;
+      float a = 0.f;
+      for (int t = ch; t < kDwThreads; t += G::CH) a += red[t * 8 + j];
+      colsum_ws[((size_t)blockIdx.x * 2 + 0) * D + c] = a;
+      colsum_ws[((size_t)blockIdx.x * 2 + 1) * D + c] = 0.f;
+    }
+  }
+}
+
+template <typename T, int D>
+int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum_ws, int64_t m, int grid, hipStream_t st) {
+  const size_t lds = DwGeom<D>::tile_bytes + DwGeom<D>::xtile_bytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weight_grad_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("weight_grad: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((weight_grad_kernel<T, D>), dim3(grid), dim3(kDwThreads), lds, st, (const T*)g, (const T*)x, dw_ws, colsum_ws, m);
+  return check_launch("weight_grad");
+}
+
 template <typename T, int D>
 int launch_rowblock(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws, const float* shift,
                     int64_t m, int grid, hipStream_t st) {
@@ -718,4 +854,18 @@ extern "C" int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, c
   if (dtype == PYGHO_BF16) return d == 128 ? PYGHO_BLW(bf16, 128) : PYGHO_BLW(bf16, 64);
   return d == 128 ? PYGHO_BLW(f16, 128) : PYGHO_BLW(f16, 64);
 #undef PYGHO_BLW
+}
+
+extern "C" int pygho_weight_grad(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t m, int64_t d, int dtype,
+                                 void* stream) {
+  if (m <= 0 || d <= 0) { set_error("weight_grad: empty input"); return PYGHO_ERR_INVALID; }
+  if (!dw_ws || !g || !x) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("weight_grad: bf16 / f16 only"); return PYGHO_ERR_UNSUPPORTED; }
+  if (d != 64 && d != 128) { set_error("weight_grad: width %lld not supported (64, 128)", (long long)d); return PYGHO_ERR_UNSUPPORTED; }
+  if ((((uintptr_t)g | (uintptr_t)x) % 16) != 0) { set_error("weight_grad: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
+  const int grid = pygho_bn_bwd_linear_dw_blocks(m);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PYGHO_BF16)
+    return d == 128 ? launch_weight_grad<bf16, 128>(g, x, dw_ws, colsum_ws, m, grid, st) : launch_weight_grad<bf16, 64>(g, x, dw_ws, colsum_ws, m, grid, st);
+  return d == 128 ? launch_weight_grad<f16, 128>(g, x, dw_ws, colsum_ws, m, grid, st) : launch_weight_grad<f16, 64>(g, x, dw_ws, colsum_ws, m, grid, st);
 }

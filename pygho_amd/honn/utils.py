@@ -30,8 +30,16 @@ class _SplitKLinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         g = g.contiguous()
         gx = g @ w if ctx.needs_input_grad[0] else None
-        gw = _ops.weight_grad_splitk(g, x, w.dtype) if ctx.needs_input_grad[1] else None
-        gb = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        gw = gb = None
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            if want_b:
+                gw, gb = _ops.weight_grad_splitk(g, x, w.dtype, want_colsum=True)
+                gb = gb.to(g.dtype)
+            else:
+                gw = _ops.weight_grad_splitk(g, x, w.dtype)
+        elif want_b:
+            gb = g.sum(0)
         return gx, gw, gb
 
 

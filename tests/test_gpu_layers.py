@@ -458,3 +458,21 @@ def test_sunconv_restructured_equals_reference_wiring(dev, mode):
     torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-4, atol=2e-4)
     for k in res[1][2]:
         torch.testing.assert_close(res[0][2][k], res[1][2][k], rtol=5e-4, atol=5e-4, msg=k)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d", [128, 64])
+def test_weight_grad_kernel(dev, dtype, d):
+    """stand-alone weight gradient g^T x (+ column sums of g) on the transpose-read MFMA kernel against an f64 product;
+    asymmetric operands (a transposed result would show), ragged row counts."""
+    from pygho_amd import _ops
+    torch.manual_seed(9)
+    for m in (8192, 100_003, 400_000):
+        g = torch.randn(m, d, device=dev).to(dtype)
+        x = (torch.randn(m, d, device=dev) * 0.5 + 0.1).to(dtype)
+        gw, cs = _ops.weight_grad_splitk(g, x, torch.float32, want_colsum=True)
+        ref = g.double().t() @ x.double()
+        s = float(ref.abs().max())
+        torch.testing.assert_close(gw.double() / s, ref / s, rtol=0, atol=2e-6)
+        torch.testing.assert_close(cs.double(), g.double().sum(0), rtol=1e-5, atol=1e-2)
+        assert torch.equal(_ops.weight_grad_splitk(g, x, torch.float32), gw)
