@@ -366,6 +366,7 @@ class MessagePlan:
         self.c_fwd, self.d_fwd = self.fwd.take(c32), self.fwd.take(d32)   # grouped-by-a order
         self._by_c = None
         self._by_d = None
+        self._lookup = None
 
     def by_c(self):
         """(plan, a-in-grouped-order, d-in-grouped-order) for the gradient wrt the first operand."""
@@ -379,6 +380,16 @@ class MessagePlan:
             p = plan_from_keys(self._d64, self.n_rhs)
             self._by_d = (p, p.take(self.a32), p.take(self.c32))
         return self._by_d
+
+    def lookup(self, row_of: Tensor):
+        """for a second operand that equals table[row_of]: the per-message table rows in forward and in by-c order
+        (cached per index tensor object)."""
+        memo = self._lookup
+        if memo is None or memo[0] is not row_of:
+            r32 = narrow_i32(row_of)
+            memo = (row_of, (gather_i32(r32, self.d_fwd), gather_i32(r32, self.by_c()[2])))
+            self._lookup = memo
+        return memo[1]
 
 
 def message_plan(acd: Tensor, n_out: int, n_lhs: int, n_rhs: int) -> MessagePlan:
@@ -1246,6 +1257,7 @@ def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype, want_colsum
 
 USE_FUSED_DW = True      # weight gradient inside the backward kernel (gpre never reaches HBM)
 USE_TABLE_PRODUCT = True
+USE_ADJ_TABLE = True     # adjacency values that are an embedding lookup are read through the table inside the fused block
 USE_ACT_ON_LOAD = True   # f32 blocks: BatchNorm + activation applied inside the aggregation kernel's loads
 USE_BN_BWD_LINEAR = True
 USE_ROWBLOCK_LINEAR = True      # module switch for A/B measurements (the library GEMM + separate passes otherwise)
@@ -1330,7 +1342,7 @@ class _TupleBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, eps, act, rhs, plan, aggr, residual,
-                fold_momentum=None):
+                fold_momentum=None, rhs_lookup=None):
         require_device(x, w, rhs)
         x = x.contiguous()
         # master weights (usually f32) are cast to the activation dtype here, outside the autograd graph; their
@@ -1353,17 +1365,23 @@ class _TupleBlock(torch.autograd.Function):
                    and (x.shape[1] * 4) % 16 == 0 and rhs.dtype == x.dtype and rhs.shape[1] == x.shape[1])
         h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum, partial,
                                           apply=not on_load)
-        affine = None
+        affine = look = None
+        rhs_read, d_idx = rhs, (plan.d_fwd if plan is not None and rhs is not None else None)
+        if plan is not None and rhs is not None and rhs_lookup is not None:
+            # rhs == table[row_of] for a small table: index the table per message (its rows stay in L1) instead of streaming
+            # the (n_edges, d) gathered array (0.339 -> 0.310 ms forward, 0.259 -> 0.244 ms backward at B = 8192).  The
+            # gradient still goes to `rhs` per edge, and from there through the lookup's own backward.
+            look = (rhs_lookup[0].detach(),) + plan.lookup(rhs_lookup[1])
+            rhs_read, d_idx = look[0], look[1]
         if plan is None:
             out = h
         elif on_load:
             affine, h = h, None
-            out = seg_gmr(plan.n_out, pre, rhs, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, aggr, addend=x if residual else None,
+            out = seg_gmr(plan.n_out, pre, rhs_read, plan.fwd.seg_ptr, plan.c_fwd, d_idx, aggr, addend=x if residual else None,
                           act=(affine[0], affine[1], act, 1))
         else:
-            out = seg_gmr(plan.n_out, h, rhs, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd if rhs is not None else None, aggr,
-                          addend=x if residual else None)
-        ctx.affine = affine
+            out = seg_gmr(plan.n_out, h, rhs_read, plan.fwd.seg_ptr, plan.c_fwd, d_idx, aggr, addend=x if residual else None)
+        ctx.affine, ctx.look = affine, look
         ctx.save_for_backward(x, wc, pre, h if plan is not None else None, rhs, *saved)
         ctx.meta = (training, act, None if b is None else b.dtype, gamma is not None, beta is not None, plan, aggr, residual, w.dtype,
                     skinny)
@@ -1380,7 +1398,10 @@ class _TupleBlock(torch.autograd.Function):
         if plan is not None:
             scale = plan.fwd.inv_count if aggr == "mean" else None
             p, a_g, d_g = plan.by_c()
-            gh = seg_gmr(plan.n_lhs, g, rhs, p.seg_ptr, a_g, d_g if rhs is not None else None, "sum", scale)
+            rhs_read = rhs
+            if ctx.look is not None:
+                rhs_read, d_g = ctx.look[0], ctx.look[2]
+            gh = seg_gmr(plan.n_lhs, g, rhs_read, p.seg_ptr, a_g, d_g if rhs is not None else None, "sum", scale)
             if rhs is not None and ctx.needs_input_grad[10]:
                 p, a_g, c_g = plan.by_d()
                 if ctx.affine is not None:
@@ -1411,11 +1432,12 @@ class _TupleBlock(torch.autograd.Function):
         if sdx is not None:
             gb = sdx.to(b_dtype)
         return (gx, gw, gb, (s2 if has_gamma else None), (s1 if has_beta else None), None, None, None, None, None,
-                g_rhs, None, None, None, None)
+                g_rhs, None, None, None, None, None)
 
 
 def tuple_block(x: Tensor, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", act: str, rhs: Optional[Tensor] = None,
-                plan: Optional[MessagePlan] = None, aggr: str = "sum", residual: bool = False) -> Tensor:
+                plan: Optional[MessagePlan] = None, aggr: str = "sum", residual: bool = False,
+                rhs_lookup: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
     """fused Linear -> BatchNorm1d -> act (-> aggregation over `plan` with `rhs` (-> + x)); parameters are read
     from the stock modules (f32 master weights are cast to the activation dtype like autocast would)."""
     training = bn.training or bn.running_mean is None
@@ -1423,6 +1445,6 @@ def tuple_block(x: Tensor, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", a
         assert plan is not None and plan.n_out == x.shape[0] and lin.out_features == x.shape[1]
     fold = _fold_momentum(bn)
     out, mean, var = _TupleBlock.apply(x, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                                       bn.eps, act, rhs, plan, aggr, residual, fold)
+                                       bn.eps, act, rhs, plan, aggr, residual, fold, rhs_lookup)
     _update_running(bn, mean, var, x.shape[0], folded=fold is not None)
     return out

@@ -89,8 +89,13 @@ def _residual_update(layer, A: Rep, X: Rep, datadict: dict) -> Rep:
         return X.add(layer.forward(A, X, datadict), True)
     lin, bn, act = block
     plan = _ops.message_plan(acd, X.nnz, X.nnz, A.nnz)
+    # adjacency values that are an embedding lookup (a handful of distinct rows) are READ through the table
+    lookup = getattr(A.values, "_pygho_lookup", None) if _ops.USE_ADJ_TABLE else None
+    if lookup is not None and not (lookup[0].dim() == 2 and lookup[0].dtype == X.values.dtype and lookup[1].numel() == A.nnz
+                                   and lookup[0].shape[1] == X.values.shape[1]):
+        lookup = None
     with torch.autocast("cuda", enabled=False):
-        vals = _ops.tuple_block(X.values, lin, bn, act, rhs=A.values, plan=plan, aggr=op.aggr, residual=True)
+        vals = _ops.tuple_block(X.values, lin, bn, act, rhs=A.values, plan=plan, aggr=op.aggr, residual=True, rhs_lookup=lookup)
     return X.tuplewiseapply(lambda _: vals)
 
 

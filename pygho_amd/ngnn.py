@@ -35,7 +35,12 @@ class IndexEmbedding(nn.Embedding):
         if not hasattr(idx, "_pygho_flat") or idx._pygho_flat[0] != idx._version:
             idx._pygho_flat = (idx._version, flat.contiguous())      # persistent object: the gather plan is cached on it
         out = _ops.gather_rows(table, idx._pygho_flat[1])
-        return out.reshape(tuple(idx.shape) + (self.embedding_dim,))
+        out = out.reshape(tuple(idx.shape) + (self.embedding_dim,))
+        if idx.dim() == 1:
+            # provenance for consumers that can index the (tiny, cache-resident) table themselves instead of streaming the
+            # gathered rows: the fused layer block reads A's values this way (honn/Conv._residual_update)
+            out._pygho_lookup = (table, idx._pygho_flat[1])
+        return out
 
 
 class InputEncoderSp(nn.Module):

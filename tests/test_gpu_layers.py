@@ -391,7 +391,7 @@ def test_model_fused_paths_match_plain_composition(dev):
     hb = synth.make_batch(512, "zinc", seed=21)
     dd = synth.to_datadict(hb, dev)
     y = dd["y"].unsqueeze(-1)
-    flags = ("USE_TABLE_PRODUCT", "USE_FUSED_DW", "USE_BN_BWD_LINEAR", "USE_ROWBLOCK_LINEAR")
+    flags = ("USE_ADJ_TABLE", "USE_TABLE_PRODUCT", "USE_FUSED_DW", "USE_BN_BWD_LINEAR", "USE_ROWBLOCK_LINEAR")
     saved = {f: getattr(_ops, f) for f in flags}
     res = {}
     try:
