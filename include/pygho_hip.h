@@ -371,18 +371,20 @@ int pygho_bn_bwd_linear(void* gx, void* gpre, const void* pre, const void* gh, c
 /* pygho_bn_bwd_linear with the weight gradient folded in and gpre kept on chip:
  *   gx = gpre . W (+ addend),   dw_ws[blk] = sum over the rows of block blk of gpre^T . x     (x = the Linear's input)
  * dw_ws: pygho_bn_bwd_linear_dw_blocks(m) x d x d floats, to be summed over blocks ([n][k] = weight layout of
- * torch.nn.Linear); colsum_ws as above with the same block count.  HBM traffic per row: pre, gh, x, addend in, gx out. */
+ * torch.nn.Linear); colsum_ws as above with the same block count.  HBM traffic per row: pre, gh, x, addend in, gx out.
+ * ws_stride != 0: block b of BOTH workspaces starts at (pointer + b * ws_stride) floats -- one interleaved buffer
+ * [blocks][d*d + 2*d] (dw_ws = buffer, colsum_ws = buffer + d*d) folds with a single pygho_sum_blocks. */
 int pygho_bn_bwd_linear_dw_blocks(int64_t m);
 int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, const void* gh, const void* x, const void* wl,
                            const void* addend, float* colsum_ws, const float* mean, const float* invstd, const float* w,
                            const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m, int64_t d, int act,
-                           int training, int dtype, void* stream);
+                           int training, int dtype, int64_t ws_stride, void* stream);
 /* Stand-alone weight gradient of a tall square Linear (bf16 / f16, d = 64 or 128; autograd of honn/utils.py:126-131 outside a
  * fused block):  dw_ws[blk][n][k] = sum over the rows m of block blk of g[m][n] * x[m][k]   (pygho_bn_bwd_linear_dw_blocks(m)
  * blocks, to be folded with pygho_sum_blocks; [n][k] = torch.nn.Linear weight layout), colsum_ws (nullable) as in
  * pygho_bn_bwd_linear: the column sums of g = the bias gradient. */
 int pygho_weight_grad(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t m, int64_t d, int dtype,
-                      void* stream);
+                      int64_t ws_stride, void* stream);
 /* out[j] = sum over b < n_blocks of in[b * n + j]: folds the per-workgroup partial results of the kernels above (weight
  * gradient slabs, column sums) deterministically. */
 int pygho_sum_blocks(float* out, const float* in, int64_t n_blocks, int64_t n, void* stream);

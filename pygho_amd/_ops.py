@@ -9,6 +9,7 @@ from __future__ import annotations
 from typing import Optional, Tuple
 
 import torch
+from ctypes import c_void_p
 from torch import Tensor
 
 from . import _native as N
@@ -1232,12 +1233,14 @@ def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype, want_colsum
         g, x = g.contiguous(), x.contiguous()
         dev = g.device
         nblk = int(lib().pygho_bn_bwd_linear_dw_blocks(m))
-        ws = torch.empty((nblk, n, k), dtype=torch.float32, device=dev)
-        cws = torch.empty((nblk, 2, n), dtype=torch.float32, device=dev) if want_colsum else None
-        check(lib().pygho_weight_grad(ptr(ws), ptr(cws), ptr(g), ptr(x), m, n, dtype_code(g), stream_ptr(dev)), "weight_grad")
-        gw = sum_blocks(ws).to(out_dtype)
+        width = n * k + (2 * n if want_colsum else 0)              # one interleaved workspace, one folding launch
+        ws = torch.empty((nblk, width), dtype=torch.float32, device=dev)
+        cws_ptr = c_void_p(ws.data_ptr() + 4 * n * k) if want_colsum else None
+        check(lib().pygho_weight_grad(ptr(ws), cws_ptr, ptr(g), ptr(x), m, n, dtype_code(g), width, stream_ptr(dev)), "weight_grad")
+        tot = sum_blocks(ws)
+        gw = tot[:n * k].reshape(n, k).to(out_dtype)
         if want_colsum:
-            cs = sum_blocks(cws)[0]
+            cs = tot[n * k:n * k + n]
     else:
         slabs = min(256, m // 2048)
         if slabs < 4 or m < (1 << 19):
@@ -1317,18 +1320,20 @@ def bn_bwd_linear(pre: Tensor, gh: Tensor, saved, training: bool, act: str, w: T
     if addend is not None:
         addend = addend.contiguous()
     nblk = int(lib().pygho_bn_bwd_linear_dw_blocks(m) if x is not None else lib().pygho_rowblock_linear_blocks(m))
-    cws = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev) if want_colsum else None
     if x is not None:
-        second = torch.empty((nblk, c, c), dtype=torch.float32, device=dev)
-        check(lib().pygho_bn_bwd_linear_dw(ptr(gx), ptr(second), ptr(pre), ptr(gh), ptr(x), ptr(wl), ptr(addend), ptr(cws), ptr(mean),
+        width = c * c + (2 * c if want_colsum else 0)              # dW slabs and column sums interleaved: one folding launch
+        ws = torch.empty((nblk, width), dtype=torch.float32, device=dev)
+        cws_ptr = c_void_p(ws.data_ptr() + 4 * c * c) if want_colsum else None
+        check(lib().pygho_bn_bwd_linear_dw(ptr(gx), ptr(ws), ptr(pre), ptr(gh), ptr(x), ptr(wl), ptr(addend), cws_ptr, ptr(mean),
                                            ptr(invstd), ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act],
-                                           1 if training else 0, dt, st), "bn_bwd_linear_dw")
-        second = sum_blocks(second)
-    else:
-        second = torch.empty_like(pre)
-        check(lib().pygho_bn_bwd_linear(ptr(gx), ptr(second), ptr(pre), ptr(gh), ptr(wl), ptr(addend), ptr(cws), ptr(mean), ptr(invstd),
-                                        ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act], 1 if training else 0, dt, st),
-              "bn_bwd_linear")
+                                           1 if training else 0, dt, width, st), "bn_bwd_linear_dw")
+        tot = sum_blocks(ws)
+        return gx, tot[:c * c].reshape(c, c), s1, s2, (tot[c * c:c * c + c] if want_colsum else None)
+    cws = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev) if want_colsum else None
+    second = torch.empty_like(pre)
+    check(lib().pygho_bn_bwd_linear(ptr(gx), ptr(second), ptr(pre), ptr(gh), ptr(wl), ptr(addend), ptr(cws), ptr(mean), ptr(invstd),
+                                    ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act], 1 if training else 0, dt, st),
+          "bn_bwd_linear")
     sdx = sum_blocks(cws)[0] if cws is not None else None
     return gx, second, s1, s2, sdx
 

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
                                                                          const T* __restrict__ gh, const T* __restrict__ x,
                                                                          const T* __restrict__ wl, const T* __restrict__ addend,
                                                                          float* __restrict__ colsum_ws, float* __restrict__ dw_ws,
-                                                                         BnBwdArgs bn, int64_t m_rows) {
+                                                                         BnBwdArgs bn, int64_t m_rows, int64_t ws_stride) {
   using G = RlGeom<D>;
   using V = Vec16<T>;
   constexpr int PB = G::PITCH * 2;                       // LDS row pitch in bytes (W^T, gpre and output tiles)
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
       for (int kb = 0; kb < G::NB; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          dw_ws[((size_t)blockIdx.x * D + n0 + u * 16 + q * 4 + r) * D + kb * 16 + r16] = acc_w[u][kb][r];
+          dw_ws[(size_t)blockIdx.x * (ws_stride ? ws_stride : (int64_t)D * D) + (size_t)(n0 + u * 16 + q * 4 + r) * D + kb * 16 + r16] = acc_w[u][kb][r];
   }
   if (colsum_ws) {
     __syncthreads();
@@ -608,15 +608,15 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
       const int ch = c / 8, j = c - ch * 8;
       float a = 0.f;
       for (int t = ch; t < kDwThreads; t += G::CH) a += red[t * 8 + j];
-      colsum_ws[((size_t)blockIdx.x * 2 + 0) * D + c] = a;
-      colsum_ws[((size_t)blockIdx.x * 2 + 1) * D + c] = 0.f;
+      colsum_ws[(size_t)blockIdx.x * (ws_stride ? ws_stride : 2 * (int64_t)D) + c] = a;
+      colsum_ws[(size_t)blockIdx.x * (ws_stride ? ws_stride : 2 * (int64_t)D) + D + c] = 0.f;
     }
   }
 }
 
 template <typename T, int D, int ACT>
 int launch_bn_bwd_linear_dw(void* gx, const void* pre, const void* gh, const void* x, const void* wl, const void* addend,
-                            float* colsum_ws, float* dw_ws, const BnBwdArgs& bn, int64_t m, int grid, hipStream_t st) {
+                            float* colsum_ws, float* dw_ws, const BnBwdArgs& bn, int64_t m, int grid, int64_t ws_stride, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_linear_dw_kernel<T, D, ACT>),
@@ -625,7 +625,7 @@ int launch_bn_bwd_linear_dw(void* gx, const void* pre, const void* gh, const voi
     attr_set = true;
   }
   hipLaunchKernelGGL((bn_bwd_linear_dw_kernel<T, D, ACT>), dim3(grid), dim3(kDwThreads), DwGeom<D>::lds_bytes, st, (T*)gx, (const T*)pre,
-                     (const T*)gh, (const T*)x, (const T*)wl, (const T*)addend, colsum_ws, dw_ws, bn, m);
+                     (const T*)gh, (const T*)x, (const T*)wl, (const T*)addend, colsum_ws, dw_ws, bn, m, ws_stride);
   return check_launch("bn_bwd_linear_dw");
 }
 
@@ -638,7 +638,7 @@ int launch_bn_bwd_linear_dw(void* gx, const void* pre, const void* gh, const voi
 template <typename T, int D>
 __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __restrict__ g, const T* __restrict__ x,
                                                                     float* __restrict__ dw_ws, float* __restrict__ colsum_ws,
-                                                                    int64_t m_rows) {
+                                                                    int64_t m_rows, int64_t ws_stride) {
   using G = RlGeom<D>;
   using V = Vec16<T>;
   constexpr int PB = G::PITCH * 2, PBX = DwGeom<D>::PBX;
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __r
       for (int kb = 0; kb < G::NB; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          dw_ws[((size_t)blockIdx.x * D + n0 + u * 16 + q * 4 + r) * D + kb * 16 + r16] = acc_w[u][kb][r];
+          dw_ws[(size_t)blockIdx.x * (ws_stride ? ws_stride : (int64_t)D * D) + (size_t)(n0 + u * 16 + q * 4 + r) * D + kb * 16 + r16] = acc_w[u][kb][r];
   }
   if (colsum_ws) {
     __syncthreads();
@@ -746,14 +746,14 @@ __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __r
       const int ch = c / 8, j = c - ch * 8;
       float a = 0.f;
       for (int t = ch; t < kDwThreads; t += G::CH) a += red[t * 8 + j];
-      colsum_ws[((size_t)blockIdx.x * 2 + 0) * D + c] = a;
-      colsum_ws[((size_t)blockIdx.x * 2 + 1) * D + c] = 0.f;
+      colsum_ws[(size_t)blockIdx.x * (ws_stride ? ws_stride : 2 * (int64_t)D) + c] = a;
+      colsum_ws[(size_t)blockIdx.x * (ws_stride ? ws_stride : 2 * (int64_t)D) + D + c] = 0.f;
     }
   }
 }
 
 template <typename T, int D>
-int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum_ws, int64_t m, int grid, hipStream_t st) {
+int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum_ws, int64_t m, int grid, int64_t ws_stride, hipStream_t st) {
   const size_t lds = DwGeom<D>::tile_bytes + DwGeom<D>::xtile_bytes;
   static bool attr_set = false;
   if (!attr_set) {
@@ -761,7 +761,7 @@ int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum
     if (e != hipSuccess) { set_error("weight_grad: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((weight_grad_kernel<T, D>), dim3(grid), dim3(kDwThreads), lds, st, (const T*)g, (const T*)x, dw_ws, colsum_ws, m);
+  hipLaunchKernelGGL((weight_grad_kernel<T, D>), dim3(grid), dim3(kDwThreads), lds, st, (const T*)g, (const T*)x, dw_ws, colsum_ws, m, ws_stride);
   return check_launch("weight_grad");
 }
 
@@ -837,7 +837,7 @@ extern "C" int pygho_bn_bwd_linear_dw_blocks(int64_t m) {
 extern "C" int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, const void* gh, const void* x, const void* wl,
                                       const void* addend, float* colsum_ws, const float* mean, const float* invstd, const float* w,
                                       const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m, int64_t d, int act,
-                                      int training, int dtype, void* stream) {
+                                      int training, int dtype, int64_t ws_stride, void* stream) {
   if (m <= 0 || d <= 0) { set_error("bn_bwd_linear_dw: empty input"); return PYGHO_ERR_INVALID; }
   if (!gx || !dw_ws || !pre || !gh || !x || !wl || !mean || !invstd || (training && (!sum_dz || !sum_dz_xhat))) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("bn_bwd_linear_dw: bf16 / f16 only"); return PYGHO_ERR_UNSUPPORTED; }
@@ -848,16 +848,16 @@ extern "C" int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, c
   hipStream_t st = (hipStream_t)stream;
   const BnBwdArgs bn{mean, invstd, w, b, sum_dz, sum_dz_xhat, act, training};
 #define PYGHO_BLW(T, DD)                                                                                                        \
-  (act == 0 ? launch_bn_bwd_linear_dw<T, DD, 0>(gx, pre, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, st)                   \
-   : act == 1 ? launch_bn_bwd_linear_dw<T, DD, 1>(gx, pre, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, st)                 \
-              : launch_bn_bwd_linear_dw<T, DD, 2>(gx, pre, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, st))
+  (act == 0 ? launch_bn_bwd_linear_dw<T, DD, 0>(gx, pre, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st)                   \
+   : act == 1 ? launch_bn_bwd_linear_dw<T, DD, 1>(gx, pre, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st)                 \
+              : launch_bn_bwd_linear_dw<T, DD, 2>(gx, pre, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st))
   if (dtype == PYGHO_BF16) return d == 128 ? PYGHO_BLW(bf16, 128) : PYGHO_BLW(bf16, 64);
   return d == 128 ? PYGHO_BLW(f16, 128) : PYGHO_BLW(f16, 64);
 #undef PYGHO_BLW
 }
 
 extern "C" int pygho_weight_grad(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t m, int64_t d, int dtype,
-                                 void* stream) {
+                                 int64_t ws_stride, void* stream) {
   if (m <= 0 || d <= 0) { set_error("weight_grad: empty input"); return PYGHO_ERR_INVALID; }
   if (!dw_ws || !g || !x) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("weight_grad: bf16 / f16 only"); return PYGHO_ERR_UNSUPPORTED; }
@@ -866,6 +866,8 @@ extern "C" int pygho_weight_grad(float* dw_ws, float* colsum_ws, const void* g, 
   const int grid = pygho_bn_bwd_linear_dw_blocks(m);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == PYGHO_BF16)
-    return d == 128 ? launch_weight_grad<bf16, 128>(g, x, dw_ws, colsum_ws, m, grid, st) : launch_weight_grad<bf16, 64>(g, x, dw_ws, colsum_ws, m, grid, st);
-  return d == 128 ? launch_weight_grad<f16, 128>(g, x, dw_ws, colsum_ws, m, grid, st) : launch_weight_grad<f16, 64>(g, x, dw_ws, colsum_ws, m, grid, st);
+    return d == 128 ? launch_weight_grad<bf16, 128>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, st)
+                    : launch_weight_grad<bf16, 64>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, st);
+  return d == 128 ? launch_weight_grad<f16, 128>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, st)
+                  : launch_weight_grad<f16, 64>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, st);
 }

@@ -69,7 +69,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.pygho_rowblock_linear(one, one, one, None, None, None, None, 5, 128, 0, None) == 2 and b"bf16" in lib.pygho_last_error()
     assert lib.pygho_rowblock_linear(one, one, one, None, None, None, None, 5, 96, 1, None) == 2 and b"width" in lib.pygho_last_error()
     assert lib.pygho_bn_bwd_linear(one, one, one, one, one, None, None, one, one, None, None, None, None, 5, 128, 2, 1, 1, None) == 1
-    assert lib.pygho_bn_bwd_linear_dw(one, one, one, one, one, one, None, None, one, one, None, None, one, one, 5, 128, 7, 1, 1, None) == 1
+    assert lib.pygho_bn_bwd_linear_dw(one, one, one, one, one, one, None, None, one, one, None, None, one, one, 5, 128, 7, 1, 1, 0, None) == 1
     assert lib.pygho_bn_prepare(None, None, None, None, None, None, 5, 8, None, None, 1e-5, None, None, 0.1, None, 0, None) == 1
     assert lib.pygho_exclusive_scan_i64(None, None, -1, None, 0, None) == 1
     assert lib.pygho_product_hash(None, None, 1, 0, 0, None, 1, 0, 0, None, None, 0, None, None) == 1                          # no remaining coordinate
