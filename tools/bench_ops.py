@@ -49,6 +49,39 @@ def spspmm_case(kind, graphs, d, dtype, dev):
             "G_msg_edges_per_s": m / ms / 1e6}
 
 
+def pooling_case(graphs, d, dtype, dev):
+    """a5 / a11: tuple-wise segment reduce (subgraph pooling X.sum(dim 1): nnz rows -> N rows, sorted index) and a8 unpooling."""
+    hb = synth.replicate(synth.make_batch(min(graphs, 1024), "zinc", seed=1), max(1, graphs // 1024))
+    row = torch.from_numpy(hb.tupleid[0]).to(dev)
+    nt, n = hb.num_tuples, hb.num_nodes
+    X = torch.randn(nt, d, device=dev).to(dtype)
+    plan = _ops.cached_plan(row, n, "bench")
+    ms = timed(lambda: _ops.seg_reduce_rows(X, plan, "sum"))
+    nbytes = X.element_size() * d * (nt + n) + 4 * (n + 1)
+    x = torch.randn(n, d, device=dev).to(dtype)
+    r32 = _ops.narrow_i32(row)
+    ms_g = timed(lambda: _ops.row_gather(x, r32))
+    nb_g = X.element_size() * d * (nt + n) + 4 * nt
+    return [{"op": "segment reduce (subgraph pooling)", "graphs": hb.num_graphs, "rows_in": nt, "rows_out": n, "d": d,
+             "dtype": str(dtype).split(".")[-1], "ms": ms, "GBps": nbytes / ms / 1e6, "frac_hbm": nbytes / ms / 1e6 / PEAK},
+            {"op": "row gather (unpooling)", "graphs": hb.num_graphs, "rows_in": n, "rows_out": nt, "d": d,
+             "dtype": str(dtype).split(".")[-1], "ms": ms_g, "GBps": nb_g / ms_g / 1e6, "frac_hbm": nb_g / ms_g / 1e6 / PEAK}]
+
+
+def spmm_case(graphs, d, dtype, dev):
+    """a17: node-level message passing out[t] = sum_e val[e] * X[src[e]] over the batch adjacency (E edges, N nodes)."""
+    hb = synth.replicate(synth.make_batch(min(graphs, 1024), "zinc", seed=1), max(1, graphs // 1024))
+    ei = torch.from_numpy(hb.edge_index).to(dev)
+    n, e = hb.num_nodes, hb.num_edges
+    val = torch.randn(e, d, device=dev).to(dtype)
+    X = torch.randn(n, d, device=dev).to(dtype)
+    _ops.spmm_values(val, X, ei[1].contiguous(), ei[0].contiguous(), n, "sum")
+    ms = timed(lambda: _ops.spmm_values(val, X, ei[1].contiguous(), ei[0].contiguous(), n, "sum"))
+    nbytes = X.element_size() * d * (e + 2 * n) + 4 * e + 4 * (n + 1)
+    return {"op": "spmm (node-level message passing)", "graphs": hb.num_graphs, "edges": e, "nodes": n, "d": d,
+            "dtype": str(dtype).split(".")[-1], "ms": ms, "GBps": nbytes / ms / 1e6, "frac_hbm": nbytes / ms / 1e6 / PEAK}
+
+
 def planner_case(kind, graphs, dev):
     """device planner (Spspmm.py:57-222): tuple pattern x adjacency -> (tarind, bcd) -> acd on the tuple pattern.
     Wall time per batch (includes the two host syncs that size the outputs)."""
@@ -164,6 +197,8 @@ def main():
     out.append(mamamm_case(128, 37, 128, torch.bfloat16, dev))
     out.append(mamamm_case(128 if args.quick else 1024, 37, 128, torch.bfloat16, dev))
     out.append(mamamm_case(128 if args.quick else 1024, 37, 128, torch.float32, dev))
+    out.extend(pooling_case(1024 if args.quick else 8192, 128, torch.bfloat16, dev))
+    out.append(spmm_case(1024 if args.quick else 8192, 128, torch.bfloat16, dev))
     out.append(sunconv_case(128, 37, 128, torch.bfloat16, dev))
     out.append(sunconv_case(128 if args.quick else 1024, 37, 128, torch.bfloat16, dev))
     out.append(planner_case("zinc", 1024 if args.quick else 8192, dev))
