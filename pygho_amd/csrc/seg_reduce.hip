@@ -309,6 +309,35 @@ __global__ __launch_bounds__(kBlock) void row_gather_fast_kernel(
     T* __restrict__ out, const T* __restrict__ src, const int32_t* __restrict__ idx,
     const int32_t* __restrict__ valid, int64_t n_rows, int64_t d, int chunks) {
   constexpr int N = Vec16<T>::N;
+  // `chunks` 16-B pieces per row; a thread keeps its piece and walks rows, four at a time: the four index loads and then the
+  // four row loads are independent and in flight together (one index -> row -> store chain per iteration held this kernel
+  // at 3.4 TB/s of stores)
+  if (chunks <= kBlock && (kBlock % chunks) == 0) {
+    const int c = threadIdx.x % chunks, rl = threadIdx.x / chunks, rpb = kBlock / chunks;
+    const int64_t stride = (int64_t)gridDim.x * rpb;
+    for (int64_t r0 = (int64_t)blockIdx.x * rpb + rl; r0 < n_rows; r0 += 4 * stride) {
+      int64_t r[4];
+      int32_t id[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        r[u] = r0 + u * stride;
+        ok[u] = r[u] < n_rows;
+        id[u] = ok[u] ? idx[r[u]] : 0;
+        if (valid && ok[u]) ok[u] = valid[r[u]] != 0;
+      }
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = make_uint4(0, 0, 0, 0);
+        if (ok[u]) v[u] = *reinterpret_cast<const uint4*>(src + (int64_t)id[u] * d + (int64_t)c * N);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r[u] < n_rows) *reinterpret_cast<uint4*>(out + r[u] * d + (int64_t)c * N) = v[u];
+    }
+    return;
+  }
   const int64_t total = n_rows * chunks;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = t / chunks;
@@ -318,7 +347,6 @@ __global__ __launch_bounds__(kBlock) void row_gather_fast_kernel(
     *reinterpret_cast<uint4*>(out + r * d + (int64_t)c * N) = v;
   }
 }
-
 template <typename T>
 __global__ __launch_bounds__(kBlock) void row_gather_generic_kernel(
     T* __restrict__ out, const T* __restrict__ src, const int32_t* __restrict__ idx,
