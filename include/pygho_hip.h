@@ -382,9 +382,10 @@ int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, const void* 
 /* Stand-alone weight gradient of a tall square Linear (bf16 / f16, d = 64 or 128; autograd of honn/utils.py:126-131 outside a
  * fused block):  dw_ws[blk][n][k] = sum over the rows m of block blk of g[m][n] * x[m][k]   (pygho_bn_bwd_linear_dw_blocks(m)
  * blocks, to be folded with pygho_sum_blocks; [n][k] = torch.nn.Linear weight layout), colsum_ws (nullable) as in
- * pygho_bn_bwd_linear: the column sums of g = the bias gradient. */
-int pygho_weight_grad(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t m, int64_t d, int dtype,
-                      int64_t ws_stride, void* stream);
+ * pygho_bn_bwd_linear: the column sums of g = the bias gradient.  x_ld: row stride of x in elements (>= d): a Linear with
+ * in_features = j * d (SSWLConv's 3 d -> d map, Conv.py:62-103) takes j launches over the column blocks x + i * d. */
+int pygho_weight_grad(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t x_ld, int64_t m, int64_t d,
+                      int dtype, int64_t ws_stride, void* stream);
 /* out[j] = sum over b < n_blocks of in[b * n + j]: folds the per-workgroup partial results of the kernels above (weight
  * gradient slabs, column sums) deterministically. */
 int pygho_sum_blocks(float* out, const float* in, int64_t n_blocks, int64_t n, void* stream);

@@ -76,7 +76,7 @@ PROTOTYPES = {
     "pygho_bn_bwd_linear": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, P]),
     "pygho_bn_bwd_linear_dw_blocks": (I, [L]),
     "pygho_bn_bwd_linear_dw": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, L, P]),
-    "pygho_weight_grad": (I, [P, P, P, P, L, L, I, L, P]),
+    "pygho_weight_grad": (I, [P, P, P, P, L, L, L, I, L, P]),
     "pygho_sum_blocks": (I, [P, P, L, L, P]),
     "pygho_bn_act_bwd_sums": (I, [P, P, P, P, P, P, P, P, L, L, I, P, I, P]),
 }

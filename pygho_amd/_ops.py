@@ -1229,18 +1229,24 @@ def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype, want_colsum
     128 x 128 output, 2.9 ms at 1.8 M rows, but the batched call costs ~3.7 ms of host time, so it only pays for huge m)."""
     m, n, k = g.shape[0], g.shape[1], x.shape[1]
     cs = None
-    if (g.is_cuda and g.dtype in (torch.bfloat16, torch.float16) and x.dtype == g.dtype and n == k and n in (64, 128) and m >= 8192):
+    if (g.is_cuda and g.dtype in (torch.bfloat16, torch.float16) and x.dtype == g.dtype and n in (64, 128) and k % n == 0
+            and k // n <= 8 and m >= 8192):
         g, x = g.contiguous(), x.contiguous()
         dev = g.device
         nblk = int(lib().pygho_bn_bwd_linear_dw_blocks(m))
-        width = n * k + (2 * n if want_colsum else 0)              # one interleaved workspace, one folding launch
-        ws = torch.empty((nblk, width), dtype=torch.float32, device=dev)
-        cws_ptr = c_void_p(ws.data_ptr() + 4 * n * k) if want_colsum else None
-        check(lib().pygho_weight_grad(ptr(ws), cws_ptr, ptr(g), ptr(x), m, n, dtype_code(g), width, stream_ptr(dev)), "weight_grad")
-        tot = sum_blocks(ws)
-        gw = tot[:n * k].reshape(n, k).to(out_dtype)
-        if want_colsum:
-            cs = tot[n * k:n * k + n]
+        parts = []
+        for j in range(k // n):                                       # one launch per n-wide column block of x (in_features = j n)
+            cs_here = want_colsum and j == 0
+            width = n * n + (2 * n if cs_here else 0)                 # one interleaved workspace, one folding launch
+            ws = torch.empty((nblk, width), dtype=torch.float32, device=dev)
+            cws_ptr = c_void_p(ws.data_ptr() + 4 * n * n) if cs_here else None
+            check(lib().pygho_weight_grad(ptr(ws), cws_ptr, ptr(g), c_void_p(x.data_ptr() + j * n * x.element_size()), k, m, n,
+                                          dtype_code(g), width, stream_ptr(dev)), "weight_grad")
+            tot = sum_blocks(ws)
+            parts.append(tot[:n * n].reshape(n, n))
+            if cs_here:
+                cs = tot[n * n:n * n + n]
+        gw = (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)).to(out_dtype)
     else:
         slabs = min(256, m // 2048)
         if slabs < 4 or m < (1 << 19):

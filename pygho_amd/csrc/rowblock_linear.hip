@@ -638,7 +638,7 @@ int launch_bn_bwd_linear_dw(void* gx, const void* pre, const void* gh, const voi
 template <typename T, int D>
 __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __restrict__ g, const T* __restrict__ x,
                                                                     float* __restrict__ dw_ws, float* __restrict__ colsum_ws,
-                                                                    int64_t m_rows, int64_t ws_stride) {
+                                                                    int64_t m_rows, int64_t ws_stride, int64_t x_ld) {
   using G = RlGeom<D>;
   using V = Vec16<T>;
   constexpr int PB = G::PITCH * 2, PBX = DwGeom<D>::PBX;
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __r
       int64_t row = base + it * EROWS + erow0;
       if (row >= m_rows) row = m_rows - 1;
       gg[it] = *reinterpret_cast<const uint4*>(g + row * D + ech * 8);
-      xx[it] = *reinterpret_cast<const uint4*>(x + row * D + ech * 8);
+      xx[it] = *reinterpret_cast<const uint4*>(x + row * x_ld + ech * 8);
     }
   };
   int64_t tile = blockIdx.x;
@@ -753,7 +753,8 @@ __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __r
 }
 
 template <typename T, int D>
-int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum_ws, int64_t m, int grid, int64_t ws_stride, hipStream_t st) {
+int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum_ws, int64_t m, int grid, int64_t ws_stride, int64_t x_ld,
+                       hipStream_t st) {
   const size_t lds = DwGeom<D>::tile_bytes + DwGeom<D>::xtile_bytes;
   static bool attr_set = false;
   if (!attr_set) {
@@ -761,7 +762,7 @@ int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum
     if (e != hipSuccess) { set_error("weight_grad: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((weight_grad_kernel<T, D>), dim3(grid), dim3(kDwThreads), lds, st, (const T*)g, (const T*)x, dw_ws, colsum_ws, m, ws_stride);
+  hipLaunchKernelGGL((weight_grad_kernel<T, D>), dim3(grid), dim3(kDwThreads), lds, st, (const T*)g, (const T*)x, dw_ws, colsum_ws, m, ws_stride, x_ld);
   return check_launch("weight_grad");
 }
 
@@ -856,18 +857,18 @@ extern "C" int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, c
 #undef PYGHO_BLW
 }
 
-extern "C" int pygho_weight_grad(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t m, int64_t d, int dtype,
-                                 int64_t ws_stride, void* stream) {
+extern "C" int pygho_weight_grad(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t x_ld, int64_t m, int64_t d,
+                                 int dtype, int64_t ws_stride, void* stream) {
   if (m <= 0 || d <= 0) { set_error("weight_grad: empty input"); return PYGHO_ERR_INVALID; }
   if (!dw_ws || !g || !x) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("weight_grad: bf16 / f16 only"); return PYGHO_ERR_UNSUPPORTED; }
   if (d != 64 && d != 128) { set_error("weight_grad: width %lld not supported (64, 128)", (long long)d); return PYGHO_ERR_UNSUPPORTED; }
-  if ((((uintptr_t)g | (uintptr_t)x) % 16) != 0) { set_error("weight_grad: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
+  if ((((uintptr_t)g | (uintptr_t)x) % 16) != 0 || x_ld < d || (x_ld % 8) != 0) { set_error("weight_grad: operands must be 16-byte aligned, x_ld >= d a multiple of 8"); return PYGHO_ERR_INVALID; }
   const int grid = pygho_bn_bwd_linear_dw_blocks(m);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == PYGHO_BF16)
-    return d == 128 ? launch_weight_grad<bf16, 128>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, st)
-                    : launch_weight_grad<bf16, 64>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, st);
-  return d == 128 ? launch_weight_grad<f16, 128>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, st)
-                  : launch_weight_grad<f16, 64>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, st);
+    return d == 128 ? launch_weight_grad<bf16, 128>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st)
+                    : launch_weight_grad<bf16, 64>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st);
+  return d == 128 ? launch_weight_grad<f16, 128>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st)
+                  : launch_weight_grad<f16, 64>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st);
 }

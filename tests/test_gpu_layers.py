@@ -476,3 +476,9 @@ def test_weight_grad_kernel(dev, dtype, d):
         torch.testing.assert_close(gw.double() / s, ref / s, rtol=0, atol=2e-6)
         torch.testing.assert_close(cs.double(), g.double().sum(0), rtol=1e-5, atol=1e-2)
         assert torch.equal(_ops.weight_grad_splitk(g, x, torch.float32), gw)
+        # in_features = 3 d (SSWLConv's concatenated input): one launch per column block, strided x
+        x3 = (torch.randn(m, 3 * d, device=dev) * 0.5).to(dtype)
+        gw3 = _ops.weight_grad_splitk(g, x3, torch.float32)
+        ref3 = g.double().t() @ x3.double()
+        s3 = float(ref3.abs().max())
+        torch.testing.assert_close(gw3.double() / s3, ref3 / s3, rtol=0, atol=2e-6)
