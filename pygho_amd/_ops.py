@@ -8,11 +8,11 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
-import torch
 from ctypes import c_void_p
+
+import torch
 from torch import Tensor
 
-from . import _native as N
 from ._native import AGGR_CODE, DTYPE_CODE, check, dtype_code, lib, ptr, require_device, stream_ptr
 
 _I32 = torch.int32

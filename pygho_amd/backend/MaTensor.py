@@ -9,7 +9,7 @@ contractions and read as ``padvalue`` through ``.data``.  The reference construc
 ``amax`` (:203); both are deliberate deviations.  The fill is applied lazily: kernels take
 (raw data, mask) and skip masked entries themselves, so no extra pass over the data is spent on it.
 """
-from typing import Callable, Iterable, Optional, Union
+from typing import Callable, Iterable, Union
 
 import torch
 from torch import BoolTensor, LongTensor, Tensor
