@@ -663,24 +663,30 @@ __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __r
 #pragma unroll
   for (int j = 0; j < 8; ++j) cs[j] = 0.f;
 
-  uint4 cg[EIT], cx[EIT];
-  auto load_tile = [&](int64_t tile, uint4 (&gg)[EIT], uint4 (&xx)[EIT]) {
+  uint4 cg[EIT];
+  auto load_tile = [&](int64_t tile, uint4 (&gg)[EIT]) {
     const int64_t base = tile * kDwTile + wave * kDwRowsPerWave;
 #pragma unroll
     for (int it = 0; it < EIT; ++it) {
       int64_t row = base + it * EROWS + erow0;
       if (row >= m_rows) row = m_rows - 1;
       gg[it] = *reinterpret_cast<const uint4*>(g + row * D + ech * 8);
-      xx[it] = *reinterpret_cast<const uint4*>(x + row * x_ld + ech * 8);
     }
   };
   int64_t tile = blockIdx.x;
-  if (tile < n_tiles) load_tile(tile, cg, cx);
+  if (tile < n_tiles) load_tile(tile, cg);
   for (; tile < n_tiles; tile += gridDim.x) {
-    uint4 ng[EIT], nx[EIT];
-    const int64_t tn = tile + gridDim.x;
-    if (tn < n_tiles) load_tile(tn, ng, nx);
     const int64_t base = tile * kDwTile + wave * kDwRowsPerWave;
+    uint4 cx[EIT];                                       // x rows of THIS tile only pass through (HBM -> registers -> LDS)
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      int64_t row = base + it * EROWS + erow0;
+      if (row >= m_rows) row = m_rows - 1;
+      cx[it] = *reinterpret_cast<const uint4*>(x + row * x_ld + ech * 8);
+    }
+    uint4 ng[EIT];
+    const int64_t tn = tile + gridDim.x;
+    if (tn < n_tiles) load_tile(tn, ng);
 #pragma unroll
     for (int it = 0; it < EIT; ++it) {
       const int rl = wave * kDwRowsPerWave + it * EROWS + erow0;
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __r
     }
     rl_lds_barrier();
 #pragma unroll
-    for (int it = 0; it < EIT; ++it) { cg[it] = ng[it]; cx[it] = nx[it]; }
+    for (int it = 0; it < EIT; ++it) cg[it] = ng[it];
   }
   if (dw_wave) {
 #pragma unroll
