@@ -100,8 +100,10 @@ __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restric
   if (tile < n_tiles) load_tile(tile, fb);
   for (; tile < n_tiles; tile += gridDim.x) {
     uint4 nxt[2][G::KS];
-    const int64_t tn = tile + gridDim.x;
-    if (tn < n_tiles) load_tile(tn, nxt);                // prefetch: in flight during this tile's MFMAs and epilogue
+    // prefetch of the next tile (clamped to the last one: an unconditional load keeps the arrays in registers -- the
+    // compiler demoted conditionally initialised prefetch arrays to scratch)
+    const int64_t tn = min((int64_t)(tile + gridDim.x), n_tiles - 1);
+    load_tile(tn, nxt);                // prefetch: in flight during this tile's MFMAs and epilogue
 
     rl_f32x4_t acc[2][G::NB];
 #pragma unroll
@@ -250,8 +252,10 @@ __global__ __launch_bounds__(kBlock, 2) void bn_bwd_linear_kernel(T* __restrict_
   if (tile < n_tiles) load_tile(tile, cy, cg);
   for (; tile < n_tiles; tile += gridDim.x) {
     uint4 ny[EIT], ng[EIT];
-    const int64_t tn = tile + gridDim.x;
-    if (tn < n_tiles) load_tile(tn, ny, ng);
+    // prefetch of the next tile (clamped to the last one: an unconditional load keeps the arrays in registers -- the
+    // compiler demoted conditionally initialised prefetch arrays to scratch)
+    const int64_t tn = min((int64_t)(tile + gridDim.x), n_tiles - 1);
+    load_tile(tn, ny, ng);
     const int64_t base = tile * kRlTile + wave * kRlRowsPerWave;
     // ---- prologue: BatchNorm / activation backward on this wave's 32 rows -> HBM (gpre) and LDS stage ---------------
     float mu[8], is[8], ww[8], bb[8], k1[8], k2[8];
@@ -475,8 +479,10 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
       cx[it] = *reinterpret_cast<const uint4*>(x + row * D + ech * 8);
     }
     uint4 ny[EIT], ng[EIT];
-    const int64_t tn = tile + gridDim.x;
-    if (tn < n_tiles) load_tile(tn, ny, ng);
+    // prefetch of the next tile (clamped to the last one: an unconditional load keeps the arrays in registers -- the
+    // compiler demoted conditionally initialised prefetch arrays to scratch)
+    const int64_t tn = min((int64_t)(tile + gridDim.x), n_tiles - 1);
+    load_tile(tn, ny, ng);
     // ---- prologue: gpre of this wave's 16 rows and the matching x rows -> LDS (rows past the end as zeros) ---------------
     float mu[8], is[8], ww[8], bb[8], k1[8], k2[8];        // re-read per tile: live only here
 #pragma unroll
@@ -685,8 +691,10 @@ __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __r
       cx[it] = *reinterpret_cast<const uint4*>(x + row * x_ld + ech * 8);
     }
     uint4 ng[EIT];
-    const int64_t tn = tile + gridDim.x;
-    if (tn < n_tiles) load_tile(tn, ng);
+    // prefetch of the next tile (clamped to the last one: an unconditional load keeps the arrays in registers -- the
+    // compiler demoted conditionally initialised prefetch arrays to scratch)
+    const int64_t tn = min((int64_t)(tile + gridDim.x), n_tiles - 1);
+    load_tile(tn, ng);
 #pragma unroll
     for (int it = 0; it < EIT; ++it) {
       const int rl = wave * kDwRowsPerWave + it * EROWS + erow0;
