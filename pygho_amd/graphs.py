@@ -1,0 +1,37 @@
+"""
+HIP-graph capture of a whole training step.
+
+Below ~2000 ZINC-shape graphs per GPU the NGNN step is bound by host issue time (~270 launches, ~4 ms of Python / ATen /
+ctypes work against ~2 ms of GPU work at 1024 graphs).  Every kernel of the library is launched on torch's current stream
+through the C ABI and no entry point synchronises or allocates, so a step on static inputs can be captured once and replayed:
+4.6 -> 2.9 ms per step at 1024 graphs (MI355X).  Requirements (all met by `pygho_amd.ngnn.SpModel` on a fixed `datadict`):
+
+* the same tensors (batch, indices, targets) are reused across replays -- new data is copied INTO them;
+* the plans are built before capture (the warm-up steps below do that: plan construction reads sizes back to the host);
+* the optimizer is created with ``capturable=True``; gradients are reset with ``set_to_none=True`` inside the step;
+* no host read-back (``.item()``, ``print(loss)``) inside the step -- return tensors and read them after ``replay()``.
+"""
+from typing import Any, Callable
+
+import torch
+
+
+class GraphedStep:
+    """``GraphedStep(fn)`` warms ``fn`` up on a side stream, captures one call into a HIP graph and replays it."""
+
+    def __init__(self, fn: Callable[[], Any], warmup: int = 3):
+        assert torch.cuda.is_available(), "HIP graph capture needs the ROCm device"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.output = fn()
+
+    def replay(self) -> Any:
+        """run the captured step once more; returns the (static) output tensors of the captured call."""
+        self.graph.replay()
+        return self.output

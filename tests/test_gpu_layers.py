@@ -482,3 +482,44 @@ def test_weight_grad_kernel(dev, dtype, d):
         ref3 = g.double().t() @ x3.double()
         s3 = float(ref3.abs().max())
         torch.testing.assert_close(gw3.double() / s3, ref3 / s3, rtol=0, atol=2e-6)
+
+
+def test_hip_graph_replay_equals_eager_steps(dev):
+    """a whole NGNN training step (forward, backward, AdamW) captured into a HIP graph and replayed k times leaves the
+    parameters where k eager steps leave them: every kernel goes through the C ABI on the capture stream, nothing
+    synchronises or allocates behind torch's back."""
+    import copy
+    from pygho_amd import synth
+    from pygho_amd.graphs import GraphedStep
+    from pygho_amd.ngnn import SpModel
+    hb = synth.make_batch(256, "zinc", seed=31)
+    dd = synth.to_datadict(hb, dev)
+    y = dd["y"].unsqueeze(-1)
+    torch.manual_seed(0)
+    m_eager = SpModel(1, 2, 128, act_dtype=torch.bfloat16).to(dev)
+    m_graph = copy.deepcopy(m_eager)
+
+    def make_step(model, opt):
+        def step():
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                pred = model(dd)
+            loss = torch.nn.functional.l1_loss(y, pred.float())
+            loss.backward()
+            opt.step()
+            return loss.detach()
+        return step
+
+    k, warm = 4, 2
+    s_e = make_step(m_eager, torch.optim.AdamW(m_eager.parameters(), lr=1e-3, capturable=True))
+    for _ in range(warm + k):                 # capture records the step without executing it
+        s_e()
+    gs = GraphedStep(make_step(m_graph, torch.optim.AdamW(m_graph.parameters(), lr=1e-3, capturable=True)), warmup=warm)
+    for _ in range(k):                        # warm-up (2) + k replays = the eager count
+        loss = gs.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    for (n1, p1), (_, p2) in zip(m_eager.named_parameters(), m_graph.named_parameters()):
+        torch.testing.assert_close(p1, p2, rtol=1e-4, atol=1e-5, msg=n1)
+    for (n1, b1), (_, b2) in zip(m_eager.named_buffers(), m_graph.named_buffers()):
+        torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=n1)

@@ -82,6 +82,43 @@ def spmm_case(graphs, d, dtype, dev):
             "dtype": str(dtype).split(".")[-1], "ms": ms, "GBps": nbytes / ms / 1e6, "frac_hbm": nbytes / ms / 1e6 / PEAK}
 
 
+def graph_step_case(graphs, dev):
+    """launch-bound regime: the NGNN training step on a small batch, eager vs captured into a HIP graph (pygho_amd.graphs)."""
+    import time
+    from pygho_amd.graphs import GraphedStep
+    from pygho_amd.ngnn import SpModel
+    hb = synth.make_batch(graphs, "zinc", seed=77)
+    dd = synth.to_datadict(hb, dev)
+    y = dd["y"].unsqueeze(-1)
+    torch.manual_seed(0)
+    model = SpModel(1, 6, 128, act_dtype=torch.bfloat16).to(dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = model(dd)
+        loss = torch.nn.functional.l1_loss(y, pred.float())
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    def wall(fn, n=20):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    eager = wall(step)
+    gs = GraphedStep(step)
+    graphed = wall(gs.replay)
+    return {"op": "NGNN train step, eager vs HIP graph", "graphs": graphs, "eager_ms": eager, "graph_ms": graphed,
+            "graphs_per_s_eager": graphs / eager * 1e3, "graphs_per_s_graph": graphs / graphed * 1e3}
+
+
 def planner_case(kind, graphs, dev):
     """device planner (Spspmm.py:57-222): tuple pattern x adjacency -> (tarind, bcd) -> acd on the tuple pattern.
     Wall time per batch (includes the two host syncs that size the outputs)."""
@@ -201,6 +238,7 @@ def main():
     out.append(spmm_case(1024 if args.quick else 8192, 128, torch.bfloat16, dev))
     out.append(sunconv_case(128, 37, 128, torch.bfloat16, dev))
     out.append(sunconv_case(128 if args.quick else 1024, 37, 128, torch.bfloat16, dev))
+    out.append(graph_step_case(1024, dev))
     out.append(planner_case("zinc", 1024 if args.quick else 8192, dev))
     out.append(collate_case(1024 if args.quick else 8192, dev))
     for r in out:
