@@ -170,3 +170,62 @@ def test_masked_bmm_transpose_detecting(dev):
     B = B.expand(nb, n, n, d).contiguous()
     got = _ops.masked_bmm(A, B, None, None, None, nb, n, n, n, d, False, True)
     assert torch.equal(got, B)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(3, 7, 5, 8), (2, 37, 37, 128), (5, 3, 9, 12), (2, 6, 4, 6), (1, 70, 2, 2048)])
+def test_masked_elementwise_kernels_all_row_sizes(dev, dtype, shape):
+    """fill / single-dim reductions (+ gradients) / broadcast at row sizes that take the 16-byte-per-lane kernels
+    (row bytes % 16 == 0), the element-wise kernels (odd rows, > 256 chunks) and ragged workgroup tails.  Masked slots hold
+    NaN: nothing of them may reach a result (the vector forms never fetch them)."""
+    from pygho_amd import _ops
+    b, n1, n2, d = shape
+    gen = torch.Generator().manual_seed(b * 1000 + d)
+    x = torch.randn(shape, generator=gen).to(dtype)
+    mask = torch.rand((b, n1, n2), generator=gen) > 0.45
+    mask[0, 1] = False
+    mask[-1, :, 0] = False
+    xd = torch.where(mask[..., None], x, torch.full_like(x, float("nan"))).to(dev)
+    md = mask.to(dev)
+    x32 = torch.where(mask[..., None], x.float(), torch.zeros(()))
+    tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+
+    filled = _ops.masked_fill(xd, md, 3.0)
+    exp = torch.where(mask[..., None], x, torch.full_like(x, 3.0))
+    assert torch.equal(filled.cpu(), exp)
+
+    for dim in (1, 2):
+        cnt = mask.sum(dim)
+        for aggr in ("sum", "mean", "max", "min"):
+            xg = xd.clone().requires_grad_(True)
+            out, om = _ops.masked_reduce(xg, md, dim, aggr)
+            assert torch.equal(om.cpu(), cnt > 0)
+            if aggr in ("sum", "mean"):
+                # sequential f32 accumulation in index order, as the kernels do
+                acc = torch.zeros(out.shape, dtype=torch.float32)
+                for k in range(shape[dim]):
+                    acc = acc + x32.select(dim, k)
+                if aggr == "mean":
+                    acc = torch.where(cnt[..., None] > 0, acc / cnt.clamp_min(1)[..., None].float(), torch.zeros(()))
+                assert torch.equal(out.detach().cpu(), acc.to(dtype))
+            else:
+                fill = float("-inf") if aggr == "max" else float("inf")
+                t = x.float().masked_fill(~mask[..., None], fill)
+                ref = t.amax(dim) if aggr == "max" else t.amin(dim)
+                ref = torch.where(torch.isinf(ref), torch.zeros(()), ref)
+                assert torch.equal(out.detach().cpu().float(), ref)
+            if aggr in ("sum", "mean"):
+                w = torch.randn(out.shape, generator=gen).to(dtype)
+                out.backward(w.to(dev))
+                g = w.float().unsqueeze(dim)
+                if aggr == "mean":
+                    g = g / cnt.clamp_min(1)[..., None].float().unsqueeze(dim)
+                gexp = torch.where(mask[..., None], g.expand(shape), torch.zeros(())).to(dtype)
+                assert torch.equal(xg.grad.cpu(), gexp)
+
+    # broadcast of a (b, n2, d) node tensor along dim 1 and of a (b, n1, d) tensor along dim 2
+    for dim, src_shape in ((1, (b, n2, d)), (2, (b, n1, d))):
+        src = torch.randn(src_shape, generator=gen).to(dtype)
+        out = _ops.masked_broadcast(src.to(dev), md, dim, -2.0, 2)
+        exp = torch.where(mask[..., None], src.unsqueeze(dim).expand(shape), torch.full((), -2.0, dtype=dtype))
+        assert torch.equal(out.cpu(), exp)
