@@ -307,6 +307,18 @@ int pygho_masked_reduce_bwd(void* gdata, const void* gout, const void* data, con
 int pygho_masked_broadcast(void* out, const void* src, const uint8_t* mask, double value,
                            int64_t outer, int64_t r, int64_t inner, int64_t d, int dtype, void* stream);
 
+/* Tuple-level recombination of node-level terms on a padded (nb, n1, n2, d) representation:
+ *   out[b,i,j,:] = mask[b,i,j] ? ((base[b,i,j,:] + row_term[b,i,:]) + col_term[b,j,:]) : 0
+ * and on the diagonal i == j, diag_term[b,i,:] is added (diag_mode 0) or REPLACES the sum (diag_mode 1).  base, row_term,
+ * col_term, diag_term, mask are each nullable (absent term = 0, absent mask = all valid); diag_term has min(n1, n2) rows per b.
+ * f32 arithmetic in the order written, one rounding.  Replaces, in one pass, the chain of MaTensor.py:225-234 (unpooling) x3,
+ * MaTensor.py:251-262 (add) x3 and the per-type select of Conv.py:345,360-361 inside SUNConv, and (base = NULL, diag_mode 0) the
+ * autograd of {MaTensor.py:175-206 sum over dim 1, sum over dim 2, MaTensor.py:208-223 diag} taken together.  Row bytes must be a
+ * multiple of 16 (else PYGHO_ERR_UNSUPPORTED); masked rows of base are never fetched. */
+int pygho_masked_pair_combine(void* out, const void* base, const void* row_term, const void* col_term, const void* diag_term,
+                              int diag_mode, const uint8_t* mask, int64_t nb, int64_t n1, int64_t n2, int64_t d, int dtype,
+                              void* stream);
+
 /* ------------------------------------------------------------------------
  * Dense neighbours of the aggregation
  * ---------------------------------------------------------------------- */

@@ -1045,6 +1045,121 @@ def masked_broadcast(src: Tensor, mask: Tensor, dim: int, value: float, src_mask
     return _MaskedBroadcast.apply(src, mask, dim, value, src_masked_dim)
 
 
+def pair_combine_supported(data: Tensor) -> bool:
+    return (data.is_cuda and data.dim() == 4 and data.dtype in (torch.float32, torch.bfloat16, torch.float16)
+            and (data.shape[-1] * data.element_size()) % 16 == 0 and data.shape[-1] * data.element_size() <= 4096)
+
+
+def masked_pair_combine(base: Optional[Tensor], row_term: Optional[Tensor], col_term: Optional[Tensor],
+                        diag_term: Optional[Tensor], replace_diag: bool, mask: Optional[Tensor], shape, dtype, device) -> Tensor:
+    """out[b,i,j] = mask ? ((base[b,i,j] + row_term[b,i]) + col_term[b,j]) : 0; diag_term[b,i] is added on / replaces the
+    diagonal (no autograd; `pygho_masked_pair_combine`)."""
+    nb, n1, n2, d = shape
+    ops = [None if t is None else t.contiguous() for t in (base, row_term, col_term, diag_term)]
+    for t in ops:
+        assert t is None or (t.dtype == dtype and t.device == device)
+    out = torch.empty(shape, dtype=dtype, device=device)
+    m8 = None if mask is None else _mask_u8(mask)
+    check(lib().pygho_masked_pair_combine(ptr(out), ptr(ops[0]), ptr(ops[1]), ptr(ops[2]), ptr(ops[3]), 1 if replace_diag else 0,
+                                          ptr(m8), nb, n1, n2, d, DTYPE_CODE[dtype], stream_ptr(device)), "masked_pair_combine")
+    return out
+
+
+def _diag_rows(data: Tensor) -> Tensor:
+    """(b, n1, n2, d) -> (b, min(n1, n2), d): rows (b, i, i)."""
+    return torch.diagonal(data, 0, 1, 2).movedim(-1, 1)
+
+
+class _PairViews(torch.autograd.Function):
+    """(data (b, n1, n2, d), mask) -> (diagonal rows, sum over dim 1, sum over dim 2): the three node-level views a
+    subgraph layer takes of a 2-D representation; their gradients return to the tuple level in ONE pass."""
+
+    @staticmethod
+    def forward(ctx, data: Tensor, mask: Tensor):
+        require_device(data, mask)
+        data = data.contiguous()
+        dmask = torch.diagonal(mask, 0, 1, 2)
+        dg = torch.where(dmask.unsqueeze(-1), _diag_rows(data), torch.zeros((), dtype=data.dtype, device=data.device))
+        s1, _ = _MaskedReduce.apply(data, mask, 1, "sum")
+        s2, _ = _MaskedReduce.apply(data, mask, 2, "sum")
+        ctx.mask = mask
+        ctx.meta = (tuple(data.shape), data.dtype)
+        return dg.contiguous(), s1, s2
+
+    @staticmethod
+    def backward(ctx, g_dg, g_s1, g_s2):
+        shape, dtype = ctx.meta
+        dev = ctx.mask.device
+        cast = lambda t: None if t is None else t.to(dtype)
+        return masked_pair_combine(None, cast(g_s2), cast(g_s1), cast(g_dg), False, ctx.mask, shape, dtype, dev), None
+
+
+def pair_views(data: Tensor, mask: Tensor):
+    return _PairViews.apply(data, mask)
+
+
+def _dense_linear(flat: Tensor, w_in_out: Tensor, addend: Optional[Tensor] = None) -> Tensor:
+    """flat @ w (+ addend) with w stored (in, out): the streaming MFMA kernel when its shape is supported, else the library."""
+    if rowblock_linear_supported(flat, w_in_out.shape[1]) and w_in_out.shape[0] == w_in_out.shape[1]:
+        return rowblock_linear(flat, w_in_out.t().contiguous(), None, addend)[0]
+    out = flat @ w_in_out
+    return out if addend is None else out + addend
+
+
+class _PairLinearMix(torch.autograd.Function):
+    """out[b,i,j] = mask ? (i == j ? dg[b,i] : ((x[b,i,j] @ w_x + y[b,i,j] @ w_y) + u[b,i]) + v[b,j]) : 0
+
+    The recombination step of SUNConv (reference Conv.py:338-362) after the linear map has been pulled through the
+    broadcasts: two tuple-level GEMMs (the second with the first in its epilogue), then one pass adding the node-level
+    terms and selecting the diagonal.  Backward: one masked copy (off-diagonal part of g), two masked reductions, two
+    input-gradient GEMMs, two weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, y, w_x, w_y, u, v, dg, mask):
+        require_device(x, y, mask)
+        x, y = x.contiguous(), y.contiguous()
+        shape = tuple(x.shape)
+        d = shape[-1]
+        a = _dense_linear(x.reshape(-1, d), w_x)
+        ab = _dense_linear(y.reshape(-1, d), w_y, a)
+        out = masked_pair_combine(ab.reshape(shape), u, v, dg, True, mask, shape[:3] + (w_x.shape[1],), x.dtype, x.device)
+        ctx.save_for_backward(x, y, w_x, w_y)
+        ctx.mask = mask
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, w_x, w_y = ctx.saved_tensors
+        mask = ctx.mask
+        g = g.contiguous()
+        d_in, d_out = w_x.shape
+        n1, n2 = mask.shape[1], mask.shape[2]
+        off = getattr(mask, "_pygho_offdiag", None)
+        if off is None:
+            eye = torch.eye(n1, n2, dtype=torch.bool, device=mask.device)
+            off = mask & ~eye
+            try:
+                mask._pygho_offdiag = off
+            except Exception:
+                pass
+        goff = _MaskedFill.apply(g, off, 0.0)
+        gu, _ = _MaskedReduce.apply(goff, off, 2, "sum")
+        gv, _ = _MaskedReduce.apply(goff, off, 1, "sum")
+        dmask = torch.diagonal(mask, 0, 1, 2)
+        gdg = torch.where(dmask.unsqueeze(-1), _diag_rows(g), torch.zeros((), dtype=g.dtype, device=g.device))
+        gf = goff.reshape(-1, d_out)
+        xf, yf = x.reshape(-1, d_in), y.reshape(-1, d_in)
+        gx = _dense_linear(gf, w_x.t()).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        gy = _dense_linear(gf, w_y.t()).reshape(y.shape) if ctx.needs_input_grad[1] else None
+        gwx = weight_grad_splitk(gf, xf, w_x.dtype).t() if ctx.needs_input_grad[2] else None
+        gwy = weight_grad_splitk(gf, yf, w_y.dtype).t() if ctx.needs_input_grad[3] else None
+        return gx, gy, gwx, gwy, gu, gv, gdg, None
+
+
+def pair_linear_mix(x, y, w_x, w_y, u, v, dg, mask):
+    return _PairLinearMix.apply(x, y, w_x, w_y, u, v, dg, mask)
+
+
 def _bmm_launch(A: Tensor, B: Tensor, amask, bmask, omask, nb, ni, nk, nj, d, a_kfirst: bool, b_kfirst: bool) -> Tensor:
     dev = require_device(A, B, amask, bmask, omask)
     out = torch.empty((nb, ni, nj, d), dtype=A.dtype, device=dev)
@@ -1270,6 +1385,7 @@ USE_ADJ_TABLE = True     # adjacency values that are an embedding lookup are rea
 USE_ACT_ON_LOAD = True   # f32 blocks: BatchNorm + activation applied inside the aggregation kernel's loads
 USE_BN_BWD_LINEAR = True
 USE_ROWBLOCK_LINEAR = True      # module switch for A/B measurements (the library GEMM + separate passes otherwise)
+USE_PAIR_COMBINE = True   # SUNConv on the padded layout: fused node-view / recombination passes
 
 
 def rowblock_linear_supported(x: Tensor, out_features: int) -> bool:

@@ -248,6 +248,73 @@ __global__ __launch_bounds__(kBlock) void masked_reduce_bwd_vec_kernel(T* __rest
   for (int k = 0; k < r; ++k) *reinterpret_cast<uint4*>(base + k * step) = mrow[(int64_t)k * inner] ? share : zero;
 }
 
+// out[b, i, j, :] = mask[b, i, j] ? ((base[b, i, j, :] + row_term[b, i, :]) + col_term[b, j, :]  (+ or replaced by, on i == j)
+// diag_term[b, i, :]) : 0 -- the tuple-level recombination of node-level terms (SUN-style layers) and, with base == NULL and the
+// additive diagonal, the gradient of {pool over dim 1, pool over dim 2, diagonal} in one pass.  f32 arithmetic, one rounding.
+template <typename T, bool REPLACE>
+__global__ __launch_bounds__(kBlock) void masked_pair_combine_kernel(T* __restrict__ out, const T* __restrict__ base,
+                                                                     const T* __restrict__ row_term, const T* __restrict__ col_term,
+                                                                     const T* __restrict__ diag_term, const uint8_t* __restrict__ mask,
+                                                                     int64_t n_rows, uint32_t n1, uint32_t n2, int chunks,
+                                                                     int rows_per_wg) {
+  using V = Vec16<T>;
+  constexpr int N = V::N;
+  const int lr = threadIdx.x / chunks, ch = threadIdx.x - lr * chunks;
+  if (lr >= rows_per_wg) return;
+  const int64_t row0 = (int64_t)blockIdx.x * kMaskRowsPerLane * rows_per_wg;
+  const uint32_t span_rows = (uint32_t)min((int64_t)kMaskRowsPerLane * rows_per_wg, n_rows - row0);
+  const __amdgpu_buffer_rsrc_t rsrc = mk_rsrc(base ? reinterpret_cast<const char*>(base) + row0 * chunks * 16 : nullptr,
+                                              base ? span_rows * (uint32_t)chunks * 16u : 0u);
+  const uint32_t nd = n1 < n2 ? n1 : n2;
+  uint8_t m[kMaskRowsPerLane];
+  int64_t row[kMaskRowsPerLane];
+#pragma unroll
+  for (int u = 0; u < kMaskRowsPerLane; ++u) {
+    row[u] = row0 + u * rows_per_wg + lr;
+    m[u] = row[u] < n_rows ? (mask ? mask[row[u]] : (uint8_t)1) : (uint8_t)0;
+  }
+  uint4 vb[kMaskRowsPerLane];
+#pragma unroll
+  for (int u = 0; u < kMaskRowsPerLane; ++u)
+    vb[u] = mk_load(rsrc, base != nullptr && m[u] != 0, ((uint32_t)(u * rows_per_wg + lr) * (uint32_t)chunks + (uint32_t)ch) * 16u);
+#pragma unroll
+  for (int u = 0; u < kMaskRowsPerLane; ++u) {
+    if (row[u] >= n_rows) continue;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    uint4 res = zero;
+    if (m[u]) {
+      const int64_t bi = row[u] / n2;                                // (b, i)
+      const uint32_t j = (uint32_t)(row[u] - bi * n2);
+      const int64_t b = bi / n1;
+      const uint32_t i = (uint32_t)(bi - b * n1);
+      const bool on_diag = diag_term != nullptr && i == j;
+      if (REPLACE && on_diag) {
+        res = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(diag_term) + ((b * nd + i) * chunks + ch) * 16);
+      } else {
+        float acc[N], t[N];
+        V::unpack(vb[u], acc);
+        if (row_term) {
+          V::unpack(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(row_term) + (bi * chunks + ch) * 16), t);
+#pragma unroll
+          for (int q = 0; q < N; ++q) acc[q] += t[q];
+        }
+        if (col_term) {
+          V::unpack(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(col_term) + ((b * n2 + j) * chunks + ch) * 16), t);
+#pragma unroll
+          for (int q = 0; q < N; ++q) acc[q] += t[q];
+        }
+        if (!REPLACE && on_diag) {
+          V::unpack(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(diag_term) + ((b * nd + i) * chunks + ch) * 16), t);
+#pragma unroll
+          for (int q = 0; q < N; ++q) acc[q] += t[q];
+        }
+        res = V::pack(acc);
+      }
+    }
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + (row[u] * chunks + ch) * 16) = res;
+  }
+}
+
 }  // namespace pygho
 
 using namespace pygho;
@@ -476,4 +543,42 @@ extern "C" int pygho_masked_broadcast(void* out, const void* src, const uint8_t*
     default: set_error("unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED;
   }
   return check_launch("masked_broadcast");
+}
+
+template <typename T>
+static int pair_combine_launch(void* out, const void* base, const void* row_term, const void* col_term, const void* diag_term,
+                               int diag_mode, const uint8_t* mask, int64_t nb, int64_t n1, int64_t n2, int64_t d, hipStream_t st) {
+  const int64_t row_bytes = d * (int64_t)sizeof(T);
+  if (row_bytes % 16 != 0 || row_bytes / 16 > kBlock) { set_error("masked_pair_combine: row of %lld bytes has no 16-byte form", (long long)row_bytes); return PYGHO_ERR_UNSUPPORTED; }
+  const int chunks = (int)(row_bytes / 16), rows_per_wg = kBlock / chunks;
+  const int64_t n_rows = nb * n1 * n2;
+  const int64_t grid = ceil_div(n_rows, (int64_t)kMaskRowsPerLane * rows_per_wg);
+  if (grid >= 0x7fffffff || n1 >= 0x7fffffff || n2 >= 0x7fffffff) { set_error("masked_pair_combine: too many rows"); return PYGHO_ERR_UNSUPPORTED; }
+  if (diag_mode)
+    hipLaunchKernelGGL((masked_pair_combine_kernel<T, true>), dim3((unsigned)grid), dim3(kBlock), 0, st, (T*)out, (const T*)base,
+                       (const T*)row_term, (const T*)col_term, (const T*)diag_term, mask, n_rows, (uint32_t)n1, (uint32_t)n2, chunks, rows_per_wg);
+  else
+    hipLaunchKernelGGL((masked_pair_combine_kernel<T, false>), dim3((unsigned)grid), dim3(kBlock), 0, st, (T*)out, (const T*)base,
+                       (const T*)row_term, (const T*)col_term, (const T*)diag_term, mask, n_rows, (uint32_t)n1, (uint32_t)n2, chunks, rows_per_wg);
+  return check_launch("masked_pair_combine");
+}
+
+extern "C" int pygho_masked_pair_combine(void* out, const void* base, const void* row_term, const void* col_term,
+                                         const void* diag_term, int diag_mode, const uint8_t* mask, int64_t nb, int64_t n1,
+                                         int64_t n2, int64_t d, int dtype, void* stream) {
+  if (nb < 0 || n1 < 0 || n2 < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (nb * n1 * n2 * d == 0) return PYGHO_OK;
+  if (!out) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (diag_mode != 0 && diag_mode != 1) { set_error("diag_mode must be 0 (add) or 1 (replace)"); return PYGHO_ERR_INVALID; }
+  if (!aligned16(out) || !aligned16(base) || !aligned16(row_term) || !aligned16(col_term) || !aligned16(diag_term)) {
+    set_error("masked_pair_combine: operands must be 16-byte aligned");
+    return PYGHO_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case PYGHO_F32: return pair_combine_launch<float>(out, base, row_term, col_term, diag_term, diag_mode, mask, nb, n1, n2, d, st);
+    case PYGHO_BF16: return pair_combine_launch<bf16>(out, base, row_term, col_term, diag_term, diag_mode, mask, nb, n1, n2, d, st);
+    case PYGHO_F16: return pair_combine_launch<f16>(out, base, row_term, col_term, diag_term, diag_mode, mask, nb, n1, n2, d, st);
+    default: set_error("unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED;
+  }
 }

@@ -195,6 +195,7 @@ class GNNAKConv(Module):
                  optuplefeat: str = "X", opadj: str = "A"):
         super().__init__()
         v = _views(mode, pool)
+        self._pool = pool
         self.lin0 = MLP(indim, indim, **mlp0)
         self.aggr = TensorOp.OpMessagePassingOnSubg2D(mode, aggr, optuplefeat, opadj)
         self.diag, self.pool2subg, self.unpool4subg = v["diag"], v["pool_subg"], v["to_subg_nodes"]
@@ -222,6 +223,7 @@ class SUNConv(Module):
                  opadj: str = "A"):
         super().__init__()
         v = _views(mode, pool)
+        self._pool = pool
         self.lin0 = MLP(indim, indim, **mlp0)
         self.aggr = TensorOp.OpMessagePassingOnSubg2D(mode, aggr, optuplefeat, opadj)
         self.diag, self.pool2subg, self.unpool4subg = v["diag"], v["pool_subg"], v["to_subg_nodes"]
@@ -271,6 +273,10 @@ class SUNConv(Module):
         add = lambda a, b: a.add(b, True) if isinstance(a, (SparseTensor, MaskedTensor)) else a + b
 
         agg = self.aggr.forward(A, X.tuplewiseapply(self.lin0), datadict, X)
+        if (_ops.USE_PAIR_COMBINE and isinstance(X, MaskedTensor) and isinstance(agg, MaskedTensor) and X.masked_dim == 3
+                and self._pool in ("sum", "mean") and _ops.pair_combine_supported(X.raw) and agg.raw.dtype == X.raw.dtype
+                and agg.raw.shape == X.raw.shape):
+            return self._recombine_dense(X, agg, blk).tuplewiseapply(self.lin1_1)
         centre, n5, n6, n7 = self.diag.forward(X), self.pool2node(X), self.pool2subg(X), self.pool2node(agg)
         # concat order of the reference: [X, to_nodes(centre), to_root(centre), agg, to_root(n5), to_nodes(n6), to_root(n7)]
         off = add(lin(X, blk(0, 0)), lin(agg, blk(0, 3)))
@@ -286,3 +292,29 @@ class SUNConv(Module):
         else:
             picked = off.diagonalapply(lambda val, is_diag: torch.where(is_diag.bool().unsqueeze(-1), dg_t.values.to(val.dtype), val))
         return picked.tuplewiseapply(self.lin1_1)
+
+    def _recombine_dense(self, X: MaskedTensor, agg: MaskedTensor, blk) -> MaskedTensor:
+        """the same arithmetic on the padded layout with the tuple-level passes fused: the node-level views of X and agg
+        (diagonal, pool over subgraphs, pool over nodes) come from one autograd node each (their gradients return to the
+        tuple level in one pass, ``_ops.pair_views``); the two tuple-level GEMMs, the three broadcasts, the three adds and
+        the diagonal select are ``_ops.pair_linear_mix`` (two GEMM launches + one pass)."""
+        mask, amask = X.mask, agg.mask
+        dt = X.raw.dtype
+        w = lambda t, v: blk(t, v).to(dt)
+
+        def views(rep_raw, m):
+            dg, s1, s2 = _ops.pair_views(rep_raw, m)                # rows (b,i,i); sum over dim 1 -> [b,j]; over dim 2 -> [b,i]
+            if self._pool == "mean":
+                s1 = s1 / m.sum(1).clamp_min(1).unsqueeze(-1).to(dt)
+                s2 = s2 / m.sum(2).clamp_min(1).unsqueeze(-1).to(dt)
+            return dg, s1, s2
+
+        centre, n5, n6 = views(X.raw, mask)                         # n5 = pool2node (dim 1), n6 = pool2subg (dim 2)
+        agg_dg, n7, _unused = views(agg.raw, amask)
+        # unpooling [2] repeats a node tensor along j (term indexed by i), unpooling [1] along i (term indexed by j)
+        u = centre @ w(0, 1) + n6 @ w(0, 5)                          # to_nodes(...)
+        v = (centre @ w(0, 2) + n5 @ w(0, 4)) + n7 @ w(0, 6)         # to_root(...)
+        dg = centre @ (blk(1, 0) + blk(1, 1) + blk(1, 2)).to(dt) + agg_dg @ w(1, 3)
+        dg = ((dg + n5 @ w(1, 4)) + n6 @ w(1, 5)) + n7 @ w(1, 6)
+        out = _ops.pair_linear_mix(X.raw, agg.raw, w(0, 0), w(0, 3), u.contiguous(), v.contiguous(), dg.contiguous(), mask)
+        return MaskedTensor(out, mask, 0.0, True)

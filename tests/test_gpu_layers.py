@@ -523,3 +523,47 @@ def test_hip_graph_replay_equals_eager_steps(dev):
         torch.testing.assert_close(p1, p2, rtol=1e-4, atol=1e-5, msg=n1)
     for (n1, b1), (_, b2) in zip(m_eager.named_buffers(), m_graph.named_buffers()):
         torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=n1)
+
+
+@pytest.mark.parametrize("case", ["f32_small", "bf16_rowblock"])
+def test_sunconv_dense_fused_passes(dev, case):
+    """SUNConv on the padded layout with the fused node-view / recombination passes (`_ops.USE_PAIR_COMBINE`: pair_views,
+    pair_linear_mix -> pygho_masked_pair_combine, and at d = 128 bf16 the streaming GEMM kernel with the first product in
+    the epilogue of the second) against the same layer with separate broadcast / add / select passes."""
+    import copy
+    from pygho_amd import MaskedTensor, synth, _ops
+    from pygho_amd.honn import Conv
+    if case == "f32_small":
+        h, nb, kw, amp, tol = 16, 5, dict(clip_nodes=9), False, dict(rtol=2e-5, atol=2e-5)
+    else:
+        h, nb, kw, amp, tol = 128, 8, dict(nmax=37), True, dict(rtol=0, atol=6e-2)
+    dn = synth.make_dense_batch(nb, seed=6, hidden=h, **kw)
+    torch.manual_seed(1)
+    mlp = dict(MLP, norm="bn")
+    layer = Conv.SUNConv(h, h, "sum", "mean", "DD", dict(mlp), dict(mlp)).to(dev)
+    dt = torch.bfloat16 if amp else torch.float32
+    xraw = T(dn["X"], dev).to(dt)
+    Amt = MaskedTensor(T(dn["A"], dev).to(dt), T(dn["Amask"], dev), 0.0, True)
+    xm = T(dn["Xmask"], dev)
+    w = torch.randn(xraw.shape, device=dev).to(dt)
+    res = {}
+    for fused in (True, False):
+        _ops.USE_PAIR_COMBINE = fused
+        try:
+            lay = copy.deepcopy(layer)
+            x = xraw.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                out = lay(Amt, MaskedTensor(x, xm, 0.0, True), {})
+            o = out.data * xm[..., None]
+            o.backward(w)
+            res[fused] = (o.detach().float(), x.grad.float() * xm[..., None], {k: p.grad.float() for k, p in lay.named_parameters()})
+        finally:
+            _ops.USE_PAIR_COMBINE = True
+    for i in (0, 1):
+        s = float(res[False][i].abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][i] / s, res[False][i] / s, **tol)
+    for k, ref in res[False][2].items():
+        if k.endswith(".lins.0.bias"):
+            continue                                       # bias in front of a BatchNorm: zero up to rounding noise
+        s = float(ref.abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][2][k] / s, ref / s, msg=k, **tol)
