@@ -311,10 +311,24 @@ class SUNConv(Module):
 
         centre, n5, n6 = views(X.raw, mask)                         # n5 = pool2node (dim 1), n6 = pool2subg (dim 2)
         agg_dg, n7, _unused = views(agg.raw, amask)
+
+        def node_lin(parts, blocks):
+            """sum_k parts[k] @ blocks[k] as ONE product over the concatenated reduction dim: (b n, k d) rows are few, so
+            the concatenation is cheap, and the weight gradient (reduction over b n rows into a d x d tile) runs on the
+            split-K kernel once instead of k times on a single-tile library GEMM."""
+            x = torch.cat(parts, dim=-1).reshape(-1, len(parts) * d_)
+            wt = torch.cat(blocks, dim=0).to(dt)                    # (k d, d)
+            if x.shape[0] >= 8192:
+                y = _SplitKLinearFn.apply(x, wt.t(), None)
+            else:
+                y = x @ wt
+            return y.reshape(parts[0].shape[:-1] + (wt.shape[1],))
+
+        d_ = X.raw.shape[-1]
         # unpooling [2] repeats a node tensor along j (term indexed by i), unpooling [1] along i (term indexed by j)
-        u = centre @ w(0, 1) + n6 @ w(0, 5)                          # to_nodes(...)
-        v = (centre @ w(0, 2) + n5 @ w(0, 4)) + n7 @ w(0, 6)         # to_root(...)
-        dg = centre @ (blk(1, 0) + blk(1, 1) + blk(1, 2)).to(dt) + agg_dg @ w(1, 3)
-        dg = ((dg + n5 @ w(1, 4)) + n6 @ w(1, 5)) + n7 @ w(1, 6)
+        u = node_lin([centre, n6], [blk(0, 1), blk(0, 5)])                                  # to_nodes(...)
+        v = node_lin([centre, n5, n7], [blk(0, 2), blk(0, 4), blk(0, 6)])                   # to_root(...)
+        dg = node_lin([centre, agg_dg, n5, n6, n7],
+                      [blk(1, 0) + blk(1, 1) + blk(1, 2), blk(1, 3), blk(1, 4), blk(1, 5), blk(1, 6)])
         out = _ops.pair_linear_mix(X.raw, agg.raw, w(0, 0), w(0, 3), u.contiguous(), v.contiguous(), dg.contiguous(), mask)
         return MaskedTensor(out, mask, 0.0, True)
