@@ -1385,6 +1385,7 @@ USE_ADJ_TABLE = True     # adjacency values that are an embedding lookup are rea
 USE_ACT_ON_LOAD = True   # f32 blocks: BatchNorm + activation applied inside the aggregation kernel's loads
 USE_BN_BWD_LINEAR = True
 USE_ROWBLOCK_LINEAR = True      # module switch for A/B measurements (the library GEMM + separate passes otherwise)
+USE_CONCAT_BLOCK = True   # SSWLConv / DSSGNNConv: Linear-BN-act over concatenated inputs without the concatenation
 USE_PAIR_COMBINE = True   # SUNConv on the padded layout: fused node-view / recombination passes
 
 
@@ -1422,8 +1423,20 @@ def sum_blocks(partials: Tensor) -> Tensor:
     return out
 
 
+def bn_bwd_sums(pre: Tensor, gh: Tensor, saved, act: str):
+    """the two channel sums of the BatchNorm + activation backward (sum dy, sum dy * xhat), two-stage and deterministic."""
+    mean, invstd, w32, b32, ws = saved
+    m, c = pre.shape
+    dev = pre.device
+    s1 = torch.empty(c, dtype=torch.float32, device=dev)
+    s2 = torch.empty(c, dtype=torch.float32, device=dev)
+    check(lib().pygho_bn_act_bwd_sums(ptr(s1), ptr(s2), ptr(pre), ptr(gh), ptr(mean), ptr(invstd), ptr(w32), ptr(b32), m, c,
+                                      ACT_CODE[act], ptr(ws), dtype_code(pre), stream_ptr(dev)), "bn_act_bwd_sums")
+    return s1, s2
+
+
 def bn_bwd_linear(pre: Tensor, gh: Tensor, saved, training: bool, act: str, w: Tensor, addend: Optional[Tensor],
-                  want_colsum: bool, x: Optional[Tensor] = None):
+                  want_colsum: bool, x: Optional[Tensor] = None, sums=None):
     """(gx, gpre or dW, d bn.bias, d bn.weight, column sums of gpre or None): BatchNorm/act backward and the
     input-gradient GEMM gx = gpre @ w (+ addend) in one streaming kernel after the two-stage channel reduction.
     With `x` (the Linear's input) the weight gradient gpre^T @ x (f32) is accumulated in the same pass and returned in
@@ -1433,10 +1446,7 @@ def bn_bwd_linear(pre: Tensor, gh: Tensor, saved, training: bool, act: str, w: T
     dev = pre.device
     st = stream_ptr(dev)
     dt = dtype_code(pre)
-    s1 = torch.empty(c, dtype=torch.float32, device=dev)
-    s2 = torch.empty(c, dtype=torch.float32, device=dev)
-    check(lib().pygho_bn_act_bwd_sums(ptr(s1), ptr(s2), ptr(pre), ptr(gh), ptr(mean), ptr(invstd), ptr(w32), ptr(b32), m, c,
-                                      ACT_CODE[act], ptr(ws), dt, st), "bn_act_bwd_sums")
+    s1, s2 = sums if sums is not None else bn_bwd_sums(pre, gh, saved, act)
     gx = torch.empty_like(pre)
     wl = w.t().contiguous()
     if addend is not None:
@@ -1574,4 +1584,75 @@ def tuple_block(x: Tensor, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", a
     out, mean, var = _TupleBlock.apply(x, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
                                        bn.eps, act, rhs, plan, aggr, residual, fold, rhs_lookup)
     _update_running(bn, mean, var, x.shape[0], folded=fold is not None)
+    return out
+
+
+class _ConcatBlock(torch.autograd.Function):
+    """act(bn(concat(x_0 .. x_{K-1}) W^T + b)) without the concatenation: W = [W_0 | .. | W_{K-1}] column blocks,
+    pre = (..((x_0 W_0^T + b) + x_1 W_1^T) ..) as a chain of streaming GEMMs, each with the previous result in its epilogue and
+    the last with the BatchNorm statistics; backward = the channel reduction once, then per input ONE pass producing its
+    input gradient and its weight-gradient block.  (SSWLConv, reference Conv.py:98-103: the (nnz, 3 d) concatenation is
+    1.4 GB at B = 8192 and was a quarter of the layer.)"""
+
+    @staticmethod
+    def forward(ctx, w, b, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum, *xs):
+        require_device(w, *xs)
+        xs = [x.contiguous() for x in xs]
+        d = xs[0].shape[1]
+        dt = xs[0].dtype
+        wc = w if w.dtype == dt else w.to(dt)
+        bc = None if b is None else (b if b.dtype == dt else b.to(dt))
+        blocks = [wc[:, k * d:(k + 1) * d].contiguous() for k in range(len(xs))]
+        shift = None
+        if training:
+            shift = torch.nn.functional.linear(torch.cat([x[:1] for x in xs], dim=1), wc, bc).float().reshape(-1)
+        pre, sums = None, None
+        for k, (x, wk) in enumerate(zip(xs, blocks)):
+            last = k == len(xs) - 1
+            pre, sums = rowblock_linear(x, wk, bc if k == 0 else None, addend=pre, stats_shift=shift if last else None)
+        h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum,
+                                          (sums, shift) if training else None, apply=True)
+        ctx.save_for_backward(pre, *xs, *blocks, *saved)
+        ctx.meta = (len(xs), training, act, None if b is None else b.dtype, gamma is not None, beta is not None, w.dtype)
+        ctx.mark_non_differentiable(mean, var)
+        return h, mean, var
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv):
+        k_in, training, act, b_dtype, has_gamma, has_beta, w_dtype = ctx.meta
+        pre = ctx.saved_tensors[0]
+        xs = ctx.saved_tensors[1:1 + k_in]
+        blocks = ctx.saved_tensors[1 + k_in:1 + 2 * k_in]
+        saved = ctx.saved_tensors[1 + 2 * k_in:]
+        g = g.contiguous()
+        sums = bn_bwd_sums(pre, g, saved, act)
+        want_cs = b_dtype is not None and ctx.needs_input_grad[1]
+        gxs, gws, gb = [], [], None
+        for k in range(k_in):
+            gx, gw32, _s1, _s2, sdx = bn_bwd_linear(pre, g, saved, training, act, blocks[k], None, want_cs and k == 0, x=xs[k],
+                                                    sums=sums)
+            gxs.append(gx if ctx.needs_input_grad[10 + k] else None)
+            gws.append(gw32)
+            if sdx is not None:
+                gb = sdx.to(b_dtype)
+        gw = torch.cat(gws, dim=1).to(w_dtype) if ctx.needs_input_grad[0] else None
+        s1, s2 = sums
+        return (gw, gb, (s2 if has_gamma else None), (s1 if has_beta else None), None, None, None, None, None, None, *gxs)
+
+
+def concat_block_supported(xs, lin: "torch.nn.Linear") -> bool:
+    d = xs[0].shape[1] if xs and xs[0].dim() == 2 else -1
+    return (USE_CONCAT_BLOCK and USE_ROWBLOCK_LINEAR and USE_BN_BWD_LINEAR and len(xs) >= 2
+            and all(x.dim() == 2 and x.shape == xs[0].shape and x.dtype == xs[0].dtype and x.is_cuda for x in xs)
+            and lin.in_features == len(xs) * d and lin.out_features == d and rowblock_linear_supported(xs[0], d)
+            and bn_act_supported_shape(xs[0].shape[0], d, xs[0].dtype))
+
+
+def concat_block(xs, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", act: str) -> Tensor:
+    """fused Linear -> BatchNorm1d -> act applied to concat(xs, dim=1), the concatenation never formed."""
+    training = bn.training or bn.running_mean is None
+    fold = _fold_momentum(bn)
+    out, mean, var = _ConcatBlock.apply(lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                                        bn.eps, act, fold, *xs)
+    _update_running(bn, mean, var, xs[0].shape[0], folded=fold is not None)
     return out

@@ -99,6 +99,24 @@ def _residual_update(layer, A: Rep, X: Rep, datadict: dict) -> Rep:
     return X.tuplewiseapply(lambda _: vals)
 
 
+def _cat_apply(first: Rep, others, mlp) -> Rep:
+    """``first.catvalue(others, True).tuplewiseapply(mlp)`` (reference Conv.py:98-103, 190-196).  Sparse representations on
+    the device whose MLP is one Linear -> BatchNorm -> act block over equally wide inputs skip the concatenation
+    (``_ops.concat_block``: chained streaming GEMMs, one backward pass per input)."""
+    block = mlp.single_block() if isinstance(mlp, MLP) else None
+    reps = [first] + list(others)
+    if (block is not None and all(isinstance(r, SparseTensor) and r.values is not None for r in reps)
+            and all(r.indices is first.indices or r.nnz == first.nnz for r in reps)):
+        vals = [r.values for r in reps]
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else vals[0].dtype
+        vals = [v if v.dtype == dt else v.to(dt) for v in vals]
+        if _ops.concat_block_supported(vals, block[0]):
+            with torch.autocast("cuda", enabled=False):
+                out = _ops.concat_block(vals, *block)
+            return first.tuplewiseapply(lambda _: out)
+    return first.catvalue(list(others), True).tuplewiseapply(mlp)
+
+
 class NGNNConv(Module):
     """nested GNN layer (reference Conv.py:20-58): tuple-wise MLP, then message passing inside each subgraph."""
 
@@ -130,7 +148,7 @@ class SSWLConv(Module):
 
     def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
         neighbours = [op.forward(A, X, datadict, X) for op in (self.aggr1, self.aggr2)]
-        return X.catvalue(neighbours, True).tuplewiseapply(self.lin)
+        return _cat_apply(X, neighbours, self.lin)
 
 
 class I2Conv(Module):
@@ -168,7 +186,7 @@ class DSSGNNConv(Module):
         node_level = self.aggr_global.forward(A, self.pool2global.forward(X))
         shared = self.unpooling2subg.forward(node_level, X)
         local = self.aggr_subg.forward(A, X, datadict, X)
-        return local.catvalue(shared, True).tuplewiseapply(self.lin)
+        return _cat_apply(local, [shared], self.lin)
 
 
 class PPGNConv(Module):

@@ -567,3 +567,51 @@ def test_sunconv_dense_fused_passes(dev, case):
             continue                                       # bias in front of a BatchNorm: zero up to rounding noise
         s = float(ref.abs().max()) + 1e-6
         torch.testing.assert_close(res[True][2][k] / s, ref / s, msg=k, **tol)
+
+
+@pytest.mark.parametrize("name", ["SSWLConv", "DSSGNNConv"])
+def test_concat_block_layers(dev, name):
+    """layers whose MLP takes a concatenation ([X, X A, A X] in SSWLConv, reference Conv.py:98-103; [local, shared] in
+    DSSGNNConv, :190-196) with `_ops.concat_block` (chained streaming GEMMs, no (nnz, k d) tensor, one backward pass per input)
+    against the same layer with the literal concatenation: outputs, input gradient and every parameter gradient, bf16."""
+    import copy
+    from pygho_amd import SparseTensor, synth, _ops
+    from pygho_amd.honn import Conv
+    from pygho_amd.honn.SpOperator import parse_precomputekey
+    h = 128
+    torch.manual_seed(3)
+    if name == "SSWLConv":
+        layer = Conv.SSWLConv(h, h, "sum", "SS", dict(MLP)).to(dev)
+    else:
+        layer = Conv.DSSGNNConv(h, h, "sum", "sum", "mean", "SS", dict(MLP)).to(dev)
+    hb = synth.make_batch(64, "zinc", seed=21, keys=tuple(parse_precomputekey(layer)))
+    dd = synth.to_datadict(hb, dev)
+    X0, A0 = dd["X"], dd["A"]
+    assert X0.nnz >= 8192
+    xv0 = torch.randn(X0.nnz, h, device=dev).to(torch.bfloat16)
+    av = (torch.randn(A0.nnz, h, device=dev) * 0.5).to(torch.bfloat16)
+    A = SparseTensor(A0.indices, av, list(A0.shape[:2]) + [h], True)
+    w = torch.randn(X0.nnz, h, device=dev).to(torch.bfloat16)
+    res = {}
+    for fused in (True, False):
+        _ops.USE_CONCAT_BLOCK = fused
+        try:
+            lay = copy.deepcopy(layer)
+            xv = xv0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = lay(A, SparseTensor(X0.indices, xv, list(X0.shape[:2]) + [h], True), dd)
+            out.values.backward(w)
+            res[fused] = (out.values.detach().float(), xv.grad.float(), {k: p.grad.float() for k, p in lay.named_parameters()},
+                          {k: v.clone() for k, v in lay.state_dict().items() if "running" in k})
+        finally:
+            _ops.USE_CONCAT_BLOCK = True
+    for i in (0, 1):
+        s = float(res[False][i].abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][i] / s, res[False][i] / s, rtol=0, atol=4e-2)
+    for k, ref in res[False][2].items():
+        if k.endswith(".lins.0.bias"):
+            continue                                       # bias in front of a BatchNorm: zero up to rounding noise
+        s = float(ref.abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][2][k] / s, ref / s, rtol=0, atol=4e-2, msg=k)
+    for k, ref in res[False][3].items():                   # running statistics updated the same way
+        torch.testing.assert_close(res[True][3][k].float(), ref.float(), rtol=2e-2, atol=2e-2, msg=k)

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Forward + backward time of ONE layer of each shipped subgraph-GNN family on the sparse backend (north_star:
+NGNNConv, SSWLConv, SUNConv, I2Conv), ZINC-shape 2-tuple batches (I2Conv: the 3-tuple stress shape), bf16 autocast.
+
+    python tools/bench_layers.py [--graphs 8192] [--profile LAYER]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pygho_amd import synth                                    # noqa: E402
+from pygho_amd.honn import Conv                                 # noqa: E402
+from pygho_amd.honn.SpOperator import parse_precomputekey       # noqa: E402
+
+MLP = {"numlayer": 1, "tailact": True, "norm": "bn", "act": "silu", "dp": 0.0}
+
+
+def build(name, h, dev):
+    torch.manual_seed(0)
+    if name == "NGNNConv":
+        return Conv.NGNNConv(h, h, "sum", "SS", dict(MLP)).to(dev)
+    if name == "SSWLConv":
+        return Conv.SSWLConv(h, h, "sum", "SS", dict(MLP)).to(dev)
+    if name == "SUNConv":
+        return Conv.SUNConv(h, h, "sum", "mean", "SS", dict(MLP), dict(MLP)).to(dev)
+    if name == "I2Conv":
+        return Conv.I2Conv(h, h, "sum", "SS", dict(MLP)).to(dev)
+    raise ValueError(name)
+
+
+def case(name, graphs, dev, profile=False):
+    kind, h = ("i2", 256) if name == "I2Conv" else ("zinc", 128)
+    layer = build(name, h, dev)
+    keys = tuple(parse_precomputekey(layer))
+    hb = synth.make_batch(min(graphs, 1024), kind, seed=11, keys=keys)
+    if graphs > 1024:
+        hb = synth.replicate(hb, graphs // 1024)
+    dd = synth.to_datadict(hb, dev, kind)
+    from pygho_amd import SparseTensor
+    X0, A0 = dd["X"], dd["A"]
+    xv = torch.randn(X0.nnz, h, device=dev).to(torch.bfloat16).requires_grad_(True)
+    av = torch.randn(A0.nnz, h, device=dev).to(torch.bfloat16)
+    A = SparseTensor(A0.indices, av, list(A0.shape[:A0.sparse_dim]) + [h], True)
+    w = torch.randn(X0.nnz, h, device=dev).to(torch.bfloat16)
+
+    def step():
+        xv.grad = None
+        for p in layer.parameters():
+            p.grad = None
+        X = SparseTensor(X0.indices, xv, list(X0.shape[:X0.sparse_dim]) + [h], True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = layer(A, X, dd)
+        out.values.backward(w)
+
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    if profile:
+        from torch.profiler import profile as prof_, ProfilerActivity
+        with prof_(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as pr:
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+        print(pr.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=90), file=sys.stderr)
+    msgs = {k: int(dd[k + "___acd"].shape[1]) for k in keys}
+    return {"op": f"{name} SS layer fwd+bwd", "graphs": hb.num_graphs, "tuples": int(X0.nnz), "d": h, "dtype": "bfloat16",
+            "msg_edges": msgs, "ms": ms, "graphs_per_s": hb.num_graphs / ms * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--graphs", type=int, default=8192)
+    ap.add_argument("--profile", default="")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    for name in ("NGNNConv", "SSWLConv", "SUNConv", "I2Conv"):
+        g = args.graphs if name != "I2Conv" else max(256, args.graphs // 4)
+        print(json.dumps(case(name, g, dev, profile=args.profile == name)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
