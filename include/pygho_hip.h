@@ -319,6 +319,17 @@ int pygho_masked_pair_combine(void* out, const void* base, const void* row_term,
                               int diag_mode, const uint8_t* mask, int64_t nb, int64_t n1, int64_t n2, int64_t d, int dtype,
                               void* stream);
 
+/* The same recombination on a SPARSE 2-D representation whose tuple t has pattern row (row_idx[t], col_idx[t]) (int32):
+ *   out[t,:] = (base[t,:] + row_term[row_idx[t],:]) + col_term[col_idx[t],:]
+ * and on diagonal tuples (row_idx[t] == col_idx[t]) diag_term[row_idx[t],:] is added (diag_mode 0) or REPLACES the sum (1).
+ * base, row_term, col_term, diag_term nullable (absent = 0).  Replaces SpTensor.py:470-476 (unpooling_fromdense1dim) x3,
+ * SpTensor.py:507-517 (add) x3 and the per-type select of Conv.py:345,360-361 inside SUNConv (mode "SS"), and with
+ * base = NULL, diag_mode 0 the joint autograd of {SpTensor.py:382-409 sum over dim 0, over dim 1, SpTensor.py:322-352 diag}.
+ * Row bytes must be a multiple of 16 (else PYGHO_ERR_UNSUPPORTED). */
+int pygho_pair_gather_combine(void* out, const void* base, const void* row_term, const void* col_term, const void* diag_term,
+                              int diag_mode, const int32_t* row_idx, const int32_t* col_idx, int64_t n_rows, int64_t d,
+                              int dtype, void* stream);
+
 /* ------------------------------------------------------------------------
  * Dense neighbours of the aggregation
  * ---------------------------------------------------------------------- */

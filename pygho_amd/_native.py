@@ -66,6 +66,7 @@ PROTOTYPES = {
     "pygho_masked_reduce_bwd": (I, [P, P, P, P, P, L, L, L, L, I, I, P]),
     "pygho_masked_broadcast": (I, [P, P, P, D, L, L, L, L, I, P]),
     "pygho_masked_pair_combine": (I, [P, P, P, P, P, I, P, L, L, L, L, I, P]),
+    "pygho_pair_gather_combine": (I, [P, P, P, P, P, I, P, P, L, L, I, P]),
     "pygho_bn_workspace": (Z, [L, L, I]),
     "pygho_bn_stats": (I, [P, P, P, L, L, P, I, P]),
     "pygho_bn_prepare": (I, [P, P, P, P, P, P, L, L, P, P, D, P, P, D, P, I, P]),

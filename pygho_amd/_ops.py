@@ -1160,6 +1160,96 @@ def pair_linear_mix(x, y, w_x, w_y, u, v, dg, mask):
     return _PairLinearMix.apply(x, y, w_x, w_y, u, v, dg, mask)
 
 
+def pair_gather_combine(base: Optional[Tensor], row_term: Optional[Tensor], col_term: Optional[Tensor],
+                        diag_term: Optional[Tensor], replace_diag: bool, ri32: Tensor, ci32: Tensor, d: int, dtype, device) -> Tensor:
+    """sparse twin of masked_pair_combine: out[t] = (base[t] + row_term[ri[t]]) + col_term[ci[t]], diag_term[ri[t]] added on /
+    replacing the tuples with ri == ci (no autograd; `pygho_pair_gather_combine`)."""
+    ops = [None if t is None else t.contiguous() for t in (base, row_term, col_term, diag_term)]
+    for t in ops:
+        assert t is None or (t.dtype == dtype and t.device == device)
+    n_rows = ri32.numel()
+    out = torch.empty((n_rows, d), dtype=dtype, device=device)
+    check(lib().pygho_pair_gather_combine(ptr(out), ptr(ops[0]), ptr(ops[1]), ptr(ops[2]), ptr(ops[3]), 1 if replace_diag else 0,
+                                          ptr(ri32), ptr(ci32), n_rows, d, DTYPE_CODE[dtype], stream_ptr(device)),
+          "pair_gather_combine")
+    return out
+
+
+def pair_gather_supported(values: Tensor) -> bool:
+    return (values.is_cuda and values.dim() == 2 and values.dtype in (torch.float32, torch.bfloat16, torch.float16)
+            and (values.shape[1] * values.element_size()) % 16 == 0 and values.shape[1] * values.element_size() <= 4096)
+
+
+def _matched_rows(src: Tensor, pos: Tensor) -> Tensor:
+    """out[r] = pos[r] >= 0 ? src[pos[r]] : 0 (no autograd)."""
+    return row_gather(src, narrow_i32(pos.clamp_min(0)), (pos >= 0).to(_I32))
+
+
+class _SparsePairViews(torch.autograd.Function):
+    """(values of a sparse 2-D representation) -> (diagonal rows (n, d), sum over tuples sharing index 0, sum over tuples
+    sharing index 1); the three gradients return to the tuples in ONE gather pass."""
+
+    @staticmethod
+    def forward(ctx, values: Tensor, ri: Tensor, ci: Tensor, diag_pos: Tensor, n: int):
+        require_device(values, ri, ci, diag_pos)
+        values = values.contiguous()
+        dg = _matched_rows(values, diag_pos)
+        s_r = _ScatterReduce.apply(values, cached_plan(ri, n, "scatter"), narrow_i32(ri), "sum")
+        s_c = _ScatterReduce.apply(values, cached_plan(ci, n, "scatter"), narrow_i32(ci), "sum")
+        ctx.idx = (narrow_i32(ri), narrow_i32(ci))
+        ctx.meta = (values.shape[1], values.dtype)
+        return dg, s_r, s_c
+
+    @staticmethod
+    def backward(ctx, g_dg, g_r, g_c):
+        d, dtype = ctx.meta
+        ri32, ci32 = ctx.idx
+        cast = lambda t: None if t is None else t.to(dtype)
+        return pair_gather_combine(None, cast(g_r), cast(g_c), cast(g_dg), False, ri32, ci32, d, dtype, ri32.device), None, None, None, None
+
+
+def sparse_pair_views(values: Tensor, ri: Tensor, ci: Tensor, diag_pos: Tensor, n: int):
+    return _SparsePairViews.apply(values, ri, ci, diag_pos, n)
+
+
+class _SparsePairLinearMix(torch.autograd.Function):
+    """out[t] = (i == j) ? dg[i] : ((x[t] @ w_x + y[t] @ w_y) + u[i]) + v[j] for the tuple t = (i, j): `_PairLinearMix` on the
+    sparse layout (SUNConv mode "SS")."""
+
+    @staticmethod
+    def forward(ctx, x, y, w_x, w_y, u, v, dg, ri, ci, diag_pos, n):
+        require_device(x, y, ri, ci)
+        x, y = x.contiguous(), y.contiguous()
+        ri32, ci32 = narrow_i32(ri), narrow_i32(ci)
+        ab = _dense_linear(y, w_y, _dense_linear(x, w_x))
+        out = pair_gather_combine(ab, u, v, dg, True, ri32, ci32, w_x.shape[1], x.dtype, x.device)
+        ctx.save_for_backward(x, y, w_x, w_y)
+        ctx.idx = (ri, ci, diag_pos, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, w_x, w_y = ctx.saved_tensors
+        ri, ci, diag_pos, n = ctx.idx
+        ri32, ci32 = narrow_i32(ri), narrow_i32(ci)
+        g = g.contiguous()
+        d_out = w_x.shape[1]
+        zeros = torch.zeros((n, d_out), dtype=g.dtype, device=g.device)
+        goff = pair_gather_combine(g, None, None, zeros, True, ri32, ci32, d_out, g.dtype, g.device)   # diagonal tuples zeroed
+        gu = _ScatterReduce.apply(goff, cached_plan(ri, n, "scatter"), ri32, "sum")
+        gv = _ScatterReduce.apply(goff, cached_plan(ci, n, "scatter"), ci32, "sum")
+        gdg = _matched_rows(g, diag_pos)
+        gx = _dense_linear(goff, w_x.t()) if ctx.needs_input_grad[0] else None
+        gy = _dense_linear(goff, w_y.t()) if ctx.needs_input_grad[1] else None
+        gwx = weight_grad_splitk(goff, x, w_x.dtype).t() if ctx.needs_input_grad[2] else None
+        gwy = weight_grad_splitk(goff, y, w_y.dtype).t() if ctx.needs_input_grad[3] else None
+        return gx, gy, gwx, gwy, gu, gv, gdg, None, None, None, None
+
+
+def sparse_pair_linear_mix(x, y, w_x, w_y, u, v, dg, ri, ci, diag_pos, n):
+    return _SparsePairLinearMix.apply(x, y, w_x, w_y, u, v, dg, ri, ci, diag_pos, n)
+
+
 def _bmm_launch(A: Tensor, B: Tensor, amask, bmask, omask, nb, ni, nk, nj, d, a_kfirst: bool, b_kfirst: bool) -> Tensor:
     dev = require_device(A, B, amask, bmask, omask)
     out = torch.empty((nb, ni, nj, d), dtype=A.dtype, device=dev)

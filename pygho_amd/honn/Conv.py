@@ -20,7 +20,7 @@ from .SpOperator import KEYSEP, OpMessagePassing
 from .utils import MLP, _SplitKLinearFn
 from .. import _ops
 from ..backend.MaTensor import MaskedTensor
-from ..backend.SpTensor import SparseTensor
+from ..backend.SpTensor import SparseTensor, indicehash
 
 Rep = Union[SparseTensor, MaskedTensor]
 
@@ -291,10 +291,14 @@ class SUNConv(Module):
         add = lambda a, b: a.add(b, True) if isinstance(a, (SparseTensor, MaskedTensor)) else a + b
 
         agg = self.aggr.forward(A, X.tuplewiseapply(self.lin0), datadict, X)
-        if (_ops.USE_PAIR_COMBINE and isinstance(X, MaskedTensor) and isinstance(agg, MaskedTensor) and X.masked_dim == 3
-                and self._pool in ("sum", "mean") and _ops.pair_combine_supported(X.raw) and agg.raw.dtype == X.raw.dtype
-                and agg.raw.shape == X.raw.shape):
-            return self._recombine_dense(X, agg, blk).tuplewiseapply(self.lin1_1)
+        if _ops.USE_PAIR_COMBINE and self._pool in ("sum", "mean"):
+            if (isinstance(X, MaskedTensor) and isinstance(agg, MaskedTensor) and X.masked_dim == 3
+                    and _ops.pair_combine_supported(X.raw) and agg.raw.dtype == X.raw.dtype and agg.raw.shape == X.raw.shape):
+                return self._recombine(X, agg, blk, dense=True).tuplewiseapply(self.lin1_1)
+            if (isinstance(X, SparseTensor) and isinstance(agg, SparseTensor) and X.sparse_dim == 2 and X.values is not None
+                    and agg.values is not None and _ops.pair_gather_supported(X.values) and agg.values.dtype == X.values.dtype
+                    and agg.values.shape == X.values.shape and agg.nnz == X.nnz and X.shape[0] == X.shape[1]):
+                return self._recombine(X, agg, blk, dense=False).tuplewiseapply(self.lin1_1)
         centre, n5, n6, n7 = self.diag.forward(X), self.pool2node(X), self.pool2subg(X), self.pool2node(agg)
         # concat order of the reference: [X, to_nodes(centre), to_root(centre), agg, to_root(n5), to_nodes(n6), to_root(n7)]
         off = add(lin(X, blk(0, 0)), lin(agg, blk(0, 3)))
@@ -311,28 +315,52 @@ class SUNConv(Module):
             picked = off.diagonalapply(lambda val, is_diag: torch.where(is_diag.bool().unsqueeze(-1), dg_t.values.to(val.dtype), val))
         return picked.tuplewiseapply(self.lin1_1)
 
-    def _recombine_dense(self, X: MaskedTensor, agg: MaskedTensor, blk) -> MaskedTensor:
-        """the same arithmetic on the padded layout with the tuple-level passes fused: the node-level views of X and agg
-        (diagonal, pool over subgraphs, pool over nodes) come from one autograd node each (their gradients return to the
-        tuple level in one pass, ``_ops.pair_views``); the two tuple-level GEMMs, the three broadcasts, the three adds and
-        the diagonal select are ``_ops.pair_linear_mix`` (two GEMM launches + one pass)."""
-        mask, amask = X.mask, agg.mask
-        dt = X.raw.dtype
+    def _recombine(self, X: Rep, agg: Rep, blk, dense: bool) -> Rep:
+        """the same arithmetic with the tuple-level passes fused, on the padded (``dense``) or the sparse layout: the
+        node-level views of X and agg (diagonal, pool over subgraphs, pool over nodes) come from one autograd node each
+        (their gradients return to the tuple level in one pass: ``_ops.pair_views`` / ``_ops.sparse_pair_views``); the two
+        tuple-level GEMMs, the three broadcasts, the three adds and the diagonal select are ``_ops.pair_linear_mix`` /
+        ``_ops.sparse_pair_linear_mix`` (two GEMM launches + one pass)."""
+        if dense:
+            mask, amask = X.mask, agg.mask
+            xv, av = X.raw, agg.raw
+            dt, d_ = xv.dtype, xv.shape[-1]
+
+            def views(vals, m):
+                dg, s1, s2 = _ops.pair_views(vals, m)               # rows (b,i,i); sum over dim 1 -> [b,j]; over dim 2 -> [b,i]
+                if self._pool == "mean":
+                    s1 = s1 / m.sum(1).clamp_min(1).unsqueeze(-1).to(dt)
+                    s2 = s2 / m.sum(2).clamp_min(1).unsqueeze(-1).to(dt)
+                return dg, s1, s2                                   # (centre, pool2node, pool2subg)
+
+            centre, n5, n6 = views(xv, mask)
+            agg_dg, n7, _unused = views(av, amask)
+        else:
+            xv, av = X.values, agg.values
+            dt, d_ = xv.dtype, xv.shape[-1]
+            n = X.shape[0]
+            ri, ci = X._row(0), X._row(1)
+            cache = X._cache()
+            if "sun_views" not in cache:
+                diag_idx = torch.arange(n, device=ri.device)
+                pos = _ops.sorted_match(X._hash(), indicehash(diag_idx.reshape(1, -1).expand(2, -1).contiguous()))
+                cnt = lambda r: torch.bincount(r, minlength=n).clamp_min(1).unsqueeze(-1)
+                cache["sun_views"] = (pos, cnt(ri), cnt(ci))
+            pos, cnt_r, cnt_c = cache["sun_views"]
+
+            def views(vals):
+                dg, s_r, s_c = _ops.sparse_pair_views(vals, ri, ci, pos, n)  # rows (i,i); sum over j -> [i]; sum over i -> [j]
+                if self._pool == "mean":
+                    s_r, s_c = s_r / cnt_r.to(dt), s_c / cnt_c.to(dt)
+                return dg, s_c, s_r                                 # (centre, pool2node, pool2subg)
+
+            centre, n5, n6 = views(xv)
+            agg_dg, n7, _unused = views(av)
         w = lambda t, v: blk(t, v).to(dt)
 
-        def views(rep_raw, m):
-            dg, s1, s2 = _ops.pair_views(rep_raw, m)                # rows (b,i,i); sum over dim 1 -> [b,j]; over dim 2 -> [b,i]
-            if self._pool == "mean":
-                s1 = s1 / m.sum(1).clamp_min(1).unsqueeze(-1).to(dt)
-                s2 = s2 / m.sum(2).clamp_min(1).unsqueeze(-1).to(dt)
-            return dg, s1, s2
-
-        centre, n5, n6 = views(X.raw, mask)                         # n5 = pool2node (dim 1), n6 = pool2subg (dim 2)
-        agg_dg, n7, _unused = views(agg.raw, amask)
-
         def node_lin(parts, blocks):
-            """sum_k parts[k] @ blocks[k] as ONE product over the concatenated reduction dim: (b n, k d) rows are few, so
-            the concatenation is cheap, and the weight gradient (reduction over b n rows into a d x d tile) runs on the
+            """sum_k parts[k] @ blocks[k] as ONE product over the concatenated reduction dim: node-level rows are few, so
+            the concatenation is cheap, and the weight gradient (reduction over all nodes into a d x d tile) runs on the
             split-K kernel once instead of k times on a single-tile library GEMM."""
             x = torch.cat(parts, dim=-1).reshape(-1, len(parts) * d_)
             wt = torch.cat(blocks, dim=0).to(dt)                    # (k d, d)
@@ -342,11 +370,13 @@ class SUNConv(Module):
                 y = x @ wt
             return y.reshape(parts[0].shape[:-1] + (wt.shape[1],))
 
-        d_ = X.raw.shape[-1]
-        # unpooling [2] repeats a node tensor along j (term indexed by i), unpooling [1] along i (term indexed by j)
+        # unpooling along dim 1 repeats a node tensor over j (term indexed by i), along dim 0 over i (term indexed by j)
         u = node_lin([centre, n6], [blk(0, 1), blk(0, 5)])                                  # to_nodes(...)
         v = node_lin([centre, n5, n7], [blk(0, 2), blk(0, 4), blk(0, 6)])                   # to_root(...)
         dg = node_lin([centre, agg_dg, n5, n6, n7],
                       [blk(1, 0) + blk(1, 1) + blk(1, 2), blk(1, 3), blk(1, 4), blk(1, 5), blk(1, 6)])
-        out = _ops.pair_linear_mix(X.raw, agg.raw, w(0, 0), w(0, 3), u.contiguous(), v.contiguous(), dg.contiguous(), mask)
-        return MaskedTensor(out, mask, 0.0, True)
+        if dense:
+            out = _ops.pair_linear_mix(xv, av, w(0, 0), w(0, 3), u.contiguous(), v.contiguous(), dg.contiguous(), mask)
+            return MaskedTensor(out, mask, 0.0, True)
+        out = _ops.sparse_pair_linear_mix(xv, av, w(0, 0), w(0, 3), u.contiguous(), v.contiguous(), dg.contiguous(), ri, ci, pos, n)
+        return X.tuplewiseapply(lambda _: out)

@@ -615,3 +615,46 @@ def test_concat_block_layers(dev, name):
         torch.testing.assert_close(res[True][2][k] / s, ref / s, rtol=0, atol=4e-2, msg=k)
     for k, ref in res[False][3].items():                   # running statistics updated the same way
         torch.testing.assert_close(res[True][3][k].float(), ref.float(), rtol=2e-2, atol=2e-2, msg=k)
+
+
+@pytest.mark.parametrize("case", ["f32_small", "bf16_rowblock"])
+def test_sunconv_sparse_fused_passes(dev, case):
+    """SUNConv mode "SS" with the fused node-view / recombination passes (sparse_pair_views, sparse_pair_linear_mix ->
+    pygho_pair_gather_combine) against the same layer with separate gather / add / select passes."""
+    import copy
+    from pygho_amd import SparseTensor, synth, _ops
+    from pygho_amd.honn import Conv
+    from pygho_amd.honn.SpOperator import parse_precomputekey
+    if case == "f32_small":
+        h, nb, amp, tol = 16, 6, False, dict(rtol=0, atol=2e-5)
+    else:
+        h, nb, amp, tol = 128, 64, True, dict(rtol=0, atol=6e-2)
+    torch.manual_seed(1)
+    layer = Conv.SUNConv(h, h, "sum", "mean", "SS", dict(MLP), dict(MLP)).to(dev)
+    hb = synth.make_batch(nb, "zinc", seed=31, keys=tuple(parse_precomputekey(layer)))
+    dd = synth.to_datadict(hb, dev)
+    X0, A0 = dd["X"], dd["A"]
+    dt = torch.bfloat16 if amp else torch.float32
+    xv0 = torch.randn(X0.nnz, h, device=dev).to(dt)
+    A = SparseTensor(A0.indices, (torch.randn(A0.nnz, h, device=dev) * 0.5).to(dt), list(A0.shape[:2]) + [h], True)
+    w = torch.randn(X0.nnz, h, device=dev).to(dt)
+    res = {}
+    for fused in (True, False):
+        _ops.USE_PAIR_COMBINE = fused
+        try:
+            lay = copy.deepcopy(layer)
+            xv = xv0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                out = lay(A, SparseTensor(X0.indices, xv, list(X0.shape[:2]) + [h], True), dd)
+            out.values.backward(w)
+            res[fused] = (out.values.detach().float(), xv.grad.float(), {k: p.grad.float() for k, p in lay.named_parameters()})
+        finally:
+            _ops.USE_PAIR_COMBINE = True
+    for i in (0, 1):
+        s = float(res[False][i].abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][i] / s, res[False][i] / s, **tol)
+    for k, ref in res[False][2].items():
+        if k.endswith(".lins.0.bias"):
+            continue                                       # bias in front of a BatchNorm: zero up to rounding noise
+        s = float(ref.abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][2][k] / s, ref / s, msg=k, **tol)

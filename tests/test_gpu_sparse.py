@@ -526,3 +526,67 @@ def test_activation_on_load_bit_identical(dev, dtype, act):
         ref = _ops.seg_gmr(ne, G, H, p.seg_ptr, a_g, c_g, "sum", rs)
         got = _ops.seg_gmr(ne, G, Y, p.seg_ptr, a_g, c_g, "sum", rs, act=(scale, shift, act, 2))
         assert torch.equal(ref, got)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d", [8, 128, 24])
+def test_pair_gather_combine(dev, dtype, d):
+    """sparse recombination out[t] = (base[t] + row_term[i_t]) + col_term[j_t] with the diagonal tuples' term added / substituted,
+    every operand optional, ragged tails (row counts that do not fill the last workgroup)."""
+    from pygho_amd import _ops
+    gen = torch.Generator().manual_seed(d)
+    n, nnz = 37, 1003
+    ri = torch.randint(0, n, (nnz,), generator=gen)
+    ci = torch.randint(0, n, (nnz,), generator=gen)
+    ci[::7] = ri[::7]                                            # plenty of diagonal tuples
+    base = torch.randn((nnz, d), generator=gen).to(dtype)
+    rt, ct, dg = (torch.randn((n, d), generator=gen).to(dtype) for _ in range(3))
+    ri32, ci32 = ri.to(torch.int32).to(dev), ci.to(torch.int32).to(dev)
+    if (d * base.element_size()) % 16 != 0:
+        assert not _ops.pair_gather_supported(base.to(dev))
+        with pytest.raises(RuntimeError, match="16-byte"):
+            _ops.pair_gather_combine(base.to(dev), None, None, None, False, ri32, ci32, d, dtype, dev)
+        return
+    on_diag = (ri == ci)[:, None]
+    for use in ((1, 1, 1, 1), (0, 1, 1, 1), (1, 0, 0, 1), (1, 1, 0, 0), (0, 0, 1, 0)):
+        for replace in (False, True):
+            args = [t.to(dev) if u else None for t, u in zip((base, rt, ct, dg), use)]
+            out = _ops.pair_gather_combine(*args, replace, ri32, ci32, d, dtype, dev)
+            acc = base.float() if use[0] else torch.zeros((nnz, d))
+            if use[1]:
+                acc = acc + rt.float()[ri]
+            if use[2]:
+                acc = acc + ct.float()[ci]
+            if use[3]:
+                acc = torch.where(on_diag, dg.float()[ri], acc) if replace else torch.where(on_diag, acc + dg.float()[ri], acc)
+            assert torch.equal(out.cpu(), acc.to(dtype)), (use, replace)
+
+
+def test_sparse_pair_views_gradient_one_pass(dev):
+    """(diagonal rows, per-i sums, per-j sums) of a sparse 2-D representation and their joint gradient against autograd through
+    index_add / indexing on the CPU."""
+    from pygho_amd import _ops
+    from pygho_amd.backend.SpTensor import indicehash
+    gen = torch.Generator().manual_seed(2)
+    n, d = 23, 8
+    dense_mask = torch.rand((n, n), generator=gen) > 0.6
+    dense_mask[5, 5] = False                                     # a node without its diagonal tuple
+    dense_mask[torch.arange(0, n, 2), torch.arange(0, n, 2)] = True
+    ri, ci = dense_mask.nonzero(as_tuple=True)
+    nnz = ri.numel()
+    x = torch.randn((nnz, d), generator=gen)
+    ind = torch.stack((ri, ci)).to(dev)
+    diag_idx = torch.arange(n, device=dev)
+    pos = _ops.sorted_match(indicehash(ind), indicehash(diag_idx.reshape(1, -1).expand(2, -1).contiguous()))
+    xd = x.to(dev).requires_grad_(True)
+    dg, s_r, s_c = _ops.sparse_pair_views(xd, ind[0].contiguous(), ind[1].contiguous(), pos, n)
+    ws = [torch.randn((n, d), generator=gen) for _ in range(3)]
+    ((dg * ws[0].to(dev)).sum() + (s_r * ws[1].to(dev)).sum() + (s_c * ws[2].to(dev)).sum()).backward()
+    xr = x.clone().requires_grad_(True)
+    rdg = torch.zeros((n, d)).index_add(0, ri[ri == ci], xr[ri == ci])
+    r_r = torch.zeros((n, d)).index_add(0, ri, xr)
+    r_c = torch.zeros((n, d)).index_add(0, ci, xr)
+    ((rdg * ws[0]).sum() + (r_r * ws[1]).sum() + (r_c * ws[2]).sum()).backward()
+    for got, ref in ((dg, rdg), (s_r, r_r), (s_c, r_c)):
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-6, atol=1e-6)
