@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kBlock) void pair_gather_combine_kernel(T* __restri
     vb[u] = base ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + (rr * chunks + ch) * 16) : zero;
     vr[u] = row_term ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(row_term) + ((int64_t)i[u] * chunks + ch) * 16) : zero;
     vc[u] = col_term ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(col_term) + ((int64_t)j[u] * chunks + ch) * 16) : zero;
-    vd[u] = diag_term ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(diag_term) + ((int64_t)i[u] * chunks + ch) * 16) : zero;
+    vd[u] = (diag_term && i[u] == j[u]) ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(diag_term) + ((int64_t)i[u] * chunks + ch) * 16) : zero;   // 1 tuple in ~10
   }
 #pragma unroll
   for (int u = 0; u < kPairRowsPerLane; ++u) {
