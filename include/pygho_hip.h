@@ -265,6 +265,23 @@ int pygho_collate_rows(int64_t* out, const int32_t* src, int64_t rows, int64_t s
                        const int64_t* src_start, const int64_t* out_ptr, const int64_t* inc, int64_t n_sel,
                        int64_t total, void* stream);
 
+/* Padded-batch builders of the dense path (hodata/MaData.py:108-147 to_dense_x, :150-214 to_dense_tuplefeat): graph b owns a
+ * row-major grid of shape[b, 0..nd-1] rows starting at source row ptr[b]; with the grid dims right-aligned in (m0, m1, m2)
+ * (a 1-D grid is (1, 1, m2)):
+ *   out[b, i0, i1, i2, :] = src[min(ptr[b] + (i0 * s1 + i1) * s2 + i2, n_src - 1), :]      (s = shape[b], clamped like the reference)
+ *   mask[b, i0, i1, i2]   = i0 < s0 && i1 < s1 && i2 < s2
+ * Rows are row_bytes bytes of any dtype.  nd in 1..3; shape is (nb, nd) int64, ptr (nb + 1) int64. */
+int pygho_pad_stack(void* out, uint8_t* mask, const void* src, const int64_t* ptr, const int64_t* shape, int64_t nb, int nd,
+                    int64_t m0, int64_t m1, int64_t m2, int64_t row_bytes, int64_t n_src, void* stream);
+
+/* Dense adjacency of a batch (hodata/MaData.py:25-72 to_dense_adj): out (nb, n, n, row) is filled with the pad element
+ * (fill_bits = its bit pattern, elem_size = 1 / 2 / 4 / 8 bytes), mask (nb, n, n) with 0, then
+ *   out[edge_batch[e], edge_row[e], edge_col[e], :] = edge_attr[e, :],  mask[...] = 1      e < nnz
+ * (graph-local coalesced edge indices: no duplicates).  Rows are row_bytes bytes of any dtype. */
+int pygho_dense_adj(void* out, uint8_t* mask, const void* edge_attr, const int64_t* edge_batch, const int64_t* edge_row,
+                    const int64_t* edge_col, int64_t nnz, int64_t nb, int64_t n, int64_t row_bytes, uint64_t fill_bits,
+                    int elem_size, void* stream);
+
 /* ------------------------------------------------------------------------
  * Masked (dense) path
  * ---------------------------------------------------------------------- */
@@ -282,7 +299,8 @@ int pygho_masked_bmm(void* out, const void* A, const void* B, const uint8_t* ama
                      int64_t nk, int64_t nj, int64_t d, int a_kfirst, int b_kfirst, int dtype,
                      void* stream);
 
-/* out = mask ? data : value over (n_rows, d) with a per-row uint8 mask.  MaTensor.py:113-128. */
+/* out = mask ? data : value over (n_rows, d) with a per-row uint8 mask.  MaTensor.py:113-128.  Every dtype code
+ * (integer features -- node / bond types, distance ids -- are legal MaskedTensor data: hodata/MaData.py:108-214). */
 int pygho_masked_fill(void* out, const void* data, const uint8_t* mask, double value,
                       int64_t n_rows, int64_t d, int dtype, void* stream);
 

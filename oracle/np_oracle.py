@@ -512,3 +512,62 @@ def spmamm(indA, valA, shapeA, dim1: int, dataB, maskB, dim2: int, aggr: str = "
     if aggr in ("max", "min"):
         out = filterinf(out)
     return out
+
+
+# --------------------------------------------------------------------------
+# padded-batch builders of the dense path (reference pygho/hodata/MaData.py)
+# --------------------------------------------------------------------------
+def to_dense_x(nodeX: np.ndarray, ptr: np.ndarray, max_num_nodes: int | None = None):
+    """MaData.py:108-147: ret[b, k] = nodeX[min(ptr[b] + k, ptr[-1] - 1)], mask[b, k] = k < ptr[b+1] - ptr[b].
+    Returns (raw, mask): the raw array carries clamped neighbours in the padded slots (the reference constructs the
+    MaskedTensor unfilled), consumers must look at it through the mask."""
+    ptr = np.asarray(ptr, dtype=np.int64)
+    counts = np.diff(ptr)
+    if max_num_nodes is None:
+        max_num_nodes = int(counts.max())
+    k = np.arange(max_num_nodes, dtype=np.int64)[None, :]
+    idx = np.minimum(ptr[:-1, None] + k, ptr[-1] - 1)
+    return nodeX[idx], k < counts[:, None]
+
+
+def to_dense_tuplefeat(tuplefeat: np.ndarray, tupleshape: np.ndarray, tptr: np.ndarray, max_tupleshape=None):
+    """MaData.py:150-214: graph b holds a row-major (tupleshape[b]) grid starting at tptr[b];
+    ret[b, i_1..i_k] = tuplefeat[min(tptr[b] + sum_j i_j * prod_{l>j} tupleshape[b, l], N - 1)],
+    mask[b, i_1..i_k] = all_j (i_j < tupleshape[b, j])."""
+    tupleshape = np.asarray(tupleshape, dtype=np.int64)
+    nb, nd = tupleshape.shape
+    if max_tupleshape is None:
+        max_tupleshape = tupleshape.max(0)
+    max_tupleshape = [int(v) for v in max_tupleshape]
+    full = np.asarray(tptr, dtype=np.int64)[:-1].reshape([nb] + [1] * nd)
+    mask = np.ones([nb] + max_tupleshape, dtype=bool)
+    stride = np.ones(nb, dtype=np.int64)
+    for j in range(nd - 1, -1, -1):
+        ar = np.arange(max_tupleshape[j], dtype=np.int64)
+        shp = [1] * (nd + 1)
+        shp[j + 1] = -1
+        bs = [nb] + [1] * nd
+        full = full + ar.reshape(shp) * stride.reshape(bs)
+        mask &= ar.reshape(shp) < tupleshape[:, j].reshape(bs)
+        stride = stride * tupleshape[:, j]
+    full = np.minimum(full, tuplefeat.shape[0] - 1)
+    return tuplefeat[full], mask
+
+
+def to_dense_adj(edge_index: np.ndarray, edge_batch: np.ndarray, edge_attr, max_num_nodes: int, batch_size: int,
+                 filled_value=0):
+    """MaData.py:25-72: ret = full(filled_value); ret[edge_batch, edge_index[0], edge_index[1]] = edge_attr (ones when
+    absent); mask marks the written slots."""
+    if edge_attr is None:
+        edge_attr = np.ones(edge_batch.shape[0], dtype=np.float32)
+    ret = np.full([batch_size, max_num_nodes, max_num_nodes] + list(edge_attr.shape[1:]), filled_value, dtype=edge_attr.dtype)
+    mask = np.zeros((batch_size, max_num_nodes, max_num_nodes), dtype=bool)
+    ret[edge_batch, edge_index[0], edge_index[1]] = edge_attr
+    mask[edge_batch, edge_index[0], edge_index[1]] = True
+    return ret, mask
+
+
+def to_sparse_adj(edge_index: np.ndarray, edge_batch: np.ndarray, edge_attr: np.ndarray, max_num_nodes: int, batch_size: int):
+    """MaData.py:75-105: indices (3, nnz) = [edge_batch; edge_index], values = edge_attr, shape (b, n, n, *dense)."""
+    ind = np.concatenate((edge_batch[None, :], edge_index), axis=0)
+    return ind, edge_attr, [batch_size, max_num_nodes, max_num_nodes] + list(edge_attr.shape[1:])

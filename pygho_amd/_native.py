@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_uint64, c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
 from typing import Optional
 
 import torch
@@ -58,6 +58,8 @@ PROTOTYPES = {
     "pygho_gather_i32_to_i64": (I, [P, P, P, L, P]),
     "pygho_plan_triples": (I, [P, P, P, P, P, L, P]),
     "pygho_collate_rows": (I, [P, P, L, L, L, P, P, P, L, L, P]),
+    "pygho_pad_stack": (I, [P, P, P, P, P, L, I, L, L, L, L, L, P]),
+    "pygho_dense_adj": (I, [P, P, P, P, P, P, L, L, L, L, c_uint64, I, P]),
     "pygho_flag_scan_nonneg": (I, [P, P, P, L, P, Z, P]),
     "pygho_compact_positions": (I, [P, P, L, P]),
     "pygho_masked_bmm": (I, [P, P, P, P, P, P, L, L, L, L, L, I, I, I, P]),

@@ -1045,6 +1045,49 @@ def masked_broadcast(src: Tensor, mask: Tensor, dim: int, value: float, src_mask
     return _MaskedBroadcast.apply(src, mask, dim, value, src_masked_dim)
 
 
+def pad_stack(src: Tensor, start: Tensor, shape: Tensor, max_shape) -> Tuple[Tensor, Tensor]:
+    """ragged per-graph grids -> padded (nb, *max_shape, *dense) + bool mask (`pygho_pad_stack`; hodata/MaData.py:108-214).
+    graph b owns the rows [start[b], start[b] + prod(shape[b])) of src as a row-major grid of shape[b]."""
+    dev = require_device(src, start, shape)
+    src = src.contiguous()
+    start = start.to(torch.int64).contiguous()
+    shape = shape.to(torch.int64).contiguous()
+    nb, nd = shape.shape
+    assert len(max_shape) == nd and 1 <= nd <= 3, "1 to 3 grid dims"
+    assert start.numel() == nb + 1
+    m = [1] * (3 - nd) + [int(v) for v in max_shape]
+    tail = tuple(src.shape[1:])
+    row_bytes = src.element_size()
+    for t in tail:
+        row_bytes *= t
+    out = torch.empty((nb,) + tuple(int(v) for v in max_shape) + tail, dtype=src.dtype, device=dev)
+    mask = torch.empty((nb,) + tuple(int(v) for v in max_shape), dtype=torch.uint8, device=dev)
+    check(lib().pygho_pad_stack(ptr(out), ptr(mask), ptr(src), ptr(start), ptr(shape), nb, nd, m[0], m[1], m[2], row_bytes,
+                                src.shape[0], stream_ptr(dev)), "pad_stack")
+    return out, mask.view(torch.bool)
+
+
+def dense_adj(edge_index: Tensor, edge_batch: Tensor, edge_attr: Tensor, n: int, nb: int, filled_value=0) -> Tuple[Tensor, Tensor]:
+    """(nb, n, n, *dense) filled with `filled_value`, edge_attr scattered at (edge_batch, edge_index[0], edge_index[1]), + mask
+    (`pygho_dense_adj`; hodata/MaData.py:25-72)."""
+    dev = require_device(edge_index, edge_batch, edge_attr)
+    edge_attr = edge_attr.contiguous()
+    eb = edge_batch.to(torch.int64).contiguous()
+    er, ec = edge_index[0].to(torch.int64).contiguous(), edge_index[1].to(torch.int64).contiguous()
+    tail = tuple(edge_attr.shape[1:])
+    es = edge_attr.element_size()
+    row_bytes = es
+    for t in tail:
+        row_bytes *= t
+    out = torch.empty((nb, n, n) + tail, dtype=edge_attr.dtype, device=dev)
+    mask = torch.empty((nb, n, n), dtype=torch.uint8, device=dev)
+    view = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[es]
+    bits = int(torch.tensor([filled_value], dtype=edge_attr.dtype).view(view).item()) & ((1 << (8 * es)) - 1)
+    check(lib().pygho_dense_adj(ptr(out), ptr(mask), ptr(edge_attr), ptr(eb), ptr(er), ptr(ec), eb.numel(), nb, n, row_bytes,
+                                bits, es, stream_ptr(dev)), "dense_adj")
+    return out, mask.view(torch.bool)
+
+
 def pair_combine_supported(data: Tensor) -> bool:
     return (data.is_cuda and data.dim() == 4 and data.dtype in (torch.float32, torch.bfloat16, torch.float16)
             and (data.shape[-1] * data.element_size()) % 16 == 0 and data.shape[-1] * data.element_size() <= 4096)

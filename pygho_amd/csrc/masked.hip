@@ -328,17 +328,20 @@ static uint16_t host_f32_to_bf16(float f) {
 
 // 16-byte pattern of the pad value, or false when the dtype / row size has no 16-byte form
 static bool vec_pattern(int dtype, int64_t d, double value, uint4* pat, int* chunks) {
-  uint32_t w;
+  uint32_t w0, w1;
   int es;
   switch (dtype) {
-    case PYGHO_F32: { float f = (float)value; memcpy(&w, &f, 4); es = 4; break; }
-    case PYGHO_BF16: { const uint16_t h = host_f32_to_bf16((float)value); w = (uint32_t)h | ((uint32_t)h << 16); es = 2; break; }
-    case PYGHO_F16: { _Float16 h = (_Float16)value; uint16_t b; memcpy(&b, &h, 2); w = (uint32_t)b | ((uint32_t)b << 16); es = 2; break; }
+    case PYGHO_F32: { float f = (float)value; memcpy(&w0, &f, 4); w1 = w0; es = 4; break; }
+    case PYGHO_BF16: { const uint16_t h = host_f32_to_bf16((float)value); w0 = w1 = (uint32_t)h | ((uint32_t)h << 16); es = 2; break; }
+    case PYGHO_F16: { _Float16 h = (_Float16)value; uint16_t b; memcpy(&b, &h, 2); w0 = w1 = (uint32_t)b | ((uint32_t)b << 16); es = 2; break; }
+    case PYGHO_F64: { uint64_t b; memcpy(&b, &value, 8); w0 = (uint32_t)b; w1 = (uint32_t)(b >> 32); es = 8; break; }
+    case PYGHO_I64: { const int64_t v = (int64_t)value; uint64_t b; memcpy(&b, &v, 8); w0 = (uint32_t)b; w1 = (uint32_t)(b >> 32); es = 8; break; }
+    case PYGHO_I32: { const int32_t v = (int32_t)value; memcpy(&w0, &v, 4); w1 = w0; es = 4; break; }
     default: return false;
   }
   const int64_t row_bytes = d * es;
   if (row_bytes % 16 != 0 || row_bytes / 16 > kBlock) return false;
-  *pat = make_uint4(w, w, w, w);
+  *pat = make_uint4(w0, w1, w0, w1);
   *chunks = (int)(row_bytes / 16);
   return true;
 }
@@ -370,6 +373,12 @@ extern "C" int pygho_masked_fill(void* out, const void* data, const uint8_t* mas
       break;
     case PYGHO_F64:
       hipLaunchKernelGGL((masked_fill_kernel<double>), grid, block, 0, st, (double*)out, (const double*)data, mask, value, n_rows, d);
+      break;
+    case PYGHO_I64:
+      hipLaunchKernelGGL((masked_fill_kernel<int64_t>), grid, block, 0, st, (int64_t*)out, (const int64_t*)data, mask, (int64_t)value, n_rows, d);
+      break;
+    case PYGHO_I32:
+      hipLaunchKernelGGL((masked_fill_kernel<int32_t>), grid, block, 0, st, (int32_t*)out, (const int32_t*)data, mask, (int32_t)value, n_rows, d);
       break;
     case PYGHO_BF16: {
       uint16_t v = 0;
@@ -529,6 +538,12 @@ extern "C" int pygho_masked_broadcast(void* out, const void* src, const uint8_t*
       break;
     case PYGHO_F64:
       hipLaunchKernelGGL((masked_broadcast_kernel<double>), grid, block, 0, st, (double*)out, (const double*)src, mask, value, outer, r, inner, d);
+      break;
+    case PYGHO_I64:
+      hipLaunchKernelGGL((masked_broadcast_kernel<int64_t>), grid, block, 0, st, (int64_t*)out, (const int64_t*)src, mask, (int64_t)value, outer, r, inner, d);
+      break;
+    case PYGHO_I32:
+      hipLaunchKernelGGL((masked_broadcast_kernel<int32_t>), grid, block, 0, st, (int32_t*)out, (const int32_t*)src, mask, (int32_t)value, outer, r, inner, d);
       break;
     case PYGHO_BF16:
       hipLaunchKernelGGL((masked_broadcast_kernel<uint16_t>), grid, block, 0, st, (uint16_t*)out, (const uint16_t*)src, mask,

@@ -11,6 +11,7 @@ import json
 import os
 import sys
 
+import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -199,6 +200,35 @@ def collate_case(graphs, dev):
             "ms": sorted(ts)[len(ts) // 2], "int64_MB_not_shipped_over_PCIe": out_bytes / 1e6}
 
 
+def dense_collate_case(b, n, d, dev):
+    """padded-batch construction of the dense layout on the device (hodata/MaData.py:217-255 batch2dense): ragged per-graph
+    tuple features (n_g x n_g x d, bf16), node features and a COO adjacency -> (b, n, n, d) MaskedTensors."""
+    import types
+    from pygho_amd.hodata import batch2dense
+    dn = synth.make_dense_batch(min(b, 256), seed=4, hidden=d, nmax=n)
+    rep = max(1, b // min(b, 256))
+    nm = np.tile(dn["nodemask"], (rep, 1))
+    counts = nm.sum(1).astype(np.int64)
+    bb = counts.shape[0]
+    ptr = np.concatenate(([0], np.cumsum(counts)))
+    tptr = np.concatenate(([0], np.cumsum(counts * counts)))
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    tf = torch.randn((int(tptr[-1]), d), generator=gen).to(torch.bfloat16).to(dev)
+    Am = np.tile(dn["Amask"], (rep, 1, 1))
+    eb, er, ec = np.nonzero(Am)
+    ea = torch.randn((eb.shape[0], d), generator=gen).to(torch.bfloat16).to(dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    base = dict(x=t(np.zeros(int(ptr[-1]), dtype=np.int64)), ptr=t(ptr), edge_index=t(np.stack((er, ec))), edge_index_batch=t(eb),
+                edge_attr=ea, tuplefeat=tf, tupleshape=t(np.stack((counts, counts), 1)), tuplefeat_ptr=t(tptr))
+
+    def run():
+        return batch2dense(types.SimpleNamespace(**base), batch_size=bb, max_num_nodes=n, denseadj=True)
+    ms = timed(run, reps=20)
+    out_bytes = 2 * bb * n * n * d * 2 + 2 * bb * n * n
+    return {"op": "device batch2dense (padded dense batch)", "b": bb, "n": n, "d": d, "dtype": "bfloat16", "ms": ms,
+            "tuples": int(tptr[-1]), "edges": int(eb.shape[0]), "written_MB": out_bytes / 1e6, "GBps_written": out_bytes / ms / 1e6}
+
+
 def mamamm_case(b, n, d, dtype, dev):
     from pygho_amd import MaskedTensor
     from pygho_amd.backend.Mamamm import mamamm
@@ -241,6 +271,7 @@ def main():
     out.append(graph_step_case(1024, dev))
     out.append(planner_case("zinc", 1024 if args.quick else 8192, dev))
     out.append(collate_case(1024 if args.quick else 8192, dev))
+    out.append(dense_collate_case(128 if args.quick else 1024, 37, 128, dev))
     for r in out:
         print(json.dumps(r))
 
