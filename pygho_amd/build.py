@@ -9,7 +9,9 @@ left to resolve against the ``libamdhip64.so`` that PyTorch-ROCm has already loa
 from __future__ import annotations
 
 import glob
+import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -19,10 +21,32 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "libpygho_hip.so")
+USAGE = os.path.join(LIBDIR, "resource_usage.json")       # per-kernel registers / scratch / occupancy from the last build
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wno-unused-result",
          "-fno-gpu-rdc", "-DNDEBUG"]
+
+
+def _resource_usage(remarks: str, src: str) -> dict:
+    """parse the compiler's -Rpass-analysis=kernel-resource-usage remarks: {kernel: vgprs, scratch, occupancy, lds} for the kernels
+    of namespace pygho (library kernels pulled in from hipCUB are not ours to fix)."""
+    out, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1) if m.group(1).startswith("_ZN5pygho") else None
+            if cur:
+                out[cur] = {"source": src}
+            continue
+        if cur is None:
+            continue
+        for key, pat in (("vgprs", r" VGPRs: (\d+)"), ("agprs", r"AGPRs: (\d+)"), ("scratch_bytes_per_lane", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("occupancy_waves_per_simd", r"Occupancy \[waves/SIMD\]: (\d+)"), ("lds_bytes_per_block", r"LDS Size \[bytes/block\]: (\d+)")):
+            m = re.search(pat, line)
+            if m:
+                out[cur][key] = int(m.group(1))
+    return {k: v for k, v in out.items() if "scratch_bytes_per_lane" in v}
 
 
 def hipcc() -> str:
@@ -54,14 +78,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [cc, *FLAGS, f"-I{INCLUDE}", "-c", src, "-o", obj]
+        cmd = [cc, *FLAGS, "-Rpass-analysis=kernel-resource-usage", f"-I{INCLUDE}", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
-        return obj
+        proc = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        if proc.returncode != 0:
+            sys.stderr.write(proc.stderr)
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        return obj, _resource_usage(proc.stderr, os.path.basename(src))
 
     with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(compile_one, sources()))
+        results = list(ex.map(compile_one, sources()))
+    objs = [r[0] for r in results]
+    usage = {k: v for r in results for k, v in r[1].items()}
+    with open(USAGE, "w") as f:
+        json.dump(usage, f, indent=1, sort_keys=True)
+    # a register array demoted to scratch turns into HBM traffic (scratch stores are memory writes): the first 16-byte forms of
+    # the masked fill / broadcast kernels wrote 2x their output that way.  Our own kernels must not spill -- fail the build.
+    spilled = {k: v["scratch_bytes_per_lane"] for k, v in usage.items() if v["scratch_bytes_per_lane"] > 0}
+    if spilled:
+        raise RuntimeError(f"kernels with scratch (register arrays demoted to memory): {spilled}")
     cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)

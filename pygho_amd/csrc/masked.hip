@@ -103,16 +103,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, uint
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0,
                                            (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
-__device__ __forceinline__ uint4 mk_load(__amdgpu_buffer_rsrc_t rsrc, bool take, uint32_t off) {
-  const mk_u4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, take ? (int)off : (int)0x80000000, 0, 0);
-  return make_uint4(v[0], v[1], v[2], v[3]);
+// Register arrays are kept as NATIVE vectors: loop-carried / selected arrays of `uint4` (a struct with a union inside) are
+// demoted to scratch by the compiler, and scratch stores are HBM writes (the first form of the fill kernel wrote 806 MB for a
+// 359 MB result, profiles/r01_pmc_masked.md).
+__device__ __forceinline__ mk_u4_t mk_load(__amdgpu_buffer_rsrc_t rsrc, bool take, uint32_t off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rsrc, take ? (int)off : (int)0x80000000, 0, 0);
 }
+__device__ __forceinline__ uint4 mk_u4(mk_u4_t v) { return make_uint4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ mk_u4_t mk_v4(uint4 v) { return mk_u4_t{v.x, v.y, v.z, v.w}; }
 
 constexpr int kMaskRowsPerLane = 4;
 
 // out[row] = mask[row] ? data[row] : value, `chunks` 16-byte pieces per row; a workgroup owns 4 * rows_per_wg consecutive rows
-__global__ __launch_bounds__(kBlock) void masked_fill_vec_kernel(uint4* __restrict__ out, const uint4* __restrict__ data,
-                                                                 const uint8_t* __restrict__ mask, uint4 value, int64_t n_rows,
+__global__ __launch_bounds__(kBlock) void masked_fill_vec_kernel(mk_u4_t* __restrict__ out, const mk_u4_t* __restrict__ data,
+                                                                 const uint8_t* __restrict__ mask, mk_u4_t value, int64_t n_rows,
                                                                  int chunks, int rows_per_wg) {
   const int lr = threadIdx.x / chunks, ch = threadIdx.x - lr * chunks;
   if (lr >= rows_per_wg) return;
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void masked_fill_vec_kernel(uint4* __restri
     const uint32_t rel = (uint32_t)(u * rows_per_wg + lr);
     m[u] = rel < span_rows ? mask[row0 + rel] : (uint8_t)0;
   }
-  uint4 v[kMaskRowsPerLane];
+  mk_u4_t v[kMaskRowsPerLane];
 #pragma unroll
   for (int u = 0; u < kMaskRowsPerLane; ++u)
     v[u] = mk_load(rsrc, m[u] != 0, ((uint32_t)(u * rows_per_wg + lr) * (uint32_t)chunks + (uint32_t)ch) * 16u);
@@ -137,8 +141,8 @@ __global__ __launch_bounds__(kBlock) void masked_fill_vec_kernel(uint4* __restri
 }
 
 // out[o, k, i, :] = mask[o, k, i] ? src[o, i, :] : value
-__global__ __launch_bounds__(kBlock) void masked_broadcast_vec_kernel(uint4* __restrict__ out, const uint4* __restrict__ src,
-                                                                      const uint8_t* __restrict__ mask, uint4 value,
+__global__ __launch_bounds__(kBlock) void masked_broadcast_vec_kernel(mk_u4_t* __restrict__ out, const mk_u4_t* __restrict__ src,
+                                                                      const uint8_t* __restrict__ mask, mk_u4_t value,
                                                                       int64_t n_rows, uint32_t r, uint32_t inner, int chunks,
                                                                       int rows_per_wg) {
   const int lr = threadIdx.x / chunks, ch = threadIdx.x - lr * chunks;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void masked_broadcast_vec_kernel(uint4* __r
     row[u] = row0 + u * rows_per_wg + lr;
     m[u] = row[u] < n_rows ? (mask ? mask[row[u]] : (uint8_t)1) : (uint8_t)0;
   }
-  uint4 v[kMaskRowsPerLane];
+  mk_u4_t v[kMaskRowsPerLane];
 #pragma unroll
   for (int u = 0; u < kMaskRowsPerLane; ++u) {
     const int64_t rr = row[u] < n_rows ? row[u] : n_rows - 1;      // clamped: the source rows are few and cache-resident
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void masked_reduce_vec_kernel(T* __restrict
     uint8_t m[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) m[u] = (k0 + u < r) ? mrow[(int64_t)(k0 + u) * inner] : (uint8_t)0;
-    uint4 v[4];
+    mk_u4_t v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       v[u] = mk_load(rsrc, m[u] != 0, (rel0 + (uint32_t)(k0 + u) * (uint32_t)inner) * row_bytes + (uint32_t)ch * 16u);
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void masked_reduce_vec_kernel(T* __restrict
     for (int u = 0; u < 4; ++u) {
       if (m[u]) {
         float x[N];
-        V::unpack(v[u], x);
+        V::unpack(mk_u4(v[u]), x);
 #pragma unroll
         for (int q = 0; q < N; ++q) acc[q] = R::op(acc[q], x[q]);
         ++cnt;
@@ -232,20 +236,20 @@ __global__ __launch_bounds__(kBlock) void masked_reduce_bwd_vec_kernel(T* __rest
   const int64_t ou = oi / inner, in = oi - ou * inner;
   const int64_t slab_rows = (int64_t)r * inner;
   const uint8_t* mrow = mask + ou * slab_rows + in;
-  uint4 share = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(gout) + (oi * chunks + ch) * 16);
+  mk_u4_t share = *reinterpret_cast<const mk_u4_t*>(reinterpret_cast<const char*>(gout) + (oi * chunks + ch) * 16);
   if (AGGR == PYGHO_MEAN) {
     int n = 0;
     for (int k = 0; k < r; ++k) n += mrow[(int64_t)k * inner] ? 1 : 0;
     float g[N];
-    V::unpack(share, g);
+    V::unpack(mk_u4(share), g);
 #pragma unroll
     for (int q = 0; q < N; ++q) g[q] = n > 0 ? g[q] / (float)n : 0.f;
-    share = V::pack(g);
+    share = mk_v4(V::pack(g));
   }
   char* base = reinterpret_cast<char*>(gdata) + ((ou * slab_rows + in) * chunks + ch) * 16;
   const int64_t step = inner * chunks * 16;
-  const uint4 zero = make_uint4(0, 0, 0, 0);
-  for (int k = 0; k < r; ++k) *reinterpret_cast<uint4*>(base + k * step) = mrow[(int64_t)k * inner] ? share : zero;
+  const mk_u4_t zero = {0u, 0u, 0u, 0u};
+  for (int k = 0; k < r; ++k) *reinterpret_cast<mk_u4_t*>(base + k * step) = mrow[(int64_t)k * inner] ? share : zero;
 }
 
 // out[b, i, j, :] = mask[b, i, j] ? ((base[b, i, j, :] + row_term[b, i, :]) + col_term[b, j, :]  (+ or replaced by, on i == j)
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void masked_pair_combine_kernel(T* __restri
     row[u] = row0 + u * rows_per_wg + lr;
     m[u] = row[u] < n_rows ? (mask ? mask[row[u]] : (uint8_t)1) : (uint8_t)0;
   }
-  uint4 vb[kMaskRowsPerLane];
+  mk_u4_t vb[kMaskRowsPerLane];
 #pragma unroll
   for (int u = 0; u < kMaskRowsPerLane; ++u)
     vb[u] = mk_load(rsrc, base != nullptr && m[u] != 0, ((uint32_t)(u * rows_per_wg + lr) * (uint32_t)chunks + (uint32_t)ch) * 16u);
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void masked_pair_combine_kernel(T* __restri
         res = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(diag_term) + ((b * nd + i) * chunks + ch) * 16);
       } else {
         float acc[N], t[N];
-        V::unpack(vb[u], acc);
+        V::unpack(mk_u4(vb[u]), acc);
         if (row_term) {
           V::unpack(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(row_term) + (bi * chunks + ch) * 16), t);
 #pragma unroll
@@ -360,8 +364,8 @@ extern "C" int pygho_masked_fill(void* out, const void* data, const uint8_t* mas
       const int rows_per_wg = kBlock / chunks;
       const int64_t grid = ceil_div(n_rows, (int64_t)kMaskRowsPerLane * rows_per_wg);
       if (grid < 0x7fffffff) {
-        hipLaunchKernelGGL(masked_fill_vec_kernel, dim3((unsigned)grid), dim3(kBlock), 0, st, (uint4*)out, (const uint4*)data, mask,
-                           pat, n_rows, chunks, rows_per_wg);
+        hipLaunchKernelGGL(masked_fill_vec_kernel, dim3((unsigned)grid), dim3(kBlock), 0, st, (mk_u4_t*)out, (const mk_u4_t*)data, mask,
+                           mk_u4_t{pat.x, pat.y, pat.z, pat.w}, n_rows, chunks, rows_per_wg);
         return check_launch("masked_fill");
       }
     }
@@ -525,8 +529,8 @@ extern "C" int pygho_masked_broadcast(void* out, const void* src, const uint8_t*
       const int64_t n_rows = outer * r * inner;
       const int64_t vgrid = ceil_div(n_rows, (int64_t)kMaskRowsPerLane * rows_per_wg);
       if (vgrid < 0x7fffffff) {
-        hipLaunchKernelGGL(masked_broadcast_vec_kernel, dim3((unsigned)vgrid), dim3(kBlock), 0, st, (uint4*)out, (const uint4*)src,
-                           mask, pat, n_rows, (uint32_t)r, (uint32_t)inner, chunks, rows_per_wg);
+        hipLaunchKernelGGL(masked_broadcast_vec_kernel, dim3((unsigned)vgrid), dim3(kBlock), 0, st, (mk_u4_t*)out, (const mk_u4_t*)src,
+                           mask, mk_u4_t{pat.x, pat.y, pat.z, pat.w}, n_rows, (uint32_t)r, (uint32_t)inner, chunks, rows_per_wg);
         return check_launch("masked_broadcast");
       }
     }

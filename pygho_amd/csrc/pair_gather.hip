@@ -6,6 +6,8 @@
 namespace pygho {
 
 constexpr int kPairRowsPerLane = 4;
+typedef __attribute__((ext_vector_type(4))) unsigned int pg_u4_t;   // native vectors: arrays of uint4 structs end up in scratch
+__device__ __forceinline__ uint4 pg_u4(pg_u4_t v) { return make_uint4(v[0], v[1], v[2], v[3]); }
 
 template <typename T, bool REPLACE>
 __global__ __launch_bounds__(kBlock) void pair_gather_combine_kernel(T* __restrict__ out, const T* __restrict__ base,
@@ -28,15 +30,15 @@ __global__ __launch_bounds__(kBlock) void pair_gather_combine_kernel(T* __restri
     j[u] = ci[rr];
     row[u] = row[u] < n_rows ? row[u] : -1;
   }
-  uint4 vb[kPairRowsPerLane], vr[kPairRowsPerLane], vc[kPairRowsPerLane], vd[kPairRowsPerLane];
-  const uint4 zero = make_uint4(0, 0, 0, 0);
+  pg_u4_t vb[kPairRowsPerLane], vr[kPairRowsPerLane], vc[kPairRowsPerLane], vd[kPairRowsPerLane];
+  const pg_u4_t zero = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int u = 0; u < kPairRowsPerLane; ++u) {
     const int64_t rr = row[u] >= 0 ? row[u] : n_rows - 1;
-    vb[u] = base ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + (rr * chunks + ch) * 16) : zero;
-    vr[u] = row_term ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(row_term) + ((int64_t)i[u] * chunks + ch) * 16) : zero;
-    vc[u] = col_term ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(col_term) + ((int64_t)j[u] * chunks + ch) * 16) : zero;
-    vd[u] = (diag_term && i[u] == j[u]) ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(diag_term) + ((int64_t)i[u] * chunks + ch) * 16) : zero;   // 1 tuple in ~10
+    vb[u] = base ? *reinterpret_cast<const pg_u4_t*>(reinterpret_cast<const char*>(base) + (rr * chunks + ch) * 16) : zero;
+    vr[u] = row_term ? *reinterpret_cast<const pg_u4_t*>(reinterpret_cast<const char*>(row_term) + ((int64_t)i[u] * chunks + ch) * 16) : zero;
+    vc[u] = col_term ? *reinterpret_cast<const pg_u4_t*>(reinterpret_cast<const char*>(col_term) + ((int64_t)j[u] * chunks + ch) * 16) : zero;
+    vd[u] = (diag_term && i[u] == j[u]) ? *reinterpret_cast<const pg_u4_t*>(reinterpret_cast<const char*>(diag_term) + ((int64_t)i[u] * chunks + ch) * 16) : zero;   // 1 tuple in ~10
   }
 #pragma unroll
   for (int u = 0; u < kPairRowsPerLane; ++u) {
@@ -44,22 +46,22 @@ __global__ __launch_bounds__(kBlock) void pair_gather_combine_kernel(T* __restri
     const bool on_diag = diag_term != nullptr && i[u] == j[u];
     uint4 res;
     if (REPLACE && on_diag) {
-      res = vd[u];
+      res = pg_u4(vd[u]);
     } else {
       float acc[N], t[N];
-      V::unpack(vb[u], acc);
+      V::unpack(pg_u4(vb[u]), acc);
       if (row_term) {
-        V::unpack(vr[u], t);
+        V::unpack(pg_u4(vr[u]), t);
 #pragma unroll
         for (int q = 0; q < N; ++q) acc[q] += t[q];
       }
       if (col_term) {
-        V::unpack(vc[u], t);
+        V::unpack(pg_u4(vc[u]), t);
 #pragma unroll
         for (int q = 0; q < N; ++q) acc[q] += t[q];
       }
       if (!REPLACE && on_diag) {
-        V::unpack(vd[u], t);
+        V::unpack(pg_u4(vd[u]), t);
 #pragma unroll
         for (int q = 0; q < N; ++q) acc[q] += t[q];
       }

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""
+Micro-benchmark of the kernels of the dense (MaskedTensor) path at the config-3 shape (b, n, n, d) = (1024, 37, 37, 128) bf16, padded
+ZINC-shape batch (X mask = node-mask outer product, A mask = adjacency): masked_bmm forward, masked fill / reductions / broadcast,
+masked_pair_combine.  Also the command the PMC passes of profiles/r01_pmc_masked.md were taken on.
+
+    python tools/masked_bench.py [--reps 20]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pygho_amd import MaskedTensor, _ops, synth            # noqa: E402
+from pygho_amd.backend.Mamamm import mamamm                  # noqa: E402
+
+
+def timed(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    return ts[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--b", type=int, default=1024)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    n, d, dt = 37, 128, torch.bfloat16
+    dn = synth.make_dense_batch(256, seed=2, hidden=d, nmax=n)
+    rep = args.b // 256
+    t = lambda a, to=None: (lambda v: v.to(to) if to else v)(torch.from_numpy(a).to(dev).repeat((rep,) + (1,) * (a.ndim - 1)))
+    xraw, xm = t(dn["X"], dt), t(dn["Xmask"])
+    araw, am = t(dn["A"], dt), t(dn["Amask"])
+    X = MaskedTensor(xraw, xm, 0.0, True)
+    A = MaskedTensor(araw, am, 0.0, True)
+    b = xraw.shape[0]
+    tensor = b * n * n * d * 2
+    valid = float(xm.float().mean())
+    node = torch.randn((b, n, d), device=dev).to(dt)
+    out = []
+
+    def rec(name, fn, alg_bytes, real_bytes=None, flops=None):
+        ms = timed(fn, args.reps)
+        r = {"kernel": name, "ms": ms, "algorithmic_MB": alg_bytes / 1e6, "GBps_algorithmic": alg_bytes / ms / 1e6,
+             "frac_hbm_algorithmic": alg_bytes / ms / 1e6 / 8000.0}
+        if real_bytes is not None:
+            r["unmasked_MB"] = real_bytes / 1e6                    # bytes a mask-aware kernel has to move (masked rows skipped)
+        if flops is not None:
+            r["TFLOPs"] = flops / ms / 1e9
+            r["frac_mfma_peak_bf16_dense"] = flops / ms / 1e9 / 2500.0
+        out.append(r)
+
+    a_valid = float(am.float().mean())
+    rec("masked_bmm_kernel<bf16> (mamamm(X,2,A,1) fwd)", lambda: mamamm(X, 2, A, 1, xm), 3 * tensor + b * n * n,
+        (2 * valid + a_valid) * tensor, 2.0 * b * d * n ** 3)
+    rec("masked_fill_vec_kernel", lambda: _ops.masked_fill(xraw, xm, 0.0), 2 * tensor, (1 + valid) * tensor)
+    rec("masked_reduce_vec_kernel (sum over dim 1)", lambda: _ops.masked_reduce(xraw, xm, 1, "sum"), tensor, valid * tensor)
+    rec("masked_reduce_vec_kernel (sum over dim 2)", lambda: _ops.masked_reduce(xraw, xm, 2, "sum"), tensor, valid * tensor)
+    rec("masked_broadcast_vec_kernel (unpool dim 1)", lambda: _ops.masked_broadcast(node, xm, 1, 0.0, 2), tensor)
+    rec("masked_pair_combine_kernel (base + u + v, diag select)",
+        lambda: _ops.masked_pair_combine(xraw, node, node, node, True, xm, tuple(xraw.shape), dt, dev), 2 * tensor, (1 + valid) * tensor)
+    rec("masked_pair_combine_kernel (views gradient: u + v + diag)",
+        lambda: _ops.masked_pair_combine(None, node, node, node, False, xm, tuple(xraw.shape), dt, dev), tensor)
+    meta = {"shape": [b, n, n, d], "dtype": "bfloat16", "tensor_MB": tensor / 1e6, "X_valid_fraction": valid, "A_valid_fraction": a_valid}
+    print(json.dumps({"meta": meta, "kernels": out}))
+
+
+if __name__ == "__main__":
+    main()
