@@ -100,3 +100,17 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_no_kernel_uses_scratch():
+    """every kernel of namespace pygho compiles without scratch: a register array demoted to memory turns into HBM traffic (scratch
+    stores are memory writes; profiles/r01_pmc_masked.md shows a kernel writing 2x its output that way).  The build records the
+    compiler's per-kernel resource usage and refuses to produce a library with a spilling kernel; this checks the record."""
+    import json
+    from pygho_amd import build
+    build.build(verbose=False)
+    assert os.path.exists(build.USAGE), "resource usage record missing: rebuild with `python -m pygho_amd.build --force`"
+    usage = json.load(open(build.USAGE))
+    assert len(usage) > 100
+    assert not {k: v for k, v in usage.items() if v["scratch_bytes_per_lane"] != 0}
+    assert all(v.get("occupancy_waves_per_simd", 1) >= 1 for v in usage.values())
