@@ -299,6 +299,21 @@ int pygho_masked_bmm(void* out, const void* A, const void* B, const uint8_t* ama
                      int64_t nk, int64_t nj, int64_t d, int a_kfirst, int b_kfirst, int dtype,
                      void* stream);
 
+/* The same contraction when ONE operand's mask is sparse (an adjacency), driven by lists of that operand's unmasked k instead
+ * of a dense product over all k (Mamamm.py:35-64 runs a dense bmm whatever the masks hold):
+ *   pygho_mask_lists: for a mask stored (nb, nk, nc) (k_first) or (nb, nc, nk): list[b, c, 0..count[b,c]) = the k with
+ *     mask[b, k, c] != 0 in ascending order, the rest of the row -1; list is (nb, nc, (nk + 3) & ~3) int16 (8-byte aligned),
+ *     count (nb, nc) int32.
+ *   pygho_masked_bmm_lists: out[b,i,j,:] = omask[b,i,j] ? sum_t A[b,i,k_t,:] * B[b,k_t,j,:] : 0 with k_t running over the list of
+ *     (b, j) (list_on_j = 1: the lists come from B's mask, A is the dense operand) or of (b, i) (list_on_j = 0: from A's mask).
+ *     dense_mask (nullable) is the mask of the OTHER operand in its own storage order: its masked rows contribute 0 and are
+ *     not fetched.  Storage flags as in pygho_masked_bmm.  f32 accumulation over k ascending; row bytes % 16 == 0. */
+int pygho_mask_lists(int16_t* list, int32_t* count, const uint8_t* mask, int64_t nb, int64_t nk, int64_t nc, int k_first,
+                     void* stream);
+int pygho_masked_bmm_lists(void* out, const void* A, const void* B, const uint8_t* dense_mask, const uint8_t* omask,
+                           const int16_t* list, const int32_t* count, int list_on_j, int64_t nb, int64_t ni, int64_t nk,
+                           int64_t nj, int64_t d, int a_kfirst, int b_kfirst, int dtype, void* stream);
+
 /* out = mask ? data : value over (n_rows, d) with a per-row uint8 mask.  MaTensor.py:113-128.  Every dtype code
  * (integer features -- node / bond types, distance ids -- are legal MaskedTensor data: hodata/MaData.py:108-214). */
 int pygho_masked_fill(void* out, const void* data, const uint8_t* mask, double value,

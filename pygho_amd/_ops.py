@@ -1293,9 +1293,61 @@ def sparse_pair_linear_mix(x, y, w_x, w_y, u, v, dg, ri, ci, diag_pos, n):
     return _SparsePairLinearMix.apply(x, y, w_x, w_y, u, v, dg, ri, ci, diag_pos, n)
 
 
+USE_BMM_LISTS = True          # masked contraction with a sparse-masked operand: neighbour-list kernel instead of the dense MFMA one
+BMM_LIST_DENSITY = 0.15       # ... when at most this fraction of that operand's positions is unmasked
+
+
+def _mask_density(m8: Optional[Tensor]) -> float:
+    """unmasked fraction of a uint8 mask, computed once per mask tensor object (one small reduction + one sync per batch)."""
+    if m8 is None:
+        return 1.0
+    c = getattr(m8, "_pygho_density", None)
+    if c is None or c[0] != m8._version:
+        c = (m8._version, float(m8.sum(dtype=torch.int64).item()) / max(1, m8.numel()))
+        try:
+            m8._pygho_density = c
+        except Exception:
+            pass
+    return c[1]
+
+
+def _mask_lists(m8: Tensor, nb: int, nk: int, nc: int, k_first: bool):
+    """(list (nb, nc, roundup4(nk)) int16, -1 terminated; count (nb, nc) int32) of the unmasked k per (b, c), cached on the mask."""
+    cache = getattr(m8, "_pygho_lists", None)
+    if cache is None:
+        cache = {}
+        try:
+            m8._pygho_lists = cache
+        except Exception:
+            pass
+    key = (m8._version, nk, nc, k_first)
+    if key not in cache:
+        dev = m8.device
+        lst = torch.empty((nb, nc, (nk + 3) & ~3), dtype=torch.int16, device=dev)       # -1 terminated rows, 8-byte groups
+        cnt = torch.empty((nb, nc), dtype=torch.int32, device=dev)
+        check(lib().pygho_mask_lists(ptr(lst), ptr(cnt), ptr(m8), nb, nk, nc, 1 if k_first else 0, stream_ptr(dev)), "mask_lists")
+        cache[key] = (lst, cnt)                                  # column and row lists of one mask coexist (forward / backward)
+    return cache[key]
+
+
 def _bmm_launch(A: Tensor, B: Tensor, amask, bmask, omask, nb, ni, nk, nj, d, a_kfirst: bool, b_kfirst: bool) -> Tensor:
     dev = require_device(A, B, amask, bmask, omask)
     out = torch.empty((nb, ni, nj, d), dtype=A.dtype, device=dev)
+    if (USE_BMM_LISTS and nk <= 32767 and (d * A.element_size()) % 16 == 0 and d * A.element_size() <= 4096
+            and A.dtype in (torch.float32, torch.bfloat16, torch.float16)):
+        da, db = _mask_density(amask), _mask_density(bmask)
+        if min(da, db) <= BMM_LIST_DENSITY:
+            on_j = db <= da                                      # the sparser operand supplies the lists
+            if on_j:
+                lst, cnt = _mask_lists(bmask, nb, nk, nj, b_kfirst)
+                dense_mask = amask
+            else:
+                lst, cnt = _mask_lists(amask, nb, nk, ni, a_kfirst)
+                dense_mask = bmask
+            check(lib().pygho_masked_bmm_lists(ptr(out), ptr(A), ptr(B), ptr(dense_mask), ptr(omask), ptr(lst), ptr(cnt),
+                                               1 if on_j else 0, nb, ni, nk, nj, d, 1 if a_kfirst else 0, 1 if b_kfirst else 0,
+                                               dtype_code(A), stream_ptr(dev)), "masked_bmm_lists")
+            return out
     check(lib().pygho_masked_bmm(ptr(out), ptr(A), ptr(B), ptr(amask), ptr(bmask), ptr(omask), nb, ni, nk, nj, d,
                                  1 if a_kfirst else 0, 1 if b_kfirst else 0, dtype_code(A), stream_ptr(dev)), "masked_bmm")
     return out

@@ -33,6 +33,20 @@ inline int grid_for(int64_t work_items, int per_block, int cap = kMaxGrid) {
   return (int)g;
 }
 
+// (q, r) = (x / d, x % d) for a row index: 32-bit unsigned division (~30 VALU instructions) whenever the index fits, the
+// 64-bit signed one (~150 per division, per wavefront) only beyond 2^32 rows.  Two 64-bit divisions per output row made the
+// neighbour-list contraction VALU-bound: 0.22 ms, all of it index arithmetic (profiles/r01_pmc_masked.md).
+__device__ __forceinline__ void row_divmod(int64_t x, int d, int64_t& q, int& r) {
+  if (x < (int64_t)0xffffffffll) {
+    const uint32_t xq = (uint32_t)x / (uint32_t)d;
+    q = xq;
+    r = (int)((uint32_t)x - xq * (uint32_t)d);
+  } else {
+    q = x / d;
+    r = (int)(x - q * d);
+  }
+}
+
 // ---- storage types -------------------------------------------------------
 struct bf16 { uint16_t bits; };
 struct f16 { _Float16 v; };

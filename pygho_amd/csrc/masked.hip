@@ -159,8 +159,11 @@ __global__ __launch_bounds__(kBlock) void masked_broadcast_vec_kernel(mk_u4_t* _
 #pragma unroll
   for (int u = 0; u < kMaskRowsPerLane; ++u) {
     const int64_t rr = row[u] < n_rows ? row[u] : n_rows - 1;      // clamped: the source rows are few and cache-resident
-    const int64_t ok = rr / inner;                                  // (o, k)
-    const int64_t i = rr - ok * inner, o = ok / r;
+    int64_t ok, o;                                                   // (o, k)
+    int ii, kk;
+    row_divmod(rr, (int)inner, ok, ii);
+    row_divmod(ok, (int)r, o, kk);
+    const int64_t i = ii;
     v[u] = src[(o * inner + i) * chunks + ch];
   }
 #pragma unroll
@@ -287,10 +290,11 @@ __global__ __launch_bounds__(kBlock) void masked_pair_combine_kernel(T* __restri
     const uint4 zero = make_uint4(0, 0, 0, 0);
     uint4 res = zero;
     if (m[u]) {
-      const int64_t bi = row[u] / n2;                                // (b, i)
-      const uint32_t j = (uint32_t)(row[u] - bi * n2);
-      const int64_t b = bi / n1;
-      const uint32_t i = (uint32_t)(bi - b * n1);
+      int64_t bi, b;                                                   // (b, i)
+      int ji, ii;
+      row_divmod(row[u], (int)n2, bi, ji);
+      row_divmod(bi, (int)n1, b, ii);
+      const uint32_t j = (uint32_t)ji, i = (uint32_t)ii;
       const bool on_diag = diag_term != nullptr && i == j;
       if (REPLACE && on_diag) {
         res = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(diag_term) + ((b * nd + i) * chunks + ch) * 16);

@@ -65,8 +65,20 @@ def main():
         out.append(r)
 
     a_valid = float(am.float().mean())
-    rec("masked_bmm_kernel<bf16> (mamamm(X,2,A,1) fwd)", lambda: mamamm(X, 2, A, 1, xm), 3 * tensor + b * n * n,
-        (2 * valid + a_valid) * tensor, 2.0 * b * d * n ** 3)
+    need = (valid + a_valid) * tensor + tensor                  # unmasked operand rows in, every output row out
+    flops = 2.0 * b * d * n ** 3
+    # the adjacency mask is 3.6 % dense: mamamm dispatches to the neighbour-list kernel; the matrix-core kernel is timed on the
+    # same inputs with the dispatch switched off (dense x dense contractions always take it)
+    rec("masked_bmm_lists_kernel<bf16> (mamamm(X,2,A,1) fwd, sparse-mask dispatch)", lambda: mamamm(X, 2, A, 1, xm),
+        3 * tensor + b * n * n, need, flops)
+
+    def dense_path():
+        _ops.USE_BMM_LISTS = False
+        try:
+            return mamamm(X, 2, A, 1, xm)
+        finally:
+            _ops.USE_BMM_LISTS = True
+    rec("masked_bmm_kernel<bf16> (same contraction on the matrix cores)", dense_path, 3 * tensor + b * n * n, need, flops)
     rec("masked_fill_vec_kernel", lambda: _ops.masked_fill(xraw, xm, 0.0), 2 * tensor, (1 + valid) * tensor)
     rec("masked_reduce_vec_kernel (sum over dim 1)", lambda: _ops.masked_reduce(xraw, xm, 1, "sum"), tensor, valid * tensor)
     rec("masked_reduce_vec_kernel (sum over dim 2)", lambda: _ops.masked_reduce(xraw, xm, 2, "sum"), tensor, valid * tensor)
