@@ -299,6 +299,16 @@ int pygho_masked_bmm(void* out, const void* A, const void* B, const uint8_t* ama
                      int64_t nk, int64_t nj, int64_t d, int a_kfirst, int b_kfirst, int dtype,
                      void* stream);
 
+/* The same kernel with per-batch-element extents: pygho_mask_extents writes, for every b, (ei, ek, ej) = one past the last row /
+ * k / column any of the three masks (each nullable, stored as for pygho_masked_bmm) leaves unmasked -- the padding of a batched
+ * graph sits behind them -- and pygho_masked_bmm_clipped stages and multiplies only up to there (every output position is still
+ * written).  extents: (nb, 3) int32.  Results are identical to pygho_masked_bmm. */
+int pygho_mask_extents(int32_t* extents, const uint8_t* amask, const uint8_t* bmask, const uint8_t* omask, int64_t nb, int64_t ni,
+                       int64_t nk, int64_t nj, int a_kfirst, int b_kfirst, void* stream);
+int pygho_masked_bmm_clipped(void* out, const void* A, const void* B, const uint8_t* amask, const uint8_t* bmask,
+                             const uint8_t* omask, const int32_t* extents, int64_t nb, int64_t ni, int64_t nk, int64_t nj,
+                             int64_t d, int a_kfirst, int b_kfirst, int dtype, void* stream);
+
 /* The same contraction when ONE operand's mask is sparse (an adjacency), driven by lists of that operand's unmasked k instead
  * of a dense product over all k (Mamamm.py:35-64 runs a dense bmm whatever the masks hold):
  *   pygho_mask_lists: for a mask stored (nb, nk, nc) (k_first) or (nb, nc, nk): list[b, c, 0..count[b,c]) = the k with

@@ -63,6 +63,8 @@ PROTOTYPES = {
     "pygho_flag_scan_nonneg": (I, [P, P, P, L, P, Z, P]),
     "pygho_compact_positions": (I, [P, P, L, P]),
     "pygho_masked_bmm": (I, [P, P, P, P, P, P, L, L, L, L, L, I, I, I, P]),
+    "pygho_mask_extents": (I, [P, P, P, P, L, L, L, L, I, I, P]),
+    "pygho_masked_bmm_clipped": (I, [P, P, P, P, P, P, P, L, L, L, L, L, I, I, I, P]),
     "pygho_mask_lists": (I, [P, P, P, L, L, L, I, P]),
     "pygho_masked_bmm_lists": (I, [P, P, P, P, P, P, P, I, L, L, L, L, L, I, I, I, P]),
     "pygho_masked_fill": (I, [P, P, P, D, L, L, I, P]),

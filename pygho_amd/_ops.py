@@ -1297,6 +1297,36 @@ USE_BMM_LISTS = True          # masked contraction with a sparse-masked operand:
 BMM_LIST_DENSITY = 0.15       # ... when at most this fraction of that operand's positions is unmasked
 
 
+USE_BMM_EXTENTS = True        # matrix-core contraction: stage / multiply only up to the last unmasked row, k and column of each batch element
+
+
+def _mask_extents(amask, bmask, omask, nb, ni, nk, nj, a_kfirst: bool, b_kfirst: bool) -> Optional[Tensor]:
+    """(nb, 3) int32 (ei, ek, ej) per batch element (`pygho_mask_extents`), cached on the first mask of the triple (the cache
+    entry keeps the masks alive, so their identities cannot be recycled); None when no mask is given."""
+    holder = amask if amask is not None else (bmask if bmask is not None else omask)
+    if holder is None:
+        return None
+    cache = getattr(holder, "_pygho_extents", None)
+    if cache is None:
+        cache = {}
+        try:
+            holder._pygho_extents = cache
+        except Exception:
+            pass
+    ver = lambda m: None if m is None else (id(m), m._version)
+    key = (ver(amask), ver(bmask), ver(omask), ni, nk, nj, a_kfirst, b_kfirst)
+    hit = cache.get(key)
+    if hit is None:
+        dev = holder.device
+        ext = torch.empty((nb, 3), dtype=torch.int32, device=dev)
+        check(lib().pygho_mask_extents(ptr(ext), ptr(amask), ptr(bmask), ptr(omask), nb, ni, nk, nj, 1 if a_kfirst else 0,
+                                       1 if b_kfirst else 0, stream_ptr(dev)), "mask_extents")
+        if len(cache) > 8:
+            cache.clear()
+        hit = cache[key] = (ext, amask, bmask, omask)
+    return hit[0]
+
+
 def _mask_density(m8: Optional[Tensor]) -> float:
     """unmasked fraction of a uint8 mask, computed once per mask tensor object (one small reduction + one sync per batch)."""
     if m8 is None:
@@ -1348,6 +1378,12 @@ def _bmm_launch(A: Tensor, B: Tensor, amask, bmask, omask, nb, ni, nk, nj, d, a_
                                                1 if on_j else 0, nb, ni, nk, nj, d, 1 if a_kfirst else 0, 1 if b_kfirst else 0,
                                                dtype_code(A), stream_ptr(dev)), "masked_bmm_lists")
             return out
+    ext = _mask_extents(amask, bmask, omask, nb, ni, nk, nj, a_kfirst, b_kfirst) if USE_BMM_EXTENTS else None
+    if ext is not None:
+        check(lib().pygho_masked_bmm_clipped(ptr(out), ptr(A), ptr(B), ptr(amask), ptr(bmask), ptr(omask), ptr(ext), nb, ni, nk, nj, d,
+                                             1 if a_kfirst else 0, 1 if b_kfirst else 0, dtype_code(A), stream_ptr(dev)),
+              "masked_bmm_clipped")
+        return out
     check(lib().pygho_masked_bmm(ptr(out), ptr(A), ptr(B), ptr(amask), ptr(bmask), ptr(omask), nb, ni, nk, nj, d,
                                  1 if a_kfirst else 0, 1 if b_kfirst else 0, dtype_code(A), stream_ptr(dev)), "masked_bmm")
     return out

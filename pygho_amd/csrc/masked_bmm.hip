@@ -43,6 +43,7 @@ struct BmmArgs {
   const uint8_t* amask;
   const uint8_t* bmask;
   const uint8_t* omask;
+  const int32_t* extents;   // (nb, 3) per batch element: rows / k / columns beyond which everything is masked (nullable)
   int ni, nk, nj, d;
   // position strides (in positions; multiply by d for elements)
   int a_si, a_sk, b_sj, b_sk;
@@ -188,7 +189,14 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
   const int64_t b = rest / (p.n_itiles * p.n_jtiles);
   const int it = tile / p.n_jtiles, jt = tile - it * p.n_jtiles;
   const int i0 = it * kTile, j0 = jt * kTile;
-  const int rows_i = min(kTile, p.ni - i0), rows_j = min(kTile, p.nj - j0);
+  // the tile as STORED (every position gets a value) and as COMPUTED: a padded batch element whose masks are empty beyond
+  // (ei, ek, ej) stages and multiplies only up to there -- 23 instead of 37 rows on average in a ZINC batch, 37 % of the
+  // staging work -- and the accumulators of the untouched tiles stay zero
+  const int srows_i = min(kTile, p.ni - i0), srows_j = min(kTile, p.nj - j0);
+  int ei = p.ni, ek = p.nk, ej = p.nj;
+  if (p.extents) { ei = p.extents[3 * b]; ek = p.extents[3 * b + 1]; ej = p.extents[3 * b + 2]; }
+  const int rows_i = max(0, min(srows_i, ei - i0)), rows_j = max(0, min(srows_j, ej - j0));
+  const int nk_eff = (rows_i > 0 && rows_j > 0) ? min(ek, p.nk) : 0;       // workgroup-uniform
   const int c0 = chunk * CH;
   const int nti = (rows_i + 15) >> 4, ntj = (rows_j + 15) >> 4;
   const int kmax = min(kKBlock, p.nk);
@@ -205,8 +213,8 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
       for (int u = 0; u < 3; ++u) acc[c][t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int64_t a_base = b * (int64_t)p.ni * p.nk, b_base = b * (int64_t)p.nk * p.nj;
-  for (int k0 = 0; k0 < p.nk; k0 += kKBlock) {
-    const int kvalid = min(kKBlock, p.nk - k0);
+  for (int k0 = 0; k0 < nk_eff; k0 += kKBlock) {
+    const int kvalid = min(kKBlock, nk_eff - k0);
     if (k0 > 0) __syncthreads();
     {
       const int kround = (kvalid + (TR::KSTEP >= 8 ? 7 : 3)) & ~(TR::KSTEP >= 8 ? 7 : 3);
@@ -231,9 +239,9 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
         const int br = ar, bg = ag;
         StageRegs<T> ra, rb;
         stage_load_at<T>(ra, ar, ag, abase, amb, (uint32_t)p.a_si * db, (uint32_t)p.a_sk * db, (uint32_t)p.a_si, (uint32_t)p.a_sk,
-                         i0, rows_i, k0, (int)p.nk);
+                         i0, rows_i, k0, nk_eff);
         stage_load_at<T>(rb, br, bg, bbase, bmb, (uint32_t)p.b_sj * db, (uint32_t)p.b_sk * db, (uint32_t)p.b_sj, (uint32_t)p.b_sk,
-                         j0, rows_j, k0, (int)p.nk);
+                         j0, rows_j, k0, nk_eff);
         stage_write_at<T>(ldsA, ra, ar, ag, rows_i, kround, kp);
         stage_write_at<T>(ldsB, rb, br, bg, rows_j, kround, kp);
       }
@@ -265,6 +273,7 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
           for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
+              if (t >= nti || u >= ntj) continue;      // workgroup-uniform: a clipped tile (rows beyond the extents) issues nothing
               if constexpr (std::is_same<T, bf16>::value)
                 acc[c][t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[t]),
                                                                        __builtin_bit_cast(bf16x8_t, fb[u]), acc[c][t][u], 0, 0, 0);
@@ -291,7 +300,10 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-          for (int u = 0; u < 3; ++u) acc[0][t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t], fb[u], acc[0][t][u], 0, 0, 0);
+          for (int u = 0; u < 3; ++u) {
+            if (t >= nti || u >= ntj) continue;
+            acc[0][t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t], fb[u], acc[0][t][u], 0, 0, 0);
+          }
       }
     }
   }
@@ -329,15 +341,59 @@ __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
       }
   }
   __syncthreads();
-  const int npos = rows_i * rows_j;
-  const float inv_rows_j = 1.0f / (float)rows_j;
+  const int npos = srows_i * srows_j;
+  const float inv_rows_j = 1.0f / (float)srows_j;
   for (int ps = threadIdx.x; ps < npos; ps += kBlock) {
-    const int i = (int)(((float)ps + 0.5f) * inv_rows_j), j = ps - i * rows_j;     // exact: ps < 2^12
+    const int i = (int)(((float)ps + 0.5f) * inv_rows_j), j = ps - i * srows_j;    // exact: ps < 2^12
     const int64_t opos = (b * p.ni + i0 + i) * p.nj + j0 + j;
     const uint32_t* lp = reinterpret_cast<const uint32_t*>(smem) + (uint32_t)(i * kOutPitch + j);
     uint4 v = make_uint4(lp[0], lp[kTile * kOutPitch], lp[2 * kTile * kOutPitch], lp[3 * kTile * kOutPitch]);
     if (p.omask && !p.omask[opos]) v = make_uint4(0, 0, 0, 0);
     *reinterpret_cast<uint4*>((T*)p.out + opos * p.d + c0) = v;
+  }
+}
+
+// ext[b] = (ei, ek, ej): one past the last row / k / column that any mask leaves unmasked (the three masks combined: a row of A
+// that is entirely masked contributes zeros, a row of the output that is entirely masked is not needed)
+__global__ __launch_bounds__(kBlock) void mask_extents_kernel(int32_t* __restrict__ ext, const uint8_t* __restrict__ amask,
+                                                              const uint8_t* __restrict__ bmask, const uint8_t* __restrict__ omask,
+                                                              int ni, int nk, int nj, int a_si, int a_sk, int b_sk, int b_sj) {
+  __shared__ int s[6];      // A: i, k   B: k, j   O: i, j
+  if (threadIdx.x < 6) s[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t b = blockIdx.x;
+  int m0 = 0, m1 = 0;
+  if (amask) {
+    for (int t = threadIdx.x; t < ni * nk; t += kBlock) {
+      const int i = t / nk, k = t - i * nk;
+      if (amask[b * ni * nk + i * a_si + k * a_sk]) { m0 = max(m0, i + 1); m1 = max(m1, k + 1); }
+    }
+    atomicMax(&s[0], m0);
+    atomicMax(&s[1], m1);
+  }
+  m0 = m1 = 0;
+  if (bmask) {
+    for (int t = threadIdx.x; t < nk * nj; t += kBlock) {
+      const int k = t / nj, j = t - k * nj;
+      if (bmask[b * nk * nj + k * b_sk + j * b_sj]) { m0 = max(m0, k + 1); m1 = max(m1, j + 1); }
+    }
+    atomicMax(&s[2], m0);
+    atomicMax(&s[3], m1);
+  }
+  m0 = m1 = 0;
+  if (omask) {
+    for (int t = threadIdx.x; t < ni * nj; t += kBlock) {
+      const int i = t / nj, j = t - i * nj;
+      if (omask[b * ni * nj + t]) { m0 = max(m0, i + 1); m1 = max(m1, j + 1); }
+    }
+    atomicMax(&s[4], m0);
+    atomicMax(&s[5], m1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ext[3 * b] = min(amask ? s[0] : ni, omask ? s[4] : ni);
+    ext[3 * b + 1] = min(amask ? s[1] : nk, bmask ? s[2] : nk);
+    ext[3 * b + 2] = min(bmask ? s[3] : nj, omask ? s[5] : nj);
   }
 }
 
@@ -369,14 +425,14 @@ int launch_bmm(const BmmArgs& p, int64_t nb, hipStream_t st) {
 
 using namespace pygho;
 
-extern "C" int pygho_masked_bmm(void* out, const void* A, const void* B, const uint8_t* amask, const uint8_t* bmask,
-                                const uint8_t* omask, int64_t nb, int64_t ni, int64_t nk, int64_t nj, int64_t d,
-                                int a_kfirst, int b_kfirst, int dtype, void* stream) {
+static int bmm_entry(void* out, const void* A, const void* B, const uint8_t* amask, const uint8_t* bmask, const uint8_t* omask,
+                     const int32_t* extents, int64_t nb, int64_t ni, int64_t nk, int64_t nj, int64_t d, int a_kfirst, int b_kfirst,
+                     int dtype, void* stream) {
   if (nb < 0 || ni < 0 || nk < 0 || nj < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
   if (nb == 0 || ni == 0 || nj == 0 || d == 0) return PYGHO_OK;
   if (!out || (nk > 0 && (!A || !B))) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   BmmArgs p;
-  p.out = out; p.A = A; p.B = B; p.amask = amask; p.bmask = bmask; p.omask = omask;
+  p.out = out; p.A = A; p.B = B; p.amask = amask; p.bmask = bmask; p.omask = omask; p.extents = extents;
   if (ni > INT32_MAX / 4 || nk > INT32_MAX / 4 || nj > INT32_MAX / 4 || d > 65536 || ni * nk * d > INT32_MAX / 8 || nk * nj * d > INT32_MAX / 8) {
     set_error("masked_bmm: one batch element must stay below 2^28 elements");
     return PYGHO_ERR_UNSUPPORTED;
@@ -393,4 +449,29 @@ extern "C" int pygho_masked_bmm(void* out, const void* A, const void* B, const u
     case PYGHO_F32: return launch_bmm<float>(p, nb, st);
     default: set_error("masked_bmm: unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED;
   }
+}
+
+extern "C" int pygho_masked_bmm(void* out, const void* A, const void* B, const uint8_t* amask, const uint8_t* bmask,
+                                const uint8_t* omask, int64_t nb, int64_t ni, int64_t nk, int64_t nj, int64_t d,
+                                int a_kfirst, int b_kfirst, int dtype, void* stream) {
+  return bmm_entry(out, A, B, amask, bmask, omask, nullptr, nb, ni, nk, nj, d, a_kfirst, b_kfirst, dtype, stream);
+}
+
+extern "C" int pygho_masked_bmm_clipped(void* out, const void* A, const void* B, const uint8_t* amask, const uint8_t* bmask,
+                                        const uint8_t* omask, const int32_t* extents, int64_t nb, int64_t ni, int64_t nk,
+                                        int64_t nj, int64_t d, int a_kfirst, int b_kfirst, int dtype, void* stream) {
+  if (!extents) { set_error("masked_bmm_clipped: extents missing"); return PYGHO_ERR_INVALID; }
+  return bmm_entry(out, A, B, amask, bmask, omask, extents, nb, ni, nk, nj, d, a_kfirst, b_kfirst, dtype, stream);
+}
+
+extern "C" int pygho_mask_extents(int32_t* extents, const uint8_t* amask, const uint8_t* bmask, const uint8_t* omask, int64_t nb,
+                                  int64_t ni, int64_t nk, int64_t nj, int a_kfirst, int b_kfirst, void* stream) {
+  if (nb < 0 || ni < 0 || nk < 0 || nj < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (nb == 0) return PYGHO_OK;
+  if (!extents) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (ni * nk > INT32_MAX / 2 || nk * nj > INT32_MAX / 2 || ni * nj > INT32_MAX / 2 || nb > INT32_MAX) { set_error("mask_extents: grid too large"); return PYGHO_ERR_UNSUPPORTED; }
+  const int a_si = a_kfirst ? 1 : (int)nk, a_sk = a_kfirst ? (int)ni : 1, b_sk = b_kfirst ? (int)nj : 1, b_sj = b_kfirst ? 1 : (int)nk;
+  hipLaunchKernelGGL(mask_extents_kernel, dim3((unsigned)nb), dim3(kBlock), 0, (hipStream_t)stream, extents, amask, bmask, omask, (int)ni,
+                     (int)nk, (int)nj, a_si, a_sk, b_sk, b_sj);
+  return check_launch("mask_extents");
 }

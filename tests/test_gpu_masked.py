@@ -204,6 +204,50 @@ def test_masked_bmm_sparse_operand_lists(dev, dtype, shape, layout, sparse_side)
     np.testing.assert_allclose(N(got), N(dense), rtol=eps, atol=eps * scale)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", [(False, True), (True, True), (False, False), (True, False)])
+def test_masked_bmm_padded_batch_extents(dev, dtype, layout):
+    """padded-batch masks (node-mask outer products of ragged sizes, one empty batch element, one full one; k spanning two staging
+    blocks): the matrix-core kernel clipped to the per-element extents (pygho_mask_extents + pygho_masked_bmm_clipped) gives the
+    same result as the unclipped kernel bit for bit, and both agree with a float64 einsum."""
+    from pygho_amd import _ops
+    nb, ni, nk, nj, d = 6, 50, 70, 41, 16
+    akf, bkf = layout
+    rng = np.random.default_rng(5)
+    sizes = [(0, 0, 0), (50, 70, 41), (17, 33, 9), (49, 1, 40), (3, 65, 41), (20, 20, 20)]
+    am = np.zeros((nb, ni, nk), bool); bm = np.zeros((nb, nk, nj), bool); om = np.zeros((nb, ni, nj), bool)
+    for b, (a, k, j) in enumerate(sizes):
+        am[b, :a, :k] = rng.random((a, k)) > 0.2
+        bm[b, :k, :j] = rng.random((k, j)) > 0.2
+        om[b, :a, :j] = rng.random((a, j)) > 0.1
+    A = rng.standard_normal((nb, ni, nk, d)).astype(np.float32)
+    B = rng.standard_normal((nb, nk, nj, d)).astype(np.float32)
+    At, Bt = T(A, dev, dtype), T(B, dev, dtype)
+    Aq, Bq = N(At).astype(np.float64), N(Bt).astype(np.float64)
+    exp = np.einsum("bikd,bkjd->bijd", Aq * am[..., None], Bq * bm[..., None]) * om[..., None]
+    a_st = At.permute(0, 2, 1, 3).contiguous() if akf else At
+    b_st = Bt if bkf else Bt.permute(0, 2, 1, 3).contiguous()
+    am_st = T(am, dev).permute(0, 2, 1).contiguous() if akf else T(am, dev)
+    bm_st = T(bm, dev) if bkf else T(bm, dev).permute(0, 2, 1).contiguous()
+    masks = (_ops._mask_u8(am_st), _ops._mask_u8(bm_st), _ops._mask_u8(T(om, dev)))
+    ext = _ops._mask_extents(*masks, nb, ni, nk, nj, akf, bkf)
+    want = np.array([[min(a, a2), min(k, k2), min(j, j2)] for (a, k, j), (a2, k2, j2) in
+                     zip([(am[b].any(1).nonzero()[0].max(initial=-1) + 1, am[b].any(0).nonzero()[0].max(initial=-1) + 1, nj) for b in range(nb)],
+                         [(ni, bm[b].any(1).nonzero()[0].max(initial=-1) + 1, bm[b].any(0).nonzero()[0].max(initial=-1) + 1) for b in range(nb)])])
+    want[:, 0] = np.minimum(want[:, 0], [om[b].any(1).nonzero()[0].max(initial=-1) + 1 for b in range(nb)])
+    want[:, 2] = np.minimum(want[:, 2], [om[b].any(0).nonzero()[0].max(initial=-1) + 1 for b in range(nb)])
+    assert np.array_equal(N(ext), want)
+    got = _ops.masked_bmm(a_st, b_st, *masks, nb, ni, nk, nj, d, akf, bkf)
+    _ops.USE_BMM_EXTENTS = False
+    try:
+        plain = _ops.masked_bmm(a_st, b_st, *masks, nb, ni, nk, nj, d, akf, bkf)
+    finally:
+        _ops.USE_BMM_EXTENTS = True
+    assert torch.equal(got, plain)
+    eps = {torch.float32: 1e-5, torch.bfloat16: 2.0 ** -8}[dtype]
+    np.testing.assert_allclose(N(got), exp, rtol=eps, atol=eps * np.abs(exp).max())
+
+
 def test_masked_bmm_transpose_detecting(dev):
     """A = I with an asymmetric B: a swapped output layout cannot pass."""
     from pygho_amd import _ops
