@@ -324,6 +324,14 @@ int pygho_masked_bmm_lists(void* out, const void* A, const void* B, const uint8_
                            const int16_t* list, const int32_t* count, int list_on_j, int64_t nb, int64_t ni, int64_t nk,
                            int64_t nj, int64_t d, int a_kfirst, int b_kfirst, int dtype, void* stream);
 
+/* Output-sparse form (the gradient of an adjacency's values: two dense operands, few outputs wanted): `list` = the lists of the
+ * OUTPUT mask, per (b, j) the i with omask[b, i, j] (pygho_mask_lists on the mask stored (nb, ni, nj), k_first = 1), max_count = the
+ * longest list.  Only the listed rows out[b, i, j, :] = sum_k A[b,i,k,:] * B[b,k,j,:] (k where both operand masks are set, each
+ * nullable) are written: the caller zeroes `out` first.  Operands below 2 GiB each, row bytes % 16 == 0. */
+int pygho_masked_bmm_outlists(void* out, const void* A, const void* B, const uint8_t* amask, const uint8_t* bmask,
+                              const int16_t* list, int64_t max_count, int64_t nb, int64_t ni, int64_t nk, int64_t nj, int64_t d,
+                              int a_kfirst, int b_kfirst, int dtype, void* stream);
+
 /* out = mask ? data : value over (n_rows, d) with a per-row uint8 mask.  MaTensor.py:113-128.  Every dtype code
  * (integer features -- node / bond types, distance ids -- are legal MaskedTensor data: hodata/MaData.py:108-214). */
 int pygho_masked_fill(void* out, const void* data, const uint8_t* mask, double value,

@@ -67,6 +67,7 @@ PROTOTYPES = {
     "pygho_masked_bmm_clipped": (I, [P, P, P, P, P, P, P, L, L, L, L, L, I, I, I, P]),
     "pygho_mask_lists": (I, [P, P, P, L, L, L, I, P]),
     "pygho_masked_bmm_lists": (I, [P, P, P, P, P, P, P, I, L, L, L, L, L, I, I, I, P]),
+    "pygho_masked_bmm_outlists": (I, [P, P, P, P, P, P, L, L, L, L, L, L, I, I, I, P]),
     "pygho_masked_fill": (I, [P, P, P, D, L, L, I, P]),
     "pygho_masked_reduce": (I, [P, P, P, P, L, L, L, L, I, I, P]),
     "pygho_masked_reduce_bwd": (I, [P, P, P, P, P, L, L, L, L, I, I, P]),

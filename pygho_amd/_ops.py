@@ -1378,6 +1378,19 @@ def _bmm_launch(A: Tensor, B: Tensor, amask, bmask, omask, nb, ni, nk, nj, d, a_
                                                1 if on_j else 0, nb, ni, nk, nj, d, 1 if a_kfirst else 0, 1 if b_kfirst else 0,
                                                dtype_code(A), stream_ptr(dev)), "masked_bmm_lists")
             return out
+        # output-sparse: two dense operands, few outputs wanted (the gradient of an adjacency's values)
+        if (omask is not None and nb * ni * nk * d * A.element_size() < 2 ** 31 - 1 and nb * nk * nj * d * A.element_size() < 2 ** 31 - 1
+                and ni <= 32767 and _mask_density(omask) <= BMM_LIST_DENSITY):
+            lst, cnt = _mask_lists(omask, nb, ni, nj, True)
+            maxc = getattr(cnt, "_pygho_max", None)
+            if maxc is None:
+                maxc = int(cnt.max().item()) if cnt.numel() else 0
+                cnt._pygho_max = maxc
+            out.zero_()
+            check(lib().pygho_masked_bmm_outlists(ptr(out), ptr(A), ptr(B), ptr(amask), ptr(bmask), ptr(lst), maxc, nb, ni, nk, nj, d,
+                                                  1 if a_kfirst else 0, 1 if b_kfirst else 0, dtype_code(A), stream_ptr(dev)),
+                  "masked_bmm_outlists")
+            return out
     ext = _mask_extents(amask, bmask, omask, nb, ni, nk, nj, a_kfirst, b_kfirst) if USE_BMM_EXTENTS else None
     if ext is not None:
         check(lib().pygho_masked_bmm_clipped(ptr(out), ptr(A), ptr(B), ptr(amask), ptr(bmask), ptr(omask), ptr(ext), nb, ni, nk, nj, d,

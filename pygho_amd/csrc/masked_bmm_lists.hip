@@ -197,6 +197,70 @@ static int launch_lists(BmmListArgs p, int list_on_j, hipStream_t st) {
   return check_launch("masked_bmm_lists");
 }
 
+// ---- output-sparse form: out[b, i, j, :] = sum_k A[b,i,k,:] * B[b,k,j,:] ONLY where the output mask is set -------------------
+// (the gradient of an adjacency's values: two dense operands, 3-4 % of the outputs wanted).  Work items are the entries of the
+// output mask's per-column lists: item (b, j, t) -> i = list[b, j, t]; the output tensor is zeroed by the caller and only the listed
+// rows are written.  Operand rows are fetched with bounds-checked buffer loads predicated on both operand masks.
+struct BmmOutListArgs {
+  void* out;
+  const void* A;
+  const void* B;
+  const uint8_t* amask;    // nullable
+  const uint8_t* bmask;    // nullable
+  const int16_t* list;     // (nb, nj, list_pitch(ni)): the i with omask[b, i, j], ascending, -1 terminated
+  int ni, nk, nj, max_count;
+  int a_si, a_sk, b_sk, b_sj;
+  int chunks, items_per_wg;
+  int64_t n_items, a_bytes, b_bytes;
+};
+
+template <typename T, bool HAS_AMASK, bool HAS_BMASK>
+__global__ __launch_bounds__(kBlock) void masked_bmm_outlists_kernel(BmmOutListArgs p) {
+  using V = Vec16<T>;
+  constexpr int N = V::N;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4_t;
+  const uint32_t lr = threadIdx.x / (uint32_t)p.chunks, ch = threadIdx.x - lr * (uint32_t)p.chunks;
+  if (lr >= (uint32_t)p.items_per_wg) return;
+  const uint32_t item = blockIdx.x * (uint32_t)p.items_per_wg + lr;
+  if (item >= (uint32_t)p.n_items) return;
+  const uint32_t col = item / (uint32_t)p.max_count, t = item - col * (uint32_t)p.max_count;     // col = (b, j)
+  const int i = p.list[(int64_t)col * list_pitch(p.ni) + t];
+  if (i < 0) return;
+  const uint32_t b = col / (uint32_t)p.nj, j = col - b * (uint32_t)p.nj;
+  const __amdgpu_buffer_rsrc_t ra = bl_rsrc(p.A, (uint32_t)p.a_bytes), rb = bl_rsrc(p.B, (uint32_t)p.b_bytes);
+  const uint32_t a0 = b * (uint32_t)(p.ni * p.nk) + (uint32_t)i * (uint32_t)p.a_si, b0 = b * (uint32_t)(p.nk * p.nj) + j * (uint32_t)p.b_sj;
+  float acc[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) acc[q] = 0.f;
+  for (int k0 = 0; k0 < p.nk; k0 += 4) {
+    uint8_t ma[4], mb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = min(k0 + u, p.nk - 1);
+      ma[u] = HAS_AMASK ? p.amask[a0 + (uint32_t)k * (uint32_t)p.a_sk] : (uint8_t)1;
+      mb[u] = HAS_BMASK ? p.bmask[b0 + (uint32_t)k * (uint32_t)p.b_sk] : (uint8_t)1;
+    }
+    u4_t va[4], vb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = k0 + u < p.nk && ma[u] != 0 && mb[u] != 0;
+      const uint32_t k = (uint32_t)(k0 + u);
+      va[u] = __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? (int)(((a0 + k * (uint32_t)p.a_sk) * (uint32_t)p.chunks + ch) * 16u) : (int)0x80000000, 0, 0);
+      vb[u] = __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? (int)(((b0 + k * (uint32_t)p.b_sk) * (uint32_t)p.chunks + ch) * 16u) : (int)0x80000000, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float x[N], y[N];
+      V::unpack(make_uint4(va[u][0], va[u][1], va[u][2], va[u][3]), x);
+      V::unpack(make_uint4(vb[u][0], vb[u][1], vb[u][2], vb[u][3]), y);
+#pragma unroll
+      for (int q = 0; q < N; ++q) { const float pr = x[q] * y[q]; acc[q] += pr; }     // a skipped slot loaded zeros: + 0
+    }
+  }
+  const int64_t orow = ((int64_t)b * p.ni + i) * p.nj + j;
+  *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.out) + (orow * p.chunks + ch) * 16) = V::pack(acc);
+}
+
 }  // namespace pygho
 
 using namespace pygho;
@@ -247,4 +311,47 @@ extern "C" int pygho_masked_bmm_lists(void* out, const void* A, const void* B, c
     case PYGHO_F16: return launch_lists<f16>(p, list_on_j, st);
     default: return launch_lists<float>(p, list_on_j, st);
   }
+}
+
+extern "C" int pygho_masked_bmm_outlists(void* out, const void* A, const void* B, const uint8_t* amask, const uint8_t* bmask,
+                                         const int16_t* list, int64_t max_count, int64_t nb, int64_t ni, int64_t nk, int64_t nj,
+                                         int64_t d, int a_kfirst, int b_kfirst, int dtype, void* stream) {
+  if (nb < 0 || ni < 0 || nk < 0 || nj < 0 || d < 0 || max_count < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (nb == 0 || ni == 0 || nj == 0 || d == 0 || max_count == 0 || nk == 0) return PYGHO_OK;
+  if (!out || !list || !A || !B) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (dtype != PYGHO_F32 && dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("masked_bmm_outlists: unsupported dtype %d", dtype); return PYGHO_ERR_UNSUPPORTED; }
+  const int es = dtype == PYGHO_F32 ? 4 : 2;
+  const int64_t row_bytes = d * es;
+  if (row_bytes % 16 != 0 || row_bytes / 16 > kBlock) { set_error("masked_bmm_outlists: row of %lld bytes has no 16-byte form", (long long)row_bytes); return PYGHO_ERR_UNSUPPORTED; }
+  if (max_count > ni) max_count = ni;
+  BmmOutListArgs p;
+  p.out = out; p.A = A; p.B = B; p.amask = amask; p.bmask = bmask; p.list = list;
+  p.ni = (int)ni; p.nk = (int)nk; p.nj = (int)nj; p.max_count = (int)max_count;
+  if (a_kfirst) { p.a_sk = (int)ni; p.a_si = 1; } else { p.a_si = (int)nk; p.a_sk = 1; }
+  if (b_kfirst) { p.b_sk = (int)nj; p.b_sj = 1; } else { p.b_sj = (int)nk; p.b_sk = 1; }
+  p.chunks = (int)(row_bytes / 16);
+  p.items_per_wg = kBlock / p.chunks;
+  p.n_items = nb * nj * max_count;
+  p.a_bytes = nb * ni * nk * row_bytes;
+  p.b_bytes = nb * nk * nj * row_bytes;
+  if (nk > 32767 || ni > 32767 || p.a_bytes >= 0x7fffffffll || p.b_bytes >= 0x7fffffffll || p.n_items >= 0x7fffffffll) {
+    set_error("masked_bmm_outlists: operands must stay below 2 GiB");
+    return PYGHO_ERR_UNSUPPORTED;
+  }
+  const dim3 g((unsigned)ceil_div(p.n_items, (int64_t)p.items_per_wg)), blk(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+#define PYGHO_OL(T)                                                                                              \
+  {                                                                                                              \
+    if (amask && bmask) hipLaunchKernelGGL((masked_bmm_outlists_kernel<T, true, true>), g, blk, 0, st, p);       \
+    else if (amask) hipLaunchKernelGGL((masked_bmm_outlists_kernel<T, true, false>), g, blk, 0, st, p);          \
+    else if (bmask) hipLaunchKernelGGL((masked_bmm_outlists_kernel<T, false, true>), g, blk, 0, st, p);          \
+    else hipLaunchKernelGGL((masked_bmm_outlists_kernel<T, false, false>), g, blk, 0, st, p);                    \
+  }
+  switch (dtype) {
+    case PYGHO_BF16: PYGHO_OL(bf16) break;
+    case PYGHO_F16: PYGHO_OL(f16) break;
+    default: PYGHO_OL(float) break;
+  }
+#undef PYGHO_OL
+  return check_launch("masked_bmm_outlists");
 }

@@ -163,7 +163,7 @@ def test_masked_bmm_vs_einsum(dev, dtype, shape, layout):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(4, 37, 37, 37, 128), (2, 50, 70, 9, 16), (3, 16, 16, 16, 8), (2, 5, 130, 33, 24)])
 @pytest.mark.parametrize("layout", [(False, True), (True, True), (False, False), (True, False)])
-@pytest.mark.parametrize("sparse_side", ["A", "B"])
+@pytest.mark.parametrize("sparse_side", ["A", "B", "O"])
 def test_masked_bmm_sparse_operand_lists(dev, dtype, shape, layout, sparse_side):
     """one operand with an adjacency-like mask (5 % unmasked, some empty columns): the contraction runs on the neighbour-list kernel
     (pygho_mask_lists + pygho_masked_bmm_lists) in every storage layout, and agrees with a float64 einsum AND with the dense
@@ -174,8 +174,9 @@ def test_masked_bmm_sparse_operand_lists(dev, dtype, shape, layout, sparse_side)
     rng = np.random.default_rng(hash((shape, layout, sparse_side)) % (2 ** 31))
     A = rng.standard_normal((nb, ni, nk, d)).astype(np.float32)
     B = rng.standard_normal((nb, nk, nj, d)).astype(np.float32)
-    dens = {"A": (0.05, 0.6), "B": (0.6, 0.05)}[sparse_side]
-    am, bm, om = rng.random((nb, ni, nk)) < dens[0], rng.random((nb, nk, nj)) < dens[1], rng.random((nb, ni, nj)) > 0.2
+    # "O": two dense operands, an adjacency-like OUTPUT mask (the gradient of an adjacency's values): pygho_masked_bmm_outlists
+    dens = {"A": (0.05, 0.6, 0.8), "B": (0.6, 0.05, 0.8), "O": (0.6, 0.6, 0.05)}[sparse_side]
+    am, bm, om = rng.random((nb, ni, nk)) < dens[0], rng.random((nb, nk, nj)) < dens[1], rng.random((nb, ni, nj)) < dens[2]
     At, Bt = T(A, dev, dtype), T(B, dev, dtype)
     Aq, Bq = N(At).astype(np.float64), N(Bt).astype(np.float64)
     exp = np.einsum("bikd,bkjd->bijd", Aq * am[..., None], Bq * bm[..., None]) * om[..., None]
@@ -188,10 +189,10 @@ def test_masked_bmm_sparse_operand_lists(dev, dtype, shape, layout, sparse_side)
     bm_st = T(bm, dev) if bkf else T(bm, dev).permute(0, 2, 1).contiguous()
     masks = (_ops._mask_u8(am_st), _ops._mask_u8(bm_st), _ops._mask_u8(T(om, dev)))
     supported = (d * At.element_size()) % 16 == 0
-    assert min(_ops._mask_density(masks[0]), _ops._mask_density(masks[1])) <= _ops.BMM_LIST_DENSITY
+    assert min(_ops._mask_density(m) for m in masks) <= _ops.BMM_LIST_DENSITY
     got = _ops.masked_bmm(a_st, b_st, *masks, nb, ni, nk, nj, d, akf, bkf)
     if supported:
-        sparse_mask = masks[0] if sparse_side == "A" else masks[1]
+        sparse_mask = masks["ABO".index(sparse_side)]
         assert getattr(sparse_mask, "_pygho_lists", None), "the neighbour-list kernel did not run"
     eps = {torch.float32: 1e-5, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
     scale = max(np.abs(exp).max(), 1e-3)
