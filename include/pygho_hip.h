@@ -431,6 +431,11 @@ int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x,
 int pygho_rowblock_linear_blocks(int64_t m);
 int pygho_rowblock_linear(void* out, const void* in, const void* wl, const void* bias, const void* addend,
                           float* stats_ws, const float* shift, int64_t m, int64_t d, int dtype, void* stream);
+/* The same launch with the statistics' shift taken inside the kernel: shift_out[n] = row 0 of the output (bias + in[0] . wl[n] +
+ * addend[0, n], f32), computed by every workgroup from the W it staged and written once; pass it on to pygho_bn_finalize.  Saves the
+ * 1-row library GEMM in front of every block (honn/utils.py:126-138 has no such step: the shift only conditions the variance). */
+int pygho_rowblock_linear_autoshift(void* out, const void* in, const void* wl, const void* bias, const void* addend,
+                                    float* stats_ws, float* shift_out, int64_t m, int64_t d, int dtype, void* stream);
 
 /* Backward of Linear -> BatchNorm -> act in one streaming pass (bf16 / f16, d = 64 or 128):
  *   gpre = the input gradient of pygho_bn_act_bwd for (pre, gh) given the finished sums (same formula, same rounding),

@@ -82,6 +82,7 @@ PROTOTYPES = {
     "pygho_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, P, I, P, P]),
     "pygho_rowblock_linear_blocks": (I, [L]),
     "pygho_rowblock_linear": (I, [P, P, P, P, P, P, P, L, L, I, P]),
+    "pygho_rowblock_linear_autoshift": (I, [P, P, P, P, P, P, P, L, L, I, P]),
     "pygho_bn_bwd_linear": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, P]),
     "pygho_bn_bwd_linear_dw_blocks": (I, [L]),
     "pygho_bn_bwd_linear_dw": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, L, P]),

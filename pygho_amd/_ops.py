@@ -1629,10 +1629,11 @@ def rowblock_linear_supported(x: Tensor, out_features: int) -> bool:
 
 
 def rowblock_linear(x: Tensor, wl: Tensor, bias: Optional[Tensor] = None, addend: Optional[Tensor] = None,
-                    stats_shift: Optional[Tensor] = None):
-    """out = x @ wl^T (+ bias) (+ addend) on the skinny-GEMM kernel; with `stats_shift` (f32, d) also returns the per-block
-    partial sums of (out - shift), (out - shift)^2 for pygho_bn_finalize: (out, partial_sums or None)."""
-    dev = require_device(x, wl, bias, addend, stats_shift)
+                    stats_shift=None):
+    """out = x @ wl^T (+ bias) (+ addend) on the skinny-GEMM kernel; with `stats_shift` also returns the per-block partial
+    sums of (out - shift), (out - shift)^2 for pygho_bn_finalize: (out, partial_sums or None).  `stats_shift` is an (f32, d)
+    tensor, or True: the kernel takes row 0 of its own output as the shift and the result is (out, (partial_sums, shift))."""
+    dev = require_device(x, wl, bias, addend, stats_shift if isinstance(stats_shift, Tensor) else None)
     x, wl = x.contiguous(), wl.contiguous()
     m, d = x.shape
     assert wl.shape == (d, d) and wl.dtype == x.dtype
@@ -1643,6 +1644,11 @@ def rowblock_linear(x: Tensor, wl: Tensor, bias: Optional[Tensor] = None, addend
         ws = torch.empty((nblk, 2, d), dtype=torch.float32, device=dev)
     if addend is not None:
         addend = addend.contiguous()
+    if stats_shift is True:
+        shift = torch.empty(d, dtype=torch.float32, device=dev)
+        check(lib().pygho_rowblock_linear_autoshift(ptr(out), ptr(x), ptr(wl), ptr(bias), ptr(addend), ptr(ws), ptr(shift), m, d,
+                                                    dtype_code(x), stream_ptr(dev)), "rowblock_linear")
+        return out, (ws, shift)
     check(lib().pygho_rowblock_linear(ptr(out), ptr(x), ptr(wl), ptr(bias), ptr(addend), ptr(ws), ptr(stats_shift), m, d,
                                       dtype_code(x), stream_ptr(dev)), "rowblock_linear")
     return out, ws
@@ -1724,9 +1730,7 @@ class _TupleBlock(torch.autograd.Function):
         partial = None
         if skinny:
             # hand-written streaming GEMM: the BatchNorm statistics of its output ride in the epilogue
-            sum_shift = torch.nn.functional.linear(x[:1], wc, bc).float().reshape(-1) if training else None
-            pre, sums = rowblock_linear(x, wc, bc, stats_shift=sum_shift)
-            partial = (sums, sum_shift) if training else None
+            pre, partial = rowblock_linear(x, wc, bc, stats_shift=True if training else None)     # partial = (sums, shift)
         else:
             pre = torch.nn.functional.linear(x, wc, bc)
         # f32 rows carry half the elements per byte: there the BatchNorm + activation can ride on the aggregation's loads
@@ -1837,15 +1841,12 @@ class _ConcatBlock(torch.autograd.Function):
         wc = w if w.dtype == dt else w.to(dt)
         bc = None if b is None else (b if b.dtype == dt else b.to(dt))
         blocks = [wc[:, k * d:(k + 1) * d].contiguous() for k in range(len(xs))]
-        shift = None
-        if training:
-            shift = torch.nn.functional.linear(torch.cat([x[:1] for x in xs], dim=1), wc, bc).float().reshape(-1)
-        pre, sums = None, None
+        pre, partial = None, None
         for k, (x, wk) in enumerate(zip(xs, blocks)):
             last = k == len(xs) - 1
-            pre, sums = rowblock_linear(x, wk, bc if k == 0 else None, addend=pre, stats_shift=shift if last else None)
+            pre, partial = rowblock_linear(x, wk, bc if k == 0 else None, addend=pre, stats_shift=True if (last and training) else None)
         h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum,
-                                          (sums, shift) if training else None, apply=True)
+                                          partial if training else None, apply=True)
         ctx.save_for_backward(pre, *xs, *blocks, *saved)
         ctx.meta = (len(xs), training, act, None if b is None else b.dtype, gamma is not None, beta is not None, w.dtype)
         ctx.mark_non_differentiable(mean, var)

@@ -56,14 +56,15 @@ template <int D> struct RlGeom {
 template <typename T, int D>
 __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ wl,
                                                                     const T* __restrict__ bias, const T* __restrict__ addend,
-                                                                    float* __restrict__ stats_ws, const float* __restrict__ shift,
-                                                                    int64_t m_rows) {
+                                                                    float* __restrict__ stats_ws, float* __restrict__ shift,
+                                                                    int self_shift, int64_t m_rows) {
   using G = RlGeom<D>;
   using V = Vec16<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_w = smem;
   char* lds_stage = smem + G::w_bytes;
   float* lds_bias = reinterpret_cast<float*>(smem + G::w_bytes + G::stage_bytes);
+  float* lds_shift = lds_bias + D;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
 
@@ -80,9 +81,27 @@ __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restric
   const int ech = lane % G::CH;                          // epilogue: this lane's 16-B channel chunk (fixed: 64 % CH == 0)
   const int erow0 = lane / G::CH;                        // ... and its first row inside the wave's 32
   constexpr int EROWS = 64 / G::CH;                      // rows covered per epilogue iteration
+  // self_shift: the shift of the statistics is row 0 of the output, computed HERE by every workgroup from the W it has just
+  // staged (128 x 128 multiply-adds, the same instruction sequence everywhere, so every workgroup and the finalisation kernel
+  // see the same bits) instead of by a 1-row library GEMM in front of the launch (14.5 us of launch latency, 8x per step)
+  if (stats_ws && self_shift) {
+    for (int n = threadIdx.x; n < D; n += kBlock) {
+      float a = lds_bias[n];
+      const T* wrow = reinterpret_cast<const T*>(lds_w + (size_t)n * G::PITCH * 2);
+      for (int k = 0; k < D; ++k) a += load_as_acc<T>(in + k) * load_as_acc<T>(wrow + k);
+      if (addend) a += load_as_acc<T>(addend + n);
+      lds_shift[n] = a;
+      if (blockIdx.x == 0) shift[n] = a;
+    }
+    __syncthreads();
+  }
   float sh[8], s1[8], s2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sh[j] = (stats_ws && shift) ? shift[ech * 8 + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) {
+    sh[j] = !stats_ws ? 0.f : (self_shift ? lds_shift[ech * 8 + j] : (shift ? shift[ech * 8 + j] : 0.f));
+    s1[j] = 0.f;
+    s2[j] = 0.f;
+  }
 
   uint4 fb[2][G::KS];                                    // `in` fragments of the current tile
   auto load_tile = [&](int64_t tile, uint4 (&dst)[2][G::KS]) {
@@ -781,8 +800,8 @@ int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum
 }
 
 template <typename T, int D>
-int launch_rowblock(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws, const float* shift,
-                    int64_t m, int grid, hipStream_t st) {
+int launch_rowblock(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws, float* shift,
+                    int self_shift, int64_t m, int grid, hipStream_t st) {
   using G = RlGeom<D>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -792,7 +811,7 @@ int launch_rowblock(void* out, const void* in, const void* wl, const void* bias,
     attr_set = true;
   }
   hipLaunchKernelGGL((rowblock_linear_kernel<T, D>), dim3(grid), dim3(kBlock), G::lds_bytes, st, (T*)out, (const T*)in, (const T*)wl,
-                     (const T*)bias, (const T*)addend, stats_ws, shift, m);
+                     (const T*)bias, (const T*)addend, stats_ws, shift, self_shift, m);
   return check_launch("rowblock_linear");
 }
 
@@ -805,21 +824,32 @@ extern "C" int pygho_rowblock_linear_blocks(int64_t m) {
   return grid_for(m, kRlTile, 512);          // 2 resident workgroups per CU (70 KB of LDS each)
 }
 
-extern "C" int pygho_rowblock_linear(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws,
-                                     const float* shift, int64_t m, int64_t d, int dtype, void* stream) {
+static int rowblock_entry(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws,
+                          float* shift, int self_shift, int64_t m, int64_t d, int dtype, void* stream) {
   if (m < 0 || d <= 0) { set_error("rowblock_linear: bad size"); return PYGHO_ERR_INVALID; }
   if (m == 0) return PYGHO_OK;
   if (!out || !in || !wl) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("rowblock_linear: bf16 / f16 only (f32 takes the library GEMM)"); return PYGHO_ERR_UNSUPPORTED; }
   if (d != 64 && d != 128) { set_error("rowblock_linear: width %lld not supported (64, 128)", (long long)d); return PYGHO_ERR_UNSUPPORTED; }
   if ((((uintptr_t)out | (uintptr_t)in | (uintptr_t)wl | (uintptr_t)addend) % 16) != 0) { set_error("rowblock_linear: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
+  if (self_shift && (!stats_ws || !shift)) { set_error("rowblock_linear: the in-kernel shift needs stats_ws and a shift buffer"); return PYGHO_ERR_INVALID; }
   const int grid = pygho_rowblock_linear_blocks(m);
   hipStream_t st = (hipStream_t)stream;
 #define PYGHO_RL(T)                                                                                               \
-  (d == 128 ? launch_rowblock<T, 128>(out, in, wl, bias, addend, stats_ws, shift, m, grid, st)                     \
-            : launch_rowblock<T, 64>(out, in, wl, bias, addend, stats_ws, shift, m, grid, st))
+  (d == 128 ? launch_rowblock<T, 128>(out, in, wl, bias, addend, stats_ws, shift, self_shift, m, grid, st)         \
+            : launch_rowblock<T, 64>(out, in, wl, bias, addend, stats_ws, shift, self_shift, m, grid, st))
   return dtype == PYGHO_BF16 ? PYGHO_RL(bf16) : PYGHO_RL(f16);
 #undef PYGHO_RL
+}
+
+extern "C" int pygho_rowblock_linear(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws,
+                                     const float* shift, int64_t m, int64_t d, int dtype, void* stream) {
+  return rowblock_entry(out, in, wl, bias, addend, stats_ws, const_cast<float*>(shift), 0, m, d, dtype, stream);
+}
+
+extern "C" int pygho_rowblock_linear_autoshift(void* out, const void* in, const void* wl, const void* bias, const void* addend,
+                                               float* stats_ws, float* shift_out, int64_t m, int64_t d, int dtype, void* stream) {
+  return rowblock_entry(out, in, wl, bias, addend, stats_ws, shift_out, 1, m, d, dtype, stream);
 }
 
 extern "C" int pygho_bn_bwd_linear(void* gx, void* gpre, const void* pre, const void* gh, const void* wl, const void* addend,

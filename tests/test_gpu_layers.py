@@ -303,6 +303,14 @@ def test_rowblock_linear_matches_f32_reference(dev, dtype, d):
         out3, _ = _ops.rowblock_linear(x, w, None, addend=g)
         prod, _ = _ops.rowblock_linear(x, w, None)
         assert torch.equal(out3, (prod.float() + g.float()).to(dtype))
+        # shift taken inside the kernel = row 0 of the (unrounded) output, with and without bias / residual row
+        for bb, add in ((b, None), (None, g), (b, g)):
+            out4, (sums4, sh4) = _ops.rowblock_linear(x, w, bb, addend=add, stats_shift=True)
+            r0 = x[0].float() @ w.float().t() + (bb.float() if bb is not None else 0) + (add[0].float() if add is not None else 0)
+            torch.testing.assert_close(sh4, r0, rtol=1e-4, atol=1e-4)
+            o = out4.double() - sh4.double()
+            torch.testing.assert_close(sums4[:, 0].double().sum(0), o.sum(0), rtol=1e-5, atol=1e-3 * m ** 0.5)
+            torch.testing.assert_close(sums4[:, 1].double().sum(0), (o * o).sum(0), rtol=1e-5, atol=1e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
