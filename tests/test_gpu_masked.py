@@ -91,6 +91,9 @@ def test_masked_tensor_methods_golden(dev):
     assert np.array_equal(N(Mx.unpooling([2], MX).data), g["unpool2"] * valid)      # documented: masked entries read padvalue
     assert np.array_equal(N(Mx.unpooling([1], MX).data), g["unpool1"] * valid)
     assert np.array_equal(N(MaskedTensor(X, Xm, padvalue=float("inf")).fill_masked(1024.)), g["fill1024"])
+    inplace = MaskedTensor(X, Xm, padvalue=float("inf"))          # fill_masked_ (MaTensor.py:113-120): mutates the container
+    inplace.fill_masked_(1024.)
+    assert inplace.padvalue == 1024. and np.array_equal(N(inplace.data), g["fill1024"]) and np.array_equal(N(inplace.mask), g["Xmask"])
     np.testing.assert_allclose(N(MX.diagonalapply(lambda v, f: v * f.unsqueeze(-1)).data), g["diagapply"], **TOL)
     assert np.array_equal(N(MX.catvalue([MX, MX], True).data), g["cat"])
     np.testing.assert_allclose(N(MX.add(MaskedTensor(X * 2, Xm), True).data), g["add_same"], **TOL)
@@ -384,3 +387,40 @@ def test_pair_views_gradient_one_pass(dev):
     for got, ref in ((dg, rdg), (s1, r1), (s2, r2)):
         np.testing.assert_allclose(N(got), ref.detach().numpy(), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(N(xd.grad), xr.grad.numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("aggr", ["sum", "max", "min"])
+@pytest.mark.parametrize("dim1", [1, 2])
+def test_spmamm_vs_oracle_and_einsum(dev, aggr, dim1):
+    """sparse (b, n, m, d) adjacency x masked representation (reference Spmamm.py:12-68, implemented to its documented semantics)
+    against the oracle; the sum form also against an einsum, and its gradients wrt both value sets against autograd on the CPU."""
+    from pygho_amd import MaskedTensor, SparseTensor
+    from pygho_amd.backend.Spmamm import spmamm
+    rng = np.random.default_rng(3 + dim1)
+    b, n, m, l, d = 4, 6, 6, 5, 8
+    Adense = rng.standard_normal((b, n, m, d)).astype(np.float32)
+    Amask = rng.random((b, n, m)) > 0.6
+    Amask[1, 2] = False                                           # a target without any message
+    ind = np.stack(np.nonzero(Amask))
+    Aval = Adense[ind[0], ind[1], ind[2]]
+    cases = [((b, m, l, d), 1), ((b, l, m, d), 2)] if aggr == "sum" else [((b, m, d), 1)]
+    for bshape, dim2 in cases:
+        B = rng.standard_normal(bshape).astype(np.float32)
+        Bmask = rng.random(bshape[:-1]) > 0.3
+        av = T(Aval, dev).requires_grad_(True)
+        bv = T(B, dev).requires_grad_(True)
+        out = spmamm(SparseTensor(T(ind, dev), av, [b, n, m, d], True), dim1, MaskedTensor(bv, T(Bmask, dev)), dim2, None, aggr)
+        exp = O.spmamm(ind, Aval, (b, n, m, d), dim1, B, Bmask, dim2, aggr)
+        np.testing.assert_allclose(N(out.raw), exp, rtol=1e-5, atol=1e-5)
+        if aggr != "sum":
+            continue
+        at, bt = torch.from_numpy(Adense).requires_grad_(True), torch.from_numpy(B).requires_grad_(True)
+        am, bm = torch.from_numpy(Amask)[..., None], torch.from_numpy(Bmask)[..., None]
+        spec = {(1, 1): "bknd,bkld->bnld", (2, 1): "bnkd,bkld->bnld", (1, 2): "bknd,blkd->blnd", (2, 2): "bnkd,blkd->blnd"}[(dim1, dim2)]
+        ref = torch.einsum(spec, at * am, bt * bm)
+        np.testing.assert_allclose(N(out.raw), ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+        w = torch.randn(ref.shape, generator=torch.Generator().manual_seed(0))
+        out.raw.backward(w.to(dev))
+        ref.backward(w)
+        np.testing.assert_allclose(N(av.grad), at.grad.numpy()[ind[0], ind[1], ind[2]], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(N(bv.grad) * Bmask[..., None], bt.grad.numpy() * Bmask[..., None], rtol=1e-5, atol=1e-5)
