@@ -666,3 +666,40 @@ def test_sunconv_sparse_fused_passes(dev, case):
             continue                                       # bias in front of a BatchNorm: zero up to rounding noise
         s = float(ref.abs().max()) + 1e-6
         torch.testing.assert_close(res[True][2][k] / s, ref / s, msg=k, **tol)
+
+
+@pytest.mark.parametrize("layer_name", ["NGNNConv", "SSWLConv", "DSSGNNConv", "SUNConv"])
+def test_sd_mode_equals_dd_mode(dev, layer_name):
+    """mode "SD" (sparse (b, n, n) adjacency from hodata.to_sparse_adj, dense representation; spmamm) gives what mode "DD"
+    (dense adjacency; masked bmm / neighbour lists) gives on the same batch: outputs and input gradients."""
+    import copy
+    from pygho_amd import MaskedTensor, synth
+    from pygho_amd.hodata import to_dense_adj, to_sparse_adj
+    from pygho_amd.honn import Conv
+    h = 16
+    dn = synth.make_dense_batch(6, seed=9, hidden=h, clip_nodes=9)
+    b, n = dn["nodemask"].shape
+    eb, er, ec = np.nonzero(dn["Amask"])
+    ei, ebt, ea = T(np.stack((er, ec)), dev), T(eb, dev), T(dn["A"][eb, er, ec], dev)
+    A_dd = to_dense_adj(ei, ebt, ea, n, b)
+    A_sd = to_sparse_adj(ei, ebt, ea, n, b)
+    torch.manual_seed(0)
+    mlp = dict(MLP, norm="none")
+    mk = {"NGNNConv": lambda m: Conv.NGNNConv(h, h, "sum", m, dict(mlp)),
+          "SSWLConv": lambda m: Conv.SSWLConv(h, h, "sum", m, dict(mlp)),
+          "DSSGNNConv": lambda m: Conv.DSSGNNConv(h, h, "sum", "sum", "mean", m, dict(mlp)),
+          "SUNConv": lambda m: Conv.SUNConv(h, h, "sum", "mean", m, dict(mlp), dict(mlp))}[layer_name]
+    dd_layer = mk("DD").to(dev)
+    sd_layer = mk("SD").to(dev)
+    sd_layer.load_state_dict(dd_layer.state_dict())
+    xm = T(dn["Xmask"], dev)
+    w = torch.randn(dn["X"].shape, device=dev)
+    res = []
+    for layer, A in ((dd_layer, A_dd), (sd_layer, A_sd)):
+        x = T(dn["X"], dev).requires_grad_(True)
+        out = layer(A, MaskedTensor(x, xm, 0.0, True), {})
+        o = out.data * xm[..., None]
+        o.backward(w)
+        res.append((o.detach(), x.grad * xm[..., None]))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-5)
