@@ -1363,7 +1363,7 @@ def _mask_lists(m8: Tensor, nb: int, nk: int, nc: int, k_first: bool):
 def _bmm_launch(A: Tensor, B: Tensor, amask, bmask, omask, nb, ni, nk, nj, d, a_kfirst: bool, b_kfirst: bool) -> Tensor:
     dev = require_device(A, B, amask, bmask, omask)
     out = torch.empty((nb, ni, nj, d), dtype=A.dtype, device=dev)
-    if (USE_BMM_LISTS and nk <= 32767 and (d * A.element_size()) % 16 == 0 and d * A.element_size() <= 4096
+    if (USE_BMM_LISTS and 0 < nk <= 32767 and nb * ni * nj > 0 and (d * A.element_size()) % 16 == 0 and d * A.element_size() <= 4096
             and A.dtype in (torch.float32, torch.bfloat16, torch.float16)):
         da, db = _mask_density(amask), _mask_density(bmask)
         if min(da, db) <= BMM_LIST_DENSITY:

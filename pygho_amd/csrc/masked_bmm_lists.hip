@@ -282,7 +282,13 @@ extern "C" int pygho_masked_bmm_lists(void* out, const void* A, const void* B, c
                                       int64_t nj, int64_t d, int a_kfirst, int b_kfirst, int dtype, void* stream) {
   if (nb < 0 || ni < 0 || nk < 0 || nj < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
   if (nb == 0 || ni == 0 || nj == 0 || d == 0) return PYGHO_OK;
-  if (!out || !list || !count || (nk > 0 && (!A || !B))) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (!out) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (nk == 0) {                                              // empty contraction: the output is all zeros
+    const int esz = dtype == PYGHO_F32 ? 4 : 2;
+    if (hipMemsetAsync(out, 0, (size_t)(nb * ni * nj * d) * esz, (hipStream_t)stream) != hipSuccess) { set_error("masked_bmm_lists: memset failed"); return PYGHO_ERR_LAUNCH; }
+    return PYGHO_OK;
+  }
+  if (!list || !count || !A || !B) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if (ni > INT32_MAX / 4 || nk > 32767 || nj > INT32_MAX / 4 || ni * nk > INT32_MAX / 4 || nk * nj > INT32_MAX / 4) {
     set_error("masked_bmm_lists: tuple grid too large");
     return PYGHO_ERR_UNSUPPORTED;

@@ -424,3 +424,36 @@ def test_spmamm_vs_oracle_and_einsum(dev, aggr, dim1):
         ref.backward(w)
         np.testing.assert_allclose(N(av.grad), at.grad.numpy()[ind[0], ind[1], ind[2]], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(N(bv.grad) * Bmask[..., None], bt.grad.numpy() * Bmask[..., None], rtol=1e-5, atol=1e-5)
+
+
+def test_new_kernels_empty_and_degenerate_inputs(dev):
+    """zero-sized batches / tuple sets / contractions and fully masked inputs through the dense-path kernels added in round 1."""
+    from pygho_amd import MaskedTensor, _ops
+    from pygho_amd.backend.Mamamm import mamamm
+    from pygho_amd.hodata import to_dense_adj, to_dense_tuplefeat, to_dense_x
+    dt = torch.float32
+    out = _ops.masked_pair_combine(torch.empty((0, 3, 3, 8), device=dev), None, None, None, False, None, (0, 3, 3, 8), dt, dev)
+    assert out.shape == (0, 3, 3, 8)
+    e32 = torch.empty(0, dtype=torch.int32, device=dev)
+    out = _ops.pair_gather_combine(torch.empty((0, 8), device=dev), torch.ones((4, 8), device=dev), None, None, False, e32, e32, 8, dt, dev)
+    assert out.shape == (0, 8)
+    # a batch whose adjacency has no edge at all: neighbour lists are empty, the product is exactly zero
+    x = torch.randn(3, 5, 5, 8, device=dev)
+    xm = torch.ones(3, 5, 5, dtype=torch.bool, device=dev)
+    a = torch.randn(3, 5, 5, 8, device=dev)
+    am = torch.zeros(3, 5, 5, dtype=torch.bool, device=dev)
+    got = mamamm(MaskedTensor(x, xm), 2, MaskedTensor(a, am), 1, xm)
+    assert torch.count_nonzero(got.data) == 0
+    # every output masked
+    got = mamamm(MaskedTensor(x, xm), 2, MaskedTensor(a, xm), 1, am)
+    assert torch.count_nonzero(got.data) == 0
+    # builders: a batch of empty graphs next to one real graph, and an edge-less batch
+    ptr = torch.tensor([0, 0, 3, 3], device=dev)
+    mt = to_dense_x(torch.arange(3, device=dev).float().reshape(3, 1), ptr)
+    assert mt.mask.cpu().tolist() == [[False] * 3, [True] * 3, [False] * 3] and mt.data[1].flatten().cpu().tolist() == [0., 1., 2.]
+    shape = torch.tensor([[0, 0], [2, 2], [0, 0]], device=dev)
+    mt = to_dense_tuplefeat(torch.arange(4, device=dev), shape, torch.tensor([0, 0, 4, 4], device=dev))
+    assert mt.mask.sum().item() == 4 and mt.data[1].cpu().tolist() == [[0, 1], [2, 3]]
+    none = torch.empty((2, 0), dtype=torch.int64, device=dev)
+    mt = to_dense_adj(none, torch.empty(0, dtype=torch.int64, device=dev), torch.empty((0, 4), device=dev), 3, 2, -1.0)
+    assert not mt.mask.any() and torch.all(mt.data == -1.0) and tuple(mt.shape) == (2, 3, 3, 4)
