@@ -125,3 +125,39 @@ def test_batch2dense_feeds_the_dense_layers(dev):
     out_a = layer(batch.A, batch.X, {})
     out_b = layer(MaskedTensor(T(dn["A"], dev), T(dn["Amask"], dev), 0.0, True), MaskedTensor(T(dn["X"], dev), T(dn["Xmask"], dev), 0.0, True), {})
     torch.testing.assert_close(out_a.data, out_b.data, rtol=1e-6, atol=1e-6)
+
+
+def test_sp_datapreprocess_and_batch2sparse(dev):
+    """reference hodata/SpData.py:80-171 on the device: per-graph preprocessing (edge coalescing incl. duplicate edges, tuple sampler,
+    precomputed message triples for two keys) against the host plan of the same graph, then batch2sparse on a collated batch."""
+    import types
+    from pygho_amd import SparseTensor, synth
+    from pygho_amd.hodata import batch2sparse, parsekey, sp_datapreprocess
+    from conftest import canon_triples
+    assert parsekey("X___A___1___X___0") == ("X", "A", 1, "X", 0)
+    keys = ["X___X___1___A___0", "X___A___1___X___0"]
+    rng = np.random.default_rng(12)
+    for _ in range(3):
+        rec = synth.make_graph(rng, "zinc", 3, tuple(keys))
+        n = rec.num_nodes
+        dup = np.concatenate((rec.edge_index, rec.edge_index[:, :3]), axis=1)          # duplicated edges: attributes are summed
+        dup_attr = np.concatenate((rec.edge_attr, rec.edge_attr[:3])).astype(np.float32)
+        data = types.SimpleNamespace(num_nodes=n, x=T(rec.x, dev), edge_index=T(dup, dev), edge_attr=T(dup_attr, dev))
+        sampler = lambda d: SparseTensor(T(rec.tupleid, dev), T(rec.tuplefeat, dev), [n, n], True)
+        out = sp_datapreprocess(data, [sampler], [""], keys)
+        assert np.array_equal(N(out.edge_index), rec.edge_index) and out.num_edges == rec.edge_index.shape[1]
+        exp_attr = rec.edge_attr.astype(np.float32).copy()
+        # edges come back in lexicographic order = the record's order; the first three were given twice
+        exp_attr[:3] *= 2
+        assert np.array_equal(N(out.edge_attr), exp_attr)
+        assert out.num_tuples == rec.tupleid.shape[1] and N(out.tupleshape).tolist() == [[n, n]]
+        for key in keys:
+            got = canon_triples(N(getattr(out, key + "___acd")))
+            assert np.array_equal(got, canon_triples(rec.acd[key])), key
+    hb = synth.make_batch(5, "zinc", seed=4)
+    batch = dict(num_nodes=hb.num_nodes, edge_index=T(hb.edge_index, dev), edge_attr=T(hb.edge_attr, dev), tupleid=T(hb.tupleid, dev),
+                 tuplefeat=T(hb.tuplefeat, dev), tupleshape=torch.tensor([[hb.num_nodes // 5 + 1, hb.num_nodes // 5 + 1]] * 4
+                                                                         + [[hb.num_nodes - 4 * (hb.num_nodes // 5 + 1)] * 2], device=dev))
+    batch = batch2sparse(batch)
+    assert tuple(batch["A"].shape[:2]) == (hb.num_nodes, hb.num_nodes) and batch["A"].nnz == hb.edge_index.shape[1]
+    assert tuple(batch["X"].shape[:2]) == (hb.num_nodes, hb.num_nodes) and np.array_equal(N(batch["X"].indices), hb.tupleid)
