@@ -1118,27 +1118,29 @@ class _PairViews(torch.autograd.Function):
     subgraph layer takes of a 2-D representation; their gradients return to the tuple level in ONE pass."""
 
     @staticmethod
-    def forward(ctx, data: Tensor, mask: Tensor):
+    def forward(ctx, data: Tensor, mask: Tensor, want_dim2: bool = True):
         require_device(data, mask)
         data = data.contiguous()
         dmask = torch.diagonal(mask, 0, 1, 2)
         dg = torch.where(dmask.unsqueeze(-1), _diag_rows(data), torch.zeros((), dtype=data.dtype, device=data.device))
         s1, _ = _MaskedReduce.apply(data, mask, 1, "sum")
-        s2, _ = _MaskedReduce.apply(data, mask, 2, "sum")
+        s2 = _MaskedReduce.apply(data, mask, 2, "sum")[0] if want_dim2 else data.new_empty((0,) + tuple(data.shape[2:]))
         ctx.mask = mask
-        ctx.meta = (tuple(data.shape), data.dtype)
+        ctx.meta = (tuple(data.shape), data.dtype, want_dim2)
         return dg.contiguous(), s1, s2
 
     @staticmethod
     def backward(ctx, g_dg, g_s1, g_s2):
-        shape, dtype = ctx.meta
+        shape, dtype, want_dim2 = ctx.meta
         dev = ctx.mask.device
         cast = lambda t: None if t is None else t.to(dtype)
-        return masked_pair_combine(None, cast(g_s2), cast(g_s1), cast(g_dg), False, ctx.mask, shape, dtype, dev), None
+        if not want_dim2:
+            g_s2 = None
+        return masked_pair_combine(None, cast(g_s2), cast(g_s1), cast(g_dg), False, ctx.mask, shape, dtype, dev), None, None
 
 
-def pair_views(data: Tensor, mask: Tensor):
-    return _PairViews.apply(data, mask)
+def pair_views(data: Tensor, mask: Tensor, want_dim2: bool = True):
+    return _PairViews.apply(data, mask, want_dim2)
 
 
 def _dense_linear(flat: Tensor, w_in_out: Tensor, addend: Optional[Tensor] = None) -> Tensor:
@@ -1233,26 +1235,32 @@ class _SparsePairViews(torch.autograd.Function):
     sharing index 1); the three gradients return to the tuples in ONE gather pass."""
 
     @staticmethod
-    def forward(ctx, values: Tensor, ri: Tensor, ci: Tensor, diag_pos: Tensor, n: int):
+    def forward(ctx, values: Tensor, ri: Tensor, ci: Tensor, diag_pos: Tensor, n: int, want_rows: bool = True):
         require_device(values, ri, ci, diag_pos)
         values = values.contiguous()
         dg = _matched_rows(values, diag_pos)
-        s_r = _ScatterReduce.apply(values, cached_plan(ri, n, "scatter"), narrow_i32(ri), "sum")
+        # want_rows = False: the per-i sums are not needed by the caller (SUNConv takes only the diagonal and the per-j sums of
+        # the aggregated representation): one pooling pass less, and an empty placeholder in its place
+        s_r = (_ScatterReduce.apply(values, cached_plan(ri, n, "scatter"), narrow_i32(ri), "sum") if want_rows
+               else values.new_empty((0, values.shape[1])))
         s_c = _ScatterReduce.apply(values, cached_plan(ci, n, "scatter"), narrow_i32(ci), "sum")
         ctx.idx = (narrow_i32(ri), narrow_i32(ci))
-        ctx.meta = (values.shape[1], values.dtype)
+        ctx.meta = (values.shape[1], values.dtype, want_rows)
         return dg, s_r, s_c
 
     @staticmethod
     def backward(ctx, g_dg, g_r, g_c):
-        d, dtype = ctx.meta
+        d, dtype, want_rows = ctx.meta
         ri32, ci32 = ctx.idx
         cast = lambda t: None if t is None else t.to(dtype)
-        return pair_gather_combine(None, cast(g_r), cast(g_c), cast(g_dg), False, ri32, ci32, d, dtype, ri32.device), None, None, None, None
+        if not want_rows:
+            g_r = None
+        return (pair_gather_combine(None, cast(g_r), cast(g_c), cast(g_dg), False, ri32, ci32, d, dtype, ri32.device),
+                None, None, None, None, None)
 
 
-def sparse_pair_views(values: Tensor, ri: Tensor, ci: Tensor, diag_pos: Tensor, n: int):
-    return _SparsePairViews.apply(values, ri, ci, diag_pos, n)
+def sparse_pair_views(values: Tensor, ri: Tensor, ci: Tensor, diag_pos: Tensor, n: int, want_rows: bool = True):
+    return _SparsePairViews.apply(values, ri, ci, diag_pos, n, want_rows)
 
 
 class _SparsePairLinearMix(torch.autograd.Function):

@@ -326,15 +326,15 @@ class SUNConv(Module):
             xv, av = X.raw, agg.raw
             dt, d_ = xv.dtype, xv.shape[-1]
 
-            def views(vals, m):
-                dg, s1, s2 = _ops.pair_views(vals, m)               # rows (b,i,i); sum over dim 1 -> [b,j]; over dim 2 -> [b,i]
+            def views(vals, m, subg=True):
+                dg, s1, s2 = _ops.pair_views(vals, m, subg)         # rows (b,i,i); sum over dim 1 -> [b,j]; over dim 2 -> [b,i]
                 if self._pool == "mean":
                     s1 = s1 / m.sum(1).clamp_min(1).unsqueeze(-1).to(dt)
-                    s2 = s2 / m.sum(2).clamp_min(1).unsqueeze(-1).to(dt)
+                    s2 = s2 / m.sum(2).clamp_min(1).unsqueeze(-1).to(dt) if subg else None
                 return dg, s1, s2                                   # (centre, pool2node, pool2subg)
 
             centre, n5, n6 = views(xv, mask)
-            agg_dg, n7, _unused = views(av, amask)
+            agg_dg, n7, _unused = views(av, amask, subg=False)       # pool2subg(agg) is not one of the seven views
         else:
             xv, av = X.values, agg.values
             dt, d_ = xv.dtype, xv.shape[-1]
@@ -348,14 +348,14 @@ class SUNConv(Module):
                 cache["sun_views"] = (pos, cnt(ri), cnt(ci))
             pos, cnt_r, cnt_c = cache["sun_views"]
 
-            def views(vals):
-                dg, s_r, s_c = _ops.sparse_pair_views(vals, ri, ci, pos, n)  # rows (i,i); sum over j -> [i]; sum over i -> [j]
+            def views(vals, subg=True):
+                dg, s_r, s_c = _ops.sparse_pair_views(vals, ri, ci, pos, n, subg)  # rows (i,i); sum over j -> [i]; over i -> [j]
                 if self._pool == "mean":
-                    s_r, s_c = s_r / cnt_r.to(dt), s_c / cnt_c.to(dt)
+                    s_r, s_c = (s_r / cnt_r.to(dt) if subg else None), s_c / cnt_c.to(dt)
                 return dg, s_c, s_r                                 # (centre, pool2node, pool2subg)
 
             centre, n5, n6 = views(xv)
-            agg_dg, n7, _unused = views(av)
+            agg_dg, n7, _unused = views(av, subg=False)              # pool2subg(agg) is not one of the seven views
         w = lambda t, v: blk(t, v).to(dt)
 
         def node_lin(parts, blocks):
