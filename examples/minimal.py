@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""
+The flow of the reference's example/minimal.py (NGNN on ZINC, sparse backend) on this backend, with synthetic ZINC-shape graphs
+in place of the dataset (no network here): per-graph preprocessing -> a device-resident graph store -> mini-batches collated ON
+THE DEVICE -> 6-layer NGNN (bf16 activations, f32 master weights) -> L1 loss -> AdamW.
+
+    python examples/minimal.py [--graphs 4096] [--batch 512] [--epochs 3]
+
+Reference lines: dataset + Sppretransform (example/minimal.py:100-130) -> synth.make_graph (k-hop tuple sampler and the
+precomputed "X___X___1___A___0" message triples, as hodata/SpTupleSampler.py:91-126 + SpData.py:115-171 produce them);
+SpDataloader (:132-140) -> collate.DeviceGraphStore; model (:37-85) -> pygho_amd.ngnn.SpModel; train loop (:142-160) -> below.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pygho_amd import synth                                   # noqa: E402
+from pygho_amd.collate import DeviceGraphStore                 # noqa: E402
+from pygho_amd.honn.SpOperator import parse_precomputekey      # noqa: E402
+from pygho_amd.ngnn import SpModel                             # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--graphs", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--epochs", type=int, default=3)
+    ap.add_argument("--hidden", type=int, default=128)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = SpModel(1, 6, args.hidden, act_dtype=torch.bfloat16).to(dev)
+    keys = tuple(parse_precomputekey(model))                    # the message plans the layers will look up
+    rng = np.random.default_rng(0)
+    t0 = time.perf_counter()
+    records = [synth.make_graph(rng, "zinc", 3, keys) for _ in range(args.graphs)]
+    for r in records:                                           # a learnable synthetic target: mean atom type
+        r.y = float(r.x.mean()) / 10.0
+    store = DeviceGraphStore(records, dev)
+    print(f"{args.graphs} graphs preprocessed and stored on the device in {time.perf_counter() - t0:.1f} s; keys {keys}")
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    for epoch in range(args.epochs):
+        perm = torch.randperm(args.graphs, generator=torch.Generator().manual_seed(epoch))
+        tot, nb = 0.0, 0
+        t0 = time.perf_counter()
+        for i in range(0, args.graphs, args.batch):
+            dd = store.collate(perm[i:i + args.batch])          # block-diagonal batch built by device kernels
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                pred = model(dd)
+            loss = torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float())
+            loss.backward()
+            opt.step()
+            tot += float(loss.detach())
+            nb += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"epoch {epoch}: mean L1 {tot / nb:.4f}, {args.graphs / dt:,.0f} graphs/s")
+
+
+if __name__ == "__main__":
+    main()
