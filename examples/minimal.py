@@ -4,7 +4,7 @@ The flow of the reference's example/minimal.py (NGNN on ZINC, sparse backend) on
 in place of the dataset (no network here): per-graph preprocessing -> a device-resident graph store -> mini-batches collated ON
 THE DEVICE -> 6-layer NGNN (bf16 activations, f32 master weights) -> L1 loss -> AdamW.
 
-    python examples/minimal.py [--graphs 4096] [--batch 512] [--epochs 3]
+    python examples/minimal.py [--graphs 8192] [--batch 2048] [--epochs 3]
 
 Reference lines: dataset + Sppretransform (example/minimal.py:100-130) -> synth.make_graph (k-hop tuple sampler and the
 precomputed "X___X___1___A___0" message triples, as hodata/SpTupleSampler.py:91-126 + SpData.py:115-171 produce them);
@@ -20,15 +20,15 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygho_amd import synth                                   # noqa: E402
-from pygho_amd.collate import DeviceGraphStore                 # noqa: E402
+from pygho_amd.collate import BatchPrefetcher, DeviceGraphStore  # noqa: E402
 from pygho_amd.honn.SpOperator import parse_precomputekey      # noqa: E402
 from pygho_amd.ngnn import SpModel                             # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--graphs", type=int, default=4096)
-    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--graphs", type=int, default=8192)
+    ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--hidden", type=int, default=128)
     args = ap.parse_args()
@@ -48,8 +48,9 @@ def main():
         perm = torch.randperm(args.graphs, generator=torch.Generator().manual_seed(epoch))
         tot, nb = 0.0, 0
         t0 = time.perf_counter()
-        for i in range(0, args.graphs, args.batch):
-            dd = store.collate(perm[i:i + args.batch])          # block-diagonal batch built by device kernels
+        batches = [perm[i:i + args.batch] for i in range(0, args.graphs, args.batch)]
+        # block-diagonal batches built by device kernels, one batch ahead on a side stream, index plans included
+        for dd in BatchPrefetcher(store, batches, model.prepare):
             opt.zero_grad(set_to_none=True)
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 pred = model(dd)

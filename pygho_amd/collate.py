@@ -94,3 +94,56 @@ class DeviceGraphStore:
             inc = torch.stack([off["tup"] if roles[i][0] == "X" else off["edge"] for i in (0, 1, 3)])
             dd[k + KEYSEP + "acd"] = self._rows(self.acd[k], self.acd_ptr[k], ids, ptrs[("acd", k)], total[("acd", k)], inc)
         return dd
+
+
+class BatchPrefetcher:
+    """Iterate device-collated batches with their index plans ALREADY BUILT, one batch ahead of the consumer.
+
+    Every kernel of the backend works from int32 / CSR plans derived from a batch's index tensors (narrowed copies, transposed
+    groupings, long-segment hierarchies ...), built on first use and cached on those tensors.  First use costs ~40 host
+    synchronisations (sizes of sorted outputs, error flags); inside a training step they stall the launch queue: a step on a
+    fresh 8192-graph batch took 17.8 ms against 13.4 ms on a batch whose plans exist.  Here batch k + 1 is collated on a SIDE
+    stream while the consumer trains on batch k and its plans are built there, so the synchronisations wait for the side stream's
+    own few kernels instead of the training step's queue.
+
+    ``prepare(datadict)`` builds the plans (``SpModel.prepare``: the model's index-consuming operators run once on width-8 dummy
+    features; the plans depend on the index tensors only, so they land in the caches the real step will hit).  Batches are kept
+    alive until the consumer's stream has passed the point where the next batch was requested (their memory belongs to the side
+    stream's allocator pool).
+    """
+
+    def __init__(self, store: DeviceGraphStore, id_batches, prepare=None):
+        self.store, self.id_batches, self.prepare = store, id_batches, prepare
+        self.side = torch.cuda.Stream(device=store.device)
+        self._pending = []          # (datadict, event on the consumer stream after which it may be freed)
+
+    def _produce(self, ids):
+        # no dependency on the consumer's stream: the store's arrays are static and the ids come from the host, so the side
+        # stream's synchronisations wait for its own few kernels only (waiting for the consumer stream here would put every one
+        # of them behind the training step that is still executing)
+        with torch.cuda.stream(self.side):
+            dd = self.store.collate(ids)
+            if self.prepare is not None:
+                self.prepare(dd)
+            ev = self.side.record_event()
+        return dd, ev
+
+    def __iter__(self):
+        it = iter(self.id_batches)
+        try:
+            nxt = self._produce(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            dd, ev = nxt
+            main = torch.cuda.current_stream(self.store.device)
+            main.wait_event(ev)
+            try:
+                nxt = self._produce(next(it))           # overlaps with the consumer's work on `dd`
+            except StopIteration:
+                nxt = None
+            yield dd
+            self._pending.append((dd, main.record_event()))
+            self._pending = [(d, e) for d, e in self._pending if not e.query()]
+        torch.cuda.current_stream(self.store.device).synchronize()
+        self._pending.clear()

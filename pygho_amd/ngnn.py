@@ -18,6 +18,13 @@ from .honn.TensorOp import OpPoolingSubg2D
 from .honn.utils import MLP, Linear
 
 
+def _flat_index(idx: Tensor) -> Tensor:
+    """the 1-D contiguous form of an integer feature tensor as a PERSISTENT object (gather plans are cached on it)"""
+    if not hasattr(idx, "_pygho_flat") or idx._pygho_flat[0] != idx._version:
+        idx._pygho_flat = (idx._version, idx.reshape(-1).contiguous())
+    return idx._pygho_flat[1]
+
+
 class IndexEmbedding(nn.Embedding):
     """``nn.Embedding`` (same parameter / state_dict) whose lookup is the backend's row gather (K6) and whose
     backward is the hierarchical segment reduction instead of ATen's sort + index_put_(accumulate): with a
@@ -31,10 +38,7 @@ class IndexEmbedding(nn.Embedding):
         if not idx.is_cuda:
             return super().forward(idx)
         table = self.weight if self.out_dtype is None else self.weight.to(self.out_dtype)
-        flat = idx.reshape(-1)
-        if not hasattr(idx, "_pygho_flat") or idx._pygho_flat[0] != idx._version:
-            idx._pygho_flat = (idx._version, flat.contiguous())      # persistent object: the gather plan is cached on it
-        out = _ops.gather_rows(table, idx._pygho_flat[1])
+        out = _ops.gather_rows(table, _flat_index(idx))              # persistent index object: the gather plan is cached on it
         out = out.reshape(tuple(idx.shape) + (self.embedding_dim,))
         if idx.dim() == 1:
             # provenance for consumers that can index the (tiny, cache-resident) table themselves instead of streaming the
@@ -102,6 +106,47 @@ class SpModel(nn.Module):
         subgx0 = X.unpooling_fromdense1dim(0, left)
         subgx1 = X.unpooling_fromdense1dim(1, right)
         return X.tuplewiseapply(lambda v: subgx0.values * subgx1.values * v)
+
+    def prepare(self, datadict: dict) -> None:
+        """Build every index plan one training step on this batch will ask for (narrowed indices, transposed groupings,
+        long-segment hierarchies, lookups), by running the model's index-consuming operators once, forward and backward, on
+        width-8 dummy features: the plans depend on the index tensors only and are cached on them, so the real step finds
+        them.  Meant to run on a side stream one batch ahead (``collate.BatchPrefetcher``): plan construction needs ~40 host
+        synchronisations, which inside the step would each wait for the step's own launch queue."""
+        X, A = datadict["X"], datadict["A"]
+        dev = X.indices.device
+        n, w = int(datadict["num_nodes"]), 8
+        enc = self.data_encoder
+        dt = enc.act_dtype or torch.float32
+        z = lambda rows: torch.zeros((rows, w), dtype=dt, device=dev, requires_grad=True)
+        outs = []
+        flats = {}
+        for name, idx, rows in (("x", datadict["x"].flatten(), enc.x_encoder.num_embeddings),
+                                ("ea", A.values, enc.ea_encoder.num_embeddings),
+                                ("tf", X.values, enc.tuplefeat_encoder.num_embeddings)):
+            if idx is None or idx.dtype != torch.int64:
+                continue
+            flats[name] = _flat_index(idx)
+            if name != "tf" or idx.numel() != X.nnz:
+                outs.append(_ops.gather_rows(z(rows), flats[name]))
+        if "tf" in flats and X.values.numel() == X.nnz:
+            if not hasattr(X.values, "_pygho_flat") or X.values._pygho_flat[0] != X.values._version:
+                X.values._pygho_flat = (X.values._version, X.values.reshape(-1).contiguous())
+            feat = X.values._pygho_flat[1]
+            outs.append(_ops.pair_product(z(n), z(n), z(enc.tuplefeat_encoder.num_embeddings), X._row(0), X._row(1), feat))
+        else:
+            outs.append(_ops.pair_product(z(n), z(n), z(X.nnz), X._row(0), X._row(1)))
+        outs.append(_ops.scatter_reduce(z(X.nnz), X._row(0), n, "mean"))                      # lpool
+        outs.append(_ops.scatter_reduce(z(n), datadict["batch"], int(datadict["num_graphs"]), self.npool))
+        torch.autograd.backward([o.sum() for o in outs])
+        for conv in self.subggnns:
+            acd = datadict.get(conv.aggr.mod.precomputekey + "___acd")
+            if acd is not None:
+                plan = _ops.message_plan(acd, X.nnz, X.nnz, A.nnz)
+                plan.by_c()
+                plan.by_d()
+                if "ea" in flats:
+                    plan.lookup(flats["ea"])
 
     def forward(self, datadict: dict) -> Tensor:
         raw = datadict["X"]

@@ -703,3 +703,53 @@ def test_sd_mode_equals_dd_mode(dev, layer_name):
         res.append((o.detach(), x.grad * xm[..., None]))
     torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-5)
+
+
+def test_batch_prefetcher_with_plan_preparation(dev):
+    """collate.BatchPrefetcher (batch k + 1 collated and its index plans built on a side stream by SpModel.prepare while batch k
+    trains): the batches are the ones plain collation gives, the prepared step performs no host synchronisation at all, and
+    training through the prefetcher leaves the parameters exactly where plain collation leaves them."""
+    import copy
+    from pygho_amd import synth
+    from pygho_amd.collate import BatchPrefetcher, DeviceGraphStore
+    from pygho_amd.ngnn import SpModel
+    rng = np.random.default_rng(3)
+    recs = [synth.make_graph(rng, "zinc", 3, ("X___X___1___A___0",)) for _ in range(96)]
+    store = DeviceGraphStore(recs, dev)
+    gen = torch.Generator().manual_seed(1)
+    ids = [torch.randperm(96, generator=gen)[:48] for _ in range(4)]
+    torch.manual_seed(0)
+    base = SpModel(1, 2, 64, act_dtype=torch.bfloat16).to(dev)
+
+    def train(batches, model):
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        for dd in batches:
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                pred = model(dd)
+            torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float()).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    m1, m2 = copy.deepcopy(base), copy.deepcopy(base)
+    plain = train((store.collate(i) for i in ids), m1)
+    pre = train(BatchPrefetcher(store, ids, m2.prepare), m2)
+    for k in plain:
+        assert torch.equal(plain[k], pre[k]), k
+    # same batches, and no synchronisation left inside a prepared step
+    for a, b in zip((store.collate(i) for i in ids), BatchPrefetcher(store, ids)):
+        assert torch.equal(a["X"].indices, b["X"].indices) and torch.equal(a["A"].values, b["A"].values)
+        assert torch.equal(a["X___X___1___A___0___acd"], b["X___X___1___A___0___acd"]) and torch.equal(a["y"], b["y"])
+    dd = store.collate(ids[0])
+    m2.prepare(dd)
+    calls = []
+    orig = torch.Tensor.item
+    torch.Tensor.item = lambda self: (calls.append(1) if self.is_cuda else None, orig(self))[1]
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = m2(dd)
+        torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float()).backward()
+    finally:
+        torch.Tensor.item = orig
+    assert not calls, f"{len(calls)} host synchronisations inside a prepared step"
