@@ -229,6 +229,45 @@ def dense_collate_case(b, n, d, dev):
             "tuples": int(tptr[-1]), "edges": int(eb.shape[0]), "written_MB": out_bytes / 1e6, "GBps_written": out_bytes / ms / 1e6}
 
 
+def fresh_batch_case(graphs, dev):
+    """training with a NEW batch every step (the bench step re-uses one resident batch): plain device collation + first-use plan
+    construction inside the step, against collate.BatchPrefetcher (collation and SpModel.prepare one batch ahead on a side stream)."""
+    import time
+    from pygho_amd.collate import BatchPrefetcher, DeviceGraphStore
+    from pygho_amd.ngnn import SpModel
+    rng = np.random.default_rng(0)
+    recs = [synth.make_graph(rng, "zinc", 3, ("X___X___1___A___0",)) for _ in range(min(2048, graphs))]
+    store = DeviceGraphStore(recs * max(2, 2 * graphs // len(recs)), dev)
+    torch.manual_seed(0)
+    model = SpModel(1, 6, 128, act_dtype=torch.bfloat16).to(dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+
+    def step(dd):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = model(dd)
+        torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float()).backward()
+        opt.step()
+    gen = torch.Generator().manual_seed(0)
+    ids = [torch.randperm(store.num_graphs, generator=gen)[:graphs] for _ in range(14)]
+    res = {}
+    resident = store.collate(ids[0])
+    for name, src in (("resident", lambda: (resident for _ in ids)), ("plain", lambda: (store.collate(i) for i in ids)),
+                      ("prefetch", lambda: BatchPrefetcher(store, ids, model.prepare))):
+        n = 0
+        for k, dd in enumerate(src()):
+            if k == 4:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            step(dd)
+            n += 1
+        torch.cuda.synchronize()
+        res[name] = (time.perf_counter() - t0) / (n - 4) * 1e3
+    return {"op": "NGNN train step, new batch every step", "graphs": graphs, "resident_batch_ms": res["resident"],
+            "plain_collate_ms": res["plain"], "prefetch_prepare_ms": res["prefetch"],
+            "graphs_per_s_prefetch": graphs / res["prefetch"] * 1e3}
+
+
 def mamamm_case(b, n, d, dtype, dev):
     from pygho_amd import MaskedTensor
     from pygho_amd.backend.Mamamm import mamamm
@@ -269,6 +308,7 @@ def main():
     out.append(sunconv_case(128, 37, 128, torch.bfloat16, dev))
     out.append(sunconv_case(128 if args.quick else 1024, 37, 128, torch.bfloat16, dev))
     out.append(graph_step_case(1024, dev))
+    out.append(fresh_batch_case(1024 if args.quick else 8192, dev))
     out.append(planner_case("zinc", 1024 if args.quick else 8192, dev))
     out.append(collate_case(1024 if args.quick else 8192, dev))
     out.append(dense_collate_case(128 if args.quick else 1024, 37, 128, dev))
