@@ -10,7 +10,10 @@ roofline" on config[1] "NGNNConv 2-tuple sparse spspmm on ZINC, hidden=128 bf16,
 A step = one full training step (forward, backward, gradient all-reduce when N > 1, AdamW) of the 6-layer NGNN
 of example/minimal.py (hidden 128, bf16 activations / f32 master weights) over one synthetic ZINC-shape batch
 that is already resident in HBM.  Every rank owns its own batch of --graphs graphs (weak scaling, graphs shard
-with no data-path collective); value = graphs of all ranks / max-over-ranks time.
+with no data-path collective); value = graphs of all ranks / max-over-ranks time.  The batch's index plans (int32 / CSR
+views and transposed groupings of its index tensors, cached on them) are part of the resident input, like the reference's
+precomputed ___acd triples; training with a NEW batch every step, plans built one batch ahead on a side stream, is measured by
+tools/bench_ops.py (fresh_batch_case: 14.3-14.8 ms per step against 13.1-13.4 ms here).
 
 Alongside: msg-edges/s and the HBM roofline fraction of the dominant kernel (the fused gather*gather->segment
 reduce of spspmm, forward and both backward plans), measured live with HIP events around every launch in the
