@@ -101,13 +101,14 @@ class SegPlan:
             dev = cur.device
             while True:
                 lens = cur[1:] - cur[:-1]
-                if n_seg == 0 or int(lens.max().item()) <= limit:
-                    out.append(cur.to(_I32))
-                    break
                 nch = (lens + (limit - 1)) // limit
                 ends = torch.cumsum(nch, 0)
+                # ONE host sync per level: longest segment and number of chunks together
+                longest, n_sub = (0, 0) if n_seg == 0 else (int(v) for v in torch.stack((lens.max(), ends[-1])).tolist())
+                if n_seg == 0 or longest <= limit:
+                    out.append(cur.to(_I32))
+                    break
                 first = ends - nch
-                n_sub = int(ends[-1].item())
                 seg_of_sub = torch.repeat_interleave(torch.arange(n_seg, device=dev), nch, output_size=n_sub)
                 q = torch.arange(n_sub, device=dev) - first[seg_of_sub]
                 start = cur[seg_of_sub] + q * limit
@@ -148,9 +149,10 @@ def plan_from_keys(keys: Tensor, n_seg: int, assume_sorted: Optional[bool] = Non
     return SegPlan(seg_ptr, perm, n_seg, m)
 
 
-def cached_plan(keys: Tensor, n_seg: int, tag: str = "") -> SegPlan:
+def cached_plan(keys: Tensor, n_seg: int, tag: str = "", assume_sorted: Optional[bool] = None) -> SegPlan:
     """plan cache keyed on the index tensor OBJECT (index tensors are shared by reference between
-    results, SpTensor.py:493) and its in-place version counter."""
+    results, SpTensor.py:493) and its in-place version counter.  `assume_sorted=False`: the caller knows the keys are not
+    sorted (second coordinates of a pattern, feature ids): skips the sortedness probe and its host sync."""
     cache = getattr(keys, "_pygho_plans", None)
     if cache is None:
         cache = {}
@@ -161,7 +163,7 @@ def cached_plan(keys: Tensor, n_seg: int, tag: str = "") -> SegPlan:
     k = (tag, n_seg, keys._version)
     plan = cache.get(k)
     if plan is None:
-        plan = plan_from_keys(keys, n_seg)
+        plan = plan_from_keys(keys, n_seg, assume_sorted)
         cache[k] = plan
     return plan
 
@@ -372,13 +374,13 @@ class MessagePlan:
     def by_c(self):
         """(plan, a-in-grouped-order, d-in-grouped-order) for the gradient wrt the first operand."""
         if self._by_c is None:
-            p = plan_from_keys(self._c64, self.n_lhs)
+            p = plan_from_keys(self._c64, self.n_lhs, False)         # the acd triples are sorted by a, not by c / d
             self._by_c = (p, p.take(self.a32), p.take(self.d32))
         return self._by_c
 
     def by_d(self):
         if self._by_d is None:
-            p = plan_from_keys(self._d64, self.n_rhs)
+            p = plan_from_keys(self._d64, self.n_rhs, False)
             self._by_d = (p, p.take(self.a32), p.take(self.c32))
         return self._by_d
 
@@ -701,12 +703,12 @@ def pair_product(left: Tensor, right: Tensor, val: Tensor, row: Tensor, col: Ten
     vidx32 = None if val_index is None else narrow_i32(val_index)
     key = (id(row32), id(col32), id(vidx32))
     p_row = cached_plan(row, left.shape[0], "pair-row")
-    p_col = cached_plan(col, right.shape[0], "pair-col")
+    p_col = cached_plan(col, right.shape[0], "pair-col", assume_sorted=False)
     by_row = (p_row,) + _grouped(p_row, key, col32, vidx32)
     by_col = (p_col,) + _grouped(p_col, key, row32, vidx32)
     by_val = None
     if val_index is not None:
-        p_val = cached_plan(val_index, val.shape[0], "pair-val")
+        p_val = cached_plan(val_index, val.shape[0], "pair-val", assume_sorted=False)
         by_val = (p_val,) + _grouped(p_val, key, row32, col32)
     return _PairProduct.apply(left, right, val, row32, col32, vidx32, by_row, by_col, by_val)
 
