@@ -77,13 +77,30 @@ class SegPlan:
         """idx32 re-ordered into grouped order."""
         return idx32 if self.perm is None else gather_i32(idx32, self.perm)
 
+    _HOST_LENS_LIMIT = 8192      # plans with at most this many segments fetch their lengths once and plan hierarchies on the host
+
+    def _host_lens(self):
+        """segment lengths on the host for small plans (embedding tables, feature types: a handful of segments, possibly very
+        long): ONE synchronisation serves `max_len` and every level of `levels`."""
+        if self._memo is None:
+            self._memo = {}
+        if "host_lens" not in self._memo:
+            import numpy as _np
+            self._memo["host_lens"] = _np.diff(_np.asarray(_fetch(self.seg_ptr), dtype=_np.int64))
+        return self._memo["host_lens"]
+
     @property
     def max_len(self) -> int:
         """longest segment (one host sync, cached)."""
         if self._memo is None:
             self._memo = {}
         if "max_len" not in self._memo:
-            self._memo["max_len"] = int((self.seg_ptr[1:] - self.seg_ptr[:-1]).max().item()) if self.n_seg > 0 else 0
+            if self.n_seg == 0:
+                self._memo["max_len"] = 0
+            elif self.n_seg <= self._HOST_LENS_LIMIT:
+                self._memo["max_len"] = int(self._host_lens().max())
+            else:
+                self._memo["max_len"] = int(_fetch((self.seg_ptr[1:] - self.seg_ptr[:-1]).max().reshape(1))[0])
         return self._memo["max_len"]
 
     def levels(self, limit: int):
@@ -94,6 +111,26 @@ class SegPlan:
         if self._memo is None:
             self._memo = {}
         key = ("levels", limit)
+        if key not in self._memo and 0 < self.n_seg <= self._HOST_LENS_LIMIT:
+            # small plan: the whole hierarchy is computed on the host from the fetched lengths and uploaded (no further sync)
+            import numpy as _np
+            lens = self._host_lens()
+            cur = _np.concatenate(([0], _np.cumsum(lens)))
+            out = []
+            while True:
+                if lens.max() <= limit:
+                    out.append(cur)
+                    break
+                nch = (lens + (limit - 1)) // limit
+                ends = _np.cumsum(nch)
+                first = ends - nch
+                seg_of_sub = _np.repeat(_np.arange(lens.shape[0]), nch)
+                q = _np.arange(int(ends[-1])) - first[seg_of_sub]
+                out.append(_np.concatenate((cur[seg_of_sub] + q * limit, cur[-1:])))
+                lens = nch
+                cur = _np.concatenate(([0], ends))
+            dev = self.seg_ptr.device
+            self._memo[key] = [torch.from_numpy(a.astype(_np.int32)).to(dev, non_blocking=True) for a in out]
         if key not in self._memo:
             out = []
             cur = self.seg_ptr.to(torch.int64)
@@ -104,7 +141,7 @@ class SegPlan:
                 nch = (lens + (limit - 1)) // limit
                 ends = torch.cumsum(nch, 0)
                 # ONE host sync per level: longest segment and number of chunks together
-                longest, n_sub = (0, 0) if n_seg == 0 else (int(v) for v in torch.stack((lens.max(), ends[-1])).tolist())
+                longest, n_sub = (0, 0) if n_seg == 0 else (int(v) for v in _fetch(torch.stack((lens.max(), ends[-1]))))
                 if n_seg == 0 or longest <= limit:
                     out.append(cur.to(_I32))
                     break
@@ -121,6 +158,51 @@ class SegPlan:
 def unit_ptr(m: int, dev) -> Tensor:
     """seg_ptr of the trivial plan (one message per segment)."""
     return torch.arange(m + 1, dtype=_I32, device=dev)
+
+
+_PENDING_ERRORS = []     # (flag tensor, message): checks that ride on the next host fetch instead of costing their own sync
+
+
+def _fetch(t: Tensor):
+    """host copy of a small device tensor (ONE synchronisation) that also carries every deferred error flag of that device"""
+    mine = [(f, m) for f, m in _PENDING_ERRORS if f.device == t.device]
+    if not mine:
+        return t.tolist()
+    for e in mine:
+        _PENDING_ERRORS.remove(e)
+    vals = torch.cat([t.reshape(-1).to(torch.int64)] + [f.reshape(-1).to(torch.int64) for f, _ in mine]).tolist()
+    n = t.numel()
+    for (f, msg), v in zip(mine, vals[n:]):
+        if v != 0:
+            raise ValueError(msg)
+    out = vals[:n]
+    return out if t.dim() > 0 else out[0]
+
+
+_DEFER_CHECKS = [False]
+
+
+class deferred_index_checks:
+    """``with deferred_index_checks(): ...``: index-range checks of the plans built inside do not synchronise on their own; they
+    are verified by the next host fetch or, at the latest, when the block ends (`collate.BatchPrefetcher` builds a batch's plans
+    this way).  Outside such a block a bad index raises at the call, as the reference's asserts do."""
+
+    def __enter__(self):
+        self.prev = _DEFER_CHECKS[0]
+        _DEFER_CHECKS[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _DEFER_CHECKS[0] = self.prev
+        if exc[0] is None:
+            check_deferred_errors()
+        return False
+
+
+def check_deferred_errors() -> None:
+    """verify the index-range checks that were deferred (one synchronisation per device with pending flags)"""
+    for dev in {f.device for f, _ in _PENDING_ERRORS}:
+        _fetch(torch.zeros(1, dtype=torch.int64, device=dev))
 
 
 def plan_from_keys(keys: Tensor, n_seg: int, assume_sorted: Optional[bool] = None) -> SegPlan:
@@ -140,12 +222,21 @@ def plan_from_keys(keys: Tensor, n_seg: int, assume_sorted: Optional[bool] = Non
             raise ValueError("pygho_amd: keys are not sorted / out of range")
     err = _flag(dev)
     perm = torch.empty(m, dtype=_I32, device=dev)
+    seg_ptr.zero_()              # entries the CSR kernel skips for out-of-range keys must not be garbage (see below)
     nbytes = int(lib().pygho_group_by_key_workspace(m, n_seg))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     check(lib().pygho_group_by_key(ptr(seg_ptr), ptr(perm), ptr(keys), m, n_seg, ptr(ws), nbytes, ptr(err), st),
           "group_by_key")
-    if int(err.item()) != 0:
-        raise ValueError("pygho_amd: scatter index out of range [0, dim_size)")
+    # the range check rides on the next host fetch (`_fetch`) or on `check_deferred_errors()`.  Until then a plan built from bad
+    # keys is wrong but harmless: `perm` is a permutation of [0, m) whatever the keys were, and the pointers the CSR kernel
+    # skips stay 0, so every consumer still reads messages inside [0, m)
+    if not _DEFER_CHECKS[0]:
+        if int(_fetch(err)[0]) != 0:
+            raise ValueError("pygho_amd: scatter index out of range [0, dim_size)")
+        return SegPlan(seg_ptr, perm, n_seg, m)
+    _PENDING_ERRORS.append((err, "pygho_amd: scatter index out of range [0, dim_size)"))
+    if len(_PENDING_ERRORS) > 64:
+        check_deferred_errors()
     return SegPlan(seg_ptr, perm, n_seg, m)
 
 
@@ -371,6 +462,26 @@ class MessagePlan:
         self._by_d = None
         self._lookup = None
 
+    @classmethod
+    def from_parts(cls, acd: Tensor, n_out: int, n_lhs: int, n_rhs: int, fwd_ptr: Tensor, ptr_c: Tensor, perm_c: Tensor,
+                   ptr_d: Tensor, perm_d: Tensor) -> "MessagePlan":
+        """the same plan from groupings that already exist (int32 CSR pointers and permutations): a block-diagonal batch's
+        groupings are the concatenation of its graphs' precomputed ones (`collate.DeviceGraphStore`), so no sort and no host
+        synchronisation is needed per batch."""
+        require_device(acd, fwd_ptr, ptr_c, perm_c, ptr_d, perm_d)
+        self = cls.__new__(cls)
+        self.m = acd.shape[1]
+        self.n_out, self.n_lhs, self.n_rhs = n_out, n_lhs, n_rhs
+        self._a64, self._c64, self._d64 = acd[0], acd[1], acd[2]
+        self.fwd = SegPlan(fwd_ptr, None, n_out, self.m)
+        self.a32, self.c32, self.d32 = narrow_i32(acd[0]), narrow_i32(acd[1]), narrow_i32(acd[2])
+        self.c_fwd, self.d_fwd = self.c32, self.d32
+        pc, pd = SegPlan(ptr_c, perm_c, n_lhs, self.m), SegPlan(ptr_d, perm_d, n_rhs, self.m)
+        self._by_c = (pc, pc.take(self.a32), pc.take(self.d32))
+        self._by_d = (pd, pd.take(self.a32), pd.take(self.c32))
+        self._lookup = None
+        return self
+
     def by_c(self):
         """(plan, a-in-grouped-order, d-in-grouped-order) for the gradient wrt the first operand."""
         if self._by_c is None:
@@ -393,6 +504,15 @@ class MessagePlan:
             memo = (row_of, (gather_i32(r32, self.d_fwd), gather_i32(r32, self.by_c()[2])))
             self._lookup = memo
         return memo[1]
+
+
+def install_message_plan(acd: Tensor, plan: MessagePlan) -> None:
+    """put a ready plan where `message_plan` will look for it"""
+    cache = getattr(acd, "_pygho_plans", None)
+    if cache is None:
+        cache = {}
+        acd._pygho_plans = cache
+    cache[("msg", plan.n_out, plan.n_lhs, plan.n_rhs, acd._version)] = plan
 
 
 def message_plan(acd: Tensor, n_out: int, n_lhs: int, n_rhs: int) -> MessagePlan:

@@ -50,6 +50,23 @@ class DeviceGraphStore:
         self.feat_shape = tuple(records[0].tuplefeat.shape[1:])
         self.acd = {k: _cat32([r.acd[k] for r in records], 1, d) for k in self.keys}
         self.acd_ptr = {k: _ptr64([r.acd[k].shape[1] for r in records], d) for k in self.keys}
+        # the transposed groupings of every graph's message triples, computed ONCE here: a block-diagonal batch's grouping by c
+        # (or d) is the concatenation of its graphs' groupings with the message / row offsets added, so a batch's message plan
+        # is collated like everything else instead of being re-sorted (two 3.5 M-key radix sorts per 8192-graph batch)
+        self.plan_parts = {}
+        for k in self.keys:
+            roles = parse_key(k)
+            rows_of = lambda r, role: r.tupleid.shape[1] if role[0] == "X" else r.edge_index.shape[1]
+            perm_c, perm_d, cnt_a, cnt_c, cnt_d = [], [], [], [], []
+            for r in records:
+                a, c, dd_ = r.acd[k]
+                perm_c.append(np.argsort(c, kind="stable").reshape(1, -1))
+                perm_d.append(np.argsort(dd_, kind="stable").reshape(1, -1))
+                cnt_a.append(np.bincount(a, minlength=rows_of(r, roles[0])).reshape(1, -1))
+                cnt_c.append(np.bincount(c, minlength=rows_of(r, roles[1])).reshape(1, -1))
+                cnt_d.append(np.bincount(dd_, minlength=rows_of(r, roles[3])).reshape(1, -1))
+            self.plan_parts[k] = {"perm_c": _cat32(perm_c, 1, d), "perm_d": _cat32(perm_d, 1, d), "cnt_a": _cat32(cnt_a, 1, d),
+                                  "cnt_c": _cat32(cnt_c, 1, d), "cnt_d": _cat32(cnt_d, 1, d)}
         self.y = torch.tensor([r.y for r in records], dtype=torch.float32, device=d)
 
     # ------------------------------------------------------------------
@@ -92,7 +109,22 @@ class DeviceGraphStore:
         for k in self.keys:
             roles = parse_key(k)
             inc = torch.stack([off["tup"] if roles[i][0] == "X" else off["edge"] for i in (0, 1, 3)])
-            dd[k + KEYSEP + "acd"] = self._rows(self.acd[k], self.acd_ptr[k], ids, ptrs[("acd", k)], total[("acd", k)], inc)
+            acd = self._rows(self.acd[k], self.acd_ptr[k], ids, ptrs[("acd", k)], total[("acd", k)], inc)
+            dd[k + KEYSEP + "acd"] = acd
+            # message plan from the stored per-graph groupings (no sort, no host sync): permutations get the message offset of
+            # their graph, the per-row message counts are collated by the operand's rows and scanned into CSR pointers
+            parts, m_off = self.plan_parts[k], ptrs[("acd", k)][:-1].reshape(1, -1)
+            name = lambda role: "tup" if role[0] == "X" else "edge"
+            sp = {"tup": self.tup_ptr, "edge": self.edge_ptr}
+
+            def csr(cnt, role):
+                c = self._rows(cnt, sp[name(role)], ids, ptrs[name(role)], total[name(role)], None).reshape(-1)
+                return _ops.exclusive_scan(c).to(torch.int32)
+            perm = lambda which: self._rows(parts[which], self.acd_ptr[k], ids, ptrs[("acd", k)], total[("acd", k)], m_off).reshape(-1).to(torch.int32)
+            plan = _ops.MessagePlan.from_parts(acd, total[name(roles[0])], total[name(roles[1])], total[name(roles[3])],
+                                               csr(parts["cnt_a"], roles[0]), csr(parts["cnt_c"], roles[1]), perm("perm_c"),
+                                               csr(parts["cnt_d"], roles[3]), perm("perm_d"))
+            _ops.install_message_plan(acd, plan)
         return dd
 
 
@@ -114,17 +146,20 @@ class BatchPrefetcher:
 
     def __init__(self, store: DeviceGraphStore, id_batches, prepare=None):
         self.store, self.id_batches, self.prepare = store, id_batches, prepare
-        self.side = torch.cuda.Stream(device=store.device)
+        # high priority: the side stream issues a few dozen tiny kernels with host synchronisations in between; behind the training
+        # stream's saturating kernels each of them would wait for a scheduling slot (measured: 11.5 ms per batch against 4.8 ms idle)
+        self.side = torch.cuda.Stream(device=store.device, priority=-1)
         self._pending = []          # (datadict, event on the consumer stream after which it may be freed)
 
     def _produce(self, ids):
         # no dependency on the consumer's stream: the store's arrays are static and the ids come from the host, so the side
         # stream's synchronisations wait for its own few kernels only (waiting for the consumer stream here would put every one
         # of them behind the training step that is still executing)
-        with torch.cuda.stream(self.side):
+        with torch.cuda.stream(self.side), _ops.deferred_index_checks():
             dd = self.store.collate(ids)
             if self.prepare is not None:
                 self.prepare(dd)
+        with torch.cuda.stream(self.side):
             ev = self.side.record_event()
         return dd, ev
 

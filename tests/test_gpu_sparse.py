@@ -590,3 +590,49 @@ def test_sparse_pair_views_gradient_one_pass(dev):
     for got, ref in ((dg, rdg), (s_r, r_r), (s_c, r_c)):
         np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_collated_message_plans_equal_sorted_ones(dev):
+    """DeviceGraphStore.collate installs the batch's message plan assembled from per-graph groupings (permutations + message
+    offsets, per-row counts scanned into CSR pointers): every array equals the plan built from the collated triples by
+    sorting, for a key whose operands are (tuples, tuples, edges) and one with (tuples, edges, tuples), repeated / shuffled ids."""
+    from pygho_amd import _ops, synth
+    from pygho_amd.collate import DeviceGraphStore
+    keys = ("X___X___1___A___0", "X___A___1___X___0")
+    rng = np.random.default_rng(8)
+    recs = [synth.make_graph(rng, "zinc", 3, keys) for _ in range(40)]
+    store = DeviceGraphStore(recs, dev)
+    ids = torch.tensor([5, 3, 3, 39, 0, 17, 21, 8, 8, 8, 30])
+    dd = store.collate(ids)
+    for key in keys:
+        acd = dd[key + "___acd"]
+        roles = synth.parse_key(key)
+        n = {"X": dd["X"].nnz, "A": dd["A"].nnz}
+        n_out, n_lhs, n_rhs = n[roles[0][0]], n[roles[1][0]], n[roles[3][0]]
+        got = _ops.message_plan(acd, n_out, n_lhs, n_rhs)                      # the installed one
+        assert got is acd._pygho_plans[("msg", n_out, n_lhs, n_rhs, acd._version)]
+        ref = _ops.MessagePlan(acd, n_out, n_lhs, n_rhs)                       # built by sorting
+        assert torch.equal(got.fwd.seg_ptr, ref.fwd.seg_ptr) and got.fwd.perm is None and ref.fwd.perm is None
+        assert torch.equal(got.c_fwd, ref.c_fwd) and torch.equal(got.d_fwd, ref.d_fwd)
+        for a, b in ((got.by_c(), ref.by_c()), (got.by_d(), ref.by_d())):
+            assert torch.equal(a[0].seg_ptr, b[0].seg_ptr) and torch.equal(a[0].perm, b[0].perm)
+            assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+def test_deferred_index_range_check(dev):
+    """inside `deferred_index_checks()` the range check of an unsorted grouping does not synchronise on its own: a bad index is
+    still reported -- by the next host fetch or when the block ends -- and the plan built meanwhile stays in bounds; outside such a
+    block the error is raised at the call."""
+    from pygho_amd import _ops
+    good = torch.tensor([3, 1, 2, 1, 0], device=dev)
+    bad = torch.tensor([3, 9, 2, 1, 0], device=dev)
+    with _ops.deferred_index_checks():
+        p = _ops.plan_from_keys(good, 4, assume_sorted=False)
+    assert p.seg_ptr.tolist() == [0, 1, 3, 4, 5] and p.perm.tolist() == [4, 1, 3, 2, 0]
+    with pytest.raises(ValueError, match="out of range"):
+        with _ops.deferred_index_checks():
+            p = _ops.plan_from_keys(bad, 4, assume_sorted=False)                # no error yet ...
+            assert sorted(p.perm.tolist()) == [0, 1, 2, 3, 4] and max(p.seg_ptr.tolist()) <= 5
+    _ops.check_deferred_errors()                                   # ... reported once, when the block ended
+    with pytest.raises(ValueError, match="out of range"):
+        _ops.plan_from_keys(bad, 4, assume_sorted=False)           # outside a block: at the call
