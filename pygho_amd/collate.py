@@ -57,6 +57,8 @@ class DeviceGraphStore:
         for k in self.keys:
             roles = parse_key(k)
             rows_of = lambda r, role: r.tupleid.shape[1] if role[0] == "X" else r.edge_index.shape[1]
+            if not all(r.acd[k].shape[1] == 0 or np.all(np.diff(r.acd[k][0]) >= 0) for r in records):
+                continue                                         # triples not sorted by target (not from filterind): plan by sorting
             perm_c, perm_d, cnt_a, cnt_c, cnt_d = [], [], [], [], []
             for r in records:
                 a, c, dd_ = r.acd[k]
@@ -113,6 +115,8 @@ class DeviceGraphStore:
             dd[k + KEYSEP + "acd"] = acd
             # message plan from the stored per-graph groupings (no sort, no host sync): permutations get the message offset of
             # their graph, the per-row message counts are collated by the operand's rows and scanned into CSR pointers
+            if k not in self.plan_parts:
+                continue
             parts, m_off = self.plan_parts[k], ptrs[("acd", k)][:-1].reshape(1, -1)
             name = lambda role: "tup" if role[0] == "X" else "edge"
             sp = {"tup": self.tup_ptr, "edge": self.edge_ptr}
