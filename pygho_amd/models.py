@@ -1,0 +1,165 @@
+"""
+The graph-level models of the reference's example/zinc.py (SpModel :222-297, MaModel :155-219, the input encoders :58-101 and
+the layer tables :109-152) over this backend's layers, for every shipped layer family:
+
+    sparse:  SSWL, DSSGNN, GNNAK, SUN, NGNN, PPGN, I2GNN (3-tuples)        dense (padded):  SSWL, DSSGNN, GNNAK, SUN, NGNN, PPGN
+
+Same module / parameter names as the reference, so its state_dicts load.  NGNN / I2GNN layers use the fused residual block
+(``forward_residual``) when the residual connection is on; `pygho_amd.ngnn.SpModel` remains the NGNN-only model the headline
+benchmark runs (it adds the table-indexed tuple initialisation).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Union
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _ops
+from .backend.MaTensor import MaskedTensor
+from .backend.SpTensor import SparseTensor
+from .backend.utils import torch_scatter_reduce
+from .honn.Conv import DSSGNNConv, GNNAKConv, I2Conv, NGNNConv, PPGNConv, SSWLConv, SUNConv
+from .honn.MaOperator import OpPooling
+from .honn.TensorOp import OpPoolingSubg2D, OpPoolingSubg3D
+from .honn.utils import MLP
+from .ngnn import IndexEmbedding
+
+
+def conv_table(mode: str, aggr: str = "sum", cpool: str = "mean") -> Dict[str, Callable]:
+    """layer name -> factory(hidden, mlp dict), as example/zinc.py:109-152 (mode "SS" sparse, "DD" dense)"""
+    one = lambda mlp: dict(mlp, numlayer=1, tailact=True)
+    return {
+        "SSWL": lambda d, mlp: SSWLConv(d, d, aggr, mode, one(mlp)),
+        "DSSGNN": lambda d, mlp: DSSGNNConv(d, d, aggr, aggr, cpool, mode, one(mlp)),
+        "GNNAK": lambda d, mlp: GNNAKConv(d, d, aggr, cpool, mode, one(mlp), one(mlp)),
+        "SUN": lambda d, mlp: SUNConv(d, d, aggr, cpool, mode, one(mlp), one(mlp)),
+        "NGNN": lambda d, mlp: NGNNConv(d, d, aggr, mode, one(mlp)),
+        "PPGN": lambda d, mlp: PPGNConv(d, d, aggr, mode, one(mlp)),
+        "I2GNN": lambda d, mlp: I2Conv(d, d, aggr, mode, one(mlp)),
+    }
+
+
+class InputEncoderSp(nn.Module):
+    """integer node / edge / tuple features -> hidden vectors (example/zinc.py:74-86; I2GNN: two tuple features, :89-101)"""
+
+    def __init__(self, hiddim: int, two_tuple_feats: bool = False, act_dtype: Optional[torch.dtype] = None) -> None:
+        super().__init__()
+        self.x_encoder = IndexEmbedding(32, hiddim, act_dtype)
+        self.ea_encoder = IndexEmbedding(16, hiddim, act_dtype)
+        if two_tuple_feats:
+            self.tuplefeat_encoder1 = IndexEmbedding(16, hiddim, act_dtype)
+            self.tuplefeat_encoder2 = IndexEmbedding(16, hiddim, act_dtype)
+        else:
+            self.tuplefeat_encoder = IndexEmbedding(16, hiddim, act_dtype)
+        self.two = two_tuple_feats
+
+    def forward(self, datadict: dict) -> dict:
+        out = dict(datadict)
+        out["x"] = self.x_encoder(datadict["x"].flatten())
+        out["A"] = datadict["A"].tuplewiseapply(self.ea_encoder)
+        if self.two:
+            out["X"] = datadict["X"].tuplewiseapply(lambda v: self.tuplefeat_encoder1(v[:, 0].contiguous())
+                                                    + self.tuplefeat_encoder2(v[:, 1].contiguous()))
+        else:
+            out["X"] = datadict["X"].tuplewiseapply(self.tuplefeat_encoder)
+        return out
+
+
+class SpModel(nn.Module):
+    """sparse-layout model of example/zinc.py:222-297 for any layer family (`conv`: a name of `conv_table` or a factory)."""
+
+    def __init__(self, conv: Union[str, Callable] = "NGNN", num_tasks: int = 1, num_layer: int = 6, hiddim: int = 128,
+                 npool: str = "mean", lpool: str = "max", residual: bool = True, outlayer: int = 1, mlplayer: int = 1,
+                 mlp: Optional[dict] = None, aggr: str = "sum", cpool: str = "mean", act_dtype: Optional[torch.dtype] = None):
+        super().__init__()
+        mlp = dict(mlp or {"norm": "bn", "act": "silu", "dp": 0.0})
+        self.three = conv == "I2GNN"
+        factory = conv_table("SS", aggr, cpool)[conv] if isinstance(conv, str) else conv
+        self.lin_tupleinit0 = nn.Linear(hiddim, hiddim)
+        self.lin_tupleinit1 = nn.Linear(hiddim, hiddim)
+        self.lin_tupleinit2 = nn.Linear(hiddim, hiddim)
+        self.residual = residual
+        self.subggnns = nn.ModuleList([factory(hiddim, mlp) for _ in range(num_layer)])
+        self.npool = npool
+        self.lpool = (nn.Sequential(OpPoolingSubg3D("S", lpool), OpPoolingSubg2D("S", lpool)) if self.three
+                      else OpPoolingSubg2D("S", lpool))
+        self.poolmlp = MLP(hiddim, hiddim, mlplayer, tailact=True, **mlp)
+        self.data_encoder = InputEncoderSp(hiddim, self.three, act_dtype)
+        self.pred_lin = nn.Sequential(MLP(hiddim, num_tasks, outlayer, tailact=False, **mlp), nn.Identity())
+
+    def tupleinit(self, X: SparseTensor, x: Tensor) -> SparseTensor:
+        left, right = self.lin_tupleinit0(x), self.lin_tupleinit1(x)
+        if self.three:          # the reference indexes BOTH of its last two factors with indices[1] (zinc.py:272-273)
+            third = self.lin_tupleinit2(x)
+            return X.tuplewiseapply(lambda v: _ops.gather_rows(left, X._row(0)) * _ops.gather_rows(right, X._row(1))
+                                    * _ops.gather_rows(third, X._row(1)) * v)
+        if X.values.is_cuda and X.values.dim() == 2 and left.dtype == right.dtype == X.values.dtype:
+            return X.tuplewiseapply(lambda v: _ops.pair_product(left, right, v, X._row(0), X._row(1)))
+        return X.tuplewiseapply(lambda v: _ops.gather_rows(left, X._row(0)) * _ops.gather_rows(right, X._row(1)) * v)
+
+    def forward(self, datadict: dict) -> Tensor:
+        datadict = self.data_encoder(datadict)
+        A, X, x = datadict["A"], datadict["X"], datadict["x"]
+        X = self.tupleinit(X, x)
+        for conv in self.subggnns:
+            if self.residual and hasattr(conv, "forward_residual"):
+                X = conv.forward_residual(A, X, datadict)
+            else:
+                tX = conv.forward(A, X, datadict)
+                X = X.add(tX, True) if self.residual else tX
+        x = self.poolmlp(self.lpool(X))
+        h_graph = torch_scatter_reduce(0, x, datadict["batch"], datadict["num_graphs"], self.npool)
+        return self.pred_lin(h_graph)
+
+
+class InputEncoderMa(nn.Module):
+    """example/zinc.py:58-71 on padded tensors (the adjacency embedding keeps padding_idx = 0)"""
+
+    def __init__(self, hiddim: int) -> None:
+        super().__init__()
+        self.x_encoder = nn.Embedding(32, hiddim)
+        self.ea_encoder = nn.Embedding(16, hiddim, padding_idx=0)
+        self.tuplefeat_encoder = nn.Embedding(16, hiddim)
+
+    def forward(self, datadict: dict) -> dict:
+        out = dict(datadict)
+        out["x"] = datadict["x"].tuplewiseapply(lambda v: self.x_encoder(v.squeeze(-1) if v.dim() > 2 else v))
+        out["A"] = datadict["A"].tuplewiseapply(self.ea_encoder)
+        out["X"] = datadict["X"].tuplewiseapply(self.tuplefeat_encoder)
+        return out
+
+
+class MaModel(nn.Module):
+    """dense-layout model of example/zinc.py:155-219: x (b, n) / A (b, n, n) / X (b, n, n) integer MaskedTensors in, (b, tasks) out"""
+
+    def __init__(self, conv: Union[str, Callable] = "NGNN", num_tasks: int = 1, num_layer: int = 6, hiddim: int = 128,
+                 npool: str = "mean", lpool: str = "max", residual: bool = True, outlayer: int = 2, mlplayer: int = 1,
+                 mlp: Optional[dict] = None, aggr: str = "sum", cpool: str = "mean"):
+        super().__init__()
+        mlp = dict(mlp or {"norm": "bn", "act": "silu", "dp": 0.0})
+        factory = conv_table("DD", aggr, cpool)[conv] if isinstance(conv, str) else conv
+        self.lin_tupleinit0 = nn.Linear(hiddim, hiddim)
+        self.lin_tupleinit1 = nn.Linear(hiddim, hiddim)
+        self.residual = residual
+        self.subggnns = nn.ModuleList([factory(hiddim, mlp) for _ in range(num_layer)])
+        self.npool = OpPooling(1, pool=npool)
+        self.lpool = OpPoolingSubg2D("D", pool=lpool)
+        self.poolmlp = MLP(hiddim, hiddim, mlplayer, tailact=True, **mlp)
+        self.data_encoder = InputEncoderMa(hiddim)
+        self.pred_lin = nn.Sequential(MLP(hiddim, num_tasks, outlayer, tailact=False, **mlp), nn.Identity())
+
+    def tupleinit(self, X: MaskedTensor, x: MaskedTensor) -> MaskedTensor:
+        xf = x.fill_masked(0.)
+        return X.tuplewiseapply(lambda val: self.lin_tupleinit0(xf).unsqueeze(1) * self.lin_tupleinit1(xf).unsqueeze(2) * val)
+
+    def forward(self, datadict: dict) -> Tensor:
+        datadict = self.data_encoder(datadict)
+        A, X, x = datadict["A"], datadict["X"], datadict["x"]
+        X = self.tupleinit(X, x)
+        for conv in self.subggnns:
+            tX = conv.forward(A, X, datadict)
+            X = X.add(tX, True) if self.residual else tX
+        x = self.lpool(X).tuplewiseapply(self.poolmlp)
+        return self.pred_lin(self.npool.forward(x).fill_masked(0.))
