@@ -79,15 +79,55 @@ def case(name, graphs, dev, profile=False):
             "msg_edges": msgs, "ms": ms, "graphs_per_s": hb.num_graphs / ms * 1e3}
 
 
+def model_case(conv, graphs, dev):
+    """one training step (forward, backward, AdamW) of the 6-layer example/zinc.py model of a layer family (pygho_amd.models.SpModel),
+    hidden 128 (I2GNN: 3-tuple batches), bf16 activations, resident batch."""
+    from pygho_amd.models import SpModel
+    kind = "i2" if conv == "I2GNN" else "zinc"
+    torch.manual_seed(0)
+    model = SpModel(conv, num_layer=6, hiddim=128, act_dtype=torch.bfloat16).to(dev)
+    keys = tuple(parse_precomputekey(model))
+    hb = synth.make_batch(min(graphs, 1024), kind, seed=11, keys=keys)
+    if graphs > 1024:
+        hb = synth.replicate(hb, graphs // 1024)
+    dd = synth.to_datadict(hb, dev, kind)
+    y = dd["y"].unsqueeze(-1)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = model(dd)
+        torch.nn.functional.l1_loss(y, pred.float()).backward()
+        opt.step()
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(8):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 8
+    return {"op": f"{conv} model train step (6 layers, hidden 128, bf16)", "graphs": hb.num_graphs, "ms": ms,
+            "graphs_per_s": hb.num_graphs / ms * 1e3}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--graphs", type=int, default=8192)
     ap.add_argument("--profile", default="")
+    ap.add_argument("--models", action="store_true", help="also time a 6-layer model train step per layer family")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for name in ("NGNNConv", "SSWLConv", "SUNConv", "I2Conv"):
         g = args.graphs if name != "I2Conv" else max(256, args.graphs // 4)
         print(json.dumps(case(name, g, dev, profile=args.profile == name)), flush=True)
+    if args.models:
+        for conv in ("NGNN", "SSWL", "DSSGNN", "GNNAK", "SUN", "PPGN", "I2GNN"):
+            g = args.graphs // 2 if conv in ("SUN", "PPGN", "GNNAK") else (max(256, args.graphs // 8) if conv == "I2GNN" else args.graphs)
+            print(json.dumps(model_case(conv, g, dev)), flush=True)
 
 
 if __name__ == "__main__":
