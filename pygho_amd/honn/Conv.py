@@ -229,7 +229,7 @@ class GNNAKConv(Module):
         extra = [centroid]
         if self.ctx:
             extra.append(self.unpool4rootnode.forward(self.pool2node.forward(H), H))
-        return pooled.catvalue(extra if self.ctx else centroid, True).tuplewiseapply(self.lin)
+        return _cat_apply(pooled, extra, self.lin)
 
 
 class SUNConv(Module):
