@@ -416,6 +416,10 @@ int pygho_bn_finalize(float* mean, float* var, float* invstd, float* scale, floa
                       void* stream);
 int pygho_bn_act_fwd(void* y, const void* x, const float* scale, const float* bias, int64_t m, int64_t c,
                      int act, int dtype, void* stream);
+/* y = act(x * scale + bias) + addend (f32 add, one rounding): the block's residual connection X.add(block(X), True)
+ * (example/zinc.py:287-290, SpTensor.py:507-517) inside the activation pass. */
+int pygho_bn_act_fwd_add(void* y, const void* x, const void* addend, const float* scale, const float* bias, int64_t m, int64_t c,
+                         int act, int dtype, void* stream);
 int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy,
                      const float* mean, const float* invstd, const float* w, const float* b, int64_t m,
                      int64_t c, int act, int training, void* workspace, int dtype, float* sum_dx, void* stream);

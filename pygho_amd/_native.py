@@ -79,6 +79,7 @@ PROTOTYPES = {
     "pygho_bn_prepare": (I, [P, P, P, P, P, P, L, L, P, P, D, P, P, D, P, I, P]),
     "pygho_bn_finalize": (I, [P, P, P, P, P, P, L, P, L, L, P, P, D, P, P, D, P]),
     "pygho_bn_act_fwd": (I, [P, P, P, P, L, L, I, I, P]),
+    "pygho_bn_act_fwd_add": (I, [P, P, P, P, P, L, L, I, I, P]),
     "pygho_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, P, I, P, P]),
     "pygho_rowblock_linear_blocks": (I, [L]),
     "pygho_rowblock_linear": (I, [P, P, P, P, P, P, P, L, L, I, P]),

@@ -1589,8 +1589,8 @@ def bn_act_supported(x: Tensor) -> bool:
 
 def _bn_forward(x: Tensor, weight, bias, running_mean, running_var, training: bool, eps: float, act: str,
                 fold_momentum: Optional[float] = None, partial: Optional[Tuple[Tensor, Tensor]] = None,
-                apply: bool = True):
-    """(y, mean, var, saved) of act(batch_norm(x)) for a contiguous 2-D x.  Statistics, 1/sqrt(var + eps), the fused
+                apply: bool = True, addend: Optional[Tensor] = None):
+    """(y, mean, var, saved) of act(batch_norm(x)) (+ addend: a residual row added inside the activation pass) for a contiguous 2-D x.  Statistics, 1/sqrt(var + eps), the fused
     scale / shift and (with `fold_momentum`) the running-average update all come out of ONE finalisation kernel;
     `partial` = (per-block shifted sums, their shift) when the producer of x already took the sums (rowblock_linear).
     `apply=False`: y is not formed; (scale, shift) are returned in its place for a consumer that applies them on load."""
@@ -1622,7 +1622,11 @@ def _bn_forward(x: Tensor, weight, bias, running_mean, running_var, training: bo
     if not apply:
         return (scale, shift), mean, var, (mean, invstd, w32, b32, ws)
     y = torch.empty_like(x)
-    check(lib().pygho_bn_act_fwd(ptr(y), ptr(x), ptr(scale), ptr(shift), m, c, ACT_CODE[act], dt, st), "bn_act_fwd")
+    if addend is not None:
+        check(lib().pygho_bn_act_fwd_add(ptr(y), ptr(x), ptr(addend.contiguous()), ptr(scale), ptr(shift), m, c, ACT_CODE[act], dt, st),
+              "bn_act_fwd_add")
+    else:
+        check(lib().pygho_bn_act_fwd(ptr(y), ptr(x), ptr(scale), ptr(shift), m, c, ACT_CODE[act], dt, st), "bn_act_fwd")
     return y, mean, var, (mean, invstd, w32, b32, ws)
 
 
@@ -1964,6 +1968,11 @@ class _ConcatBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w, b, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum, *xs):
+        # fold_momentum may arrive as (momentum, residual): residual = the block's output gets xs[0] added (the layer's residual
+        # connection, in the activation pass) and xs[0]'s gradient gets the output gradient added (in its backward GEMM's epilogue)
+        residual = False
+        if isinstance(fold_momentum, tuple):
+            fold_momentum, residual = fold_momentum
         require_device(w, *xs)
         xs = [x.contiguous() for x in xs]
         d = xs[0].shape[1]
@@ -1976,8 +1985,9 @@ class _ConcatBlock(torch.autograd.Function):
             last = k == len(xs) - 1
             pre, partial = rowblock_linear(x, wk, bc if k == 0 else None, addend=pre, stats_shift=True if (last and training) else None)
         h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum,
-                                          partial if training else None, apply=True)
+                                          partial if training else None, apply=True, addend=xs[0] if residual else None)
         ctx.save_for_backward(pre, *xs, *blocks, *saved)
+        ctx.residual = residual
         ctx.meta = (len(xs), training, act, None if b is None else b.dtype, gamma is not None, beta is not None, w.dtype)
         ctx.mark_non_differentiable(mean, var)
         return h, mean, var
@@ -1994,8 +2004,8 @@ class _ConcatBlock(torch.autograd.Function):
         want_cs = b_dtype is not None and ctx.needs_input_grad[1]
         gxs, gws, gb = [], [], None
         for k in range(k_in):
-            gx, gw32, _s1, _s2, sdx = bn_bwd_linear(pre, g, saved, training, act, blocks[k], None, want_cs and k == 0, x=xs[k],
-                                                    sums=sums)
+            gx, gw32, _s1, _s2, sdx = bn_bwd_linear(pre, g, saved, training, act, blocks[k], g if (ctx.residual and k == 0) else None,
+                                                    want_cs and k == 0, x=xs[k], sums=sums)
             gxs.append(gx if ctx.needs_input_grad[10 + k] else None)
             gws.append(gw32)
             if sdx is not None:
@@ -2013,11 +2023,11 @@ def concat_block_supported(xs, lin: "torch.nn.Linear") -> bool:
             and bn_act_supported_shape(xs[0].shape[0], d, xs[0].dtype))
 
 
-def concat_block(xs, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", act: str) -> Tensor:
-    """fused Linear -> BatchNorm1d -> act applied to concat(xs, dim=1), the concatenation never formed."""
+def concat_block(xs, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", act: str, residual: bool = False) -> Tensor:
+    """fused Linear -> BatchNorm1d -> act applied to concat(xs, dim=1), the concatenation never formed; `residual`: + xs[0]."""
     training = bn.training or bn.running_mean is None
     fold = _fold_momentum(bn)
     out, mean, var = _ConcatBlock.apply(lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                                        bn.eps, act, fold, *xs)
+                                        bn.eps, act, (fold, True) if residual else fold, *xs)
     _update_running(bn, mean, var, xs[0].shape[0], folded=fold is not None)
     return out

@@ -137,7 +137,7 @@ __global__ void bn_derive_kernel(const float* __restrict__ mean, const float* __
 template <typename T, int ACT>
 __global__ __launch_bounds__(kBlock) void bn_act_fwd_kernel(T* __restrict__ y, const T* __restrict__ x,
                                                             const float* __restrict__ scale, const float* __restrict__ bias,
-                                                            int64_t m, int c, int chunks) {
+                                                            int64_t m, int c, int chunks, const T* __restrict__ addend = nullptr) {
   constexpr int N = Vec16<T>::N;
   const int tpr = chunks, rows_per_it = kBlock / tpr;
   const int chunk = threadIdx.x % tpr, rlane = threadIdx.x / tpr;
@@ -149,6 +149,12 @@ __global__ __launch_bounds__(kBlock) void bn_act_fwd_kernel(T* __restrict__ y, c
     Vec16<T>::unpack(*reinterpret_cast<const uint4*>(x + r * c + (int64_t)chunk * N), v);
 #pragma unroll
     for (int q = 0; q < N; ++q) v[q] = act_fwd<ACT>(v[q] * sc[q] + bi[q]);
+    if (addend) {                                  // residual connection: added in f32, one rounding (workgroup-uniform branch)
+      float a[N];
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(addend + r * c + (int64_t)chunk * N), a);
+#pragma unroll
+      for (int q = 0; q < N; ++q) v[q] += a[q];
+    }
     *reinterpret_cast<uint4*>(y + r * c + (int64_t)chunk * N) = Vec16<T>::pack(v);
   }
 }
@@ -353,6 +359,19 @@ extern "C" int pygho_bn_act_fwd(void* y, const void* x, const float* scale, cons
   PYGHO_BN_T(dtype, PYGHO_BN_ACT(act, hipLaunchKernelGGL((bn_act_fwd_kernel<T, A>), dim3(grid), dim3(kBlock), 0, st, (T*)y,
                                                          (const T*)x, scale, bias, m, (int)c, chunks)));
   return check_launch("bn_act_fwd");
+}
+
+extern "C" int pygho_bn_act_fwd_add(void* y, const void* x, const void* addend, const float* scale, const float* bias, int64_t m,
+                                    int64_t c, int act, int dtype, void* stream) {
+  if (m < 0 || c <= 0) { set_error("bad size"); return PYGHO_ERR_INVALID; }
+  if (m == 0) return PYGHO_OK;
+  if (!y || !x || !addend || !scale || !bias) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  int chunks, grid;
+  if (int rc = bn_geometry(m, c, dtype, &chunks, &grid)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  PYGHO_BN_T(dtype, PYGHO_BN_ACT(act, hipLaunchKernelGGL((bn_act_fwd_kernel<T, A>), dim3(grid), dim3(kBlock), 0, st, (T*)y,
+                                                         (const T*)x, scale, bias, m, (int)c, chunks, (const T*)addend)));
+  return check_launch("bn_act_fwd_add");
 }
 
 extern "C" int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,

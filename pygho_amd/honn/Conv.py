@@ -99,7 +99,7 @@ def _residual_update(layer, A: Rep, X: Rep, datadict: dict) -> Rep:
     return X.tuplewiseapply(lambda _: vals)
 
 
-def _cat_apply(first: Rep, others, mlp) -> Rep:
+def _cat_apply(first: Rep, others, mlp, residual: bool = False) -> Rep:
     """``first.catvalue(others, True).tuplewiseapply(mlp)`` (reference Conv.py:98-103, 190-196).  Sparse representations on
     the device whose MLP is one Linear -> BatchNorm -> act block over equally wide inputs skip the concatenation
     (``_ops.concat_block``: chained streaming GEMMs, one backward pass per input)."""
@@ -112,9 +112,10 @@ def _cat_apply(first: Rep, others, mlp) -> Rep:
         vals = [v if v.dtype == dt else v.to(dt) for v in vals]
         if _ops.concat_block_supported(vals, block[0]):
             with torch.autocast("cuda", enabled=False):
-                out = _ops.concat_block(vals, *block)
+                out = _ops.concat_block(vals, *block, residual=residual)     # residual: + first, inside the activation pass
             return first.tuplewiseapply(lambda _: out)
-    return first.catvalue(list(others), True).tuplewiseapply(mlp)
+    out = first.catvalue(list(others), True).tuplewiseapply(mlp)
+    return first.add(out, True) if residual else out
 
 
 class NGNNConv(Module):
@@ -149,6 +150,12 @@ class SSWLConv(Module):
     def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
         neighbours = [op.forward(A, X, datadict, X) for op in (self.aggr1, self.aggr2)]
         return _cat_apply(X, neighbours, self.lin)
+
+    def forward_residual(self, A: Rep, X: Rep, datadict: dict) -> Rep:
+        """``X.add(self.forward(A, X, datadict), True)`` (the model loop of example/zinc.py:287-290) with the residual row added
+        inside the block's activation pass and its gradient inside the first backward GEMM's epilogue."""
+        neighbours = [op.forward(A, X, datadict, X) for op in (self.aggr1, self.aggr2)]
+        return _cat_apply(X, neighbours, self.lin, residual=True)
 
 
 class I2Conv(Module):

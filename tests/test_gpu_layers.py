@@ -829,3 +829,42 @@ def test_zinc_model_i2gnn_trains(dev):
         opt.step()
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_sswl_forward_residual_fused(dev):
+    """SSWLConv.forward_residual (residual row added in the concat block's activation pass, its gradient in the first backward
+    GEMM's epilogue) against X.add(conv.forward(...), True) with the fused concat block switched off: bf16, outputs and gradients."""
+    import copy
+    from pygho_amd import SparseTensor, synth, _ops
+    from pygho_amd.honn import Conv
+    from pygho_amd.honn.SpOperator import parse_precomputekey
+    h = 128
+    torch.manual_seed(3)
+    layer = Conv.SSWLConv(h, h, "sum", "SS", dict(MLP)).to(dev)
+    hb = synth.make_batch(64, "zinc", seed=22, keys=tuple(parse_precomputekey(layer)))
+    dd = synth.to_datadict(hb, dev)
+    X0, A0 = dd["X"], dd["A"]
+    xv0 = torch.randn(X0.nnz, h, device=dev).to(torch.bfloat16)
+    A = SparseTensor(A0.indices, (torch.randn(A0.nnz, h, device=dev) * 0.5).to(torch.bfloat16), list(A0.shape[:2]) + [h], True)
+    w = torch.randn(X0.nnz, h, device=dev).to(torch.bfloat16)
+    res = {}
+    for fused in (True, False):
+        _ops.USE_CONCAT_BLOCK = fused
+        try:
+            lay = copy.deepcopy(layer)
+            xv = xv0.clone().requires_grad_(True)
+            X = SparseTensor(X0.indices, xv, list(X0.shape[:2]) + [h], True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = lay.forward_residual(A, X, dd) if fused else X.add(lay.forward(A, X, dd), True)
+            out.values.backward(w)
+            res[fused] = (out.values.detach().float(), xv.grad.float(), {k: p.grad.float() for k, p in lay.named_parameters()})
+        finally:
+            _ops.USE_CONCAT_BLOCK = True
+    for i in (0, 1):
+        s = float(res[False][i].abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][i] / s, res[False][i] / s, rtol=0, atol=4e-2)
+    for k, ref in res[False][2].items():
+        if k.endswith(".lins.0.bias"):
+            continue
+        s = float(ref.abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][2][k] / s, ref / s, rtol=0, atol=4e-2, msg=k)
