@@ -61,7 +61,7 @@ def sources():
 
 
 def up_to_date() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(USAGE):     # the resource-usage record is part of a complete build
         return False
     t = os.path.getmtime(LIB)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
