@@ -299,13 +299,18 @@ class SUNConv(Module):
 
         agg = self.aggr.forward(A, X.tuplewiseapply(self.lin0), datadict, X)
         if _ops.USE_PAIR_COMBINE and self._pool in ("sum", "mean"):
-            if (isinstance(X, MaskedTensor) and isinstance(agg, MaskedTensor) and X.masked_dim == 3
-                    and _ops.pair_combine_supported(X.raw) and agg.raw.dtype == X.raw.dtype and agg.raw.shape == X.raw.shape):
-                return self._recombine(X, agg, blk, dense=True).tuplewiseapply(self.lin1_1)
+            # compute dtype of the fused passes: the autocast dtype when autocast is on (operands are cast once), else X's
+            cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
+            as_c = lambda t: t if cdt is None or t.dtype == cdt or not t.is_floating_point() else t.to(cdt)
+            if (isinstance(X, MaskedTensor) and isinstance(agg, MaskedTensor) and X.masked_dim == 3 and X.raw.is_floating_point()
+                    and agg.raw.shape == X.raw.shape and (cdt is not None or agg.raw.dtype == X.raw.dtype)
+                    and _ops.pair_combine_supported(as_c(X.raw))):
+                return self._recombine(X, agg, blk, True, as_c).tuplewiseapply(self.lin1_1)
             if (isinstance(X, SparseTensor) and isinstance(agg, SparseTensor) and X.sparse_dim == 2 and X.values is not None
-                    and agg.values is not None and _ops.pair_gather_supported(X.values) and agg.values.dtype == X.values.dtype
-                    and agg.values.shape == X.values.shape and agg.nnz == X.nnz and X.shape[0] == X.shape[1]):
-                return self._recombine(X, agg, blk, dense=False).tuplewiseapply(self.lin1_1)
+                    and agg.values is not None and X.values.is_floating_point() and agg.values.shape == X.values.shape
+                    and (cdt is not None or agg.values.dtype == X.values.dtype) and agg.nnz == X.nnz and X.shape[0] == X.shape[1]
+                    and _ops.pair_gather_supported(as_c(X.values))):
+                return self._recombine(X, agg, blk, False, as_c).tuplewiseapply(self.lin1_1)
         centre, n5, n6, n7 = self.diag.forward(X), self.pool2node(X), self.pool2subg(X), self.pool2node(agg)
         # concat order of the reference: [X, to_nodes(centre), to_root(centre), agg, to_root(n5), to_nodes(n6), to_root(n7)]
         off = add(lin(X, blk(0, 0)), lin(agg, blk(0, 3)))
@@ -322,7 +327,11 @@ class SUNConv(Module):
             picked = off.diagonalapply(lambda val, is_diag: torch.where(is_diag.bool().unsqueeze(-1), dg_t.values.to(val.dtype), val))
         return picked.tuplewiseapply(self.lin1_1)
 
-    def _recombine(self, X: Rep, agg: Rep, blk, dense: bool) -> Rep:
+    def _recombine(self, X: Rep, agg: Rep, blk, dense: bool, as_c=lambda t: t) -> Rep:
+        with torch.autocast("cuda", enabled=False):          # one compute dtype throughout (operands cast by `as_c`)
+            return self._recombine_impl(X, agg, blk, dense, as_c)
+
+    def _recombine_impl(self, X: Rep, agg: Rep, blk, dense: bool, as_c) -> Rep:
         """the same arithmetic with the tuple-level passes fused, on the padded (``dense``) or the sparse layout: the
         node-level views of X and agg (diagonal, pool over subgraphs, pool over nodes) come from one autograd node each
         (their gradients return to the tuple level in one pass: ``_ops.pair_views`` / ``_ops.sparse_pair_views``); the two
@@ -330,7 +339,7 @@ class SUNConv(Module):
         ``_ops.sparse_pair_linear_mix`` (two GEMM launches + one pass)."""
         if dense:
             mask, amask = X.mask, agg.mask
-            xv, av = X.raw, agg.raw
+            xv, av = as_c(X.raw), as_c(agg.raw)
             dt, d_ = xv.dtype, xv.shape[-1]
 
             def views(vals, m, subg=True):
@@ -343,7 +352,7 @@ class SUNConv(Module):
             centre, n5, n6 = views(xv, mask)
             agg_dg, n7, _unused = views(av, amask, subg=False)       # pool2subg(agg) is not one of the seven views
         else:
-            xv, av = X.values, agg.values
+            xv, av = as_c(X.values), as_c(agg.values)
             dt, d_ = xv.dtype, xv.shape[-1]
             n = X.shape[0]
             ri, ci = X._row(0), X._row(1)

@@ -117,11 +117,13 @@ class SpModel(nn.Module):
 class InputEncoderMa(nn.Module):
     """example/zinc.py:58-71 on padded tensors (the adjacency embedding keeps padding_idx = 0)"""
 
-    def __init__(self, hiddim: int) -> None:
+    def __init__(self, hiddim: int, act_dtype: Optional[torch.dtype] = None) -> None:
         super().__init__()
-        self.x_encoder = nn.Embedding(32, hiddim)
-        self.ea_encoder = nn.Embedding(16, hiddim, padding_idx=0)
-        self.tuplefeat_encoder = nn.Embedding(16, hiddim)
+        # IndexEmbedding: same parameters as nn.Embedding; its backward is a hierarchical segment reduction (ATen's
+        # embedding_dense_backward took 97 of 121 ms per step here: 1.4 M lookups into 16 rows)
+        self.x_encoder = IndexEmbedding(32, hiddim, act_dtype)
+        self.ea_encoder = IndexEmbedding(16, hiddim, act_dtype, padding_idx=0)
+        self.tuplefeat_encoder = IndexEmbedding(16, hiddim, act_dtype)
 
     def forward(self, datadict: dict) -> dict:
         out = dict(datadict)
@@ -136,7 +138,7 @@ class MaModel(nn.Module):
 
     def __init__(self, conv: Union[str, Callable] = "NGNN", num_tasks: int = 1, num_layer: int = 6, hiddim: int = 128,
                  npool: str = "mean", lpool: str = "max", residual: bool = True, outlayer: int = 2, mlplayer: int = 1,
-                 mlp: Optional[dict] = None, aggr: str = "sum", cpool: str = "mean"):
+                 mlp: Optional[dict] = None, aggr: str = "sum", cpool: str = "mean", act_dtype: Optional[torch.dtype] = None):
         super().__init__()
         mlp = dict(mlp or {"norm": "bn", "act": "silu", "dp": 0.0})
         factory = conv_table("DD", aggr, cpool)[conv] if isinstance(conv, str) else conv
@@ -147,7 +149,7 @@ class MaModel(nn.Module):
         self.npool = OpPooling(1, pool=npool)
         self.lpool = OpPoolingSubg2D("D", pool=lpool)
         self.poolmlp = MLP(hiddim, hiddim, mlplayer, tailact=True, **mlp)
-        self.data_encoder = InputEncoderMa(hiddim)
+        self.data_encoder = InputEncoderMa(hiddim, act_dtype)
         self.pred_lin = nn.Sequential(MLP(hiddim, num_tasks, outlayer, tailact=False, **mlp), nn.Identity())
 
     def tupleinit(self, X: MaskedTensor, x: MaskedTensor) -> MaskedTensor:

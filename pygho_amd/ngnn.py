@@ -30,14 +30,19 @@ class IndexEmbedding(nn.Embedding):
     backward is the hierarchical segment reduction instead of ATen's sort + index_put_(accumulate): with a
     handful of table rows and 10^6 lookups the stock backward was 35 % of the training step."""
 
-    def __init__(self, num_embeddings: int, embedding_dim: int, out_dtype: Optional[torch.dtype] = None):
-        super().__init__(num_embeddings, embedding_dim)
+    def __init__(self, num_embeddings: int, embedding_dim: int, out_dtype: Optional[torch.dtype] = None,
+                 padding_idx: Optional[int] = None):
+        super().__init__(num_embeddings, embedding_dim, padding_idx=padding_idx)
         self.out_dtype = out_dtype
 
     def forward(self, idx: Tensor) -> Tensor:
         if not idx.is_cuda:
             return super().forward(idx)
         table = self.weight if self.out_dtype is None else self.weight.to(self.out_dtype)
+        if self.padding_idx is not None:            # nn.Embedding semantics: that row reads as stored (zero) and gets no gradient
+            keep = torch.ones((self.num_embeddings, 1), dtype=table.dtype, device=table.device)
+            keep[self.padding_idx] = 0
+            table = table * keep + (table * (1 - keep)).detach()
         out = _ops.gather_rows(table, _flat_index(idx))              # persistent index object: the gather plan is cached on it
         out = out.reshape(tuple(idx.shape) + (self.embedding_dim,))
         if idx.dim() == 1:

@@ -868,3 +868,29 @@ def test_sswl_forward_residual_fused(dev):
             continue
         s = float(ref.abs().max()) + 1e-6
         torch.testing.assert_close(res[True][2][k] / s, ref / s, rtol=0, atol=4e-2, msg=k)
+
+
+@pytest.mark.parametrize("conv", ["NGNN", "SSWL", "DSSGNN", "GNNAK", "SUN", "PPGN"])
+def test_zinc_dense_models_train_under_autocast(dev, conv):
+    """the dense-layout model of every 2-tuple family runs training steps under bf16 autocast (f32 and bf16 activations: mixed
+    operand dtypes reach the fused passes) and its loss decreases; the padding row of the adjacency embedding stays zero."""
+    from pygho_amd import synth
+    from pygho_amd.models import MaModel
+    hb = synth.make_batch(16, "zinc", seed=19)
+    y = T(hb.y, dev).unsqueeze(-1)
+    for act_dtype in (None, torch.bfloat16):
+        torch.manual_seed(0)
+        model = MaModel(conv, num_layer=2, hiddim=64, act_dtype=act_dtype).to(dev)
+        opt = torch.optim.AdamW(model.parameters(), lr=3e-3)
+        dd = _dense_inputs_of(hb, dev)
+        losses = []
+        for _ in range(10):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                pred = model(dict(dd))
+            loss = torch.nn.functional.l1_loss(y, pred.float())
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0], (conv, act_dtype, losses)
+        assert float(model.data_encoder.ea_encoder.weight[0].detach().abs().sum()) == 0.0
