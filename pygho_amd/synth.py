@@ -326,6 +326,24 @@ def to_datadict(hb: HostBatch, device, kind: str = "zinc") -> dict:
     return dd
 
 
+def to_dense_datadict(hb: HostBatch, device) -> dict:
+    """mirror of ``batch2dense`` + ``batch.to_dict()`` (hodata/MaData.py:146-255) for a synthetic 2-tuple batch: padded
+    integer MaskedTensors x (b, n), A (b, n, n) and X (b, n, n), built by the device builders of ``hodata.MaData``."""
+    import torch
+    from .hodata import to_dense_adj, to_dense_x
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    counts = np.bincount(hb.batch, minlength=hb.num_graphs)
+    ptr = np.concatenate(([0], np.cumsum(counts)))
+    n = int(counts.max())
+    local = lambda idx: idx - ptr[hb.batch[idx]]
+    eb, tb = hb.batch[hb.edge_index[0]], hb.batch[hb.tupleid[0]]
+    return {
+        "x": to_dense_x(t(hb.x), t(ptr)), "num_graphs": hb.num_graphs, "y": t(hb.y),
+        "A": to_dense_adj(t(np.stack((local(hb.edge_index[0]), local(hb.edge_index[1])))), t(eb), t(hb.edge_attr), n, hb.num_graphs),
+        "X": to_dense_adj(t(np.stack((local(hb.tupleid[0]), local(hb.tupleid[1])))), t(tb), t(hb.tuplefeat), n, hb.num_graphs),
+    }
+
+
 def make_dense_batch(num_graphs: int, seed: int = 0, hidden: int = 128, nmax: Optional[int] = None,
                      dtype=np.float32, clip_nodes: Optional[int] = None):
     """padded dense form for the masked path (hodata/MaData.py:25-255): node mask

@@ -114,6 +114,36 @@ def model_case(conv, graphs, dev):
             "graphs_per_s": hb.num_graphs / ms * 1e3}
 
 
+def dense_model_case(conv, graphs, dev):
+    """the same training step on the dense layout (pygho_amd.models.MaModel: padded (b, n, n) MaskedTensors, zinc.py:150-236)"""
+    from pygho_amd.models import MaModel
+    torch.manual_seed(0)
+    model = MaModel(conv, num_layer=6, hiddim=128, act_dtype=torch.bfloat16).to(dev)
+    hb = synth.make_batch(graphs, "zinc", seed=11)
+    dd = synth.to_dense_datadict(hb, dev)
+    y = dd["y"].unsqueeze(-1)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = model(dict(dd))
+        torch.nn.functional.l1_loss(y, pred.float()).backward()
+        opt.step()
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(8):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 8
+    return {"op": f"{conv} dense-layout model train step (6 layers, hidden 128, bf16)", "graphs": hb.num_graphs,
+            "padded_nodes": int(dd["x"].shape[1]), "ms": ms, "graphs_per_s": hb.num_graphs / ms * 1e3}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--graphs", type=int, default=8192)
@@ -128,6 +158,8 @@ def main():
         for conv in ("NGNN", "SSWL", "DSSGNN", "GNNAK", "SUN", "PPGN", "I2GNN"):
             g = args.graphs // 2 if conv in ("SUN", "PPGN", "GNNAK") else (max(256, args.graphs // 8) if conv == "I2GNN" else args.graphs)
             print(json.dumps(model_case(conv, g, dev)), flush=True)
+        for conv in ("NGNN", "SSWL", "DSSGNN", "GNNAK", "SUN", "PPGN"):
+            print(json.dumps(dense_model_case(conv, min(args.graphs, 1024), dev)), flush=True)
 
 
 if __name__ == "__main__":
