@@ -114,6 +114,17 @@ def _cat_apply(first: Rep, others, mlp, residual: bool = False) -> Rep:
             with torch.autocast("cuda", enabled=False):
                 out = _ops.concat_block(vals, *block, residual=residual)     # residual: + first, inside the activation pass
             return first.tuplewiseapply(lambda _: out)
+    if block is not None and all(isinstance(r, MaskedTensor) for r in reps) and first.data.is_cuda:
+        # dense layout: the same block over the padded rows (catvalue + tuplewiseapply zero-fill the concatenation under
+        # first's mask, reference MaTensor.py:264-270, 318-330; here each part is filled, parts a product already filled are not copied)
+        parts = [(r if r.mask is first.mask else MaskedTensor(r.data, first.mask)).fill_masked(0.) for r in reps]
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else parts[0].dtype
+        d = parts[0].shape[-1]
+        vals = [(v if v.dtype == dt else v.to(dt)).reshape(-1, d) for v in parts]
+        if all(v.shape == vals[0].shape for v in vals) and _ops.concat_block_supported(vals, block[0]):
+            with torch.autocast("cuda", enabled=False):
+                out = _ops.concat_block(vals, *block, residual=residual)
+            return MaskedTensor(out.view(tuple(parts[0].shape[:-1]) + (out.shape[-1],)), first.mask)
     out = first.catvalue(list(others), True).tuplewiseapply(mlp)
     return first.add(out, True) if residual else out
 

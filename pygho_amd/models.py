@@ -161,7 +161,10 @@ class MaModel(nn.Module):
         A, X, x = datadict["A"], datadict["X"], datadict["x"]
         X = self.tupleinit(X, x)
         for conv in self.subggnns:
-            tX = conv.forward(A, X, datadict)
-            X = X.add(tX, True) if self.residual else tX
+            if self.residual and hasattr(conv, "forward_residual"):
+                X = conv.forward_residual(A, X, datadict)
+            else:
+                tX = conv.forward(A, X, datadict)
+                X = X.add(tX, True) if self.residual else tX
         x = self.lpool(X).tuplewiseapply(self.poolmlp)
         return self.pred_lin(self.npool.forward(x).fill_masked(0.))

@@ -894,3 +894,54 @@ def test_zinc_dense_models_train_under_autocast(dev, conv):
             losses.append(float(loss.detach()))
         assert all(np.isfinite(losses)) and losses[-1] < losses[0], (conv, act_dtype, losses)
         assert float(model.data_encoder.ea_encoder.weight[0].detach().abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("name,residual", [("SSWLConv", False), ("SSWLConv", True), ("DSSGNNConv", False), ("GNNAKConv", False)])
+def test_concat_block_dense_layers(dev, name, residual):
+    """the concatenating layers on the padded layout ("DD"): `_cat_apply` runs the fused concat block over the zero-filled padded
+    rows (what catvalue + tuplewiseapply feed the MLP, reference MaTensor.py:264-270, 318-330) — against the same layer with the
+    literal concatenation, valid entries of the output, input gradient, parameter gradients and running statistics, bf16."""
+    import copy
+    from pygho_amd import MaskedTensor, synth, _ops
+    from pygho_amd.honn import Conv
+    h = 128
+    dn = synth.make_dense_batch(8, seed=8, hidden=h, nmax=37)
+    torch.manual_seed(2)
+    if name == "SSWLConv":
+        layer = Conv.SSWLConv(h, h, "sum", "DD", dict(MLP)).to(dev)
+    elif name == "DSSGNNConv":
+        layer = Conv.DSSGNNConv(h, h, "sum", "sum", "mean", "DD", dict(MLP)).to(dev)
+    else:
+        layer = Conv.GNNAKConv(h, h, "sum", "mean", "DD", dict(MLP), dict(MLP)).to(dev)
+    xraw = T(dn["X"], dev).to(torch.bfloat16)
+    Amt = MaskedTensor(T(dn["A"], dev).to(torch.bfloat16), T(dn["Amask"], dev), 0.0, True)
+    xm = T(dn["Xmask"], dev)
+    w = torch.randn(xraw.shape, device=dev).to(torch.bfloat16)
+    res = {}
+    for fused in (True, False):
+        _ops.USE_CONCAT_BLOCK = fused
+        try:
+            lay = copy.deepcopy(layer)
+            x = xraw.clone().requires_grad_(True)
+            X = MaskedTensor(x, xm, 0.0, True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                if residual:
+                    out = lay.forward_residual(Amt, X, {}) if fused else X.add(lay.forward(Amt, X, {}), True)
+                else:
+                    out = lay(Amt, X, {})
+            o = out.data * xm[..., None]
+            o.backward(w)
+            res[fused] = (o.detach().float(), x.grad.float() * xm[..., None], {k: p.grad.float() for k, p in lay.named_parameters()},
+                          {k: v.clone() for k, v in lay.state_dict().items() if "running" in k})
+        finally:
+            _ops.USE_CONCAT_BLOCK = True
+    for i in (0, 1):
+        s = float(res[False][i].abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][i] / s, res[False][i] / s, rtol=0, atol=4e-2)
+    for k, ref in res[False][2].items():
+        if k.endswith(".lins.0.bias"):
+            continue
+        s = float(ref.abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][2][k] / s, ref / s, rtol=0, atol=4e-2, msg=k)
+    for k, ref in res[False][3].items():
+        torch.testing.assert_close(res[True][3][k].float(), ref.float(), rtol=2e-2, atol=2e-2, msg=k)
