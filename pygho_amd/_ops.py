@@ -2015,6 +2015,80 @@ class _ConcatBlock(torch.autograd.Function):
         return (gw, gb, (s2 if has_gamma else None), (s1 if has_beta else None), None, None, None, None, None, None, *gxs)
 
 
+class _ProxyCtx:
+    """stands in for the autograd context when a fused Function runs another Function's forward / backward as one of its steps"""
+
+    def __init__(self, needs_input_grad=()):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+USE_SSWL_BLOCK = True
+
+
+class _SSWLBlock(torch.autograd.Function):
+    """the whole SSWLConv update (reference Conv.py:98-103) as one autograd node: x1 = X A inside the subgraphs, x2 = A X across
+    them, h = act(bn([x | x1 | x2] W^T + b)) [+ x].  What one node buys over three: the gradient of X has three contributions
+    (the block's first input, the two products) and the gradient of A two; here each aggregation launch takes the running sum in
+    its epilogue instead of autograd adding (nnz, d) tensors afterwards (two read-read-write passes per layer)."""
+
+    @staticmethod
+    def forward(ctx, x, a, plan1, plan2, aggr, residual, w, b, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum):
+        x, a = x.contiguous(), a.contiguous()
+        x1 = seg_gmr(plan1.n_out, x, a, plan1.fwd.seg_ptr, plan1.c_fwd, plan1.d_fwd, aggr)
+        x2 = seg_gmr(plan2.n_out, a, x, plan2.fwd.seg_ptr, plan2.c_fwd, plan2.d_fwd, aggr)
+        sub = _ProxyCtx()
+        h, mean, var = _ConcatBlock.forward(sub, w, b, gamma, beta, running_mean, running_var, training, eps, act,
+                                            (fold_momentum, residual), x, x1, x2)
+        ctx.save_for_backward(a, *sub.saved_tensors)
+        ctx.sub = (sub.residual, sub.meta)
+        ctx.plans, ctx.aggr = (plan1, plan2), aggr
+        ctx.mark_non_differentiable(mean, var)
+        return h, mean, var
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv):
+        a = ctx.saved_tensors[0]
+        sub = _ProxyCtx((ctx.needs_input_grad[6], ctx.needs_input_grad[7]) + (False,) * 8 + (True, True, True))
+        sub.saved_tensors = ctx.saved_tensors[1:]
+        sub.residual, sub.meta = ctx.sub
+        res = _ConcatBlock.backward(sub, g, None, None)
+        gw, gb, ggamma, gbeta = res[:4]
+        g0, g1, g2 = res[10:13]
+        x = sub.saved_tensors[1]
+        plan1, plan2 = ctx.plans
+        sc1 = plan1.fwd.inv_count if ctx.aggr == "mean" else None
+        sc2 = plan2.fwd.inv_count if ctx.aggr == "mean" else None
+        gx = ga = None
+        if ctx.needs_input_grad[0]:
+            p, a_g, d_g = plan1.by_c()                      # x is the left operand of X A ...
+            gx = seg_gmr(plan1.n_lhs, g1, a, p.seg_ptr, a_g, d_g, "sum", sc1, addend=g0)
+            p, a_g, c_g = plan2.by_d()                      # ... and the right operand of A X
+            gx = seg_gmr(plan2.n_rhs, g2, a, p.seg_ptr, a_g, c_g, "sum", sc2, addend=gx)
+        if ctx.needs_input_grad[1]:
+            p, a_g, c_g = plan1.by_d()
+            ga = seg_gmr(plan1.n_rhs, g1, x, p.seg_ptr, a_g, c_g, "sum", sc1)
+            p, a_g, d_g = plan2.by_c()
+            ga = seg_gmr(plan2.n_lhs, g2, x, p.seg_ptr, a_g, d_g, "sum", sc2, addend=ga)
+        return (gx, ga, None, None, None, None, gw, gb, ggamma, gbeta) + (None,) * 6
+
+
+def sswl_block(x: Tensor, a: Tensor, plan1: "MessagePlan", plan2: "MessagePlan", aggr: str, lin: "torch.nn.Linear",
+               bn: "torch.nn.BatchNorm1d", act: str, residual: bool) -> Tensor:
+    training = bn.training or bn.running_mean is None
+    fold = _fold_momentum(bn)
+    out, mean, var = _SSWLBlock.apply(x, a, plan1, plan2, aggr, residual, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean,
+                                      bn.running_var, training, bn.eps, act, fold)
+    _update_running(bn, mean, var, x.shape[0], folded=fold is not None)
+    return out
+
+
 def concat_block_supported(xs, lin: "torch.nn.Linear") -> bool:
     d = xs[0].shape[1] if xs and xs[0].dim() == 2 else -1
     return (USE_CONCAT_BLOCK and USE_ROWBLOCK_LINEAR and USE_BN_BWD_LINEAR and len(xs) >= 2

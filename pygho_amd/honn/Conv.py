@@ -158,13 +158,41 @@ class SSWLConv(Module):
         self.aggr2 = TensorOp.OpMessagePassingCrossSubg2D(mode, aggr, optuplefeat, opadj)
         self.lin = MLP(3 * indim, outdim, **mlp)
 
+    def _fused(self, A: Rep, X: Rep, datadict: dict, residual: bool) -> Optional[Rep]:
+        """the update as one autograd node (``_ops.sswl_block``) when the layer is sparse on the device with precomputed plans,
+        sum / mean aggregation and a single Linear -> BatchNorm -> act block over equally wide operands; None otherwise."""
+        block = self.lin.single_block() if isinstance(self.lin, MLP) else None
+        ops = [getattr(op, "mod", op) for op in (self.aggr1, self.aggr2)]
+        if not (_ops.USE_SSWL_BLOCK and block is not None and isinstance(X, SparseTensor) and isinstance(A, SparseTensor)
+                and datadict is not None and all(isinstance(op, OpMessagePassing) and not op.use_mpnn for op in ops)
+                and ops[0].aggr == ops[1].aggr and ops[0].aggr in ("sum", "mean")
+                and X.values is not None and A.values is not None and X.values.is_cuda and X.values.dim() == 2
+                and A.values.dim() == 2 and A.values.shape[1] == X.values.shape[1]):
+            return None
+        acds = [datadict.get(op.precomputekey + KEYSEP + "acd") for op in ops]
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else X.values.dtype
+        if (any(acd is None for acd in acds) or X.values.dtype != dt or A.values.dtype != dt
+                or not _ops.concat_block_supported([X.values] * 3, block[0])):
+            return None
+        plan1 = _ops.message_plan(acds[0], X.nnz, X.nnz, A.nnz)       # X A inside each subgraph
+        plan2 = _ops.message_plan(acds[1], X.nnz, A.nnz, X.nnz)       # A X across subgraphs
+        with torch.autocast("cuda", enabled=False):
+            out = _ops.sswl_block(X.values, A.values, plan1, plan2, ops[0].aggr, *block, residual=residual)
+        return X.tuplewiseapply(lambda _: out)
+
     def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
+        fused = self._fused(A, X, datadict, False)
+        if fused is not None:
+            return fused
         neighbours = [op.forward(A, X, datadict, X) for op in (self.aggr1, self.aggr2)]
         return _cat_apply(X, neighbours, self.lin)
 
     def forward_residual(self, A: Rep, X: Rep, datadict: dict) -> Rep:
         """``X.add(self.forward(A, X, datadict), True)`` (the model loop of example/zinc.py:287-290) with the residual row added
         inside the block's activation pass and its gradient inside the first backward GEMM's epilogue."""
+        fused = self._fused(A, X, datadict, True)
+        if fused is not None:
+            return fused
         neighbours = [op.forward(A, X, datadict, X) for op in (self.aggr1, self.aggr2)]
         return _cat_apply(X, neighbours, self.lin, residual=True)
 

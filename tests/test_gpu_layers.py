@@ -831,36 +831,42 @@ def test_zinc_model_i2gnn_trains(dev):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
-def test_sswl_forward_residual_fused(dev):
-    """SSWLConv.forward_residual (residual row added in the concat block's activation pass, its gradient in the first backward
-    GEMM's epilogue) against X.add(conv.forward(...), True) with the fused concat block switched off: bf16, outputs and gradients."""
+@pytest.mark.parametrize("aggr", ["sum", "mean"])
+def test_sswl_forward_residual_fused(dev, aggr):
+    """SSWLConv.forward_residual (one autograd node, `_ops.sswl_block`: residual row added in the concat block's activation pass,
+    the three contributions to the gradient of X and the two to the gradient of A summed in the aggregation launches' epilogues)
+    against X.add(conv.forward(...), True) with the fused blocks switched off: bf16, outputs, input / adjacency / parameter gradients."""
     import copy
     from pygho_amd import SparseTensor, synth, _ops
     from pygho_amd.honn import Conv
     from pygho_amd.honn.SpOperator import parse_precomputekey
     h = 128
     torch.manual_seed(3)
-    layer = Conv.SSWLConv(h, h, "sum", "SS", dict(MLP)).to(dev)
+    layer = Conv.SSWLConv(h, h, aggr, "SS", dict(MLP)).to(dev)
     hb = synth.make_batch(64, "zinc", seed=22, keys=tuple(parse_precomputekey(layer)))
     dd = synth.to_datadict(hb, dev)
     X0, A0 = dd["X"], dd["A"]
     xv0 = torch.randn(X0.nnz, h, device=dev).to(torch.bfloat16)
-    A = SparseTensor(A0.indices, (torch.randn(A0.nnz, h, device=dev) * 0.5).to(torch.bfloat16), list(A0.shape[:2]) + [h], True)
+    av0 = (torch.randn(A0.nnz, h, device=dev) * 0.5).to(torch.bfloat16)
     w = torch.randn(X0.nnz, h, device=dev).to(torch.bfloat16)
     res = {}
     for fused in (True, False):
         _ops.USE_CONCAT_BLOCK = fused
         try:
             lay = copy.deepcopy(layer)
-            xv = xv0.clone().requires_grad_(True)
+            xv, av = xv0.clone().requires_grad_(True), av0.clone().requires_grad_(True)
             X = SparseTensor(X0.indices, xv, list(X0.shape[:2]) + [h], True)
+            A = SparseTensor(A0.indices, av, list(A0.shape[:2]) + [h], True)
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 out = lay.forward_residual(A, X, dd) if fused else X.add(lay.forward(A, X, dd), True)
+            if fused:
+                assert type(out.values.grad_fn).__name__ == "_SSWLBlockBackward"
             out.values.backward(w)
-            res[fused] = (out.values.detach().float(), xv.grad.float(), {k: p.grad.float() for k, p in lay.named_parameters()})
+            res[fused] = (out.values.detach().float(), xv.grad.float(), {k: p.grad.float() for k, p in lay.named_parameters()},
+                          av.grad.float())
         finally:
             _ops.USE_CONCAT_BLOCK = True
-    for i in (0, 1):
+    for i in (0, 1, 3):
         s = float(res[False][i].abs().max()) + 1e-6
         torch.testing.assert_close(res[True][i] / s, res[False][i] / s, rtol=0, atol=4e-2)
     for k, ref in res[False][2].items():
