@@ -91,6 +91,17 @@ int pygho_seg_gather_mul_reduce_add(void* out, const void* addend, const void* l
                                     const float* lhs_rowscale, int64_t n_seg, int64_t d, int64_t lhs_d, int64_t rhs_d,
                                     int64_t lhs_rows, int64_t rhs_rows, int dtype, int aggr, void* stream);
 
+/* The same two-operand sum / mean reduction (addend may be NULL) with the rows of the SMALL operand served from LDS: a
+ * workgroup copies the window [min, max] of the rhs rows its segments touch (the edge rows of the one or two graphs of a block
+ * diagonal batch, Spspmm.py:307-315 with B = the adjacency; or a whole embedding table) into LDS with one contiguous sweep and
+ * gathers only the lhs rows through the vector-memory path; a pass whose window does not fit gathers rhs from global memory.
+ * rhs_idx is required; row bytes a multiple of 16, at most 1024; f32 / bf16 / f16; every operand below 4 GiB.  Results are bit-identical to
+ * pygho_seg_gather_mul_reduce(_add): same products, same summation order. */
+int pygho_seg_gather_mul_reduce_window(void* out, const void* addend, const void* lhs, const void* rhs,
+                                       const int32_t* seg_ptr, const int32_t* lhs_idx, const int32_t* rhs_idx,
+                                       const float* lhs_rowscale, int64_t n_seg, int64_t d, int64_t lhs_rows,
+                                       int64_t rhs_rows, int dtype, int aggr, void* stream);
+
 /* The same reduction with the layer MLP's BatchNorm + activation applied to one operand AS IT IS LOADED:
  *   act_side 1:  out[s] = [addend[s] +] (+) act(lhs[li] * act_scale + act_shift) * rhs[ri]
  *   act_side 2:  out[s] = [addend[s] +] (+) lhs[li] * act(rhs[ri] * act_scale + act_shift)

@@ -10,6 +10,7 @@ from typing import Optional, Tuple
 
 from ctypes import c_void_p
 
+import os
 import torch
 from torch import Tensor
 
@@ -296,6 +297,20 @@ class LaunchTimer:
         return {k: (v[0], v[1] / v[0], v[2] / v[0]) for k, v in agg.items()}
 
 
+USE_SEG_WINDOW = os.environ.get("PYGHO_SEG_WINDOW", "1") != "0"
+SEG_WINDOW_MIN_ROW_BYTES = int(os.environ.get("PYGHO_SEG_WINDOW_MIN_ROW_BYTES", "512"))
+
+
+def _window_eligible(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], rhs_idx: Optional[Tensor], aggr: str) -> bool:
+    """two-operand sum / mean whose rhs is the small operand (edge rows, an embedding table): its rows are served from LDS
+    (`pygho_seg_gather_mul_reduce_window`).  Rows of 512 B and more: that is where the L2 -> L1 gather path binds."""
+    if not USE_SEG_WINDOW or lhs is None or rhs is None or rhs_idx is None or aggr not in ("sum", "mean"):
+        return False
+    rb = rhs.shape[1] * rhs.element_size()
+    return (rhs.dtype in (torch.float32, torch.bfloat16, torch.float16) and rb % 16 == 0 and SEG_WINDOW_MIN_ROW_BYTES <= rb <= 1024
+            and 2 * rhs.shape[0] <= out_rows and out_rows >= 4096 and max(out_rows, lhs.shape[0]) * rb < (1 << 32))
+
+
 def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr: Tensor,
             lhs_idx: Optional[Tensor], rhs_idx: Optional[Tensor], aggr: str,
             lhs_rowscale: Optional[Tensor] = None, addend: Optional[Tensor] = None,
@@ -323,6 +338,12 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
             ptr(out), ptr(addend), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale),
             ptr(a_scale.contiguous()), ptr(a_shift.contiguous()), ACT_CODE[a_name], a_side, out_rows, d, lhs.shape[0], rhs.shape[0],
             dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev)), "seg_gather_mul_reduce_act")
+    elif _window_eligible(out_rows, lhs, rhs, rhs_idx, aggr):
+        if addend is not None:
+            assert addend.shape == out.shape and addend.dtype == out.dtype and addend.is_contiguous()
+        check(lib().pygho_seg_gather_mul_reduce_window(
+            ptr(out), ptr(addend), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale), out_rows, d,
+            lhs.shape[0], rhs.shape[0], dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev)), "seg_gather_mul_reduce_window")
     elif addend is None:
         check(lib().pygho_seg_gather_mul_reduce(
             ptr(out), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale), *dims),

@@ -1,0 +1,243 @@
+// Fused gather * gather -> segment reduce with the SMALL operand's rows served from LDS.
+//
+// Same function as seg_gmr_fast_kernel (seg_reduce.hip) for two-operand sum / mean: out[s] = [addend[s] +] sum_{m in s}
+// [scale *] lhs[lhs_idx[m]] * rhs[rhs_idx[m]], products rounded and summed in message order (bit-identical results).
+// Difference: the rhs rows a workgroup's segments touch lie in a narrow index window when the batch is block diagonal (the
+// edges of one or two graphs; an embedding table's handful of rows), and each of them is gathered M / rows(rhs) times
+// (66x for the I2-shape 3-tuple plan).  The fast kernel fetches every one of those gathers through the L2 -> L1 path, which
+// is what binds it at 512-B rows.  Here a workgroup of 8 wavefronts
+//   1. stages its CSR pointers and message indices (one coalesced load each, per wavefront) and reduces min / max of its
+//      rhs indices,
+//   2. copies rows [min, max] of rhs into LDS with one contiguous, coalesced sweep (when the window fits: a uniform test,
+//      otherwise this pass gathers rhs from global memory like the fast kernel),
+//   3. walks its segments: the lhs row of a message comes from global memory, the rhs row from LDS (ds_read_b128).
+// Half of the gather traffic leaves the vector-memory path; the window copy adds rows(window) / messages(pass) of it back.
+#include "common.h"
+
+namespace pygho {
+
+constexpr int kWinBlock = 512;                   // 8 wavefronts share one window
+constexpr int kWinWaves = kWinBlock / kWave;
+constexpr int kWinSegCap = 32;                   // segments per wavefront and pass
+constexpr int kWinMsgCap = 128;                  // message indices staged per wavefront and pass
+
+template <bool OFF32>
+__device__ __forceinline__ uint4 win_load_row16(const char* __restrict__ base, int idx, uint32_t row_bytes, uint32_t col_bytes) {
+  if (OFF32) return *reinterpret_cast<const uint4*>(base + ((uint32_t)idx * row_bytes + col_bytes));
+  return *reinterpret_cast<const uint4*>(base + ((int64_t)idx * (int64_t)row_bytes + col_bytes));
+}
+
+template <typename T, bool SCALED>
+__device__ __forceinline__ void win_accumulate(float (&acc)[Vec16<T>::N], const uint4& la, const uint4& rb, float sc) {
+  using V = Vec16<T>;
+  constexpr int N = V::N;
+  float a[N], b[N];
+  V::unpack(la, a);
+  V::unpack(rb, b);
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    if (!SCALED && ExactProduct<T>::value) acc[q] = __builtin_fmaf(a[q], b[q], acc[q]);     // exact product: == mul then add
+    else {
+      float p = a[q] * b[q];
+      if (SCALED) p = sc * p;
+      acc[q] = acc[q] + p;
+    }
+  }
+}
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+
+// 80 VGPRs: three workgroups (6 wavefronts per SIMD) next to 3 x 49.3 KB of LDS; the scaled form (mean backward) needs more
+template <typename T, bool SCALED, bool MEAN>
+__global__ __launch_bounds__(kWinBlock, SCALED ? 4 : 6) void seg_gmr_window_kernel(
+    T* __restrict__ out, const T* __restrict__ lhs, const T* __restrict__ rhs, const int32_t* __restrict__ seg_ptr,
+    const int32_t* __restrict__ lhs_idx, const int32_t* __restrict__ rhs_idx, const float* __restrict__ lhs_rowscale,
+    const T* __restrict__ addend, int64_t n_seg, int d, int chunks, int log2g, int spp, int win_rows) {
+  using V = Vec16<T>;
+  constexpr int N = V::N;
+  constexpr bool OFF32 = true;          // 32-bit byte offsets: the entry point refuses operands of 4 GiB and more
+  extern __shared__ __attribute__((aligned(16))) char s_win[];            // win_rows * row_bytes
+  __shared__ int32_t s_ptr[kWinWaves][kWinSegCap + 1];
+  __shared__ int32_t s_li[kWinWaves][kWinMsgCap];
+  __shared__ int32_t s_ri[kWinWaves][kWinMsgCap];
+  __shared__ int32_t s_lo[kWinWaves], s_hi[kWinWaves];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = threadIdx.x >> 6;
+  const int gl = lane & ((1 << log2g) - 1);
+  const int grp = lane >> log2g;
+  const int gw = kWave >> log2g;
+  const bool active = gl < chunks;
+  const uint32_t row_bytes = (uint32_t)d * sizeof(T);
+  const uint32_t col_bytes = (uint32_t)(active ? gl : 0) * 16u;
+  const char* lbase = reinterpret_cast<const char*>(lhs);
+  const char* rbase = reinterpret_cast<const char*>(rhs);
+  char* obase = reinterpret_cast<char*>(out);
+  const bool has_li = lhs_idx != nullptr;
+  // XCD-aware sweep, as in the fast kernel: the workgroups of one XCD cover a contiguous stretch of segments per sweep step
+  int64_t lb = blockIdx.x;
+  if ((gridDim.x & 7) == 0) lb = (lb & 7) * (gridDim.x >> 3) + (lb >> 3);
+  const int64_t per_wg = (int64_t)kWinWaves * spp;
+
+  for (int64_t wg_base = lb * per_wg; wg_base < n_seg; wg_base += (int64_t)gridDim.x * per_wg) {       // uniform per workgroup
+    const int64_t base = wg_base + (int64_t)wv * spp;
+    // ---- stage pointers and indices; min / max of this wavefront's rhs rows -----------------------------------------
+    const int pv = seg_ptr[min(base + min(lane, spp), n_seg)];
+    const int pend = seg_ptr[min(base + spp, n_seg)];
+    s_ptr[wv][min(lane, kWinSegCap)] = pv;                 // spp <= kWinSegCap: lanes beyond it rewrite the last slot with ...
+    if (lane == 0) s_ptr[wv][spp] = pend;                  // ... a value lane 0 then fixes (same wave: program order)
+    const int mbeg = __builtin_amdgcn_readfirstlane(pv);
+    const int nmsg = __builtin_amdgcn_readfirstlane(pend) - mbeg;
+    const bool staged = nmsg <= kWinMsgCap;                // wave-uniform
+    int lo = 0x7fffffff, hi = -1;
+    for (int j = lane; j < nmsg; j += kWave) {
+      const int r = rhs_idx[mbeg + j];
+      lo = min(lo, r);
+      hi = max(hi, r);
+      if (staged) {
+        s_ri[wv][j] = r;
+        if (has_li) s_li[wv][j] = lhs_idx[mbeg + j];
+      }
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if (lane == 0) { s_lo[wv] = lo; s_hi[wv] = hi; }
+    __syncthreads();
+    const int rmin = wave_min(s_lo[lane & (kWinWaves - 1)]);
+    const int rmax = wave_max(s_hi[lane & (kWinWaves - 1)]);
+    const bool use_win = rmax >= rmin && (rmax - rmin) < win_rows;       // uniform over the workgroup
+    if (use_win) {                                                      // rows [rmin, rmax] are one contiguous byte range
+      const uint32_t n16 = (uint32_t)(rmax - rmin + 1) * (uint32_t)chunks;
+      const uint4* src = reinterpret_cast<const uint4*>(rbase + (int64_t)rmin * (int64_t)row_bytes);
+      uint4* dst = reinterpret_cast<uint4*>(s_win);
+      for (uint32_t u = threadIdx.x; u < n16; u += kWinBlock) dst[u] = src[u];
+    }
+    __syncthreads();
+    // ---- reduce: lane group `grp` takes segments grp, grp + gw, ... of this wavefront's pass ---------------------------
+    const int nloc = (int)max((int64_t)0, min((int64_t)spp, n_seg - base));
+    for (int i = grp; i < nloc; i += gw) {
+      const int beg = s_ptr[wv][i], end = s_ptr[wv][i + 1];
+      float acc[N];
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] = 0.f;
+      uint4 res;
+      if (addend) res = win_load_row16<OFF32>(reinterpret_cast<const char*>(addend), (int)(base + i), row_bytes, col_bytes);
+      for (int m0 = beg; m0 < end; m0 += 2) {
+        const bool two = m0 + 1 < end;
+        const int m1 = two ? m0 + 1 : m0;
+        int l0 = m0, l1 = m1, r0, r1;
+        if (staged) {
+          r0 = s_ri[wv][m0 - mbeg]; r1 = s_ri[wv][m1 - mbeg];
+          if (has_li) { l0 = s_li[wv][m0 - mbeg]; l1 = s_li[wv][m1 - mbeg]; }
+        } else {
+          r0 = rhs_idx[m0]; r1 = rhs_idx[m1];
+          if (has_li) { l0 = lhs_idx[m0]; l1 = lhs_idx[m1]; }
+        }
+        const uint4 la0 = win_load_row16<OFF32>(lbase, l0, row_bytes, col_bytes);
+        const uint4 la1 = win_load_row16<OFF32>(lbase, l1, row_bytes, col_bytes);
+        uint4 rb0, rb1;
+        if (use_win) {
+          rb0 = *reinterpret_cast<const uint4*>(s_win + ((uint32_t)(r0 - rmin) * row_bytes + col_bytes));
+          rb1 = *reinterpret_cast<const uint4*>(s_win + ((uint32_t)(r1 - rmin) * row_bytes + col_bytes));
+        } else {
+          rb0 = win_load_row16<OFF32>(rbase, r0, row_bytes, col_bytes);
+          rb1 = win_load_row16<OFF32>(rbase, r1, row_bytes, col_bytes);
+        }
+        float sc0 = 1.f, sc1 = 1.f;
+        if (SCALED) { sc0 = lhs_rowscale[l0]; sc1 = lhs_rowscale[l1]; }
+        win_accumulate<T, SCALED>(acc, la0, rb0, sc0);
+        if (two) win_accumulate<T, SCALED>(acc, la1, rb1, sc1);
+      }
+      const int cnt = end - beg;
+      if (MEAN) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) acc[q] = cnt > 0 ? mean_div(acc[q], cnt) : 0.f;
+      }
+      if (addend) {
+        float rv[N];
+        V::unpack(res, rv);
+#pragma unroll
+        for (int q = 0; q < N; ++q) acc[q] = rv[q] + acc[q];
+      }
+      if (active) {
+        if (OFF32) *reinterpret_cast<uint4*>(obase + ((uint32_t)(base + i) * row_bytes + col_bytes)) = V::pack(acc);
+        else *reinterpret_cast<uint4*>(obase + ((int64_t)(base + i) * (int64_t)row_bytes + col_bytes)) = V::pack(acc);
+      }
+    }
+    __syncthreads();                                       // the window and the staging arrays are rewritten by the next pass
+  }
+}
+
+constexpr int kWinLdsBytes = 40 * 1024;                    // window; + 9.3 KB of staging: three workgroups (24 wavefronts) per CU
+
+template <typename T>
+int launch_window(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx, const int32_t* rhs_idx,
+                  const float* scale, const void* addend, int64_t n_seg, int64_t d, int aggr, hipStream_t st) {
+  const int chunks = (int)(d * sizeof(T) / 16);
+  int log2g = 0;
+  while ((1 << log2g) < chunks) ++log2g;
+  const int gw = kWave >> log2g;
+  int64_t spp = 16 * gw;                                   // segments per wavefront and pass (capped below): the window copy and the three
+                                                           // barriers of a pass are amortised over its messages (measured at the I2 shape,
+                                                           // d = 256 bf16: 2 / 4 / 8 / 16 per lane group -> 1.13 / 0.96 / 0.87 / 0.85 ms)
+  const int64_t even = ceil_div(ceil_div(n_seg, (int64_t)768 * kWinWaves), gw) * gw;
+  if (even < spp) spp = even;
+  if (spp < gw) spp = gw;
+  if (spp > kWinSegCap) spp = kWinSegCap;
+  const int win_rows = (int)(kWinLdsBytes / (d * (int64_t)sizeof(T)));
+  int gx = grid_for(n_seg, (int)(kWinWaves * spp), 768);  // 3 resident workgroups per CU
+  if (gx > 8) gx = (gx + 7) & ~7;
+  const bool mean = aggr == PYGHO_MEAN;
+#define PYGHO_WIN(SC, MEAN)                                                                                                     \
+  do {                                                                                                                         \
+    static bool attr_set = false;                                                                                              \
+    if (!attr_set) {                                                                                                           \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_gmr_window_kernel<T, SC, MEAN>),             \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kWinLdsBytes);                            \
+      if (e != hipSuccess) { set_error("seg_gather_mul_reduce_window: cannot reserve LDS: %s", hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; } \
+      attr_set = true;                                                                                                         \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((seg_gmr_window_kernel<T, SC, MEAN>), dim3(gx), dim3(kWinBlock), kWinLdsBytes, st, (T*)out,       \
+                       (const T*)lhs, (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, (const T*)addend, n_seg, (int)d, chunks, \
+                       log2g, (int)spp, win_rows);                                                                             \
+  } while (0)
+  if (scale) { if (mean) PYGHO_WIN(true, true); else PYGHO_WIN(true, false); }
+  else       { if (mean) PYGHO_WIN(false, true); else PYGHO_WIN(false, false); }
+#undef PYGHO_WIN
+  return check_launch("seg_gather_mul_reduce_window");
+}
+
+}  // namespace pygho
+
+using namespace pygho;
+
+extern "C" int pygho_seg_gather_mul_reduce_window(void* out, const void* addend, const void* lhs, const void* rhs,
+                                                  const int32_t* seg_ptr, const int32_t* lhs_idx, const int32_t* rhs_idx,
+                                                  const float* lhs_rowscale, int64_t n_seg, int64_t d, int64_t lhs_rows,
+                                                  int64_t rhs_rows, int dtype, int aggr, void* stream) {
+  if (n_seg < 0 || d <= 0 || lhs_rows <= 0 || rhs_rows <= 0) { set_error("seg_gather_mul_reduce_window: bad size"); return PYGHO_ERR_INVALID; }
+  if (n_seg == 0) return PYGHO_OK;
+  if (!out || !lhs || !rhs || !seg_ptr || !rhs_idx) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (aggr != PYGHO_SUM && aggr != PYGHO_MEAN) { set_error("seg_gather_mul_reduce_window: sum / mean only"); return PYGHO_ERR_UNSUPPORTED; }
+  const int64_t es = dtype == PYGHO_F32 ? 4 : ((dtype == PYGHO_BF16 || dtype == PYGHO_F16) ? 2 : 0);
+  if (es == 0) { set_error("seg_gather_mul_reduce_window: f32 / bf16 / f16 only"); return PYGHO_ERR_UNSUPPORTED; }
+  const int64_t rb = d * es;
+  if (rb % 16 != 0 || rb > 1024) { set_error("seg_gather_mul_reduce_window: row bytes %lld (a multiple of 16, <= 1024)", (long long)rb); return PYGHO_ERR_UNSUPPORTED; }
+  if ((((uintptr_t)out | (uintptr_t)lhs | (uintptr_t)rhs | (uintptr_t)addend) % 16) != 0) { set_error("seg_gather_mul_reduce_window: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
+  const int64_t lim = (int64_t)1 << 32;
+  if (n_seg * rb >= lim || lhs_rows * rb >= lim || rhs_rows * rb >= lim) { set_error("seg_gather_mul_reduce_window: operands of 4 GiB and more are not supported"); return PYGHO_ERR_UNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+#define PYGHO_WIN_T(T) launch_window<T>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, addend, n_seg, d, aggr, st)
+  if (dtype == PYGHO_F32) return PYGHO_WIN_T(float);
+  if (dtype == PYGHO_BF16) return PYGHO_WIN_T(bf16);
+  return PYGHO_WIN_T(f16);
+#undef PYGHO_WIN_T
+}

@@ -636,3 +636,48 @@ def test_deferred_index_range_check(dev):
     _ops.check_deferred_errors()                                   # ... reported once, when the block ended
     with pytest.raises(ValueError, match="out of range"):
         _ops.plan_from_keys(bad, 4, assume_sorted=False)           # outside a block: at the call
+
+
+@pytest.mark.parametrize("dtype,d", [(torch.bfloat16, 256), (torch.float16, 256), (torch.float32, 128), (torch.float32, 256),
+                                     (torch.bfloat16, 128)])
+@pytest.mark.parametrize("aggr", ["sum", "mean"])
+def test_window_kernel_bit_identical(dev, dtype, d, aggr):
+    """`pygho_seg_gather_mul_reduce_window` (rhs rows served from an LDS window) against the gather-everything kernel: same
+    products and summation order, so forward, residual form and both gradients are bit-identical — on the I2-shape plan (window =
+    the edge rows of one or two graphs), on a plan whose rhs indices are spread over all rows (every pass falls back to global
+    gathers) and against the oracle in f32."""
+    from pygho_amd import _ops, synth
+    hb = synth.replicate(synth.make_batch(32, "i2", seed=9), 4)
+    acd_np = hb.acd["X___X___2___A___0"]
+    nt, ne = hb.num_tuples, hb.num_edges
+    assert nt >= 4096 and 2 * ne <= nt
+    torch.manual_seed(0)
+    xv = torch.randn(nt, d, device=dev).to(dtype)
+    av = torch.randn(ne, d, device=dev).to(dtype)
+    res = torch.randn(nt, d, device=dev).to(dtype)
+    g = torch.randn(nt, d, device=dev).to(dtype)
+    rng = np.random.default_rng(3)
+    spread = acd_np.copy()
+    spread[2] = rng.integers(0, ne, size=spread.shape[1])               # no locality: the window never fits
+    saved = (_ops.USE_SEG_WINDOW, _ops.SEG_WINDOW_MIN_ROW_BYTES)
+    out = {}
+    try:
+        _ops.SEG_WINDOW_MIN_ROW_BYTES = 256
+        for name, plan_np in (("i2", acd_np), ("spread", spread)):
+            for win in (True, False):
+                _ops.USE_SEG_WINDOW = win
+                acd = T(plan_np, dev)                                   # a new tensor per run: plans are cached on it
+                plan = _ops.message_plan(acd, nt, nt, ne)
+                x, a = xv.clone().requires_grad_(True), av.clone().requires_grad_(True)
+                y = _ops.message_reduce(x, a, acd, nt, nt, ne, aggr)
+                y.backward(g)
+                y_res = _ops.seg_gmr(nt, xv, av, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, aggr, addend=res)
+                out[(name, win)] = (y.detach(), x.grad, a.grad, y_res)
+    finally:
+        _ops.USE_SEG_WINDOW, _ops.SEG_WINDOW_MIN_ROW_BYTES = saved
+    for name in ("i2", "spread"):
+        for got, want in zip(out[(name, True)], out[(name, False)]):
+            assert torch.equal(got, want), name
+    if dtype == torch.float32:
+        want = O.spspmm_values(N(xv), N(av), acd_np, nt, aggr)
+        assert np.array_equal(N(out[("i2", True)][0]), want)

@@ -293,9 +293,13 @@ def mamamm_case(b, n, d, dtype, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--i2-only", action="store_true", help="only the I2-shape spspmm case (profiling runs)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     out = []
+    if args.i2_only:
+        print(json.dumps(spspmm_case("i2", 256 if args.quick else 2048, 256, torch.bfloat16, dev)))
+        return
     out.append(spspmm_case("zinc", 1024 if args.quick else 8192, 128, torch.bfloat16, dev))
     out.append(spspmm_case("zinc", 1024 if args.quick else 8192, 128, torch.float32, dev))
     out.append(spspmm_case("zinc", 128, 128, torch.bfloat16, dev))
