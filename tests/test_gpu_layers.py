@@ -951,3 +951,51 @@ def test_concat_block_dense_layers(dev, name, residual):
         torch.testing.assert_close(res[True][2][k] / s, ref / s, rtol=0, atol=4e-2, msg=k)
     for k, ref in res[False][3].items():
         torch.testing.assert_close(res[True][3][k].float(), ref.float(), rtol=2e-2, atol=2e-2, msg=k)
+
+
+@pytest.mark.parametrize("layout", ["sparse", "dense"])
+def test_sswl_fused_update_in_eval_mode_without_grad(dev, layout):
+    """inference (BatchNorm in eval mode, torch.no_grad) through the fused SSWL update — one autograd node on the sparse layout,
+    the concat block over the padded rows on the dense one — equals the literal concatenation path, and leaves the running
+    statistics untouched."""
+    import copy
+    from pygho_amd import MaskedTensor, SparseTensor, synth, _ops
+    from pygho_amd.honn import Conv
+    from pygho_amd.honn.SpOperator import parse_precomputekey
+    h = 128
+    torch.manual_seed(4)
+    layer = Conv.SSWLConv(h, h, "sum", "SS" if layout == "sparse" else "DD", dict(MLP)).to(dev)
+    with torch.no_grad():
+        for m in layer.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 2.0)
+    layer.eval()
+    if layout == "sparse":
+        hb = synth.make_batch(64, "zinc", seed=23, keys=tuple(parse_precomputekey(layer)))
+        dd = synth.to_datadict(hb, dev)
+        X0, A0 = dd["X"], dd["A"]
+        X = SparseTensor(X0.indices, torch.randn(X0.nnz, h, device=dev).to(torch.bfloat16), list(X0.shape[:2]) + [h], True)
+        A = SparseTensor(A0.indices, (torch.randn(A0.nnz, h, device=dev) * 0.5).to(torch.bfloat16), list(A0.shape[:2]) + [h], True)
+        valid = None
+    else:
+        dn = synth.make_dense_batch(8, seed=8, hidden=h, nmax=37)
+        dd = {}
+        X = MaskedTensor(T(dn["X"], dev).to(torch.bfloat16), T(dn["Xmask"], dev), 0.0, True)
+        A = MaskedTensor(T(dn["A"], dev).to(torch.bfloat16), T(dn["Amask"], dev), 0.0, True)
+        valid = T(dn["Xmask"], dev)[..., None]
+    stats = {k: v.clone() for k, v in layer.state_dict().items() if "running" in k}
+    res = {}
+    for fused in (True, False):
+        _ops.USE_CONCAT_BLOCK = fused
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                out = layer.forward_residual(A, X, dd) if fused else X.add(layer.forward(A, X, dd), True)
+            res[fused] = (out.values if layout == "sparse" else out.data * valid).float()
+        finally:
+            _ops.USE_CONCAT_BLOCK = True
+    s = float(res[False].abs().max()) + 1e-6
+    torch.testing.assert_close(res[True] / s, res[False] / s, rtol=0, atol=2e-2)
+    for k, v in layer.state_dict().items():
+        if "running" in k:
+            assert torch.equal(v, stats[k]), k
