@@ -20,6 +20,10 @@ constexpr int kWinBlock = 512;                   // 8 wavefronts share one windo
 constexpr int kWinWaves = kWinBlock / kWave;
 constexpr int kWinSegCap = 32;                   // segments per wavefront and pass
 constexpr int kWinMsgCap = 128;                  // message indices staged per wavefront and pass
+#ifndef PYGHO_WIN_TRIP
+#define PYGHO_WIN_TRIP 2
+#endif
+constexpr int kWinTrip = PYGHO_WIN_TRIP;         // messages of a segment in flight per trip
 
 template <bool OFF32>
 __device__ __forceinline__ uint4 win_load_row16(const char* __restrict__ base, int idx, uint32_t row_bytes, uint32_t col_bytes) {
@@ -58,7 +62,7 @@ __device__ __forceinline__ int wave_max(int v) {
 
 // 80 VGPRs: three workgroups (6 wavefronts per SIMD) next to 3 x 49.3 KB of LDS; the scaled form (mean backward) needs more
 template <typename T, bool SCALED, bool MEAN>
-__global__ __launch_bounds__(kWinBlock, SCALED ? 4 : 6) void seg_gmr_window_kernel(
+__global__ __launch_bounds__(kWinBlock, (SCALED || kWinTrip > 2) ? 4 : 6) void seg_gmr_window_kernel(
     T* __restrict__ out, const T* __restrict__ lhs, const T* __restrict__ rhs, const int32_t* __restrict__ seg_ptr,
     const int32_t* __restrict__ lhs_idx, const int32_t* __restrict__ rhs_idx, const float* __restrict__ lhs_rowscale,
     const T* __restrict__ addend, int64_t n_seg, int d, int chunks, int log2g, int spp, int win_rows) {
@@ -130,31 +134,33 @@ __global__ __launch_bounds__(kWinBlock, SCALED ? 4 : 6) void seg_gmr_window_kern
       for (int q = 0; q < N; ++q) acc[q] = 0.f;
       uint4 res;
       if (addend) res = win_load_row16<OFF32>(reinterpret_cast<const char*>(addend), (int)(base + i), row_bytes, col_bytes);
-      for (int m0 = beg; m0 < end; m0 += 2) {
-        const bool two = m0 + 1 < end;
-        const int m1 = two ? m0 + 1 : m0;
-        int l0 = m0, l1 = m1, r0, r1;
-        if (staged) {
-          r0 = s_ri[wv][m0 - mbeg]; r1 = s_ri[wv][m1 - mbeg];
-          if (has_li) { l0 = s_li[wv][m0 - mbeg]; l1 = s_li[wv][m1 - mbeg]; }
-        } else {
-          r0 = rhs_idx[m0]; r1 = rhs_idx[m1];
-          if (has_li) { l0 = lhs_idx[m0]; l1 = lhs_idx[m1]; }
+      for (int m0 = beg; m0 < end; m0 += kWinTrip) {
+        // kWinTrip messages per trip: the lhs rows go out together, the rhs rows are read from LDS as each product is formed
+        int li[kWinTrip], ri[kWinTrip];
+#pragma unroll
+        for (int k = 0; k < kWinTrip; ++k) {
+          const int m = min(m0 + k, end - 1);
+          if (staged) {
+            ri[k] = s_ri[wv][m - mbeg];
+            li[k] = has_li ? s_li[wv][m - mbeg] : m;
+          } else {
+            ri[k] = rhs_idx[m];
+            li[k] = has_li ? lhs_idx[m] : m;
+          }
         }
-        const uint4 la0 = win_load_row16<OFF32>(lbase, l0, row_bytes, col_bytes);
-        const uint4 la1 = win_load_row16<OFF32>(lbase, l1, row_bytes, col_bytes);
-        uint4 rb0, rb1;
-        if (use_win) {
-          rb0 = *reinterpret_cast<const uint4*>(s_win + ((uint32_t)(r0 - rmin) * row_bytes + col_bytes));
-          rb1 = *reinterpret_cast<const uint4*>(s_win + ((uint32_t)(r1 - rmin) * row_bytes + col_bytes));
-        } else {
-          rb0 = win_load_row16<OFF32>(rbase, r0, row_bytes, col_bytes);
-          rb1 = win_load_row16<OFF32>(rbase, r1, row_bytes, col_bytes);
+        uint4 la[kWinTrip];
+#pragma unroll
+        for (int k = 0; k < kWinTrip; ++k) la[k] = win_load_row16<OFF32>(lbase, li[k], row_bytes, col_bytes);
+        float sc[kWinTrip];
+#pragma unroll
+        for (int k = 0; k < kWinTrip; ++k) sc[k] = SCALED ? lhs_rowscale[li[k]] : 1.f;
+#pragma unroll
+        for (int k = 0; k < kWinTrip; ++k) {
+          uint4 rb;
+          if (use_win) rb = *reinterpret_cast<const uint4*>(s_win + ((uint32_t)(ri[k] - rmin) * row_bytes + col_bytes));
+          else rb = win_load_row16<OFF32>(rbase, ri[k], row_bytes, col_bytes);
+          if (k == 0 || m0 + k < end) win_accumulate<T, SCALED>(acc, la[k], rb, sc[k]);
         }
-        float sc0 = 1.f, sc1 = 1.f;
-        if (SCALED) { sc0 = lhs_rowscale[l0]; sc1 = lhs_rowscale[l1]; }
-        win_accumulate<T, SCALED>(acc, la0, rb0, sc0);
-        if (two) win_accumulate<T, SCALED>(acc, la1, rb1, sc1);
       }
       const int cnt = end - beg;
       if (MEAN) {
