@@ -1682,10 +1682,13 @@ class _BNAct(torch.autograd.Function):
         ctx.save_for_backward(x, *saved)
         ctx.meta = (training, act, weight is not None, bias is not None)
         ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)            # no zero tensors for the statistics' (never used) gradients
         return y, mean, var
 
     @staticmethod
     def backward(ctx, gy, _gm, _gv):
+        if gy is None:
+            return (None,) * len(ctx.needs_input_grad)
         x, *saved = ctx.saved_tensors
         training, act, has_w, has_b = ctx.meta
         dx, s1, s2, _ = _bn_backward(x, gy.contiguous(), saved, training, act)
@@ -1916,10 +1919,13 @@ class _TupleBlock(torch.autograd.Function):
         ctx.meta = (training, act, None if b is None else b.dtype, gamma is not None, beta is not None, plan, aggr, residual, w.dtype,
                     skinny)
         ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)            # no zero tensors for the statistics' (never used) gradients
         return out, mean, var
 
     @staticmethod
     def backward(ctx, g, _gm, _gv):
+        if g is None:
+            return (None,) * len(ctx.needs_input_grad)
         x, w, pre, h, rhs, *saved = ctx.saved_tensors
         training, act, b_dtype, has_gamma, has_beta, plan, aggr, residual, w_dtype, skinny = ctx.meta
         g = g.contiguous()
@@ -2011,10 +2017,13 @@ class _ConcatBlock(torch.autograd.Function):
         ctx.residual = residual
         ctx.meta = (len(xs), training, act, None if b is None else b.dtype, gamma is not None, beta is not None, w.dtype)
         ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)            # no zero tensors for the statistics' (never used) gradients
         return h, mean, var
 
     @staticmethod
     def backward(ctx, g, _gm, _gv):
+        if g is None:
+            return (None,) * len(ctx.needs_input_grad)
         k_in, training, act, b_dtype, has_gamma, has_beta, w_dtype = ctx.meta
         pre = ctx.saved_tensors[0]
         xs = ctx.saved_tensors[1:1 + k_in]
@@ -2049,6 +2058,9 @@ class _ProxyCtx:
     def mark_non_differentiable(self, *tensors):
         pass
 
+    def set_materialize_grads(self, value):
+        pass
+
 
 USE_SSWL_BLOCK = True
 
@@ -2071,10 +2083,13 @@ class _SSWLBlock(torch.autograd.Function):
         ctx.sub = (sub.residual, sub.meta)
         ctx.plans, ctx.aggr = (plan1, plan2), aggr
         ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)            # no zero tensors for the statistics' (never used) gradients
         return h, mean, var
 
     @staticmethod
     def backward(ctx, g, _gm, _gv):
+        if g is None:
+            return (None,) * len(ctx.needs_input_grad)
         a = ctx.saved_tensors[0]
         sub = _ProxyCtx((ctx.needs_input_grad[6], ctx.needs_input_grad[7]) + (False,) * 8 + (True, True, True))
         sub.saved_tensors = ctx.saved_tensors[1:]
