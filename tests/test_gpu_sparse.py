@@ -681,3 +681,41 @@ def test_window_kernel_bit_identical(dev, dtype, d, aggr):
     if dtype == torch.float32:
         want = O.spspmm_values(N(xv), N(av), acd_np, nt, aggr)
         assert np.array_equal(N(out[("i2", True)][0]), want)
+
+
+def test_window_kernel_long_and_empty_segments(dev):
+    """the LDS-window kernel on a plan with empty segments and segments far longer than the staged index capacity (indices then
+    come from global memory), a 64-row rhs (an embedding table: the window is the whole operand), scaled lhs rows and a residual
+    addend — bit-identical to the gather-everything kernel."""
+    from pygho_amd import _ops
+    rng = np.random.default_rng(5)
+    n_seg, n_lhs, n_rhs, d = 6000, 10_000, 64, 256
+    lens = rng.integers(0, 400, size=n_seg)
+    lens[rng.random(n_seg) < 0.2] = 0
+    lens[17] = 5000
+    ptr = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    m = int(ptr[-1])
+    li = T(rng.integers(0, n_lhs, size=m).astype(np.int32), dev)
+    ri = T(rng.integers(0, n_rhs, size=m).astype(np.int32), dev)
+    seg_ptr = T(ptr, dev)
+    torch.manual_seed(1)
+    lhs = torch.randn(n_lhs, d, device=dev).to(torch.bfloat16)
+    rhs = torch.randn(n_rhs, d, device=dev).to(torch.bfloat16)
+    add = torch.randn(n_seg, d, device=dev).to(torch.bfloat16)
+    scale = torch.rand(n_lhs, device=dev)
+    saved = _ops.USE_SEG_WINDOW
+    out = {}
+    try:
+        for win in (True, False):
+            _ops.USE_SEG_WINDOW = win
+            out[win] = (_ops.seg_gmr(n_seg, lhs, rhs, seg_ptr, li, ri, "sum"),
+                        _ops.seg_gmr(n_seg, lhs, rhs, seg_ptr, li, ri, "mean", addend=add),
+                        _ops.seg_gmr(n_seg, lhs, rhs, seg_ptr, li, ri, "sum", scale, addend=add))
+    finally:
+        _ops.USE_SEG_WINDOW = saved
+    assert _ops._window_eligible(n_seg, lhs, rhs, ri, "sum")
+    for got, want in zip(out[True], out[False]):
+        assert torch.equal(got, want)
+    ref = torch.zeros(n_seg, d, device=dev).index_add_(0, torch.repeat_interleave(torch.arange(n_seg, device=dev), T(lens, dev)),
+                                                          lhs.float()[li.long()] * rhs.float()[ri.long()])
+    torch.testing.assert_close(out[True][0].float(), ref, rtol=2e-2, atol=2e-1)
