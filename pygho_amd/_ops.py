@@ -2002,6 +2002,9 @@ class _ConcatBlock(torch.autograd.Function):
             fold_momentum, residual = fold_momentum
         require_device(w, *xs)
         xs = [x.contiguous() for x in xs]
+        res_row = None
+        if residual == "last":                 # the residual operand is a tensor of its own, passed after the block's inputs
+            res_row, xs = xs[-1], xs[:-1]
         d = xs[0].shape[1]
         dt = xs[0].dtype
         wc = w if w.dtype == dt else w.to(dt)
@@ -2012,7 +2015,8 @@ class _ConcatBlock(torch.autograd.Function):
             last = k == len(xs) - 1
             pre, partial = rowblock_linear(x, wk, bc if k == 0 else None, addend=pre, stats_shift=True if (last and training) else None)
         h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum,
-                                          partial if training else None, apply=True, addend=xs[0] if residual else None)
+                                          partial if training else None, apply=True,
+                                          addend=res_row if res_row is not None else (xs[0] if residual else None))
         ctx.save_for_backward(pre, *xs, *blocks, *saved)
         ctx.residual = residual
         ctx.meta = (len(xs), training, act, None if b is None else b.dtype, gamma is not None, beta is not None, w.dtype)
@@ -2034,7 +2038,7 @@ class _ConcatBlock(torch.autograd.Function):
         want_cs = b_dtype is not None and ctx.needs_input_grad[1]
         gxs, gws, gb = [], [], None
         for k in range(k_in):
-            gx, gw32, _s1, _s2, sdx = bn_bwd_linear(pre, g, saved, training, act, blocks[k], g if (ctx.residual and k == 0) else None,
+            gx, gw32, _s1, _s2, sdx = bn_bwd_linear(pre, g, saved, training, act, blocks[k], g if (ctx.residual is True and k == 0) else None,
                                                     want_cs and k == 0, x=xs[k], sums=sums)
             gxs.append(gx if ctx.needs_input_grad[10 + k] else None)
             gws.append(gw32)
@@ -2042,6 +2046,8 @@ class _ConcatBlock(torch.autograd.Function):
                 gb = sdx.to(b_dtype)
         gw = torch.cat(gws, dim=1).to(w_dtype) if ctx.needs_input_grad[0] else None
         s1, s2 = sums
+        if ctx.residual == "last":             # the separate residual operand receives the output gradient as it is
+            gxs.append(g if ctx.needs_input_grad[10 + k_in] else None)
         return (gw, gb, (s2 if has_gamma else None), (s1 if has_beta else None), None, None, None, None, None, None, *gxs)
 
 
@@ -2133,11 +2139,17 @@ def concat_block_supported(xs, lin: "torch.nn.Linear") -> bool:
             and bn_act_supported_shape(xs[0].shape[0], d, xs[0].dtype))
 
 
-def concat_block(xs, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", act: str, residual: bool = False) -> Tensor:
-    """fused Linear -> BatchNorm1d -> act applied to concat(xs, dim=1), the concatenation never formed; `residual`: + xs[0]."""
+def concat_block(xs, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", act: str, residual=False) -> Tensor:
+    """fused Linear -> BatchNorm1d -> act applied to concat(xs, dim=1), the concatenation never formed; `residual`: True adds
+    xs[0] to the result, a tensor (same shape and dtype as the result) adds that tensor — both inside the activation pass."""
     training = bn.training or bn.running_mean is None
     fold = _fold_momentum(bn)
+    if isinstance(residual, Tensor):
+        assert residual.shape == xs[0].shape and residual.dtype == xs[0].dtype
+        mode, extra = (fold, "last"), (residual,)
+    else:
+        mode, extra = ((fold, True) if residual else fold), ()
     out, mean, var = _ConcatBlock.apply(lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                                        bn.eps, act, (fold, True) if residual else fold, *xs)
+                                        bn.eps, act, mode, *xs, *extra)
     _update_running(bn, mean, var, xs[0].shape[0], folded=fold is not None)
     return out

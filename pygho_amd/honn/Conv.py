@@ -99,33 +99,44 @@ def _residual_update(layer, A: Rep, X: Rep, datadict: dict) -> Rep:
     return X.tuplewiseapply(lambda _: vals)
 
 
-def _cat_apply(first: Rep, others, mlp, residual: bool = False) -> Rep:
+def _cat_apply(first: Rep, others, mlp, residual=False) -> Rep:
     """``first.catvalue(others, True).tuplewiseapply(mlp)`` (reference Conv.py:98-103, 190-196).  Sparse representations on
     the device whose MLP is one Linear -> BatchNorm -> act block over equally wide inputs skip the concatenation
-    (``_ops.concat_block``: chained streaming GEMMs, one backward pass per input)."""
+    (``_ops.concat_block``: chained streaming GEMMs, one backward pass per input).  `residual`: True = the result + `first`,
+    a representation R of the same pattern = R + the result (``R.add(.., True)``, the model loop's residual connection)."""
     block = mlp.single_block() if isinstance(mlp, MLP) else None
     reps = [first] + list(others)
+    res_rep = residual if isinstance(residual, (SparseTensor, MaskedTensor)) else None
     if (block is not None and all(isinstance(r, SparseTensor) and r.values is not None for r in reps)
             and all(r.indices is first.indices or r.nnz == first.nnz for r in reps)):
         vals = [r.values for r in reps]
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else vals[0].dtype
         vals = [v if v.dtype == dt else v.to(dt) for v in vals]
-        if _ops.concat_block_supported(vals, block[0]):
+        res_ok = res_rep is None or (isinstance(res_rep, SparseTensor) and res_rep.values is not None and res_rep.nnz == first.nnz
+                                     and res_rep.values.shape == vals[0].shape)
+        if res_ok and _ops.concat_block_supported(vals, block[0]):
+            res_arg = residual if res_rep is None else (res_rep.values if res_rep.values.dtype == dt else res_rep.values.to(dt))
             with torch.autocast("cuda", enabled=False):
-                out = _ops.concat_block(vals, *block, residual=residual)     # residual: + first, inside the activation pass
-            return first.tuplewiseapply(lambda _: out)
-    if block is not None and all(isinstance(r, MaskedTensor) for r in reps) and first.data.is_cuda:
+                out = _ops.concat_block(vals, *block, residual=res_arg)      # residual: added inside the activation pass
+            return (first if res_rep is None else res_rep).tuplewiseapply(lambda _: out)
+    if block is not None and all(isinstance(r, MaskedTensor) for r in reps) and first.raw.is_cuda:
         # dense layout: the same block over the padded rows (catvalue + tuplewiseapply zero-fill the concatenation under
         # first's mask, reference MaTensor.py:264-270, 318-330; here each part is filled, parts a product already filled are not copied)
         parts = [(r if r.mask is first.mask else MaskedTensor(r.data, first.mask)).fill_masked(0.) for r in reps]
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else parts[0].dtype
         d = parts[0].shape[-1]
         vals = [(v if v.dtype == dt else v.to(dt)).reshape(-1, d) for v in parts]
-        if all(v.shape == vals[0].shape for v in vals) and _ops.concat_block_supported(vals, block[0]):
+        res_ok = res_rep is None or (isinstance(res_rep, MaskedTensor) and res_rep.raw.shape == parts[0].shape)
+        if res_ok and all(v.shape == vals[0].shape for v in vals) and _ops.concat_block_supported(vals, block[0]):
+            res_arg = residual
+            if res_rep is not None:            # R.add(out, True) adds the raw data (MaTensor.py:251-262): masked entries stay don't-care
+                res_arg = (res_rep.raw if res_rep.raw.dtype == dt else res_rep.raw.to(dt)).reshape(-1, d)
             with torch.autocast("cuda", enabled=False):
-                out = _ops.concat_block(vals, *block, residual=residual)
-            return MaskedTensor(out.view(tuple(parts[0].shape[:-1]) + (out.shape[-1],)), first.mask)
+                out = _ops.concat_block(vals, *block, residual=res_arg)
+            return MaskedTensor(out.view(tuple(parts[0].shape[:-1]) + (out.shape[-1],)), first.mask if res_rep is None else res_rep.mask)
     out = first.catvalue(list(others), True).tuplewiseapply(mlp)
+    if res_rep is not None:
+        return res_rep.add(out, True)
     return first.add(out, True) if residual else out
 
 
@@ -228,11 +239,16 @@ class DSSGNNConv(Module):
         self.unpooling2subg = TensorOp.OpUnpoolingRootNodes2D(mode[1])
         self.lin = MLP(2 * indim, outdim, **mlp)
 
-    def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
+    def forward(self, A: Rep, X: Rep, datadict: dict, residual=False) -> Rep:
         node_level = self.aggr_global.forward(A, self.pool2global.forward(X))
         shared = self.unpooling2subg.forward(node_level, X)
         local = self.aggr_subg.forward(A, X, datadict, X)
-        return _cat_apply(local, [shared], self.lin)
+        return _cat_apply(local, [shared], self.lin, residual=residual)
+
+    def forward_residual(self, A: Rep, X: Rep, datadict: dict) -> Rep:
+        """``X.add(self.forward(A, X, datadict), True)`` (the model loop of example/zinc.py:287-290), X added inside the block's
+        activation pass when the fused block applies."""
+        return self.forward(A, X, datadict, residual=X)
 
 
 class PPGNConv(Module):
@@ -268,14 +284,18 @@ class GNNAKConv(Module):
             self.pool2node, self.unpool4rootnode = v["pool_node"], v["to_root"]
         self.lin = MLP((3 if ctx else 2) * indim, outdim, **mlp1)
 
-    def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
+    def forward(self, A: Rep, X: Rep, datadict: dict, residual=False) -> Rep:
         H = self.aggr.forward(A, X.tuplewiseapply(self.lin0), datadict, X)
         centroid = self.unpool4subg.forward(self.diag.forward(H), H)
         pooled = self.unpool4subg.forward(self.pool2subg.forward(H), H)
         extra = [centroid]
         if self.ctx:
             extra.append(self.unpool4rootnode.forward(self.pool2node.forward(H), H))
-        return _cat_apply(pooled, extra, self.lin)
+        return _cat_apply(pooled, extra, self.lin, residual=residual)
+
+    def forward_residual(self, A: Rep, X: Rep, datadict: dict) -> Rep:
+        """``X.add(self.forward(A, X, datadict), True)``, X added inside the last block's activation pass when it is fused."""
+        return self.forward(A, X, datadict, residual=X)
 
 
 class SUNConv(Module):

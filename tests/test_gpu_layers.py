@@ -999,3 +999,62 @@ def test_sswl_fused_update_in_eval_mode_without_grad(dev, layout):
     for k, v in layer.state_dict().items():
         if "running" in k:
             assert torch.equal(v, stats[k]), k
+
+
+@pytest.mark.parametrize("layout", ["sparse", "dense"])
+@pytest.mark.parametrize("name", ["DSSGNNConv", "GNNAKConv"])
+def test_forward_residual_of_concatenating_layers(dev, name, layout):
+    """DSSGNNConv / GNNAKConv.forward_residual (X added inside the concat block's activation pass as a separate residual operand,
+    its gradient = the output gradient) against X.add(conv.forward(A, X, datadict), True) with the fused block switched off:
+    bf16, outputs on valid entries, input gradient, parameter gradients."""
+    import copy
+    from pygho_amd import MaskedTensor, SparseTensor, synth, _ops
+    from pygho_amd.honn import Conv
+    from pygho_amd.honn.SpOperator import parse_precomputekey
+    h = 128
+    mode = "SS" if layout == "sparse" else "DD"
+    torch.manual_seed(6)
+    if name == "DSSGNNConv":
+        layer = Conv.DSSGNNConv(h, h, "sum", "sum", "mean", mode, dict(MLP)).to(dev)
+    else:
+        layer = Conv.GNNAKConv(h, h, "sum", "mean", mode, dict(MLP), dict(MLP)).to(dev)
+    if layout == "sparse":
+        hb = synth.make_batch(64, "zinc", seed=25, keys=tuple(parse_precomputekey(layer)))
+        dd = synth.to_datadict(hb, dev)
+        X0, A0 = dd["X"], dd["A"]
+        xraw = torch.randn(X0.nnz, h, device=dev).to(torch.bfloat16)
+        A = SparseTensor(A0.indices, (torch.randn(A0.nnz, h, device=dev) * 0.5).to(torch.bfloat16), list(A0.shape[:2]) + [h], True)
+        mk = lambda x: SparseTensor(X0.indices, x, list(X0.shape[:2]) + [h], True)
+        valid = None
+    else:
+        dn = synth.make_dense_batch(8, seed=10, hidden=h, nmax=37)
+        dd = {}
+        xraw = T(dn["X"], dev).to(torch.bfloat16)
+        A = MaskedTensor(T(dn["A"], dev).to(torch.bfloat16), T(dn["Amask"], dev), 0.0, True)
+        xm = T(dn["Xmask"], dev)
+        mk = lambda x: MaskedTensor(x, xm, 0.0, True)
+        valid = xm[..., None]
+    w = torch.randn(xraw.shape, device=dev).to(torch.bfloat16)
+    res = {}
+    for fused in (True, False):
+        _ops.USE_CONCAT_BLOCK = fused
+        try:
+            lay = copy.deepcopy(layer)
+            x = xraw.clone().requires_grad_(True)
+            X = mk(x)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = lay.forward_residual(A, X, dd) if fused else X.add(lay.forward(A, X, dd), True)
+            o = out.values if valid is None else out.data * valid
+            o.backward(w)
+            gx = x.grad.float() if valid is None else x.grad.float() * valid
+            res[fused] = (o.detach().float(), gx, {k: p.grad.float() for k, p in lay.named_parameters()})
+        finally:
+            _ops.USE_CONCAT_BLOCK = True
+    for i in (0, 1):
+        s = float(res[False][i].abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][i] / s, res[False][i] / s, rtol=0, atol=4e-2)
+    for k, ref in res[False][2].items():
+        if k.endswith(".lins.0.bias"):
+            continue
+        s = float(ref.abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][2][k] / s, ref / s, rtol=0, atol=4e-2, msg=k)
