@@ -1896,8 +1896,10 @@ class _TupleBlock(torch.autograd.Function):
         # transcendentals per element make that kernel VALU-bound (0.52 vs 0.50 ms forward, 0.41 vs 0.30 ms backward)
         on_load = (USE_ACT_ON_LOAD and plan is not None and rhs is not None and x.dtype == torch.float32 and aggr in ("sum", "mean")
                    and (x.shape[1] * 4) % 16 == 0 and rhs.dtype == x.dtype and rhs.shape[1] == x.shape[1])
+        # without a plan `rhs` is a residual row operand: out = H + rhs, added inside the activation pass
+        row_res = rhs.contiguous() if (plan is None and rhs is not None) else None
         h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum, partial,
-                                          apply=not on_load)
+                                          apply=not on_load, addend=row_res)
         affine = look = None
         rhs_read, d_idx = rhs, (plan.d_fwd if plan is not None and rhs is not None else None)
         if plan is not None and rhs is not None and rhs_lookup is not None:
@@ -1945,6 +1947,8 @@ class _TupleBlock(torch.autograd.Function):
                                     act=(ctx.affine[0], ctx.affine[1], act, 2))
                 else:
                     g_rhs = seg_gmr(plan.n_rhs, g, h, p.seg_ptr, a_g, c_g, "sum", scale)
+        elif rhs is not None and ctx.needs_input_grad[10]:
+            g_rhs = g                                   # residual row operand: receives the output gradient as it is
         want_cs = b_dtype is not None and ctx.needs_input_grad[2]
         gx = gw = gb = None
         if skinny and USE_BN_BWD_LINEAR and USE_FUSED_DW and ctx.needs_input_grad[1]:
@@ -1979,6 +1983,8 @@ def tuple_block(x: Tensor, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", a
     training = bn.training or bn.running_mean is None
     if residual:
         assert plan is not None and plan.n_out == x.shape[0] and lin.out_features == x.shape[1]
+    if plan is None and rhs is not None:                # residual row operand (see _TupleBlock.forward)
+        assert rhs.shape == (x.shape[0], lin.out_features) and rhs.dtype == x.dtype and rhs_lookup is None
     fold = _fold_momentum(bn)
     out, mean, var = _TupleBlock.apply(x, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
                                        bn.eps, act, rhs, plan, aggr, residual, fold, rhs_lookup)

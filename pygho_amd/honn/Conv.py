@@ -107,6 +107,16 @@ def _cat_apply(first: Rep, others, mlp, residual=False) -> Rep:
     block = mlp.single_block() if isinstance(mlp, MLP) else None
     reps = [first] + list(others)
     res_rep = residual if isinstance(residual, (SparseTensor, MaskedTensor)) else None
+    if residual is True:
+        res_rep, residual = first, first       # "+ first": the same rule as for a separate residual representation
+    if res_rep is not None:
+        # the sum is formed inside the block only when R already has the block's compute dtype: an f32 residual stream under
+        # autocast stays f32 (R.add(out, True) promotes), exactly as in the model loop
+        rows = res_rep.values if isinstance(res_rep, SparseTensor) else res_rep.raw
+        lead = first.values if isinstance(first, SparseTensor) else first.raw
+        cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else (None if lead is None else lead.dtype)
+        if rows is None or lead is None or rows.dtype != cdt or type(res_rep) is not type(first):
+            return res_rep.add(_cat_apply(first, others, mlp), True)
     if (block is not None and all(isinstance(r, SparseTensor) and r.values is not None for r in reps)
             and all(r.indices is first.indices or r.nnz == first.nnz for r in reps)):
         vals = [r.values for r in reps]
@@ -115,7 +125,7 @@ def _cat_apply(first: Rep, others, mlp, residual=False) -> Rep:
         res_ok = res_rep is None or (isinstance(res_rep, SparseTensor) and res_rep.values is not None and res_rep.nnz == first.nnz
                                      and res_rep.values.shape == vals[0].shape)
         if res_ok and _ops.concat_block_supported(vals, block[0]):
-            res_arg = residual if res_rep is None else (res_rep.values if res_rep.values.dtype == dt else res_rep.values.to(dt))
+            res_arg = residual if res_rep is None else (True if res_rep is first else res_rep.values)
             with torch.autocast("cuda", enabled=False):
                 out = _ops.concat_block(vals, *block, residual=res_arg)      # residual: added inside the activation pass
             return (first if res_rep is None else res_rep).tuplewiseapply(lambda _: out)
@@ -130,7 +140,7 @@ def _cat_apply(first: Rep, others, mlp, residual=False) -> Rep:
         if res_ok and all(v.shape == vals[0].shape for v in vals) and _ops.concat_block_supported(vals, block[0]):
             res_arg = residual
             if res_rep is not None:            # R.add(out, True) adds the raw data (MaTensor.py:251-262): masked entries stay don't-care
-                res_arg = (res_rep.raw if res_rep.raw.dtype == dt else res_rep.raw.to(dt)).reshape(-1, d)
+                res_arg = True if res_rep is first else res_rep.raw.reshape(-1, d)
             with torch.autocast("cuda", enabled=False):
                 out = _ops.concat_block(vals, *block, residual=res_arg)
             return MaskedTensor(out.view(tuple(parts[0].shape[:-1]) + (out.shape[-1],)), first.mask if res_rep is None else res_rep.mask)
@@ -331,7 +341,12 @@ class SUNConv(Module):
 
         return stacked.diagonalapply(per_type).tuplewiseapply(self.lin1_1)
 
-    def forward(self, A: Rep, X: Rep, datadict: dict) -> Rep:
+    def forward_residual(self, A: Rep, X: Rep, datadict: dict) -> Rep:
+        """``X.add(self.forward(A, X, datadict), True)`` (the model loop of example/zinc.py:287-290); X is added inside the
+        activation pass of the last MLP block when that block is fused."""
+        return self.forward(A, X, datadict, residual=True)
+
+    def forward(self, A: Rep, X: Rep, datadict: dict, residual: bool = False) -> Rep:
         """Same function with the linear map pulled through the broadcasts.  Five of the seven concatenated views are
         node-level tensors unpooled to tuple level, and ``unpool(v) W = unpool(v W)``: the (7 d -> d) map is applied block
         by block -- to X and agg at tuple level, to the five node-level tensors BEFORE they are broadcast -- and the
@@ -340,7 +355,14 @@ class SUNConv(Module):
         to_nodes, to_root = self.unpool4subg.forward, self.unpool4rootnode.forward
         d = self.lin1_0.in_channels // 7
         if self.lin1_0.bias is not None or self.lin1_0.num_types != 2:
-            return self.forward_concat(A, X, datadict)
+            out = self.forward_concat(A, X, datadict)
+            return X.add(out, True) if residual else out
+        x_rows = X.values if isinstance(X, SparseTensor) else X.raw
+
+        def tail(rep):                       # the last MLP, with the layer input as its residual row operand when asked for
+            if not residual:
+                return rep.tuplewiseapply(self.lin1_1)
+            return rep.tuplewiseapply(lambda val: self.lin1_1(val, residual=x_rows))
         W = self.lin1_0.weight                                   # (2, 7 d, d): [off-diagonal, diagonal]
         blk = lambda t, v: W[t, v * d:(v + 1) * d]
         def mm(val, w):                      # val @ w; tall operands get the split-K weight gradient (honn/utils.py)
@@ -364,12 +386,12 @@ class SUNConv(Module):
             if (isinstance(X, MaskedTensor) and isinstance(agg, MaskedTensor) and X.masked_dim == 3 and X.raw.is_floating_point()
                     and agg.raw.shape == X.raw.shape and (cdt is not None or agg.raw.dtype == X.raw.dtype)
                     and _ops.pair_combine_supported(as_c(X.raw))):
-                return self._recombine(X, agg, blk, True, as_c).tuplewiseapply(self.lin1_1)
+                return tail(self._recombine(X, agg, blk, True, as_c))
             if (isinstance(X, SparseTensor) and isinstance(agg, SparseTensor) and X.sparse_dim == 2 and X.values is not None
                     and agg.values is not None and X.values.is_floating_point() and agg.values.shape == X.values.shape
                     and (cdt is not None or agg.values.dtype == X.values.dtype) and agg.nnz == X.nnz and X.shape[0] == X.shape[1]
                     and _ops.pair_gather_supported(as_c(X.values))):
-                return self._recombine(X, agg, blk, False, as_c).tuplewiseapply(self.lin1_1)
+                return tail(self._recombine(X, agg, blk, False, as_c))
         centre, n5, n6, n7 = self.diag.forward(X), self.pool2node(X), self.pool2subg(X), self.pool2node(agg)
         # concat order of the reference: [X, to_nodes(centre), to_root(centre), agg, to_root(n5), to_nodes(n6), to_root(n7)]
         off = add(lin(X, blk(0, 0)), lin(agg, blk(0, 3)))
@@ -384,7 +406,7 @@ class SUNConv(Module):
             picked = MaskedTensor(torch.where(eye, dg_t.raw.to(off.raw.dtype), off.raw), off.mask)
         else:
             picked = off.diagonalapply(lambda val, is_diag: torch.where(is_diag.bool().unsqueeze(-1), dg_t.values.to(val.dtype), val))
-        return picked.tuplewiseapply(self.lin1_1)
+        return tail(picked)
 
     def _recombine(self, X: Rep, agg: Rep, blk, dense: bool, as_c=lambda t: t) -> Rep:
         with torch.autocast("cuda", enabled=False):          # one compute dtype throughout (operands cast by `as_c`)

@@ -4,7 +4,7 @@ utils.py:46-142): these are dense ``torch.nn`` stacks (rocBLAS / hipBLASLt GEMMs
 and are not part of the hand-written hot path; module / parameter names match the reference so that
 ``state_dict``s are interchangeable.
 """
-from typing import Callable
+from typing import Callable, Optional
 
 import torch
 import torch.nn as nn
@@ -157,9 +157,17 @@ class MLP(nn.Module):
             return lin, norm.norm, name
         return None
 
-    def forward(self, x: Tensor):
+    def forward(self, x: Tensor, residual: Optional[Tensor] = None):
+        """`residual` (optional, shape of the output): returns residual + MLP(x); when the MLP ends in a fused
+        [Linear, BatchNorm, act] block the sum is formed inside that block's activation pass."""
+        if residual is not None:
+            y, fused = self._forward(x, residual)
+            return y if fused else residual + y
+        return self._forward(x, None)[0]
+
+    def _forward(self, x: Tensor, residual: Optional[Tensor]):
         if not isinstance(self.lins, nn.Sequential):
-            return self.lins(x)
+            return self.lins(x), False
         # same module sequence as the reference.  On device tensors a [Linear, BatchNorm, act] run is ONE autograd
         # node (GEMM + fused BatchNorm/activation kernels; the bias gradient falls out of the BatchNorm backward
         # pass) and a [BatchNorm, act] pair is one fused kernel pair; everything else is the stock module.
@@ -171,10 +179,18 @@ class MLP(nn.Module):
                 act = _ACT_NAMES.get(type(mods[i + 2])) if i + 2 < len(mods) else None
                 x2 = _autocast_input(x.flatten(0, -2) if x.dim() > 2 else x)
                 if x2.shape[0] >= 8192 and _ops.bn_act_supported_shape(x2.shape[0], mod.out_features, x2.dtype):
+                    step = 3 if act is not None else 2
+                    row_res = None
+                    # fused only when the residual already has the block's compute dtype (an f32 residual stream stays f32)
+                    if (residual is not None and i + step == len(mods) and residual.dtype == x2.dtype
+                            and residual.shape == tuple(x.shape[:-1]) + (mod.out_features,)):
+                        row_res = residual.reshape(-1, mod.out_features)
                     with torch.autocast("cuda", enabled=False):
-                        y = _ops.tuple_block(x2, mod, mods[i + 1].norm, act or "none")
+                        y = _ops.tuple_block(x2, mod, mods[i + 1].norm, act or "none", rhs=row_res)
                     x = y.reshape(tuple(x.shape[:-1]) + (mod.out_features,))
-                    i += 3 if act is not None else 2
+                    i += step
+                    if row_res is not None:
+                        return x, True
                     continue
             if type(mod) is BatchNorm and x.is_cuda and x.dim() >= 2:
                 act = _ACT_NAMES.get(type(mods[i + 1])) if i + 1 < len(mods) else None
@@ -186,7 +202,7 @@ class MLP(nn.Module):
                     continue
             x = mod(x)
             i += 1
-        return x
+        return x, False
 
 
 _ACT_NAMES = {nn.SiLU: "silu", nn.ReLU: "relu"}

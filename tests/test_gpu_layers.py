@@ -1058,3 +1058,56 @@ def test_forward_residual_of_concatenating_layers(dev, name, layout):
             continue
         s = float(ref.abs().max()) + 1e-6
         torch.testing.assert_close(res[True][2][k] / s, ref / s, rtol=0, atol=4e-2, msg=k)
+
+
+@pytest.mark.parametrize("layout", ["sparse", "dense"])
+def test_sunconv_forward_residual(dev, layout):
+    """SUNConv.forward_residual (the layer input as residual row operand of the last fused MLP block) against
+    X.add(conv.forward(A, X, datadict), True): bf16 activations (sum formed in the block) and f32 activations under autocast
+    (the residual stream stays f32: the add is not fused), outputs, input gradient and parameter gradients."""
+    import copy
+    from pygho_amd import MaskedTensor, SparseTensor, synth, _ops
+    from pygho_amd.honn import Conv
+    from pygho_amd.honn.SpOperator import parse_precomputekey
+    h = 128
+    mode = "SS" if layout == "sparse" else "DD"
+    torch.manual_seed(8)
+    layer = Conv.SUNConv(h, h, "sum", "mean", mode, dict(MLP), dict(MLP)).to(dev)
+    for xdt in (torch.bfloat16, torch.float32):
+        if layout == "sparse":
+            hb = synth.make_batch(64, "zinc", seed=27, keys=tuple(parse_precomputekey(layer)))
+            dd = synth.to_datadict(hb, dev)
+            X0, A0 = dd["X"], dd["A"]
+            xraw = torch.randn(X0.nnz, h, device=dev).to(xdt)
+            A = SparseTensor(A0.indices, (torch.randn(A0.nnz, h, device=dev) * 0.5).to(xdt), list(A0.shape[:2]) + [h], True)
+            mk = lambda x: SparseTensor(X0.indices, x, list(X0.shape[:2]) + [h], True)
+            valid = None
+        else:
+            dn = synth.make_dense_batch(8, seed=12, hidden=h, nmax=37)
+            dd = {}
+            xraw = T(dn["X"], dev).to(xdt)
+            A = MaskedTensor(T(dn["A"], dev).to(xdt), T(dn["Amask"], dev), 0.0, True)
+            xm = T(dn["Xmask"], dev)
+            mk = lambda x: MaskedTensor(x, xm, 0.0, True)
+            valid = xm[..., None]
+        w = torch.randn(xraw.shape, device=dev).to(xdt)
+        res = {}
+        for fused in (True, False):
+            lay = copy.deepcopy(layer)
+            x = xraw.clone().requires_grad_(True)
+            X = mk(x)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = lay.forward_residual(A, X, dd) if fused else X.add(lay.forward(A, X, dd), True)
+            o = out.values if valid is None else out.data * valid
+            assert o.dtype == xdt                                     # the residual stream keeps its dtype
+            o.backward(w)
+            gx = x.grad.float() if valid is None else x.grad.float() * valid
+            res[fused] = (o.detach().float(), gx, {k: p.grad.float() for k, p in lay.named_parameters()})
+        for i in (0, 1):
+            s = float(res[False][i].abs().max()) + 1e-6
+            torch.testing.assert_close(res[True][i] / s, res[False][i] / s, rtol=0, atol=4e-2)
+        for k, ref in res[False][2].items():
+            if k.endswith(".lins.0.bias"):
+                continue
+            s = float(ref.abs().max()) + 1e-6
+            torch.testing.assert_close(res[True][2][k] / s, ref / s, rtol=0, atol=4e-2, msg=k)
