@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--distinct", type=int, default=1024, help="distinct graphs generated per rank (tiled up to --graphs)")
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "foreach"], help="AdamW implementation (same update rule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-graphs", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -136,7 +137,7 @@ def main():
     model = SpModel(1, args.layers, args.hidden, act_dtype=act_dtype).to(dev)
     sync = FlatGradSync(model.parameters())
     sync.broadcast_params(0)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=args.optimizer == "fused")
     y = datadict["y"].unsqueeze(-1)
 
     def step():

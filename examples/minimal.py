@@ -43,7 +43,7 @@ def main():
         r.y = float(r.x.mean()) / 10.0
     store = DeviceGraphStore(records, dev)
     print(f"{args.graphs} graphs preprocessed and stored on the device in {time.perf_counter() - t0:.1f} s; keys {keys}")
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
     for epoch in range(args.epochs):
         perm = torch.randperm(args.graphs, generator=torch.Generator().manual_seed(epoch))
         tot, nb = 0.0, 0
