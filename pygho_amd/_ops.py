@@ -556,9 +556,9 @@ class _MessageReduce(torch.autograd.Function):
     """out[a] = (+) lhs[c] * rhs[d] over the plan; either operand may be None (pattern only)."""
 
     @staticmethod
-    def forward(ctx, lhs: Optional[Tensor], rhs: Optional[Tensor], plan: MessagePlan, aggr: str):
+    def forward(ctx, lhs: Optional[Tensor], rhs: Optional[Tensor], plan: MessagePlan, aggr: str, addend: Optional[Tensor] = None):
         out = seg_gmr(plan.n_out, lhs, rhs, plan.fwd.seg_ptr, plan.c_fwd if lhs is not None else None,
-                      plan.d_fwd if rhs is not None else None, aggr)
+                      plan.d_fwd if rhs is not None else None, aggr, addend=None if addend is None else addend.contiguous())
         ctx.plan, ctx.aggr = plan, aggr
         ctx.has = (lhs is not None, rhs is not None)
         ctx.save_for_backward(lhs, rhs, out if aggr in ("max", "min") else None)
@@ -587,7 +587,8 @@ class _MessageReduce(torch.autograd.Function):
                 g_rhs = seg_gmr(plan.n_rhs, gout, lhs, p.seg_ptr, a_g, c_g if lhs is not None else None, "sum", scale)
             else:
                 g_rhs = _extremum_bwd(plan.n_rhs, gout, fwd, ties, rhs, lhs, p.seg_ptr, a_g, c_g)
-        return g_lhs, g_rhs, None, None
+        g_add = gout if len(ctx.needs_input_grad) > 4 and ctx.needs_input_grad[4] else None      # out = addend + reduction
+        return g_lhs, g_rhs, None, None, g_add
 
 
 def _broadcast_dense(a: Optional[Tensor], b: Optional[Tensor]) -> Tuple[Optional[Tensor], Optional[Tensor], Tuple[int, ...]]:
@@ -610,15 +611,20 @@ def _broadcast_dense(a: Optional[Tensor], b: Optional[Tensor]) -> Tuple[Optional
 
 
 def message_reduce(lhs: Optional[Tensor], rhs: Optional[Tensor], acd: Tensor, n_out: int, n_lhs: int, n_rhs: int,
-                   aggr: str) -> Tensor:
-    """spspmm value computation (Spspmm.py:307-315) on the HIP path."""
+                   aggr: str, addend: Optional[Tensor] = None) -> Tensor:
+    """spspmm value computation (Spspmm.py:307-315) on the HIP path; `addend` (sum / mean, shape of the result): + addend in the
+    kernel's epilogue (a residual connection around the product)."""
     if lhs is None and rhs is None:
         raise ValueError("pygho_amd: both operands are pattern-only; nothing to multiply")
     if aggr not in AGGR_CODE:
         raise NotImplementedError(f"aggr {aggr!r} is not supported (sum, mean, max, min)")
     l2, r2, dense = _broadcast_dense(lhs, rhs)
     plan = message_plan(acd, n_out, n_lhs, n_rhs)
-    out = _MessageReduce.apply(l2, r2, plan, aggr)
+    if addend is not None:
+        assert aggr in ("sum", "mean") and tuple(addend.shape) == (n_out,) + dense and addend.dtype == (l2 if l2 is not None else r2).dtype
+        out = _MessageReduce.apply(l2, r2, plan, aggr, _as2d(addend))
+    else:
+        out = _MessageReduce.apply(l2, r2, plan, aggr)
     return out.reshape((n_out,) + dense)
 
 

@@ -275,6 +275,20 @@ class PPGNConv(Module):
         left, right = (X.tuplewiseapply(f) for f in (self.lin1, self.lin2))
         return self.op.forward(left, right, datadict, X)
 
+    def forward_residual(self, A: Rep, X: Rep, datadict: dict) -> Rep:
+        """``X.add(self.forward(A, X, datadict), True)`` (the model loop of example/zinc.py:287-290); on the sparse layout with a
+        precomputed plan and sum / mean the residual row is added in the product kernel's epilogue."""
+        op = getattr(self.op, "mod", None)
+        acd = None if datadict is None or not isinstance(op, OpMessagePassing) else datadict.get(op.precomputekey + KEYSEP + "acd")
+        if not (isinstance(X, SparseTensor) and acd is not None and not op.use_mpnn and op.aggr in ("sum", "mean")
+                and X.values is not None and X.values.is_cuda):
+            return X.add(self.forward(A, X, datadict), True)
+        left, right = (X.tuplewiseapply(f) for f in (self.lin1, self.lin2))
+        if not (left.values.dtype == right.values.dtype == X.values.dtype and left.values.shape == right.values.shape == X.values.shape):
+            return X.add(self.op.forward(left, right, datadict, X), True)         # e.g. an f32 residual stream under autocast
+        vals = _ops.message_reduce(left.values, right.values, acd, X.nnz, X.nnz, X.nnz, op.aggr, addend=X.values)
+        return X.tuplewiseapply(lambda _: vals)
+
 
 class GNNAKConv(Module):
     """GNN-AK layer (reference Conv.py:236-297): aggregate, then concatenate the subgraph-pooled view, the

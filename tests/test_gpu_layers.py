@@ -1111,3 +1111,39 @@ def test_sunconv_forward_residual(dev, layout):
                 continue
             s = float(ref.abs().max()) + 1e-6
             torch.testing.assert_close(res[True][2][k] / s, ref / s, rtol=0, atol=4e-2, msg=k)
+
+
+def test_ppgn_forward_residual(dev):
+    """PPGNConv.forward_residual (residual row added in the 2-FWL product kernel's epilogue, its gradient = the output gradient)
+    against X.add(conv.forward(A, X, datadict), True): bf16, outputs, input gradient, parameter gradients."""
+    import copy
+    from pygho_amd import SparseTensor, synth
+    from pygho_amd.honn import Conv
+    from pygho_amd.honn.SpOperator import parse_precomputekey
+    h = 128
+    torch.manual_seed(9)
+    layer = Conv.PPGNConv(h, h, "sum", "SS", dict(MLP)).to(dev)
+    hb = synth.make_batch(48, "zinc", seed=29, keys=tuple(parse_precomputekey(layer)))
+    dd = synth.to_datadict(hb, dev)
+    X0 = dd["X"]
+    xraw = torch.randn(X0.nnz, h, device=dev).to(torch.bfloat16)
+    w = torch.randn(X0.nnz, h, device=dev).to(torch.bfloat16)
+    res = {}
+    for fused in (True, False):
+        lay = copy.deepcopy(layer)
+        x = xraw.clone().requires_grad_(True)
+        X = SparseTensor(X0.indices, x, list(X0.shape[:2]) + [h], True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = lay.forward_residual(dd["A"], X, dd) if fused else X.add(lay.forward(dd["A"], X, dd), True)
+        if fused:
+            assert type(out.values.grad_fn).__name__ in ("_MessageReduceBackward", "ViewBackward0", "ReshapeAliasBackward0")
+        out.values.backward(w)
+        res[fused] = (out.values.detach().float(), x.grad.float(), {k: p.grad.float() for k, p in lay.named_parameters()})
+    for i in (0, 1):
+        s = float(res[False][i].abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][i] / s, res[False][i] / s, rtol=0, atol=4e-2)
+    for k, ref in res[False][2].items():
+        if k.endswith(".lins.0.bias"):
+            continue
+        s = float(ref.abs().max()) + 1e-6
+        torch.testing.assert_close(res[True][2][k] / s, ref / s, rtol=0, atol=4e-2, msg=k)
