@@ -43,11 +43,40 @@ def run(dd, dev, fused_adamw=True, steps=12, warmup=4):
     return e0.elapsed_time(e1) / steps
 
 
+def layers(dev):
+    """the other layers: one forward + backward of SSWLConv / SUNConv (sparse, 8192 graphs), SUNConv on the padded layout
+    (1024 graphs) and I2Conv (2048 3-tuple graphs, hidden 256), each with its own switches off one at a time"""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bench_layers
+    import bench_ops
+    cases = [
+        ("SSWLConv SS", lambda: bench_layers.case("SSWLConv", 8192, dev)["ms"], ("USE_SSWL_BLOCK", "USE_CONCAT_BLOCK")),
+        ("SUNConv SS", lambda: bench_layers.case("SUNConv", 8192, dev)["ms"], ("USE_PAIR_COMBINE",)),
+        ("SUNConv DD (1024, 37, 37, 128)", lambda: bench_ops.sunconv_case(1024, 37, 128, torch.bfloat16, dev)["ms"],
+         ("USE_PAIR_COMBINE", "USE_BMM_LISTS", "USE_BMM_EXTENTS")),
+        ("I2Conv SS hidden 256", lambda: bench_layers.case("I2Conv", 2048, dev)["ms"], ("USE_SEG_WINDOW",)),
+    ]
+    for name, fn, flags in cases:
+        base = fn()
+        print(json.dumps({"layer": name, "config": "all on", "ms": base}), flush=True)
+        for flag in flags:
+            setattr(_ops, flag, False)
+            try:
+                ms = fn()
+            finally:
+                setattr(_ops, flag, True)
+            print(json.dumps({"layer": name, "config": f"{flag} = False", "ms": ms, "delta_ms": ms - base}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--graphs", type=int, default=8192)
+    ap.add_argument("--layers", action="store_true", help="the per-layer switches instead of the benchmarked step")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.layers:
+        layers(dev)
+        return
     hb = synth.replicate(synth.make_batch(1024, "zinc", seed=1000), args.graphs // 1024)
     dd = synth.to_datadict(hb, dev)
     base = run(dd, dev)
