@@ -116,3 +116,29 @@ def test_shard_ranges_balance_and_cover():
         loads = [w[a:b].sum() for a, b in r]
         assert max(loads) <= 1.05 * w.sum() / world + 900
     assert shard_ranges(np.ones(3), 8)[-1][1] == 3                        # more ranks than graphs: empty tails
+
+
+def test_window_kernel_dispatch_rule():
+    """host-side choice between the gather-everything segment kernel and its LDS-window variant (`_ops._window_eligible`):
+    two-operand sum / mean with an indexed, SMALL rhs and rows of 512 B ... 1 KB only."""
+    import torch
+    from pygho_amd import _ops
+    idx = torch.zeros(10, dtype=torch.int32)
+    big = lambda rows, d, dt: torch.empty(rows, d, dtype=dt)
+    lhs, rhs = big(100_000, 256, torch.bfloat16), big(5_000, 256, torch.bfloat16)
+    saved = (_ops.USE_SEG_WINDOW, _ops.SEG_WINDOW_MIN_ROW_BYTES)
+    try:
+        _ops.USE_SEG_WINDOW, _ops.SEG_WINDOW_MIN_ROW_BYTES = True, 512
+        assert _ops._window_eligible(100_000, lhs, rhs, idx, "sum") and _ops._window_eligible(100_000, lhs, rhs, idx, "mean")
+        assert not _ops._window_eligible(100_000, lhs, rhs, idx, "max")                    # extremum: other kernel
+        assert not _ops._window_eligible(100_000, lhs, rhs, None, "sum")                   # rhs read in message order: no window
+        assert not _ops._window_eligible(100_000, None, rhs, idx, "sum")                   # one operand only
+        assert not _ops._window_eligible(100_000, lhs, big(80_000, 256, torch.bfloat16), idx, "sum")   # rhs is not the small operand
+        assert not _ops._window_eligible(100_000, big(100_000, 128, torch.bfloat16), big(5_000, 128, torch.bfloat16), idx, "sum")  # 256-B rows
+        assert _ops._window_eligible(100_000, big(100_000, 128, torch.float32), big(5_000, 128, torch.float32), idx, "sum")       # 512-B rows
+        assert not _ops._window_eligible(100_000, big(100_000, 512, torch.float32), big(5_000, 512, torch.float32), idx, "sum")   # 2-KB rows
+        assert not _ops._window_eligible(1_000, big(1_000, 256, torch.bfloat16), big(100, 256, torch.bfloat16), idx, "sum")       # tiny launch
+        _ops.USE_SEG_WINDOW = False
+        assert not _ops._window_eligible(100_000, lhs, rhs, idx, "sum")
+    finally:
+        _ops.USE_SEG_WINDOW, _ops.SEG_WINDOW_MIN_ROW_BYTES = saved
