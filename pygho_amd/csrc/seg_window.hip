@@ -8,8 +8,8 @@
 // is what binds it at 512-B rows.  Here a workgroup of 8 wavefronts
 //   1. stages its CSR pointers and message indices (one coalesced load each, per wavefront) and reduces min / max of its
 //      rhs indices,
-//   2. copies rows [min, max] of rhs into LDS with one contiguous, coalesced sweep (when the window fits: a uniform test,
-//      otherwise this pass gathers rhs from global memory like the fast kernel),
+//   2. copies rows [min, max] of rhs into LDS with one contiguous, coalesced sweep (the first `win_rows` of them when the range
+//      is longer: messages whose row lies beyond the window gather it from global memory like the fast kernel),
 //   3. walks its segments: the lhs row of a message comes from global memory, the rhs row from LDS (ds_read_b128).
 // Half of the gather traffic leaves the vector-memory path; the window copy adds rows(window) / messages(pass) of it back.
 #include "common.h"
@@ -62,7 +62,7 @@ __device__ __forceinline__ int wave_max(int v) {
 
 // 80 VGPRs: three workgroups (6 wavefronts per SIMD) next to 3 x 49.3 KB of LDS; the scaled form (mean backward) needs more
 template <typename T, bool SCALED, bool MEAN>
-__global__ __launch_bounds__(kWinBlock, (SCALED || kWinTrip > 2) ? 4 : 6) void seg_gmr_window_kernel(
+__global__ __launch_bounds__(kWinBlock, (SCALED || kWinTrip > 2) ? 4 : (MEAN ? 5 : 6)) void seg_gmr_window_kernel(
     T* __restrict__ out, const T* __restrict__ lhs, const T* __restrict__ rhs, const int32_t* __restrict__ seg_ptr,
     const int32_t* __restrict__ lhs_idx, const int32_t* __restrict__ rhs_idx, const float* __restrict__ lhs_rowscale,
     const T* __restrict__ addend, int64_t n_seg, int d, int chunks, int log2g, int spp, int win_rows) {
@@ -117,9 +117,11 @@ __global__ __launch_bounds__(kWinBlock, (SCALED || kWinTrip > 2) ? 4 : 6) void s
     __syncthreads();
     const int rmin = wave_min(s_lo[lane & (kWinWaves - 1)]);
     const int rmax = wave_max(s_hi[lane & (kWinWaves - 1)]);
-    const bool use_win = rmax >= rmin && (rmax - rmin) < win_rows;       // uniform over the workgroup
-    if (use_win) {                                                      // rows [rmin, rmax] are one contiguous byte range
-      const uint32_t n16 = (uint32_t)(rmax - rmin + 1) * (uint32_t)chunks;
+    // the window holds rows [rmin, rmin + nwin): all of the pass's rhs rows when they fit, otherwise the first win_rows of them
+    // (a pass that straddles two graphs keeps the first graph's edge rows; the rest is gathered from global memory per message)
+    const uint32_t nwin = rmax >= rmin ? (uint32_t)min(rmax - rmin + 1, win_rows) : 0u;      // uniform over the workgroup
+    {                                                                   // rows [rmin, rmin + nwin) are one contiguous byte range
+      const uint32_t n16 = nwin * (uint32_t)chunks;
       const uint4* src = reinterpret_cast<const uint4*>(rbase + (int64_t)rmin * (int64_t)row_bytes);
       uint4* dst = reinterpret_cast<uint4*>(s_win);
       for (uint32_t u = threadIdx.x; u < n16; u += kWinBlock) dst[u] = src[u];
@@ -157,7 +159,8 @@ __global__ __launch_bounds__(kWinBlock, (SCALED || kWinTrip > 2) ? 4 : 6) void s
 #pragma unroll
         for (int k = 0; k < kWinTrip; ++k) {
           uint4 rb;
-          if (use_win) rb = *reinterpret_cast<const uint4*>(s_win + ((uint32_t)(ri[k] - rmin) * row_bytes + col_bytes));
+          const uint32_t wr = (uint32_t)(ri[k] - rmin);                 // uniform per lane group (one message), not per wavefront
+          if (wr < nwin) rb = *reinterpret_cast<const uint4*>(s_win + (wr * row_bytes + col_bytes));
           else rb = win_load_row16<OFF32>(rbase, ri[k], row_bytes, col_bytes);
           if (k == 0 || m0 + k < end) win_accumulate<T, SCALED>(acc, la[k], rb, sc[k]);
         }
