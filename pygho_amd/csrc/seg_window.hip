@@ -5,7 +5,7 @@
 // Difference: the rhs rows a workgroup's segments touch lie in a narrow index window when the batch is block diagonal (the
 // edges of one or two graphs; an embedding table's handful of rows), and each of them is gathered M / rows(rhs) times
 // (66x for the I2-shape 3-tuple plan).  The fast kernel fetches every one of those gathers through the L2 -> L1 path, which
-// is what binds it at 512-B rows.  Here a workgroup of 8 wavefronts
+// is what binds it at 512-B rows.  Here a workgroup of 12 wavefronts
 //   1. stages its CSR pointers and message indices (one coalesced load each, per wavefront) and reduces min / max of its
 //      rhs indices,
 //   2. copies rows [min, max] of rhs into LDS with one contiguous, coalesced sweep (the first `win_rows` of them when the range
@@ -16,7 +16,7 @@
 
 namespace pygho {
 
-constexpr int kWinBlock = 512;                   // 8 wavefronts share one window
+constexpr int kWinBlock = 768;                   // 12 wavefronts share one window
 constexpr int kWinWaves = kWinBlock / kWave;
 constexpr int kWinSegCap = 32;                   // segments per wavefront and pass
 constexpr int kWinMsgCap = 128;                  // message indices staged per wavefront and pass
@@ -60,7 +60,7 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
-// 80 VGPRs: three workgroups (6 wavefronts per SIMD) next to 3 x 49.3 KB of LDS; the scaled form (mean backward) needs more
+// 80 VGPRs: two workgroups of 12 wavefronts (6 per SIMD) next to 2 x 78 KB of LDS; the scaled form (mean backward) needs more
 template <typename T, bool SCALED, bool MEAN>
 __global__ __launch_bounds__(kWinBlock, (SCALED || kWinTrip > 2) ? 4 : (MEAN ? 5 : 6)) void seg_gmr_window_kernel(
     T* __restrict__ out, const T* __restrict__ lhs, const T* __restrict__ rhs, const int32_t* __restrict__ seg_ptr,
@@ -73,7 +73,8 @@ __global__ __launch_bounds__(kWinBlock, (SCALED || kWinTrip > 2) ? 4 : (MEAN ? 5
   __shared__ int32_t s_ptr[kWinWaves][kWinSegCap + 1];
   __shared__ int32_t s_li[kWinWaves][kWinMsgCap];
   __shared__ int32_t s_ri[kWinWaves][kWinMsgCap];
-  __shared__ int32_t s_lo[kWinWaves], s_hi[kWinWaves];
+  __shared__ int32_t s_lo[16], s_hi[16];             // one slot per wavefront; the slots past kWinWaves stay neutral
+  static_assert(kWinWaves <= 16, "min / max slots");
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = threadIdx.x >> 6;
   const int gl = lane & ((1 << log2g) - 1);
@@ -90,6 +91,8 @@ __global__ __launch_bounds__(kWinBlock, (SCALED || kWinTrip > 2) ? 4 : (MEAN ? 5
   int64_t lb = blockIdx.x;
   if ((gridDim.x & 7) == 0) lb = (lb & 7) * (gridDim.x >> 3) + (lb >> 3);
   const int64_t per_wg = (int64_t)kWinWaves * spp;
+  if (threadIdx.x < 16) { s_lo[threadIdx.x] = 0x7fffffff; s_hi[threadIdx.x] = -1; }
+  __syncthreads();
 
   for (int64_t wg_base = lb * per_wg; wg_base < n_seg; wg_base += (int64_t)gridDim.x * per_wg) {       // uniform per workgroup
     const int64_t base = wg_base + (int64_t)wv * spp;
@@ -115,8 +118,8 @@ __global__ __launch_bounds__(kWinBlock, (SCALED || kWinTrip > 2) ? 4 : (MEAN ? 5
     hi = wave_max(hi);
     if (lane == 0) { s_lo[wv] = lo; s_hi[wv] = hi; }
     __syncthreads();
-    const int rmin = wave_min(s_lo[lane & (kWinWaves - 1)]);
-    const int rmax = wave_max(s_hi[lane & (kWinWaves - 1)]);
+    const int rmin = wave_min(s_lo[lane & 15]);
+    const int rmax = wave_max(s_hi[lane & 15]);
     // the window holds rows [rmin, rmin + nwin): all of the pass's rhs rows when they fit, otherwise the first win_rows of them
     // (a pass that straddles two graphs keeps the first graph's edge rows; the rest is gathered from global memory per message)
     const uint32_t nwin = rmax >= rmin ? (uint32_t)min(rmax - rmin + 1, win_rows) : 0u;      // uniform over the workgroup
@@ -185,7 +188,9 @@ __global__ __launch_bounds__(kWinBlock, (SCALED || kWinTrip > 2) ? 4 : (MEAN ? 5
   }
 }
 
-constexpr int kWinLdsBytes = 40 * 1024;                    // window; + 9.3 KB of staging: three workgroups (24 wavefronts) per CU
+constexpr int kWinLdsBytes = 64 * 1024;                    // window (128 rows of 512 B: the edges of two graphs); + 14 KB of staging: two
+                                                           // workgroups (24 wavefronts) per CU.  Measured at the I2 shape: 8 wavefronts + 40 KB x 3
+                                                           // per CU 3250 GB/s, 8 wavefronts + 64 KB x 2 per CU 2600 GB/s, this form 3300 GB/s
 
 template <typename T>
 int launch_window(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx, const int32_t* rhs_idx,
@@ -197,12 +202,12 @@ int launch_window(void* out, const void* lhs, const void* rhs, const int32_t* se
   int64_t spp = 16 * gw;                                   // segments per wavefront and pass (capped below): the window copy and the three
                                                            // barriers of a pass are amortised over its messages (measured at the I2 shape,
                                                            // d = 256 bf16: 2 / 4 / 8 / 16 per lane group -> 1.13 / 0.96 / 0.87 / 0.85 ms)
-  const int64_t even = ceil_div(ceil_div(n_seg, (int64_t)768 * kWinWaves), gw) * gw;
+  const int64_t even = ceil_div(ceil_div(n_seg, (int64_t)512 * kWinWaves), gw) * gw;
   if (even < spp) spp = even;
   if (spp < gw) spp = gw;
   if (spp > kWinSegCap) spp = kWinSegCap;
   const int win_rows = (int)(kWinLdsBytes / (d * (int64_t)sizeof(T)));
-  int gx = grid_for(n_seg, (int)(kWinWaves * spp), 768);  // 3 resident workgroups per CU
+  int gx = grid_for(n_seg, (int)(kWinWaves * spp), 512);  // 2 resident workgroups per CU
   if (gx > 8) gx = (gx + 7) & ~7;
   const bool mean = aggr == PYGHO_MEAN;
 #define PYGHO_WIN(SC, MEAN)                                                                                                     \
