@@ -4,8 +4,9 @@ Model layers built on the operators.  Mirror of ``pygho/honn/Conv.py`` (construc
 stay ``torch.nn``; every aggregation runs on the HIP kernels behind ``TensorOp``.
 
 ``SUNConv`` needs ``torch_geometric.nn.HeteroLinear`` in the reference (Conv.py:15, :345); torch_geometric is
-not a dependency here, so ``HeteroLinear`` is restated below (bias-free per-type linear).  No reference
-test pins that layer: parity is UNPINNED at that boundary.
+not a dependency here, so ``HeteroLinear`` is restated below with torch_geometric 2.3.0's signature (per-type affine
+map, bias on by default).  ``SUNConv`` is pinned to the reference's own forward wiring run around a labelled stand-in
+for that one class (tests/golden/make_golden.py ``gen_sun`` -> sun.npz): pinned modulo the stand-in's arithmetic.
 """
 import math
 from typing import Callable, Literal, Optional, Union
@@ -26,13 +27,21 @@ Rep = Union[SparseTensor, MaskedTensor]
 
 
 class HeteroLinear(Module):
-    """``out[i] = x[i] @ W[type[i]] (+ b[type[i]])``: one linear map per integer type."""
+    """``out[i] = x[i] @ W[type[i]] + b[type[i]]``: one affine map per integer type.  Constructor signature, parameter
+    names and shapes follow ``torch_geometric.nn.HeteroLinear`` of torch_geometric 2.3.0 (the reference's pin,
+    requirements.txt:7): ``(in_channels, out_channels, num_types, is_sorted=False, **kwargs)`` -- the reference's call
+    ``HeteroLinear(7 * indim, indim, 2, False)`` (Conv.py:345) therefore sets ``is_sorted``; ``bias`` is a keyword
+    (default True) -- with ``weight (num_types, in, out)`` and ``bias (num_types, out)``."""
 
-    def __init__(self, in_channels: int, out_channels: int, num_types: int, bias: bool = True):
+    def __init__(self, in_channels: int, out_channels: int, num_types: int, is_sorted: bool = False, **kwargs):
         super().__init__()
         self.in_channels, self.out_channels, self.num_types = in_channels, out_channels, num_types
+        self.is_sorted = is_sorted              # a hint that type_vec is sorted; the result does not depend on it
         self.weight = nn.Parameter(torch.empty(num_types, in_channels, out_channels))
-        self.bias = nn.Parameter(torch.empty(num_types, out_channels)) if bias else None
+        if kwargs.get("bias", True):
+            self.bias = nn.Parameter(torch.empty(num_types, out_channels))
+        else:
+            self.register_parameter("bias", None)
         bound = 1.0 / math.sqrt(in_channels)
         nn.init.uniform_(self.weight, -bound, bound)
         if self.bias is not None:
@@ -368,7 +377,7 @@ class SUNConv(Module):
         concatenation (2.5 GB at b = 1024, n = 37, d = 128) and its 896-wide GEMMs never exist."""
         to_nodes, to_root = self.unpool4subg.forward, self.unpool4rootnode.forward
         d = self.lin1_0.in_channels // 7
-        if self.lin1_0.bias is not None or self.lin1_0.num_types != 2:
+        if self.lin1_0.num_types != 2:
             out = self.forward_concat(A, X, datadict)
             return X.add(out, True) if residual else out
         x_rows = X.values if isinstance(X, SparseTensor) else X.raw
@@ -409,11 +418,18 @@ class SUNConv(Module):
         centre, n5, n6, n7 = self.diag.forward(X), self.pool2node(X), self.pool2subg(X), self.pool2node(agg)
         # concat order of the reference: [X, to_nodes(centre), to_root(centre), agg, to_root(n5), to_nodes(n6), to_root(n7)]
         off = add(lin(X, blk(0, 0)), lin(agg, blk(0, 3)))
-        off = add(off, to_nodes(add(lin(centre, blk(0, 1)), lin(n6, blk(0, 5))), X))
+        bias = self.lin1_0.bias                                  # (2, d) or None: [off-diagonal, diagonal]
+        def nb(rep, t):                      # + b[t] on a node-level tensor (masked rows stay don't-care)
+            if bias is None:
+                return rep
+            if isinstance(rep, MaskedTensor):
+                return MaskedTensor(rep.raw + bias[t].to(rep.raw.dtype), rep.mask)
+            return rep + bias[t].to(rep.dtype)
+        off = add(off, to_nodes(nb(add(lin(centre, blk(0, 1)), lin(n6, blk(0, 5))), 0), X))
         off = add(off, to_root(add(add(lin(centre, blk(0, 2)), lin(n5, blk(0, 4))), lin(n7, blk(0, 6))), X))
         # diagonal tuples (i, i): every view reduces to a node-level tensor there
         dg = add(lin(centre, blk(1, 0) + blk(1, 1) + blk(1, 2)), lin(self.diag.forward(agg), blk(1, 3)))
-        dg = add(add(add(dg, lin(n5, blk(1, 4))), lin(n6, blk(1, 5))), lin(n7, blk(1, 6)))
+        dg = nb(add(add(add(dg, lin(n5, blk(1, 4))), lin(n6, blk(1, 5))), lin(n7, blk(1, 6))), 1)
         dg_t = to_root(dg, X)
         if isinstance(off, MaskedTensor):
             eye = torch.eye(off.shape[1], off.shape[2], dtype=torch.bool, device=off.raw.device).reshape(1, off.shape[1], off.shape[2], 1)
@@ -482,10 +498,15 @@ class SUNConv(Module):
             return y.reshape(parts[0].shape[:-1] + (wt.shape[1],))
 
         # unpooling along dim 1 repeats a node tensor over j (term indexed by i), along dim 0 over i (term indexed by j)
+        # the per-type bias of HeteroLinear rides on the node-level terms: b[0] on the term broadcast to every off-diagonal
+        # tuple, b[1] on the diagonal rows
+        bias = self.lin1_0.bias
         u = node_lin([centre, n6], [blk(0, 1), blk(0, 5)])                                  # to_nodes(...)
         v = node_lin([centre, n5, n7], [blk(0, 2), blk(0, 4), blk(0, 6)])                   # to_root(...)
         dg = node_lin([centre, agg_dg, n5, n6, n7],
                       [blk(1, 0) + blk(1, 1) + blk(1, 2), blk(1, 3), blk(1, 4), blk(1, 5), blk(1, 6)])
+        if bias is not None:
+            u, dg = u + bias[0].to(dt), dg + bias[1].to(dt)
         if dense:
             out = _ops.pair_linear_mix(xv, av, w(0, 0), w(0, 3), u.contiguous(), v.contiguous(), dg.contiguous(), mask)
             return MaskedTensor(out, mask, 0.0, True)

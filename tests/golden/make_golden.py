@@ -13,9 +13,16 @@ Index-planner outputs are stored in canonical form (columns lexsorted by
 deterministic.
 
 ``torch_geometric`` is absent here.  ``pygho.honn.Conv`` imports
-``torch_geometric.nn.HeteroLinear`` at module scope (Conv.py:15) but NGNNConv /
-SSWLConv / I2Conv never use it, so a placeholder module entry is registered to
-let the import succeed; fixtures are only produced for layers that do not touch it.
+``torch_geometric.nn.HeteroLinear`` at module scope (Conv.py:15); NGNNConv /
+SSWLConv / I2Conv / PPGN / GNNAK / DSSGNN never use it.  Only ``SUNConv`` does
+(Conv.py:345, :360-361), so a clearly labelled STAND-IN with torch_geometric
+2.3.0's constructor signature (``in_channels, out_channels, num_types,
+is_sorted=False, **kwargs``; ``bias`` comes from kwargs and defaults to True;
+parameters ``weight (T, in, out)``, ``bias (T, out)``) and its documented
+arithmetic ``out[i] = x[i] @ W[type[i]] + b[type[i]]`` is registered.  The SUN
+fixtures (``sun.npz``) are therefore outputs of the REFERENCE's
+``SUNConv.forward`` wiring around that stand-in: pinned modulo the stand-in's
+arithmetic.
 """
 import os
 import sys
@@ -31,17 +38,43 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, REF)
 sys.path.insert(0, REPO)
 
-# placeholder so that `from torch_geometric.nn import HeteroLinear` resolves
+# STAND-IN (not torch_geometric code): lets `from torch_geometric.nn import HeteroLinear` resolve
 _tg = types.ModuleType("torch_geometric")
 _tgnn = types.ModuleType("torch_geometric.nn")
 
 
-class _Unavailable(torch.nn.Module):
-    def __init__(self, *a, **k):
-        raise RuntimeError("torch_geometric is not available in this container")
+class StandInHeteroLinear(torch.nn.Module):
+    """Stand-in for torch_geometric==2.3.0 ``HeteroLinear`` (requirements.txt:7; not installed): same constructor
+    signature and parameter shapes, the documented per-type affine map, nothing else.  Records its last inputs
+    so that the fixture can pin what the reference's SUNConv wiring feeds it."""
+
+    def __init__(self, in_channels, out_channels, num_types, is_sorted=False, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels, self.num_types, self.is_sorted = in_channels, out_channels, num_types, is_sorted
+        self.weight = torch.nn.Parameter(torch.empty(num_types, in_channels, out_channels))
+        if kwargs.get("bias", True):
+            self.bias = torch.nn.Parameter(torch.empty(num_types, out_channels))
+        else:
+            self.register_parameter("bias", None)
+        bound = 1.0 / in_channels ** 0.5
+        torch.nn.init.uniform_(self.weight, -bound, bound)
+        if self.bias is not None:
+            torch.nn.init.uniform_(self.bias, -bound, bound)
+        self.last_x = self.last_type = None
+
+    def forward(self, x, type_vec):
+        self.last_x, self.last_type = x.detach().clone(), type_vec.detach().clone()
+        out = x.new_zeros(x.shape[0], self.out_channels)
+        for t in range(self.num_types):
+            sel = (type_vec == t).unsqueeze(-1).to(x.dtype)
+            y = x @ self.weight[t]
+            if self.bias is not None:
+                y = y + self.bias[t]
+            out = out + sel * y
+        return out
 
 
-_tgnn.HeteroLinear = _Unavailable
+_tgnn.HeteroLinear = StandInHeteroLinear
 _tg.nn = _tgnn
 sys.modules.setdefault("torch_geometric", _tg)
 sys.modules.setdefault("torch_geometric.nn", _tgnn)
@@ -457,6 +490,74 @@ def gen_layers():
     save("layers.npz", **out)
 
 
+# --------------------------------------------------------------------------
+def gen_sun():
+    """SUNConv (Conv.py:301-362) through the REFERENCE's forward wiring, HeteroLinear = the labelled stand-in above.
+    sun_*   : sparse (SS) layer, pool = mean (the default) on 4 ZINC-shape graphs; sunsum_*: pool = sum.
+    sundd_* : dense (DD) layer.  The reference's MaskedTensor constructor never fills (MaTensor.py:107-120) and
+              mamamm computes the padded rows too (Mamamm.py:52-64), so on a RAGGED padded batch the padded rows of the
+              aggregate leak into pool2node (recorded as sundd_leaky_out: the documented-semantics deviation).  The
+              pinned DD vectors are therefore the reference layer run graph by graph WITHOUT padding (b = 1, n = the
+              graph's own size, BatchNorm in eval mode so graphs are independent), assembled into the padded layout."""
+    out = {}
+    h = 16
+    mlp = {"numlayer": 1, "tailact": True, "norm": "bn", "act": "silu", "dp": 0.0}
+    key = "X___X___1___A___0"
+    hb = synth.make_batch(4, "zinc", seed=45, keys=(key,))
+    N = hb.num_nodes
+    g = torch.Generator().manual_seed(19)
+    ei, tid = T(hb.edge_index), T(hb.tupleid)
+    Av = torch.randn((hb.num_edges, h), generator=g)
+    Xv = torch.randn((hb.num_tuples, h), generator=g)
+    out.update(N=np.int64(N), edge_index=hb.edge_index, tupleid=hb.tupleid, Av=Av.numpy(), Xv=Xv.numpy(), acd=hb.acd[key])
+    dd = {key + "___acd": T(hb.acd[key])}
+    for name, pool, seed in (("sun", "mean", 11), ("sunsum", "sum", 12)):
+        torch.manual_seed(seed)
+        layer = RefConv.SUNConv(h, h, "sum", pool, "SS", dict(mlp), dict(mlp))
+        _randomize_bn(layer, g)
+        layer.eval()
+        for k, v in layer.state_dict().items():
+            out[f"{name}_sd_{k}"] = v.numpy()
+        xv, av = Xv.clone().requires_grad_(True), Av.clone().requires_grad_(True)
+        res = layer(SparseTensor(ei, av, [N, N, h], True), SparseTensor(tid, xv, [N, N, h], True), dd)
+        w = torch.randn(res.values.shape, generator=g)
+        (res.values * w).sum().backward()
+        out[f"{name}_out"], out[f"{name}_w"] = res.values.detach().numpy(), w.numpy()
+        out[f"{name}_gX"], out[f"{name}_gA"] = xv.grad.numpy(), av.grad.numpy()
+        for k, p in layer.named_parameters():
+            out[f"{name}_pg_{k}"] = p.grad.numpy()
+        # what the reference wiring hands to HeteroLinear: the 7-way concatenation and the diagonal-type vector
+        out[f"{name}_cat7"], out[f"{name}_type"] = layer.lin1_0.last_x.numpy(), layer.lin1_0.last_type.numpy()
+    # ---- dense layout --------------------------------------------------------------------------------------
+    dn = synth.make_dense_batch(3, seed=46, hidden=h, clip_nodes=9)
+    Xd, Ad, Xm, Am = T(dn["X"]), T(dn["A"]), T(dn["Xmask"]), T(dn["Amask"])
+    sizes = dn["nodemask"].sum(1)
+    assert len(set(sizes.tolist())) > 1, "the DD fixture must be ragged"
+    out.update(dd_X=dn["X"], dd_A=dn["A"], dd_Xmask=dn["Xmask"], dd_Amask=dn["Amask"])
+    torch.manual_seed(13)
+    layer = RefConv.SUNConv(h, h, "sum", "mean", "DD", dict(mlp), dict(mlp))
+    _randomize_bn(layer, g)
+    layer.eval()
+    for k, v in layer.state_dict().items():
+        out[f"sundd_sd_{k}"] = v.numpy()
+    w = torch.randn(Xd.shape, generator=g) * Xm.unsqueeze(-1)
+    exp, gX, gA = torch.zeros_like(Xd), torch.zeros_like(Xd), torch.zeros_like(Ad)
+    for b, n in enumerate(sizes.tolist()):
+        xg = Xd[b:b + 1, :n, :n].clone().requires_grad_(True)
+        ag = Ad[b:b + 1, :n, :n].clone().requires_grad_(True)
+        res = layer(MaskedTensor(ag, Am[b:b + 1, :n, :n]), MaskedTensor(xg, Xm[b:b + 1, :n, :n]), {})
+        assert bool(res.mask.all())
+        (res.data * w[b:b + 1, :n, :n]).sum().backward()        # parameter gradients accumulate over the graphs
+        exp[b, :n, :n], gX[b, :n, :n], gA[b, :n, :n] = res.data.detach()[0], xg.grad[0], ag.grad[0]
+    out.update(sundd_out=exp.numpy(), sundd_w=w.numpy(), sundd_gX=gX.numpy(), sundd_gA=(gA * Am.unsqueeze(-1)).numpy())
+    for k, p in layer.named_parameters():
+        out[f"sundd_pg_{k}"] = p.grad.numpy()
+    with torch.no_grad():                    # the reference on the padded batch itself: padded rows leak (deviation record)
+        leaky = layer(MaskedTensor(Ad, Am), MaskedTensor(Xd, Xm), {})
+    out["sundd_leaky_out"] = (leaky.data * Xm.unsqueeze(-1)).numpy()
+    save("sun.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(1)
@@ -466,3 +567,4 @@ if __name__ == "__main__":
     gen_sparse_ops()
     gen_masked_ops()
     gen_layers()
+    gen_sun()
