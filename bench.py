@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--distinct", type=int, default=1024, help="distinct graphs generated per rank (tiled up to --graphs)")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "foreach"], help="AdamW implementation (same update rule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-regimes", action="store_true", help="skip the fresh-batch / small-batch side measurements")
+    ap.add_argument("--global-stream", action="store_true",
+                    help="N > 1: ONE global batch of N x --graphs graphs (same seed on every rank), sharded into contiguous graph "
+                         "ranges balanced by message count (parallel.shard_ranges) instead of one independent batch per rank")
     ap.add_argument("--cpu-graphs", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -104,15 +108,144 @@ def cpu_baseline(args, seed):
             "spspmm_fwd_msg_edges_per_sec": hb.num_messages(KEY) * reps / dts}
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the sources of the dominant kernel: a committed PMC traffic figure is only reported for the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("common.h", "seg_reduce.hip"):
+        h.update(open(os.path.join(REPO, "pygho_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
+
+
+def committed_traffic(config):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (tools/collect_traffic.py), or
+    (None, reason) when no file matches this configuration AND the current kernel sources."""
+    import glob
+    want = kernel_source_hash()
+    reason = "no profiles/*_traffic.json for this configuration"
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(f))
+        except Exception:
+            continue
+        if tj.get("config") != config:
+            continue
+        if tj.get("kernel_source_sha256") != want:
+            reason = f"{os.path.basename(f)} was measured on other kernel sources (stale)"
+            continue
+        return tj["traffic_bytes_per_launch"], os.path.basename(f)
+    return None, reason
+
+
+def side_regimes(args, dev):
+    """Outside `value`: the regimes the headline step does not show.  (a) a NEW batch every step -- the reference's loop
+    (example/minimal.py:142-160) -- with device collation and plan preparation one batch ahead on a side stream;
+    (b) the reference's own batch size (128, example/minimal.py:119) and 1024 graphs, eager and as a captured HIP graph."""
+    from pygho_amd import synth
+    from pygho_amd.collate import BatchPrefetcher, DeviceGraphStore
+    from pygho_amd.graphs import GraphedStep
+    from pygho_amd.ngnn import SpModel
+    out = {}
+    act = torch.bfloat16 if args.dtype == "bf16" else None
+
+    def make_step(model, opt, dd_of):
+        def step(dd=None):
+            dd = dd_of() if dd is None else dd
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=act is not None):
+                pred = model(dd)
+            loss = torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float())
+            loss.backward()
+            opt.step()
+            return loss.detach()
+        return step
+
+    # (a) fresh batch every step
+    rng = np.random.default_rng(0)
+    recs = [synth.make_graph(rng, "zinc", 3, (KEY,)) for _ in range(min(1024, args.graphs))]
+    store = DeviceGraphStore(recs * max(2, 2 * args.graphs // len(recs)), dev)
+    torch.manual_seed(0)
+    model = SpModel(1, args.layers, args.hidden, act_dtype=act).to(dev)
+    step = make_step(model, torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True), None)
+    gen = torch.Generator().manual_seed(0)
+    ids = [torch.randperm(store.num_graphs, generator=gen)[:args.graphs] for _ in range(16)]
+    n = 0
+    for k, dd in enumerate(BatchPrefetcher(store, ids, model.prepare)):
+        if k == 4:
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+        step(dd)
+        n += 1
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / (n - 4) * 1e3
+    out["fresh_batch_ms_per_step"] = ms
+    out["fresh_batch_graphs_per_s"] = args.graphs / ms * 1e3
+    out["fresh_batch_note"] = (f"{n - 4} timed steps, every step a different {args.graphs}-graph batch collated on the device from a "
+                               f"resident int32 graph store ({store.num_graphs} graphs), plans prepared one batch ahead on a side stream")
+    del store, model, step
+    # (b) small batches
+    for graphs in (128, 1024):
+        hb = synth.make_batch(graphs, "zinc", seed=7)
+        dd = synth.to_datadict(hb, dev)
+        res = {}
+        for mode in ("eager", "hipgraph"):
+            torch.manual_seed(0)
+            model = SpModel(1, args.layers, args.hidden, act_dtype=act).to(dev)
+            step = make_step(model, torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True), lambda: dd)
+            if mode == "eager":
+                run = step
+                for _ in range(5):
+                    run()
+            else:
+                gs = GraphedStep(step, warmup=3)
+                run = gs.replay
+                run()
+            torch.cuda.synchronize(dev)
+            reps = 50
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                loss = run()
+            torch.cuda.synchronize(dev)
+            res[mode] = (time.perf_counter() - t0) / reps * 1e3
+            assert bool(torch.isfinite(loss))
+        out[f"bs{graphs}"] = {"graphs": graphs, "eager_ms_per_step": res["eager"], "hipgraph_ms_per_step": res["hipgraph"],
+                              "eager_graphs_per_s": graphs / res["eager"] * 1e3, "hipgraph_graphs_per_s": graphs / res["hipgraph"] * 1e3}
+    out["small_batch_note"] = ("same model and full train step on one resident batch; 128 graphs is the reference's batch size "
+                               "(example/minimal.py:119); hipgraph = the whole step captured once (pygho_amd.graphs.GraphedStep) and replayed")
+    return out
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: start N ranks as a CHILD `torch.distributed.run` (one process per
+    GPU, RCCL rendezvous on 127.0.0.1) before this process has touched the GPU, pass its output through and return its
+    exit code.  Nothing is re-exec'ed: the parent never initialises HIP."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()                     # counts devices without initialising the GPU
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -130,7 +263,19 @@ def main():
     # ---- synthetic ZINC-shape batch of this rank, resident in HBM before timing ------------------------
     distinct = min(args.distinct, args.graphs)
     times = max(1, args.graphs // distinct)
-    hb = synth.replicate(synth.make_batch(distinct, "zinc", seed=1000 + rank), times)
+    if args.global_stream and world > 1:
+        # BASELINE config 4's wording: a fixed global batch, sharded by graph.  Every rank generates the same records
+        # and keeps its contiguous range (balanced by message count); the loss below is weighted so that the averaged
+        # gradient equals the gradient of the global mean loss whatever the shard sizes are.
+        from pygho_amd.parallel import shard_ranges
+        rng = np.random.default_rng(1000)
+        recs = [synth.make_graph(rng, "zinc", 3, (KEY,)) for _ in range(distinct)] * (times * world)
+        lo, hi = shard_ranges([r.acd[KEY].shape[1] for r in recs], world)[rank]
+        hb = synth.collate(recs[lo:hi])
+        loss_scale = world * hb.num_graphs / len(recs)
+    else:
+        hb = synth.replicate(synth.make_batch(distinct, "zinc", seed=1000 + rank), times)
+        loss_scale = 1.0
     datadict = synth.to_datadict(hb, dev)
     act_dtype = torch.bfloat16 if args.dtype == "bf16" else None
     torch.manual_seed(0)
@@ -145,7 +290,7 @@ def main():
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=act_dtype is not None):
             pred = model(datadict)
         loss = torch.nn.functional.l1_loss(y, pred.float())
-        loss.backward()
+        (loss if loss_scale == 1.0 else loss * loss_scale).backward()
         sync.sync()
         opt.step()
         return loss
@@ -190,14 +335,8 @@ def main():
         fwd_bytes = es * args.hidden * (2 * hb.num_tuples + hb.num_edges) + 8 * hb.num_messages(KEY) + 4 * (hb.num_tuples + 1)
         # HBM traffic of the dominant kernel: collected OUTSIDE this process in separate rocprofv3 --pmc passes of
         # this very command (FETCH_SIZE corrected by the calibrated gfx950 factor, WRITE_SIZE as is) and committed
-        # under profiles/; reported only when the configuration matches, otherwise null.
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "r01_final_traffic.json")))
-            if tj["config"] == {"graphs_per_gpu": hb.num_graphs, "hidden": args.hidden, "dtype": args.dtype}:
-                traffic = tj["traffic_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        # under profiles/ with the hash of the kernel sources it was measured on; null when configuration or sources differ.
+        traffic, traffic_src = committed_traffic({"graphs_per_gpu": hb.num_graphs, "hidden": args.hidden, "dtype": args.dtype})
         line = {
             "metric": "graphs/sec, ZINC-shape NGNN train step (+ 2-tuple msg-edges/sec and HBM roofline fraction of the spspmm kernel)",
             "value": total_graphs * args.steps / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
@@ -211,12 +350,21 @@ def main():
             "msg_edges_per_sec_train": total_msgs * args.layers * args.steps / elapsed,
             "msg_edges_per_sec_kernel": hb.num_messages(KEY) / (ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "seg_gmr_fast_kernel<bf16,SUM,BOTH>"
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "seg_gmr_fast_kernel<bf16,SUM,BOTH>"
                          if act_dtype is not None else "seg_gmr_fast_kernel<float,SUM,BOTH>",
                          "launches": launches, "avg_ms": ms, "algorithmic_bytes_per_launch": nbytes,
                          "forward_bytes_per_msg_edge": fwd_bytes / hb.num_messages(KEY)},
             "kernels": {k: {"launches": v[0], "avg_ms": v[1], "GBps": v[2] / (v[1] * 1e-3) / 1e9} for k, v in summ.items()},
         }
+        if use_dist:
+            line["collectives"] = {"backend": dist.get_backend(), "allreduce_calls": sync.allreduce_calls,
+                                   "allreduce_bytes": sync.flat.numel() * sync.flat.element_size(),
+                                   "batch": "global stream sharded by message count" if loss_scale != 1.0 or (args.global_stream and world > 1)
+                                   else "one independent batch per rank"}
+        if world == 1 and not args.no_regimes:
+            del datadict, model, opt, sync, y
+            torch.cuda.empty_cache()
+            line["regimes"] = side_regimes(args, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, 1000)
         print(json.dumps(line), flush=True)

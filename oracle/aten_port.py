@@ -45,6 +45,19 @@ def _mlp(h_in, h_out, tailact=True):
     return nn.Sequential(*layers)
 
 
+def port_key(ref_key: str) -> str:
+    """state_dict key of the reference's model (example/minimal.py:37-85 with honn/utils.py MLP naming) -> NGNNPort key."""
+    import re
+    k = ref_key.replace("data_encoder.", "")
+    k = re.sub(r"^subggnns\.(\d+)\.lin\.lins\.0\.", r"convs.\1.0.", k)
+    k = re.sub(r"^subggnns\.(\d+)\.lin\.lins\.1\.norm\.", r"convs.\1.1.", k)
+    k = re.sub(r"^poolmlp\.lins\.0\.", "poolmlp.0.", k)
+    k = re.sub(r"^poolmlp\.lins\.1\.norm\.", "poolmlp.1.", k)
+    k = re.sub(r"^pred_lin\.lins\.(\d+)\.norm\.", r"pred.\1.", k)
+    k = re.sub(r"^pred_lin\.lins\.(\d+)\.", r"pred.\1.", k)
+    return k
+
+
 class NGNNPort(nn.Module):
     """functional twin of pygho_amd.ngnn.SpModel on plain CPU tensors (same layer stack and sizes)."""
 

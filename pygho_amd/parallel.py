@@ -36,6 +36,7 @@ class FlatGradSync:
             self.views.append(self.flat[off:off + n].view_as(p))
             off += n
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.allreduce_calls = 0
 
     def zero_grad(self) -> None:
         for p in self.params:
@@ -57,6 +58,7 @@ class FlatGradSync:
         self.pack()
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.allreduce_calls += 1
             if self.world > 1:
                 self.flat.div_(self.world)
 

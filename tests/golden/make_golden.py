@@ -558,6 +558,76 @@ def gen_sun():
     save("sun.npz", **out)
 
 
+# --------------------------------------------------------------------------
+def gen_model():
+    """BASELINE config 1 / SURVEY 8d config 1: the 6-layer NGNN of example/minimal.py on 16 ZINC-shape graphs, d = 128,
+    f32, one training-mode forward + L1 loss + backward on CPU.  example/minimal.py cannot be imported (it downloads ZINC
+    and needs torch_geometric at module scope), so its model class (minimal.py:22-85) is re-assembled here FROM THE
+    REFERENCE'S OWN operator classes (pygho.honn.Conv.NGNNConv, pygho.honn.utils.MLP, pygho.honn.TensorOp.OpPoolingSubg2D,
+    pygho.backend.utils.torch_scatter_reduce, pygho.SparseTensor): every arithmetic step is reference code."""
+    from pygho.honn.utils import MLP as RefMLP
+    h, layers, key = 128, 6, "X___X___1___A___0"
+
+    class RefEncoder(torch.nn.Module):                  # minimal.py:22-34
+        def __init__(self):
+            super().__init__()
+            self.x_encoder = torch.nn.Embedding(32, h)
+            self.ea_encoder = torch.nn.Embedding(16, h)
+            self.tuplefeat_encoder = torch.nn.Embedding(16, h)
+
+        def forward(self, dd):
+            dd["x"] = self.x_encoder(dd["x"].flatten())
+            dd["A"] = dd["A"].tuplewiseapply(self.ea_encoder)
+            dd["X"] = dd["X"].tuplewiseapply(self.tuplefeat_encoder)
+            return dd
+
+    class RefSpModel(torch.nn.Module):                  # minimal.py:37-85, constructor order kept (parameter init order)
+        def __init__(self, mlp):
+            super().__init__()
+            self.lin_tupleinit0 = torch.nn.Linear(h, h)
+            self.lin_tupleinit1 = torch.nn.Linear(h, h)
+            self.lpool = RefTensorOp.OpPoolingSubg2D("S", "mean")
+            self.poolmlp = RefMLP(h, h, 1, tailact=True, **mlp)
+            self.data_encoder = RefEncoder()
+            self.pred_lin = RefMLP(h, 1, 2, tailact=False, **mlp)
+            mlp.update({"numlayer": 1, "tailact": True})
+            self.subggnns = torch.nn.ModuleList([RefConv.NGNNConv(h, h, "sum", "SS", mlp) for _ in range(layers)])
+
+        def forward(self, dd):
+            dd = self.data_encoder(dd)
+            A, X, x = dd["A"], dd["X"], dd["x"]
+            s0 = X.unpooling_fromdense1dim(0, self.lin_tupleinit0(x))
+            s1 = X.unpooling_fromdense1dim(1, self.lin_tupleinit1(x))
+            X = X.tuplewiseapply(lambda val: s0.values * s1.values * val)
+            for conv in self.subggnns:
+                X = X.add(conv.forward(A, X, dd), True)
+            x = self.poolmlp(self.lpool(X))
+            return self.pred_lin(torch_scatter_reduce(0, x, dd["batch"], dd["num_graphs"], "sum"))
+
+    hb = synth.make_batch(16, "zinc", seed=47, keys=(key,))
+    out = dict(num_nodes=np.int64(hb.num_nodes), num_graphs=np.int64(hb.num_graphs), x=hb.x, batch=hb.batch,
+               edge_index=hb.edge_index, edge_attr=hb.edge_attr, tupleid=hb.tupleid, tuplefeat=hb.tuplefeat, acd=hb.acd[key], y=hb.y)
+    torch.manual_seed(21)
+    model = RefSpModel({"norm": "bn", "act": "silu", "dp": 0.0})
+    model.train()
+    for k, v in model.state_dict().items():
+        out[f"sd_{k}"] = v.numpy().copy()
+    N = hb.num_nodes
+    dd = {"x": T(hb.x), "batch": T(hb.batch), "num_graphs": hb.num_graphs, key + "___acd": T(hb.acd[key]),
+          "A": SparseTensor(T(hb.edge_index), T(hb.edge_attr), [N, N], True),
+          "X": SparseTensor(T(hb.tupleid), T(hb.tuplefeat), [N, N], True)}
+    pred = model(dd)
+    loss = torch.nn.functional.l1_loss(T(hb.y).unsqueeze(-1), pred, reduction="mean")
+    loss.backward()
+    out["pred"], out["loss"] = pred.detach().numpy(), loss.detach().numpy()
+    for k, p in model.named_parameters():
+        out[f"pg_{k}"] = p.grad.numpy()
+    for k, v in model.state_dict().items():             # BatchNorm running statistics after the training-mode forward
+        if "running_" in k:
+            out[f"after_{k}"] = v.numpy().copy()
+    save("ngnn_model.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(1)
@@ -568,3 +638,4 @@ if __name__ == "__main__":
     gen_masked_ops()
     gen_layers()
     gen_sun()
+    gen_model()

@@ -1,0 +1,69 @@
+"""
+bench.py's launch contract.  CPU part: a --gpus N that does not match the launcher's WORLD_SIZE is a hard error, and
+`python bench.py --gpus N` without a launcher refuses when fewer than N GPUs are visible (it never silently runs one rank).
+GPU part: bench.py under `torch.distributed.run --nproc-per-node 1` so that RCCL initialisation, the parameter broadcast and
+the flat gradient all-reduce execute on the hardware; `python bench.py --gpus 2` (self-launched ranks) where two GPUs exist.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(REPO, "bench.py")
+SMALL = ["--steps", "3", "--warmup", "2", "--graphs", "256", "--distinct", "128", "--no-cpu-baseline", "--no-regimes"]
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+    return env
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_world_size_mismatch_is_a_hard_error():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="only meaningful where fewer than 2 GPUs are visible")
+def test_self_launch_refuses_without_enough_gpus():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr and not r.stdout.strip()
+
+
+def _line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_one_rank_uses_rccl():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), BENCH, "--gpus", "1"] + SMALL
+    r = subprocess.run(cmd, env=_env(PYGHO_BENCH_TRACE_COLLECTIVES="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = _line(r.stdout)
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert line["collectives"]["backend"] == "nccl" and line["collectives"]["allreduce_calls"] >= 5
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_bench_self_launches_two_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + SMALL, env=_env(PYGHO_BENCH_TRACE_COLLECTIVES="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = _line(r.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["graphs_per_gpu"] == 256

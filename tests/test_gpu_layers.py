@@ -104,6 +104,36 @@ def test_ppgn_gnnak_dssgnn_match_reference(dev):
            T(g["Xvp"], dev), dd, dev)
 
 
+def test_ngnn_model_matches_reference_model(dev):
+    """BASELINE config 1 replayed on the HIP path: pygho_amd.ngnn.SpModel (f32) loads the REFERENCE model's state_dict
+    strict (example/minimal.py's model assembled from the reference's operator classes, tests/golden/make_golden.py
+    gen_model) and reproduces its training-mode prediction, L1 loss, every parameter gradient and the updated BatchNorm
+    running statistics on 16 ZINC-shape graphs, d = 128."""
+    from pygho_amd import SparseTensor
+    from pygho_amd.ngnn import SpModel
+    g = load_golden("ngnn_model.npz")
+    model = SpModel(1, 6, 128)
+    res = model.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model = model.to(dev).train()
+    n = int(g["num_nodes"])
+    dd = {"x": T(g["x"], dev), "batch": T(g["batch"], dev), "num_graphs": int(g["num_graphs"]), "num_nodes": n,
+          "X___X___1___A___0___acd": T(g["acd"], dev),
+          "A": SparseTensor(T(g["edge_index"], dev), T(g["edge_attr"], dev), [n, n], True),
+          "X": SparseTensor(T(g["tupleid"], dev), T(g["tuplefeat"], dev), [n, n], True)}
+    pred = model(dd)
+    loss = torch.nn.functional.l1_loss(T(g["y"], dev).unsqueeze(-1), pred, reduction="mean")
+    loss.backward()
+    np.testing.assert_allclose(N(pred), g["pred"], **TOL)
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-5)
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(N(p.grad), g[f"pg_{k}"], rtol=2e-4, atol=5e-6, err_msg=k)
+    after = model.state_dict()
+    for k in g.files:
+        if k.startswith("after_"):
+            np.testing.assert_allclose(N(after[k[6:]]), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
 def _sun_check(layer, g, name, A_of, X_of, av, xv, dd, dev, fn="forward", amask=1.0):
     xv, av = xv.clone().requires_grad_(True), av.clone().requires_grad_(True)
     res = getattr(layer, fn)(A_of(av), X_of(xv), dd)
