@@ -137,6 +137,11 @@ def require_device(*tensors) -> torch.device:
             dev = t.device
         elif t.device != dev:
             raise RuntimeError(f"pygho_amd: tensors on different devices ({dev} vs {t.device})")
+    if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
+        # kernels are launched on the CURRENT device with the tensor device's stream: one process drives one GPU
+        # (torch.cuda.set_device(local_rank), as bench.py does); another device needs `with torch.cuda.device(dev):`
+        raise RuntimeError(f"pygho_amd: tensors live on {dev} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "call torch.cuda.set_device(...) or wrap the call in `with torch.cuda.device(...)`")
     return dev
 
 

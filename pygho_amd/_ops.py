@@ -217,7 +217,7 @@ def plan_from_keys(keys: Tensor, n_seg: int, assume_sorted: Optional[bool] = Non
     if assume_sorted is not False:
         err = _flag(dev)
         check(lib().pygho_csr_from_sorted(ptr(seg_ptr), ptr(keys), m, n_seg, ptr(err), st), "csr_from_sorted")
-        if int(err.item()) == 0:
+        if int(_fetch(err)[0]) == 0:             # the probe's synchronisation also carries every pending range flag
             return SegPlan(seg_ptr, None, n_seg, m)
         if assume_sorted:
             raise ValueError("pygho_amd: keys are not sorted / out of range")
@@ -475,6 +475,13 @@ class MessagePlan:
         self.m = acd.shape[1]
         self.n_out, self.n_lhs, self.n_rhs = n_out, n_lhs, n_rhs
         self._a64, self._c64, self._d64 = acd[0], acd[1], acd[2]
+        if self.m > 0:
+            # operand indices must address rows of the operands (the reference's gathers raise IndexError,
+            # Spspmm.py:309-311); the flag rides on the synchronisation of the forward plan's sortedness probe below
+            lo, hi = torch.aminmax(acd[1:3], dim=1)
+            bad = ((lo < 0).any() | (hi[0] >= n_lhs) | (hi[1] >= n_rhs)).to(torch.int32).reshape(1)
+            _PENDING_ERRORS.append((bad, f"pygho_amd: acd operand index out of range (acd[1] must lie in [0, {n_lhs}), "
+                                         f"acd[2] in [0, {n_rhs}))"))
         self.fwd = plan_from_keys(acd[0], n_out)
         a32, c32, d32 = narrow_i32(acd[0]), narrow_i32(acd[1]), narrow_i32(acd[2])
         self.a32, self.c32, self.d32 = a32, c32, d32                 # message order
@@ -833,8 +840,8 @@ class _PairProduct(torch.autograd.Function):
 
 def _grouped(plan: SegPlan, key, *idx32):
     """index arrays re-ordered into the plan's grouped order, memoised on the plan object."""
-    memo = plan._partner
-    if memo is None or memo[0] != key:
+    memo = plan._partner                     # `key`: the index tensor OBJECTS (kept alive by the memo, compared by identity)
+    if memo is None or len(memo[0]) != len(key) or any(a is not b for a, b in zip(memo[0], key)):
         memo = (key, tuple(None if i is None else plan.take(i) for i in idx32))
         plan._partner = memo
     return memo[1]
@@ -848,7 +855,7 @@ def pair_product(left: Tensor, right: Tensor, val: Tensor, row: Tensor, col: Ten
     assert left.dim() == right.dim() == val.dim() == 2
     row32, col32 = narrow_i32(row), narrow_i32(col)
     vidx32 = None if val_index is None else narrow_i32(val_index)
-    key = (id(row32), id(col32), id(vidx32))
+    key = (row32, col32, vidx32)
     p_row = cached_plan(row, left.shape[0], "pair-row")
     p_col = cached_plan(col, right.shape[0], "pair-col", assume_sorted=False)
     by_row = (p_row,) + _grouped(p_row, key, col32, vidx32)

@@ -276,10 +276,13 @@ class SparseTensor:
         if __debug__:
             assert bool(torch.all(torch.diff(self_hash) > 0)), "self is not coalesced"
         c = tarX._cache()
-        k = ("match", taridx, id(self.indices), self.indices._version)
-        if k not in c:
-            c[k] = _ops.sorted_match(self_hash, tarX._hash(taridx))
-        ret = _ops.gather_rows_matched(self.values, c[k])
+        # one entry per projection of tarX; the entry holds the source index tensor itself (identity + version decide a
+        # hit: an id() alone could be recycled by a later transient pattern)
+        k = ("match", taridx)
+        hit = c.get(k)
+        if hit is None or hit[0] is not self.indices or hit[1] != self.indices._version:
+            hit = c[k] = (self.indices, self.indices._version, _ops.sorted_match(self_hash, tarX._hash(taridx)))
+        ret = _ops.gather_rows_matched(self.values, hit[2])
         return tarX.tuplewiseapply(lambda x: ret)
 
     def unpooling_fromdense1dim(self, dims: int, X: Tensor):

@@ -212,7 +212,10 @@ int launch_window(void* out, const void* lhs, const void* rhs, const int32_t* se
   const bool mean = aggr == PYGHO_MEAN;
 #define PYGHO_WIN(SC, MEAN)                                                                                                     \
   do {                                                                                                                         \
-    static bool attr_set = false;                                                                                              \
+    static bool attr_set_dev[64] = {}; /* the attribute is per device; setting it twice is harmless */                         \
+    int cur_dev = 0;                                                                                                           \
+    (void)hipGetDevice(&cur_dev);                                                                                              \
+    bool& attr_set = attr_set_dev[cur_dev & 63];                                                                               \
     if (!attr_set) {                                                                                                           \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_gmr_window_kernel<T, SC, MEAN>),             \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, kWinLdsBytes);                            \

@@ -6,12 +6,16 @@ ctypes work against ~2 ms of GPU work at 1024 graphs).  Every kernel of the libr
 through the C ABI and no entry point synchronises or allocates, so a step on static inputs can be captured once and replayed:
 4.6 -> 2.9 ms per step at 1024 graphs (MI355X).  Requirements (all met by `pygho_amd.ngnn.SpModel` on a fixed `datadict`):
 
-* the same tensors (batch, indices, targets) are reused across replays -- new data is copied INTO them;
+* the same tensors (batch, indices, targets) are reused across replays.  New FEATURE / TARGET values may be copied into them;
+  the INDEX PATTERN must stay what it was at capture: the graph bakes in the plans built from the index tensors during warm-up
+  (CSR pointers, permutations, grid sizes, output row counts).  Pass the index tensors as ``static_indices`` and ``replay()``
+  raises if one of them was written to since capture; a new batch pattern needs a new capture (or the eager
+  ``collate.BatchPrefetcher`` path);
 * the plans are built before capture (the warm-up steps below do that: plan construction reads sizes back to the host);
 * the optimizer is created with ``capturable=True``; gradients are reset with ``set_to_none=True`` inside the step;
 * no host read-back (``.item()``, ``print(loss)``) inside the step -- return tensors and read them after ``replay()``.
 """
-from typing import Any, Callable
+from typing import Any, Callable, Iterable
 
 import torch
 
@@ -19,8 +23,9 @@ import torch
 class GraphedStep:
     """``GraphedStep(fn)`` warms ``fn`` up on a side stream, captures one call into a HIP graph and replays it."""
 
-    def __init__(self, fn: Callable[[], Any], warmup: int = 3):
+    def __init__(self, fn: Callable[[], Any], warmup: int = 3, static_indices: Iterable[torch.Tensor] = ()):
         assert torch.cuda.is_available(), "HIP graph capture needs the ROCm device"
+        self._static = [(t, t._version) for t in static_indices]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -33,5 +38,9 @@ class GraphedStep:
 
     def replay(self) -> Any:
         """run the captured step once more; returns the (static) output tensors of the captured call."""
+        for t, v in self._static:
+            if t._version != v:
+                raise RuntimeError("GraphedStep.replay: an index tensor was modified after capture; the captured launches still "
+                                   "use the plans of the old pattern -- capture a new GraphedStep for the new batch pattern")
         self.graph.replay()
         return self.output

@@ -11,8 +11,18 @@ import torch
 from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
-TOL = dict(rtol=2e-5, atol=2e-5)
-PTOL = dict(rtol=2e-4, atol=2e-4)
+# north_star: "within 1e-5 relative for floating-point aggregation".  Layer outputs and input gradients (values of order 1)
+# are held to rtol = atol = 1e-5.  Parameter gradients are sums over every tuple of the batch with entries up to ~30: they are
+# held to 1e-5 RELATIVE TO THE LARGEST ENTRY of the gradient tensor (an element that cancels to ~0 inside a tensor of order 10
+# cannot be compared to 1e-5 of itself: f32 summation order differs between ATen's GEMM and the kernels here).
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def assert_param_grad(got, exp, err_msg=""):
+    scale = max(float(np.abs(exp).max()), 1.0)
+    np.testing.assert_allclose(got / scale, exp / scale, rtol=1e-5, atol=1e-5, err_msg=err_msg)
+
+
 MLP = {"numlayer": 1, "tailact": True, "norm": "bn", "act": "silu", "dp": 0.0}
 
 
@@ -49,7 +59,7 @@ def _check(layer, g, name, A, mkX, xv, dd, dev, valid=None):
     if valid is None:
         np.testing.assert_allclose(N(xv.grad), g[f"{name}_gX"], **TOL)
         for k, p in layer.named_parameters():
-            np.testing.assert_allclose(N(p.grad), g[f"{name}_pg_{k}"], rtol=2e-4, atol=2e-4, err_msg=k)
+            assert_param_grad(N(p.grad), g[f"{name}_pg_{k}"], err_msg=k)
 
 
 def test_sparse_layers_match_reference(dev):
@@ -127,7 +137,7 @@ def test_ngnn_model_matches_reference_model(dev):
     np.testing.assert_allclose(N(pred), g["pred"], **TOL)
     np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-5)
     for k, p in model.named_parameters():
-        np.testing.assert_allclose(N(p.grad), g[f"pg_{k}"], rtol=2e-4, atol=5e-6, err_msg=k)
+        assert_param_grad(N(p.grad), g[f"pg_{k}"], err_msg=k)
     after = model.state_dict()
     for k in g.files:
         if k.startswith("after_"):
@@ -143,7 +153,7 @@ def _sun_check(layer, g, name, A_of, X_of, av, xv, dd, dev, fn="forward", amask=
     np.testing.assert_allclose(N(xv.grad), g[f"{name}_gX"], **TOL, err_msg=f"{name} {fn} gX")
     np.testing.assert_allclose(N(av.grad) * amask, g[f"{name}_gA"], **TOL, err_msg=f"{name} {fn} gA")
     for k, p in layer.named_parameters():
-        np.testing.assert_allclose(N(p.grad), g[f"{name}_pg_{k}"], **PTOL, err_msg=f"{name} {fn} {k}")
+        assert_param_grad(N(p.grad), g[f"{name}_pg_{k}"], err_msg=f"{name} {fn} {k}")
         p.grad = None
 
 
