@@ -86,7 +86,20 @@ def mamamm(A: MaskedTensor, dim1: int, B: MaskedTensor, dim2: int, mask: BoolTen
     b4, bm, nj, nk2, bkf, restb, _ = _as_bik(Bd, dim2)
     assert nk == nk2, "contracted dims differ"
     nb, d = a4.shape[0], a4.shape[3]
-    om = _ops._mask_u8(mask.contiguous().reshape(nb, ni, nj))
+    # the (b, i, j) uint8 view of the output mask is cached on the mask object: everything derived from a mask (density, extents,
+    # neighbour lists) is cached on its uint8 view, and a fresh view per call cost a reduction + a host synchronisation + the
+    # extents kernel on every contraction (profiles/r02_masked_bmm.md)
+    ocache = getattr(mask, "_pygho_bik", None)
+    if ocache is None:
+        ocache = {}
+        try:
+            mask._pygho_bik = ocache
+        except Exception:
+            pass
+    okey = ("out", mask._version, nb, ni, nj)
+    if okey not in ocache:
+        ocache[okey] = _ops._mask_u8(mask.contiguous().reshape(nb, ni, nj))
+    om = ocache[okey]
     out = _ops.masked_bmm(a4, b4, am, bm, om, nb, ni, nk, nj, d, akf, bkf)
     out = out.reshape((nb,) + resta + restb + dense)
     return MaskedTensor(out, mask, 0.0, True)

@@ -21,7 +21,11 @@
 //
 // Roofline: HBM-bound (arithmetic intensity ~ n/3 flop/B); algorithmic bytes
 //   s*d*nb*(ni*nk + nk*nj + ni*nj) + mask bytes.
+#include <stdlib.h>
+#include <string.h>
+
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -170,6 +174,12 @@ __device__ __forceinline__ void stage_write_at(char* lds, const StageRegs<T>& re
     for (int c = 0; c < CH; ++c) *reinterpret_cast<uint2*>(dst + c * plane) = make_uint2(w[0][c], w[1][c]);
   }
 }
+
+}  // namespace pygho
+
+#include "masked_bmm_blocks.h"      // the multi-block matrix-core form (no LDS): taken whenever d is a multiple of 16 pieces
+
+namespace pygho {
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void masked_bmm_kernel(BmmArgs p) {
@@ -401,6 +411,7 @@ template <typename T>
 int launch_bmm(const BmmArgs& p, int64_t nb, hipStream_t st) {
   using TR = BmmTraits<T>;
   if (p.d % TR::CH != 0) { set_error("masked_bmm: d must be a multiple of %d for this dtype", TR::CH); return PYGHO_ERR_UNSUPPORTED; }
+  if (bmm_blocks_eligible<T>(p)) return launch_bmm_blocks<T>(p, nb, st);
   const int kmax = (int)(p.nk < kKBlock ? p.nk : kKBlock);
   const int kp = bmm_pitch(kmax, sizeof(T));
   const int ri = (int)(p.ni < kTile ? p.ni : kTile), rj = (int)(p.nj < kTile ? p.nj : kTile);

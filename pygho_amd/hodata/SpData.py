@@ -20,12 +20,14 @@ from ..honn.SpOperator import KEYSEP
 
 
 def parseop(op: str):
-    """attribute that counts the rows an operand contributes when graphs are concatenated (reference SpData.py:14-31)"""
-    if op[0] == "X":
+    """attribute that counts the rows an operand contributes when graphs are concatenated (reference SpData.py:14-31).
+    An unknown operand name RAISES ``NotImplementedError``; the reference returns the tuple ``(NotImplementedError, msg)``
+    there (SpData.py:31, evidently a missing ``raise``), which its caller then uses as an attribute name."""
+    if op and op[0] == "X":
         return f"num_tuples{op[1:]}"
     if op == "A":
         return "num_edges"
-    return NotImplementedError, f"operator name {op} not implemented now"
+    raise NotImplementedError(f"operator name {op} not implemented now")
 
 
 def parsekey(key: str) -> Tuple[str, str, int, str, int]:

@@ -193,7 +193,11 @@ def test_masked_bmm_sparse_operand_lists(dev, dtype, shape, layout, sparse_side)
     masks = (_ops._mask_u8(am_st), _ops._mask_u8(bm_st), _ops._mask_u8(T(om, dev)))
     supported = (d * At.element_size()) % 16 == 0
     assert min(_ops._mask_density(m) for m in masks) <= _ops.BMM_LIST_DENSITY
-    got = _ops.masked_bmm(a_st, b_st, *masks, nb, ni, nk, nj, d, akf, bkf)
+    _ops.USE_BMM_BLOCKS = False       # where the multi-block matrix-core kernel is eligible it is preferred over the lists
+    try:
+        got = _ops.masked_bmm(a_st, b_st, *masks, nb, ni, nk, nj, d, akf, bkf)
+    finally:
+        _ops.USE_BMM_BLOCKS = True
     if supported:
         sparse_mask = masks["ABO".index(sparse_side)]
         assert getattr(sparse_mask, "_pygho_lists", None), "the neighbour-list kernel did not run"
@@ -202,10 +206,54 @@ def test_masked_bmm_sparse_operand_lists(dev, dtype, shape, layout, sparse_side)
     np.testing.assert_allclose(N(got), exp, rtol=eps, atol=eps * scale)
     _ops.USE_BMM_LISTS = False
     try:
-        dense = _ops.masked_bmm(a_st, b_st, *masks, nb, ni, nk, nj, d, akf, bkf)
+        dense = _ops.masked_bmm(a_st, b_st, *masks, nb, ni, nk, nj, d, akf, bkf)      # multi-block / 16x16x32 matrix-core kernel
     finally:
         _ops.USE_BMM_LISTS = True
     np.testing.assert_allclose(N(got), N(dense), rtol=eps, atol=eps * scale)
+    np.testing.assert_allclose(N(dense), exp, rtol=eps, atol=eps * scale)                # NaN-planted masked slots never reach it either
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(3, 37, 37, 37, 128), (2, 9, 64, 23, 256), (5, 1, 1, 1, 128), (2, 40, 3, 8, 384), (2, 33, 61, 70, 128)])
+@pytest.mark.parametrize("layout", [(False, True), (True, False)])
+def test_masked_bmm_multiblock_kernel_shapes(dev, dtype, shape, layout):
+    """the multi-block matrix-core kernel (csrc/masked_bmm_blocks.h: rows of whole 256-B multiples, k <= 64): ragged tiles in
+    both output dims, k = 1 / 3 / 61 / 64, two and three channel groups, padded-batch extents with an empty and a full batch
+    element, NaN planted in every masked operand slot, against a float64 einsum; asymmetric operands (a transposed or
+    lane-permuted result cannot pass)."""
+    from pygho_amd import _ops
+    nb, ni, nk, nj, d = shape
+    akf, bkf = layout
+    rng = np.random.default_rng(hash((shape, layout)) % (2 ** 31))
+    A = (rng.standard_normal((nb, ni, nk, d)) + np.arange(d) * 0.01).astype(np.float32)
+    B = (rng.standard_normal((nb, nk, nj, d)) - np.arange(nj)[None, None, :, None] * 0.02).astype(np.float32)
+    am, bm, om = rng.random((nb, ni, nk)) > 0.3, rng.random((nb, nk, nj)) > 0.3, rng.random((nb, ni, nj)) > 0.2
+    if nb > 2:                       # padded-batch structure: one empty element, one clipped to a corner
+        am[0], bm[0], om[0] = False, False, False
+        am[1, ni // 2:], bm[1, :, nj // 2:], om[1, ni // 2:], om[1, :, nj // 2:] = False, False, False, False
+    At, Bt = T(A, dev, dtype), T(B, dev, dtype)
+    Aq, Bq = N(At).astype(np.float64), N(Bt).astype(np.float64)
+    exp = np.einsum("bikd,bkjd->bijd", Aq * am[..., None], Bq * bm[..., None]) * om[..., None]
+    nan = torch.full((), float("nan"), dtype=dtype, device=dev)
+    At = torch.where(T(am, dev)[..., None], At, nan)
+    Bt = torch.where(T(bm, dev)[..., None], Bt, nan)
+    a_st = At.permute(0, 2, 1, 3).contiguous() if akf else At
+    b_st = Bt if bkf else Bt.permute(0, 2, 1, 3).contiguous()
+    am_st = T(am, dev).permute(0, 2, 1).contiguous() if akf else T(am, dev)
+    bm_st = T(bm, dev) if bkf else T(bm, dev).permute(0, 2, 1).contiguous()
+    masks = (_ops._mask_u8(am_st), _ops._mask_u8(bm_st), _ops._mask_u8(T(om, dev)))
+    assert (d * At.element_size()) % 256 == 0 and nk <= 64
+    eps = {torch.float32: 1e-5, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    scale = max(np.abs(exp).max(), 1e-3)
+    for use_ext in (True, False):
+        _ops.USE_BMM_EXTENTS = use_ext
+        try:
+            got = _ops.masked_bmm(a_st, b_st, *masks, nb, ni, nk, nj, d, akf, bkf)
+            nomask = _ops.masked_bmm(torch.nan_to_num(a_st), torch.nan_to_num(b_st), None, None, None, nb, ni, nk, nj, d, akf, bkf)
+        finally:
+            _ops.USE_BMM_EXTENTS = True
+        np.testing.assert_allclose(N(got), exp, rtol=eps, atol=eps * scale)
+        np.testing.assert_allclose(N(nomask) * om[..., None], exp, rtol=eps, atol=eps * scale)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

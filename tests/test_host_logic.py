@@ -142,3 +142,15 @@ def test_window_kernel_dispatch_rule():
         assert not _ops._window_eligible(100_000, lhs, rhs, idx, "sum")
     finally:
         _ops.USE_SEG_WINDOW, _ops.SEG_WINDOW_MIN_ROW_BYTES = saved
+
+
+def test_parsekey_and_parseop():
+    """reference SpData.py:14-53; an unknown operand name raises here (the reference returns a tuple, SpData.py:31)"""
+    import pytest
+    from pygho_amd.hodata.SpData import parsekey, parseop
+    assert parsekey("X___A___1___X___0") == ("X", "A", 1, "X", 0)
+    assert parseop("X") == "num_tuples" and parseop("X1") == "num_tuples1" and parseop("A") == "num_edges"
+    with pytest.raises(NotImplementedError):
+        parseop("B")
+    with pytest.raises(NotImplementedError):
+        parsekey("X___B___1___X___0")

@@ -279,15 +279,33 @@ def mamamm_case(b, n, d, dtype, dev):
     ms = timed(lambda: mamamm(X, 2, A, 1, X.mask))
     bb = X.shape[0]
     es = X.raw.element_size()
-    nbytes = 3 * bb * n * n * d * es + bb * n * n
+    tensor = bb * n * n * d * es
+    dense = 3 * tensor + bb * n * n                       # three full tensors + mask
+    xv, av = float(X.mask.float().mean()), float(A.mask.float().mean())
+    move = (xv + av) * tensor + tensor                    # has to move: unmasked operand rows in, every output row out
     flops = 2 * bb * d * n ** 3
     Xg = MaskedTensor(X.raw.clone().requires_grad_(True), X.mask, 0.0, True)
     Ag = MaskedTensor(A.raw.clone().requires_grad_(True), A.mask, 0.0, True)
     out = mamamm(Xg, 2, Ag, 1, X.mask).data
     g = torch.randn_like(out)
     msb = timed(lambda: torch.autograd.grad(out, (Xg.raw, Ag.raw), g, retain_graph=True), reps=10)
-    return {"op": "mamamm(X,2,A,1) fwd", "b": bb, "n": n, "d": d, "dtype": str(dtype).split(".")[-1], "ms": ms, "alg_MB": nbytes / 1e6,
-            "GBps": nbytes / ms / 1e6, "frac_hbm": nbytes / ms / 1e6 / PEAK, "TFLOPs": flops / ms / 1e9, "bwd_ms": msb}
+    res = [{"op": "mamamm(X,2,A,1) fwd (sparse adjacency mask -> neighbour lists)", "b": bb, "n": n, "d": d,
+            "dtype": str(dtype).split(".")[-1], "ms": ms, "has_to_move_MB": move / 1e6, "GBps": move / ms / 1e6,
+            "frac_hbm": move / ms / 1e6 / PEAK, "dense_MB": dense / 1e6, "frac_hbm_on_dense_bytes": dense / ms / 1e6 / PEAK,
+            "TFLOPs": flops / ms / 1e9, "bwd_ms": msb}]
+    # dense x dense (PPGN / 2-FWL): both operands carry the node-pair mask -> the matrix-core kernel
+    Y = MaskedTensor(torch.randn_like(X.raw) * X.mask.unsqueeze(-1).to(X.raw.dtype), X.mask, 0.0, True)   # a second tensor: X X would alias
+    ms2 = timed(lambda: mamamm(X, 2, Y, 1, X.mask))
+    move2 = 2 * xv * tensor + tensor
+    Xh = MaskedTensor(X.raw.clone().requires_grad_(True), X.mask, 0.0, True)
+    Yh = MaskedTensor(Y.raw.clone().requires_grad_(True), X.mask, 0.0, True)
+    out2 = mamamm(Xh, 2, Yh, 1, X.mask).data
+    msb2 = timed(lambda: torch.autograd.grad(out2, (Xh.raw, Yh.raw), g, retain_graph=True), reps=10)
+    res.append({"op": "mamamm(X,2,Y,1) fwd (dense x dense -> matrix cores)", "b": bb, "n": n, "d": d,
+                "dtype": str(dtype).split(".")[-1], "ms": ms2, "has_to_move_MB": move2 / 1e6, "GBps": move2 / ms2 / 1e6,
+                "frac_hbm": move2 / ms2 / 1e6 / PEAK, "dense_MB": dense / 1e6, "frac_hbm_on_dense_bytes": dense / ms2 / 1e6 / PEAK,
+                "TFLOPs": flops / ms2 / 1e9, "bwd_ms": msb2})
+    return res
 
 
 def main():
@@ -304,9 +322,9 @@ def main():
     out.append(spspmm_case("zinc", 1024 if args.quick else 8192, 128, torch.float32, dev))
     out.append(spspmm_case("zinc", 128, 128, torch.bfloat16, dev))
     out.append(spspmm_case("i2", 256 if args.quick else 2048, 256, torch.bfloat16, dev))
-    out.append(mamamm_case(128, 37, 128, torch.bfloat16, dev))
-    out.append(mamamm_case(128 if args.quick else 1024, 37, 128, torch.bfloat16, dev))
-    out.append(mamamm_case(128 if args.quick else 1024, 37, 128, torch.float32, dev))
+    out.extend(mamamm_case(128, 37, 128, torch.bfloat16, dev))
+    out.extend(mamamm_case(128 if args.quick else 1024, 37, 128, torch.bfloat16, dev))
+    out.extend(mamamm_case(128 if args.quick else 1024, 37, 128, torch.float32, dev))
     out.extend(pooling_case(1024 if args.quick else 8192, 128, torch.bfloat16, dev))
     out.append(spmm_case(1024 if args.quick else 8192, 128, torch.bfloat16, dev))
     out.append(sunconv_case(128, 37, 128, torch.bfloat16, dev))

@@ -36,6 +36,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--b", type=int, default=1024)
+    ap.add_argument("--only", default="", help="run only the cases whose name contains this substring (profiling passes)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     n, d, dt = 37, 128, torch.bfloat16
@@ -53,11 +54,15 @@ def main():
     out = []
 
     def rec(name, fn, alg_bytes, real_bytes=None, flops=None):
+        if args.only and args.only not in name:
+            return
         ms = timed(fn, args.reps)
-        r = {"kernel": name, "ms": ms, "algorithmic_MB": alg_bytes / 1e6, "GBps_algorithmic": alg_bytes / ms / 1e6,
-             "frac_hbm_algorithmic": alg_bytes / ms / 1e6 / 8000.0}
-        if real_bytes is not None:
-            r["unmasked_MB"] = real_bytes / 1e6                    # bytes a mask-aware kernel has to move (masked rows skipped)
+        # frac_hbm is quoted on the bytes that HAVE TO MOVE (unmasked operand rows in + every output row out); the dense
+        # figure of SURVEY.md 8(d) (three full tensors + mask) counts padded rows no mask-aware kernel fetches and is kept
+        # as a second field only
+        move = real_bytes if real_bytes is not None else alg_bytes
+        r = {"kernel": name, "ms": ms, "has_to_move_MB": move / 1e6, "GBps": move / ms / 1e6, "frac_hbm": move / ms / 1e6 / 8000.0,
+             "dense_MB": alg_bytes / 1e6, "frac_hbm_on_dense_bytes": alg_bytes / ms / 1e6 / 8000.0}
         if flops is not None:
             r["TFLOPs"] = flops / ms / 1e9
             r["frac_mfma_peak_bf16_dense"] = flops / ms / 1e9 / 2500.0
@@ -77,7 +82,17 @@ def main():
             return mamamm(X, 2, A, 1, xm)
         finally:
             _ops.USE_BMM_LISTS = True
-    rec("masked_bmm_kernel<bf16> (same contraction on the matrix cores)", dense_path, 3 * tensor + b * n * n, need, flops)
+    rec("masked_bmm matrix-core kernel <bf16> (same contraction X A, dispatch to the lists switched off)", dense_path,
+        3 * tensor + b * n * n, need, flops)
+    # dense x dense: the PPGN / 2-FWL contraction X X (both operands 40 % valid) -- the case the matrix-core kernel serves
+    # (two DIFFERENT tensors: X X would let the second operand's rows hit in L2 and halve the read volume)
+    Y = MaskedTensor(torch.randn_like(xraw) * xm.unsqueeze(-1).to(dt), xm, 0.0, True)
+    rec("masked_bmm matrix-core kernel <bf16> (mamamm(X,2,Y,1): dense x dense, PPGN)", lambda: mamamm(X, 2, Y, 1, xm),
+        3 * tensor + b * n * n, 2 * valid * tensor + tensor, flops)
+    xf, yf = MaskedTensor(xraw.float(), xm, 0.0, True), MaskedTensor(Y.raw.float(), xm, 0.0, True)
+    rec("masked_bmm matrix-core kernel <f32> (mamamm(X,2,Y,1))", lambda: mamamm(xf, 2, yf, 1, xm),
+        2 * (3 * tensor) + b * n * n, 2 * (2 * valid * tensor + tensor), flops)
+    del xf, yf
     rec("masked_fill_vec_kernel", lambda: _ops.masked_fill(xraw, xm, 0.0), 2 * tensor, (1 + valid) * tensor)
     rec("masked_reduce_vec_kernel (sum over dim 1)", lambda: _ops.masked_reduce(xraw, xm, 1, "sum"), tensor, valid * tensor)
     rec("masked_reduce_vec_kernel (sum over dim 2)", lambda: _ops.masked_reduce(xraw, xm, 2, "sum"), tensor, valid * tensor)
@@ -86,7 +101,8 @@ def main():
         lambda: _ops.masked_pair_combine(xraw, node, node, node, True, xm, tuple(xraw.shape), dt, dev), 2 * tensor, (1 + valid) * tensor)
     rec("masked_pair_combine_kernel (views gradient: u + v + diag)",
         lambda: _ops.masked_pair_combine(None, node, node, node, False, xm, tuple(xraw.shape), dt, dev), tensor)
-    meta = {"shape": [b, n, n, d], "dtype": "bfloat16", "tensor_MB": tensor / 1e6, "X_valid_fraction": valid, "A_valid_fraction": a_valid}
+    meta = {"shape": [b, n, n, d], "dtype": "bfloat16", "tensor_MB": tensor / 1e6, "X_valid_fraction": valid, "A_valid_fraction": a_valid,
+            "bmm_variant": os.environ.get("PYGHO_BMM_VARIANT", "blocks (default)")}
     print(json.dumps({"meta": meta, "kernels": out}))
 
 
