@@ -488,6 +488,32 @@ int pygho_bn_act_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* x, cons
                           const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act,
                           void* workspace, int dtype, void* stream);
 
+/* ---- tuple samplers (reference pygho/hodata/SpTupleSampler.py) ------------------------------------------------------------
+ * A block-diagonal batch of graphs: node_ptr (n_graphs + 1) int32 = first node of every graph, node_graph (n_nodes) int32 = the
+ * graph of a node, (rowptr (n_nodes + 1), col) int32 = for every node v the SOURCES of the edges that end in v (global node ids):
+ * the direction k_hop_subgraph walks with flow = 'source_to_target' (SpTupleSampler.py:47-51, :62-66).
+ *
+ * pygho_graph_bfs_dist (SpTupleSampler.py:12-88 for every root at once; with max_hop >= 254 also the all-pairs matrix of :145-150):
+ *   dist + sq_ptr[g] = the (n_g x n_g) matrix of graph g, row = root, as bytes: hop distance if <= max_hop, else 255.
+ *   sq_ptr (n_graphs + 1) int64 = exclusive sum of n_g^2; max_nodes = max n_g <= 255 (the matrix of a graph lives in LDS). */
+int pygho_graph_bfs_dist(uint8_t* dist, const int64_t* sq_ptr, const int32_t* node_ptr, const int32_t* rowptr,
+                         const int32_t* col, int64_t n_graphs, int64_t max_nodes, int max_hop, void* stream);
+/* KhopSampler (SpTupleSampler.py:91-126): count[i] = #{v : dist(i, v) <= hop};  with offset = its exclusive scan,
+ * tupleid (2, n_tuples) int64 = (i, v) sorted, feat (n_tuples) int64 = dist(i, v)  (the coalesced `reduce="min"` result, :126). */
+int pygho_khop_count(int64_t* count, const uint8_t* dist, const int64_t* sq_ptr, const int32_t* node_ptr,
+                     const int32_t* node_graph, int64_t n_nodes, int hop, void* stream);
+int pygho_khop_emit(int64_t* tupleid, int64_t* feat, const int64_t* offset, int64_t n_tuples, const uint8_t* dist,
+                    const int64_t* sq_ptr, const int32_t* node_ptr, const int32_t* node_graph, int64_t n_nodes, int hop,
+                    void* stream);
+/* I2Sampler (SpTupleSampler.py:129-173): for every directed edge e = (src[e], dst[e]) (int32 global ids, sorted by (src, dst))
+ * the nodes v within `hop` of either end; dist must be the full matrix (max_hop = 254).
+ * tupleid (3, n_tuples) int64 = (i, j, v) sorted, feat (n_tuples, 2) int64 = (dist(i, v), dist(j, v))   (:160-163). */
+int pygho_pair_count(int64_t* count, const int32_t* src, const int32_t* dst, int64_t n_edges, const uint8_t* dist,
+                     const int64_t* sq_ptr, const int32_t* node_ptr, const int32_t* node_graph, int hop, void* stream);
+int pygho_pair_emit(int64_t* tupleid, int64_t* feat, const int64_t* offset, int64_t n_tuples, const int32_t* src,
+                    const int32_t* dst, int64_t n_edges, const uint8_t* dist, const int64_t* sq_ptr,
+                    const int32_t* node_ptr, const int32_t* node_graph, int hop, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

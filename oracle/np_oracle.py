@@ -571,3 +571,70 @@ def to_sparse_adj(edge_index: np.ndarray, edge_batch: np.ndarray, edge_attr: np.
     """MaData.py:75-105: indices (3, nnz) = [edge_batch; edge_index], values = edge_attr, shape (b, n, n, *dense)."""
     ind = np.concatenate((edge_batch[None, :], edge_index), axis=0)
     return ind, edge_attr, [batch_size, max_num_nodes, max_num_nodes] + list(edge_attr.shape[1:])
+
+
+# --------------------------------------------------------------------------
+# tuple samplers (pygho/hodata/SpTupleSampler.py)
+# --------------------------------------------------------------------------
+def k_hop_subgraph(roots, num_hops: int, edge_index: np.ndarray, num_nodes: int):
+    """SpTupleSampler.py:12-88 (flow = 'source_to_target'): level h = the SOURCES of the edges whose target is in level
+    h - 1 (levels keep duplicates and already-seen nodes, exactly like the reference); dist[v] = the smallest level v
+    appears in (:68-69 assigns from the last level down to level 0); subset = sorted unique nodes."""
+    col, row = edge_index[0], edge_index[1]
+    levels = [np.atleast_1d(np.asarray(roots, dtype=np.int64))]
+    for _ in range(num_hops):
+        node_mask = np.zeros(num_nodes, dtype=bool)
+        node_mask[levels[-1]] = True
+        levels.append(col[node_mask[row]])
+    dist = np.full(num_nodes, num_nodes + 1, dtype=np.int64)
+    for h in range(num_hops, -1, -1):
+        dist[levels[h]] = h
+    subset = np.unique(np.concatenate(levels))
+    return subset, dist[subset]
+
+
+def khop_sampler(edge_index: np.ndarray, num_nodes: int, hop: int = 2):
+    """KhopSampler (SpTupleSampler.py:91-126): tuples (i, j) for every j within `hop` of root i, feature = hop distance;
+    coalesced (sorted by (i, j))."""
+    ids, feats = [], []
+    for i in range(num_nodes):
+        subset, dist = k_hop_subgraph(i, hop, edge_index, num_nodes)
+        ids.append(np.stack((np.full_like(subset, i), subset)))
+        feats.append(dist)
+    ind, val = np.concatenate(ids, axis=1), np.concatenate(feats)
+    return coalesce(ind, val, "min")
+
+
+def shortest_path_matrix(edge_index: np.ndarray, num_nodes: int) -> np.ndarray:
+    """scipy.sparse.csgraph.shortest_path(directed=False, unweighted=True) (SpTupleSampler.py:145-150) as a BFS over the
+    symmetrised edge list; unreachable = num_nodes + 1 here (the reference's cast of inf to int64 is platform noise; such
+    pairs never enter a sample)."""
+    adj = np.zeros((num_nodes, num_nodes), dtype=bool)
+    adj[edge_index[0], edge_index[1]] = True
+    adj |= adj.T
+    dist = np.full((num_nodes, num_nodes), num_nodes + 1, dtype=np.int64)
+    reach = np.eye(num_nodes, dtype=bool)
+    dist[reach] = 0
+    frontier = reach
+    h = 0
+    while frontier.any():
+        h += 1
+        nxt = ((frontier.astype(np.int64) @ adj.astype(np.int64)) > 0) & ~reach
+        dist[nxt] = h
+        reach |= nxt
+        frontier = nxt
+    return dist
+
+
+def i2_sampler(edge_index: np.ndarray, num_nodes: int, hop: int = 3):
+    """I2Sampler (SpTupleSampler.py:129-173): for every directed edge (i, j) the nodes within `hop` of i or j (pair-rooted
+    k_hop_subgraph), features = (shortest-path distance to i, to j); coalesced (sorted by (i, j, k))."""
+    full = shortest_path_matrix(edge_index, num_nodes)
+    ids, feats = [], []
+    for e in range(edge_index.shape[1]):
+        i, j = int(edge_index[0, e]), int(edge_index[1, e])
+        subset, _ = k_hop_subgraph([i, j], hop, edge_index, num_nodes)
+        ids.append(np.stack((np.full_like(subset, i), np.full_like(subset, j), subset)))
+        feats.append(np.stack((full[i][subset], full[j][subset]), axis=-1))
+    ind, val = np.concatenate(ids, axis=1), np.concatenate(feats, axis=0)
+    return coalesce(ind, val, "min")

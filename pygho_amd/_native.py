@@ -14,7 +14,9 @@ from typing import Optional
 
 import torch
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libpygho_hip.so")
+# PYGHO_AMD_LIB: an A/B build of the same sources (python -m pygho_amd.build --variant NAME -D...), for timing two kernel
+# versions on one box; the product default is the in-tree build
+LIB_PATH = os.environ.get("PYGHO_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libpygho_hip.so")
 
 # enum pygho_dtype / pygho_aggr (include/pygho_hip.h)
 F32, BF16, F16, F64, I64, I32 = 0, 1, 2, 3, 4, 5
@@ -91,6 +93,11 @@ PROTOTYPES = {
     "pygho_weight_grad": (I, [P, P, P, P, L, L, L, I, L, P]),
     "pygho_sum_blocks": (I, [P, P, L, L, P]),
     "pygho_bn_act_bwd_sums": (I, [P, P, P, P, P, P, P, P, L, L, I, P, I, P]),
+    "pygho_graph_bfs_dist": (I, [P, P, P, P, P, L, L, I, P]),
+    "pygho_khop_count": (I, [P, P, P, P, P, L, I, P]),
+    "pygho_khop_emit": (I, [P, P, P, L, P, P, P, P, L, I, P]),
+    "pygho_pair_count": (I, [P, P, P, L, P, P, P, P, I, P]),
+    "pygho_pair_emit": (I, [P, P, P, L, P, P, L, P, P, P, P, I, P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -68,17 +68,26 @@ def up_to_date() -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, variant: str = "", defines=()) -> str:
+    """`variant` + `defines`: an A/B build of the same sources with extra -D flags into _lib/variants/<variant>/ (loaded with
+    PYGHO_AMD_LIB=<path>, see _native.py) so that two kernel versions can be timed on the SAME box in one gpurun call."""
+    if variant:
+        return _build_into(os.path.join(LIBDIR, "variants", variant), list(defines), verbose)
     if not force and up_to_date():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    return _build_into(LIBDIR, [], verbose)
+
+
+def _build_into(libdir: str, defines, verbose: bool) -> str:
+    os.makedirs(libdir, exist_ok=True)
+    objdir = os.path.join(libdir, "obj")
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
+    lib, usage_path = os.path.join(libdir, "libpygho_hip.so"), os.path.join(libdir, "resource_usage.json")
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [cc, *FLAGS, "-Rpass-analysis=kernel-resource-usage", f"-I{INCLUDE}", "-c", src, "-o", obj]
+        cmd = [cc, *FLAGS, *defines, "-Rpass-analysis=kernel-resource-usage", f"-I{INCLUDE}", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         proc = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
@@ -91,19 +100,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
         results = list(ex.map(compile_one, sources()))
     objs = [r[0] for r in results]
     usage = {k: v for r in results for k, v in r[1].items()}
-    with open(USAGE, "w") as f:
+    with open(usage_path, "w") as f:
         json.dump(usage, f, indent=1, sort_keys=True)
     # a register array demoted to scratch turns into HBM traffic (scratch stores are memory writes): the first 16-byte forms of
     # the masked fill / broadcast kernels wrote 2x their output that way.  Our own kernels must not spill -- fail the build.
     spilled = {k: v["scratch_bytes_per_lane"] for k, v in usage.items() if v["scratch_bytes_per_lane"] > 0}
     if spilled:
         raise RuntimeError(f"kernels with scratch (register arrays demoted to memory): {spilled}")
-    cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", *objs, "-o", LIB]
+    cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", *objs, "-o", lib]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    args = sys.argv[1:]
+    variant = args[args.index("--variant") + 1] if "--variant" in args else ""
+    print(build(force="--force" in args, variant=variant, defines=[a for a in args if a.startswith("-D")]))

@@ -47,6 +47,14 @@ __device__ __forceinline__ void row_divmod(int64_t x, int d, int64_t& q, int& r)
   }
 }
 
+// the index of a wavefront inside its workgroup is wavefront-uniform: through readfirstlane everything derived from it (pass
+// bases, staging rows) lives in SGPRs (the LDS-window segment kernel: 80 -> 72 VGPRs)
+#ifndef PYGHO_VECTOR_WAVE_INDEX
+#define PYGHO_WAVE_INDEX(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define PYGHO_WAVE_INDEX(x) (x)
+#endif
+
 // ---- storage types -------------------------------------------------------
 struct bf16 { uint16_t bits; };
 struct f16 { _Float16 v; };

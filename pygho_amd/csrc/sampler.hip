@@ -1,0 +1,228 @@
+// Tuple samplers on the device (reference pygho/hodata/SpTupleSampler.py:91-173).
+//
+// The reference samples one graph at a time on the host: a k-hop breadth-first search per root node (KhopSampler, :91-126)
+// or per directed edge (I2Sampler, :129-173, plus an all-pairs shortest-path matrix for the features), each search a handful
+// of torch calls, the results concatenated and coalesced.  Here a whole block-diagonal batch of graphs is sampled in three
+// launches:
+//
+//   1. pygho_graph_bfs_dist   one workgroup per graph: the (n x n) hop-distance matrix of the graph, all roots at once, in
+//                             LDS (level-synchronous, pull-based: a cell (root, v) that is still unreached looks at v's
+//                             predecessors -- the sources of the edges that end in v, the direction the reference's
+//                             k_hop_subgraph walks with flow = 'source_to_target' -- for one at distance h - 1);
+//   2. pygho_khop_count / pygho_pair_count    tuples per root node / per directed edge (one wavefront each, ballots);
+//      [exclusive scan of the counts by the caller: pygho_exclusive_scan_i64]
+//   3. pygho_khop_emit / pygho_pair_emit      the tuples themselves, written in coalesced (sorted) order: indices int64
+//                             (i, j) / (i, j, k), features int64 hop distance / (distance to i, distance to j).
+//
+// Integer work, bit-exact against the reference's samplers (tests/golden/samplers.npz).  Graphs of up to 255 nodes (the
+// distance matrix of one graph lives in 64 KB of LDS as bytes; 255 = not reached).
+#include "common.h"
+
+namespace pygho {
+
+constexpr int kUnreached = 255;
+
+__global__ __launch_bounds__(kBlock) void graph_bfs_dist_kernel(uint8_t* __restrict__ dist, const int64_t* __restrict__ sq_ptr,
+                                                                const int32_t* __restrict__ node_ptr,
+                                                                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                int max_hop) {
+  extern __shared__ uint8_t s_d[];                     // n * n bytes
+  __shared__ int s_changed;
+  const int g = blockIdx.x;
+  const int base = node_ptr[g], n = node_ptr[g + 1] - base;
+  const int cells = n * n;
+  for (int c = threadIdx.x; c < cells; c += kBlock) s_d[c] = (c / n == c % n) ? 0 : kUnreached;
+  __syncthreads();
+  for (int h = 1; h <= max_hop; ++h) {
+    if (threadIdx.x == 0) s_changed = 0;
+    __syncthreads();
+    bool any = false;
+    for (int c = threadIdx.x; c < cells; c += kBlock) {
+      if (s_d[c] != kUnreached) continue;
+      const int i = c / n, v = c - i * n;
+      const int pb = rowptr[base + v], pe = rowptr[base + v + 1];
+      for (int q = pb; q < pe; ++q) {
+        // a cell written in this level holds h, never h - 1: reading next to the writes is level-synchronous
+        if (s_d[i * n + (col[q] - base)] == h - 1) { s_d[c] = (uint8_t)h; any = true; break; }
+      }
+    }
+    if (any) s_changed = 1;
+    __syncthreads();
+    if (!s_changed) break;
+  }
+  uint8_t* out = dist + sq_ptr[g];
+  for (int c = threadIdx.x; c < cells; c += kBlock) out[c] = s_d[c];
+}
+
+// one wavefront per root node: count[i] = #{v : dist(i, v) <= hop}
+__global__ __launch_bounds__(kBlock) void khop_count_kernel(int64_t* __restrict__ count, const uint8_t* __restrict__ dist,
+                                                            const int64_t* __restrict__ sq_ptr, const int32_t* __restrict__ node_ptr,
+                                                            const int32_t* __restrict__ node_graph, int64_t n_nodes, int hop) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  if (i >= n_nodes) return;
+  const int g = node_graph[i], base = node_ptr[g], n = node_ptr[g + 1] - base;
+  const uint8_t* row = dist + sq_ptr[g] + (int64_t)(i - base) * n;
+  int total = 0;
+  for (int v0 = 0; v0 < n; v0 += kWave) {
+    const int v = v0 + lane;
+    const bool in = v < n && row[v] <= hop;
+    total += __popcll(__builtin_amdgcn_ballot_w64(in));
+  }
+  if (lane == 0) count[i] = total;
+}
+
+__global__ __launch_bounds__(kBlock) void khop_emit_kernel(int64_t* __restrict__ tupleid, int64_t* __restrict__ feat,
+                                                           const int64_t* __restrict__ offset, int64_t n_tuples,
+                                                           const uint8_t* __restrict__ dist, const int64_t* __restrict__ sq_ptr,
+                                                           const int32_t* __restrict__ node_ptr, const int32_t* __restrict__ node_graph,
+                                                           int64_t n_nodes, int hop) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  if (i >= n_nodes) return;
+  const int g = node_graph[i], base = node_ptr[g], n = node_ptr[g + 1] - base;
+  const uint8_t* row = dist + sq_ptr[g] + (int64_t)(i - base) * n;
+  int64_t off = offset[i];
+  for (int v0 = 0; v0 < n; v0 += kWave) {
+    const int v = v0 + lane;
+    const int d = v < n ? row[v] : kUnreached;
+    const bool in = d <= hop;
+    const uint64_t bal = __builtin_amdgcn_ballot_w64(in);
+    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    if (in) {
+      const int64_t t = off + rank;
+      tupleid[t] = i;
+      tupleid[n_tuples + t] = base + v;
+      feat[t] = d;
+    }
+    off += __popcll(bal);
+  }
+}
+
+// one wavefront per directed edge (i, j): the nodes within `hop` of i or of j
+__global__ __launch_bounds__(kBlock) void pair_count_kernel(int64_t* __restrict__ count, const int32_t* __restrict__ src,
+                                                            const int32_t* __restrict__ dst, int64_t n_edges,
+                                                            const uint8_t* __restrict__ dist, const int64_t* __restrict__ sq_ptr,
+                                                            const int32_t* __restrict__ node_ptr, const int32_t* __restrict__ node_graph,
+                                                            int hop) {
+  const int lane = threadIdx.x & 63;
+  const int64_t e = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  if (e >= n_edges) return;
+  const int i = src[e], j = dst[e];
+  const int g = node_graph[i], base = node_ptr[g], n = node_ptr[g + 1] - base;
+  const uint8_t* ri = dist + sq_ptr[g] + (int64_t)(i - base) * n;
+  const uint8_t* rj = dist + sq_ptr[g] + (int64_t)(j - base) * n;
+  int total = 0;
+  for (int v0 = 0; v0 < n; v0 += kWave) {
+    const int v = v0 + lane;
+    const bool in = v < n && min((int)ri[v], (int)rj[v]) <= hop;
+    total += __popcll(__builtin_amdgcn_ballot_w64(in));
+  }
+  if (lane == 0) count[e] = total;
+}
+
+__global__ __launch_bounds__(kBlock) void pair_emit_kernel(int64_t* __restrict__ tupleid, int64_t* __restrict__ feat,
+                                                           const int64_t* __restrict__ offset, int64_t n_tuples,
+                                                           const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                           int64_t n_edges, const uint8_t* __restrict__ dist,
+                                                           const int64_t* __restrict__ sq_ptr, const int32_t* __restrict__ node_ptr,
+                                                           const int32_t* __restrict__ node_graph, int hop) {
+  const int lane = threadIdx.x & 63;
+  const int64_t e = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  if (e >= n_edges) return;
+  const int i = src[e], j = dst[e];
+  const int g = node_graph[i], base = node_ptr[g], n = node_ptr[g + 1] - base;
+  const uint8_t* ri = dist + sq_ptr[g] + (int64_t)(i - base) * n;
+  const uint8_t* rj = dist + sq_ptr[g] + (int64_t)(j - base) * n;
+  int64_t off = offset[e];
+  for (int v0 = 0; v0 < n; v0 += kWave) {
+    const int v = v0 + lane;
+    const int di = v < n ? ri[v] : kUnreached, dj = v < n ? rj[v] : kUnreached;
+    const bool in = min(di, dj) <= hop;
+    const uint64_t bal = __builtin_amdgcn_ballot_w64(in);
+    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    if (in) {
+      const int64_t t = off + rank;
+      tupleid[t] = i;
+      tupleid[n_tuples + t] = j;
+      tupleid[2 * n_tuples + t] = base + v;
+      feat[2 * t] = di;
+      feat[2 * t + 1] = dj;
+    }
+    off += __popcll(bal);
+  }
+}
+
+}  // namespace pygho
+
+using namespace pygho;
+
+static int wave_grid(int64_t items, unsigned& gx) {
+  const int64_t blocks = ceil_div(items, kBlock / kWave);
+  if (blocks > INT32_MAX) { set_error("sampler: grid too large"); return PYGHO_ERR_UNSUPPORTED; }
+  gx = (unsigned)blocks;
+  return PYGHO_OK;
+}
+
+extern "C" int pygho_graph_bfs_dist(uint8_t* dist, const int64_t* sq_ptr, const int32_t* node_ptr, const int32_t* rowptr,
+                                    const int32_t* col, int64_t n_graphs, int64_t max_nodes, int max_hop, void* stream) {
+  if (n_graphs < 0 || max_nodes < 0 || max_hop < 0) { set_error("graph_bfs_dist: negative size"); return PYGHO_ERR_INVALID; }
+  if (n_graphs == 0 || max_nodes == 0) return PYGHO_OK;
+  if (!dist || !sq_ptr || !node_ptr || !rowptr) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (max_nodes > 255) { set_error("graph_bfs_dist: graphs of more than 255 nodes are not supported (got %lld)", (long long)max_nodes); return PYGHO_ERR_UNSUPPORTED; }
+  if (n_graphs > INT32_MAX) { set_error("graph_bfs_dist: grid too large"); return PYGHO_ERR_UNSUPPORTED; }
+  if (max_hop > 254) max_hop = 254;
+  hipLaunchKernelGGL(graph_bfs_dist_kernel, dim3((unsigned)n_graphs), dim3(kBlock), (size_t)(max_nodes * max_nodes), (hipStream_t)stream,
+                     dist, sq_ptr, node_ptr, rowptr, col, max_hop);
+  return check_launch("graph_bfs_dist");
+}
+
+extern "C" int pygho_khop_count(int64_t* count, const uint8_t* dist, const int64_t* sq_ptr, const int32_t* node_ptr,
+                                const int32_t* node_graph, int64_t n_nodes, int hop, void* stream) {
+  if (n_nodes < 0 || hop < 0) { set_error("khop_count: negative size"); return PYGHO_ERR_INVALID; }
+  if (n_nodes == 0) return PYGHO_OK;
+  if (!count || !dist || !sq_ptr || !node_ptr || !node_graph) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  unsigned gx;
+  if (int rc = wave_grid(n_nodes, gx)) return rc;
+  hipLaunchKernelGGL(khop_count_kernel, dim3(gx), dim3(kBlock), 0, (hipStream_t)stream, count, dist, sq_ptr, node_ptr, node_graph, n_nodes,
+                     hop > 254 ? 254 : hop);
+  return check_launch("khop_count");
+}
+
+extern "C" int pygho_khop_emit(int64_t* tupleid, int64_t* feat, const int64_t* offset, int64_t n_tuples, const uint8_t* dist,
+                               const int64_t* sq_ptr, const int32_t* node_ptr, const int32_t* node_graph, int64_t n_nodes, int hop,
+                               void* stream) {
+  if (n_nodes < 0 || n_tuples < 0 || hop < 0) { set_error("khop_emit: negative size"); return PYGHO_ERR_INVALID; }
+  if (n_nodes == 0 || n_tuples == 0) return PYGHO_OK;
+  if (!tupleid || !feat || !offset || !dist || !sq_ptr || !node_ptr || !node_graph) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  unsigned gx;
+  if (int rc = wave_grid(n_nodes, gx)) return rc;
+  hipLaunchKernelGGL(khop_emit_kernel, dim3(gx), dim3(kBlock), 0, (hipStream_t)stream, tupleid, feat, offset, n_tuples, dist, sq_ptr,
+                     node_ptr, node_graph, n_nodes, hop > 254 ? 254 : hop);
+  return check_launch("khop_emit");
+}
+
+extern "C" int pygho_pair_count(int64_t* count, const int32_t* src, const int32_t* dst, int64_t n_edges, const uint8_t* dist,
+                                const int64_t* sq_ptr, const int32_t* node_ptr, const int32_t* node_graph, int hop, void* stream) {
+  if (n_edges < 0 || hop < 0) { set_error("pair_count: negative size"); return PYGHO_ERR_INVALID; }
+  if (n_edges == 0) return PYGHO_OK;
+  if (!count || !src || !dst || !dist || !sq_ptr || !node_ptr || !node_graph) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  unsigned gx;
+  if (int rc = wave_grid(n_edges, gx)) return rc;
+  hipLaunchKernelGGL(pair_count_kernel, dim3(gx), dim3(kBlock), 0, (hipStream_t)stream, count, src, dst, n_edges, dist, sq_ptr, node_ptr,
+                     node_graph, hop > 254 ? 254 : hop);
+  return check_launch("pair_count");
+}
+
+extern "C" int pygho_pair_emit(int64_t* tupleid, int64_t* feat, const int64_t* offset, int64_t n_tuples, const int32_t* src,
+                               const int32_t* dst, int64_t n_edges, const uint8_t* dist, const int64_t* sq_ptr,
+                               const int32_t* node_ptr, const int32_t* node_graph, int hop, void* stream) {
+  if (n_edges < 0 || n_tuples < 0 || hop < 0) { set_error("pair_emit: negative size"); return PYGHO_ERR_INVALID; }
+  if (n_edges == 0 || n_tuples == 0) return PYGHO_OK;
+  if (!tupleid || !feat || !offset || !src || !dst || !dist || !sq_ptr || !node_ptr || !node_graph) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  unsigned gx;
+  if (int rc = wave_grid(n_edges, gx)) return rc;
+  hipLaunchKernelGGL(pair_emit_kernel, dim3(gx), dim3(kBlock), 0, (hipStream_t)stream, tupleid, feat, offset, n_tuples, src, dst, n_edges,
+                     dist, sq_ptr, node_ptr, node_graph, hop > 254 ? 254 : hop);
+  return check_launch("pair_emit");
+}

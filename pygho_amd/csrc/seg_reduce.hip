@@ -23,6 +23,11 @@ enum { MODE_BOTH = 0, MODE_LHS = 1, MODE_RHS = 2 };
 
 constexpr int kSegsPerPass = 64;   // segments a wavefront stages and reduces per pass
 constexpr int kMsgCap = 256;       // message indices staged in LDS per pass (longer passes read the rest from global)
+constexpr int kCountClasses = 10;  // segments of a pass are ordered by min(message count, 9)
+#ifndef PYGHO_SEG_ORDERED
+#define PYGHO_SEG_ORDERED 1
+#endif
+constexpr bool ORDERED = PYGHO_SEG_ORDERED != 0;
 
 // row address: 32-bit byte offsets off a uniform base when the operand is < 4 GiB (one v_mad_u32 instead
 // of a 64-bit multiply-add chain; the kernel is VALU-issue sensitive), 64-bit otherwise
@@ -95,8 +100,9 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
   __shared__ int32_t s_li[kBlock / kWave][kMsgCap];
   __shared__ int32_t s_ri[kBlock / kWave][kMsgCap];
   __shared__ int32_t s_ti[THIRD ? kBlock / kWave : 1][THIRD ? kMsgCap : 1];
+  __shared__ uint8_t s_ord[kBlock / kWave][kSegsPerPass];      // the pass's segments ordered by message count
   const int lane = threadIdx.x & (kWave - 1);
-  const int wv = threadIdx.x >> 6;
+  const int wv = PYGHO_WAVE_INDEX(threadIdx.x >> 6);      // wavefront-uniform: what derives from it lives in SGPRs
   const int gl = lane & ((1 << log2g) - 1);   // lane within the row group: 16-B chunk of the row
   const int grp = lane >> log2g;
   const int gw = kWave >> log2g;              // lane groups (= segments in flight) per wave
@@ -146,12 +152,30 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
         if (THIRD && has_ti) s_ti[wv][j] = third_idx[mbeg + j];
       }
     }
+    // ---- order: the lane groups of a wavefront walk their segments in lockstep, so a round of gw segments costs what its
+    // LONGEST segment costs (ZINC plan: 1.6 trips per round for 1.2 per segment).  The pass's segments are therefore taken in
+    // order of their message count (stable counting sort over the 64 lanes: ballots + prefix counts): the segments of a round
+    // have equal trip counts and the branches of the message loop are wavefront-uniform almost everywhere.  Each segment is
+    // still summed in message order by one lane group: results do not change by a bit.
+    const int nloc = (int)min((int64_t)spp, n_seg - base);
+    if (ORDERED) {
+      const int pn = seg_ptr[min(base + min(lane + 1, spp), n_seg)];
+      const int key = lane < nloc ? min(pn - pv, kCountClasses - 1) : kCountClasses;
+      int pos = 0;
+#pragma unroll
+      for (int k = 0; k < kCountClasses; ++k) {
+        const uint64_t mk = __builtin_amdgcn_ballot_w64(key == k);
+        const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+        pos += key > k ? __popcll(mk) : (key == k ? below : 0);
+      }
+      if (lane < nloc) s_ord[wv][pos] = (uint8_t)lane;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- reduce: lane group `grp` takes segments grp, grp + gw, ... of the pass ------------------------
-    const int nloc = (int)min((int64_t)spp, n_seg - base);
-    for (int i = grp; i < nloc; i += gw) {
+    // ---- reduce: lane group `grp` takes the segments at positions grp, grp + gw, ... of that order -------------------
+    for (int it = grp; it < nloc; it += gw) {
+      const int i = ORDERED ? (int)s_ord[wv][it] : it;
       const int beg = s_ptr[wv][i], end = s_ptr[wv][i + 1];
       float acc[N];
 #pragma unroll
@@ -171,12 +195,23 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
           if (MODE != MODE_LHS && has_ri) { r0 = rhs_idx[m0]; r1 = rhs_idx[m1]; }
           if (THIRD && has_ti) { t0 = third_idx[m0]; t1 = third_idx[m1]; }
         }
-        uint4 la0, la1, rb0, rb1, tc0 = uint4{}, tc1 = uint4{};
-        if (THIRD) { tc0 = load_row16<OFF32>(tbase, t0, row_bytes, col_bytes); tc1 = load_row16<OFF32>(tbase, t1, row_bytes, col_bytes); }
+        uint4 la0, la1 = uint4{}, rb0, rb1 = uint4{}, tc0 = uint4{}, tc1 = uint4{};
         float sc0 = 1.f, sc1 = 1.f;
-        if (MODE != MODE_RHS) { la0 = load_row16<OFF32>(lbase, l0, row_bytes, col_bytes); la1 = load_row16<OFF32>(lbase, l1, row_bytes, col_bytes); }
-        if (MODE != MODE_LHS) { rb0 = load_row16<OFF32>(rbase, r0, row_bytes, col_bytes); rb1 = load_row16<OFF32>(rbase, r1, row_bytes, col_bytes); }
-        if (SCALED) { sc0 = lhs_rowscale[l0]; sc1 = lhs_rowscale[l1]; }
+        if (THIRD) tc0 = load_row16<OFF32>(tbase, t0, row_bytes, col_bytes);
+        if (MODE != MODE_RHS) la0 = load_row16<OFF32>(lbase, l0, row_bytes, col_bytes);
+        if (MODE != MODE_LHS) rb0 = load_row16<OFF32>(rbase, r0, row_bytes, col_bytes);
+        if (SCALED) sc0 = lhs_rowscale[l0];
+        // the second message of an odd-length segment: skipped by a branch (wavefront-uniform almost everywhere now that a
+        // round's segments have equal lengths) in the one- and three-operand forms -- three-operand product 210 -> 193 us,
+        // pooling 136 -> 113 us -- but loaded unconditionally (a duplicate of the first, an L1 hit) in the two-operand form,
+        // where the branch costs the compiler's load batching 30 % (0.248 -> 0.320 ms)
+        constexpr bool SKIP2 = MODE != MODE_BOTH || THIRD;
+        if (!SKIP2 || two) {
+          if (THIRD) tc1 = load_row16<OFF32>(tbase, t1, row_bytes, col_bytes);
+          if (MODE != MODE_RHS) la1 = load_row16<OFF32>(lbase, l1, row_bytes, col_bytes);
+          if (MODE != MODE_LHS) rb1 = load_row16<OFF32>(rbase, r1, row_bytes, col_bytes);
+          if (SCALED) sc1 = lhs_rowscale[l1];
+        }
         if (ACTSIDE) {
           accumulate16<T, AGGR, MODE, SCALED, THIRD, ACTSIDE>(acc, la0, rb0, sc0, tc0, reinterpret_cast<const float(*)[N]>(&asc),
                                                               reinterpret_cast<const float(*)[N]>(&ash), act);

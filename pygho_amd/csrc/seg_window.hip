@@ -24,6 +24,11 @@ constexpr int kWinMsgCap = 128;                  // message indices staged per w
 #define PYGHO_WIN_TRIP 2
 #endif
 constexpr int kWinTrip = PYGHO_WIN_TRIP;         // messages of a segment in flight per trip
+constexpr int kWinClasses = 12;                  // segments are ordered by min(message count, 11)
+#ifndef PYGHO_SEG_ORDERED
+#define PYGHO_SEG_ORDERED 1
+#endif
+constexpr bool kWinOrdered = PYGHO_SEG_ORDERED != 0;
 
 template <bool OFF32>
 __device__ __forceinline__ uint4 win_load_row16(const char* __restrict__ base, int idx, uint32_t row_bytes, uint32_t col_bytes) {
@@ -74,9 +79,10 @@ __global__ __launch_bounds__(kWinBlock, (SCALED || kWinTrip > 2) ? 4 : (MEAN ? 5
   __shared__ int32_t s_li[kWinWaves][kWinMsgCap];
   __shared__ int32_t s_ri[kWinWaves][kWinMsgCap];
   __shared__ int32_t s_lo[16], s_hi[16];             // one slot per wavefront; the slots past kWinWaves stay neutral
+  __shared__ uint8_t s_ord[kWinWaves][kWinSegCap];   // a wavefront's segments of the pass ordered by message count
   static_assert(kWinWaves <= 16, "min / max slots");
   const int lane = threadIdx.x & (kWave - 1);
-  const int wv = threadIdx.x >> 6;
+  const int wv = PYGHO_WAVE_INDEX(threadIdx.x >> 6);      // wavefront-uniform: everything derived from it lives in SGPRs
   const int gl = lane & ((1 << log2g) - 1);
   const int grp = lane >> log2g;
   const int gw = kWave >> log2g;
@@ -101,6 +107,21 @@ __global__ __launch_bounds__(kWinBlock, (SCALED || kWinTrip > 2) ? 4 : (MEAN ? 5
     const int pend = seg_ptr[min(base + spp, n_seg)];
     s_ptr[wv][min(lane, kWinSegCap)] = pv;                 // spp <= kWinSegCap: lanes beyond it rewrite the last slot with ...
     if (lane == 0) s_ptr[wv][spp] = pend;                  // ... a value lane 0 then fixes (same wave: program order)
+    // the lane groups walk their segments in lockstep: take the pass's segments in order of their message count (stable
+    // counting sort over the lanes), so that the segments of one round have equal trip counts (seg_reduce.hip)
+    const int nloc = (int)max((int64_t)0, min((int64_t)spp, n_seg - base));
+    if (kWinOrdered) {
+      const int pn = seg_ptr[min(base + min(lane + 1, spp), n_seg)];
+      const int key = lane < nloc ? min(pn - pv, kWinClasses - 1) : kWinClasses;
+      int pos = 0;
+#pragma unroll 1
+      for (int k = 0; k < kWinClasses; ++k) {      // not unrolled: the kernel lives at the 80-register limit of 6 wavefronts per SIMD
+        const uint64_t mk = __builtin_amdgcn_ballot_w64(key == k);
+        const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+        pos += key > k ? __popcll(mk) : (key == k ? below : 0);
+      }
+      if (lane < nloc) s_ord[wv][pos] = (uint8_t)lane;
+    }
     const int mbeg = __builtin_amdgcn_readfirstlane(pv);
     const int nmsg = __builtin_amdgcn_readfirstlane(pend) - mbeg;
     const bool staged = nmsg <= kWinMsgCap;                // wave-uniform
@@ -131,8 +152,11 @@ __global__ __launch_bounds__(kWinBlock, (SCALED || kWinTrip > 2) ? 4 : (MEAN ? 5
     }
     __syncthreads();
     // ---- reduce: lane group `grp` takes segments grp, grp + gw, ... of this wavefront's pass ---------------------------
-    const int nloc = (int)max((int64_t)0, min((int64_t)spp, n_seg - base));
-    for (int i = grp; i < nloc; i += gw) {
+    const int rounds = (nloc + gw - 1) >> (6 - log2g);            // gw = 64 >> log2g segments per round; the counter is scalar
+    for (int t = 0; t < rounds; ++t) {
+      const int it = t * gw + grp;
+      if (it >= nloc) continue;
+      const int i = kWinOrdered ? (int)s_ord[wv][it] : it;
       const int beg = s_ptr[wv][i], end = s_ptr[wv][i + 1];
       float acc[N];
 #pragma unroll

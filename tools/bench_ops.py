@@ -120,6 +120,29 @@ def graph_step_case(graphs, dev):
             "graphs_per_s_eager": graphs / eager * 1e3, "graphs_per_s_graph": graphs / graphed * 1e3}
 
 
+def sampler_case(kind, graphs, dev):
+    """device tuple sampler (SpTupleSampler.py:91-173) on a whole batch: k-hop (ZINC shape) or pair-rooted (I2 shape) tuples +
+    distance features from the edge list.  Wall time per batch (three host syncs size the outputs)."""
+    import time
+    from pygho_amd.hodata import i2_sample, khop_sample
+    base = 1024 if kind == "zinc" else 128
+    hb = synth.replicate(synth.make_batch(min(graphs, base), kind, seed=1), max(1, graphs // base))
+    ei, nb = torch.from_numpy(hb.edge_index).to(dev), torch.from_numpy(hb.batch).to(dev)
+    fn = khop_sample if kind == "zinc" else i2_sample
+    tid, tf = fn(ei, hb.num_nodes, 3, nb)
+    assert tid.shape[1] == hb.num_tuples
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        fn(ei, hb.num_nodes, 3, nb)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ms = sorted(ts)[len(ts) // 2]
+    return {"op": f"device tuple sampler ({'KhopSampler' if kind == 'zinc' else 'I2Sampler'}, hop 3) {kind}", "graphs": hb.num_graphs,
+            "nodes": hb.num_nodes, "edges": hb.num_edges, "tuples": hb.num_tuples, "ms": ms, "tuples_per_s": hb.num_tuples / ms * 1e3}
+
+
 def planner_case(kind, graphs, dev):
     """device planner (Spspmm.py:57-222): tuple pattern x adjacency -> (tarind, bcd) -> acd on the tuple pattern.
     Wall time per batch (includes the two host syncs that size the outputs)."""
@@ -331,6 +354,8 @@ def main():
     out.append(sunconv_case(128 if args.quick else 1024, 37, 128, torch.bfloat16, dev))
     out.append(graph_step_case(1024, dev))
     out.append(fresh_batch_case(1024 if args.quick else 8192, dev))
+    out.append(sampler_case("zinc", 1024 if args.quick else 8192, dev))
+    out.append(sampler_case("i2", 256 if args.quick else 2048, dev))
     out.append(planner_case("zinc", 1024 if args.quick else 8192, dev))
     out.append(collate_case(1024 if args.quick else 8192, dev))
     out.append(dense_collate_case(128 if args.quick else 1024, 37, 128, dev))
