@@ -135,7 +135,7 @@ def test_ngnn_model_matches_reference_model(dev):
     loss = torch.nn.functional.l1_loss(T(g["y"], dev).unsqueeze(-1), pred, reduction="mean")
     loss.backward()
     np.testing.assert_allclose(N(pred), g["pred"], **TOL)
-    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-5)
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-5)
     for k, p in model.named_parameters():
         assert_param_grad(N(p.grad), g[f"pg_{k}"], err_msg=k)
     after = model.state_dict()

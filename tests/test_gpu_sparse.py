@@ -678,9 +678,20 @@ def test_window_kernel_bit_identical(dev, dtype, d, aggr):
     for name in ("i2", "spread"):
         for got, want in zip(out[(name, True)], out[(name, False)]):
             assert torch.equal(got, want), name
+    # directly against the oracle on the I2 plan (not only through the gather-everything kernel): f32 bit for bit; 16-bit
+    # operands: the oracle on the operands' exact values in f32, the kernel's result within one rounding of the output type,
+    # and both gradients (the two transposed plans, also through the window kernel) against the oracle's
+    want = O.spspmm_values(N(xv.float()), N(av.float()), acd_np, nt, aggr)
+    got = out[("i2", True)][0]
     if dtype == torch.float32:
-        want = O.spspmm_values(N(xv), N(av), acd_np, nt, aggr)
-        assert np.array_equal(N(out[("i2", True)][0]), want)
+        assert np.array_equal(N(got), want)
+    else:
+        ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        np.testing.assert_allclose(N(got.float()), want, rtol=ulp, atol=ulp * np.abs(want).max() * 2.0 ** -6)
+    gx_want, ga_want = O.spspmm_values_grad(N(xv.float()), N(av.float()), acd_np, nt, aggr, N(g.float()))
+    tol = dict(rtol=1e-5, atol=1e-4) if dtype == torch.float32 else dict(rtol=2.0 ** -7, atol=2.0 ** -7 * max(np.abs(gx_want).max(), np.abs(ga_want).max()) * 0.25)
+    np.testing.assert_allclose(N(out[("i2", True)][1].float()), gx_want, **tol)
+    np.testing.assert_allclose(N(out[("i2", True)][2].float()), ga_want, **tol)
 
 
 def test_window_kernel_long_and_empty_segments(dev):
