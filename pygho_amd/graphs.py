@@ -14,6 +14,12 @@ through the C ABI and no entry point synchronises or allocates, so a step on sta
 * the plans are built before capture (the warm-up steps below do that: plan construction reads sizes back to the host);
 * the optimizer is created with ``capturable=True``; gradients are reset with ``set_to_none=True`` inside the step;
 * no host read-back (``.item()``, ``print(loss)``) inside the step -- return tensors and read them after ``replay()``.
+
+Several captured steps (one per fixed mini-batch, ``examples/minimal.py``): a caveat of this PyTorch 2.10 / ROCm 7.2 build, not of
+the kernels here -- with four or more captured steps sharing one capturable AdamW, an EAGER kernel launched between replays
+(even ``torch.full((1,), 7.0)``) makes later replays return NaN unless ``torch.cuda.synchronize()`` (device-wide; a stream
+synchronisation is not enough) runs after it.  Reproduced with a plain ``torch.nn.Sequential`` model; form statistics on the host
+(``float(loss)``) or synchronise the device after eager work, before the next ``replay()``.
 """
 from typing import Any, Callable, Iterable
 

@@ -83,3 +83,70 @@ def test_flat_views_alias_parameter_grads():
     sync.sync()
     n0 = sum(p.numel() for p in model[0].parameters())
     assert float(sync.flat[:n0].abs().sum()) > 0 and float(sync.flat[n0:].abs().sum()) == 0
+
+# ---- BASELINE config 4's wording: ONE global batch stream sharded by graph, balanced by message count -----------------------
+def _global_records():
+    import numpy as np
+    from pygho_amd import synth
+    rng = np.random.default_rng(11)
+    return [synth.make_graph(rng, "zinc", 3, ("X___X___1___A___0",)) for _ in range(12)]
+
+
+def _ngnn_step_inputs(records):
+    import numpy as np
+    from pygho_amd import synth
+    hb = synth.collate(records)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    return hb, (t(hb.x), t(hb.edge_attr), t(hb.tupleid), t(hb.tuplefeat), t(hb.acd["X___X___1___A___0"]), t(hb.batch), hb.num_graphs)
+
+
+def _port_model():
+    from oracle import aten_port as P
+    torch.manual_seed(3)
+    m = P.NGNNPort(16, 2)
+    m.eval()                     # BatchNorm per rank differs from BatchNorm over the global batch by design (no SyncBN in the reference)
+    return m
+
+
+def _sharded_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    recs = _global_records()
+    lo, hi = shard_ranges([r.acd["X___X___1___A___0"].shape[1] for r in recs], world)[rank]
+    hb, args = _ngnn_step_inputs(recs[lo:hi])
+    model = _port_model()
+    sync = FlatGradSync(model.parameters())
+    sync.broadcast_params(0)
+    sync.zero_grad()
+    pred = model(*args)
+    y = torch.from_numpy(hb.y).unsqueeze(-1)
+    # weight of this shard: the averaged gradient must be the gradient of the GLOBAL mean loss whatever the shard sizes are
+    loss = torch.nn.functional.l1_loss(y, pred) * (world * hb.num_graphs / len(recs))
+    loss.backward()
+    sync.sync()
+    ret[rank] = (lo, hi, sync.flat.clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_stream_sharded_by_message_count_equals_single_process():
+    """bench.py --global-stream: every rank collates its own contiguous graph range (offsets restart at 0, plans are rank-local),
+    ranges balanced by message count (unequal graph counts), losses weighted by shard size: the flat all-reduced gradient equals
+    the gradient of the global mean loss computed by one process on the whole batch.  The model is the CPU port of the
+    benchmark's NGNN (oracle/aten_port.py, test infrastructure)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sharded_worker, args=(2, port, ret), nprocs=2, join=True)
+    (lo0, hi0, flat0), (lo1, hi1, flat1) = ret[0], ret[1]
+    assert lo0 == 0 and hi0 == lo1 and hi1 == 12 and 0 < hi0 < 12
+    torch.testing.assert_close(flat0, flat1, rtol=0, atol=0)          # both ranks hold the same averaged gradient
+    hb, args = _ngnn_step_inputs(_global_records())
+    model = _port_model()
+    sync = FlatGradSync(model.parameters())
+    sync.zero_grad()
+    torch.nn.functional.l1_loss(torch.from_numpy(hb.y).unsqueeze(-1), model(*args)).backward()
+    sync.sync()
+    torch.testing.assert_close(flat0, sync.flat, rtol=1e-5, atol=1e-6)
