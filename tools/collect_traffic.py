@@ -9,8 +9,20 @@ usage: collect_traffic.py <fetch_dir> <write_dir> <kernel_stats.csv> <out.json> 
 """
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():
+    """the same hash bench.py computes: a traffic figure is only reported for the kernel sources it was measured on"""
+    h = hashlib.sha256()
+    for name in ("common.h", "seg_reduce.hip"):
+        h.update(open(os.path.join(REPO, "pygho_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
 
 KERNEL = "seg_gmr_fast_kernel<pygho::bf16, 0, 0, false, true, false, false, 0>"     # <T, SUM, BOTH, !SCALED, OFF32, !OUTF32, !THIRD, no act>
 FETCH_CORRECTION = 1.97
@@ -32,6 +44,7 @@ def main():
     json.dump({
         "kernel": "seg_gmr_fast_kernel<bf16,SUM,BOTH>",
         "config": {"graphs_per_gpu": graphs, "hidden": hidden, "dtype": dtype},
+        "kernel_source_sha256": kernel_source_hash(),
         "launches_profiled": n,
         "FETCH_SIZE_bytes_raw": fetch, "FETCH_SIZE_correction": FETCH_CORRECTION, "WRITE_SIZE_bytes": write,
         "traffic_bytes_per_launch": fetch * FETCH_CORRECTION + write,
