@@ -297,6 +297,7 @@ class LaunchTimer:
         return {k: (v[0], v[1] / v[0], v[2] / v[0]) for k, v in agg.items()}
 
 
+USE_UNIT_TRIPLE = True        # forward of the three-operand tuple initialisation (unit segments) on its own elementwise kernel
 USE_SEG_WINDOW = os.environ.get("PYGHO_SEG_WINDOW", "1") != "0"
 SEG_WINDOW_MIN_ROW_BYTES = int(os.environ.get("PYGHO_SEG_WINDOW_MIN_ROW_BYTES", "512"))
 
@@ -370,10 +371,11 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
     return out
 
 
-def seg_triple(out_rows: int, a: Tensor, b: Tensor, c: Tensor, seg_ptr: Tensor, a_idx: Optional[Tensor],
+def seg_triple(out_rows: int, a: Tensor, b: Tensor, c: Tensor, seg_ptr: Optional[Tensor], a_idx: Optional[Tensor],
                b_idx: Optional[Tensor], c_idx: Optional[Tensor], out_f32: bool = False) -> Tensor:
     """out[s] = sum_{m in seg s} a[a_idx[m]] * b[b_idx[m]] * c[c_idx[m]]  (2-D operands of one dtype and width);
-    `out_f32`: f32 result for 16-bit operands (first level of a long-segment hierarchy)."""
+    `out_f32`: f32 result for 16-bit operands (first level of a long-segment hierarchy).  `seg_ptr = None`: unit segments
+    (message s belongs to output row s): a plain three-row gather-multiply kernel without the segment machinery."""
     dev = require_device(a, b, c, seg_ptr, a_idx, b_idx, c_idx)
     assert a.dim() == b.dim() == c.dim() == 2 and a.shape[1] == b.shape[1] == c.shape[1] and a.dtype == b.dtype == c.dtype
     a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
@@ -806,7 +808,9 @@ class _PairProduct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, left, right, val, row32, col32, vidx32, by_row, by_col, by_val):
         n = row32.numel()
-        out = seg_triple(n, left, right, val, unit_ptr(n, val.device), row32, col32, vidx32)
+        unit_ok = USE_UNIT_TRIPLE and (left.shape[1] * left.element_size()) % 16 == 0 and left.shape[1] * left.element_size() <= 1024 \
+            and left.dtype in (torch.float32, torch.bfloat16, torch.float16)
+        out = seg_triple(n, left, right, val, None if unit_ok else unit_ptr(n, val.device), row32, col32, vidx32)
         ctx.save_for_backward(left, right, val)
         ctx.idx = (row32, col32, vidx32, by_row, by_col, by_val)
         return out

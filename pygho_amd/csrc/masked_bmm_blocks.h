@@ -10,7 +10,7 @@
 //
 // v_mfma_f32_4x4x4_16b_{bf16,f16} / v_mfma_f32_4x4x1_16b_f32 multiply SIXTEEN independent 4x4 blocks per instruction:
 // lane l = 4 * block + r holds row r (A) / column r (B, D) of block `block`, the register elements are k (A, B) or the row
-// (D) -- layout probed on gfx950.  With block = 16-byte channel chunk:
+// (D) -- layout probed on gfx950 (tools/probe_mfma_4x4x4.hip).  With block = 16-byte channel chunk:
 //
 //   * a 16-B piece (8 bf16 channels of ONE position) is exactly what lane (chunk, r) needs: four pieces (k .. k+3) are
 //     byte-permuted IN THE LANE into 8 per-channel 4-k operands, and instruction m of 8 multiplies channel 8*chunk + m

@@ -722,13 +722,83 @@ extern "C" int pygho_seg_sum_f32out(float* out, const void* src, const int32_t* 
   return check_launch("seg_sum_f32out");
 }
 
+namespace pygho {
+// Unit segments (one message per output row): out[t] = (a[ai[t]] * b[bi[t]]) * c[ci[t]] -- the FORWARD of the tuple
+// initialisation (example/minimal.py:62-67).  The segment machinery above (pointer / index staging per pass, ordering, the
+// per-segment loop) is pure overhead when every segment holds exactly one message: 193 us through it against the output's
+// write time.  One lane group per row, 16 B per lane, two rows per thread in flight, grid-stride.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void unit_triple_kernel(T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b,
+                                                             const T* __restrict__ c, const int32_t* __restrict__ ai,
+                                                             const int32_t* __restrict__ bi, const int32_t* __restrict__ ci,
+                                                             int64_t n, int chunks, int log2g, int d) {
+  using V = Vec16<T>;
+  constexpr int N = V::N;
+  const int gl = threadIdx.x & ((1 << log2g) - 1);
+  if (gl >= chunks) return;
+  const uint32_t row_bytes = (uint32_t)d * sizeof(T), col = (uint32_t)gl * 16u;
+  const int64_t rows_per_block = kBlock >> log2g;
+  const int64_t stride = (int64_t)gridDim.x * rows_per_block;
+  const char *ab = reinterpret_cast<const char*>(a), *bb = reinterpret_cast<const char*>(b), *cb = reinterpret_cast<const char*>(c);
+  char* ob = reinterpret_cast<char*>(out);
+  for (int64_t t0 = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> log2g); t0 < n; t0 += 2 * stride) {
+    const int64_t t1 = t0 + stride;
+    const bool two = t1 < n;
+    const int64_t u1 = two ? t1 : t0;
+    const int64_t ia0 = ai ? ai[t0] : t0, ib0 = bi ? bi[t0] : t0, ic0 = ci ? ci[t0] : t0;
+    const int64_t ia1 = ai ? ai[u1] : u1, ib1 = bi ? bi[u1] : u1, ic1 = ci ? ci[u1] : u1;
+    const uint4 a0 = *reinterpret_cast<const uint4*>(ab + ia0 * row_bytes + col), b0 = *reinterpret_cast<const uint4*>(bb + ib0 * row_bytes + col),
+                c0 = *reinterpret_cast<const uint4*>(cb + ic0 * row_bytes + col);
+    const uint4 a1 = *reinterpret_cast<const uint4*>(ab + ia1 * row_bytes + col), b1 = *reinterpret_cast<const uint4*>(bb + ib1 * row_bytes + col),
+                c1 = *reinterpret_cast<const uint4*>(cb + ic1 * row_bytes + col);
+    float x[N], y[N], z[N], r[N];
+    V::unpack(a0, x); V::unpack(b0, y); V::unpack(c0, z);
+#pragma unroll
+    for (int q = 0; q < N; ++q) { const float p = x[q] * y[q]; r[q] = p * z[q]; }
+    *reinterpret_cast<uint4*>(ob + t0 * row_bytes + col) = V::pack(r);
+    if (two) {
+      V::unpack(a1, x); V::unpack(b1, y); V::unpack(c1, z);
+#pragma unroll
+      for (int q = 0; q < N; ++q) { const float p = x[q] * y[q]; r[q] = p * z[q]; }
+      *reinterpret_cast<uint4*>(ob + t1 * row_bytes + col) = V::pack(r);
+    }
+  }
+}
+
+template <typename T>
+int launch_unit_triple(void* out, const void* a, const void* b, const void* c, const int32_t* ai, const int32_t* bi, const int32_t* ci,
+                       int64_t n, int64_t d, hipStream_t st) {
+  const int chunks = (int)(d * sizeof(T) / 16);
+  int log2g = 0;
+  while ((1 << log2g) < chunks) ++log2g;
+  const int64_t rows_per_block = kBlock >> log2g;
+  const int gx = grid_for(n, (int)(2 * rows_per_block), 256 * 16);
+  hipLaunchKernelGGL((unit_triple_kernel<T>), dim3(gx), dim3(kBlock), 0, st, (T*)out, (const T*)a, (const T*)b, (const T*)c, ai, bi, ci, n,
+                     chunks, log2g, (int)d);
+  return check_launch("seg_triple_product(unit)");
+}
+
+}  // namespace pygho
+using namespace pygho;
+
 extern "C" int pygho_seg_triple_product(void* out, const void* a, const void* b, const void* c, const int32_t* seg_ptr,
                                         const int32_t* a_idx, const int32_t* b_idx, const int32_t* c_idx, int64_t n_seg, int64_t d,
                                         int64_t a_rows, int64_t b_rows, int64_t c_rows, int dtype, int out_f32, void* stream) {
   if (n_seg < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
   if (n_seg == 0 || d == 0) return PYGHO_OK;
-  if (!out || !a || !b || !c || !seg_ptr) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (!out || !a || !b || !c) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
+  if (!seg_ptr) {      // unit segments: one message per output row
+    const int64_t es = dtype == PYGHO_F32 ? 4 : ((dtype == PYGHO_BF16 || dtype == PYGHO_F16) ? 2 : 0);
+    if (es == 0 || out_f32 || (d * es) % 16 != 0 || d * es > 1024 ||
+        (((uintptr_t)out | (uintptr_t)a | (uintptr_t)b | (uintptr_t)c) % 16) != 0) {
+      set_error("seg_triple_product: the unit-segment form takes f32 / bf16 / f16 rows of a multiple of 16 bytes (<= 1024), 16-byte aligned");
+      return PYGHO_ERR_UNSUPPORTED;
+    }
+    if (dtype == PYGHO_F32) return launch_unit_triple<float>(out, a, b, c, a_idx, b_idx, c_idx, n_seg, d, st);
+    if (dtype == PYGHO_BF16) return launch_unit_triple<bf16>(out, a, b, c, a_idx, b_idx, c_idx, n_seg, d, st);
+    return launch_unit_triple<f16>(out, a, b, c, a_idx, b_idx, c_idx, n_seg, d, st);
+  }
   switch (dtype) {
     case PYGHO_F32: return dispatch_triple<float, true>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, out_f32 != 0, st);
     case PYGHO_BF16: return dispatch_triple<bf16, true>(out, a, b, c, seg_ptr, a_idx, b_idx, c_idx, n_seg, d, a_rows, b_rows, c_rows, out_f32 != 0, st);

@@ -441,6 +441,12 @@ def test_pair_product_matches_elementwise_chain(dev, dtype):
         for x, y in zip(a, b):
             s = float(y.grad.abs().max())
             torch.testing.assert_close(x.grad.double() / s, y.grad / s, rtol=0, atol=2.0 ** -7)
+    # the forward runs on the unit-segment kernel: same values as through the segment machinery
+    _ops.USE_UNIT_TRIPLE = False
+    try:
+        assert torch.equal(out, _ops.pair_product(left, right, val, row, col))
+    finally:
+        _ops.USE_UNIT_TRIPLE = True
     # generic width (d = 5), f32
     l5, r5, v5 = left.float()[:, :5].contiguous(), right.float()[:, :5].contiguous(), val.float()[:, :5].contiguous()
     assert torch.equal(_ops.pair_product(l5, r5, v5, row, col), l5[row] * r5[col] * v5)
