@@ -43,8 +43,8 @@ def test_self_launch_refuses_without_enough_gpus():
 
 
 def _line(stdout):
-    lines = [l for l in stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, stdout
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), stdout      # stdout carries the JSON line and nothing else (no RCCL banner)
     return json.loads(lines[0])
 
 
