@@ -121,8 +121,33 @@ def lib() -> ctypes.CDLL:
             fn.restype, fn.argtypes = res, args
         if handle.pygho_abi_version() != 1:
             raise BackendUnavailable("pygho_amd: ABI version mismatch, rebuild the extension")
+        if os.environ.get("PYGHO_ROCTX", "0") not in ("", "0"):
+            handle = _RangedLib(handle)
         _lib = handle
     return _lib
+
+
+class _RangedLib:
+    """PYGHO_ROCTX=1: every C-ABI launch is bracketed by a roctx range named after its entry point (torch.cuda.nvtx maps to
+    roctx on ROCm), so `rocprofv3 --marker-trace` groups the kernels by operator family.  Off by default (two extra calls per
+    launch)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __getattr__(self, name):
+        fn = getattr(self._h, name)
+        if name not in PROTOTYPES or name.endswith("_workspace") or PROTOTYPES[name][0] is not I or not PROTOTYPES[name][1]:
+            return fn
+
+        def ranged(*args):
+            torch.cuda.nvtx.range_push(name)
+            try:
+                return fn(*args)
+            finally:
+                torch.cuda.nvtx.range_pop()
+        setattr(self, name, ranged)
+        return ranged
 
 
 def check(rc: int, what: str) -> None:

@@ -298,7 +298,24 @@ class LaunchTimer:
 
 
 USE_UNIT_TRIPLE = True        # forward of the three-operand tuple initialisation (unit segments) on its own elementwise kernel
+DEBUG_INDICES = os.environ.get("PYGHO_DEBUG", "0") not in ("", "0")   # validate every index array of a segment launch (host sync per call)
 USE_SEG_WINDOW = os.environ.get("PYGHO_SEG_WINDOW", "1") != "0"
+
+
+def _debug_check_segments(out_rows: int, seg_ptr: Tensor, idx_rows) -> None:
+    """PYGHO_DEBUG=1: the kernels trust their index arrays (the reference's gathers raise IndexError); this checks, before a launch,
+    that the CSR pointers are monotone from 0 and that every index addresses a row of its operand."""
+    ptr_ok = seg_ptr.numel() == out_rows + 1 and int(seg_ptr[0]) == 0 and bool((seg_ptr[1:] >= seg_ptr[:-1]).all())
+    if not ptr_ok:
+        raise IndexError("pygho_amd (PYGHO_DEBUG): segment pointers are not a monotone CSR array starting at 0")
+    m = int(seg_ptr[-1])
+    for name, idx, rows in idx_rows:
+        if idx is None:
+            if rows is not None and rows < m:
+                raise IndexError(f"pygho_amd (PYGHO_DEBUG): {name} has {rows} rows for {m} messages")
+            continue
+        if idx.numel() < m or (m and (int(idx[:m].min()) < 0 or int(idx[:m].max()) >= rows)):
+            raise IndexError(f"pygho_amd (PYGHO_DEBUG): {name} index out of range [0, {rows})")
 SEG_WINDOW_MIN_ROW_BYTES = int(os.environ.get("PYGHO_SEG_WINDOW_MIN_ROW_BYTES", "512"))
 
 
@@ -321,6 +338,9 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
     act(x * scale + shift) is applied to its rows as they are loaded."""
     ref = lhs if lhs is not None else rhs
     dev = require_device(lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, addend)
+    if DEBUG_INDICES:
+        _debug_check_segments(out_rows, seg_ptr, (("lhs", lhs_idx, None if lhs is None else lhs.shape[0]),
+                                                  ("rhs", rhs_idx, None if rhs is None else rhs.shape[0])))
     d = ref.shape[1]
     out = torch.empty((out_rows, d), dtype=ref.dtype, device=dev)
     timer = LaunchTimer.active

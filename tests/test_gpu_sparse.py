@@ -736,3 +736,30 @@ def test_window_kernel_long_and_empty_segments(dev):
     ref = torch.zeros(n_seg, d, device=dev).index_add_(0, torch.repeat_interleave(torch.arange(n_seg, device=dev), T(lens, dev)),
                                                           lhs.float()[li.long()] * rhs.float()[ri.long()])
     torch.testing.assert_close(out[True][0].float(), ref, rtol=2e-2, atol=2e-1)
+
+
+def test_debug_index_validation_and_roctx_ranges(dev):
+    """PYGHO_DEBUG=1 validates the index arrays of a segment launch before it (the kernels trust them); PYGHO_ROCTX=1 brackets
+    every C-ABI launch with a roctx range.  Both are process-wide switches read at import: exercised in a child process."""
+    import subprocess, sys, os
+    code = r'''
+import torch
+from pygho_amd import _ops, _native
+dev = torch.device("cuda:0")
+x = torch.randn(10, 8, device=dev)
+ptr = torch.tensor([0, 2, 3], dtype=torch.int32, device=dev)
+ok = torch.tensor([0, 9, 5], dtype=torch.int32, device=dev)
+out = _ops.seg_gmr(2, x, None, ptr, ok, None, "sum")
+assert torch.allclose(out, torch.stack((x[0] + x[9], x[5])))
+assert type(_native.lib()).__name__ == "_RangedLib"
+bad = torch.tensor([0, 10, 5], dtype=torch.int32, device=dev)
+try:
+    _ops.seg_gmr(2, x, None, ptr, bad, None, "sum")
+except IndexError as e:
+    print("caught", e)
+else:
+    raise SystemExit("out-of-range index not caught")
+'''
+    env = dict(os.environ, PYGHO_DEBUG="1", PYGHO_ROCTX="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "caught" in r.stdout, r.stderr[-2000:]
