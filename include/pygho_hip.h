@@ -488,6 +488,30 @@ int pygho_bn_act_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* x, cons
                           const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act,
                           void* workspace, int dtype, void* stream);
 
+/* ---- Linear -> BatchNorm1d -> act WITHOUT keeping the pre-activation in HBM (training blocks of honn/utils.py:126-138 as
+ * driven by Conv.py:56; bf16 / f16, d = 64 or 128).  The reference's ATen sequence stores Y = in . W^T + b, normalises it in a
+ * second pass and keeps it for the backward.  Here Y is a value that every pass RECOMPUTES from `in` on the matrix cores (the
+ * product is 43 flop per byte streamed: free next to the stream), bit-identically in all of them:
+ *   forward   pygho_rowblock_linear_autoshift(out = NULL, ...)     statistics of the rounded Y only          in  -> (sums)
+ *             pygho_rowblock_linear_bn_act                         out = act(Y * scale + shift) (+ addend)   in  -> out
+ *   backward  pygho_rowblock_linear_bwd_sums                       sum dz, sum dz * xhat of (Y, gh)          in, gh -> (sums)
+ *             pygho_bn_bwd_linear_dw_recompute                     gx, dW (Y from the staged x tile)         in, gh, addend -> gx
+ * = 3 + 2 + 4 streams of m x d instead of 4 + 2 + 5 with a stored Y.  wl: W row-major ([n][k], torch.nn.Linear layout) in the
+ * first three, wlt = W^T row-major in the last (as in pygho_bn_bwd_linear_dw).  scale / shift: pygho_bn_finalize's outputs.
+ * workspace of _bwd_sums: pygho_rowblock_linear_blocks(m) x 2 x d floats. */
+int pygho_rowblock_linear_bn_act(void* out, const void* in, const void* wl, const void* bias, const float* scale,
+                                 const float* shift, const void* addend, int64_t m, int64_t d, int act, int dtype, void* stream);
+int pygho_rowblock_linear_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* in, const void* wl, const void* bias,
+                                   const void* gh, const float* mean, const float* invstd, const float* w, const float* b,
+                                   int64_t m, int64_t d, int act, float* workspace, int dtype, void* stream);
+int pygho_bn_bwd_linear_dw_recompute(void* gx, float* dw_ws, const void* gh, const void* x, const void* wlt, const void* bias,
+                                     const void* addend, float* colsum_ws, const float* mean, const float* invstd, const float* w,
+                                     const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m, int64_t d, int act,
+                                     int training, int dtype, int64_t ws_stride, void* stream);
+/* folds per-block partial sums ws[blk][0 / 1][c] (n_blocks blocks) into the two channel sums, in double precision (the second
+ * stage of pygho_bn_act_bwd_sums / pygho_rowblock_linear_bwd_sums). */
+int pygho_bn_bwd_fold_sums(float* sum_a, float* sum_b, const float* ws, int64_t c, int64_t n_blocks, void* stream);
+
 /* ---- tuple samplers (reference pygho/hodata/SpTupleSampler.py) ------------------------------------------------------------
  * A block-diagonal batch of graphs: node_ptr (n_graphs + 1) int32 = first node of every graph, node_graph (n_nodes) int32 = the
  * graph of a node, (rowptr (n_nodes + 1), col) int32 = for every node v the SOURCES of the edges that end in v (global node ids):

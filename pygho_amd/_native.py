@@ -93,6 +93,10 @@ PROTOTYPES = {
     "pygho_weight_grad": (I, [P, P, P, P, L, L, L, I, L, P]),
     "pygho_sum_blocks": (I, [P, P, L, L, P]),
     "pygho_bn_act_bwd_sums": (I, [P, P, P, P, P, P, P, P, L, L, I, P, I, P]),
+    "pygho_rowblock_linear_bn_act": (I, [P, P, P, P, P, P, P, L, L, I, I, P]),
+    "pygho_rowblock_linear_bwd_sums": (I, [P, P, P, P, P, P, P, P, P, P, L, L, I, P, I, P]),
+    "pygho_bn_bwd_linear_dw_recompute": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, L, P]),
+    "pygho_bn_bwd_fold_sums": (I, [P, P, P, L, L, P]),
     "pygho_graph_bfs_dist": (I, [P, P, P, P, P, L, L, I, P]),
     "pygho_khop_count": (I, [P, P, P, P, P, L, I, P]),
     "pygho_khop_emit": (I, [P, P, P, L, P, P, P, P, L, I, P]),

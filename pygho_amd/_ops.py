@@ -1651,19 +1651,27 @@ def bn_act_supported(x: Tensor) -> bool:
             and int(lib().pygho_bn_workspace(x.shape[0], x.shape[1], dtype_code(x))) > 0)
 
 
-def _bn_forward(x: Tensor, weight, bias, running_mean, running_var, training: bool, eps: float, act: str,
+def _bn_forward(x: Optional[Tensor], weight, bias, running_mean, running_var, training: bool, eps: float, act: str,
                 fold_momentum: Optional[float] = None, partial: Optional[Tuple[Tensor, Tensor]] = None,
-                apply: bool = True, addend: Optional[Tensor] = None):
+                apply: bool = True, addend: Optional[Tensor] = None, producer=None):
     """(y, mean, var, saved) of act(batch_norm(x)) (+ addend: a residual row added inside the activation pass) for a contiguous 2-D x.  Statistics, 1/sqrt(var + eps), the fused
     scale / shift and (with `fold_momentum`) the running-average update all come out of ONE finalisation kernel;
     `partial` = (per-block shifted sums, their shift) when the producer of x already took the sums (rowblock_linear).
-    `apply=False`: y is not formed; (scale, shift) are returned in its place for a consumer that applies them on load."""
-    dev = x.device
-    m, c = x.shape
-    dt = dtype_code(x)
+    `apply=False`: y is not formed; (scale, shift) are returned in its place for a consumer that applies them on load.
+    `producer=(x_in, wl, lin_bias)` with x = None: the BatchNorm input x_in @ wl^T + lin_bias is NOT in memory; the statistics
+    came from `partial` (training) or are the running ones, and y is produced by recomputing the product inside the
+    activation pass (`rowblock_linear_bn_act`)."""
+    src = x if x is not None else producer[0]
+    dev = src.device
+    m, c = src.shape
+    dt = dtype_code(src)
     st = stream_ptr(dev)
-    nbytes = int(lib().pygho_bn_workspace(m, c, dt))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = None
+    if x is not None:
+        nbytes = int(lib().pygho_bn_workspace(m, c, dt))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    else:
+        assert apply and (partial is not None or not training)
     w32 = None if weight is None else weight.detach().float().contiguous()
     b32 = None if bias is None else bias.detach().float().contiguous()
     if training:
@@ -1685,6 +1693,9 @@ def _bn_forward(x: Tensor, weight, bias, running_mean, running_var, training: bo
               "bn_prepare")
     if not apply:
         return (scale, shift), mean, var, (mean, invstd, w32, b32, ws)
+    if x is None:
+        y = rowblock_linear_bn_act(producer[0], producer[1], producer[2], scale, shift, act, addend)
+        return y, mean, var, (mean, invstd, w32, b32, ws)
     y = torch.empty_like(x)
     if addend is not None:
         check(lib().pygho_bn_act_fwd_add(ptr(y), ptr(x), ptr(addend.contiguous()), ptr(scale), ptr(shift), m, c, ACT_CODE[act], dt, st),
@@ -1819,6 +1830,8 @@ USE_TABLE_PRODUCT = True
 USE_ADJ_TABLE = True     # adjacency values that are an embedding lookup are read through the table inside the fused block
 USE_ACT_ON_LOAD = True   # f32 blocks: BatchNorm + activation applied inside the aggregation kernel's loads
 USE_BN_BWD_LINEAR = True
+USE_RECOMPUTE_PRE = os.environ.get("PYGHO_RECOMPUTE_PRE", "1") != "0"   # training blocks: the pre-activation is never stored (3 + 2 + 4 streams
+                                                                        # per block instead of 4 + 2 + 5; every pass recomputes it from x)
 USE_ROWBLOCK_LINEAR = True      # module switch for A/B measurements (the library GEMM + separate passes otherwise)
 USE_CONCAT_BLOCK = True   # SSWLConv / DSSGNNConv: Linear-BN-act over concatenated inputs without the concatenation
 USE_PAIR_COMBINE = True   # SUNConv on the padded layout: fused node-view / recombination passes
@@ -1830,7 +1843,7 @@ def rowblock_linear_supported(x: Tensor, out_features: int) -> bool:
 
 
 def rowblock_linear(x: Tensor, wl: Tensor, bias: Optional[Tensor] = None, addend: Optional[Tensor] = None,
-                    stats_shift=None):
+                    stats_shift=None, store: bool = True):
     """out = x @ wl^T (+ bias) (+ addend) on the skinny-GEMM kernel; with `stats_shift` also returns the per-block partial
     sums of (out - shift), (out - shift)^2 for pygho_bn_finalize: (out, partial_sums or None).  `stats_shift` is an (f32, d)
     tensor, or True: the kernel takes row 0 of its own output as the shift and the result is (out, (partial_sums, shift))."""
@@ -1838,7 +1851,8 @@ def rowblock_linear(x: Tensor, wl: Tensor, bias: Optional[Tensor] = None, addend
     x, wl = x.contiguous(), wl.contiguous()
     m, d = x.shape
     assert wl.shape == (d, d) and wl.dtype == x.dtype
-    out = torch.empty_like(x)
+    assert store or stats_shift is not None        # store=False: statistics of the (never stored) product only
+    out = torch.empty_like(x) if store else None
     ws = None
     if stats_shift is not None:
         nblk = int(lib().pygho_rowblock_linear_blocks(m))
@@ -1853,6 +1867,38 @@ def rowblock_linear(x: Tensor, wl: Tensor, bias: Optional[Tensor] = None, addend
     check(lib().pygho_rowblock_linear(ptr(out), ptr(x), ptr(wl), ptr(bias), ptr(addend), ptr(ws), ptr(stats_shift), m, d,
                                       dtype_code(x), stream_ptr(dev)), "rowblock_linear")
     return out, ws
+
+
+def rowblock_linear_bn_act(x: Tensor, wl: Tensor, bias: Optional[Tensor], scale: Tensor, shift: Tensor, act: str,
+                           addend: Optional[Tensor] = None) -> Tensor:
+    """act((x @ wl^T + bias) * scale + shift) (+ addend) in ONE pass over x: the product is rounded to the storage type exactly as
+    `rowblock_linear` stores it, then normalised / activated in the epilogue (= bn_act_fwd on the stored product, bit for bit)."""
+    dev = require_device(x, wl, bias, scale, shift, addend)
+    x, wl = x.contiguous(), wl.contiguous()
+    m, d = x.shape
+    assert wl.shape == (d, d) and wl.dtype == x.dtype and scale.dtype == torch.float32 and shift.dtype == torch.float32
+    out = torch.empty_like(x)
+    if addend is not None:
+        addend = addend.contiguous()
+    check(lib().pygho_rowblock_linear_bn_act(ptr(out), ptr(x), ptr(wl), ptr(bias), ptr(scale), ptr(shift), ptr(addend), m, d,
+                                             ACT_CODE[act], dtype_code(x), stream_ptr(dev)), "rowblock_linear_bn_act")
+    return out
+
+
+def rowblock_linear_bwd_sums(x: Tensor, wl: Tensor, bias: Optional[Tensor], gh: Tensor, saved, act: str):
+    """the two channel sums of the BatchNorm + activation backward for pre = x @ wl^T + bias, which is recomputed (same bits as
+    the forward's) instead of read: one pass over (x, gh)."""
+    mean, invstd, w32, b32, _ws = saved
+    dev = require_device(x, wl, bias, gh)
+    m, d = x.shape
+    s1 = torch.empty(d, dtype=torch.float32, device=dev)
+    s2 = torch.empty(d, dtype=torch.float32, device=dev)
+    nblk = int(lib().pygho_rowblock_linear_blocks(m))
+    ws = torch.empty((nblk, 2, d), dtype=torch.float32, device=dev)
+    check(lib().pygho_rowblock_linear_bwd_sums(ptr(s1), ptr(s2), ptr(x), ptr(wl.contiguous()), ptr(bias), ptr(gh.contiguous()), ptr(mean),
+                                               ptr(invstd), ptr(w32), ptr(b32), m, d, ACT_CODE[act], ptr(ws), dtype_code(x),
+                                               stream_ptr(dev)), "rowblock_linear_bwd_sums")
+    return s1, s2
 
 
 def sum_blocks(partials: Tensor) -> Tensor:
@@ -1876,13 +1922,34 @@ def bn_bwd_sums(pre: Tensor, gh: Tensor, saved, act: str):
     return s1, s2
 
 
-def bn_bwd_linear(pre: Tensor, gh: Tensor, saved, training: bool, act: str, w: Tensor, addend: Optional[Tensor],
-                  want_colsum: bool, x: Optional[Tensor] = None, sums=None):
+def bn_bwd_linear(pre: Optional[Tensor], gh: Tensor, saved, training: bool, act: str, w: Tensor, addend: Optional[Tensor],
+                  want_colsum: bool, x: Optional[Tensor] = None, sums=None, lin_bias: Optional[Tensor] = None):
     """(gx, gpre or dW, d bn.bias, d bn.weight, column sums of gpre or None): BatchNorm/act backward and the
     input-gradient GEMM gx = gpre @ w (+ addend) in one streaming kernel after the two-stage channel reduction.
     With `x` (the Linear's input) the weight gradient gpre^T @ x (f32) is accumulated in the same pass and returned in
     place of gpre, which then never reaches HBM."""
     mean, invstd, w32, b32, ws = saved
+    if pre is None:
+        # the pre-activation was not kept: both passes recompute it from x (`w` here is the Linear's weight in x's dtype)
+        assert x is not None
+        m, c = x.shape
+        dev = x.device
+        if sums is None:
+            sums = rowblock_linear_bwd_sums(x, w, lin_bias, gh, saved, act)
+        s1, s2 = sums
+        gx = torch.empty_like(x)
+        wlt = w.t().contiguous()
+        addend = None if addend is None else addend.contiguous()
+        nblk = int(lib().pygho_bn_bwd_linear_dw_blocks(m))
+        width = c * c + (2 * c if want_colsum else 0)
+        ws = torch.empty((nblk, width), dtype=torch.float32, device=dev)
+        cws_ptr = c_void_p(ws.data_ptr() + 4 * c * c) if want_colsum else None
+        check(lib().pygho_bn_bwd_linear_dw_recompute(ptr(gx), ptr(ws), ptr(gh), ptr(x), ptr(wlt), ptr(lin_bias), ptr(addend), cws_ptr,
+                                                     ptr(mean), ptr(invstd), ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act],
+                                                     1 if training else 0, dtype_code(x), width, stream_ptr(dev)),
+              "bn_bwd_linear_dw_recompute")
+        tot = sum_blocks(ws)
+        return gx, tot[:c * c].reshape(c, c), s1, s2, (tot[c * c:c * c + c] if want_colsum else None)
     m, c = pre.shape
     dev = pre.device
     st = stream_ptr(dev)
@@ -1929,7 +1996,16 @@ class _TupleBlock(torch.autograd.Function):
         bc = None if b is None else (b if b.dtype == x.dtype else b.to(x.dtype))
         skinny = rowblock_linear_supported(x, w.shape[0]) and w.shape[0] == w.shape[1]
         partial = None
-        if skinny:
+        # the pre-activation is kept only when a backward pass will read it: with the weight gradient folded into the backward
+        # kernel every pass recomputes it from x (same bits), and without a backward nobody needs it
+        needs = ctx.needs_input_grad
+        recompute = (USE_RECOMPUTE_PRE and skinny and USE_BN_BWD_LINEAR and USE_FUSED_DW
+                     and (needs[1] or not any(needs[i] for i in (0, 2, 3, 4, 10))))
+        if recompute:
+            pre = None
+            if training:
+                _none, partial = rowblock_linear(x, wc, bc, stats_shift=True, store=False)
+        elif skinny:
             # hand-written streaming GEMM: the BatchNorm statistics of its output ride in the epilogue
             pre, partial = rowblock_linear(x, wc, bc, stats_shift=True if training else None)     # partial = (sums, shift)
         else:
@@ -1937,12 +2013,12 @@ class _TupleBlock(torch.autograd.Function):
         # f32 rows carry half the elements per byte: there the BatchNorm + activation can ride on the aggregation's loads
         # (act-on-load: 0.61 vs 0.35 + 0.62 ms) and the activated tensor is never formed; with 16-bit rows the two
         # transcendentals per element make that kernel VALU-bound (0.52 vs 0.50 ms forward, 0.41 vs 0.30 ms backward)
-        on_load = (USE_ACT_ON_LOAD and plan is not None and rhs is not None and x.dtype == torch.float32 and aggr in ("sum", "mean")
+        on_load = (not recompute and USE_ACT_ON_LOAD and plan is not None and rhs is not None and x.dtype == torch.float32 and aggr in ("sum", "mean")
                    and (x.shape[1] * 4) % 16 == 0 and rhs.dtype == x.dtype and rhs.shape[1] == x.shape[1])
         # without a plan `rhs` is a residual row operand: out = H + rhs, added inside the activation pass
         row_res = rhs.contiguous() if (plan is None and rhs is not None) else None
         h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum, partial,
-                                          apply=not on_load, addend=row_res)
+                                          apply=not on_load, addend=row_res, producer=(x, wc, bc) if recompute else None)
         affine = look = None
         rhs_read, d_idx = rhs, (plan.d_fwd if plan is not None and rhs is not None else None)
         if plan is not None and rhs is not None and rhs_lookup is not None:
@@ -1960,7 +2036,7 @@ class _TupleBlock(torch.autograd.Function):
         else:
             out = seg_gmr(plan.n_out, h, rhs_read, plan.fwd.seg_ptr, plan.c_fwd, d_idx, aggr, addend=x if residual else None)
         ctx.affine, ctx.look = affine, look
-        ctx.save_for_backward(x, wc, pre, h if plan is not None else None, rhs, *saved)
+        ctx.save_for_backward(x, wc, pre, h if plan is not None else None, rhs, bc, *saved)
         ctx.meta = (training, act, None if b is None else b.dtype, gamma is not None, beta is not None, plan, aggr, residual, w.dtype,
                     skinny)
         ctx.mark_non_differentiable(mean, var)
@@ -1971,7 +2047,7 @@ class _TupleBlock(torch.autograd.Function):
     def backward(ctx, g, _gm, _gv):
         if g is None:
             return (None,) * len(ctx.needs_input_grad)
-        x, w, pre, h, rhs, *saved = ctx.saved_tensors
+        x, w, pre, h, rhs, bc, *saved = ctx.saved_tensors
         training, act, b_dtype, has_gamma, has_beta, plan, aggr, residual, w_dtype, skinny = ctx.meta
         g = g.contiguous()
         g_rhs = None
@@ -1994,8 +2070,9 @@ class _TupleBlock(torch.autograd.Function):
             g_rhs = g                                   # residual row operand: receives the output gradient as it is
         want_cs = b_dtype is not None and ctx.needs_input_grad[2]
         gx = gw = gb = None
-        if skinny and USE_BN_BWD_LINEAR and USE_FUSED_DW and ctx.needs_input_grad[1]:
-            gx, gw32, s1, s2, sdx = bn_bwd_linear(pre, gh.contiguous(), saved, training, act, w, g if residual else None, want_cs, x=x)
+        if pre is None or (skinny and USE_BN_BWD_LINEAR and USE_FUSED_DW and ctx.needs_input_grad[1]):
+            gx, gw32, s1, s2, sdx = bn_bwd_linear(pre, gh.contiguous(), saved, training, act, w, g if residual else None, want_cs, x=x,
+                                                  lin_bias=bc)
             gw = gw32.to(w_dtype)
         elif skinny and USE_BN_BWD_LINEAR:
             gx, gpre, s1, s2, sdx = bn_bwd_linear(pre, gh.contiguous(), saved, training, act, w, g if residual else None, want_cs)

@@ -427,6 +427,14 @@ extern "C" int pygho_bn_act_bwd_sums(float* sum_dz, float* sum_dz_xhat, const vo
   return check_launch("bn_act_bwd_sums");
 }
 
+extern "C" int pygho_bn_bwd_fold_sums(float* sum_a, float* sum_b, const float* ws, int64_t c, int64_t n_blocks, void* stream) {
+  if (c <= 0 || n_blocks <= 0) { set_error("bn_bwd_fold_sums: empty input"); return PYGHO_ERR_INVALID; }
+  if (!sum_a || !sum_b || !ws) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, (hipStream_t)stream, sum_a,
+                     sum_b, ws, (int)c, (int)n_blocks);
+  return check_launch("bn_bwd_fold_sums");
+}
+
 // out[j] = sum_b in[b * n + j]: per-workgroup partial results (weight-gradient slabs, column sums) -> one.  Coalesced along j,
 // the block range split over the 4 waves of a workgroup and combined through LDS in a fixed order (deterministic).
 namespace pygho {

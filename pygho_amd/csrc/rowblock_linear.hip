@@ -53,11 +53,34 @@ template <int D> struct RlGeom {
   static constexpr size_t lds_bytes = w_bytes + stage_bytes + 6 * (size_t)D * 4;   // + bias (forward) / BatchNorm constants (backward)
 };
 
-template <typename T, int D>
+// Epilogues of the streaming product (the pre-activation Y = in . Wl^T + bias is formed identically -- same instruction
+// sequence, so the same bits -- in every one of them, which is what lets a training block NOT keep Y in HBM):
+//   RL_STORE     out = Y (+ addend), optionally the BatchNorm partial sums of the rounded Y; `out` may be null (sums only)
+//   RL_BN_ACT    out = act(Y * scale + shift) (+ addend): Linear -> BatchNorm -> activation in one pass over `in`
+//   RL_BWD_SUMS  nothing stored: the two channel sums of the BatchNorm / activation backward (sum dz, sum dz * xhat) of
+//                (Y, gh) -- the reduction pass of the backward reads `in` and recomputes Y instead of reading a stored Y
+enum { RL_STORE = 0, RL_BN_ACT = 1, RL_BWD_SUMS = 2 };
+struct RlEpi {
+  const float* scale; const float* shift;                                     // RL_BN_ACT
+  const void* gh; const float* mean; const float* invstd; const float* w; const float* b;   // RL_BWD_SUMS (w / b nullable)
+};
+
+template <int ACT> __device__ __forceinline__ float rl_act_fwd(float z) {       // = bn_act.hip
+  if (ACT == 1) return z > 0.f ? z : 0.f;
+  if (ACT == 2) return z * __builtin_amdgcn_rcpf(1.f + __expf(-z));
+  return z;
+}
+template <int ACT> __device__ __forceinline__ float rl_act_grad(float z) {
+  if (ACT == 1) return z > 0.f ? 1.f : 0.f;
+  if (ACT == 2) { const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-z)); return sg * (1.f + z * (1.f - sg)); }   // = bn_act.hip
+  return 1.f;
+}
+
+template <typename T, int D, int EPI = RL_STORE, int ACT = 0>
 __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ wl,
                                                                     const T* __restrict__ bias, const T* __restrict__ addend,
                                                                     float* __restrict__ stats_ws, float* __restrict__ shift,
-                                                                    int self_shift, int64_t m_rows) {
+                                                                    int self_shift, int64_t m_rows, RlEpi epi) {
   using G = RlGeom<D>;
   using V = Vec16<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,10 +121,22 @@ __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restric
   float sh[8], s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    sh[j] = !stats_ws ? 0.f : (self_shift ? lds_shift[ech * 8 + j] : (shift ? shift[ech * 8 + j] : 0.f));
+    sh[j] = (!stats_ws || EPI != RL_STORE) ? 0.f : (self_shift ? lds_shift[ech * 8 + j] : (shift ? shift[ech * 8 + j] : 0.f));
     s1[j] = 0.f;
     s2[j] = 0.f;
   }
+  // per-channel constants of the fused epilogues, for this lane's fixed channel chunk: c0 / c1 = scale / shift (RL_BN_ACT) or
+  // mean / invstd (RL_BWD_SUMS), c2 / c3 = BatchNorm weight / bias (RL_BWD_SUMS)
+  float c0[8], c1[8], c2[8], c3[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = ech * 8 + j;
+    c0[j] = EPI == RL_BN_ACT ? epi.scale[c] : (EPI == RL_BWD_SUMS ? epi.mean[c] : 0.f);
+    c1[j] = EPI == RL_BN_ACT ? epi.shift[c] : (EPI == RL_BWD_SUMS ? epi.invstd[c] : 0.f);
+    c2[j] = (EPI == RL_BWD_SUMS && epi.w) ? epi.w[c] : 1.f;
+    c3[j] = (EPI == RL_BWD_SUMS && epi.b) ? epi.b[c] : 0.f;
+  }
+  const T* gh = reinterpret_cast<const T*>(epi.gh);
 
   uint4 fb[2][G::KS];                                    // `in` fragments of the current tile
   auto load_tile = [&](int64_t tile, uint4 (&dst)[2][G::KS]) {
@@ -123,6 +158,16 @@ __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restric
     // compiler demoted conditionally initialised prefetch arrays to scratch)
     const int64_t tn = min((int64_t)(tile + gridDim.x), n_tiles - 1);
     load_tile(tn, nxt);                // prefetch: in flight during this tile's MFMAs and epilogue
+    uint4 cgh[kRlRowsPerWave / EROWS];  // RL_BWD_SUMS: this tile's gh chunks (row-contiguous), in flight during the MFMAs
+    if constexpr (EPI == RL_BWD_SUMS) {
+      const int64_t b0 = tile * kRlTile + wave * kRlRowsPerWave;
+#pragma unroll
+      for (int it = 0; it < kRlRowsPerWave / EROWS; ++it) {
+        int64_t row = b0 + it * EROWS + erow0;
+        if (row >= m_rows) row = m_rows - 1;
+        cgh[it] = *reinterpret_cast<const uint4*>(gh + row * D + ech * 8);
+      }
+    }
 
     rl_f32x4_t acc[2][G::NB];
 #pragma unroll
@@ -155,20 +200,44 @@ __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restric
       const int64_t row = base + rl;
       uint4 v = *reinterpret_cast<const uint4*>(my_stage + ((size_t)rl * G::PITCH + ech * 8) * 2);
       if (row < m_rows) {
-        if (addend) {
-          float a[8], b[8];
-          V::unpack(v, a);
-          V::unpack(*reinterpret_cast<const uint4*>(addend + row * D + ech * 8), b);
+        if constexpr (EPI == RL_STORE) {
+          if (addend) {
+            float a[8], b[8];
+            V::unpack(v, a);
+            V::unpack(*reinterpret_cast<const uint4*>(addend + row * D + ech * 8), b);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) a[j] += b[j];
-          v = V::pack(a);
-        }
-        *reinterpret_cast<uint4*>(out + row * D + ech * 8) = v;
-        if (stats_ws) {
+            for (int j = 0; j < 8; ++j) a[j] += b[j];
+            v = V::pack(a);
+          }
+          if (out) *reinterpret_cast<uint4*>(out + row * D + ech * 8) = v;
+          if (stats_ws) {
+            float a[8];
+            V::unpack(v, a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float dlt = a[j] - sh[j]; s1[j] += dlt; s2[j] += dlt * dlt; }
+          }
+        } else if constexpr (EPI == RL_BN_ACT) {          // = bn_act_fwd_kernel on the rounded Y (bn_act.hip), same formula
           float a[8];
           V::unpack(v, a);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { const float dlt = a[j] - sh[j]; s1[j] += dlt; s2[j] += dlt * dlt; }
+          for (int j = 0; j < 8; ++j) a[j] = rl_act_fwd<ACT>(a[j] * c0[j] + c1[j]);
+          if (addend) {
+            float b[8];
+            V::unpack(*reinterpret_cast<const uint4*>(addend + row * D + ech * 8), b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += b[j];
+          }
+          *reinterpret_cast<uint4*>(out + row * D + ech * 8) = V::pack(a);
+        } else {                                          // = bn_act_bwd_reduce_kernel on the rounded Y
+          float a[8], g[8];
+          V::unpack(v, a);
+          V::unpack(cgh[it], g);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xh = (a[j] - c0[j]) * c1[j];
+            const float dz = g[j] * rl_act_grad<ACT>(xh * c2[j] + c3[j]);
+            s1[j] += dz; s2[j] += dz * xh;
+          }
         }
       }
     }
@@ -207,12 +276,6 @@ struct BnBwdArgs {
   const float* sum_dz; const float* sum_dz_xhat;
   int act; int training;
 };
-
-template <int ACT> __device__ __forceinline__ float rl_act_grad(float z) {
-  if (ACT == 1) return z > 0.f ? 1.f : 0.f;
-  if (ACT == 2) { const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-z)); return sg * (1.f + z * (1.f - sg)); }   // = bn_act.hip
-  return 1.f;
-}
 
 template <typename T, int D, int ACT>
 __global__ __launch_bounds__(kBlock, 2) void bn_bwd_linear_kernel(T* __restrict__ gx, T* __restrict__ gpre, const T* __restrict__ pre,
@@ -417,17 +480,23 @@ template <int D> struct DwGeom {
                                                            // 8 consecutive rows (one 32-lane half) cover all 64 banks once
   static constexpr size_t tile_bytes = (size_t)kDwTile * RlGeom<D>::PITCH * 2;
   static constexpr size_t xtile_bytes = (size_t)kDwTile * PBX;
-  static constexpr size_t const_bytes = 6 * (size_t)D * 4;                                   // per-channel BatchNorm constants
+  static constexpr size_t const_bytes = 7 * (size_t)D * 4;                                   // per-channel BatchNorm constants + the Linear's bias
   static constexpr size_t lds_bytes = RlGeom<D>::w_bytes + tile_bytes + xtile_bytes + const_bytes;   // 73.7 KB at d = 128: 2 per CU
   static constexpr int NBW = (RlGeom<D>::NB + kDwWaves - 1) / kDwWaves;                      // dW row blocks per wave
 };
 
-template <typename T, int D, int ACT>
+// RECOMP: `pre` is not read; the wave recomputes the pre-activation of its 16 rows from the x rows it has just staged,
+//   Y[m][n] = bias[n] + sum_k x[m][k] W[n][k], with the SAME fragments in the SAME order as rowblock_linear_kernel (lane (r16, q)
+// holds k = 32 ks + 8 q + 0..7 of row m = r16 / of output channel n = 16 nb + r16), so the result has the forward's bits.  W sits
+// in LDS as W^T (rows k) for the gx product: the 8 consecutive k of a fixed n are a COLUMN there, delivered by two transpose
+// reads (rows 8 q + 0..3 and 8 q + 4..7 of the 32-row step).  One HBM stream (pre) less per row: 4 instead of 5.
+template <typename T, int D, int ACT, bool RECOMP = false>
 __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __restrict__ gx, const T* __restrict__ pre,
                                                                          const T* __restrict__ gh, const T* __restrict__ x,
                                                                          const T* __restrict__ wl, const T* __restrict__ addend,
                                                                          float* __restrict__ colsum_ws, float* __restrict__ dw_ws,
-                                                                         BnBwdArgs bn, int64_t m_rows, int64_t ws_stride) {
+                                                                         BnBwdArgs bn, int64_t m_rows, int64_t ws_stride,
+                                                                         const T* __restrict__ lin_bias = nullptr) {
   using G = RlGeom<D>;
   using V = Vec16<T>;
   constexpr int PB = G::PITCH * 2;                       // LDS row pitch in bytes (W^T, gpre and output tiles)
@@ -459,6 +528,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
       lds_c[3 * D + c] = bn.b ? bn.b[c] : 0.f;
       lds_c[4 * D + c] = bn.training ? bn.sum_dz[c] * inv_m : 0.f;
       lds_c[5 * D + c] = bn.training ? bn.sum_dz_xhat[c] * inv_m : 0.f;
+      lds_c[6 * D + c] = (RECOMP && lin_bias) ? load_as_acc<T>(lin_bias + c) : 0.f;
     }
   }
   float cs[8];
@@ -481,7 +551,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
       int64_t row = base + it * EROWS + erow0;
       if (row >= m_rows) row = m_rows - 1;
       const int64_t off = row * D + ech * 8;
-      y[it] = *reinterpret_cast<const uint4*>(pre + off);
+      if constexpr (!RECOMP) y[it] = *reinterpret_cast<const uint4*>(pre + off);
       g[it] = *reinterpret_cast<const uint4*>(gh + off);
     }
   };
@@ -502,6 +572,39 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
     // compiler demoted conditionally initialised prefetch arrays to scratch)
     const int64_t tn = min((int64_t)(tile + gridDim.x), n_tiles - 1);
     load_tile(tn, ny, ng);
+    if constexpr (RECOMP) {
+      // ---- the pre-activation of this wave's 16 rows, recomputed from the x rows (see the head comment) ------------------
+#pragma unroll
+      for (int it = 0; it < EIT; ++it)
+        *reinterpret_cast<uint4*>(stage_x + (size_t)(wave * kDwRowsPerWave + it * EROWS + erow0) * PBX + ech * 16) = cx[it];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      rl_f32x4_t ay[G::NB];
+#pragma unroll
+      for (int nb = 0; nb < G::NB; ++nb) ay[nb] = *reinterpret_cast<const rl_f32x4_t*>(lds_c + 6 * D + nb * 16 + q * 4);
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        const uint4 fx = *reinterpret_cast<const uint4*>(stage_x + (size_t)(wave * kDwRowsPerWave + r16) * PBX + (ks * 32 + q * 8) * 2);
+        const char* wa = lds_w + (size_t)(ks * 32 + q * 8 + (r16 >> 2)) * PB + (r16 & 3) * 8;
+#pragma unroll
+        for (int nb = 0; nb < G::NB; ++nb) {
+          const rl_s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(wa + nb * 32));
+          const rl_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(wa + nb * 32 + 4 * PB));
+          const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+          ay[nb] = rl_mfma<T>(make_uint4(a.x, a.y, b.x, b.y), fx, ay[nb]);
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < G::NB; ++nb)
+        *reinterpret_cast<uint2*>(stage_g + (size_t)(wave * kDwRowsPerWave + r16) * PB + (nb * 16 + q * 4) * 2) = rl_pack4<T>(ay[nb]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int it = 0; it < EIT; ++it)
+        cy[it] = *reinterpret_cast<const uint4*>(stage_g + (size_t)(wave * kDwRowsPerWave + it * EROWS + erow0) * PB + ech * 16);
+    }
     // ---- prologue: gpre of this wave's 16 rows and the matching x rows -> LDS (rows past the end as zeros) ---------------
     float mu[8], is[8], ww[8], bb[8], k1[8], k2[8];        // re-read per tile: live only here
 #pragma unroll
@@ -536,9 +639,11 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
         for (int j = 0; j < 8; ++j) cs[j] += v[j];
       }
     }
+    if constexpr (!RECOMP) {
 #pragma unroll
-    for (int it = 0; it < EIT; ++it)
-      *reinterpret_cast<uint4*>(stage_x + (size_t)(wave * kDwRowsPerWave + it * EROWS + erow0) * PBX + ech * 16) = cx[it];
+      for (int it = 0; it < EIT; ++it)
+        *reinterpret_cast<uint4*>(stage_x + (size_t)(wave * kDwRowsPerWave + it * EROWS + erow0) * PBX + ech * 16) = cx[it];
+    }
     rl_lds_barrier();
     // ---- gx rows of this wave: gpre . W ------------------------------------------------------------------------------------
     rl_f32x4_t acc[G::NB];
@@ -611,7 +716,10 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < EIT; ++it) { cy[it] = ny[it]; cg[it] = ng[it]; }
+    for (int it = 0; it < EIT; ++it) {
+      if constexpr (!RECOMP) cy[it] = ny[it];
+      cg[it] = ng[it];
+    }
   }
   // ---- per-workgroup results: dW partial (D x D f32) and the column sums of gpre ------------------------------------------
   if (dw_wave) {
@@ -639,18 +747,20 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
   }
 }
 
-template <typename T, int D, int ACT>
+template <typename T, int D, int ACT, bool RECOMP = false>
 int launch_bn_bwd_linear_dw(void* gx, const void* pre, const void* gh, const void* x, const void* wl, const void* addend,
-                            float* colsum_ws, float* dw_ws, const BnBwdArgs& bn, int64_t m, int grid, int64_t ws_stride, hipStream_t st) {
+                            float* colsum_ws, float* dw_ws, const BnBwdArgs& bn, int64_t m, int grid, int64_t ws_stride, hipStream_t st,
+                            const void* lin_bias = nullptr) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_linear_dw_kernel<T, D, ACT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_linear_dw_kernel<T, D, ACT, RECOMP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)DwGeom<D>::lds_bytes);
     if (e != hipSuccess) { set_error("bn_bwd_linear_dw: cannot reserve %zu B of LDS: %s", DwGeom<D>::lds_bytes, hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((bn_bwd_linear_dw_kernel<T, D, ACT>), dim3(grid), dim3(kDwThreads), DwGeom<D>::lds_bytes, st, (T*)gx, (const T*)pre,
-                     (const T*)gh, (const T*)x, (const T*)wl, (const T*)addend, colsum_ws, dw_ws, bn, m, ws_stride);
+  hipLaunchKernelGGL((bn_bwd_linear_dw_kernel<T, D, ACT, RECOMP>), dim3(grid), dim3(kDwThreads), DwGeom<D>::lds_bytes, st, (T*)gx,
+                     (const T*)pre, (const T*)gh, (const T*)x, (const T*)wl, (const T*)addend, colsum_ws, dw_ws, bn, m, ws_stride,
+                     (const T*)lin_bias);
   return check_launch("bn_bwd_linear_dw");
 }
 
@@ -799,19 +909,19 @@ int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum
   return check_launch("weight_grad");
 }
 
-template <typename T, int D>
+template <typename T, int D, int EPI = RL_STORE, int ACT = 0>
 int launch_rowblock(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws, float* shift,
-                    int self_shift, int64_t m, int grid, hipStream_t st) {
+                    int self_shift, int64_t m, int grid, hipStream_t st, const RlEpi& epi = RlEpi{}) {
   using G = RlGeom<D>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_linear_kernel<T, D>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_linear_kernel<T, D, EPI, ACT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
     if (e != hipSuccess) { set_error("rowblock_linear: cannot reserve %zu B of LDS: %s", G::lds_bytes, hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((rowblock_linear_kernel<T, D>), dim3(grid), dim3(kBlock), G::lds_bytes, st, (T*)out, (const T*)in, (const T*)wl,
-                     (const T*)bias, (const T*)addend, stats_ws, shift, self_shift, m);
+  hipLaunchKernelGGL((rowblock_linear_kernel<T, D, EPI, ACT>), dim3(grid), dim3(kBlock), G::lds_bytes, st, (T*)out, (const T*)in,
+                     (const T*)wl, (const T*)bias, (const T*)addend, stats_ws, shift, self_shift, m, epi);
   return check_launch("rowblock_linear");
 }
 
@@ -828,7 +938,7 @@ static int rowblock_entry(void* out, const void* in, const void* wl, const void*
                           float* shift, int self_shift, int64_t m, int64_t d, int dtype, void* stream) {
   if (m < 0 || d <= 0) { set_error("rowblock_linear: bad size"); return PYGHO_ERR_INVALID; }
   if (m == 0) return PYGHO_OK;
-  if (!out || !in || !wl) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if ((!out && !stats_ws) || !in || !wl) { set_error("null pointer"); return PYGHO_ERR_INVALID; }      // out may be null: sums only
   if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("rowblock_linear: bf16 / f16 only (f32 takes the library GEMM)"); return PYGHO_ERR_UNSUPPORTED; }
   if (d != 64 && d != 128) { set_error("rowblock_linear: width %lld not supported (64, 128)", (long long)d); return PYGHO_ERR_UNSUPPORTED; }
   if ((((uintptr_t)out | (uintptr_t)in | (uintptr_t)wl | (uintptr_t)addend) % 16) != 0) { set_error("rowblock_linear: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
@@ -851,6 +961,50 @@ extern "C" int pygho_rowblock_linear_autoshift(void* out, const void* in, const 
                                                float* stats_ws, float* shift_out, int64_t m, int64_t d, int dtype, void* stream) {
   return rowblock_entry(out, in, wl, bias, addend, stats_ws, shift_out, 1, m, d, dtype, stream);
 }
+
+static int rowblock_check(const char* what, const void* a, const void* b, const void* c, const void* d4, int64_t m, int64_t d, int act,
+                          int dtype) {
+  if (m <= 0 || d <= 0) { set_error("%s: empty input", what); return PYGHO_ERR_INVALID; }
+  if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("%s: bf16 / f16 only", what); return PYGHO_ERR_UNSUPPORTED; }
+  if (d != 64 && d != 128) { set_error("%s: width %lld not supported (64, 128)", what, (long long)d); return PYGHO_ERR_UNSUPPORTED; }
+  if (act < 0 || act > 2) { set_error("%s: unknown activation %d", what, act); return PYGHO_ERR_INVALID; }
+  if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d4) % 16) != 0) { set_error("%s: operands must be 16-byte aligned", what); return PYGHO_ERR_INVALID; }
+  return PYGHO_OK;
+}
+
+#define PYGHO_RL_EPI(T, DD, EPI, ...)                                                           \
+  (act == 0 ? launch_rowblock<T, DD, EPI, 0>(__VA_ARGS__) : act == 1 ? launch_rowblock<T, DD, EPI, 1>(__VA_ARGS__) \
+                                                                     : launch_rowblock<T, DD, EPI, 2>(__VA_ARGS__))
+#define PYGHO_RL_EPI_T(EPI, ...)                                                                                  \
+  (dtype == PYGHO_BF16 ? (d == 128 ? PYGHO_RL_EPI(bf16, 128, EPI, __VA_ARGS__) : PYGHO_RL_EPI(bf16, 64, EPI, __VA_ARGS__)) \
+                       : (d == 128 ? PYGHO_RL_EPI(f16, 128, EPI, __VA_ARGS__) : PYGHO_RL_EPI(f16, 64, EPI, __VA_ARGS__)))
+
+extern "C" int pygho_rowblock_linear_bn_act(void* out, const void* in, const void* wl, const void* bias, const float* scale,
+                                            const float* shift, const void* addend, int64_t m, int64_t d, int act, int dtype,
+                                            void* stream) {
+  if (!out || !in || !wl || !scale || !shift) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (int rc = rowblock_check("rowblock_linear_bn_act", out, in, wl, addend, m, d, act, dtype)) return rc;
+  const int grid = pygho_rowblock_linear_blocks(m);
+  hipStream_t st = (hipStream_t)stream;
+  RlEpi epi{};
+  epi.scale = scale; epi.shift = shift;
+  return PYGHO_RL_EPI_T(RL_BN_ACT, out, in, wl, bias, addend, nullptr, nullptr, 0, m, grid, st, epi);
+}
+
+extern "C" int pygho_rowblock_linear_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* in, const void* wl, const void* bias,
+                                              const void* gh, const float* mean, const float* invstd, const float* w, const float* b,
+                                              int64_t m, int64_t d, int act, float* workspace, int dtype, void* stream) {
+  if (!sum_dz || !sum_dz_xhat || !in || !wl || !gh || !mean || !invstd || !workspace) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (int rc = rowblock_check("rowblock_linear_bwd_sums", in, wl, gh, nullptr, m, d, act, dtype)) return rc;
+  const int grid = pygho_rowblock_linear_blocks(m);
+  hipStream_t st = (hipStream_t)stream;
+  RlEpi epi{};
+  epi.gh = gh; epi.mean = mean; epi.invstd = invstd; epi.w = w; epi.b = b;
+  if (int rc = PYGHO_RL_EPI_T(RL_BWD_SUMS, nullptr, in, wl, bias, nullptr, workspace, nullptr, 0, m, grid, st, epi)) return rc;
+  return pygho_bn_bwd_fold_sums(sum_dz, sum_dz_xhat, workspace, d, grid, stream);
+}
+#undef PYGHO_RL_EPI_T
+#undef PYGHO_RL_EPI
 
 extern "C" int pygho_bn_bwd_linear(void* gx, void* gpre, const void* pre, const void* gh, const void* wl, const void* addend,
                                    float* colsum_ws, const float* mean, const float* invstd, const float* w, const float* b,
@@ -899,6 +1053,28 @@ extern "C" int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, c
   if (dtype == PYGHO_BF16) return d == 128 ? PYGHO_BLW(bf16, 128) : PYGHO_BLW(bf16, 64);
   return d == 128 ? PYGHO_BLW(f16, 128) : PYGHO_BLW(f16, 64);
 #undef PYGHO_BLW
+}
+
+extern "C" int pygho_bn_bwd_linear_dw_recompute(void* gx, float* dw_ws, const void* gh, const void* x, const void* wlt, const void* bias,
+                                                const void* addend, float* colsum_ws, const float* mean, const float* invstd,
+                                                const float* w, const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m,
+                                                int64_t d, int act, int training, int dtype, int64_t ws_stride, void* stream) {
+  if (m <= 0 || d <= 0) { set_error("bn_bwd_linear_dw_recompute: empty input"); return PYGHO_ERR_INVALID; }
+  if (!gx || !dw_ws || !gh || !x || !wlt || !mean || !invstd || (training && (!sum_dz || !sum_dz_xhat))) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("bn_bwd_linear_dw_recompute: bf16 / f16 only"); return PYGHO_ERR_UNSUPPORTED; }
+  if (d != 64 && d != 128) { set_error("bn_bwd_linear_dw_recompute: width %lld not supported (64, 128)", (long long)d); return PYGHO_ERR_UNSUPPORTED; }
+  if (act < 0 || act > 2) { set_error("bn_bwd_linear_dw_recompute: unknown activation %d", act); return PYGHO_ERR_INVALID; }
+  if ((((uintptr_t)gx | (uintptr_t)gh | (uintptr_t)x | (uintptr_t)wlt | (uintptr_t)addend) % 16) != 0) { set_error("bn_bwd_linear_dw_recompute: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
+  const int grid = pygho_bn_bwd_linear_dw_blocks(m);
+  hipStream_t st = (hipStream_t)stream;
+  const BnBwdArgs bn{mean, invstd, w, b, sum_dz, sum_dz_xhat, act, training};
+#define PYGHO_BLR(T, DD)                                                                                                                \
+  (act == 0 ? launch_bn_bwd_linear_dw<T, DD, 0, true>(gx, nullptr, gh, x, wlt, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st, bias)   \
+   : act == 1 ? launch_bn_bwd_linear_dw<T, DD, 1, true>(gx, nullptr, gh, x, wlt, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st, bias) \
+              : launch_bn_bwd_linear_dw<T, DD, 2, true>(gx, nullptr, gh, x, wlt, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st, bias))
+  if (dtype == PYGHO_BF16) return d == 128 ? PYGHO_BLR(bf16, 128) : PYGHO_BLR(bf16, 64);
+  return d == 128 ? PYGHO_BLR(f16, 128) : PYGHO_BLR(f16, 64);
+#undef PYGHO_BLR
 }
 
 extern "C" int pygho_weight_grad(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t x_ld, int64_t m, int64_t d,

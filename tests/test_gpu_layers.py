@@ -447,6 +447,93 @@ def test_bn_bwd_linear_equals_two_kernel_path(dev, dtype, act):
         torch.testing.assert_close(dw.double() / scale, dw_ref / scale, rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("act", ["silu", "relu", "none"])
+@pytest.mark.parametrize("d", [128, 64])
+def test_recomputed_preactivation_passes_are_bit_identical_to_stored_ones(dev, dtype, act, d):
+    """a training block that never stores pre = x W^T + b: every pass recomputes it from x with the forward's instruction
+    sequence.  Against the passes that read a stored pre: the statistics' partial sums, the activated output (with and
+    without a residual row), the two backward channel sums' partials-folded values (close: different reduction tree) and,
+    GIVEN the same channel sums, the input gradient (bit for bit), weight gradient and bias gradient of the one-pass backward."""
+    from pygho_amd import _ops
+    torch.manual_seed(5)
+    for m, training, bias in ((70_001, True, True), (33_000, False, False), (190, True, True)):
+        x = (torch.randn(m, d, device=dev) * 0.9).to(dtype)
+        w = (torch.randn(d, d, device=dev) / d ** 0.5).to(dtype)
+        b = (torch.randn(d, device=dev) * 0.2).to(dtype) if bias else None
+        gh = torch.randn(m, d, device=dev).to(dtype)
+        g = torch.randn(m, d, device=dev).to(dtype)
+        res = torch.randn(m, d, device=dev).to(dtype)
+        bn = torch.nn.BatchNorm1d(d).to(dev).train(training)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3); bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 2.0)
+        pre, partial = _ops.rowblock_linear(x, w, b, stats_shift=True if training else None)
+        none, partial_r = _ops.rowblock_linear(x, w, b, stats_shift=True, store=False)
+        assert none is None
+        if training:
+            assert torch.equal(partial[0], partial_r[0]) and torch.equal(partial[1], partial_r[1])
+        for addend in (None, res):
+            h0, mean0, var0, saved = _ops._bn_forward(pre, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, act,
+                                                      None, partial, addend=addend)
+            h1, mean1, var1, saved1 = _ops._bn_forward(None, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, act,
+                                                       None, partial_r if training else None, addend=addend, producer=(x, w, b))
+            assert torch.equal(h0, h1) and torch.equal(mean0, mean1) and torch.equal(var0, var1)
+        s1, s2 = _ops.bn_bwd_sums(pre, gh, saved, act)
+        t1, t2 = _ops.rowblock_linear_bwd_sums(x, w, b, gh, saved1, act)
+        scale = float(s1.abs().max()) + float(s2.abs().max())
+        torch.testing.assert_close(t1 / scale, s1 / scale, rtol=0, atol=1e-6)
+        torch.testing.assert_close(t2 / scale, s2 / scale, rtol=0, atol=1e-6)
+        for addend, want_cs in ((None, False), (g, True)):
+            gx0, dw0, _, _, sdx0 = _ops.bn_bwd_linear(pre, gh, saved, training, act, w, addend, want_cs, x=x, sums=(s1, s2))
+            gx1, dw1, u1, u2, sdx1 = _ops.bn_bwd_linear(None, gh, saved1, training, act, w, addend, want_cs, x=x, sums=(s1, s2), lin_bias=b)
+            assert torch.equal(gx0, gx1) and torch.equal(dw0, dw1)
+            assert (sdx0 is None and sdx1 is None) or torch.equal(sdx0, sdx1)
+        # and end to end with its own sums
+        gx2, dw2, v1, v2, _ = _ops.bn_bwd_linear(None, gh, saved1, training, act, w, g, True, x=x, lin_bias=b)
+        assert torch.equal(v1, t1) and torch.equal(v2, t2)
+        gs = float(gx0.float().abs().max())
+        torch.testing.assert_close(gx2.float() / gs, gx0.float() / gs, rtol=0, atol=2e-2)
+
+
+def test_tuple_block_without_stored_preactivation_equals_stored(dev):
+    """NGNNConv.forward_residual with and without the stored pre-activation (module switch): output bit-identical, gradients equal
+    up to the reduction order of the two backward channel sums; eval mode without gradients takes the two-stream forward."""
+    import copy
+    from pygho_amd import SparseTensor, _ops
+    from pygho_amd.honn import Conv
+    h = 128
+    A, tid, xv, dd, n = _ngnn_inputs(dev, torch.bfloat16, graphs=700)
+    torch.manual_seed(2)
+    wgt = torch.randn(xv.shape, device=dev)
+    layer = Conv.NGNNConv(h, h, "sum", "SS", dict(MLP)).to(dev)
+    old = _ops.USE_RECOMPUTE_PRE
+    res = {}
+    try:
+        for mode in (True, False):
+            _ops.USE_RECOMPUTE_PRE = mode
+            la = copy.deepcopy(layer).train(True)
+            x = xv.clone().requires_grad_(True)
+            av = A.values.clone().requires_grad_(True)
+            out = la.forward_residual(SparseTensor(A.indices, av, A.shape, True), SparseTensor(tid, x, [n, n, h], True), dd)
+            (out.values.float() * wgt).sum().backward()
+            la.eval()
+            with torch.no_grad():
+                ev = la.forward_residual(SparseTensor(A.indices, A.values, A.shape, True), SparseTensor(tid, xv, [n, n, h], True), dd)
+            res[mode] = (out.values.detach(), ev.values, x.grad, av.grad, {k: p.grad.float() for k, p in la.named_parameters()})
+    finally:
+        _ops.USE_RECOMPUTE_PRE = old
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for i in (2, 3):
+        s = float(b[i].float().abs().max())
+        torch.testing.assert_close(a[i].float() / s, b[i].float() / s, rtol=0, atol=1e-2)
+    for k in b[4]:
+        s = float(b[4][k].abs().max()) + 1e-6
+        if k.endswith("lins.0.bias"):
+            continue
+        torch.testing.assert_close(a[4][k] / s, b[4][k] / s, rtol=0, atol=1e-3, msg=k)
+
+
 def test_fused_residual_i2conv_3tuples(dev):
     """the same fused block on 3-tuples (I2Conv, BASELINE config 5 shape, d = 64 -> the d = 64 instantiation of the MFMA
     kernels): forward_residual against the unfused composition, values and input / parameter gradients, bf16."""
