@@ -496,15 +496,15 @@ int pygho_bn_act_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* x, cons
  *             pygho_rowblock_linear_bn_act                         out = act(Y * scale + shift) (+ addend)   in  -> out
  *   backward  pygho_rowblock_linear_bwd_sums                       sum dz, sum dz * xhat of (Y, gh)          in, gh -> (sums)
  *             pygho_bn_bwd_linear_dw_recompute                     gx, dW (Y from the staged x tile)         in, gh, addend -> gx
- * = 3 + 2 + 4 streams of m x d instead of 4 + 2 + 5 with a stored Y.  wl: W row-major ([n][k], torch.nn.Linear layout) in the
- * first three, wlt = W^T row-major in the last (as in pygho_bn_bwd_linear_dw).  scale / shift: pygho_bn_finalize's outputs.
+ * = 3 + 2 + 4 streams of m x d instead of 4 + 2 + 5 with a stored Y.  wl: W row-major ([n][k], torch.nn.Linear layout) in all
+ * four (the last one transposes it into LDS itself; pygho_bn_bwd_linear_dw takes W^T).  scale / shift: pygho_bn_finalize's outputs.
  * workspace of _bwd_sums: pygho_rowblock_linear_blocks(m) x 2 x d floats. */
 int pygho_rowblock_linear_bn_act(void* out, const void* in, const void* wl, const void* bias, const float* scale,
                                  const float* shift, const void* addend, int64_t m, int64_t d, int act, int dtype, void* stream);
 int pygho_rowblock_linear_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* in, const void* wl, const void* bias,
                                    const void* gh, const float* mean, const float* invstd, const float* w, const float* b,
                                    int64_t m, int64_t d, int act, float* workspace, int dtype, void* stream);
-int pygho_bn_bwd_linear_dw_recompute(void* gx, float* dw_ws, const void* gh, const void* x, const void* wlt, const void* bias,
+int pygho_bn_bwd_linear_dw_recompute(void* gx, float* dw_ws, const void* gh, const void* x, const void* wl, const void* bias,
                                      const void* addend, float* colsum_ws, const float* mean, const float* invstd, const float* w,
                                      const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m, int64_t d, int act,
                                      int training, int dtype, int64_t ws_stride, void* stream);

@@ -1781,6 +1781,103 @@ def batch_norm_act(x: Tensor, bn: "torch.nn.BatchNorm1d", act: str) -> Tensor:
 
 
 # --------------------------------------------------------------------------
+# low-precision copies of the f32 master parameters: ONE multi-tensor copy per optimizer step instead of a cast kernel per use
+# --------------------------------------------------------------------------
+USE_CAST_ARENA = os.environ.get("PYGHO_CAST_ARENA", "1") != "0"
+_ARENA_OF = {}          # id(parameter) -> (weakref to its arena, position); validated by identity on lookup
+_ARENA_EPOCH = [0]      # bumped by whoever changes parameters behind the version counters' back (a HIP graph replay)
+
+
+def invalidate_cast_arenas() -> None:
+    """every arena copy is out of date (parameters were updated without their version counters moving: a replayed HIP graph
+    contains the optimizer's in-place update, and replaying it does not touch Python-side versions)."""
+    _ARENA_EPOCH[0] += 1
+
+
+class ParamCastArena:
+    """16-bit copies of a module's f32 parameters in one flat buffer (16-byte aligned views).  `refresh()` re-casts every
+    parameter whose version changed since the last refresh with ONE `torch._foreach_copy_` (the training step had ~25 separate
+    cast launches of 1-16 k elements, 4.7 us each); a lookup is valid only while the parameter's version is the refreshed one,
+    so an in-place update that nobody told the arena about simply falls back to a direct cast."""
+
+    def __init__(self, params, dtype: torch.dtype):
+        import weakref
+        self.dtype = dtype
+        self.params = [p for p in params if p.is_cuda and p.dtype == torch.float32]
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 7) // 8 * 8
+        dev = self.params[0].device if self.params else None
+        self.flat = torch.empty(total, dtype=dtype, device=dev) if self.params else None
+        self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
+        self.versions = [-1] * len(self.params)
+        self.epoch = -1
+        ref = weakref.ref(self)
+        for i, p in enumerate(self.params):
+            _ARENA_OF[id(p)] = (ref, i)
+
+    def refresh(self) -> None:
+        if self.epoch != _ARENA_EPOCH[0]:
+            stale = list(range(len(self.params)))
+        else:
+            stale = [i for i, p in enumerate(self.params) if self.versions[i] != p._version]
+        self.epoch = _ARENA_EPOCH[0]
+        if not stale:
+            return
+        with torch.no_grad():
+            torch._foreach_copy_([self.views[i] for i in stale], [self.params[i].detach() for i in stale])
+        for i in stale:
+            self.versions[i] = self.params[i]._version
+
+
+def ensure_cast_arena(module, dtype: Optional[torch.dtype]) -> None:
+    """create (once) and refresh the cast arena of `module`'s parameters for the 16-bit compute dtype; call at the top of forward."""
+    if not USE_CAST_ARENA or dtype not in (torch.bfloat16, torch.float16):
+        return
+    arena = module.__dict__.get("_pygho_cast_arena")
+    params = list(module.parameters())
+    if (arena is None or arena.dtype != dtype or len(arena.params) != sum(1 for p in params if p.is_cuda and p.dtype == torch.float32)
+            or any(a is not b for a, b in zip(arena.params, (p for p in params if p.is_cuda and p.dtype == torch.float32)))):
+        arena = ParamCastArena(params, dtype)
+        module.__dict__["_pygho_cast_arena"] = arena
+    arena.refresh()
+
+
+def param_as(p: Tensor, dtype: torch.dtype) -> Tensor:
+    """`p` in `dtype`, without autograd: the arena's copy when it is current, a direct cast otherwise."""
+    if p.dtype == dtype:
+        return p
+    ent = _ARENA_OF.get(id(p))
+    if ent is not None:
+        arena = ent[0]()
+        if arena is None:
+            del _ARENA_OF[id(p)]
+        elif (arena.dtype == dtype and arena.epoch == _ARENA_EPOCH[0] and arena.params[ent[1]] is p
+              and arena.versions[ent[1]] == p._version):
+            return arena.views[ent[1]]
+    return p.detach().to(dtype)
+
+
+class _CastParam(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, dtype):
+        ctx.src_dtype = p.dtype
+        return param_as(p, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.src_dtype), None
+
+
+def cast_param(p: Tensor, dtype: torch.dtype) -> Tensor:
+    """differentiable `p.to(dtype)` that reads the cast arena (the gradient returns in p's dtype)."""
+    if p.dtype == dtype:
+        return p
+    return _CastParam.apply(p, dtype)
+
+
+# --------------------------------------------------------------------------
 # one tuple-wise block: Linear -> BatchNorm -> act [-> message passing [+ residual]]   (SURVEY.md 8 row f3)
 # --------------------------------------------------------------------------
 def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype, want_colsum: bool = False):
@@ -1938,13 +2035,12 @@ def bn_bwd_linear(pre: Optional[Tensor], gh: Tensor, saved, training: bool, act:
             sums = rowblock_linear_bwd_sums(x, w, lin_bias, gh, saved, act)
         s1, s2 = sums
         gx = torch.empty_like(x)
-        wlt = w.t().contiguous()
         addend = None if addend is None else addend.contiguous()
         nblk = int(lib().pygho_bn_bwd_linear_dw_blocks(m))
         width = c * c + (2 * c if want_colsum else 0)
         ws = torch.empty((nblk, width), dtype=torch.float32, device=dev)
         cws_ptr = c_void_p(ws.data_ptr() + 4 * c * c) if want_colsum else None
-        check(lib().pygho_bn_bwd_linear_dw_recompute(ptr(gx), ptr(ws), ptr(gh), ptr(x), ptr(wlt), ptr(lin_bias), ptr(addend), cws_ptr,
+        check(lib().pygho_bn_bwd_linear_dw_recompute(ptr(gx), ptr(ws), ptr(gh), ptr(x), ptr(w.contiguous()), ptr(lin_bias), ptr(addend), cws_ptr,
                                                      ptr(mean), ptr(invstd), ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act],
                                                      1 if training else 0, dtype_code(x), width, stream_ptr(dev)),
               "bn_bwd_linear_dw_recompute")
@@ -1992,8 +2088,8 @@ class _TupleBlock(torch.autograd.Function):
         x = x.contiguous()
         # master weights (usually f32) are cast to the activation dtype here, outside the autograd graph; their
         # gradients are returned in the master dtype straight from the f32 split-K / column sums
-        wc = w if w.dtype == x.dtype else w.to(x.dtype)
-        bc = None if b is None else (b if b.dtype == x.dtype else b.to(x.dtype))
+        wc = param_as(w, x.dtype)
+        bc = None if b is None else param_as(b, x.dtype)
         skinny = rowblock_linear_supported(x, w.shape[0]) and w.shape[0] == w.shape[1]
         partial = None
         # the pre-activation is kept only when a backward pass will read it: with the weight gradient folded into the backward
@@ -2133,8 +2229,8 @@ class _ConcatBlock(torch.autograd.Function):
             res_row, xs = xs[-1], xs[:-1]
         d = xs[0].shape[1]
         dt = xs[0].dtype
-        wc = w if w.dtype == dt else w.to(dt)
-        bc = None if b is None else (b if b.dtype == dt else b.to(dt))
+        wc = param_as(w, dt)
+        bc = None if b is None else param_as(b, dt)
         blocks = [wc[:, k * d:(k + 1) * d].contiguous() for k in range(len(xs))]
         pre, partial = None, None
         for k, (x, wk) in enumerate(zip(xs, blocks)):

@@ -511,9 +511,22 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
                                                                                // needed for the two accumulator sets)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
-  for (int item = threadIdx.x; item < D * G::CH; item += kDwThreads) {
-    const int n = item / G::CH, ch = item - n * G::CH;
-    *reinterpret_cast<uint4*>(lds_w + (size_t)n * PB + ch * 16) = *reinterpret_cast<const uint4*>(wl + (size_t)n * D + ch * 8);
+  if constexpr (RECOMP) {
+    // `wl` is W itself ([n][k] row-major, the operand of the forward passes): transposed into LDS here, once per workgroup,
+    // instead of by a transposing copy kernel in front of every launch
+    for (int item = threadIdx.x; item < D * G::CH; item += kDwThreads) {
+      const int n = item / G::CH, ch = item - n * G::CH;
+      const uint4 v = *reinterpret_cast<const uint4*>(wl + (size_t)n * D + ch * 8);
+      const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<uint16_t*>(lds_w + (size_t)(ch * 8 + j) * PB + n * 2) = (uint16_t)(e[j >> 1] >> ((j & 1) * 16));
+    }
+  } else {
+    for (int item = threadIdx.x; item < D * G::CH; item += kDwThreads) {
+      const int n = item / G::CH, ch = item - n * G::CH;
+      *reinterpret_cast<uint4*>(lds_w + (size_t)n * PB + ch * 16) = *reinterpret_cast<const uint4*>(wl + (size_t)n * D + ch * 8);
+    }
   }
   const int64_t n_tiles = (m_rows + kDwTile - 1) / kDwTile;
   const int ech = lane % G::CH, erow0 = lane / G::CH;
@@ -1055,23 +1068,23 @@ extern "C" int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, c
 #undef PYGHO_BLW
 }
 
-extern "C" int pygho_bn_bwd_linear_dw_recompute(void* gx, float* dw_ws, const void* gh, const void* x, const void* wlt, const void* bias,
+extern "C" int pygho_bn_bwd_linear_dw_recompute(void* gx, float* dw_ws, const void* gh, const void* x, const void* wl, const void* bias,
                                                 const void* addend, float* colsum_ws, const float* mean, const float* invstd,
                                                 const float* w, const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m,
                                                 int64_t d, int act, int training, int dtype, int64_t ws_stride, void* stream) {
   if (m <= 0 || d <= 0) { set_error("bn_bwd_linear_dw_recompute: empty input"); return PYGHO_ERR_INVALID; }
-  if (!gx || !dw_ws || !gh || !x || !wlt || !mean || !invstd || (training && (!sum_dz || !sum_dz_xhat))) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (!gx || !dw_ws || !gh || !x || !wl || !mean || !invstd || (training && (!sum_dz || !sum_dz_xhat))) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("bn_bwd_linear_dw_recompute: bf16 / f16 only"); return PYGHO_ERR_UNSUPPORTED; }
   if (d != 64 && d != 128) { set_error("bn_bwd_linear_dw_recompute: width %lld not supported (64, 128)", (long long)d); return PYGHO_ERR_UNSUPPORTED; }
   if (act < 0 || act > 2) { set_error("bn_bwd_linear_dw_recompute: unknown activation %d", act); return PYGHO_ERR_INVALID; }
-  if ((((uintptr_t)gx | (uintptr_t)gh | (uintptr_t)x | (uintptr_t)wlt | (uintptr_t)addend) % 16) != 0) { set_error("bn_bwd_linear_dw_recompute: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
+  if ((((uintptr_t)gx | (uintptr_t)gh | (uintptr_t)x | (uintptr_t)wl | (uintptr_t)addend) % 16) != 0) { set_error("bn_bwd_linear_dw_recompute: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
   const int grid = pygho_bn_bwd_linear_dw_blocks(m);
   hipStream_t st = (hipStream_t)stream;
   const BnBwdArgs bn{mean, invstd, w, b, sum_dz, sum_dz_xhat, act, training};
 #define PYGHO_BLR(T, DD)                                                                                                                \
-  (act == 0 ? launch_bn_bwd_linear_dw<T, DD, 0, true>(gx, nullptr, gh, x, wlt, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st, bias)   \
-   : act == 1 ? launch_bn_bwd_linear_dw<T, DD, 1, true>(gx, nullptr, gh, x, wlt, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st, bias) \
-              : launch_bn_bwd_linear_dw<T, DD, 2, true>(gx, nullptr, gh, x, wlt, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st, bias))
+  (act == 0 ? launch_bn_bwd_linear_dw<T, DD, 0, true>(gx, nullptr, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st, bias)   \
+   : act == 1 ? launch_bn_bwd_linear_dw<T, DD, 1, true>(gx, nullptr, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st, bias) \
+              : launch_bn_bwd_linear_dw<T, DD, 2, true>(gx, nullptr, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st, bias))
   if (dtype == PYGHO_BF16) return d == 128 ? PYGHO_BLR(bf16, 128) : PYGHO_BLR(bf16, 64);
   return d == 128 ? PYGHO_BLR(f16, 128) : PYGHO_BLR(f16, 64);
 #undef PYGHO_BLR

@@ -49,4 +49,6 @@ class GraphedStep:
                 raise RuntimeError("GraphedStep.replay: an index tensor was modified after capture; the captured launches still "
                                    "use the plans of the old pattern -- capture a new GraphedStep for the new batch pattern")
         self.graph.replay()
+        from . import _ops
+        _ops.invalidate_cast_arenas()      # a captured optimizer step moved the parameters without moving their version counters
         return self.output

@@ -51,9 +51,9 @@ class Linear(nn.Linear):
         if x.is_cuda and x.dim() == 2 and x.shape[0] >= 8192 and torch.is_grad_enabled():
             dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
             xx = x if x.dtype == dt else x.to(dt)
-            b = None if self.bias is None else self.bias.to(dt)
+            b = None if self.bias is None else _ops.cast_param(self.bias, dt)
             with torch.autocast("cuda", enabled=False):
-                return _SplitKLinearFn.apply(xx.contiguous(), self.weight.to(dt), b)
+                return _SplitKLinearFn.apply(xx.contiguous(), _ops.cast_param(self.weight, dt), b)
         return super().forward(x)
 
 

@@ -38,7 +38,7 @@ class IndexEmbedding(nn.Embedding):
     def forward(self, idx: Tensor) -> Tensor:
         if not idx.is_cuda:
             return super().forward(idx)
-        table = self.weight if self.out_dtype is None else self.weight.to(self.out_dtype)
+        table = self.weight if self.out_dtype is None else _ops.cast_param(self.weight, self.out_dtype)
         if self.padding_idx is not None:            # nn.Embedding semantics: that row reads as stored (zero) and gets no gradient
             keep = torch.ones((self.num_embeddings, 1), dtype=table.dtype, device=table.device)
             keep[self.padding_idx] = 0
@@ -155,6 +155,7 @@ class SpModel(nn.Module):
 
     def forward(self, datadict: dict) -> Tensor:
         raw = datadict["X"]
+        _ops.ensure_cast_arena(self, self.data_encoder.act_dtype)     # 16-bit parameter copies: one multi-tensor cast per step
         fuse = (_ops.USE_TABLE_PRODUCT and isinstance(raw, SparseTensor) and raw.values is not None and raw.values.is_cuda
                 and raw.values.dtype == torch.int64 and raw.values.numel() == raw.nnz)
         datadict = self.data_encoder(datadict, defer_tuplefeat=fuse)
