@@ -726,8 +726,12 @@ namespace pygho {
 // Unit segments (one message per output row): out[t] = (a[ai[t]] * b[bi[t]]) * c[ci[t]] -- the FORWARD of the tuple
 // initialisation (example/minimal.py:62-67).  The segment machinery above (pointer / index staging per pass, ordering, the
 // per-segment loop) is pure overhead when every segment holds exactly one message: 193 us through it against the output's
-// write time.  One lane group per row, 16 B per lane, two rows per thread in flight, grid-stride.
-template <typename T>
+// write time.  One lane group per row, 16 B per lane, R consecutive rows per lane group and sweep, grid-stride.  Measured at
+// 1.78 M tuples of 256 B (same box): rows of a sweep strided over the grid, 2 per group 238 us; R = 4 consecutive rows with the
+// next sweep's indices prefetched 184 us; + XCD-contiguous sweeps 179 us (R = 8: 194 us; additionally requesting the next
+// sweep's ROWS before this sweep's stores: 136 registers, 3 wavefronts per SIMD, 204 us).  Floors: stores alone 112 us, gathers
+// alone 115 us -- they do not overlap fully.
+template <typename T, int R>
 __global__ __launch_bounds__(kBlock) void unit_triple_kernel(T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b,
                                                              const T* __restrict__ c, const int32_t* __restrict__ ai,
                                                              const int32_t* __restrict__ bi, const int32_t* __restrict__ ci,
@@ -737,34 +741,55 @@ __global__ __launch_bounds__(kBlock) void unit_triple_kernel(T* __restrict__ out
   const int gl = threadIdx.x & ((1 << log2g) - 1);
   if (gl >= chunks) return;
   const uint32_t row_bytes = (uint32_t)d * sizeof(T), col = (uint32_t)gl * 16u;
-  const int64_t rows_per_block = kBlock >> log2g;
-  const int64_t stride = (int64_t)gridDim.x * rows_per_block;
+  const int64_t groups_per_block = kBlock >> log2g;
+  const int64_t stride = (int64_t)gridDim.x * groups_per_block * R;       // rows per grid sweep
   const char *ab = reinterpret_cast<const char*>(a), *bb = reinterpret_cast<const char*>(b), *cb = reinterpret_cast<const char*>(c);
   char* ob = reinterpret_cast<char*>(out);
-  for (int64_t t0 = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> log2g); t0 < n; t0 += 2 * stride) {
-    const int64_t t1 = t0 + stride;
-    const bool two = t1 < n;
-    const int64_t u1 = two ? t1 : t0;
-    const int64_t ia0 = ai ? ai[t0] : t0, ib0 = bi ? bi[t0] : t0, ic0 = ci ? ci[t0] : t0;
-    const int64_t ia1 = ai ? ai[u1] : u1, ib1 = bi ? bi[u1] : u1, ic1 = ci ? ci[u1] : u1;
-    const uint4 a0 = *reinterpret_cast<const uint4*>(ab + ia0 * row_bytes + col), b0 = *reinterpret_cast<const uint4*>(bb + ib0 * row_bytes + col),
-                c0 = *reinterpret_cast<const uint4*>(cb + ic0 * row_bytes + col);
-    const uint4 a1 = *reinterpret_cast<const uint4*>(ab + ia1 * row_bytes + col), b1 = *reinterpret_cast<const uint4*>(bb + ib1 * row_bytes + col),
-                c1 = *reinterpret_cast<const uint4*>(cb + ic1 * row_bytes + col);
-    float x[N], y[N], z[N], r[N];
-    V::unpack(a0, x); V::unpack(b0, y); V::unpack(c0, z);
+  // a lane group takes R CONSECUTIVE rows per sweep (neighbouring tuples share their root and their graph: the gathers of one
+  // group hit the same few cache lines) and loads the NEXT sweep's indices before it touches this sweep's rows, so the
+  // index -> row dependency is off the critical path
+  // workgroup b runs on XCD b % 8: the workgroups of one XCD take a contiguous eighth of every sweep, so the node rows a graph's
+  // tuples gather are fetched into ONE L2 (gridDim.x is a multiple of 8)
+  const int64_t lb = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  int64_t t0 = (lb * groups_per_block + (threadIdx.x >> log2g)) * R;
+  int32_t ia[R], ib[R], ic[R];
+  auto load_idx = [&](int64_t base, int32_t (&xa)[R], int32_t (&xb)[R], int32_t (&xc)[R]) {
 #pragma unroll
-    for (int q = 0; q < N; ++q) { const float p = x[q] * y[q]; r[q] = p * z[q]; }
-    *reinterpret_cast<uint4*>(ob + t0 * row_bytes + col) = V::pack(r);
-    if (two) {
-      V::unpack(a1, x); V::unpack(b1, y); V::unpack(c1, z);
-#pragma unroll
-      for (int q = 0; q < N; ++q) { const float p = x[q] * y[q]; r[q] = p * z[q]; }
-      *reinterpret_cast<uint4*>(ob + t1 * row_bytes + col) = V::pack(r);
+    for (int r = 0; r < R; ++r) {
+      const int64_t t = base + r;
+      const int64_t u = t < n ? t : n - 1;
+      xa[r] = ai ? ai[u] : (int32_t)u; xb[r] = bi ? bi[u] : (int32_t)u; xc[r] = ci ? ci[u] : (int32_t)u;
     }
+  };
+  if (t0 < n) load_idx(t0, ia, ib, ic);
+  for (; t0 < n; t0 += stride) {
+    int32_t na[R], nb[R], nc[R];
+    const int64_t tn = t0 + stride < n ? t0 + stride : t0;          // clamped: an unconditional load keeps the arrays in registers
+    load_idx(tn, na, nb, nc);
+    uint4 va[R], vb[R], vc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      va[r] = *reinterpret_cast<const uint4*>(ab + (int64_t)ia[r] * row_bytes + col);
+      vb[r] = *reinterpret_cast<const uint4*>(bb + (int64_t)ib[r] * row_bytes + col);
+      vc[r] = *reinterpret_cast<const uint4*>(cb + (int64_t)ic[r] * row_bytes + col);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t t = t0 + r;
+      float x[N], y[N], z[N], o[N];
+      V::unpack(va[r], x); V::unpack(vb[r], y); V::unpack(vc[r], z);
+#pragma unroll
+      for (int q = 0; q < N; ++q) { const float p = x[q] * y[q]; o[q] = p * z[q]; }
+      if (t < n) *reinterpret_cast<uint4*>(ob + t * row_bytes + col) = V::pack(o);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { ia[r] = na[r]; ib[r] = nb[r]; ic[r] = nc[r]; }
   }
 }
 
+#ifndef PYGHO_UNIT_ROWS
+#define PYGHO_UNIT_ROWS 4
+#endif
 template <typename T>
 int launch_unit_triple(void* out, const void* a, const void* b, const void* c, const int32_t* ai, const int32_t* bi, const int32_t* ci,
                        int64_t n, int64_t d, hipStream_t st) {
@@ -772,9 +797,9 @@ int launch_unit_triple(void* out, const void* a, const void* b, const void* c, c
   int log2g = 0;
   while ((1 << log2g) < chunks) ++log2g;
   const int64_t rows_per_block = kBlock >> log2g;
-  const int gx = grid_for(n, (int)(2 * rows_per_block), 256 * 16);
-  hipLaunchKernelGGL((unit_triple_kernel<T>), dim3(gx), dim3(kBlock), 0, st, (T*)out, (const T*)a, (const T*)b, (const T*)c, ai, bi, ci, n,
-                     chunks, log2g, (int)d);
+  const int gx = (grid_for(n, (int)(PYGHO_UNIT_ROWS * rows_per_block), 256 * 16) + 7) & ~7;
+  hipLaunchKernelGGL((unit_triple_kernel<T, PYGHO_UNIT_ROWS>), dim3(gx), dim3(kBlock), 0, st, (T*)out, (const T*)a, (const T*)b, (const T*)c, ai,
+                     bi, ci, n, chunks, log2g, (int)d);
   return check_launch("seg_triple_product(unit)");
 }
 
