@@ -34,7 +34,7 @@ constexpr bool ORDERED = PYGHO_SEG_ORDERED != 0;
 template <bool OFF32>
 __device__ __forceinline__ uint4 load_row16(const char* __restrict__ base, int idx, uint32_t row_bytes, uint32_t col_bytes) {
   if (OFF32) {
-    const uint32_t off = (uint32_t)idx * row_bytes + col_bytes;
+    const uint32_t off = (uint32_t)idx * row_bytes + col_bytes;      // (a 24-bit multiply-add instead of v_mad_u64_u32: no change, measured)
     return *reinterpret_cast<const uint4*>(base + off);
   }
   return *reinterpret_cast<const uint4*>(base + ((int64_t)idx * (int64_t)row_bytes + col_bytes));
