@@ -218,7 +218,7 @@ constexpr int kWinLdsBytes = 64 * 1024;                    // window (128 rows o
 
 template <typename T>
 int launch_window(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx, const int32_t* rhs_idx,
-                  const float* scale, const void* addend, int64_t n_seg, int64_t d, int aggr, hipStream_t st) {
+                  const float* scale, const void* addend, int64_t n_seg, int64_t d, int aggr, hipStream_t st, bool rhs_big = false) {
   const int chunks = (int)(d * sizeof(T) / 16);
   int log2g = 0;
   while ((1 << log2g) < chunks) ++log2g;
@@ -230,6 +230,11 @@ int launch_window(void* out, const void* lhs, const void* rhs, const int32_t* se
   if (even < spp) spp = even;
   if (spp < gw) spp = gw;
   if (spp > kWinSegCap) spp = kWinSegCap;
+  // the windowed operand is the LARGE one (the by-edge backward plan of spspmm: segments = edges, both operands tuple-level rows
+  // that span their whole graph): a pass is kept to about two graphs' worth of segments so that its row range is near the
+  // window size.  Measured in the ZINC step (256-B rows, 8.7 messages per segment; fast kernel 288 us): 1 / 2 / 4 / 8 segments
+  // per lane group and pass -> 274 / 258 / 314 / 350 us
+  if (rhs_big && spp > 2 * gw) spp = 2 * gw;
   const int win_rows = (int)(kWinLdsBytes / (d * (int64_t)sizeof(T)));
   int gx = grid_for(n_seg, (int)(kWinWaves * spp), 512);  // 2 resident workgroups per CU
   if (gx > 8) gx = (gx + 7) & ~7;
@@ -276,7 +281,7 @@ extern "C" int pygho_seg_gather_mul_reduce_window(void* out, const void* addend,
   const int64_t lim = (int64_t)1 << 32;
   if (n_seg * rb >= lim || lhs_rows * rb >= lim || rhs_rows * rb >= lim) { set_error("seg_gather_mul_reduce_window: operands of 4 GiB and more are not supported"); return PYGHO_ERR_UNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
-#define PYGHO_WIN_T(T) launch_window<T>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, addend, n_seg, d, aggr, st)
+#define PYGHO_WIN_T(T) launch_window<T>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, addend, n_seg, d, aggr, st, rhs_rows > 2 * n_seg)
   if (dtype == PYGHO_F32) return PYGHO_WIN_T(float);
   if (dtype == PYGHO_BF16) return PYGHO_WIN_T(bf16);
   return PYGHO_WIN_T(f16);

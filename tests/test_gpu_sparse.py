@@ -700,6 +700,45 @@ def test_window_kernel_bit_identical(dev, dtype, d, aggr):
     np.testing.assert_allclose(N(out[("i2", True)][2].float()), ga_want, **tol)
 
 
+@pytest.mark.parametrize("dtype,d", [(torch.bfloat16, 128), (torch.float16, 64)])
+@pytest.mark.parametrize("aggr", ["sum", "mean"])
+def test_window_kernel_on_the_by_edge_backward_plan(dev, dtype, d, aggr):
+    """the gradient of spspmm's second operand on the ZINC 2-tuple plan (segments = edges, BOTH operands tuple-level rows spread
+    over their graph) takes the LDS-window kernel with few segments per pass: bit-identical to the gather-everything kernel
+    (module switch), and the whole backward against the oracle's gradient."""
+    from pygho_amd import _ops, synth
+    hb = synth.make_batch(300, "zinc", seed=12)
+    key = "X___X___1___A___0"
+    acd_np = hb.acd[key]
+    nt, ne = hb.num_tuples, hb.num_edges
+    assert ne >= 4096 and nt > 2 * ne
+    torch.manual_seed(0)
+    xv = torch.randn(nt, d, device=dev).to(dtype)
+    av = torch.randn(ne, d, device=dev).to(dtype)
+    g = torch.randn(nt, d, device=dev).to(dtype)
+    saved = _ops.USE_SEG_WINDOW_BY_EDGE
+    out = {}
+    try:
+        for win in (True, False):
+            _ops.USE_SEG_WINDOW_BY_EDGE = win
+            acd = T(acd_np, dev)
+            plan = _ops.message_plan(acd, nt, nt, ne)
+            p, a_g, c_g = plan.by_d()
+            scale = plan.fwd.inv_count if aggr == "mean" else None
+            assert _ops._window_eligible(ne, g, xv, c_g, "sum") == win
+            x, a = xv.clone().requires_grad_(True), av.clone().requires_grad_(True)
+            _ops.message_reduce(x, a, acd, nt, nt, ne, aggr).backward(g)
+            out[win] = (_ops.seg_gmr(ne, g, xv, p.seg_ptr, a_g, c_g, "sum", scale), a.grad, x.grad)
+    finally:
+        _ops.USE_SEG_WINDOW_BY_EDGE = saved
+    for got, want in zip(out[True], out[False]):
+        assert torch.equal(got, want)
+    assert torch.equal(out[True][0], out[True][1])
+    _gx, ga_want = O.spspmm_values_grad(N(xv.float()), N(av.float()), acd_np, nt, aggr, N(g.float()))
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    np.testing.assert_allclose(N(out[True][1].float()), ga_want, rtol=ulp, atol=ulp * np.abs(ga_want).max() * 0.25)
+
+
 def test_window_kernel_long_and_empty_segments(dev):
     """the LDS-window kernel on a plan with empty segments and segments far longer than the staged index capacity (indices then
     come from global memory), a 64-row rhs (an embedding table: the window is the whole operand), scaled lhs rows and a residual
