@@ -330,12 +330,17 @@ def main():
         summ = timer.summary()
         # the dominant kernel is ONE template instance (seg_gmr_fast_kernel<T, SUM, BOTH>): the forward launches carry
         # the residual row in their epilogue (",res"), the two backward launches per layer do not
+        # (seg_gmr_window_kernel -- ",window" -- serves the by-edge backward plan since round 2; it is reported beside it)
         dom = f"seg_gmr[{'bfloat16' if act_dtype is not None else 'float32'},sum,both"
-        parts = [v for k, v in summ.items() if k.startswith(dom)]
+        every = [v for k, v in summ.items() if k.startswith(dom)]
+        parts = [v for k, v in summ.items() if k.startswith(dom) and ",window" not in k]
         launches = sum(v[0] for v in parts)
         ms = sum(v[0] * v[1] for v in parts) / launches
         nbytes = sum(v[0] * v[2] for v in parts) / launches
         achieved = nbytes / (ms * 1e-3) / 1e9
+        op_launches = sum(v[0] for v in every)
+        op_ms = sum(v[0] * v[1] for v in every) / op_launches
+        op_bytes = sum(v[0] * v[2] for v in every) / op_launches
         es = 2 if act_dtype is not None else 4
         fwd_bytes = es * args.hidden * (2 * hb.num_tuples + hb.num_edges) + 8 * hb.num_messages(KEY) + 4 * (hb.num_tuples + 1)
         # HBM traffic of the dominant kernel: collected OUTSIDE this process in separate rocprofv3 --pmc passes of
@@ -358,7 +363,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "seg_gmr_fast_kernel<bf16,SUM,BOTH>"
                          if act_dtype is not None else "seg_gmr_fast_kernel<float,SUM,BOTH>",
                          "launches": launches, "avg_ms": ms, "algorithmic_bytes_per_launch": nbytes,
-                         "forward_bytes_per_msg_edge": fwd_bytes / hb.num_messages(KEY)},
+                         "forward_bytes_per_msg_edge": fwd_bytes / hb.num_messages(KEY),
+                         # every spspmm launch of the step (forward + both backward plans, BOTH kernels), same definition
+                         "spspmm_all_launches": {"launches": op_launches, "avg_ms": op_ms, "algorithmic_bytes_per_launch": op_bytes,
+                                                 "achieved": op_bytes / (op_ms * 1e-3) / 1e9,
+                                                 "frac": op_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             "kernels": {k: {"launches": v[0], "avg_ms": v[1], "GBps": v[2] / (v[1] * 1e-3) / 1e9} for k, v in summ.items()},
         }
         if use_dist:

@@ -351,6 +351,7 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
     d = ref.shape[1]
     out = torch.empty((out_rows, d), dtype=ref.dtype, device=dev)
     timer = LaunchTimer.active
+    windowed = False
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(dev))
@@ -367,6 +368,7 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
             ptr(a_scale.contiguous()), ptr(a_shift.contiguous()), ACT_CODE[a_name], a_side, out_rows, d, lhs.shape[0], rhs.shape[0],
             dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev)), "seg_gather_mul_reduce_act")
     elif _window_eligible(out_rows, lhs, rhs, rhs_idx, aggr):
+        windowed = True
         if addend is not None:
             assert addend.shape == out.shape and addend.dtype == out.dtype and addend.is_contiguous()
         check(lib().pygho_seg_gather_mul_reduce_window(
@@ -393,7 +395,7 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
         if addend is not None:
             nbytes += es * d * out_rows
         mode = "both" if (lhs is not None and rhs is not None) else ("lhs" if lhs is not None else "rhs")
-        timer.records.append((f"seg_gmr[{str(ref.dtype).split('.')[-1]},{aggr},{mode}{',scaled' if lhs_rowscale is not None else ''}{',res' if addend is not None else ''}{',act' if act is not None else ''}]",
+        timer.records.append((f"seg_gmr[{str(ref.dtype).split('.')[-1]},{aggr},{mode}{',scaled' if lhs_rowscale is not None else ''}{',res' if addend is not None else ''}{',act' if act is not None else ''}{',window' if windowed else ''}]",
                               nbytes, e0, e1))
     return out
 
