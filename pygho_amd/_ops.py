@@ -1933,6 +1933,7 @@ def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype, want_colsum
 
 USE_FUSED_DW = True      # weight gradient inside the backward kernel (gpre never reaches HBM)
 USE_TABLE_PRODUCT = True
+USE_GRAD_CHAIN = os.environ.get("PYGHO_GRAD_CHAIN", "1") != "0"   # layers sharing A: A's gradient is summed inside the aggregation epilogues
 USE_ADJ_TABLE = True     # adjacency values that are an embedding lookup are read through the table inside the fused block
 USE_ACT_ON_LOAD = True   # f32 blocks: BatchNorm + activation applied inside the aggregation kernel's loads
 USE_BN_BWD_LINEAR = True
@@ -2092,7 +2093,7 @@ class _TupleBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, eps, act, rhs, plan, aggr, residual,
-                fold_momentum=None, rhs_lookup=None):
+                fold_momentum=None, rhs_lookup=None, chain=False):
         require_device(x, w, rhs)
         x = x.contiguous()
         # master weights (usually f32) are cast to the activation dtype here, outside the autograd graph; their
@@ -2146,11 +2147,19 @@ class _TupleBlock(torch.autograd.Function):
                     skinny)
         ctx.mark_non_differentiable(mean, var)
         ctx.set_materialize_grads(False)            # no zero tensors for the statistics' (never used) gradients
+        ctx.chain = bool(chain)
+        if chain:
+            # `rhs` again as an OUTPUT: the next block that shares this operand takes it from here, so the operand's gradient
+            # arrives in this block's backward already summed over the later blocks and is extended in the aggregation's epilogue
+            # (out = addend + ...), instead of autograd adding one (n_rhs, d) tensor per consumer
+            return out, mean, var, rhs.view_as(rhs)
         return out, mean, var
 
     @staticmethod
-    def backward(ctx, g, _gm, _gv):
+    def backward(ctx, g, _gm, _gv, g_chain=None):
         if g is None:
+            if g_chain is not None:
+                return (None,) * 10 + (g_chain,) + (None,) * (len(ctx.needs_input_grad) - 11)
             return (None,) * len(ctx.needs_input_grad)
         x, w, pre, h, rhs, bc, *saved = ctx.saved_tensors
         training, act, b_dtype, has_gamma, has_beta, plan, aggr, residual, w_dtype, skinny = ctx.meta
@@ -2169,10 +2178,15 @@ class _TupleBlock(torch.autograd.Function):
                 if ctx.affine is not None:
                     g_rhs = seg_gmr(plan.n_rhs, g, pre, p.seg_ptr, a_g, c_g, "sum", scale,
                                     act=(ctx.affine[0], ctx.affine[1], act, 2))
+                    if g_chain is not None:
+                        g_rhs = g_rhs + g_chain
                 else:
-                    g_rhs = seg_gmr(plan.n_rhs, g, h, p.seg_ptr, a_g, c_g, "sum", scale)
+                    g_rhs = seg_gmr(plan.n_rhs, g, h, p.seg_ptr, a_g, c_g, "sum", scale,
+                                    addend=None if g_chain is None else g_chain.contiguous())
+            elif g_chain is not None:
+                g_rhs = g_chain
         elif rhs is not None and ctx.needs_input_grad[10]:
-            g_rhs = g                                   # residual row operand: receives the output gradient as it is
+            g_rhs = g if g_chain is None else g + g_chain      # residual row operand: receives the output gradient as it is
         want_cs = b_dtype is not None and ctx.needs_input_grad[2]
         gx = gw = gb = None
         if pre is None or (skinny and USE_BN_BWD_LINEAR and USE_FUSED_DW and ctx.needs_input_grad[1]):
@@ -2197,12 +2211,12 @@ class _TupleBlock(torch.autograd.Function):
         if sdx is not None:
             gb = sdx.to(b_dtype)
         return (gx, gw, gb, (s2 if has_gamma else None), (s1 if has_beta else None), None, None, None, None, None,
-                g_rhs, None, None, None, None, None)
+                g_rhs, None, None, None, None, None, None)
 
 
 def tuple_block(x: Tensor, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", act: str, rhs: Optional[Tensor] = None,
                 plan: Optional[MessagePlan] = None, aggr: str = "sum", residual: bool = False,
-                rhs_lookup: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
+                rhs_lookup: Optional[Tuple[Tensor, Tensor]] = None, chain: bool = False):
     """fused Linear -> BatchNorm1d -> act (-> aggregation over `plan` with `rhs` (-> + x)); parameters are read
     from the stock modules (f32 master weights are cast to the activation dtype like autocast would)."""
     training = bn.training or bn.running_mean is None
@@ -2211,10 +2225,11 @@ def tuple_block(x: Tensor, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", a
     if plan is None and rhs is not None:                # residual row operand (see _TupleBlock.forward)
         assert rhs.shape == (x.shape[0], lin.out_features) and rhs.dtype == x.dtype and rhs_lookup is None
     fold = _fold_momentum(bn)
-    out, mean, var = _TupleBlock.apply(x, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                                       bn.eps, act, rhs, plan, aggr, residual, fold, rhs_lookup)
+    res = _TupleBlock.apply(x, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                            bn.eps, act, rhs, plan, aggr, residual, fold, rhs_lookup, chain)
+    out, mean, var = res[:3]
     _update_running(bn, mean, var, x.shape[0], folded=fold is not None)
-    return out
+    return (out, res[3]) if chain else out
 
 
 class _ConcatBlock(torch.autograd.Function):

@@ -103,8 +103,19 @@ def _residual_update(layer, A: Rep, X: Rep, datadict: dict) -> Rep:
     if lookup is not None and not (lookup[0].dim() == 2 and lookup[0].dtype == X.values.dtype and lookup[1].numel() == A.nnz
                                    and lookup[0].shape[1] == X.values.shape[1]):
         lookup = None
+    # the layers of a model share A: each block hands A's values on to the next one as an autograd OUTPUT (same storage), so that
+    # their gradient travels back through the blocks and is summed in the aggregation epilogues (`_ops._TupleBlock`); the link is
+    # kept on A and is valid for the values tensor it was made from
+    rhs, chain = A.values, _ops.USE_GRAD_CHAIN and torch.is_grad_enabled() and A.values.requires_grad
+    if chain:
+        link = A.__dict__.get("_pygho_grad_chain")
+        if link is not None and link[0] is A.values and link[1] == A.values._version:
+            rhs = link[2]
     with torch.autocast("cuda", enabled=False):
-        vals = _ops.tuple_block(X.values, lin, bn, act, rhs=A.values, plan=plan, aggr=op.aggr, residual=True, rhs_lookup=lookup)
+        vals = _ops.tuple_block(X.values, lin, bn, act, rhs=rhs, plan=plan, aggr=op.aggr, residual=True, rhs_lookup=lookup, chain=chain)
+    if chain:
+        vals, nxt = vals
+        A.__dict__["_pygho_grad_chain"] = (A.values, A.values._version, nxt)
     return X.tuplewiseapply(lambda _: vals)
 
 

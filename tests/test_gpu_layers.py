@@ -534,6 +534,47 @@ def test_tuple_block_without_stored_preactivation_equals_stored(dev):
         torch.testing.assert_close(a[4][k] / s, b[4][k] / s, rtol=0, atol=1e-3, msg=k)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_shared_adjacency_gradient_chain(dev, dtype):
+    """three layers share A (the model loop of example/minimal.py:76-79): with the gradient chain every block hands A's values on
+    as an autograd output and extends their gradient in its by-edge aggregation's epilogue; without it autograd adds the three
+    per-edge gradients.  Same outputs (bit for bit), same gradients (one rounding of the sum instead of one per addend)."""
+    import copy
+    from pygho_amd import SparseTensor, _ops
+    from pygho_amd.honn import Conv
+    h = 128
+    A, tid, xv, dd, n = _ngnn_inputs(dev, dtype, graphs=700)
+    torch.manual_seed(3)
+    layers = [Conv.NGNNConv(h, h, "sum", "SS", dict(MLP)).to(dev) for _ in range(3)]
+    wgt = torch.randn(xv.shape, device=dev)
+    old = _ops.USE_GRAD_CHAIN
+    res = {}
+    try:
+        for mode in (True, False):
+            _ops.USE_GRAD_CHAIN = mode
+            ls = copy.deepcopy(layers)
+            x = xv.clone().requires_grad_(True)
+            av = A.values.clone().requires_grad_(True)
+            Ax = SparseTensor(A.indices, av, A.shape, True)
+            X = SparseTensor(tid, x, [n, n, h], True)
+            for l in ls:
+                X = l.forward_residual(Ax, X, dd)
+            (X.values.float() * wgt).sum().backward()
+            res[mode] = (X.values.detach(), av.grad, x.grad, [p.grad for l in ls for p in l.parameters()])
+            assert ("_pygho_grad_chain" in Ax.__dict__) == mode
+    finally:
+        _ops.USE_GRAD_CHAIN = old
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0])
+    s = float(b[1].float().abs().max())
+    # bf16: the unchained sum rounds after every addend (up to one ulp = 2^-8 relative each), the chained one once
+    tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=2.0 ** -6, atol=2.0 ** -8)   # (atol: addends that cancel)
+    torch.testing.assert_close(a[1].float() / s, b[1].float() / s, **tol)
+    assert torch.equal(a[2], b[2])
+    for ga, gb in zip(a[3], b[3]):
+        assert torch.equal(ga, gb)
+
+
 def test_fused_residual_i2conv_3tuples(dev):
     """the same fused block on 3-tuples (I2Conv, BASELINE config 5 shape, d = 64 -> the d = 64 instantiation of the MFMA
     kernels): forward_residual against the unfused composition, values and input / parameter gradients, bf16."""
