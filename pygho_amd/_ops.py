@@ -1872,7 +1872,10 @@ class _CastParam(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, dtype):
         ctx.src_dtype = p.dtype
-        return param_as(p, dtype)
+        # a NEW tensor object every call: autograd writes this node into the returned object, and the arena's own view object
+        # would carry it -- and the AccumulateGrad node behind it, with the stream it was created on -- into the next iteration
+        # (a HIP graph capture after eager steps then pulled the eager stream into the capture and crashed in hipStreamEndCapture)
+        return param_as(p, dtype).detach()
 
     @staticmethod
     def backward(ctx, g):

@@ -758,6 +758,54 @@ def test_hip_graph_replay_equals_eager_steps(dev):
         torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=n1)
 
 
+def test_hip_graph_capture_after_eager_steps_and_eager_after_replay(dev):
+    """the SAME model trains eagerly, is then captured and replayed, and is evaluated eagerly afterwards.  (i) capture after eager
+    steps: the 16-bit parameter copies of `_ops.ParamCastArena` must not carry autograd state from one iteration into the next
+    (a view object that kept the previous iteration's node alive dragged the eager stream into the capture: crash in
+    hipStreamEndCapture); (ii) eager use after replays: a replayed optimizer step moves the parameters without moving their
+    version counters, so the arena must be told (`invalidate_cast_arenas`) -- the eager forward has to see the CURRENT weights."""
+    from pygho_amd import synth, _ops
+    from pygho_amd.graphs import GraphedStep
+    from pygho_amd.ngnn import SpModel
+    hb = synth.make_batch(256, "zinc", seed=32)
+    dd = synth.to_datadict(hb, dev)
+    y = dd["y"].unsqueeze(-1)
+    torch.manual_seed(0)
+    model = SpModel(1, 2, 128, act_dtype=torch.bfloat16).to(dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-3, capturable=True)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = model(dd)
+        loss = torch.nn.functional.l1_loss(y, pred.float())
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    for _ in range(3):
+        step()                                         # eager: creates the arena on the default stream
+    torch.cuda.synchronize()
+    gs = GraphedStep(step, warmup=2)
+    for _ in range(6):
+        loss = gs.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    model.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        after = model(dd).float()
+    old = _ops.USE_CAST_ARENA
+    try:
+        _ops.USE_CAST_ARENA = False                    # direct casts of the current parameters
+        model.__dict__.pop("_pygho_cast_arena", None)
+        _ops._ARENA_OF.clear()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            want = model(dd).float()
+    finally:
+        _ops.USE_CAST_ARENA = old
+    assert torch.equal(after, want)
+
+
 @pytest.mark.parametrize("case", ["f32_small", "bf16_rowblock"])
 def test_sunconv_dense_fused_passes(dev, case):
     """SUNConv on the padded layout with the fused node-view / recombination passes (`_ops.USE_PAIR_COMBINE`: pair_views,

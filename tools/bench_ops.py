@@ -337,7 +337,15 @@ def main():
     ap.add_argument("--i2-only", action="store_true", help="only the I2-shape spspmm case (profiling runs)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    out = []
+
+    class _Emit(list):                     # every line is printed as soon as its case is done
+        def append(self, r):
+            print(json.dumps(r), flush=True)
+
+        def extend(self, rs):
+            for r in rs:
+                self.append(r)
+    out = _Emit()
     if args.i2_only:
         print(json.dumps(spspmm_case("i2", 256 if args.quick else 2048, 256, torch.bfloat16, dev)))
         return
@@ -359,8 +367,6 @@ def main():
     out.append(planner_case("zinc", 1024 if args.quick else 8192, dev))
     out.append(collate_case(1024 if args.quick else 8192, dev))
     out.append(dense_collate_case(128 if args.quick else 1024, 37, 128, dev))
-    for r in out:
-        print(json.dumps(r))
 
 
 if __name__ == "__main__":
