@@ -80,6 +80,9 @@ def _views(mode: str, pool: str):
     }
 
 
+GRAD_CHAIN_KEY = "_pygho_grad_chain"      # datadict key a model loop sets to {} for one forward pass (see _residual_update)
+
+
 def _residual_update(layer, A: Rep, X: Rep, datadict: dict) -> Rep:
     """X + aggr(lin(X), A) for the layers whose update is `tuple-wise MLP, then X A inside the subgraph`.  Fused
     path (sparse X and A on the device, single-block MLP with square weight, sum / mean, precomputed acd):
@@ -104,18 +107,20 @@ def _residual_update(layer, A: Rep, X: Rep, datadict: dict) -> Rep:
                                    and lookup[0].shape[1] == X.values.shape[1]):
         lookup = None
     # the layers of a model share A: each block hands A's values on to the next one as an autograd OUTPUT (same storage), so that
-    # their gradient travels back through the blocks and is summed in the aggregation epilogues (`_ops._TupleBlock`); the link is
-    # kept on A and is valid for the values tensor it was made from
-    rhs, chain = A.values, _ops.USE_GRAD_CHAIN and torch.is_grad_enabled() and A.values.requires_grad
+    # their gradient travels back through the blocks and is summed in the aggregation epilogues (`_ops._TupleBlock`).  Opt-in by
+    # the model loop: it puts an empty dict under GRAD_CHAIN_KEY into the datadict of ONE forward pass (the links belong to that
+    # pass's autograd graph and must not outlive it); layers called without it do not chain
+    holder = datadict.get(GRAD_CHAIN_KEY) if _ops.USE_GRAD_CHAIN else None
+    rhs, chain = A.values, holder is not None and torch.is_grad_enabled() and A.values.requires_grad
     if chain:
-        link = A.__dict__.get("_pygho_grad_chain")
+        link = holder.get(id(A.values))
         if link is not None and link[0] is A.values and link[1] == A.values._version:
             rhs = link[2]
     with torch.autocast("cuda", enabled=False):
         vals = _ops.tuple_block(X.values, lin, bn, act, rhs=rhs, plan=plan, aggr=op.aggr, residual=True, rhs_lookup=lookup, chain=chain)
     if chain:
         vals, nxt = vals
-        A.__dict__["_pygho_grad_chain"] = (A.values, A.values._version, nxt)
+        holder[id(A.values)] = (A.values, A.values._version, nxt)
     return X.tuplewiseapply(lambda _: vals)
 
 

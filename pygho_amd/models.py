@@ -20,7 +20,7 @@ from . import _ops
 from .backend.MaTensor import MaskedTensor
 from .backend.SpTensor import SparseTensor
 from .backend.utils import torch_scatter_reduce
-from .honn.Conv import DSSGNNConv, GNNAKConv, I2Conv, NGNNConv, PPGNConv, SSWLConv, SUNConv
+from .honn.Conv import GRAD_CHAIN_KEY, DSSGNNConv, GNNAKConv, I2Conv, NGNNConv, PPGNConv, SSWLConv, SUNConv
 from .honn.MaOperator import OpPooling
 from .honn.TensorOp import OpPoolingSubg2D, OpPoolingSubg3D
 from .honn.utils import MLP
@@ -100,7 +100,8 @@ class SpModel(nn.Module):
         return X.tuplewiseapply(lambda v: _ops.gather_rows(left, X._row(0)) * _ops.gather_rows(right, X._row(1)) * v)
 
     def forward(self, datadict: dict) -> Tensor:
-        datadict = self.data_encoder(datadict)
+        datadict = dict(self.data_encoder(datadict))      # a dict of this forward pass only
+        datadict[GRAD_CHAIN_KEY] = {}                     # layers sharing A sum its gradient inside their aggregations (honn/Conv.py)
         A, X, x = datadict["A"], datadict["X"], datadict["x"]
         X = self.tupleinit(X, x)
         for conv in self.subggnns:
@@ -157,7 +158,8 @@ class MaModel(nn.Module):
         return X.tuplewiseapply(lambda val: self.lin_tupleinit0(xf).unsqueeze(1) * self.lin_tupleinit1(xf).unsqueeze(2) * val)
 
     def forward(self, datadict: dict) -> Tensor:
-        datadict = self.data_encoder(datadict)
+        datadict = dict(self.data_encoder(datadict))      # a dict of this forward pass only
+        datadict[GRAD_CHAIN_KEY] = {}                     # layers sharing A sum its gradient inside their aggregations (honn/Conv.py)
         A, X, x = datadict["A"], datadict["X"], datadict["x"]
         X = self.tupleinit(X, x)
         for conv in self.subggnns:

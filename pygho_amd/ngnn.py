@@ -13,7 +13,7 @@ from torch import Tensor
 from . import _ops
 from .backend.SpTensor import SparseTensor
 from .backend.utils import torch_scatter_reduce
-from .honn.Conv import NGNNConv
+from .honn.Conv import GRAD_CHAIN_KEY, NGNNConv
 from .honn.TensorOp import OpPoolingSubg2D
 from .honn.utils import MLP, Linear
 
@@ -158,7 +158,8 @@ class SpModel(nn.Module):
         _ops.ensure_cast_arena(self, self.data_encoder.act_dtype)     # 16-bit parameter copies: one multi-tensor cast per step
         fuse = (_ops.USE_TABLE_PRODUCT and isinstance(raw, SparseTensor) and raw.values is not None and raw.values.is_cuda
                 and raw.values.dtype == torch.int64 and raw.values.numel() == raw.nnz)
-        datadict = self.data_encoder(datadict, defer_tuplefeat=fuse)
+        datadict = self.data_encoder(datadict, defer_tuplefeat=fuse)        # a new dict per forward pass
+        datadict[GRAD_CHAIN_KEY] = {}           # the layers share A: its gradient is summed inside their by-edge aggregations
         A, X, x = datadict["A"], datadict["X"], datadict["x"]
         X = self.tupleinit(X, x, datadict.get("X_table"))
         for conv in self.subggnns:
