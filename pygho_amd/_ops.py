@@ -1823,6 +1823,8 @@ class ParamCastArena:
         self.versions = [-1] * len(self.params)
         self.epoch = -1
         ref = weakref.ref(self)
+        for k in [k for k, (r, _i) in _ARENA_OF.items() if r() is None]:      # entries of arenas that are gone
+            del _ARENA_OF[k]
         for i, p in enumerate(self.params):
             _ARENA_OF[id(p)] = (ref, i)
 
