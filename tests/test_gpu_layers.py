@@ -268,6 +268,52 @@ def test_fused_batchnorm_act_matches_torch(dev, dtype, act):
         assert int(bn1.num_batches_tracked) == int(bn2.num_batches_tracked)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d", [128, 64])
+def test_tuple_block_without_stored_preactivation_matches_torch(dev, dtype, d):
+    """the whole Linear -> BatchNorm1d -> SiLU block on the recompute kernels (statistics-only pass, one-pass forward, backward sums
+    and one-pass backward, none of which reads a stored pre-activation) against plain torch in f32 on the same 16-bit inputs:
+    output, input / weight / bias and BatchNorm gradients, running statistics; training and eval mode.  Tolerances: one rounding
+    of the 16-bit pre-activation and output (the f32 reference does not round the pre-activation)."""
+    from pygho_amd import _ops
+    torch.manual_seed(0)
+    m = 24_001
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    x = (torch.randn(m, d, device=dev) * 0.8 + 0.2).to(dtype)
+    g = torch.randn(m, d, device=dev).to(dtype)
+    for training in (True, False):
+        lin1 = torch.nn.Linear(d, d).to(dev)
+        bn1, bn2 = torch.nn.BatchNorm1d(d).to(dev), torch.nn.BatchNorm1d(d).to(dev)
+        with torch.no_grad():
+            lin1.weight.copy_(lin1.weight.to(dtype).float()); lin1.bias.copy_(lin1.bias.to(dtype).float())      # exactly representable
+            bn1.weight.uniform_(0.5, 1.5); bn1.bias.normal_(0, 0.3); bn1.running_mean.normal_(0, 0.2); bn1.running_var.uniform_(0.5, 2.0)
+        bn2.load_state_dict(bn1.state_dict())
+        lin2 = torch.nn.Linear(d, d).to(dev)
+        lin2.load_state_dict(lin1.state_dict())
+        bn1.train(training); bn2.train(training)
+        assert _ops.USE_RECOMPUTE_PRE
+        xa = x.clone().requires_grad_(True)
+        ya = _ops.tuple_block(xa, lin1, bn1, "silu")
+        (ya.float() * g.float()).sum().backward()
+        xb = x.float().clone().requires_grad_(True)
+        yb = torch.nn.functional.silu(bn2(lin2(xb)))
+        (yb * g.float()).sum().backward()
+        scale = float(yb.abs().max())
+        torch.testing.assert_close(ya.float() / scale, yb / scale, rtol=0, atol=6 * ulp)
+        gs = float(xb.grad.abs().max())
+        torch.testing.assert_close(xa.grad.float() / gs, xb.grad / gs, rtol=0, atol=8 * ulp)
+        ws = float(lin2.weight.grad.abs().max())
+        torch.testing.assert_close(lin1.weight.grad / ws, lin2.weight.grad / ws, rtol=0, atol=4 * ulp)
+        for pa, pb in ((bn1.weight, bn2.weight), (bn1.bias, bn2.bias)):
+            s = float(pb.grad.abs().max())
+            torch.testing.assert_close(pa.grad / s, pb.grad / s, rtol=0, atol=4 * ulp)
+        if not training:                               # in training mode the bias in front of a BatchNorm has a zero gradient
+            s = float(lin2.bias.grad.abs().max())
+            torch.testing.assert_close(lin1.bias.grad / s, lin2.bias.grad / s, rtol=0, atol=4 * ulp)
+        torch.testing.assert_close(bn1.running_mean, bn2.running_mean, rtol=0, atol=4 * ulp)
+        torch.testing.assert_close(bn1.running_var, bn2.running_var, rtol=4 * ulp, atol=4 * ulp)
+
+
 def _ngnn_inputs(dev, dtype, graphs=64, h=128, seed=5):
     from pygho_amd import SparseTensor, synth
     hb = synth.make_batch(graphs, "zinc", seed=seed)
