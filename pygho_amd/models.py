@@ -100,6 +100,7 @@ class SpModel(nn.Module):
         return X.tuplewiseapply(lambda v: _ops.gather_rows(left, X._row(0)) * _ops.gather_rows(right, X._row(1)) * v)
 
     def forward(self, datadict: dict) -> Tensor:
+        _ops.ensure_cast_arena(self, self.data_encoder.x_encoder.out_dtype)   # 16-bit parameter copies: one multi-tensor cast per step
         datadict = dict(self.data_encoder(datadict))      # a dict of this forward pass only
         datadict[GRAD_CHAIN_KEY] = {}                     # layers sharing A sum its gradient inside their aggregations (honn/Conv.py)
         A, X, x = datadict["A"], datadict["X"], datadict["x"]
@@ -158,6 +159,7 @@ class MaModel(nn.Module):
         return X.tuplewiseapply(lambda val: self.lin_tupleinit0(xf).unsqueeze(1) * self.lin_tupleinit1(xf).unsqueeze(2) * val)
 
     def forward(self, datadict: dict) -> Tensor:
+        _ops.ensure_cast_arena(self, self.data_encoder.x_encoder.out_dtype)   # 16-bit parameter copies: one multi-tensor cast per step
         datadict = dict(self.data_encoder(datadict))      # a dict of this forward pass only
         datadict[GRAD_CHAIN_KEY] = {}                     # layers sharing A sum its gradient inside their aggregations (honn/Conv.py)
         A, X, x = datadict["A"], datadict["X"], datadict["x"]
