@@ -362,6 +362,43 @@ def test_i2_shape_and_large_linearity(dev):
     assert bool((torch.diff(acd_b[0]) >= 0).all())                            # collated plan stays sorted
 
 
+@pytest.mark.parametrize("kind,graphs,d,key", [("zinc", 8192, 128, "X___X___1___A___0"), ("i2", 2048, 256, "X___X___2___A___0")])
+def test_baseline_size_properties_bf16(dev, kind, graphs, d, key):
+    """BASELINE.json's full sizes (config 2: 8192 ZINC-shape graphs, hidden 128; config 5: 2048 I2-shape graphs, hidden 256; bf16),
+    where the oracle no longer finishes in seconds: size-independent properties of the forward launch and of both backward plans
+    (fast kernel, LDS-window kernels).  (i) scaling an operand by a power of two scales the result by it, bit for bit; (ii) a
+    per-channel checksum of every output equals the f64 sum over all messages of the operand products within the rounding of
+    the bf16 outputs; (iii) two runs are bit-identical (no atomics anywhere)."""
+    from pygho_amd import _ops, synth
+    hb = synth.replicate(synth.make_batch(min(graphs, 1024), kind, seed=1000), max(1, graphs // 1024))
+    acd = T(hb.acd[key], dev)
+    nt, ne = hb.num_tuples, hb.num_edges
+    plan = _ops.message_plan(acd, nt, nt, ne)
+    torch.manual_seed(0)
+    x = torch.randn(nt, d, device=dev).to(torch.bfloat16)
+    a = torch.randn(ne, d, device=dev).to(torch.bfloat16)
+    g = torch.randn(nt, d, device=dev).to(torch.bfloat16)
+    pc, a_c, d_c = plan.by_c()
+    pd, a_d, c_d = plan.by_d()
+    calls = {
+        "forward": (lambda u, v: _ops.seg_gmr(nt, u, v, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, "sum"), x, a, acd[1], acd[2]),
+        "by-tuple backward": (lambda u, v: _ops.seg_gmr(nt, u, v, pc.seg_ptr, a_c, d_c, "sum"), g, a, acd[0], acd[2]),
+        "by-edge backward": (lambda u, v: _ops.seg_gmr(ne, u, v, pd.seg_ptr, a_d, c_d, "sum"), g, x, acd[0], acd[1]),
+    }
+    for name, (fn, u, v, iu, iv) in calls.items():
+        out = fn(u, v)
+        assert torch.equal(out, fn(u, v)), name                                  # (iii)
+        assert torch.equal(fn(u * 4, v), out * 4) and torch.equal(fn(u, v * 0.5), out * 0.5), name      # (i)
+        direct = torch.zeros(d, dtype=torch.float64, device=dev)                 # (ii), in slices: 8 M messages x 256 f64 do not fit at once
+        step = 1 << 20
+        for lo in range(0, acd.shape[1], step):
+            direct += (u.double()[iu[lo:lo + step]] * v.double()[iv[lo:lo + step]]).sum(0)
+        got = out.double().sum(0)
+        # every output row carries one bf16 rounding (2^-9 relative, random sign): the checksum's error grows like the root of the row count
+        scale = float(out.float().abs().mean()) * out.shape[0] ** 0.5 * 2.0 ** -8
+        torch.testing.assert_close(got, direct, rtol=0, atol=6 * scale, msg=name)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_long_segments_hierarchical(dev, dtype):
     """a 4-row table receiving 300k rows (the embedding-backward shape): hierarchical chunks, f32 partials"""
