@@ -256,6 +256,39 @@ def test_masked_bmm_multiblock_kernel_shapes(dev, dtype, shape, layout):
         np.testing.assert_allclose(N(nomask) * om[..., None], exp, rtol=eps, atol=eps * scale)
 
 
+def test_masked_bmm_baseline_size_properties(dev):
+    """BASELINE config 3's size -- (1024, 37, 37, 128) bf16, a padded ZINC-shape batch: node-pair masks on both operands and the
+    output (the PPGN contraction) and an adjacency mask on the second operand -- where a float64 einsum of the whole batch is 11 GB:
+    (i) a batch slice of 16 elements against the float64 einsum; (ii) scaling an operand by a power of two scales the result bit
+    for bit; (iii) batch elements are independent: the first 64 elements computed alone equal the first 64 of the full launch bit
+    for bit; (iv) masked output slots are exact zeros; (v) two runs are bit-identical."""
+    from pygho_amd import _ops, synth
+    dn = synth.make_dense_batch(256, seed=2, hidden=128, nmax=37)
+    rep = 4
+    t = lambda a, dt=None: (torch.from_numpy(a).to(dev).repeat((rep,) + (1,) * (a.ndim - 1)).to(dt) if dt
+                            else torch.from_numpy(a).to(dev).repeat((rep,) + (1,) * (a.ndim - 1)))
+    X, Xm = t(dn["X"], torch.bfloat16), t(dn["Xmask"])
+    Am = t(dn["Amask"])
+    nb, n, d = X.shape[0], X.shape[1], X.shape[3]
+    assert (nb, n, d) == (1024, 37, 128)
+    torch.manual_seed(0)
+    Y = torch.randn_like(X)
+    mx, ma = _ops._mask_u8(Xm), _ops._mask_u8(Am)
+    for name, bmask, bmask_b in (("X Y (pair masks)", mx, Xm), ("X A (adjacency mask)", ma, Am)):
+        f = lambda a, b, nbb=nb: _ops.masked_bmm(a[:nbb].contiguous(), b[:nbb].contiguous(), mx[:nbb].contiguous(), bmask[:nbb].contiguous(),
+                                                 mx[:nbb].contiguous(), nbb, n, n, n, d, False, True)
+        out = f(X, Y)
+        assert torch.equal(out, f(X, Y)), name                                                     # (v)
+        assert torch.equal(f(X * 2, Y), out * 2) and torch.equal(f(X, Y * 0.25), out * 0.25), name   # (ii)
+        assert torch.equal(f(X, Y, 64), out[:64]), name                                            # (iii)
+        assert float(out[~Xm.bool()].abs().max()) == 0.0, name                                     # (iv)
+        sl = slice(100, 116)
+        exp = torch.einsum("bikd,bkjd->bijd", X[sl].double() * Xm[sl].bool()[..., None], Y[sl].double() * bmask_b[sl].bool()[..., None]) \
+            * Xm[sl].bool()[..., None]
+        scale = float(exp.abs().max())
+        torch.testing.assert_close(out[sl].double() / scale, exp / scale, rtol=0, atol=2.0 ** -8, msg=name)   # (i)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("layout", [(False, True), (True, True), (False, False), (True, False)])
 def test_masked_bmm_padded_batch_extents(dev, dtype, layout):
