@@ -1307,7 +1307,7 @@ class _PairViews(torch.autograd.Function):
     subgraph layer takes of a 2-D representation; their gradients return to the tuple level in ONE pass."""
 
     @staticmethod
-    def forward(ctx, data: Tensor, mask: Tensor, want_dim2: bool = True):
+    def forward(ctx, data: Tensor, mask: Tensor, want_dim2: bool = True, chain: bool = False):
         require_device(data, mask)
         data = data.contiguous()
         dmask = torch.diagonal(mask, 0, 1, 2)
@@ -1316,20 +1316,27 @@ class _PairViews(torch.autograd.Function):
         s2 = _MaskedReduce.apply(data, mask, 2, "sum")[0] if want_dim2 else data.new_empty((0,) + tuple(data.shape[2:]))
         ctx.mask = mask
         ctx.meta = (tuple(data.shape), data.dtype, want_dim2)
+        ctx.set_materialize_grads(False)
+        if chain:       # `data` again as an output: a later consumer's gradient arrives here and rides in the combine pass as its base
+            return dg.contiguous(), s1, s2, data.view_as(data)
         return dg.contiguous(), s1, s2
 
     @staticmethod
-    def backward(ctx, g_dg, g_s1, g_s2):
+    def backward(ctx, g_dg, g_s1, g_s2, g_chain=None):
         shape, dtype, want_dim2 = ctx.meta
         dev = ctx.mask.device
-        cast = lambda t: None if t is None else t.to(dtype)
+        cast = lambda t: None if t is None else t.to(dtype).contiguous()
         if not want_dim2:
             g_s2 = None
-        return masked_pair_combine(None, cast(g_s2), cast(g_s1), cast(g_dg), False, ctx.mask, shape, dtype, dev), None, None
+        if g_dg is None and g_s1 is None and g_s2 is None:
+            return g_chain, None, None, None
+        return masked_pair_combine(cast(g_chain), cast(g_s2), cast(g_s1), cast(g_dg), False, ctx.mask, shape, dtype, dev), None, None, None
 
 
-def pair_views(data: Tensor, mask: Tensor, want_dim2: bool = True):
-    return _PairViews.apply(data, mask, want_dim2)
+def pair_views(data: Tensor, mask: Tensor, want_dim2: bool = True, chain: bool = False):
+    """`chain`: also returns `data` as an autograd output (same storage) for the consumer that comes after the views, so that its
+    gradient is summed with the views' gradients inside their one combine pass instead of by a separate accumulation."""
+    return _PairViews.apply(data, mask, want_dim2, chain)
 
 
 def _dense_linear(flat: Tensor, w_in_out: Tensor, addend: Optional[Tensor] = None) -> Tensor:
@@ -1424,7 +1431,7 @@ class _SparsePairViews(torch.autograd.Function):
     sharing index 1); the three gradients return to the tuples in ONE gather pass."""
 
     @staticmethod
-    def forward(ctx, values: Tensor, ri: Tensor, ci: Tensor, diag_pos: Tensor, n: int, want_rows: bool = True):
+    def forward(ctx, values: Tensor, ri: Tensor, ci: Tensor, diag_pos: Tensor, n: int, want_rows: bool = True, chain: bool = False):
         require_device(values, ri, ci, diag_pos)
         values = values.contiguous()
         dg = _matched_rows(values, diag_pos)
@@ -1435,21 +1442,26 @@ class _SparsePairViews(torch.autograd.Function):
         s_c = _ScatterReduce.apply(values, cached_plan(ci, n, "scatter"), narrow_i32(ci), "sum")
         ctx.idx = (narrow_i32(ri), narrow_i32(ci))
         ctx.meta = (values.shape[1], values.dtype, want_rows)
+        ctx.set_materialize_grads(False)
+        if chain:       # see _PairViews
+            return dg, s_r, s_c, values.view_as(values)
         return dg, s_r, s_c
 
     @staticmethod
-    def backward(ctx, g_dg, g_r, g_c):
+    def backward(ctx, g_dg, g_r, g_c, g_chain=None):
         d, dtype, want_rows = ctx.meta
         ri32, ci32 = ctx.idx
-        cast = lambda t: None if t is None else t.to(dtype)
+        cast = lambda t: None if t is None else t.to(dtype).contiguous()
         if not want_rows:
             g_r = None
-        return (pair_gather_combine(None, cast(g_r), cast(g_c), cast(g_dg), False, ri32, ci32, d, dtype, ri32.device),
-                None, None, None, None, None)
+        if g_dg is None and g_r is None and g_c is None:
+            return g_chain, None, None, None, None, None, None
+        return (pair_gather_combine(cast(g_chain), cast(g_r), cast(g_c), cast(g_dg), False, ri32, ci32, d, dtype, ri32.device),
+                None, None, None, None, None, None)
 
 
-def sparse_pair_views(values: Tensor, ri: Tensor, ci: Tensor, diag_pos: Tensor, n: int, want_rows: bool = True):
-    return _SparsePairViews.apply(values, ri, ci, diag_pos, n, want_rows)
+def sparse_pair_views(values: Tensor, ri: Tensor, ci: Tensor, diag_pos: Tensor, n: int, want_rows: bool = True, chain: bool = False):
+    return _SparsePairViews.apply(values, ri, ci, diag_pos, n, want_rows, chain)
 
 
 class _SparsePairLinearMix(torch.autograd.Function):

@@ -470,14 +470,16 @@ class SUNConv(Module):
             dt, d_ = xv.dtype, xv.shape[-1]
 
             def views(vals, m, subg=True):
-                dg, s1, s2 = _ops.pair_views(vals, m, subg)         # rows (b,i,i); sum over dim 1 -> [b,j]; over dim 2 -> [b,i]
+                # `vals` comes back as an autograd output: the recombination below consumes THAT, so its gradient wrt the tuple rows
+                # is the base of the views' one backward pass instead of a separate accumulation (a (b, n, n, d) add each)
+                dg, s1, s2, vals = _ops.pair_views(vals, m, subg, True)   # rows (b,i,i); sum over dim 1 -> [b,j]; over dim 2 -> [b,i]
                 if self._pool == "mean":
                     s1 = s1 / m.sum(1).clamp_min(1).unsqueeze(-1).to(dt)
                     s2 = s2 / m.sum(2).clamp_min(1).unsqueeze(-1).to(dt) if subg else None
-                return dg, s1, s2                                   # (centre, pool2node, pool2subg)
+                return dg, s1, s2, vals                             # (centre, pool2node, pool2subg)
 
-            centre, n5, n6 = views(xv, mask)
-            agg_dg, n7, _unused = views(av, amask, subg=False)       # pool2subg(agg) is not one of the seven views
+            centre, n5, n6, xv = views(xv, mask)
+            agg_dg, n7, _unused, av = views(av, amask, subg=False)   # pool2subg(agg) is not one of the seven views
         else:
             xv, av = as_c(X.values), as_c(agg.values)
             dt, d_ = xv.dtype, xv.shape[-1]
@@ -492,13 +494,13 @@ class SUNConv(Module):
             pos, cnt_r, cnt_c = cache["sun_views"]
 
             def views(vals, subg=True):
-                dg, s_r, s_c = _ops.sparse_pair_views(vals, ri, ci, pos, n, subg)  # rows (i,i); sum over j -> [i]; over i -> [j]
+                dg, s_r, s_c, vals = _ops.sparse_pair_views(vals, ri, ci, pos, n, subg, True)  # rows (i,i); sum over j -> [i]; over i -> [j]
                 if self._pool == "mean":
                     s_r, s_c = (s_r / cnt_r.to(dt) if subg else None), s_c / cnt_c.to(dt)
-                return dg, s_c, s_r                                 # (centre, pool2node, pool2subg)
+                return dg, s_c, s_r, vals                           # (centre, pool2node, pool2subg; the values again, see above)
 
-            centre, n5, n6 = views(xv)
-            agg_dg, n7, _unused = views(av, subg=False)              # pool2subg(agg) is not one of the seven views
+            centre, n5, n6, xv = views(xv)
+            agg_dg, n7, _unused, av = views(av, subg=False)          # pool2subg(agg) is not one of the seven views
         w = lambda t, v: blk(t, v).to(dt)
 
         def node_lin(parts, blocks):
