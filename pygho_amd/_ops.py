@@ -2110,7 +2110,7 @@ class _TupleBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, eps, act, rhs, plan, aggr, residual,
-                fold_momentum=None, rhs_lookup=None, chain=False):
+                fold_momentum=None, rhs_lookup=None, chain=False, chain_x=False):
         require_device(x, w, rhs)
         x = x.contiguous()
         # master weights (usually f32) are cast to the activation dtype here, outside the autograd graph; their
@@ -2164,23 +2164,34 @@ class _TupleBlock(torch.autograd.Function):
                     skinny)
         ctx.mark_non_differentiable(mean, var)
         ctx.set_materialize_grads(False)            # no zero tensors for the statistics' (never used) gradients
-        ctx.chain = bool(chain)
+        ctx.chain = (bool(chain), bool(chain_x))
+        extra = ()
         if chain:
             # `rhs` again as an OUTPUT: the next block that shares this operand takes it from here, so the operand's gradient
             # arrives in this block's backward already summed over the later blocks and is extended in the aggregation's epilogue
             # (out = addend + ...), instead of autograd adding one (n_rhs, d) tensor per consumer
-            return out, mean, var, rhs.view_as(rhs)
-        return out, mean, var
+            extra += (rhs.view_as(rhs),)
+        if chain_x:
+            # the same for the block's INPUT: whoever else reads x takes it from here; that gradient arrives below and is added in the
+            # epilogue of the input-gradient GEMM (where the residual gradient goes), not by a separate (m, d) accumulation
+            extra += (x.view_as(x),)
+        return (out, mean, var) + extra
 
     @staticmethod
-    def backward(ctx, g, _gm, _gv, g_chain=None):
+    def backward(ctx, g, _gm, _gv, *g_extra):
+        g_extra = list(g_extra)
+        g_chain = g_extra.pop(0) if ctx.chain[0] else None
+        g_x = g_extra.pop(0) if ctx.chain[1] else None
         if g is None:
-            if g_chain is not None:
-                return (None,) * 10 + (g_chain,) + (None,) * (len(ctx.needs_input_grad) - 11)
-            return (None,) * len(ctx.needs_input_grad)
+            n_in = len(ctx.needs_input_grad)
+            return (g_x,) + (None,) * 9 + (g_chain,) + (None,) * (n_in - 11)
         x, w, pre, h, rhs, bc, *saved = ctx.saved_tensors
         training, act, b_dtype, has_gamma, has_beta, plan, aggr, residual, w_dtype, skinny = ctx.meta
         g = g.contiguous()
+        # what is added to the input gradient in the GEMM epilogue: the residual gradient and / or the gradient of x's other readers
+        res_g = g if residual else None
+        if g_x is not None:
+            res_g = g_x.contiguous() if res_g is None else res_g + g_x
         g_rhs = None
         gh = g
         if plan is not None:
@@ -2207,33 +2218,35 @@ class _TupleBlock(torch.autograd.Function):
         want_cs = b_dtype is not None and ctx.needs_input_grad[2]
         gx = gw = gb = None
         if pre is None or (skinny and USE_BN_BWD_LINEAR and USE_FUSED_DW and ctx.needs_input_grad[1]):
-            gx, gw32, s1, s2, sdx = bn_bwd_linear(pre, gh.contiguous(), saved, training, act, w, g if residual else None, want_cs, x=x,
+            gx, gw32, s1, s2, sdx = bn_bwd_linear(pre, gh.contiguous(), saved, training, act, w, res_g, want_cs, x=x,
                                                   lin_bias=bc)
             gw = gw32.to(w_dtype)
         elif skinny and USE_BN_BWD_LINEAR:
-            gx, gpre, s1, s2, sdx = bn_bwd_linear(pre, gh.contiguous(), saved, training, act, w, g if residual else None, want_cs)
+            gx, gpre, s1, s2, sdx = bn_bwd_linear(pre, gh.contiguous(), saved, training, act, w, res_g, want_cs)
         else:
             gpre, s1, s2, sdx = _bn_backward(pre, gh, saved, training, act, want_colsum=want_cs)
         if gx is None and ctx.needs_input_grad[0]:
             if skinny:
                 # dX = gpre . W (+ g): the residual gradient is added in the GEMM epilogue
-                gx, _ = rowblock_linear(gpre, w.t().contiguous(), None, addend=g if residual else None)
+                gx, _ = rowblock_linear(gpre, w.t().contiguous(), None, addend=res_g)
             else:
                 # (addmm(g, gpre, w) copies g first and then runs a slower beta = 1 GEMM: product + add is faster)
                 gx = gpre @ w
-                if residual:
-                    gx = gx.add_(g)
+                if res_g is not None:
+                    gx = gx.add_(res_g)
         if gw is None and ctx.needs_input_grad[1]:
             gw = weight_grad_splitk(gpre, x, w_dtype)
         if sdx is not None:
             gb = sdx.to(b_dtype)
+        if gx is None and g_x is not None:
+            gx = g_x
         return (gx, gw, gb, (s2 if has_gamma else None), (s1 if has_beta else None), None, None, None, None, None,
-                g_rhs, None, None, None, None, None, None)
+                g_rhs, None, None, None, None, None, None, None)
 
 
 def tuple_block(x: Tensor, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", act: str, rhs: Optional[Tensor] = None,
                 plan: Optional[MessagePlan] = None, aggr: str = "sum", residual: bool = False,
-                rhs_lookup: Optional[Tuple[Tensor, Tensor]] = None, chain: bool = False):
+                rhs_lookup: Optional[Tuple[Tensor, Tensor]] = None, chain: bool = False, chain_x: bool = False):
     """fused Linear -> BatchNorm1d -> act (-> aggregation over `plan` with `rhs` (-> + x)); parameters are read
     from the stock modules (f32 master weights are cast to the activation dtype like autocast would)."""
     training = bn.training or bn.running_mean is None
@@ -2243,10 +2256,11 @@ def tuple_block(x: Tensor, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", a
         assert rhs.shape == (x.shape[0], lin.out_features) and rhs.dtype == x.dtype and rhs_lookup is None
     fold = _fold_momentum(bn)
     res = _TupleBlock.apply(x, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                            bn.eps, act, rhs, plan, aggr, residual, fold, rhs_lookup, chain)
+                            bn.eps, act, rhs, plan, aggr, residual, fold, rhs_lookup, chain, chain_x)
     out, mean, var = res[:3]
     _update_running(bn, mean, var, x.shape[0], folded=fold is not None)
-    return (out, res[3]) if chain else out
+    # (out[, rhs again when `chain`][, x again when `chain_x`]): see _TupleBlock.forward
+    return (out,) + tuple(res[3:]) if (chain or chain_x) else out
 
 
 class _ConcatBlock(torch.autograd.Function):

@@ -417,20 +417,33 @@ class SUNConv(Module):
 
         add = lambda a, b: a.add(b, True) if isinstance(a, (SparseTensor, MaskedTensor)) else a + b
 
-        agg = self.aggr.forward(A, X.tuplewiseapply(self.lin0), datadict, X)
-        if _ops.USE_PAIR_COMBINE and self._pool in ("sum", "mean"):
+        fused_ok = _ops.USE_PAIR_COMBINE and self._pool in ("sum", "mean")
+        chained = {}
+        if fused_ok and isinstance(self.lin0, MLP):
+            # X feeds lin0 AND the recombination below: lin0's first block hands its input on as an autograd output, the recombination
+            # reads that, and its gradient wrt the tuple rows is added inside lin0's input-gradient GEMM (no (nnz, d) accumulation)
+            def lin0(v):
+                y, chained["x"] = self.lin0(v, return_input=True)
+                return y
+        else:
+            lin0 = self.lin0
+        agg = self.aggr.forward(A, X.tuplewiseapply(lin0), datadict, X)
+        if fused_ok:
             # compute dtype of the fused passes: the autocast dtype when autocast is on (operands are cast once), else X's
             cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
             as_c = lambda t: t if cdt is None or t.dtype == cdt or not t.is_floating_point() else t.to(cdt)
+            xin = chained.get("x")
             if (isinstance(X, MaskedTensor) and isinstance(agg, MaskedTensor) and X.masked_dim == 3 and X.raw.is_floating_point()
                     and agg.raw.shape == X.raw.shape and (cdt is not None or agg.raw.dtype == X.raw.dtype)
                     and _ops.pair_combine_supported(as_c(X.raw))):
-                return tail(self._recombine(X, agg, blk, True, as_c))
+                Xc = MaskedTensor(xin, X.mask) if xin is not None and xin.shape == X.raw.shape else X
+                return tail(self._recombine(Xc, agg, blk, True, as_c))
             if (isinstance(X, SparseTensor) and isinstance(agg, SparseTensor) and X.sparse_dim == 2 and X.values is not None
                     and agg.values is not None and X.values.is_floating_point() and agg.values.shape == X.values.shape
                     and (cdt is not None or agg.values.dtype == X.values.dtype) and agg.nnz == X.nnz and X.shape[0] == X.shape[1]
                     and _ops.pair_gather_supported(as_c(X.values))):
-                return tail(self._recombine(X, agg, blk, False, as_c))
+                Xc = X.tuplewiseapply(lambda _v: xin) if xin is not None and xin.shape == X.values.shape else X
+                return tail(self._recombine(Xc, agg, blk, False, as_c))
         centre, n5, n6, n7 = self.diag.forward(X), self.pool2node(X), self.pool2subg(X), self.pool2node(agg)
         # concat order of the reference: [X, to_nodes(centre), to_root(centre), agg, to_root(n5), to_nodes(n6), to_root(n7)]
         off = add(lin(X, blk(0, 0)), lin(agg, blk(0, 3)))

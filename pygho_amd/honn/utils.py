@@ -157,15 +157,23 @@ class MLP(nn.Module):
             return lin, norm.norm, name
         return None
 
-    def forward(self, x: Tensor, residual: Optional[Tensor] = None):
+    def forward(self, x: Tensor, residual: Optional[Tensor] = None, return_input: bool = False):
         """`residual` (optional, shape of the output): returns residual + MLP(x); when the MLP ends in a fused
-        [Linear, BatchNorm, act] block the sum is formed inside that block's activation pass."""
+        [Linear, BatchNorm, act] block the sum is formed inside that block's activation pass.
+        `return_input`: returns (MLP(x), x') where x' holds x's values (in the block's compute dtype) and -- when the MLP starts with
+        a fused block -- is an autograd OUTPUT of that block: a caller that also reads x elsewhere reads x' instead, and that
+        gradient is added inside the block's input-gradient GEMM rather than by autograd's accumulation."""
+        if return_input:
+            self._chained_input = None
+            y = self._forward(x, None, True)[0]
+            xin, self._chained_input = self._chained_input, None
+            return y, (x if xin is None else xin)
         if residual is not None:
             y, fused = self._forward(x, residual)
             return y if fused else residual + y
         return self._forward(x, None)[0]
 
-    def _forward(self, x: Tensor, residual: Optional[Tensor]):
+    def _forward(self, x: Tensor, residual: Optional[Tensor], chain_first: bool = False):
         if not isinstance(self.lins, nn.Sequential):
             return self.lins(x), False
         # same module sequence as the reference.  On device tensors a [Linear, BatchNorm, act] run is ONE autograd
@@ -185,8 +193,12 @@ class MLP(nn.Module):
                     if (residual is not None and i + step == len(mods) and residual.dtype == x2.dtype
                             and residual.shape == tuple(x.shape[:-1]) + (mod.out_features,)):
                         row_res = residual.reshape(-1, mod.out_features)
+                    want_x = chain_first and i == 0 and row_res is None and torch.is_grad_enabled() and x2.requires_grad
                     with torch.autocast("cuda", enabled=False):
-                        y = _ops.tuple_block(x2, mod, mods[i + 1].norm, act or "none", rhs=row_res)
+                        y = _ops.tuple_block(x2, mod, mods[i + 1].norm, act or "none", rhs=row_res, chain_x=want_x)
+                    if want_x:
+                        y, xin = y
+                        self._chained_input = xin.reshape(x.shape)
                     x = y.reshape(tuple(x.shape[:-1]) + (mod.out_features,))
                     i += step
                     if row_res is not None:
