@@ -433,6 +433,8 @@ class SUNConv(Module):
             cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
             as_c = lambda t: t if cdt is None or t.dtype == cdt or not t.is_floating_point() else t.to(cdt)
             xin = chained.get("x")
+            if residual and xin is not None and xin.shape == x_rows.shape and xin.dtype == x_rows.dtype:
+                x_rows = xin                 # the residual row operand of the last block too: its gradient joins lin0's GEMM epilogue
             if (isinstance(X, MaskedTensor) and isinstance(agg, MaskedTensor) and X.masked_dim == 3 and X.raw.is_floating_point()
                     and agg.raw.shape == X.raw.shape and (cdt is not None or agg.raw.dtype == X.raw.dtype)
                     and _ops.pair_combine_supported(as_c(X.raw))):
