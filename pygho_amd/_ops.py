@@ -1464,6 +1464,30 @@ def sparse_pair_views(values: Tensor, ri: Tensor, ci: Tensor, diag_pos: Tensor, 
     return _SparsePairViews.apply(values, ri, ci, diag_pos, n, want_rows, chain)
 
 
+class _SparsePairBroadcast(torch.autograd.Function):
+    """out[t] = u[i] (+ v[j]) for the tuple t = (i, j): two node-level tensors broadcast onto a sparse 2-D pattern and added in one
+    pass (`pygho_pair_gather_combine`); the gradients are the two segment sums of the output gradient."""
+
+    @staticmethod
+    def forward(ctx, u, v, ri, ci, n):
+        require_device(u, v, ri, ci)
+        ri32, ci32 = narrow_i32(ri), narrow_i32(ci)
+        ctx.idx = (ri, ci, n, v is not None)
+        return pair_gather_combine(None, u, v, None, False, ri32, ci32, u.shape[1], u.dtype, u.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        ri, ci, n, has_v = ctx.idx
+        g = g.contiguous()
+        gu = seg_reduce_rows(g, cached_plan(ri, n, "scatter"), "sum") if ctx.needs_input_grad[0] else None
+        gv = seg_reduce_rows(g, cached_plan(ci, n, "scatter"), "sum") if has_v and ctx.needs_input_grad[1] else None
+        return gu, gv, None, None, None
+
+
+def sparse_pair_broadcast(u: Tensor, v: Optional[Tensor], ri: Tensor, ci: Tensor, n: int) -> Tensor:
+    return _SparsePairBroadcast.apply(u.contiguous(), None if v is None else v.contiguous(), ri, ci, n)
+
+
 class _SparsePairLinearMix(torch.autograd.Function):
     """out[t] = (i == j) ? dg[i] : ((x[t] @ w_x + y[t] @ w_y) + u[i]) + v[j] for the tuple t = (i, j): `_PairLinearMix` on the
     sparse layout (SUNConv mode "SS")."""
@@ -1750,10 +1774,11 @@ class _BNAct(torch.autograd.Function):
     """y = act(batch_norm(x)); training uses batch statistics (and returns them for the running averages)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act, fold_momentum=None):
-        require_device(x)
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act, fold_momentum=None, addend=None):
+        require_device(x, addend)
         x = x.contiguous()
-        y, mean, var, saved = _bn_forward(x, weight, bias, running_mean, running_var, training, eps, act, fold_momentum)
+        y, mean, var, saved = _bn_forward(x, weight, bias, running_mean, running_var, training, eps, act, fold_momentum,
+                                          addend=None if addend is None else addend.contiguous())
         ctx.save_for_backward(x, *saved)
         ctx.meta = (training, act, weight is not None, bias is not None)
         ctx.mark_non_differentiable(mean, var)
@@ -1767,7 +1792,8 @@ class _BNAct(torch.autograd.Function):
         x, *saved = ctx.saved_tensors
         training, act, has_w, has_b = ctx.meta
         dx, s1, s2, _ = _bn_backward(x, gy.contiguous(), saved, training, act)
-        return dx, (s2 if has_w else None), (s1 if has_b else None), None, None, None, None, None, None
+        g_add = gy if len(ctx.needs_input_grad) > 9 and ctx.needs_input_grad[9] else None     # y = act(bn(x)) + addend
+        return dx, (s2 if has_w else None), (s1 if has_b else None), None, None, None, None, None, None, g_add
 
 
 def _fold_momentum(bn) -> Optional[float]:
@@ -1791,12 +1817,12 @@ def _update_running(bn, mean: Tensor, var: Tensor, n: int, folded: bool = False)
             bn.running_var.mul_(1 - mom).add_(var.to(bn.running_var.dtype), alpha=mom * n / max(n - 1, 1))
 
 
-def batch_norm_act(x: Tensor, bn: "torch.nn.BatchNorm1d", act: str) -> Tensor:
-    """BatchNorm1d(x) followed by `act`, with torch's semantics (batch statistics + running-average update in
-    training mode, running statistics in eval mode)."""
+def batch_norm_act(x: Tensor, bn: "torch.nn.BatchNorm1d", act: str, residual: Optional[Tensor] = None) -> Tensor:
+    """BatchNorm1d(x) followed by `act` (+ `residual`, added inside the activation pass), with torch's semantics (batch statistics
+    + running-average update in training mode, running statistics in eval mode)."""
     training = bn.training or bn.running_mean is None
     fold = _fold_momentum(bn)
-    y, mean, var = _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, act, fold)
+    y, mean, var = _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, act, fold, residual)
     _update_running(bn, mean, var, x.shape[0], folded=fold is not None)
     return y
 
@@ -1959,6 +1985,7 @@ USE_RECOMPUTE_PRE = os.environ.get("PYGHO_RECOMPUTE_PRE", "1") != "0"   # traini
 USE_ROWBLOCK_LINEAR = True      # module switch for A/B measurements (the library GEMM + separate passes otherwise)
 USE_CONCAT_BLOCK = True   # SSWLConv / DSSGNNConv: Linear-BN-act over concatenated inputs without the concatenation
 USE_PAIR_COMBINE = True   # SUNConv on the padded layout: fused node-view / recombination passes
+USE_NODE_LEVEL_LINEAR = os.environ.get("PYGHO_NODE_LEVEL_LINEAR", "1") != "0"   # GNNAKConv (sparse): the 3 d -> d map applied before the broadcasts
 
 
 def rowblock_linear_supported(x: Tensor, out_features: int) -> bool:

@@ -333,8 +333,62 @@ class GNNAKConv(Module):
             self.pool2node, self.unpool4rootnode = v["pool_node"], v["to_root"]
         self.lin = MLP((3 if ctx else 2) * indim, outdim, **mlp1)
 
+    def _forward_node_level(self, H: SparseTensor, block, residual_rows: Optional[Tensor]) -> Rep:
+        """the second half of the layer with the linear map pulled through the broadcasts (sparse layout).  All three concatenated
+        views are NODE-level tensors unpooled onto the tuples -- pooled[i], centroid[i], context[j] -- and unpool(z) W = unpool(z W):
+        the (3 d -> d) map runs on (n, d) tensors, the tuple level sees one broadcast-add pass, BatchNorm statistics, and the
+        activation pass (with the layer's residual row).  The three (nnz, d) views, their (nnz, 3 d) concatenation (or the chained
+        GEMMs that replace it) and the three tuple-level backward GEMMs never exist; the views' gradients return to H in one pass."""
+        lin, bn, act = block
+        hv = H.values
+        cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else hv.dtype
+        hv = hv if hv.dtype == cdt else hv.to(cdt)
+        d, n = hv.shape[1], H.shape[0]
+        ri, ci = H._row(0), H._row(1)
+        cache = H._cache()
+        if "sun_views" not in cache:
+            diag_idx = torch.arange(n, device=ri.device)
+            pos = _ops.sorted_match(H._hash(), indicehash(diag_idx.reshape(1, -1).expand(2, -1).contiguous()))
+            cnt = lambda r: torch.bincount(r, minlength=n).clamp_min(1).unsqueeze(-1)
+            cache["sun_views"] = (pos, cnt(ri), cnt(ci))
+        pos, cnt_r, cnt_c = cache["sun_views"]
+        with torch.autocast("cuda", enabled=False):
+            dg, s_r, s_c = _ops.sparse_pair_views(hv, ri, ci, pos, n, True)      # rows (i, i); sum over j -> [i]; sum over i -> [j]
+            if self._pool == "mean":
+                s_r, s_c = s_r / cnt_r.to(cdt), s_c / cnt_c.to(cdt)
+            W = _ops.cast_param(lin.weight, cdt)                                  # (out, 3 d) or (out, 2 d): [pooled | centroid | context]
+            b = None if lin.bias is None else _ops.cast_param(lin.bias, cdt)
+
+            def node_lin(x, w, bias):            # x @ w^T (+ bias); tall inputs take the split-K weight gradient (honn/utils.py)
+                if x.shape[0] >= 8192:
+                    return _SplitKLinearFn.apply(x.contiguous(), w, bias)
+                return torch.nn.functional.linear(x, w, bias)
+            u = node_lin(torch.cat((s_r, dg), dim=-1), W[:, :2 * d], b)           # indexed by i: pooled and centroid views
+            v = node_lin(s_c, W[:, 2 * d:3 * d], None) if self.ctx else None      # indexed by j: context view
+            pre = _ops.sparse_pair_broadcast(u, v, ri, ci, n)
+            out = _ops.batch_norm_act(pre, bn, act, residual=residual_rows)
+        return H.tuplewiseapply(lambda _: out)
+
     def forward(self, A: Rep, X: Rep, datadict: dict, residual=False) -> Rep:
         H = self.aggr.forward(A, X.tuplewiseapply(self.lin0), datadict, X)
+        block = self.lin.single_block() if isinstance(self.lin, MLP) else None
+        if (_ops.USE_NODE_LEVEL_LINEAR and block is not None and self._pool in ("sum", "mean") and isinstance(H, SparseTensor)
+                and H.sparse_dim == 2 and H.values is not None and H.values.is_cuda and H.values.dim() == 2
+                and H.values.is_floating_point() and H.shape[0] == H.shape[1] and _ops.pair_gather_supported(H.values)
+                and block[0].in_features == (3 if self.ctx else 2) * H.values.shape[1]
+                and _ops.bn_act_supported_shape(H.nnz, block[0].out_features, torch.get_autocast_dtype("cuda")
+                                                if torch.is_autocast_enabled("cuda") else H.values.dtype)):
+            res_rows, outer = None, None
+            if residual is not False and residual is not None:
+                rep = X if residual is True else residual
+                cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else H.values.dtype
+                if (isinstance(rep, SparseTensor) and rep.values is not None and rep.values.dtype == cdt and rep.nnz == H.nnz
+                        and rep.values.shape[1] == block[0].out_features):
+                    res_rows = rep.values
+                else:
+                    outer = rep                                   # e.g. an f32 residual stream under autocast: added outside, as the model loop does
+            out = self._forward_node_level(H, block, res_rows)
+            return outer.add(out, True) if outer is not None else out
         centroid = self.unpool4subg.forward(self.diag.forward(H), H)
         pooled = self.unpool4subg.forward(self.pool2subg.forward(H), H)
         extra = [centroid]
