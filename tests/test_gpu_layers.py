@@ -580,6 +580,52 @@ def test_tuple_block_without_stored_preactivation_equals_stored(dev):
         torch.testing.assert_close(a[4][k] / s, b[4][k] / s, rtol=0, atol=1e-3, msg=k)
 
 
+@pytest.mark.parametrize("dtype,pool,ctx", [(torch.float32, "mean", True), (torch.float32, "sum", False), (torch.bfloat16, "mean", True)])
+def test_gnnak_node_level_linear_equals_reference_wiring(dev, dtype, pool, ctx):
+    """GNNAKConv (sparse) with the 3 d -> d map applied at node level before the broadcasts against the reference's literal wiring
+    (unpool the three views, concatenate, tuple-wise MLP; module switch): output, gradients wrt X, the adjacency values and every
+    parameter, BatchNorm running statistics; with and without the model loop's residual."""
+    import copy
+    from pygho_amd import SparseTensor, _ops
+    from pygho_amd.honn import Conv
+    h = 128
+    A, tid, xv, dd, n = _ngnn_inputs(dev, dtype, graphs=700)
+    torch.manual_seed(4)
+    layer = Conv.GNNAKConv(h, h, "sum", pool, "SS", dict(MLP), dict(MLP), ctx=ctx).to(dev)
+    wgt = torch.randn(xv.shape, device=dev)
+    old = _ops.USE_NODE_LEVEL_LINEAR
+    f32 = dtype == torch.float32
+    for residual in (False, True):
+        res = {}
+        try:
+            for mode in (True, False):
+                _ops.USE_NODE_LEVEL_LINEAR = mode
+                la = copy.deepcopy(layer)
+                x = xv.clone().requires_grad_(True)
+                av = A.values.clone().requires_grad_(True)
+                Ax, X = SparseTensor(A.indices, av, A.shape, True), SparseTensor(tid, x, [n, n, h], True)
+                out = la.forward_residual(Ax, X, dd) if residual else la.forward(Ax, X, dd)
+                (out.values.float() * wgt).sum().backward()
+                bn = la.lin.lins[1].norm
+                res[mode] = (out.values.float(), x.grad.float(), av.grad.float(), {k: p.grad.float() for k, p in la.named_parameters()},
+                             bn.running_mean.clone(), bn.running_var.clone())
+        finally:
+            _ops.USE_NODE_LEVEL_LINEAR = old
+        a, b = res[True], res[False]
+        tol = dict(rtol=2e-4, atol=2e-4) if f32 else dict(rtol=3e-2, atol=6e-2)
+        torch.testing.assert_close(a[0], b[0], **tol)
+        for i in (1, 2):
+            s = float(b[i].abs().max())
+            torch.testing.assert_close(a[i] / s, b[i] / s, rtol=0, atol=2e-4 if f32 else 3e-2)
+        for k, ref in b[3].items():
+            if k.endswith("lins.0.bias"):
+                continue                                       # bias in front of a BatchNorm: zero up to rounding noise
+            s = float(ref.abs().max()) + 1e-6
+            torch.testing.assert_close(a[3][k] / s, ref / s, rtol=0, atol=2e-4 if f32 else 3e-2, msg=k)
+        torch.testing.assert_close(a[4], b[4], rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(a[5], b[5], rtol=1e-3, atol=1e-3)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_shared_adjacency_gradient_chain(dev, dtype):
     """three layers share A (the model loop of example/minimal.py:76-79): with the gradient chain every block hands A's values on
