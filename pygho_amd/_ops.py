@@ -336,6 +336,50 @@ def _window_eligible(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor]
             and 2 * rhs.shape[0] <= out_rows and out_rows >= 4096 and max(out_rows, lhs.shape[0]) * rb < (1 << 32))
 
 
+SEG_TILE = os.environ.get("PYGHO_SEG_TILE", "0")            # "0": never, "1": whenever the shape allows, "auto": by plan shape
+SEG_TILE_WIN_ROWS = int(os.environ.get("PYGHO_SEG_TILE_WIN_ROWS", "32"))
+
+
+def tile_plan(seg_ptr: Tensor, lhs_idx: Tensor, n_seg: int, win_rows: int):
+    """(tile_cnt, tiles) of `pygho_seg_tile_plan` for one (CSR pointers, lhs index) pair: consecutive segments whose lhs rows lie in
+    a window of `win_rows` consecutive rows.  A pure function of the index arrays; cached on the index tensor object."""
+    cache = getattr(lhs_idx, "_pygho_tiles", None)
+    if cache is None:
+        cache = {}
+        try:
+            lhs_idx._pygho_tiles = cache
+        except Exception:
+            pass
+    k = (seg_ptr.data_ptr(), n_seg, win_rows, lhs_idx._version, seg_ptr._version)
+    hit = cache.get(k)
+    if hit is None:
+        dev = require_device(seg_ptr, lhs_idx)
+        chunk = int(lib().pygho_seg_tile_chunk())
+        n_chunks = (n_seg + chunk - 1) // chunk
+        tile_cnt = torch.empty(n_chunks, dtype=_I32, device=dev)
+        tiles = torch.empty((n_chunks, chunk, 4), dtype=_I32, device=dev)
+        check(lib().pygho_seg_tile_plan(ptr(tile_cnt), ptr(tiles), ptr(seg_ptr), ptr(lhs_idx), n_seg, win_rows, stream_ptr(dev)),
+              "seg_tile_plan")
+        hit = (tile_cnt, tiles, seg_ptr)            # the pointers are kept alive with the entry that is keyed on their address
+        cache[k] = hit
+    return hit[0], hit[1]
+
+
+def _tile_eligible(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], lhs_idx: Optional[Tensor], rhs_idx: Optional[Tensor],
+                   aggr: str) -> bool:
+    """two-operand sum / mean with both index arrays and rows of 256 / 512 / 1024 bytes (`pygho_seg_gather_mul_reduce_tiled`)."""
+    if SEG_TILE == "0" or lhs is None or rhs is None or lhs_idx is None or rhs_idx is None or aggr not in ("sum", "mean"):
+        return False
+    rb = lhs.shape[1] * lhs.element_size()
+    if rb not in (256, 512, 1024) or lhs.dtype not in (torch.float32, torch.bfloat16, torch.float16) or out_rows < 4096:
+        return False
+    if SEG_TILE == "1":
+        return True
+    # auto: the plans whose segments gather lhs rows of one narrow block (forward and by-tuple backward of the tuple products);
+    # the by-edge backward plan (few long segments over rows spread across a graph) stays on the window kernel
+    return rb >= 512 and 2 * rhs.shape[0] <= out_rows
+
+
 def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr: Tensor,
             lhs_idx: Optional[Tensor], rhs_idx: Optional[Tensor], aggr: str,
             lhs_rowscale: Optional[Tensor] = None, addend: Optional[Tensor] = None,
@@ -351,7 +395,7 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
     d = ref.shape[1]
     out = torch.empty((out_rows, d), dtype=ref.dtype, device=dev)
     timer = LaunchTimer.active
-    windowed = False
+    windowed = tiled = False
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(dev))
@@ -367,6 +411,15 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
             ptr(out), ptr(addend), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale),
             ptr(a_scale.contiguous()), ptr(a_shift.contiguous()), ACT_CODE[a_name], a_side, out_rows, d, lhs.shape[0], rhs.shape[0],
             dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev)), "seg_gather_mul_reduce_act")
+    elif _tile_eligible(out_rows, lhs, rhs, lhs_idx, rhs_idx, aggr):
+        tiled = True
+        if addend is not None:
+            assert addend.shape == out.shape and addend.dtype == out.dtype and addend.is_contiguous()
+        tile_cnt, tiles = tile_plan(seg_ptr, lhs_idx, out_rows, SEG_TILE_WIN_ROWS)
+        check(lib().pygho_seg_gather_mul_reduce_tiled(
+            ptr(out), ptr(addend), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale), ptr(tile_cnt),
+            ptr(tiles), out_rows, d, lhs.shape[0], rhs.shape[0], SEG_TILE_WIN_ROWS, dtype_code(ref), AGGR_CODE[aggr],
+            stream_ptr(dev)), "seg_gather_mul_reduce_tiled")
     elif _window_eligible(out_rows, lhs, rhs, rhs_idx, aggr):
         windowed = True
         if addend is not None:
@@ -395,7 +448,7 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
         if addend is not None:
             nbytes += es * d * out_rows
         mode = "both" if (lhs is not None and rhs is not None) else ("lhs" if lhs is not None else "rhs")
-        timer.records.append((f"seg_gmr[{str(ref.dtype).split('.')[-1]},{aggr},{mode}{',scaled' if lhs_rowscale is not None else ''}{',res' if addend is not None else ''}{',act' if act is not None else ''}{',window' if windowed else ''}]",
+        timer.records.append((f"seg_gmr[{str(ref.dtype).split('.')[-1]},{aggr},{mode}{',scaled' if lhs_rowscale is not None else ''}{',res' if addend is not None else ''}{',act' if act is not None else ''}{',window' if windowed else ''}{',tiled' if tiled else ''}]",
                               nbytes, e0, e1))
     return out
 

@@ -27,15 +27,12 @@ __global__ __launch_bounds__(kBlock) void graph_bfs_dist_kernel(uint8_t* __restr
                                                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                                 int max_hop) {
   extern __shared__ uint8_t s_d[];                     // n * n bytes
-  __shared__ int s_changed;
   const int g = blockIdx.x;
   const int base = node_ptr[g], n = node_ptr[g + 1] - base;
   const int cells = n * n;
   for (int c = threadIdx.x; c < cells; c += kBlock) s_d[c] = (c / n == c % n) ? 0 : kUnreached;
   __syncthreads();
   for (int h = 1; h <= max_hop; ++h) {
-    if (threadIdx.x == 0) s_changed = 0;
-    __syncthreads();
     bool any = false;
     for (int c = threadIdx.x; c < cells; c += kBlock) {
       if (s_d[c] != kUnreached) continue;
@@ -46,9 +43,9 @@ __global__ __launch_bounds__(kBlock) void graph_bfs_dist_kernel(uint8_t* __restr
         if (s_d[i * n + (col[q] - base)] == h - 1) { s_d[c] = (uint8_t)h; any = true; break; }
       }
     }
-    if (any) s_changed = 1;
-    __syncthreads();
-    if (!s_changed) break;
+    // barrier + OR in one step: every wavefront leaves the level with the same verdict (a shared flag that thread 0 resets for
+    // the next level could be cleared before a slower wavefront had read it)
+    if (!__syncthreads_or(any ? 1 : 0)) break;
   }
   uint8_t* out = dist + sq_ptr[g];
   for (int c = threadIdx.x; c < cells; c += kBlock) out[c] = s_d[c];
