@@ -15,6 +15,11 @@ views and transposed groupings of its index tensors, cached on them) are part of
 precomputed ___acd triples; training with a NEW batch every step, plans built one batch ahead on a side stream, is measured by
 tools/bench_ops.py (fresh_batch_case: 14.3-14.8 ms per step against 13.1-13.4 ms here).
 
+`configs` (N == 1): the other measured configurations of BASELINE.json in the same line -- config 5 (I2-shape 3-tuple spspmm
+launch, d = 256 bf16, and an I2Conv layer step), config 3 (mamamm X A / X Y at (1024, 37, 37, 128) bf16 and a SUNConv DD layer step)
+and one forward + backward of the other shipped sparse layers -- each kernel with HIP-event time, algorithmic bytes, roofline
+fraction and committed PMC traffic (tools/bench_configs.py; rocprofv3 summaries under profiles/).
+
 Alongside: msg-edges/s and the HBM roofline fraction of the dominant kernel (the fused gather*gather->segment
 reduce of spspmm, forward and both backward plans), measured live with HIP events around every launch in the
 timed region; and the CPU baseline = the reference's ATen op sequence (oracle/aten_port.py) on the host cores
@@ -51,6 +56,7 @@ def parse():
     ap.add_argument("--optimizer", default="fused", choices=["fused", "foreach"], help="AdamW implementation (same update rule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-regimes", action="store_true", help="skip the fresh-batch / small-batch side measurements")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-kernel figures of BASELINE configs 3 and 5 and the layer steps")
     ap.add_argument("--global-stream", action="store_true",
                     help="N > 1: ONE global batch of N x --graphs graphs (same seed on every rank), sharded into contiguous graph "
                          "ranges balanced by message count (parallel.shard_ranges) instead of one independent batch per rank")
@@ -215,14 +221,36 @@ def side_regimes(args, dev):
     return out
 
 
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT touching the HIP runtime (torch.cuda.device_count() falls back to hipGetDeviceCount when
+    amdsmi is missing, which initialises the runtime in the parent): the visibility variables if set, else the KFD topology
+    (nodes with SIMDs are GPUs).  None when neither source is readable -- the child ranks then fail on their own."""
+    import glob
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n, seen = 0, False
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        seen = True
+        n += int(props.get("simd_count", "0")) > 0
+    if not seen and not os.path.isdir("/sys/class/kfd"):
+        return 0                                             # no KFD driver node at all: no AMD GPU on this host
+    return n if seen else None
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` outside a launcher: start N ranks as a CHILD `torch.distributed.run` (one process per
     GPU, RCCL rendezvous on 127.0.0.1) before this process has touched the GPU, pass its output through and return its
-    exit code.  Nothing is re-exec'ed: the parent never initialises HIP."""
+    exit code.  Nothing is re-exec'ed, and the parent makes no HIP runtime call (the device count comes from the environment / sysfs)."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()                     # counts devices without initialising the GPU
-    if have < args.gpus:
+    have = visible_gpu_count()                           # from the environment / sysfs: no runtime call, the parent stays off the GPU
+    if have is not None and have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
     with socket.socket() as sock:
@@ -285,7 +313,9 @@ def main():
     act_dtype = torch.bfloat16 if args.dtype == "bf16" else None
     torch.manual_seed(0)
     model = SpModel(1, args.layers, args.hidden, act_dtype=act_dtype).to(dev)
-    sync = FlatGradSync(model.parameters())
+    # under a launcher: the gradient travels in two ranges issued on a side stream from backward hooks (the later layers' range
+    # overlaps the rest of backward); a single process only packs
+    sync = FlatGradSync(model.parameters(), overlap=use_dist, buckets=2)
     sync.broadcast_params(0)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=args.optimizer == "fused")
     y = datadict["y"].unsqueeze(-1)
@@ -373,12 +403,21 @@ def main():
         if use_dist:
             line["collectives"] = {"backend": dist.get_backend(), "allreduce_calls": sync.allreduce_calls,
                                    "allreduce_bytes": sync.flat.numel() * sync.flat.element_size(),
+                                   "allreduce_ms": sync.allreduce_ms(), "allreduce_ranges_per_step": len(getattr(sync, "_ranges", [0])),
+                                   "overlap": "ranges are all-reduced on a side stream as backward completes them (pygho_amd/parallel.py)",
                                    "batch": "global stream sharded by message count" if loss_scale != 1.0 or (args.global_stream and world > 1)
                                    else "one independent batch per rank"}
         if world == 1 and not args.no_regimes:
             del datadict, model, opt, sync, y
             torch.cuda.empty_cache()
             line["regimes"] = side_regimes(args, dev)
+        if world == 1 and not args.no_configs:
+            # BASELINE configs 3 (dense MaskedTensor path) and 5 (3-tuple stress) and one forward + backward of every shipped layer:
+            # per-kernel HIP-event times, algorithmic bytes, roofline fraction and committed PMC traffic (tools/bench_configs.py)
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            import bench_configs
+            torch.cuda.empty_cache()
+            line["configs"] = bench_configs.run(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, 1000)
         sys.stdout.flush()

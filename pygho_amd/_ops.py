@@ -1912,6 +1912,7 @@ class ParamCastArena:
         self.flat = torch.empty(total, dtype=dtype, device=dev) if self.params else None
         self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
         self.versions = [-1] * len(self.params)
+        self.ptrs = [0] * len(self.params)          # storage address at the last refresh: `module.to()` / `p.data = ...` swap it
         self.epoch = -1
         ref = weakref.ref(self)
         for k in [k for k, (r, _i) in _ARENA_OF.items() if r() is None]:      # entries of arenas that are gone
@@ -1920,10 +1921,15 @@ class ParamCastArena:
             _ARENA_OF[id(p)] = (ref, i)
 
     def refresh(self) -> None:
-        if self.epoch != _ARENA_EPOCH[0]:
+        """Freshness is decided by the parameter's version counter and storage address.  Covered update paths: in-place ops on the
+        parameter (optimizers, `p.copy_`, `load_state_dict`), `module.to()` / `p.data = t` (new storage), a replayed HIP graph
+        (`GraphedStep.replay` bumps the epoch).  NOT visible from here: writes through a `.data` alias (`p.data.mul_(...)` has its
+        own version counter) -- call `invalidate_cast_arenas()` after those.  Under stream capture every copy is re-cast INSIDE
+        the graph: a graph that captured only forward + backward must not bake in the views of a cast that happened before it."""
+        if self.epoch != _ARENA_EPOCH[0] or (self.flat is not None and torch.cuda.is_current_stream_capturing()):
             stale = list(range(len(self.params)))
         else:
-            stale = [i for i, p in enumerate(self.params) if self.versions[i] != p._version]
+            stale = [i for i, p in enumerate(self.params) if self.versions[i] != p._version or self.ptrs[i] != p.data_ptr()]
         self.epoch = _ARENA_EPOCH[0]
         if not stale:
             return
@@ -1931,6 +1937,7 @@ class ParamCastArena:
             torch._foreach_copy_([self.views[i] for i in stale], [self.params[i].detach() for i in stale])
         for i in stale:
             self.versions[i] = self.params[i]._version
+            self.ptrs[i] = self.params[i].data_ptr()
 
 
 def ensure_cast_arena(module, dtype: Optional[torch.dtype]) -> None:
@@ -1943,6 +1950,10 @@ def ensure_cast_arena(module, dtype: Optional[torch.dtype]) -> None:
             or any(a is not b for a, b in zip(arena.params, (p for p in params if p.is_cuda and p.dtype == torch.float32)))):
         arena = ParamCastArena(params, dtype)
         module.__dict__["_pygho_cast_arena"] = arena
+        if not module.__dict__.get("_pygho_cast_hook"):
+            # belt and braces next to the version / address checks: a loaded state dict invalidates every copy
+            module.register_load_state_dict_post_hook(lambda _m, _keys: invalidate_cast_arenas())
+            module.__dict__["_pygho_cast_hook"] = True
     arena.refresh()
 
 
@@ -1956,7 +1967,7 @@ def param_as(p: Tensor, dtype: torch.dtype) -> Tensor:
         if arena is None:
             del _ARENA_OF[id(p)]
         elif (arena.dtype == dtype and arena.epoch == _ARENA_EPOCH[0] and arena.params[ent[1]] is p
-              and arena.versions[ent[1]] == p._version):
+              and arena.versions[ent[1]] == p._version and arena.ptrs[ent[1]] == p.data_ptr()):
             return arena.views[ent[1]]
     return p.detach().to(dtype)
 

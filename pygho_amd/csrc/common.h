@@ -26,6 +26,14 @@ inline int check_launch(const char* what) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE attribute: the "already set" flag of a launcher is kept per
+// device, so a process that drives a second GPU (`with torch.cuda.device(...)`) sets it there too
+inline bool& per_device_flag(bool (&flags)[64]) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return flags[dev & 63];
+}
+
 inline int grid_for(int64_t work_items, int per_block, int cap = kMaxGrid) {
   int64_t g = ceil_div(work_items, per_block);
   if (g < 1) g = 1;

@@ -448,7 +448,8 @@ template <typename T, int D, int ACT>
 int launch_bn_bwd_linear(void* gx, void* gpre, const void* pre, const void* gh, const void* wl, const void* addend, float* colsum_ws,
                          const BnBwdArgs& bn, int64_t m, int grid, hipStream_t st) {
   using G = RlGeom<D>;
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {};
+  bool& attr_set = per_device_flag(attr_set_dev);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_linear_kernel<T, D, ACT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
@@ -764,7 +765,8 @@ template <typename T, int D, int ACT, bool RECOMP = false>
 int launch_bn_bwd_linear_dw(void* gx, const void* pre, const void* gh, const void* x, const void* wl, const void* addend,
                             float* colsum_ws, float* dw_ws, const BnBwdArgs& bn, int64_t m, int grid, int64_t ws_stride, hipStream_t st,
                             const void* lin_bias = nullptr) {
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {};
+  bool& attr_set = per_device_flag(attr_set_dev);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_linear_dw_kernel<T, D, ACT, RECOMP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)DwGeom<D>::lds_bytes);
@@ -912,7 +914,8 @@ template <typename T, int D>
 int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum_ws, int64_t m, int grid, int64_t ws_stride, int64_t x_ld,
                        hipStream_t st) {
   const size_t lds = DwGeom<D>::tile_bytes + DwGeom<D>::xtile_bytes;
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {};
+  bool& attr_set = per_device_flag(attr_set_dev);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weight_grad_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("weight_grad: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
@@ -926,7 +929,8 @@ template <typename T, int D, int EPI = RL_STORE, int ACT = 0>
 int launch_rowblock(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws, float* shift,
                     int self_shift, int64_t m, int grid, hipStream_t st, const RlEpi& epi = RlEpi{}) {
   using G = RlGeom<D>;
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {};
+  bool& attr_set = per_device_flag(attr_set_dev);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_linear_kernel<T, D, EPI, ACT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);

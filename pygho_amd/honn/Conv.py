@@ -376,6 +376,8 @@ class GNNAKConv(Module):
                 and H.sparse_dim == 2 and H.values is not None and H.values.is_cuda and H.values.dim() == 2
                 and H.values.is_floating_point() and H.shape[0] == H.shape[1] and _ops.pair_gather_supported(H.values)
                 and block[0].in_features == (3 if self.ctx else 2) * H.values.shape[1]
+                # the pair kernels run on rows of the block's OUTPUT width (u, v): those must be whole 16-byte pieces of at most 4 KB too
+                and (block[0].out_features * H.values.element_size()) % 16 == 0 and block[0].out_features * H.values.element_size() <= 4096
                 and _ops.bn_act_supported_shape(H.nnz, block[0].out_features, torch.get_autocast_dtype("cuda")
                                                 if torch.is_autocast_enabled("cuda") else H.values.dtype)):
             res_rows, outer = None, None

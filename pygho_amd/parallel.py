@@ -4,8 +4,8 @@ operator path shards by graph with no data-path collective; the only exchange is
 all-reduce.  The reference has no distributed code at all; this is new work.
 
 ``FlatGradSync`` packs every parameter gradient into ONE flat buffer so that the step's gradient exchange is
-a single RCCL all-reduce over xGMI (0.70 MB for the minimal NGNN: latency- not bandwidth-bound, so one bucket
-is optimal) issued right after backward.
+a single RCCL all-reduce over xGMI (0.70 MB for the minimal NGNN: latency-bound), or -- ``overlap=True`` -- two
+halves of it issued on a side stream from backward hooks, the later layers' half while backward still runs.
 """
 from typing import Iterable, List, Optional, Tuple
 
@@ -19,48 +19,127 @@ class FlatGradSync:
 
     ``zero_grad()`` drops the gradients (autograd then hands its freshly produced tensors over instead of launching
     one accumulate kernel per parameter); ``sync()`` packs them into ONE flat buffer with a multi-tensor copy,
-    averages it over the ranks with a single all-reduce and re-points every ``param.grad`` at its slice (without a
-    process group only the packing happens)."""
+    averages it over the ranks and re-points every ``param.grad`` at its slice (without a process group only the
+    packing happens).
+
+    ``overlap=True``: the flat buffer is cut into ``buckets`` contiguous parameter ranges (in ``parameters()`` order:
+    backward finishes the LAST range first); a post-accumulate hook on every parameter counts its range down, and the
+    moment a range is complete its gradients are packed and its all-reduce is issued on a SIDE stream while backward
+    goes on with the earlier layers.  ``sync()`` then only launches what is left (ranges holding parameters without a
+    gradient), joins the side stream and scales.  The result is the same buffer as the single collective's: an
+    all-reduce sums element-wise, so the bucket boundaries cannot change a bit."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional["dist.ProcessGroup"] = None,
-                 dtype: torch.dtype = torch.float32):
+                 dtype: torch.dtype = torch.float32, overlap: bool = False, buckets: int = 2):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=dtype, device=dev)
         self.views: List[torch.Tensor] = []
-        off = 0
+        offs = [0]
         for p in self.params:
             n = p.numel()
-            self.views.append(self.flat[off:off + n].view_as(p))
-            off += n
+            self.views.append(self.flat[offs[-1]:offs[-1] + n].view_as(p))
+            offs.append(offs[-1] + n)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.allreduce_calls = 0
+        self.overlap = bool(overlap) and dist.is_available() and dist.is_initialized()
+        self._events = []                     # (start, end) device events around every side-stream collective (allreduce_ms)
+        if self.overlap:
+            # contiguous parameter ranges of about equal size
+            nb = max(1, min(int(buckets), len(self.params)))
+            cuts, target = [0], total / nb
+            for i in range(1, len(self.params)):
+                if len(cuts) < nb and offs[i] >= target * len(cuts):
+                    cuts.append(i)
+            cuts.append(len(self.params))
+            self._ranges = [(cuts[i], cuts[i + 1], offs[cuts[i]], offs[cuts[i + 1]]) for i in range(len(cuts) - 1)]
+            self._bucket_of = [b for b, (lo, hi, _, _) in enumerate(self._ranges) for _ in range(lo, hi)]
+            self._pending = [hi - lo for lo, hi, _, _ in self._ranges]
+            self._launched = [False] * len(self._ranges)
+            self._works = []
+            self._side = torch.cuda.Stream(device=dev) if self.flat.is_cuda else None
+            for i, p in enumerate(self.params):
+                p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
 
     def zero_grad(self) -> None:
         for p in self.params:
             p.grad = None
+        if self.overlap:
+            self._pending = [hi - lo for lo, hi, _, _ in self._ranges]
+            self._launched = [False] * len(self._ranges)
 
-    def pack(self) -> None:
-        """flat <- gradients (parameters without a gradient contribute zeros), then param.grad = its flat slice."""
-        missing = [v for v, p in zip(self.views, self.params) if p.grad is None]
-        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+    def _pack_range(self, lo: int, hi: int) -> None:
+        missing = [v for v, p in zip(self.views[lo:hi], self.params[lo:hi]) if p.grad is None]
+        have = [(v, p.grad) for v, p in zip(self.views[lo:hi], self.params[lo:hi])
+                if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if missing:
             torch._foreach_zero_(missing)
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+
+    def pack(self) -> None:
+        """flat <- gradients (parameters without a gradient contribute zeros), then param.grad = its flat slice."""
+        self._pack_range(0, len(self.params))
         for v, p in zip(self.views, self.params):
             p.grad = v
 
+    def _on_grad(self, i: int) -> None:
+        b = self._bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and not self._launched[b]:
+            self._launch(b)
+
+    def _launch(self, b: int) -> None:
+        lo, hi, flo, fhi = self._ranges[b]
+        self._launched[b] = True
+        self._pack_range(lo, hi)                       # on the stream backward runs on
+        piece = self.flat[flo:fhi]
+        if self._side is None:                         # host tensors (gloo on CPU): no streams to overlap
+            self._works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            cur = torch.cuda.current_stream(self.flat.device)
+            self._side.wait_stream(cur)                # the packed range is complete on the side stream
+            with torch.cuda.stream(self._side):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self._side)
+                work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                work.wait()                            # RCCL: the SIDE stream waits for the collective (the host does not block)
+                e1.record(self._side)
+                self._events.append((e0, e1))
+                del self._events[:-256]
+        self.allreduce_calls += 1
+
     def sync(self) -> None:
-        """average the gradient over all ranks (one collective over the flat buffer)."""
-        self.pack()
-        if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.allreduce_calls += 1
-            if self.world > 1:
-                self.flat.div_(self.world)
+        """average the gradient over all ranks (one collective over the flat buffer; with `overlap` one per range, most of them
+        already in flight)."""
+        if not self.overlap:
+            self.pack()
+            if dist.is_available() and dist.is_initialized():
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                self.allreduce_calls += 1
+                if self.world > 1:
+                    self.flat.div_(self.world)
+            return
+        for b in range(len(self._ranges)):
+            if not self._launched[b]:                  # a range with a parameter that received no gradient
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self._side is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._side)
+        if self.world > 1:
+            self.flat.div_(self.world)
+        for v, p in zip(self.views, self.params):
+            p.grad = v
+
+    def allreduce_ms(self) -> Optional[float]:
+        """mean device time of one side-stream collective so far (after a device synchronisation); None without `overlap`"""
+        if not self._events:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self._events) / len(self._events)
 
     def broadcast_params(self, src: int = 0) -> None:
         if dist.is_available() and dist.is_initialized():

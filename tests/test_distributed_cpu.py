@@ -26,13 +26,13 @@ def _data():
     return torch.randn(40, 6, generator=g), torch.randn(40, 1, generator=g)
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, overlap=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     x, y = _data()
     lo, hi = shard_ranges(np.ones(40), world)[rank]
     model = _model()
-    sync = FlatGradSync(model.parameters())
+    sync = FlatGradSync(model.parameters(), overlap=overlap, buckets=2)
     sync.broadcast_params(0)
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
     for _ in range(3):
@@ -44,17 +44,25 @@ def _worker(rank, world, port, ret):
     if rank == 0:
         ret["flat"] = sync.flat.clone()
         ret["params"] = [p.detach().clone() for p in model.parameters()]
+        ret["calls"] = sync.allreduce_calls
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_flat_allreduce_equals_single_process():
+import pytest
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_rank_flat_allreduce_equals_single_process(overlap):
+    """overlap=True: the gradient is exchanged in two ranges launched from backward hooks (the later layers' range while backward
+    still runs); same averaged gradient, same parameters after the optimizer steps."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, ret, overlap), nprocs=2, join=True)
+    assert ret["calls"] == (6 if overlap else 3)
     x, y = _data()
     model = _model()
     sync = FlatGradSync(model.parameters())

@@ -289,6 +289,38 @@ def test_masked_bmm_baseline_size_properties(dev):
         torch.testing.assert_close(out[sl].double() / scale, exp / scale, rtol=0, atol=2.0 ** -8, msg=name)   # (i)
 
 
+def test_mamamm_baseline_size_elementwise_vs_f64_einsum(dev):
+    """BASELINE config 3's size, EVERY output element of the whole (1024, 37, 37, 128) bf16 batch: mamamm(X, 2, Y, 1) (pair masks on
+    both operands) and mamamm(X, 2, A, 1) (adjacency-masked second operand) through the pygho API against the reference's einsum
+    (pygho/backend/Mamamm.py:45-47) evaluated in float64 on the device in batch slices of 64.  Bar: one bf16 rounding of an
+    f32-accumulated sum of exact products -- 2^-9 relative (2^-8 allowed) plus 1e-5 of the largest magnitude for the accumulation
+    order of the matrix-core instruction; masked output slots exactly zero."""
+    from pygho_amd import MaskedTensor, synth
+    from pygho_amd.backend.Mamamm import mamamm
+    dn = synth.make_dense_batch(256, seed=2, hidden=128, nmax=37)
+    rep = 4
+    t = lambda a, dt=None: (torch.from_numpy(a).to(dev).repeat((rep,) + (1,) * (a.ndim - 1)).to(dt) if dt
+                            else torch.from_numpy(a).to(dev).repeat((rep,) + (1,) * (a.ndim - 1)))
+    Xraw, Xm, Araw, Am = t(dn["X"], torch.bfloat16), t(dn["Xmask"]), t(dn["A"], torch.bfloat16), t(dn["Amask"])
+    assert tuple(Xraw.shape) == (1024, 37, 37, 128)
+    torch.manual_seed(0)
+    Yraw = torch.randn_like(Xraw) * Xm.unsqueeze(-1).to(torch.bfloat16)
+    X = MaskedTensor(Xraw, Xm, 0.0, True)
+    for name, Braw, Bm in (("X Y", Yraw, Xm), ("X A", Araw, Am)):
+        out = mamamm(X, 2, MaskedTensor(Braw, Bm, 0.0, True), 1, Xm)
+        got = out.data
+        assert float(got[~Xm.bool()].float().abs().max()) == 0.0, name
+        worst = 0.0
+        for lo in range(0, got.shape[0], 64):
+            sl = slice(lo, lo + 64)
+            exp = torch.einsum("bikd,bkjd->bijd", Xraw[sl].double() * Xm[sl].bool()[..., None], Braw[sl].double() * Bm[sl].bool()[..., None]) \
+                * Xm[sl].bool()[..., None]
+            scale = float(exp.abs().max())
+            err = (got[sl].double() - exp).abs() - 2.0 ** -8 * exp.abs()
+            worst = max(worst, float(err.max()) / max(scale, 1e-30))
+        assert worst <= 1e-5, f"{name}: an element is off by more than one bf16 rounding + 1e-5 of the scale ({worst:.3e})"
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("layout", [(False, True), (True, True), (False, False), (True, False)])
 def test_masked_bmm_padded_batch_extents(dev, dtype, layout):
