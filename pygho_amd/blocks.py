@@ -1,0 +1,804 @@
+"""
+The dense steps around the aggregation as fused blocks: BatchNorm + activation, 16-bit parameter copies
+(cast arena), the streaming row-block Linear family and the tuple-wise / concatenation / SSWL blocks built from them.
+"""
+from __future__ import annotations
+
+import os
+from ctypes import c_void_p
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from ._native import AGGR_CODE, DTYPE_CODE, check, dtype_code, lib, ptr, require_device, stream_ptr
+
+from .plans import *          # noqa: F401,F403
+from .plans import _I32, _fetch, _flag
+from .segment import *        # noqa: F401,F403
+from .segment import _as2d
+from .masked import *         # noqa: F401,F403
+
+
+# --------------------------------------------------------------------------
+# fused BatchNorm + activation (dense neighbour of the aggregation)
+# --------------------------------------------------------------------------
+
+
+def bn_act_supported(x: Tensor) -> bool:
+    return (x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and x.shape[0] > 1
+            and int(lib().pygho_bn_workspace(x.shape[0], x.shape[1], dtype_code(x))) > 0)
+
+
+def _bn_forward(x: Optional[Tensor], weight, bias, running_mean, running_var, training: bool, eps: float, act: str,
+                fold_momentum: Optional[float] = None, partial: Optional[Tuple[Tensor, Tensor]] = None,
+                apply: bool = True, addend: Optional[Tensor] = None, producer=None):
+    """(y, mean, var, saved) of act(batch_norm(x)) (+ addend: a residual row added inside the activation pass) for a contiguous 2-D x.  Statistics, 1/sqrt(var + eps), the fused
+    scale / shift and (with `fold_momentum`) the running-average update all come out of ONE finalisation kernel;
+    `partial` = (per-block shifted sums, their shift) when the producer of x already took the sums (rowblock_linear).
+    `apply=False`: y is not formed; (scale, shift) are returned in its place for a consumer that applies them on load.
+    `producer=(x_in, wl, lin_bias)` with x = None: the BatchNorm input x_in @ wl^T + lin_bias is NOT in memory; the statistics
+    came from `partial` (training) or are the running ones, and y is produced by recomputing the product inside the
+    activation pass (`rowblock_linear_bn_act`)."""
+    src = x if x is not None else producer[0]
+    dev = src.device
+    m, c = src.shape
+    dt = dtype_code(src)
+    st = stream_ptr(dev)
+    ws = None
+    if x is not None:
+        nbytes = int(lib().pygho_bn_workspace(m, c, dt))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    else:
+        assert apply and (partial is not None or not training)
+    w32 = None if weight is None else weight.detach().float().contiguous()
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    if training:
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        var = torch.empty(c, dtype=torch.float32, device=dev)
+    else:
+        mean, var = running_mean.float().clone(), running_var.float().clone()
+    invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(3))
+    fold = training and fold_momentum is not None
+    if training and partial is not None:
+        sums, sum_shift = partial
+        check(lib().pygho_bn_finalize(ptr(mean), ptr(var), ptr(invstd), ptr(scale), ptr(shift), ptr(sums), sums.shape[0],
+                                      ptr(sum_shift), m, c, ptr(w32), ptr(b32), float(eps), ptr(running_mean) if fold else None,
+                                      ptr(running_var) if fold else None, float(fold_momentum or 0.0), st), "bn_finalize")
+    else:
+        check(lib().pygho_bn_prepare(ptr(mean), ptr(var), ptr(invstd), ptr(scale), ptr(shift), ptr(x) if training else None, m, c,
+                                     ptr(w32), ptr(b32), float(eps), ptr(running_mean) if fold else None,
+                                     ptr(running_var) if fold else None, float(fold_momentum or 0.0), ptr(ws), dt, st),
+              "bn_prepare")
+    if not apply:
+        return (scale, shift), mean, var, (mean, invstd, w32, b32, ws)
+    if x is None:
+        y = rowblock_linear_bn_act(producer[0], producer[1], producer[2], scale, shift, act, addend)
+        return y, mean, var, (mean, invstd, w32, b32, ws)
+    y = torch.empty_like(x)
+    if addend is not None:
+        check(lib().pygho_bn_act_fwd_add(ptr(y), ptr(x), ptr(addend.contiguous()), ptr(scale), ptr(shift), m, c, ACT_CODE[act], dt, st),
+              "bn_act_fwd_add")
+    else:
+        check(lib().pygho_bn_act_fwd(ptr(y), ptr(x), ptr(scale), ptr(shift), m, c, ACT_CODE[act], dt, st), "bn_act_fwd")
+    return y, mean, var, (mean, invstd, w32, b32, ws)
+
+
+def _bn_backward(x: Tensor, gy: Tensor, saved, training: bool, act: str, want_colsum: bool = False):
+    """(dx, d bn.bias, d bn.weight, column sums of dx or None)."""
+    mean, invstd, w32, b32, ws = saved
+    m, c = x.shape
+    dev = x.device
+    dx = torch.empty_like(x)
+    s1 = torch.empty(c, dtype=torch.float32, device=dev)
+    s2 = torch.empty(c, dtype=torch.float32, device=dev)
+    sdx = torch.empty(c, dtype=torch.float32, device=dev) if want_colsum else None
+    check(lib().pygho_bn_act_bwd(ptr(dx), ptr(s1), ptr(s2), ptr(x), ptr(gy), ptr(mean), ptr(invstd), ptr(w32), ptr(b32),
+                                 m, c, ACT_CODE[act], 1 if training else 0, ptr(ws), dtype_code(x), ptr(sdx),
+                                 stream_ptr(dev)), "bn_act_bwd")
+    return dx, s1, s2, sdx
+
+
+def bn_act_supported_shape(m: int, c: int, dtype: torch.dtype) -> bool:
+    return (dtype in (torch.float32, torch.bfloat16, torch.float16) and m > 1
+            and int(lib().pygho_bn_workspace(m, c, DTYPE_CODE[dtype])) > 0)
+
+
+class _BNAct(torch.autograd.Function):
+    """y = act(batch_norm(x)); training uses batch statistics (and returns them for the running averages)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act, fold_momentum=None, addend=None):
+        require_device(x, addend)
+        x = x.contiguous()
+        y, mean, var, saved = _bn_forward(x, weight, bias, running_mean, running_var, training, eps, act, fold_momentum,
+                                          addend=None if addend is None else addend.contiguous())
+        ctx.save_for_backward(x, *saved)
+        ctx.meta = (training, act, weight is not None, bias is not None)
+        ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)            # no zero tensors for the statistics' (never used) gradients
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv):
+        if gy is None:
+            return (None,) * len(ctx.needs_input_grad)
+        x, *saved = ctx.saved_tensors
+        training, act, has_w, has_b = ctx.meta
+        dx, s1, s2, _ = _bn_backward(x, gy.contiguous(), saved, training, act)
+        g_add = gy if len(ctx.needs_input_grad) > 9 and ctx.needs_input_grad[9] else None     # y = act(bn(x)) + addend
+        return dx, (s2 if has_w else None), (s1 if has_b else None), None, None, None, None, None, None, g_add
+
+
+def _fold_momentum(bn) -> Optional[float]:
+    """momentum when the running-average update can run inside the statistics kernel (f32 contiguous buffers and a
+    fixed momentum; the cumulative-average mode needs the batch counter on the host and takes the torch path)."""
+    if (bn.training and bn.track_running_stats and bn.running_mean is not None and bn.momentum is not None
+            and bn.running_mean.dtype == torch.float32 and bn.running_var.dtype == torch.float32
+            and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous()):
+        return float(bn.momentum)
+    return None
+
+
+def _update_running(bn, mean: Tensor, var: Tensor, n: int, folded: bool = False) -> None:
+    if bn.training and bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            if folded:
+                return
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var.to(bn.running_var.dtype), alpha=mom * n / max(n - 1, 1))
+
+
+def batch_norm_act(x: Tensor, bn: "torch.nn.BatchNorm1d", act: str, residual: Optional[Tensor] = None) -> Tensor:
+    """BatchNorm1d(x) followed by `act` (+ `residual`, added inside the activation pass), with torch's semantics (batch statistics
+    + running-average update in training mode, running statistics in eval mode)."""
+    training = bn.training or bn.running_mean is None
+    fold = _fold_momentum(bn)
+    y, mean, var = _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, act, fold, residual)
+    _update_running(bn, mean, var, x.shape[0], folded=fold is not None)
+    return y
+
+
+# --------------------------------------------------------------------------
+# low-precision copies of the f32 master parameters: ONE multi-tensor copy per optimizer step instead of a cast kernel per use
+# --------------------------------------------------------------------------
+USE_CAST_ARENA = os.environ.get("PYGHO_CAST_ARENA", "1") != "0"
+_ARENA_OF = {}          # id(parameter) -> (weakref to its arena, position); validated by identity on lookup
+_ARENA_EPOCH = [0]      # bumped by whoever changes parameters behind the version counters' back (a HIP graph replay)
+
+
+def invalidate_cast_arenas() -> None:
+    """every arena copy is out of date (parameters were updated without their version counters moving: a replayed HIP graph
+    contains the optimizer's in-place update, and replaying it does not touch Python-side versions)."""
+    _ARENA_EPOCH[0] += 1
+
+
+class ParamCastArena:
+    """16-bit copies of a module's f32 parameters in one flat buffer (16-byte aligned views).  `refresh()` re-casts every
+    parameter whose version changed since the last refresh with ONE `torch._foreach_copy_` (the training step had ~25 separate
+    cast launches of 1-16 k elements, 4.7 us each); a lookup is valid only while the parameter's version is the refreshed one,
+    so an in-place update that nobody told the arena about simply falls back to a direct cast."""
+
+    def __init__(self, params, dtype: torch.dtype):
+        import weakref
+        self.dtype = dtype
+        self.params = [p for p in params if p.is_cuda and p.dtype == torch.float32]
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 7) // 8 * 8
+        dev = self.params[0].device if self.params else None
+        self.flat = torch.empty(total, dtype=dtype, device=dev) if self.params else None
+        self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
+        self.versions = [-1] * len(self.params)
+        self.ptrs = [0] * len(self.params)          # storage address at the last refresh: `module.to()` / `p.data = ...` swap it
+        self.epoch = -1
+        ref = weakref.ref(self)
+        for k in [k for k, (r, _i) in _ARENA_OF.items() if r() is None]:      # entries of arenas that are gone
+            del _ARENA_OF[k]
+        for i, p in enumerate(self.params):
+            _ARENA_OF[id(p)] = (ref, i)
+
+    def refresh(self) -> None:
+        """Freshness is decided by the parameter's version counter and storage address.  Covered update paths: in-place ops on the
+        parameter (optimizers, `p.copy_`, `load_state_dict`), `module.to()` / `p.data = t` (new storage), a replayed HIP graph
+        (`GraphedStep.replay` bumps the epoch).  NOT visible from here: writes through a `.data` alias (`p.data.mul_(...)` has its
+        own version counter) -- call `invalidate_cast_arenas()` after those.  Under stream capture every copy is re-cast INSIDE
+        the graph: a graph that captured only forward + backward must not bake in the views of a cast that happened before it."""
+        if self.epoch != _ARENA_EPOCH[0] or (self.flat is not None and torch.cuda.is_current_stream_capturing()):
+            stale = list(range(len(self.params)))
+        else:
+            stale = [i for i, p in enumerate(self.params) if self.versions[i] != p._version or self.ptrs[i] != p.data_ptr()]
+        self.epoch = _ARENA_EPOCH[0]
+        if not stale:
+            return
+        with torch.no_grad():
+            torch._foreach_copy_([self.views[i] for i in stale], [self.params[i].detach() for i in stale])
+        for i in stale:
+            self.versions[i] = self.params[i]._version
+            self.ptrs[i] = self.params[i].data_ptr()
+
+
+def ensure_cast_arena(module, dtype: Optional[torch.dtype]) -> None:
+    """create (once) and refresh the cast arena of `module`'s parameters for the 16-bit compute dtype; call at the top of forward."""
+    if not USE_CAST_ARENA or dtype not in (torch.bfloat16, torch.float16):
+        return
+    arena = module.__dict__.get("_pygho_cast_arena")
+    params = list(module.parameters())
+    if (arena is None or arena.dtype != dtype or len(arena.params) != sum(1 for p in params if p.is_cuda and p.dtype == torch.float32)
+            or any(a is not b for a, b in zip(arena.params, (p for p in params if p.is_cuda and p.dtype == torch.float32)))):
+        arena = ParamCastArena(params, dtype)
+        module.__dict__["_pygho_cast_arena"] = arena
+        if not module.__dict__.get("_pygho_cast_hook"):
+            # belt and braces next to the version / address checks: a loaded state dict invalidates every copy
+            module.register_load_state_dict_post_hook(lambda _m, _keys: invalidate_cast_arenas())
+            module.__dict__["_pygho_cast_hook"] = True
+    arena.refresh()
+
+
+def param_as(p: Tensor, dtype: torch.dtype) -> Tensor:
+    """`p` in `dtype`, without autograd: the arena's copy when it is current, a direct cast otherwise."""
+    if p.dtype == dtype:
+        return p
+    ent = _ARENA_OF.get(id(p))
+    if ent is not None:
+        arena = ent[0]()
+        if arena is None:
+            del _ARENA_OF[id(p)]
+        elif (arena.dtype == dtype and arena.epoch == _ARENA_EPOCH[0] and arena.params[ent[1]] is p
+              and arena.versions[ent[1]] == p._version and arena.ptrs[ent[1]] == p.data_ptr()):
+            return arena.views[ent[1]]
+    return p.detach().to(dtype)
+
+
+class _CastParam(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, dtype):
+        ctx.src_dtype = p.dtype
+        # a NEW tensor object every call: autograd writes this node into the returned object, and the arena's own view object
+        # would carry it -- and the AccumulateGrad node behind it, with the stream it was created on -- into the next iteration
+        # (a HIP graph capture after eager steps then pulled the eager stream into the capture and crashed in hipStreamEndCapture)
+        return param_as(p, dtype).detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.src_dtype), None
+
+
+def cast_param(p: Tensor, dtype: torch.dtype) -> Tensor:
+    """differentiable `p.to(dtype)` that reads the cast arena (the gradient returns in p's dtype)."""
+    if p.dtype == dtype:
+        return p
+    return _CastParam.apply(p, dtype)
+
+
+# --------------------------------------------------------------------------
+# one tuple-wise block: Linear -> BatchNorm -> act [-> message passing [+ residual]]   
+# --------------------------------------------------------------------------
+def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype, want_colsum: bool = False):
+    """dW = g^T x for tall (nnz ~ 10^5..10^6) operands; with `want_colsum` returns (dW, g.sum(0)).
+    Square 16-bit Linears of width 64 / 128 run on the transpose-read MFMA kernel (`pygho_weight_grad`); the rest falls back
+    to the library: a plain GEMM below 2^19 rows, a batched split-K product above (the BLAS heuristics pick no split-K for a
+    128 x 128 output, 2.9 ms at 1.8 M rows, but the batched call costs ~3.7 ms of host time, so it only pays for huge m)."""
+    m, n, k = g.shape[0], g.shape[1], x.shape[1]
+    cs = None
+    if (g.is_cuda and g.dtype in (torch.bfloat16, torch.float16) and x.dtype == g.dtype and n in (64, 128) and k % n == 0
+            and k // n <= 8 and m >= 8192):
+        g, x = g.contiguous(), x.contiguous()
+        dev = g.device
+        nblk = int(lib().pygho_bn_bwd_linear_dw_blocks(m))
+        parts = []
+        for j in range(k // n):                                       # one launch per n-wide column block of x (in_features = j n)
+            cs_here = want_colsum and j == 0
+            width = n * n + (2 * n if cs_here else 0)                 # one interleaved workspace, one folding launch
+            ws = torch.empty((nblk, width), dtype=torch.float32, device=dev)
+            cws_ptr = c_void_p(ws.data_ptr() + 4 * n * n) if cs_here else None
+            check(lib().pygho_weight_grad(ptr(ws), cws_ptr, ptr(g), c_void_p(x.data_ptr() + j * n * x.element_size()), k, m, n,
+                                          dtype_code(g), width, stream_ptr(dev)), "weight_grad")
+            tot = sum_blocks(ws)
+            parts.append(tot[:n * n].reshape(n, n))
+            if cs_here:
+                cs = tot[n * n:n * n + n]
+        gw = (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)).to(out_dtype)
+    else:
+        slabs = min(256, m // 2048)
+        if slabs < 4 or m < (1 << 19):
+            gw = (g.t() @ x).to(out_dtype)
+        else:
+            rows = m // slabs
+            main = rows * slabs
+            part = torch.bmm(g[:main].view(slabs, rows, n).transpose(1, 2), x[:main].view(slabs, rows, k))
+            gw = part.float().sum(0)
+            if main < m:
+                gw = gw + (g[main:].t() @ x[main:]).float()
+            gw = gw.to(out_dtype)
+        if want_colsum:
+            cs = g.sum(0, dtype=torch.float32)
+    return (gw, cs) if want_colsum else gw
+
+
+USE_FUSED_DW = True      # weight gradient inside the backward kernel (gpre never reaches HBM)
+USE_TABLE_PRODUCT = True
+USE_GRAD_CHAIN = os.environ.get("PYGHO_GRAD_CHAIN", "1") != "0"   # layers sharing A: A's gradient is summed inside the aggregation epilogues
+USE_ADJ_TABLE = True     # adjacency values that are an embedding lookup are read through the table inside the fused block
+USE_ACT_ON_LOAD = True   # f32 blocks: BatchNorm + activation applied inside the aggregation kernel's loads
+USE_BN_BWD_LINEAR = True
+USE_RECOMPUTE_PRE = os.environ.get("PYGHO_RECOMPUTE_PRE", "1") != "0"   # training blocks: the pre-activation is never stored (3 + 2 + 4 streams
+                                                                        # per block instead of 4 + 2 + 5; every pass recomputes it from x)
+USE_ROWBLOCK_LINEAR = True      # module switch for A/B measurements (the library GEMM + separate passes otherwise)
+USE_CONCAT_BLOCK = True   # SSWLConv / DSSGNNConv: Linear-BN-act over concatenated inputs without the concatenation
+USE_PAIR_COMBINE = True   # SUNConv on the padded layout: fused node-view / recombination passes
+USE_NODE_LEVEL_LINEAR = os.environ.get("PYGHO_NODE_LEVEL_LINEAR", "1") != "0"   # GNNAKConv (sparse): the 3 d -> d map applied before the broadcasts
+
+
+def rowblock_linear_supported(x: Tensor, out_features: int) -> bool:
+    return (USE_ROWBLOCK_LINEAR and x.is_cuda and x.dim() == 2 and x.dtype in (torch.bfloat16, torch.float16) and x.shape[1] == out_features
+            and out_features in (64, 128) and x.shape[0] >= 8192)
+
+
+def rowblock_linear(x: Tensor, wl: Tensor, bias: Optional[Tensor] = None, addend: Optional[Tensor] = None,
+                    stats_shift=None, store: bool = True):
+    """out = x @ wl^T (+ bias) (+ addend) on the skinny-GEMM kernel; with `stats_shift` also returns the per-block partial
+    sums of (out - shift), (out - shift)^2 for pygho_bn_finalize: (out, partial_sums or None).  `stats_shift` is an (f32, d)
+    tensor, or True: the kernel takes row 0 of its own output as the shift and the result is (out, (partial_sums, shift))."""
+    dev = require_device(x, wl, bias, addend, stats_shift if isinstance(stats_shift, Tensor) else None)
+    x, wl = x.contiguous(), wl.contiguous()
+    m, d = x.shape
+    assert wl.shape == (d, d) and wl.dtype == x.dtype
+    assert store or stats_shift is not None        # store=False: statistics of the (never stored) product only
+    out = torch.empty_like(x) if store else None
+    ws = None
+    if stats_shift is not None:
+        nblk = int(lib().pygho_rowblock_linear_blocks(m))
+        ws = torch.empty((nblk, 2, d), dtype=torch.float32, device=dev)
+    if addend is not None:
+        addend = addend.contiguous()
+    if stats_shift is True:
+        shift = torch.empty(d, dtype=torch.float32, device=dev)
+        check(lib().pygho_rowblock_linear_autoshift(ptr(out), ptr(x), ptr(wl), ptr(bias), ptr(addend), ptr(ws), ptr(shift), m, d,
+                                                    dtype_code(x), stream_ptr(dev)), "rowblock_linear")
+        return out, (ws, shift)
+    check(lib().pygho_rowblock_linear(ptr(out), ptr(x), ptr(wl), ptr(bias), ptr(addend), ptr(ws), ptr(stats_shift), m, d,
+                                      dtype_code(x), stream_ptr(dev)), "rowblock_linear")
+    return out, ws
+
+
+def rowblock_linear_bn_act(x: Tensor, wl: Tensor, bias: Optional[Tensor], scale: Tensor, shift: Tensor, act: str,
+                           addend: Optional[Tensor] = None) -> Tensor:
+    """act((x @ wl^T + bias) * scale + shift) (+ addend) in ONE pass over x: the product is rounded to the storage type exactly as
+    `rowblock_linear` stores it, then normalised / activated in the epilogue (= bn_act_fwd on the stored product, bit for bit)."""
+    dev = require_device(x, wl, bias, scale, shift, addend)
+    x, wl = x.contiguous(), wl.contiguous()
+    m, d = x.shape
+    assert wl.shape == (d, d) and wl.dtype == x.dtype and scale.dtype == torch.float32 and shift.dtype == torch.float32
+    out = torch.empty_like(x)
+    if addend is not None:
+        addend = addend.contiguous()
+    check(lib().pygho_rowblock_linear_bn_act(ptr(out), ptr(x), ptr(wl), ptr(bias), ptr(scale), ptr(shift), ptr(addend), m, d,
+                                             ACT_CODE[act], dtype_code(x), stream_ptr(dev)), "rowblock_linear_bn_act")
+    return out
+
+
+def rowblock_linear_bwd_sums(x: Tensor, wl: Tensor, bias: Optional[Tensor], gh: Tensor, saved, act: str):
+    """the two channel sums of the BatchNorm + activation backward for pre = x @ wl^T + bias, which is recomputed (same bits as
+    the forward's) instead of read: one pass over (x, gh)."""
+    mean, invstd, w32, b32, _ws = saved
+    dev = require_device(x, wl, bias, gh)
+    m, d = x.shape
+    s1 = torch.empty(d, dtype=torch.float32, device=dev)
+    s2 = torch.empty(d, dtype=torch.float32, device=dev)
+    nblk = int(lib().pygho_rowblock_linear_blocks(m))
+    ws = torch.empty((nblk, 2, d), dtype=torch.float32, device=dev)
+    check(lib().pygho_rowblock_linear_bwd_sums(ptr(s1), ptr(s2), ptr(x), ptr(wl.contiguous()), ptr(bias), ptr(gh.contiguous()), ptr(mean),
+                                               ptr(invstd), ptr(w32), ptr(b32), m, d, ACT_CODE[act], ptr(ws), dtype_code(x),
+                                               stream_ptr(dev)), "rowblock_linear_bwd_sums")
+    return s1, s2
+
+
+def sum_blocks(partials: Tensor) -> Tensor:
+    """(n_blocks, ...) f32 per-workgroup partial results -> their sum over the first dim (one deterministic kernel)."""
+    dev = require_device(partials)
+    assert partials.dtype == torch.float32 and partials.is_contiguous()
+    out = torch.empty(partials.shape[1:], dtype=torch.float32, device=dev)
+    check(lib().pygho_sum_blocks(ptr(out), ptr(partials), partials.shape[0], out.numel(), stream_ptr(dev)), "sum_blocks")
+    return out
+
+
+def bn_bwd_sums(pre: Tensor, gh: Tensor, saved, act: str):
+    """the two channel sums of the BatchNorm + activation backward (sum dy, sum dy * xhat), two-stage and deterministic."""
+    mean, invstd, w32, b32, ws = saved
+    m, c = pre.shape
+    dev = pre.device
+    s1 = torch.empty(c, dtype=torch.float32, device=dev)
+    s2 = torch.empty(c, dtype=torch.float32, device=dev)
+    check(lib().pygho_bn_act_bwd_sums(ptr(s1), ptr(s2), ptr(pre), ptr(gh), ptr(mean), ptr(invstd), ptr(w32), ptr(b32), m, c,
+                                      ACT_CODE[act], ptr(ws), dtype_code(pre), stream_ptr(dev)), "bn_act_bwd_sums")
+    return s1, s2
+
+
+def bn_bwd_linear(pre: Optional[Tensor], gh: Tensor, saved, training: bool, act: str, w: Tensor, addend: Optional[Tensor],
+                  want_colsum: bool, x: Optional[Tensor] = None, sums=None, lin_bias: Optional[Tensor] = None):
+    """(gx, gpre or dW, d bn.bias, d bn.weight, column sums of gpre or None): BatchNorm/act backward and the
+    input-gradient GEMM gx = gpre @ w (+ addend) in one streaming kernel after the two-stage channel reduction.
+    With `x` (the Linear's input) the weight gradient gpre^T @ x (f32) is accumulated in the same pass and returned in
+    place of gpre, which then never reaches HBM."""
+    mean, invstd, w32, b32, ws = saved
+    if pre is None:
+        # the pre-activation was not kept: both passes recompute it from x (`w` here is the Linear's weight in x's dtype)
+        assert x is not None
+        m, c = x.shape
+        dev = x.device
+        if sums is None:
+            sums = rowblock_linear_bwd_sums(x, w, lin_bias, gh, saved, act)
+        s1, s2 = sums
+        gx = torch.empty_like(x)
+        addend = None if addend is None else addend.contiguous()
+        nblk = int(lib().pygho_bn_bwd_linear_dw_blocks(m))
+        width = c * c + (2 * c if want_colsum else 0)
+        ws = torch.empty((nblk, width), dtype=torch.float32, device=dev)
+        cws_ptr = c_void_p(ws.data_ptr() + 4 * c * c) if want_colsum else None
+        check(lib().pygho_bn_bwd_linear_dw_recompute(ptr(gx), ptr(ws), ptr(gh), ptr(x), ptr(w.contiguous()), ptr(lin_bias), ptr(addend), cws_ptr,
+                                                     ptr(mean), ptr(invstd), ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act],
+                                                     1 if training else 0, dtype_code(x), width, stream_ptr(dev)),
+              "bn_bwd_linear_dw_recompute")
+        tot = sum_blocks(ws)
+        return gx, tot[:c * c].reshape(c, c), s1, s2, (tot[c * c:c * c + c] if want_colsum else None)
+    m, c = pre.shape
+    dev = pre.device
+    st = stream_ptr(dev)
+    dt = dtype_code(pre)
+    s1, s2 = sums if sums is not None else bn_bwd_sums(pre, gh, saved, act)
+    gx = torch.empty_like(pre)
+    wl = w.t().contiguous()
+    if addend is not None:
+        addend = addend.contiguous()
+    nblk = int(lib().pygho_bn_bwd_linear_dw_blocks(m) if x is not None else lib().pygho_rowblock_linear_blocks(m))
+    if x is not None:
+        width = c * c + (2 * c if want_colsum else 0)              # dW slabs and column sums interleaved: one folding launch
+        ws = torch.empty((nblk, width), dtype=torch.float32, device=dev)
+        cws_ptr = c_void_p(ws.data_ptr() + 4 * c * c) if want_colsum else None
+        check(lib().pygho_bn_bwd_linear_dw(ptr(gx), ptr(ws), ptr(pre), ptr(gh), ptr(x), ptr(wl), ptr(addend), cws_ptr, ptr(mean),
+                                           ptr(invstd), ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act],
+                                           1 if training else 0, dt, width, st), "bn_bwd_linear_dw")
+        tot = sum_blocks(ws)
+        return gx, tot[:c * c].reshape(c, c), s1, s2, (tot[c * c:c * c + c] if want_colsum else None)
+    cws = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev) if want_colsum else None
+    second = torch.empty_like(pre)
+    check(lib().pygho_bn_bwd_linear(ptr(gx), ptr(second), ptr(pre), ptr(gh), ptr(wl), ptr(addend), ptr(cws), ptr(mean), ptr(invstd),
+                                    ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act], 1 if training else 0, dt, st),
+          "bn_bwd_linear")
+    sdx = sum_blocks(cws)[0] if cws is not None else None
+    return gx, second, s1, s2, sdx
+
+
+class _TupleBlock(torch.autograd.Function):
+    """H = act(bn(x W^T + b));  out = H                                  (plan is None)
+                                  out = [x +] (+)_{(a,c,d)} H[c] * rhs[d]   (plan given; `residual` adds x)
+    One autograd node for the whole block so that (i) the Linear's bias gradient comes out of the BatchNorm
+    backward pass, (ii) the residual add runs in the aggregation epilogue and (iii) the residual gradient is
+    added in place into the fresh input-gradient GEMM output."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, eps, act, rhs, plan, aggr, residual,
+                fold_momentum=None, rhs_lookup=None, chain=False, chain_x=False):
+        require_device(x, w, rhs)
+        x = x.contiguous()
+        # master weights (usually f32) are cast to the activation dtype here, outside the autograd graph; their
+        # gradients are returned in the master dtype straight from the f32 split-K / column sums
+        wc = param_as(w, x.dtype)
+        bc = None if b is None else param_as(b, x.dtype)
+        skinny = rowblock_linear_supported(x, w.shape[0]) and w.shape[0] == w.shape[1]
+        partial = None
+        # the pre-activation is kept only when a backward pass will read it: with the weight gradient folded into the backward
+        # kernel every pass recomputes it from x (same bits), and without a backward nobody needs it
+        needs = ctx.needs_input_grad
+        recompute = (USE_RECOMPUTE_PRE and skinny and USE_BN_BWD_LINEAR and USE_FUSED_DW
+                     and (needs[1] or not any(needs[i] for i in (0, 2, 3, 4, 10))))
+        if recompute:
+            pre = None
+            if training:
+                _none, partial = rowblock_linear(x, wc, bc, stats_shift=True, store=False)
+        elif skinny:
+            # hand-written streaming GEMM: the BatchNorm statistics of its output ride in the epilogue
+            pre, partial = rowblock_linear(x, wc, bc, stats_shift=True if training else None)     # partial = (sums, shift)
+        else:
+            pre = torch.nn.functional.linear(x, wc, bc)
+        # f32 rows carry half the elements per byte: there the BatchNorm + activation can ride on the aggregation's loads
+        # (act-on-load: 0.61 vs 0.35 + 0.62 ms) and the activated tensor is never formed; with 16-bit rows the two
+        # transcendentals per element make that kernel VALU-bound (0.52 vs 0.50 ms forward, 0.41 vs 0.30 ms backward)
+        on_load = (not recompute and USE_ACT_ON_LOAD and plan is not None and rhs is not None and x.dtype == torch.float32 and aggr in ("sum", "mean")
+                   and (x.shape[1] * 4) % 16 == 0 and rhs.dtype == x.dtype and rhs.shape[1] == x.shape[1])
+        # without a plan `rhs` is a residual row operand: out = H + rhs, added inside the activation pass
+        row_res = rhs.contiguous() if (plan is None and rhs is not None) else None
+        h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum, partial,
+                                          apply=not on_load, addend=row_res, producer=(x, wc, bc) if recompute else None)
+        affine = look = None
+        rhs_read, d_idx = rhs, (plan.d_fwd if plan is not None and rhs is not None else None)
+        if plan is not None and rhs is not None and rhs_lookup is not None:
+            # rhs == table[row_of] for a small table: index the table per message (its rows stay in L1) instead of streaming
+            # the (n_edges, d) gathered array (0.339 -> 0.310 ms forward, 0.259 -> 0.244 ms backward at B = 8192).  The
+            # gradient still goes to `rhs` per edge, and from there through the lookup's own backward.
+            look = (rhs_lookup[0].detach(),) + plan.lookup(rhs_lookup[1])
+            rhs_read, d_idx = look[0], look[1]
+        if plan is None:
+            out = h
+        elif on_load:
+            affine, h = h, None
+            out = seg_gmr(plan.n_out, pre, rhs_read, plan.fwd.seg_ptr, plan.c_fwd, d_idx, aggr, addend=x if residual else None,
+                          act=(affine[0], affine[1], act, 1))
+        else:
+            out = seg_gmr(plan.n_out, h, rhs_read, plan.fwd.seg_ptr, plan.c_fwd, d_idx, aggr, addend=x if residual else None)
+        ctx.affine, ctx.look = affine, look
+        ctx.save_for_backward(x, wc, pre, h if plan is not None else None, rhs, bc, *saved)
+        ctx.meta = (training, act, None if b is None else b.dtype, gamma is not None, beta is not None, plan, aggr, residual, w.dtype,
+                    skinny)
+        ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)            # no zero tensors for the statistics' (never used) gradients
+        ctx.chain = (bool(chain), bool(chain_x))
+        extra = ()
+        if chain:
+            # `rhs` again as an OUTPUT: the next block that shares this operand takes it from here, so the operand's gradient
+            # arrives in this block's backward already summed over the later blocks and is extended in the aggregation's epilogue
+            # (out = addend + ...), instead of autograd adding one (n_rhs, d) tensor per consumer
+            extra += (rhs.view_as(rhs),)
+        if chain_x:
+            # the same for the block's INPUT: whoever else reads x takes it from here; that gradient arrives below and is added in the
+            # epilogue of the input-gradient GEMM (where the residual gradient goes), not by a separate (m, d) accumulation
+            extra += (x.view_as(x),)
+        return (out, mean, var) + extra
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv, *g_extra):
+        g_extra = list(g_extra)
+        g_chain = g_extra.pop(0) if ctx.chain[0] else None
+        g_x = g_extra.pop(0) if ctx.chain[1] else None
+        if g is None:
+            n_in = len(ctx.needs_input_grad)
+            return (g_x,) + (None,) * 9 + (g_chain,) + (None,) * (n_in - 11)
+        x, w, pre, h, rhs, bc, *saved = ctx.saved_tensors
+        training, act, b_dtype, has_gamma, has_beta, plan, aggr, residual, w_dtype, skinny = ctx.meta
+        g = g.contiguous()
+        # what is added to the input gradient in the GEMM epilogue: the residual gradient and / or the gradient of x's other readers
+        res_g = g if residual else None
+        if g_x is not None:
+            res_g = g_x.contiguous() if res_g is None else res_g + g_x
+        g_rhs = None
+        gh = g
+        if plan is not None:
+            scale = plan.fwd.inv_count if aggr == "mean" else None
+            p, a_g, d_g = plan.by_c()
+            rhs_read = rhs
+            if ctx.look is not None:
+                rhs_read, d_g = ctx.look[0], ctx.look[2]
+            gh = seg_gmr(plan.n_lhs, g, rhs_read, p.seg_ptr, a_g, d_g if rhs is not None else None, "sum", scale)
+            if rhs is not None and ctx.needs_input_grad[10]:
+                p, a_g, c_g = plan.by_d()
+                if ctx.affine is not None:
+                    g_rhs = seg_gmr(plan.n_rhs, g, pre, p.seg_ptr, a_g, c_g, "sum", scale,
+                                    act=(ctx.affine[0], ctx.affine[1], act, 2))
+                    if g_chain is not None:
+                        g_rhs = g_rhs + g_chain
+                else:
+                    g_rhs = seg_gmr(plan.n_rhs, g, h, p.seg_ptr, a_g, c_g, "sum", scale,
+                                    addend=None if g_chain is None else g_chain.contiguous())
+            elif g_chain is not None:
+                g_rhs = g_chain
+        elif rhs is not None and ctx.needs_input_grad[10]:
+            g_rhs = g if g_chain is None else g + g_chain      # residual row operand: receives the output gradient as it is
+        want_cs = b_dtype is not None and ctx.needs_input_grad[2]
+        gx = gw = gb = None
+        if pre is None or (skinny and USE_BN_BWD_LINEAR and USE_FUSED_DW and ctx.needs_input_grad[1]):
+            gx, gw32, s1, s2, sdx = bn_bwd_linear(pre, gh.contiguous(), saved, training, act, w, res_g, want_cs, x=x,
+                                                  lin_bias=bc)
+            gw = gw32.to(w_dtype)
+        elif skinny and USE_BN_BWD_LINEAR:
+            gx, gpre, s1, s2, sdx = bn_bwd_linear(pre, gh.contiguous(), saved, training, act, w, res_g, want_cs)
+        else:
+            gpre, s1, s2, sdx = _bn_backward(pre, gh, saved, training, act, want_colsum=want_cs)
+        if gx is None and ctx.needs_input_grad[0]:
+            if skinny:
+                # dX = gpre . W (+ g): the residual gradient is added in the GEMM epilogue
+                gx, _ = rowblock_linear(gpre, w.t().contiguous(), None, addend=res_g)
+            else:
+                # (addmm(g, gpre, w) copies g first and then runs a slower beta = 1 GEMM: product + add is faster)
+                gx = gpre @ w
+                if res_g is not None:
+                    gx = gx.add_(res_g)
+        if gw is None and ctx.needs_input_grad[1]:
+            gw = weight_grad_splitk(gpre, x, w_dtype)
+        if sdx is not None:
+            gb = sdx.to(b_dtype)
+        if gx is None and g_x is not None:
+            gx = g_x
+        return (gx, gw, gb, (s2 if has_gamma else None), (s1 if has_beta else None), None, None, None, None, None,
+                g_rhs, None, None, None, None, None, None, None)
+
+
+def tuple_block(x: Tensor, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", act: str, rhs: Optional[Tensor] = None,
+                plan: Optional[MessagePlan] = None, aggr: str = "sum", residual: bool = False,
+                rhs_lookup: Optional[Tuple[Tensor, Tensor]] = None, chain: bool = False, chain_x: bool = False):
+    """fused Linear -> BatchNorm1d -> act (-> aggregation over `plan` with `rhs` (-> + x)); parameters are read
+    from the stock modules (f32 master weights are cast to the activation dtype like autocast would)."""
+    training = bn.training or bn.running_mean is None
+    if residual:
+        assert plan is not None and plan.n_out == x.shape[0] and lin.out_features == x.shape[1]
+    if plan is None and rhs is not None:                # residual row operand (see _TupleBlock.forward)
+        assert rhs.shape == (x.shape[0], lin.out_features) and rhs.dtype == x.dtype and rhs_lookup is None
+    fold = _fold_momentum(bn)
+    res = _TupleBlock.apply(x, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                            bn.eps, act, rhs, plan, aggr, residual, fold, rhs_lookup, chain, chain_x)
+    out, mean, var = res[:3]
+    _update_running(bn, mean, var, x.shape[0], folded=fold is not None)
+    # (out[, rhs again when `chain`][, x again when `chain_x`]): see _TupleBlock.forward
+    return (out,) + tuple(res[3:]) if (chain or chain_x) else out
+
+
+class _ConcatBlock(torch.autograd.Function):
+    """act(bn(concat(x_0 .. x_{K-1}) W^T + b)) without the concatenation: W = [W_0 | .. | W_{K-1}] column blocks,
+    pre = (..((x_0 W_0^T + b) + x_1 W_1^T) ..) as a chain of streaming GEMMs, each with the previous result in its epilogue and
+    the last with the BatchNorm statistics; backward = the channel reduction once, then per input ONE pass producing its
+    input gradient and its weight-gradient block.  (SSWLConv, reference Conv.py:98-103: the (nnz, 3 d) concatenation is
+    1.4 GB at B = 8192 and was a quarter of the layer.)"""
+
+    @staticmethod
+    def forward(ctx, w, b, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum, *xs):
+        # fold_momentum may arrive as (momentum, residual): residual = the block's output gets xs[0] added (the layer's residual
+        # connection, in the activation pass) and xs[0]'s gradient gets the output gradient added (in its backward GEMM's epilogue)
+        residual = False
+        if isinstance(fold_momentum, tuple):
+            fold_momentum, residual = fold_momentum
+        require_device(w, *xs)
+        xs = [x.contiguous() for x in xs]
+        res_row = None
+        if residual == "last":                 # the residual operand is a tensor of its own, passed after the block's inputs
+            res_row, xs = xs[-1], xs[:-1]
+        d = xs[0].shape[1]
+        dt = xs[0].dtype
+        wc = param_as(w, dt)
+        bc = None if b is None else param_as(b, dt)
+        blocks = [wc[:, k * d:(k + 1) * d].contiguous() for k in range(len(xs))]
+        pre, partial = None, None
+        for k, (x, wk) in enumerate(zip(xs, blocks)):
+            last = k == len(xs) - 1
+            pre, partial = rowblock_linear(x, wk, bc if k == 0 else None, addend=pre, stats_shift=True if (last and training) else None)
+        h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum,
+                                          partial if training else None, apply=True,
+                                          addend=res_row if res_row is not None else (xs[0] if residual else None))
+        ctx.save_for_backward(pre, *xs, *blocks, *saved)
+        ctx.residual = residual
+        ctx.meta = (len(xs), training, act, None if b is None else b.dtype, gamma is not None, beta is not None, w.dtype)
+        ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)            # no zero tensors for the statistics' (never used) gradients
+        return h, mean, var
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv):
+        if g is None:
+            return (None,) * len(ctx.needs_input_grad)
+        k_in, training, act, b_dtype, has_gamma, has_beta, w_dtype = ctx.meta
+        pre = ctx.saved_tensors[0]
+        xs = ctx.saved_tensors[1:1 + k_in]
+        blocks = ctx.saved_tensors[1 + k_in:1 + 2 * k_in]
+        saved = ctx.saved_tensors[1 + 2 * k_in:]
+        g = g.contiguous()
+        sums = bn_bwd_sums(pre, g, saved, act)
+        want_cs = b_dtype is not None and ctx.needs_input_grad[1]
+        gxs, gws, gb = [], [], None
+        for k in range(k_in):
+            gx, gw32, _s1, _s2, sdx = bn_bwd_linear(pre, g, saved, training, act, blocks[k], g if (ctx.residual is True and k == 0) else None,
+                                                    want_cs and k == 0, x=xs[k], sums=sums)
+            gxs.append(gx if ctx.needs_input_grad[10 + k] else None)
+            gws.append(gw32)
+            if sdx is not None:
+                gb = sdx.to(b_dtype)
+        gw = torch.cat(gws, dim=1).to(w_dtype) if ctx.needs_input_grad[0] else None
+        s1, s2 = sums
+        if ctx.residual == "last":             # the separate residual operand receives the output gradient as it is
+            gxs.append(g if ctx.needs_input_grad[10 + k_in] else None)
+        return (gw, gb, (s2 if has_gamma else None), (s1 if has_beta else None), None, None, None, None, None, None, *gxs)
+
+
+class _ProxyCtx:
+    """stands in for the autograd context when a fused Function runs another Function's forward / backward as one of its steps"""
+
+    def __init__(self, needs_input_grad=()):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+
+USE_SSWL_BLOCK = True
+
+
+class _SSWLBlock(torch.autograd.Function):
+    """the whole SSWLConv update (reference Conv.py:98-103) as one autograd node: x1 = X A inside the subgraphs, x2 = A X across
+    them, h = act(bn([x | x1 | x2] W^T + b)) [+ x].  What one node buys over three: the gradient of X has three contributions
+    (the block's first input, the two products) and the gradient of A two; here each aggregation launch takes the running sum in
+    its epilogue instead of autograd adding (nnz, d) tensors afterwards (two read-read-write passes per layer)."""
+
+    @staticmethod
+    def forward(ctx, x, a, plan1, plan2, aggr, residual, w, b, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum):
+        x, a = x.contiguous(), a.contiguous()
+        x1 = seg_gmr(plan1.n_out, x, a, plan1.fwd.seg_ptr, plan1.c_fwd, plan1.d_fwd, aggr)
+        x2 = seg_gmr(plan2.n_out, a, x, plan2.fwd.seg_ptr, plan2.c_fwd, plan2.d_fwd, aggr)
+        sub = _ProxyCtx()
+        h, mean, var = _ConcatBlock.forward(sub, w, b, gamma, beta, running_mean, running_var, training, eps, act,
+                                            (fold_momentum, residual), x, x1, x2)
+        ctx.save_for_backward(a, *sub.saved_tensors)
+        ctx.sub = (sub.residual, sub.meta)
+        ctx.plans, ctx.aggr = (plan1, plan2), aggr
+        ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)            # no zero tensors for the statistics' (never used) gradients
+        return h, mean, var
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv):
+        if g is None:
+            return (None,) * len(ctx.needs_input_grad)
+        a = ctx.saved_tensors[0]
+        sub = _ProxyCtx((ctx.needs_input_grad[6], ctx.needs_input_grad[7]) + (False,) * 8 + (True, True, True))
+        sub.saved_tensors = ctx.saved_tensors[1:]
+        sub.residual, sub.meta = ctx.sub
+        res = _ConcatBlock.backward(sub, g, None, None)
+        gw, gb, ggamma, gbeta = res[:4]
+        g0, g1, g2 = res[10:13]
+        x = sub.saved_tensors[1]
+        plan1, plan2 = ctx.plans
+        sc1 = plan1.fwd.inv_count if ctx.aggr == "mean" else None
+        sc2 = plan2.fwd.inv_count if ctx.aggr == "mean" else None
+        gx = ga = None
+        if ctx.needs_input_grad[0]:
+            p, a_g, d_g = plan1.by_c()                      # x is the left operand of X A ...
+            gx = seg_gmr(plan1.n_lhs, g1, a, p.seg_ptr, a_g, d_g, "sum", sc1, addend=g0)
+            p, a_g, c_g = plan2.by_d()                      # ... and the right operand of A X
+            gx = seg_gmr(plan2.n_rhs, g2, a, p.seg_ptr, a_g, c_g, "sum", sc2, addend=gx)
+        if ctx.needs_input_grad[1]:
+            p, a_g, c_g = plan1.by_d()
+            ga = seg_gmr(plan1.n_rhs, g1, x, p.seg_ptr, a_g, c_g, "sum", sc1)
+            p, a_g, d_g = plan2.by_c()
+            ga = seg_gmr(plan2.n_lhs, g2, x, p.seg_ptr, a_g, d_g, "sum", sc2, addend=ga)
+        return (gx, ga, None, None, None, None, gw, gb, ggamma, gbeta) + (None,) * 6
+
+
+def sswl_block(x: Tensor, a: Tensor, plan1: "MessagePlan", plan2: "MessagePlan", aggr: str, lin: "torch.nn.Linear",
+               bn: "torch.nn.BatchNorm1d", act: str, residual: bool) -> Tensor:
+    training = bn.training or bn.running_mean is None
+    fold = _fold_momentum(bn)
+    out, mean, var = _SSWLBlock.apply(x, a, plan1, plan2, aggr, residual, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean,
+                                      bn.running_var, training, bn.eps, act, fold)
+    _update_running(bn, mean, var, x.shape[0], folded=fold is not None)
+    return out
+
+
+def concat_block_supported(xs, lin: "torch.nn.Linear") -> bool:
+    d = xs[0].shape[1] if xs and xs[0].dim() == 2 else -1
+    return (USE_CONCAT_BLOCK and USE_ROWBLOCK_LINEAR and USE_BN_BWD_LINEAR and len(xs) >= 2
+            and all(x.dim() == 2 and x.shape == xs[0].shape and x.dtype == xs[0].dtype and x.is_cuda for x in xs)
+            and lin.in_features == len(xs) * d and lin.out_features == d and rowblock_linear_supported(xs[0], d)
+            and bn_act_supported_shape(xs[0].shape[0], d, xs[0].dtype))
+
+
+def concat_block(xs, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", act: str, residual=False) -> Tensor:
+    """fused Linear -> BatchNorm1d -> act applied to concat(xs, dim=1), the concatenation never formed; `residual`: True adds
+    xs[0] to the result, a tensor (same shape and dtype as the result) adds that tensor — both inside the activation pass."""
+    training = bn.training or bn.running_mean is None
+    fold = _fold_momentum(bn)
+    if isinstance(residual, Tensor):
+        assert residual.shape == xs[0].shape and residual.dtype == xs[0].dtype
+        mode, extra = (fold, "last"), (residual,)
+    else:
+        mode, extra = ((fold, True) if residual else fold), ()
+    out, mean, var = _ConcatBlock.apply(lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                                        bn.eps, act, mode, *xs, *extra)
+    _update_running(bn, mean, var, xs[0].shape[0], folded=fold is not None)
+    return out

@@ -1,0 +1,711 @@
+"""
+Segment kernels behind the sparse operators: the raw launches of the fused gather * gather -> segment reduce family (fast /
+LDS-window / tiled), the message plan of an `acd` triple array with its transposed groupings, and the autograd Functions of
+spspmm, scatter-reduce, row gather, spmm and the three-operand tuple initialisation.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from ._native import AGGR_CODE, DTYPE_CODE, check, dtype_code, lib, ptr, require_device, stream_ptr
+
+from . import plans as _plans
+from .plans import *          # noqa: F401,F403
+from .plans import _I32, _PENDING_ERRORS, _DEFER_CHECKS, _fetch, _flag
+
+
+# --------------------------------------------------------------------------
+# raw launches
+# --------------------------------------------------------------------------
+def _as2d(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    t = t.contiguous()
+    return t.reshape(t.shape[0], -1) if t.dim() != 2 else t
+
+
+class LaunchTimer:
+    """Opt-in per-launch timing of the fused segment kernel with HIP events recorded on the stream the
+    kernel is launched on (torch's current stream is the one handed to the C ABI).  Used by bench.py for the
+    roofline figure; `records` holds (kernel variant, algorithmic bytes, start event, end event)."""
+    active: Optional["LaunchTimer"] = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        LaunchTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        LaunchTimer.active = None
+
+    def summary(self):
+        """{variant: (launches, mean ms, mean algorithmic bytes)} -- call after a device synchronize."""
+        agg = {}
+        for name, nbytes, e0, e1 in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+            a[2] += nbytes
+        return {k: (v[0], v[1] / v[0], v[2] / v[0]) for k, v in agg.items()}
+
+
+USE_UNIT_TRIPLE = True        # forward of the three-operand tuple initialisation (unit segments) on its own elementwise kernel
+DEBUG_INDICES = os.environ.get("PYGHO_DEBUG", "0") not in ("", "0")   # validate every index array of a segment launch (host sync per call)
+USE_SEG_WINDOW = os.environ.get("PYGHO_SEG_WINDOW", "1") != "0"
+
+
+def _debug_check_segments(out_rows: int, seg_ptr: Tensor, idx_rows) -> None:
+    """PYGHO_DEBUG=1: the kernels trust their index arrays (the reference's gathers raise IndexError); this checks, before a launch,
+    that the CSR pointers are monotone from 0 and that every index addresses a row of its operand."""
+    ptr_ok = seg_ptr.numel() == out_rows + 1 and int(seg_ptr[0]) == 0 and bool((seg_ptr[1:] >= seg_ptr[:-1]).all())
+    if not ptr_ok:
+        raise IndexError("pygho_amd (PYGHO_DEBUG): segment pointers are not a monotone CSR array starting at 0")
+    m = int(seg_ptr[-1])
+    for name, idx, rows in idx_rows:
+        if idx is None:
+            if rows is not None and rows < m:
+                raise IndexError(f"pygho_amd (PYGHO_DEBUG): {name} has {rows} rows for {m} messages")
+            continue
+        if idx.numel() < m or (m and (int(idx[:m].min()) < 0 or int(idx[:m].max()) >= rows)):
+            raise IndexError(f"pygho_amd (PYGHO_DEBUG): {name} index out of range [0, {rows})")
+USE_SEG_WINDOW_BY_EDGE = os.environ.get("PYGHO_SEG_WINDOW_BY_EDGE", "1") != "0"
+SEG_WINDOW_MIN_ROW_BYTES = int(os.environ.get("PYGHO_SEG_WINDOW_MIN_ROW_BYTES", "512"))
+
+
+def _window_eligible(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], rhs_idx: Optional[Tensor], aggr: str) -> bool:
+    """two-operand sum / mean whose rhs is the small operand (edge rows, an embedding table): its rows are served from LDS
+    (`pygho_seg_gather_mul_reduce_window`).  Rows of 512 B and more: that is where the L2 -> L1 gather path binds."""
+    if not USE_SEG_WINDOW or lhs is None or rhs is None or rhs_idx is None or aggr not in ("sum", "mean"):
+        return False
+    rb = rhs.shape[1] * rhs.element_size()
+    if (USE_SEG_WINDOW_BY_EDGE and rhs.shape[0] > 2 * out_rows and lhs.shape[0] == rhs.shape[0] and rb % 16 == 0 and 128 <= rb <= 256
+            and rhs.dtype in (torch.bfloat16, torch.float16) and out_rows >= 4096 and rhs.shape[0] * rb < (1 << 32)):
+        # the by-edge backward plan of spspmm (gradient of the adjacency values): both operands are tuple-level rows spread over
+        # their whole graph (a 110-KB working set per graph against 32 KB of L1), few segments per pass so that one operand's
+        # row range fits the window: 288 -> 258 us per launch in the ZINC step
+        return True
+    return (rhs.dtype in (torch.float32, torch.bfloat16, torch.float16) and rb % 16 == 0 and SEG_WINDOW_MIN_ROW_BYTES <= rb <= 1024
+            and 2 * rhs.shape[0] <= out_rows and out_rows >= 4096 and max(out_rows, lhs.shape[0]) * rb < (1 << 32))
+
+
+SEG_TILE = os.environ.get("PYGHO_SEG_TILE", "0")            # "0": never, "1": whenever the shape allows, "auto": by plan shape
+SEG_TILE_WIN_ROWS = int(os.environ.get("PYGHO_SEG_TILE_WIN_ROWS", "32"))
+
+
+def tile_plan(seg_ptr: Tensor, lhs_idx: Tensor, n_seg: int, win_rows: int):
+    """(tile_cnt, tiles) of `pygho_seg_tile_plan` for one (CSR pointers, lhs index) pair: consecutive segments whose lhs rows lie in
+    a window of `win_rows` consecutive rows.  A pure function of the index arrays; cached on the index tensor object."""
+    cache = getattr(lhs_idx, "_pygho_tiles", None)
+    if cache is None:
+        cache = {}
+        try:
+            lhs_idx._pygho_tiles = cache
+        except Exception:
+            pass
+    k = (seg_ptr.data_ptr(), n_seg, win_rows, lhs_idx._version, seg_ptr._version)
+    hit = cache.get(k)
+    if hit is None:
+        dev = require_device(seg_ptr, lhs_idx)
+        chunk = int(lib().pygho_seg_tile_chunk())
+        n_chunks = (n_seg + chunk - 1) // chunk
+        tile_cnt = torch.empty(n_chunks, dtype=_I32, device=dev)
+        tiles = torch.empty((n_chunks, chunk, 4), dtype=_I32, device=dev)
+        check(lib().pygho_seg_tile_plan(ptr(tile_cnt), ptr(tiles), ptr(seg_ptr), ptr(lhs_idx), n_seg, win_rows, stream_ptr(dev)),
+              "seg_tile_plan")
+        hit = (tile_cnt, tiles, seg_ptr)            # the pointers are kept alive with the entry that is keyed on their address
+        cache[k] = hit
+    return hit[0], hit[1]
+
+
+def _tile_eligible(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], lhs_idx: Optional[Tensor], rhs_idx: Optional[Tensor],
+                   aggr: str) -> bool:
+    """two-operand sum / mean with both index arrays and rows of 256 / 512 / 1024 bytes (`pygho_seg_gather_mul_reduce_tiled`)."""
+    if SEG_TILE == "0" or lhs is None or rhs is None or lhs_idx is None or rhs_idx is None or aggr not in ("sum", "mean"):
+        return False
+    rb = lhs.shape[1] * lhs.element_size()
+    if rb not in (256, 512, 1024) or lhs.dtype not in (torch.float32, torch.bfloat16, torch.float16) or out_rows < 4096:
+        return False
+    if SEG_TILE == "1":
+        return True
+    # auto: the plans whose segments gather lhs rows of one narrow block (forward and by-tuple backward of the tuple products);
+    # the by-edge backward plan (few long segments over rows spread across a graph) stays on the window kernel
+    return rb >= 512 and 2 * rhs.shape[0] <= out_rows
+
+
+def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr: Tensor,
+            lhs_idx: Optional[Tensor], rhs_idx: Optional[Tensor], aggr: str,
+            lhs_rowscale: Optional[Tensor] = None, addend: Optional[Tensor] = None,
+            act: Optional[Tuple[Tensor, Tensor, str, int]] = None) -> Tensor:
+    """out[s] = [addend[s] +] (+)_{m in seg s} scale * lhs[lhs_idx[m]] * rhs[rhs_idx[m]]  (2-D operands).
+    `act` = (scale, shift, name, side): operand `side` (1 lhs, 2 rhs) holds pre-activations and
+    act(x * scale + shift) is applied to its rows as they are loaded."""
+    ref = lhs if lhs is not None else rhs
+    dev = require_device(lhs, rhs, seg_ptr, lhs_idx, rhs_idx, lhs_rowscale, addend)
+    if DEBUG_INDICES:
+        _debug_check_segments(out_rows, seg_ptr, (("lhs", lhs_idx, None if lhs is None else lhs.shape[0]),
+                                                  ("rhs", rhs_idx, None if rhs is None else rhs.shape[0])))
+    d = ref.shape[1]
+    out = torch.empty((out_rows, d), dtype=ref.dtype, device=dev)
+    timer = LaunchTimer.active
+    windowed = tiled = False
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(dev))
+    dims = (out_rows, d, d if lhs is not None else 0, d if rhs is not None else 0,
+            lhs.shape[0] if lhs is not None else 0, rhs.shape[0] if rhs is not None else 0,
+            dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev))
+    if act is not None:
+        a_scale, a_shift, a_name, a_side = act
+        assert lhs is not None and rhs is not None and a_scale.dtype == torch.float32 and a_shift.dtype == torch.float32
+        if addend is not None:
+            assert addend.shape == out.shape and addend.dtype == out.dtype and addend.is_contiguous()
+        check(lib().pygho_seg_gather_mul_reduce_act(
+            ptr(out), ptr(addend), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale),
+            ptr(a_scale.contiguous()), ptr(a_shift.contiguous()), ACT_CODE[a_name], a_side, out_rows, d, lhs.shape[0], rhs.shape[0],
+            dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev)), "seg_gather_mul_reduce_act")
+    elif _tile_eligible(out_rows, lhs, rhs, lhs_idx, rhs_idx, aggr):
+        tiled = True
+        if addend is not None:
+            assert addend.shape == out.shape and addend.dtype == out.dtype and addend.is_contiguous()
+        tile_cnt, tiles = tile_plan(seg_ptr, lhs_idx, out_rows, SEG_TILE_WIN_ROWS)
+        check(lib().pygho_seg_gather_mul_reduce_tiled(
+            ptr(out), ptr(addend), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale), ptr(tile_cnt),
+            ptr(tiles), out_rows, d, lhs.shape[0], rhs.shape[0], SEG_TILE_WIN_ROWS, dtype_code(ref), AGGR_CODE[aggr],
+            stream_ptr(dev)), "seg_gather_mul_reduce_tiled")
+    elif _window_eligible(out_rows, lhs, rhs, rhs_idx, aggr):
+        windowed = True
+        if addend is not None:
+            assert addend.shape == out.shape and addend.dtype == out.dtype and addend.is_contiguous()
+        check(lib().pygho_seg_gather_mul_reduce_window(
+            ptr(out), ptr(addend), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale), out_rows, d,
+            lhs.shape[0], rhs.shape[0], dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev)), "seg_gather_mul_reduce_window")
+    elif addend is None:
+        check(lib().pygho_seg_gather_mul_reduce(
+            ptr(out), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale), *dims),
+            "seg_gather_mul_reduce")
+    else:
+        assert addend.shape == out.shape and addend.dtype == out.dtype and addend.is_contiguous()
+        check(lib().pygho_seg_gather_mul_reduce_add(
+            ptr(out), ptr(addend), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale), *dims),
+            "seg_gather_mul_reduce_add")
+    if timer is not None:
+        e1.record(torch.cuda.current_stream(dev))
+        # algorithmic bytes: every operand row once, every output row once, int32 indices once
+        es = ref.element_size()
+        m = lhs_idx.numel() if lhs_idx is not None else (rhs_idx.numel() if rhs_idx is not None else ref.shape[0])
+        rows = (lhs.shape[0] if lhs is not None else 0) + (rhs.shape[0] if rhs is not None else 0) + out_rows
+        nbytes = es * d * rows + 4 * m * ((lhs_idx is not None) + (rhs_idx is not None)) + 4 * (out_rows + 1)
+        if lhs_rowscale is not None:
+            nbytes += 4 * lhs_rowscale.numel()
+        if addend is not None:
+            nbytes += es * d * out_rows
+        mode = "both" if (lhs is not None and rhs is not None) else ("lhs" if lhs is not None else "rhs")
+        timer.records.append((f"seg_gmr[{str(ref.dtype).split('.')[-1]},{aggr},{mode}{',scaled' if lhs_rowscale is not None else ''}{',res' if addend is not None else ''}{',act' if act is not None else ''}{',window' if windowed else ''}{',tiled' if tiled else ''}]",
+                              nbytes, e0, e1))
+    return out
+
+
+def seg_triple(out_rows: int, a: Tensor, b: Tensor, c: Tensor, seg_ptr: Optional[Tensor], a_idx: Optional[Tensor],
+               b_idx: Optional[Tensor], c_idx: Optional[Tensor], out_f32: bool = False) -> Tensor:
+    """out[s] = sum_{m in seg s} a[a_idx[m]] * b[b_idx[m]] * c[c_idx[m]]  (2-D operands of one dtype and width);
+    `out_f32`: f32 result for 16-bit operands (first level of a long-segment hierarchy).  `seg_ptr = None`: unit segments
+    (message s belongs to output row s): a plain three-row gather-multiply kernel without the segment machinery."""
+    dev = require_device(a, b, c, seg_ptr, a_idx, b_idx, c_idx)
+    assert a.dim() == b.dim() == c.dim() == 2 and a.shape[1] == b.shape[1] == c.shape[1] and a.dtype == b.dtype == c.dtype
+    a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
+    d = a.shape[1]
+    out = torch.empty((out_rows, d), dtype=torch.float32 if out_f32 else a.dtype, device=dev)
+    timer = LaunchTimer.active
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(dev))
+    check(lib().pygho_seg_triple_product(ptr(out), ptr(a), ptr(b), ptr(c), ptr(seg_ptr), ptr(a_idx), ptr(b_idx), ptr(c_idx),
+                                         out_rows, d, a.shape[0], b.shape[0], c.shape[0], dtype_code(a),
+                                         1 if out_f32 and a.dtype != torch.float32 else 0, stream_ptr(dev)),
+          "seg_triple_product")
+    if timer is not None:
+        e1.record(torch.cuda.current_stream(dev))
+        m = next((i.numel() for i in (a_idx, b_idx, c_idx) if i is not None), a.shape[0])
+        nbytes = (a.element_size() * d * (a.shape[0] + b.shape[0] + c.shape[0] + out_rows)
+                  + 4 * m * sum(i is not None for i in (a_idx, b_idx, c_idx)) + 4 * (out_rows + 1))
+        timer.records.append((f"seg_triple[{str(a.dtype).split('.')[-1]}]", nbytes, e0, e1))
+    return out
+
+
+LONG_SEGMENT = 256      # segments longer than this are reduced hierarchically ...
+LONG_CHUNK = 32         # ... in chunks of this many rows (a lane group walks its chunk sequentially)
+
+
+def seg_sum_f32out(src: Tensor, seg_ptr: Tensor, idx: Optional[Tensor], n_seg: int) -> Tensor:
+    dev = require_device(src, seg_ptr, idx)
+    d = src.shape[1]
+    out = torch.empty((n_seg, d), dtype=torch.float32, device=dev)
+    check(lib().pygho_seg_sum_f32out(ptr(out), ptr(src), ptr(seg_ptr), ptr(idx), n_seg, d, src.shape[0], dtype_code(src),
+                                     stream_ptr(dev)), "seg_sum_f32out")
+    return out
+
+
+def seg_reduce_rows(src: Tensor, plan: SegPlan, aggr: str) -> Tensor:
+    """out[s] = (+)_{m in segment s} src[perm[m]] for a 2-D `src`; long segments go through a hierarchy of
+    bounded chunks (f32 partial sums for 16-bit inputs)."""
+    if plan.m == 0 or plan.max_len <= LONG_SEGMENT:
+        return seg_gmr(plan.n_seg, src, None, plan.seg_ptr, plan.perm, None, aggr)
+    levels = plan.levels(LONG_CHUNK)
+    red = "sum" if aggr == "mean" else aggr
+    sixteen = src.dtype in (torch.bfloat16, torch.float16) and red == "sum" and (src.shape[1] * 2) % 16 == 0
+    n0 = levels[0].numel() - 1
+    if sixteen:
+        cur = seg_sum_f32out(src, levels[0], plan.perm, n0)
+    else:
+        cur = seg_gmr(n0, src, None, levels[0], plan.perm, None, red)
+    for lv in levels[1:]:
+        cur = seg_gmr(lv.numel() - 1, cur, None, lv, None, None, red)
+    if aggr == "mean":
+        cur = cur * plan.inv_count.to(cur.dtype).unsqueeze(-1)
+    return cur.to(src.dtype)
+
+
+def row_gather(src: Tensor, idx32: Tensor, valid: Optional[Tensor] = None) -> Tensor:
+    dev = require_device(src, idx32, valid)
+    src = src.contiguous()
+    n = idx32.numel()
+    tail = src.shape[1:]
+    d = 1
+    for s in tail:
+        d *= s
+    out = torch.empty((n,) + tuple(tail), dtype=src.dtype, device=dev)
+    check(lib().pygho_row_gather(ptr(out), ptr(src), ptr(idx32), ptr(valid), n, d, dtype_code(src), stream_ptr(dev)),
+          "row_gather")
+    return out
+
+
+def _ties(fwd: Tensor, lhs, rhs, seg_ptr, lhs_idx, rhs_idx) -> Tensor:
+    dev = fwd.device
+    ties = torch.empty(fwd.shape, dtype=torch.float32, device=dev)
+    check(lib().pygho_seg_extremum_ties(ptr(ties), ptr(fwd), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx),
+                                        ptr(rhs_idx), fwd.shape[0], fwd.shape[1], dtype_code(fwd), stream_ptr(dev)),
+          "seg_extremum_ties")
+    return ties
+
+
+def _extremum_bwd(n_rows, gin, fwd, ties, self_vals, other, seg_ptr, out_idx, other_idx) -> Tensor:
+    dev = gin.device
+    d = gin.shape[1]
+    gout = torch.empty((n_rows, d), dtype=gin.dtype, device=dev)
+    check(lib().pygho_seg_extremum_bwd(ptr(gout), ptr(gin), ptr(fwd), ptr(ties), ptr(self_vals), ptr(other),
+                                       ptr(seg_ptr), ptr(out_idx), ptr(other_idx), n_rows, d, dtype_code(gin),
+                                       stream_ptr(dev)), "seg_extremum_bwd")
+    return gout
+
+
+# --------------------------------------------------------------------------
+# the message-passing plan of one (acd, n_out) pair
+# --------------------------------------------------------------------------
+class MessagePlan:
+    """int32 / CSR view of an ``acd`` triple array (Spspmm.py:186-222): forward grouping by the
+    output slot `a`, and (lazily, for backward) the transposed groupings by `c` and by `d`."""
+
+    def __init__(self, acd: Tensor, n_out: int, n_lhs: int, n_rhs: int):
+        require_device(acd)
+        assert acd.dim() == 2 and acd.shape[0] == 3, "acd must be (3, M)"
+        self.m = acd.shape[1]
+        self.n_out, self.n_lhs, self.n_rhs = n_out, n_lhs, n_rhs
+        self._a64, self._c64, self._d64 = acd[0], acd[1], acd[2]
+        if self.m > 0:
+            # operand indices must address rows of the operands (the reference's gathers raise IndexError,
+            # Spspmm.py:309-311); the flag rides on the synchronisation of the forward plan's sortedness probe below
+            lo, hi = torch.aminmax(acd[1:3], dim=1)
+            bad = ((lo < 0).any() | (hi[0] >= n_lhs) | (hi[1] >= n_rhs)).to(torch.int32).reshape(1)
+            _PENDING_ERRORS.append((bad, f"pygho_amd: acd operand index out of range (acd[1] must lie in [0, {n_lhs}), "
+                                         f"acd[2] in [0, {n_rhs}))"))
+        self.fwd = plan_from_keys(acd[0], n_out)
+        a32, c32, d32 = narrow_i32(acd[0]), narrow_i32(acd[1]), narrow_i32(acd[2])
+        self.a32, self.c32, self.d32 = a32, c32, d32                 # message order
+        self.c_fwd, self.d_fwd = self.fwd.take(c32), self.fwd.take(d32)   # grouped-by-a order
+        self._by_c = None
+        self._by_d = None
+        self._lookup = None
+
+    @classmethod
+    def from_parts(cls, acd: Tensor, n_out: int, n_lhs: int, n_rhs: int, fwd_ptr: Tensor, ptr_c: Tensor, perm_c: Tensor,
+                   ptr_d: Tensor, perm_d: Tensor) -> "MessagePlan":
+        """the same plan from groupings that already exist (int32 CSR pointers and permutations): a block-diagonal batch's
+        groupings are the concatenation of its graphs' precomputed ones (`collate.DeviceGraphStore`), so no sort and no host
+        synchronisation is needed per batch."""
+        require_device(acd, fwd_ptr, ptr_c, perm_c, ptr_d, perm_d)
+        self = cls.__new__(cls)
+        self.m = acd.shape[1]
+        self.n_out, self.n_lhs, self.n_rhs = n_out, n_lhs, n_rhs
+        self._a64, self._c64, self._d64 = acd[0], acd[1], acd[2]
+        self.fwd = SegPlan(fwd_ptr, None, n_out, self.m)
+        self.a32, self.c32, self.d32 = narrow_i32(acd[0]), narrow_i32(acd[1]), narrow_i32(acd[2])
+        self.c_fwd, self.d_fwd = self.c32, self.d32
+        pc, pd = SegPlan(ptr_c, perm_c, n_lhs, self.m), SegPlan(ptr_d, perm_d, n_rhs, self.m)
+        self._by_c = (pc, pc.take(self.a32), pc.take(self.d32))
+        self._by_d = (pd, pd.take(self.a32), pd.take(self.c32))
+        self._lookup = None
+        return self
+
+    def by_c(self):
+        """(plan, a-in-grouped-order, d-in-grouped-order) for the gradient wrt the first operand."""
+        if self._by_c is None:
+            p = plan_from_keys(self._c64, self.n_lhs, False)         # the acd triples are sorted by a, not by c / d
+            self._by_c = (p, p.take(self.a32), p.take(self.d32))
+        return self._by_c
+
+    def by_d(self):
+        if self._by_d is None:
+            p = plan_from_keys(self._d64, self.n_rhs, False)
+            self._by_d = (p, p.take(self.a32), p.take(self.c32))
+        return self._by_d
+
+    def lookup(self, row_of: Tensor):
+        """for a second operand that equals table[row_of]: the per-message table rows in forward and in by-c order
+        (cached per index tensor object)."""
+        memo = self._lookup
+        if memo is None or memo[0] is not row_of:
+            r32 = narrow_i32(row_of)
+            memo = (row_of, (gather_i32(r32, self.d_fwd), gather_i32(r32, self.by_c()[2])))
+            self._lookup = memo
+        return memo[1]
+
+
+def install_message_plan(acd: Tensor, plan: MessagePlan) -> None:
+    """put a ready plan where `message_plan` will look for it"""
+    cache = getattr(acd, "_pygho_plans", None)
+    if cache is None:
+        cache = {}
+        acd._pygho_plans = cache
+    cache[("msg", plan.n_out, plan.n_lhs, plan.n_rhs, acd._version)] = plan
+
+
+def message_plan(acd: Tensor, n_out: int, n_lhs: int, n_rhs: int) -> MessagePlan:
+    cache = getattr(acd, "_pygho_plans", None)
+    if cache is None:
+        cache = {}
+        try:
+            acd._pygho_plans = cache
+        except Exception:
+            pass
+    k = ("msg", n_out, n_lhs, n_rhs, acd._version)
+    plan = cache.get(k)
+    if plan is None:
+        plan = MessagePlan(acd, n_out, n_lhs, n_rhs)
+        cache[k] = plan
+    return plan
+
+
+class _MessageReduce(torch.autograd.Function):
+    """out[a] = (+) lhs[c] * rhs[d] over the plan; either operand may be None (pattern only)."""
+
+    @staticmethod
+    def forward(ctx, lhs: Optional[Tensor], rhs: Optional[Tensor], plan: MessagePlan, aggr: str, addend: Optional[Tensor] = None):
+        out = seg_gmr(plan.n_out, lhs, rhs, plan.fwd.seg_ptr, plan.c_fwd if lhs is not None else None,
+                      plan.d_fwd if rhs is not None else None, aggr, addend=None if addend is None else addend.contiguous())
+        ctx.plan, ctx.aggr = plan, aggr
+        ctx.has = (lhs is not None, rhs is not None)
+        ctx.save_for_backward(lhs, rhs, out if aggr in ("max", "min") else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        lhs, rhs, fwd = ctx.saved_tensors
+        plan, aggr = ctx.plan, ctx.aggr
+        gout = gout.contiguous()
+        g_lhs = g_rhs = None
+        scale = plan.fwd.inv_count if aggr == "mean" else None
+        ties = None
+        if aggr in ("max", "min"):
+            ties = _ties(fwd, lhs, rhs, plan.fwd.seg_ptr, plan.c_fwd if lhs is not None else None,
+                         plan.d_fwd if rhs is not None else None)
+        if lhs is not None and ctx.needs_input_grad[0]:
+            p, a_g, d_g = plan.by_c()
+            if ties is None:
+                g_lhs = seg_gmr(plan.n_lhs, gout, rhs, p.seg_ptr, a_g, d_g if rhs is not None else None, "sum", scale)
+            else:
+                g_lhs = _extremum_bwd(plan.n_lhs, gout, fwd, ties, lhs, rhs, p.seg_ptr, a_g, d_g)
+        if rhs is not None and ctx.needs_input_grad[1]:
+            p, a_g, c_g = plan.by_d()
+            if ties is None:
+                g_rhs = seg_gmr(plan.n_rhs, gout, lhs, p.seg_ptr, a_g, c_g if lhs is not None else None, "sum", scale)
+            else:
+                g_rhs = _extremum_bwd(plan.n_rhs, gout, fwd, ties, rhs, lhs, p.seg_ptr, a_g, c_g)
+        g_add = gout if len(ctx.needs_input_grad) > 4 and ctx.needs_input_grad[4] else None      # out = addend + reduction
+        return g_lhs, g_rhs, None, None, g_add
+
+
+def _broadcast_dense(a: Optional[Tensor], b: Optional[Tensor]) -> Tuple[Optional[Tensor], Optional[Tensor], Tuple[int, ...]]:
+    """broadcast the dense (trailing) shapes of two value tensors and flatten them to 2-D."""
+    if a is None or b is None:
+        t = a if a is not None else b
+        return (None if a is None else _as2d(a)), (None if b is None else _as2d(b)), tuple(t.shape[1:])
+    if a.dtype != b.dtype:
+        dt = torch.promote_types(a.dtype, b.dtype)
+        a, b = a.to(dt), b.to(dt)
+    if a.shape[1:] == b.shape[1:]:
+        return _as2d(a), _as2d(b), tuple(a.shape[1:])
+    nd = max(a.dim(), b.dim()) - 1
+    sa = (1,) * (nd - (a.dim() - 1)) + tuple(a.shape[1:])
+    sb = (1,) * (nd - (b.dim() - 1)) + tuple(b.shape[1:])
+    dense = torch.broadcast_shapes(sa, sb)
+    a = a.reshape((a.shape[0],) + sa).expand((a.shape[0],) + dense)
+    b = b.reshape((b.shape[0],) + sb).expand((b.shape[0],) + dense)
+    return _as2d(a), _as2d(b), tuple(dense)
+
+
+def message_reduce(lhs: Optional[Tensor], rhs: Optional[Tensor], acd: Tensor, n_out: int, n_lhs: int, n_rhs: int,
+                   aggr: str, addend: Optional[Tensor] = None) -> Tensor:
+    """spspmm value computation (Spspmm.py:307-315) on the HIP path; `addend` (sum / mean, shape of the result): + addend in the
+    kernel's epilogue (a residual connection around the product)."""
+    if lhs is None and rhs is None:
+        raise ValueError("pygho_amd: both operands are pattern-only; nothing to multiply")
+    if aggr not in AGGR_CODE:
+        raise NotImplementedError(f"aggr {aggr!r} is not supported (sum, mean, max, min)")
+    l2, r2, dense = _broadcast_dense(lhs, rhs)
+    plan = message_plan(acd, n_out, n_lhs, n_rhs)
+    if addend is not None:
+        assert aggr in ("sum", "mean") and tuple(addend.shape) == (n_out,) + dense and addend.dtype == (l2 if l2 is not None else r2).dtype
+        out = _MessageReduce.apply(l2, r2, plan, aggr, _as2d(addend))
+    else:
+        out = _MessageReduce.apply(l2, r2, plan, aggr)
+    return out.reshape((n_out,) + dense)
+
+
+# --------------------------------------------------------------------------
+# scatter / segment reduce and gather
+# --------------------------------------------------------------------------
+class _ScatterReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src: Tensor, plan: SegPlan, ind32: Tensor, aggr: str):
+        out = seg_reduce_rows(src, plan, aggr)
+        ctx.plan, ctx.aggr, ctx.ind32 = plan, aggr, ind32
+        ctx.save_for_backward(*((src, out) if aggr in ("max", "min") else ()))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        plan, aggr, ind32 = ctx.plan, ctx.aggr, ctx.ind32
+        gout = gout.contiguous()
+        if aggr == "sum":
+            return row_gather(gout, ind32), None, None, None
+        if aggr == "mean":
+            scaled = gout * plan.inv_count.to(gout.dtype).unsqueeze(-1)
+            return row_gather(scaled, ind32), None, None, None
+        src, fwd = ctx.saved_tensors
+        ties = _ties(fwd, src, None, plan.seg_ptr, plan.perm, None)
+        up = unit_ptr(src.shape[0], src.device)
+        return _extremum_bwd(src.shape[0], gout, fwd, ties, src, None, up, ind32, None), None, None, None
+
+
+def scatter_reduce(src: Tensor, ind: Tensor, dim_size: int, aggr: str) -> Tensor:
+    """torch_scatter_reduce(dim=0) (utils.py:44-56) on the HIP path."""
+    require_device(src, ind)
+    if aggr not in AGGR_CODE:
+        raise NotImplementedError(f"aggr {aggr!r} is not supported (sum, mean, max, min)")
+    assert ind.dim() == 1, "indice must be 1-d"
+    assert src.shape[0] == ind.shape[0], "src and index length differ"
+    plan = cached_plan(ind, dim_size, "scatter")
+    tail = tuple(src.shape[1:])
+    src2 = _as2d(src) if src.dim() > 1 else src.contiguous().reshape(-1, 1)
+    out = _ScatterReduce.apply(src2, plan, narrow_i32(ind), aggr)
+    return out.reshape((dim_size,) + tail)
+
+
+def scatter_reduce_planned(src: Tensor, plan: SegPlan, ind32: Tensor, aggr: str) -> Tensor:
+    """scatter-reduce along a prebuilt plan (coalesce / sparse pooling)."""
+    if aggr not in AGGR_CODE:
+        raise NotImplementedError(f"aggr {aggr!r} is not supported (sum, mean, max, min)")
+    tail = tuple(src.shape[1:])
+    src2 = _as2d(src) if src.dim() > 1 else src.contiguous().reshape(-1, 1)
+    out = _ScatterReduce.apply(src2, plan, ind32, aggr)
+    return out.reshape((plan.n_seg,) + tail)
+
+
+class _RowGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src: Tensor, ind: Tensor):
+        ctx.ind, ctx.n = ind, src.shape[0]
+        return row_gather(src, narrow_i32(ind))
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        ind = ctx.ind
+        plan = cached_plan(ind, ctx.n, "scatter")
+        g2 = _as2d(gout) if gout.dim() > 1 else gout.contiguous().reshape(-1, 1)
+        g = seg_reduce_rows(g2, plan, "sum")
+        return g.reshape((ctx.n,) + tuple(gout.shape[1:])), None
+
+
+def gather_rows(src: Tensor, ind: Tensor) -> Tensor:
+    """src[ind] along dim 0 (SpTensor.py:476) with a segment-reduce backward."""
+    require_device(src, ind)
+    return _RowGather.apply(src, ind)
+
+
+class _MaskedRowGather(torch.autograd.Function):
+    """out[r] = pos[r] >= 0 ? src[pos[r]] : 0   (diag / sparse unpooling)."""
+
+    @staticmethod
+    def forward(ctx, src: Tensor, pos: Tensor):
+        valid = (pos >= 0).to(_I32)
+        idx = narrow_i32(pos.clamp_min(0))
+        ctx.pos, ctx.n = pos, src.shape[0]
+        return row_gather(src, idx, valid)
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        pos, n = ctx.pos, ctx.n
+        cache = getattr(pos, "_pygho_plans", None)
+        if cache is None:
+            cache = {}
+            try:
+                pos._pygho_plans = cache
+            except Exception:
+                pass
+        k = ("spill", n, pos._version)
+        if k not in cache:
+            keys = torch.where(pos >= 0, pos, torch.full_like(pos, n))      # misses go to a spill segment
+            cache[k] = plan_from_keys(keys, n + 1)
+        plan = cache[k]
+        g2 = _as2d(gout) if gout.dim() > 1 else gout.contiguous().reshape(-1, 1)
+        g = seg_reduce_rows(g2, plan, "sum")[:n]
+        return g.reshape((n,) + tuple(gout.shape[1:])), None
+
+
+def gather_rows_matched(src: Tensor, pos: Tensor) -> Tensor:
+    require_device(src, pos)
+    return _MaskedRowGather.apply(src, pos)
+
+
+# --------------------------------------------------------------------------
+# node-level sparse x dense
+# --------------------------------------------------------------------------
+class _Spmm(torch.autograd.Function):
+    """out[t] = (+)_e val[e] * X[src[e]] grouped by tar[e]   (Spmm.py:31-44)."""
+
+    @staticmethod
+    def forward(ctx, val: Optional[Tensor], X: Tensor, src: Tensor, tar: Tensor, n_tar: int, aggr: str):
+        plan = cached_plan(tar, n_tar, "scatter")
+        src32, tar32 = narrow_i32(src), narrow_i32(tar)
+        src_g = plan.take(src32)
+        out = seg_gmr(n_tar, val, X, plan.seg_ptr, plan.perm if val is not None else None, src_g, aggr)
+        ctx.meta = (plan, src, src32, tar32, src_g, n_tar, aggr)
+        ctx.save_for_backward(val, X, out if aggr in ("max", "min") else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        val, X, fwd = ctx.saved_tensors
+        plan, src, src32, tar32, src_g, n_tar, aggr = ctx.meta
+        gout = gout.contiguous()
+        e = src32.numel()
+        g_val = g_x = None
+        scale = plan.inv_count if aggr == "mean" else None
+        ties = None
+        if aggr in ("max", "min"):
+            ties = _ties(fwd, val, X, plan.seg_ptr, plan.perm if val is not None else None, src_g)
+        if val is not None and ctx.needs_input_grad[0]:
+            up = unit_ptr(e, gout.device)
+            if ties is None:
+                g_val = seg_gmr(e, gout, X, up, tar32, src32, "sum", scale)
+            else:
+                g_val = _extremum_bwd(e, gout, fwd, ties, val, X, up, tar32, src32)
+        if ctx.needs_input_grad[1]:
+            p = cached_plan(src, X.shape[0], "scatter")
+            tar_g = p.take(tar32)
+            if ties is None:
+                g_x = seg_gmr(X.shape[0], gout, val, p.seg_ptr, tar_g, p.perm if val is not None else None, "sum", scale)
+            else:
+                eid = p.perm if p.perm is not None else torch.arange(e, dtype=_I32, device=gout.device)
+                g_x = _extremum_bwd(X.shape[0], gout, fwd, ties, X, val, p.seg_ptr, tar_g, eid)
+        return g_val, g_x, None, None, None, None
+
+
+def spmm_values(val: Optional[Tensor], X: Tensor, src: Tensor, tar: Tensor, n_tar: int, aggr: str) -> Tensor:
+    require_device(val, X, src, tar)
+    if aggr not in AGGR_CODE:
+        raise NotImplementedError(f"aggr {aggr!r} is not supported (sum, mean, max, min)")
+    if val is not None:
+        v2, x2, dense = _broadcast_dense(val, X)
+    else:
+        v2, x2, dense = None, _as2d(X) if X.dim() > 1 else X.reshape(-1, 1), tuple(X.shape[1:])
+    out = _Spmm.apply(v2, x2, src, tar, n_tar, aggr)
+    return out.reshape((n_tar,) + dense)
+
+
+class _PairProduct(torch.autograd.Function):
+    """out[t] = (left[row[t]] * right[col[t]]) * val[vidx[t]] (vidx None = t): the tuple initialisation of
+    example/minimal.py:62-67 (two unpoolings of node features onto the tuple pattern and two elementwise products; with
+    `vidx` also the embedding lookup of the tuple feature, example/minimal.py:30-33) as ONE pass; the three operand
+    gradients are the same three-operand kernel over the unit / by-row / by-col / by-feature groupings of the tuples."""
+
+    @staticmethod
+    def forward(ctx, left, right, val, row32, col32, vidx32, by_row, by_col, by_val):
+        n = row32.numel()
+        unit_ok = USE_UNIT_TRIPLE and (left.shape[1] * left.element_size()) % 16 == 0 and left.shape[1] * left.element_size() <= 1024 \
+            and left.dtype in (torch.float32, torch.bfloat16, torch.float16)
+        out = seg_triple(n, left, right, val, None if unit_ok else unit_ptr(n, val.device), row32, col32, vidx32)
+        ctx.save_for_backward(left, right, val)
+        ctx.idx = (row32, col32, vidx32, by_row, by_col, by_val)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        left, right, val = ctx.saved_tensors
+        row32, col32, vidx32, by_row, by_col, by_val = ctx.idx
+        g = g.contiguous()
+        n = row32.numel()
+        g_left = g_right = g_val = None
+        if ctx.needs_input_grad[0]:
+            p, col_p, v_p = by_row
+            g_left = seg_triple(p.n_seg, g, val, right, p.seg_ptr, p.perm, v_p if vidx32 is not None else p.perm, col_p)
+        if ctx.needs_input_grad[1]:
+            p, row_p, v_p = by_col
+            g_right = seg_triple(p.n_seg, g, val, left, p.seg_ptr, p.perm, v_p if vidx32 is not None else p.perm, row_p)
+        if ctx.needs_input_grad[2]:
+            if vidx32 is None:
+                g_val = seg_triple(n, g, left, right, unit_ptr(n, g.device), None, row32, col32)
+            else:
+                # gradient of the (small) table: a handful of very long segments -> chunked f32 partial sums, then a tree
+                p, row_p, col_p = by_val
+                levels = p.levels(LONG_CHUNK) if p.max_len > LONG_SEGMENT else [p.seg_ptr]
+                cur = seg_triple(levels[0].numel() - 1, g, left, right, levels[0], p.perm, row_p, col_p, out_f32=len(levels) > 1)
+                for lv in levels[1:]:
+                    cur = seg_gmr(lv.numel() - 1, cur, None, lv, None, None, "sum")
+                g_val = cur.to(val.dtype)
+        return g_left, g_right, g_val, None, None, None, None, None, None
+
+
+def _grouped(plan: SegPlan, key, *idx32):
+    """index arrays re-ordered into the plan's grouped order, memoised on the plan object."""
+    memo = plan._partner                     # `key`: the index tensor OBJECTS (kept alive by the memo, compared by identity)
+    if memo is None or len(memo[0]) != len(key) or any(a is not b for a, b in zip(memo[0], key)):
+        memo = (key, tuple(None if i is None else plan.take(i) for i in idx32))
+        plan._partner = memo
+    return memo[1]
+
+
+def pair_product(left: Tensor, right: Tensor, val: Tensor, row: Tensor, col: Tensor, val_index: Optional[Tensor] = None) -> Tensor:
+    """``left[row] * right[col] * val`` for (n_rows, d) / (n_cols, d) node features and (nnz, d) tuple values -- or, with
+    `val_index`, ``... * val[val_index]`` for a small (n_types, d) table.  `row` / `col` / `val_index` are persistent
+    int64 index arrays of the tuple pattern (plans are cached on them)."""
+    require_device(left, right, val, row, col, val_index)
+    assert left.dim() == right.dim() == val.dim() == 2
+    row32, col32 = narrow_i32(row), narrow_i32(col)
+    vidx32 = None if val_index is None else narrow_i32(val_index)
+    key = (row32, col32, vidx32)
+    p_row = cached_plan(row, left.shape[0], "pair-row")
+    p_col = cached_plan(col, right.shape[0], "pair-col", assume_sorted=False)
+    by_row = (p_row,) + _grouped(p_row, key, col32, vidx32)
+    by_col = (p_col,) + _grouped(p_col, key, row32, vidx32)
+    by_val = None
+    if val_index is not None:
+        p_val = cached_plan(val_index, val.shape[0], "pair-val", assume_sorted=False)
+        by_val = (p_val,) + _grouped(p_val, key, row32, col32)
+    return _PairProduct.apply(left, right, val, row32, col32, vidx32, by_row, by_col, by_val)

@@ -502,6 +502,25 @@ def test_pair_views_gradient_one_pass(dev):
     np.testing.assert_allclose(N(xd.grad), xr.grad.numpy(), rtol=1e-6, atol=1e-6)
 
 
+def test_spmamm_vs_reference_fixture(dev):
+    """spmamm in the configuration the reference itself can run (scalar adjacency values / value-less A, no dense dims, pre-filled
+    MaskedTensor, explicit output mask): HIP path against outputs of the reference (tests/golden/spmamm.npz)."""
+    from conftest import load_golden
+    from pygho_amd import MaskedTensor, SparseTensor
+    from pygho_amd.backend.Spmamm import spmamm
+    g = load_golden("spmamm.npz")
+    shape = [int(v) for v in g["shapeA"]]
+    for dim1 in (1, 2):
+        for dim2 in (1, 2):
+            tag = f"dim1_{dim1}_dim2_{dim2}"
+            B = MaskedTensor(T(g["B_" + tag], dev), T(g["Bmask_" + tag], dev), 0.0, True)
+            om = T(g["omask_" + tag], dev)
+            for av, key in ((T(g["Aval"], dev), "sum_"), (None, "sum_novalue_")):
+                out = spmamm(SparseTensor(T(g["ind"], dev), av, shape, True), dim1, B, dim2, om, "sum")
+                assert torch.equal(out.mask, om)
+                np.testing.assert_allclose(N(out.raw), g[key + tag], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("aggr", ["sum", "max", "min"])
 @pytest.mark.parametrize("dim1", [1, 2])
 def test_spmamm_vs_oracle_and_einsum(dev, aggr, dim1):
