@@ -15,11 +15,13 @@ through the C ABI and no entry point synchronises or allocates, so a step on sta
 * the optimizer is created with ``capturable=True``; gradients are reset with ``set_to_none=True`` inside the step;
 * no host read-back (``.item()``, ``print(loss)``) inside the step -- return tensors and read them after ``replay()``.
 
-Several captured steps (one per fixed mini-batch, ``examples/minimal.py``): a caveat of this PyTorch 2.10 / ROCm 7.2 build, not of
-the kernels here -- with four or more captured steps sharing one capturable AdamW, an EAGER kernel launched between replays
-(even ``torch.full((1,), 7.0)``) makes later replays return NaN unless ``torch.cuda.synchronize()`` (device-wide; a stream
-synchronisation is not enough) runs after it.  Reproduced with a plain ``torch.nn.Sequential`` model; form statistics on the host
-(``float(loss)``) or synchronise the device after eager work, before the next ``replay()``.
+Several captured steps (one per fixed mini-batch, ``examples/minimal.py``): with four or more captured SpModel steps sharing one
+capturable AdamW, an EAGER kernel launched between replays made later replays return NaN in round 2 unless
+``torch.cuda.synchronize()`` (device-wide; a stream synchronisation was not enough) ran after it; ``examples/minimal.py`` therefore
+forms its statistics on the host (``float(loss)``).  Round 2 attributed this to the PyTorch 2.10 / ROCm 7.2 build; the plain
+``torch.nn`` reduction committed as ``tools/repro_graph_nan.py`` does NOT show it on this build (0 non-finite losses of 120 with
+2, 4 and 6 captured steps, with and without the synchronisation), so the cause is not pinned down -- it may as well lie in how
+this package's step interacts with capture.  Keep the device synchronisation after eager work between replays until it is.
 """
 from typing import Any, Callable, Iterable
 

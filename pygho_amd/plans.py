@@ -262,6 +262,20 @@ def cached_plan(keys: Tensor, n_seg: int, tag: str = "", assume_sorted: Optional
 # --------------------------------------------------------------------------
 # integer planner primitives
 # --------------------------------------------------------------------------
+def row_gather(src: Tensor, idx32: Tensor, valid: Optional[Tensor] = None) -> Tensor:
+    dev = require_device(src, idx32, valid)
+    src = src.contiguous()
+    n = idx32.numel()
+    tail = src.shape[1:]
+    d = 1
+    for s in tail:
+        d *= s
+    out = torch.empty((n,) + tuple(tail), dtype=src.dtype, device=dev)
+    check(lib().pygho_row_gather(ptr(out), ptr(src), ptr(idx32), ptr(valid), n, d, dtype_code(src), stream_ptr(dev)),
+          "row_gather")
+    return out
+
+
 def hash_pack(ind: Tensor, validate: bool = True) -> Tensor:
     """indicehash (SpTensor.py:10-44) on the device."""
     dev = require_device(ind)
@@ -336,7 +350,6 @@ def unique_sorted(sorted_keys: Tensor) -> Tuple[Tensor, Tensor, int]:
     n_runs = int(cnt.item())
     if n:
         plan = plan_from_keys(run.to(torch.int64), n_runs, assume_sorted=True)
-        from .segment import row_gather            # the launch wrappers sit one layer up
         uniq = row_gather(sorted_keys.reshape(-1, 1), plan.seg_ptr[:-1].contiguous()).reshape(-1)
     else:
         uniq = sorted_keys

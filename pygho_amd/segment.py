@@ -271,20 +271,6 @@ def seg_reduce_rows(src: Tensor, plan: SegPlan, aggr: str) -> Tensor:
     return cur.to(src.dtype)
 
 
-def row_gather(src: Tensor, idx32: Tensor, valid: Optional[Tensor] = None) -> Tensor:
-    dev = require_device(src, idx32, valid)
-    src = src.contiguous()
-    n = idx32.numel()
-    tail = src.shape[1:]
-    d = 1
-    for s in tail:
-        d *= s
-    out = torch.empty((n,) + tuple(tail), dtype=src.dtype, device=dev)
-    check(lib().pygho_row_gather(ptr(out), ptr(src), ptr(idx32), ptr(valid), n, d, dtype_code(src), stream_ptr(dev)),
-          "row_gather")
-    return out
-
-
 def _ties(fwd: Tensor, lhs, rhs, seg_ptr, lhs_idx, rhs_idx) -> Tensor:
     dev = fwd.device
     ties = torch.empty(fwd.shape, dtype=torch.float32, device=dev)

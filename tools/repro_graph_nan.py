@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Reproducer for the caveat in pygho_amd/graphs.py (PyTorch 2.10 / ROCm 7.2, no pygho_amd code involved): N captured training
-steps (one per fixed mini-batch) sharing ONE capturable AdamW; an eager kernel launched between replays makes later replays
-return NaN unless the DEVICE is synchronised after it.     python tools/repro_graph_nan.py [n_graphs=4] [sync=0|1]"""
+"""Plain-torch reduction of the caveat in pygho_amd/graphs.py (no pygho_amd code involved): N captured training steps (one per fixed
+mini-batch) sharing ONE capturable AdamW, an eager kernel launched between replays.  Result on PyTorch 2.10 / ROCm 7.2, MI355X
+(round 3): 0 non-finite losses with 2 / 4 / 6 captured steps, with and without a device synchronisation -- this reduction does
+NOT reproduce the NaN seen with the captured SpModel steps.     python tools/repro_graph_nan.py [n_graphs=4] [sync=0|1]"""
 import sys
 import torch
 
