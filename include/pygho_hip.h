@@ -102,15 +102,17 @@ int pygho_seg_gather_mul_reduce_window(void* out, const void* addend, const void
                                        const float* lhs_rowscale, int64_t n_seg, int64_t d, int64_t lhs_rows,
                                        int64_t rhs_rows, int dtype, int aggr, void* stream);
 
-/* The same two-operand sum / mean reduction (addend may be NULL) with ONE WAVEFRONT PER TILE of consecutive segments: the 64 lanes
- * cover one row (row bytes 256, 512 or 1024), every message is wavefront-uniform, and the lhs rows a tile gathers -- the window
- * [row0, row0 + rows) recorded by pygho_seg_tile_plan: the (i, j) group of the 3-tuple product X(i,j,k') A(k',k), the root block of a
- * 2-tuple product (Spspmm.py:307-315) -- are copied ONCE into the wavefront's LDS slice and gathered from there; lhs rows outside the
- * window and all rhs rows come through L1 / L2.  Both index arrays are required.  Bit-identical to pygho_seg_gather_mul_reduce(_add)
- * (same products, same summation order).
+/* The same two-operand sum / mean reduction (addend may be NULL) with ONE WAVEFRONT PER TILE of consecutive segments (row bytes 256,
+ * 512 or 1024): the lhs rows a tile gathers -- the window [row0, row0 + rows) recorded by pygho_seg_tile_plan: the (i, j) group of
+ * the 3-tuple product X(i,j,k') A(k',k), the root block of a 2-tuple product (Spspmm.py:307-315) -- are copied ONCE into the
+ * wavefront's LDS slice and gathered from there; rhs rows come through L1 / L2.  Inside a tile the wavefront works as 64 / (row
+ * bytes / 16) streams of 16-byte lanes, each walking its share of the tile's segments in message order.  Both index arrays are
+ * required.  Bit-identical to pygho_seg_gather_mul_reduce(_add) (same products, same summation order per segment).
  *   tile_cnt : (ceil(n_seg / pygho_seg_tile_chunk()))      tiles per chunk of consecutive segments
- *   tiles    : (that many chunks x chunk x 4) int32        per tile (first segment in chunk | segments << 8 | window rows << 16,
- *                                                          first window row, first message, messages); window rows = 0: a tile
+ *   tiles    : (that many chunks x chunk x 8) int32        per tile (first segment in chunk | segments << 8 | window rows << 16,
+ *                                                          first window row, first message, messages) and the quarter
+ *                                                          boundaries of its segments by message count (s1 | s2 << 8 | s3 << 16
+ *                                                          as segment offsets, three message offsets); window rows = 0: a tile
  *                                                          without messages, or ONE segment whose lhs rows do not fit a window
  *                                                          (gathered from global memory)
  * pygho_seg_tile_plan fills both from (seg_ptr, lhs_idx): a pure function of the index arrays, built once per plan (the reference

@@ -94,8 +94,8 @@ def _window_eligible(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor]
             and 2 * rhs.shape[0] <= out_rows and out_rows >= 4096 and max(out_rows, lhs.shape[0]) * rb < (1 << 32))
 
 
-SEG_TILE = os.environ.get("PYGHO_SEG_TILE", "0")            # "0": never, "1": whenever the shape allows, "auto": by plan shape
-SEG_TILE_WIN_ROWS = int(os.environ.get("PYGHO_SEG_TILE_WIN_ROWS", "32"))
+SEG_TILE = os.environ.get("PYGHO_SEG_TILE", "auto")            # "0": never, "1": whenever the shape allows, "auto": by plan shape
+SEG_TILE_WIN_ROWS = int(os.environ.get("PYGHO_SEG_TILE_WIN_ROWS", "24"))
 
 
 def tile_plan(seg_ptr: Tensor, lhs_idx: Tensor, n_seg: int, win_rows: int):
@@ -115,7 +115,7 @@ def tile_plan(seg_ptr: Tensor, lhs_idx: Tensor, n_seg: int, win_rows: int):
         chunk = int(lib().pygho_seg_tile_chunk())
         n_chunks = (n_seg + chunk - 1) // chunk
         tile_cnt = torch.empty(n_chunks, dtype=_I32, device=dev)
-        tiles = torch.empty((n_chunks, chunk, 4), dtype=_I32, device=dev)
+        tiles = torch.empty((n_chunks, chunk, 8), dtype=_I32, device=dev)
         check(lib().pygho_seg_tile_plan(ptr(tile_cnt), ptr(tiles), ptr(seg_ptr), ptr(lhs_idx), n_seg, win_rows, stream_ptr(dev)),
               "seg_tile_plan")
         hit = (tile_cnt, tiles, seg_ptr)            # the pointers are kept alive with the entry that is keyed on their address
@@ -124,18 +124,22 @@ def tile_plan(seg_ptr: Tensor, lhs_idx: Tensor, n_seg: int, win_rows: int):
 
 
 def _tile_eligible(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], lhs_idx: Optional[Tensor], rhs_idx: Optional[Tensor],
-                   aggr: str) -> bool:
+                   aggr: str, scaled: bool = False, residual: bool = False) -> bool:
     """two-operand sum / mean with both index arrays and rows of 256 / 512 / 1024 bytes (`pygho_seg_gather_mul_reduce_tiled`)."""
     if SEG_TILE == "0" or lhs is None or rhs is None or lhs_idx is None or rhs_idx is None or aggr not in ("sum", "mean"):
         return False
     rb = lhs.shape[1] * lhs.element_size()
     if rb not in (256, 512, 1024) or lhs.dtype not in (torch.float32, torch.bfloat16, torch.float16) or out_rows < 4096:
         return False
+    if (scaled and (residual or aggr != "sum")) or max(out_rows, lhs.shape[0], rhs.shape[0]) * rb >= (1 << 32) or lhs_idx.numel() == 0:
+        return False
     if SEG_TILE == "1":
         return True
-    # auto: the plans whose segments gather lhs rows of one narrow block (forward and by-tuple backward of the tuple products);
-    # the by-edge backward plan (few long segments over rows spread across a graph) stays on the window kernel
-    return rb >= 512 and 2 * rhs.shape[0] <= out_rows
+    # auto: plans whose segments re-use the lhs rows of one narrow block several times -- forward and by-tuple backward of the 3-tuple
+    # product (3.4 messages per output row, 512-B rows: 0.72-0.75 ms against 0.78-0.80 ms on the window kernel at 2048 I2 graphs).
+    # Two messages per row (the 2-tuple plans) or 256-B rows gain nothing over the fast kernel; the by-edge backward plan (few long
+    # segments over rows spread across a graph) stays on the window kernel
+    return rb >= 512 and 2 * rhs.shape[0] <= out_rows and 2 * lhs_idx.numel() >= 5 * out_rows
 
 
 def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr: Tensor,
@@ -169,7 +173,7 @@ def seg_gmr(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr
             ptr(out), ptr(addend), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), ptr(lhs_rowscale),
             ptr(a_scale.contiguous()), ptr(a_shift.contiguous()), ACT_CODE[a_name], a_side, out_rows, d, lhs.shape[0], rhs.shape[0],
             dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev)), "seg_gather_mul_reduce_act")
-    elif _tile_eligible(out_rows, lhs, rhs, lhs_idx, rhs_idx, aggr):
+    elif _tile_eligible(out_rows, lhs, rhs, lhs_idx, rhs_idx, aggr, lhs_rowscale is not None, addend is not None):
         tiled = True
         if addend is not None:
             assert addend.shape == out.shape and addend.dtype == out.dtype and addend.is_contiguous()

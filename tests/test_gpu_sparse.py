@@ -453,6 +453,71 @@ def test_baseline_size_elementwise_vs_host_oracle(dev, kind, graphs, d, key, dty
         del xg, ag, out
 
 
+@pytest.mark.parametrize("kind,d,dtype", [("i2", 256, torch.bfloat16), ("i2", 128, torch.bfloat16), ("i2", 128, torch.float32),
+                                          ("i2", 256, torch.float32), ("zinc", 128, torch.float32), ("i2", 256, torch.float16)])
+def test_tile_kernel_bit_identical_to_fast_kernel(dev, kind, d, dtype):
+    """`pygho_seg_gather_mul_reduce_tiled` (one wavefront per tile, lhs window in LDS, 1 / 2 / 4 streams per wavefront for 1024 / 512 /
+    256-B rows) against the fast kernel on the forward, by-tuple and by-edge plans: sum, mean, sum with a per-row scale (the mean's
+    gradient plans) and sum / mean with a residual row -- the same bits.  The plans are the shipped ones plus a doctored copy with
+    empty segments at both ends and in the middle, one segment whose lhs rows span more than any window (an irregular tile) and
+    one very long segment (more messages than a stream's index vector holds)."""
+    from pygho_amd import _ops, synth
+    key = "X___X___1___A___0" if kind == "zinc" else "X___X___2___A___0"
+    hb = synth.make_batch(48 if kind == "zinc" else 8, kind, seed=5)
+    acd = T(hb.acd[key], dev)
+    nt, ne = hb.num_tuples, hb.num_edges
+    assert nt >= 4096
+    # doctored plan: drop the messages of a few output rows (empty segments), send one row's messages to far-apart lhs rows, and give
+    # one row 300 messages
+    a, c, dd = acd[0].clone(), acd[1].clone(), acd[2].clone()
+    keep = ~((a < 3) | (a == 1000) | (a == 1001) | (a >= nt - 2))
+    a, c, dd = a[keep], c[keep], dd[keep]
+    wide = a == 2000
+    c[wide] = torch.linspace(0, nt - 1, int(wide.sum()), device=dev).long()
+    extra = 300
+    ins = int(torch.searchsorted(a, torch.tensor(3000, device=dev)))
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    c_long = (int(c[ins]) + torch.randint(0, 8, (extra,), generator=gen)).clamp_max(nt - 1).to(dev)
+    d_long = torch.randint(0, ne, (extra,), generator=gen).to(dev)
+    a2 = torch.cat((a[:ins], torch.full((extra,), 3000, device=dev), a[ins:]))
+    c2 = torch.cat((c[:ins], c_long, c[ins:]))
+    d2 = torch.cat((dd[:ins], d_long, dd[ins:]))
+    acd_doc = torch.stack((a2, c2, d2)).contiguous()
+    torch.manual_seed(0)
+    x = torch.randn(nt, d, device=dev).to(dtype)
+    av = torch.randn(ne, d, device=dev).to(dtype)
+    g = torch.randn(nt, d, device=dev).to(dtype)
+    res = torch.randn(nt, d, device=dev).to(dtype)
+    saved = (_ops.SEG_TILE, _ops.SEG_TILE_WIN_ROWS)
+    try:
+        for plan_acd in (acd, acd_doc):
+            plan = _ops.message_plan(plan_acd, nt, nt, ne)
+            pc, a_c, d_c = plan.by_c()
+            pd, a_d, c_d = plan.by_d()
+            scale = plan.fwd.inv_count
+            calls = [("forward sum", nt, x, av, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, "sum", None, None),
+                     ("forward mean", nt, x, av, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, "mean", None, None),
+                     ("forward sum + residual", nt, x, av, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, "sum", None, res),
+                     ("forward mean + residual", nt, x, av, plan.fwd.seg_ptr, plan.c_fwd, plan.d_fwd, "mean", None, res),
+                     ("by-tuple backward", nt, g, av, pc.seg_ptr, a_c, d_c, "sum", None, None),
+                     ("by-tuple backward of a mean", nt, g, av, pc.seg_ptr, a_c, d_c, "sum", scale, None),
+                     ("by-edge backward", ne, g, x, pd.seg_ptr, a_d, c_d, "sum", None, None)]
+            for name, n, lhs, rhs, sp, li, ri, aggr, sc, add in calls:
+                if n < 4096:
+                    continue
+                outs = {}
+                for mode, win in (("0", 24), ("1", 24), ("1", 32)):
+                    _ops.SEG_TILE, _ops.SEG_TILE_WIN_ROWS = mode, win
+                    addend = None if add is None else add[:n].contiguous()
+                    outs[(mode, win)] = _ops.seg_gmr(n, lhs, rhs, sp, li, ri, aggr, sc, addend)
+                ref = outs[("0", 24)]
+                view = torch.int16 if ref.element_size() == 2 else torch.int32
+                for k, o in outs.items():
+                    assert torch.equal(o.view(view), ref.view(view)), f"{kind} d={d} {dtype} {name}: tiled (window {k[1]}) differs from the fast kernel"
+    finally:
+        _ops.SEG_TILE, _ops.SEG_TILE_WIN_ROWS = saved
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_long_segments_hierarchical(dev, dtype):
     """a 4-row table receiving 300k rows (the embedding-backward shape): hierarchical chunks, f32 partials"""
