@@ -188,7 +188,14 @@ def ptr(t: Optional[torch.Tensor]):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device: torch.device):
+    """torch's current stream on `device` as the raw hipStream_t the C ABI takes (the private raw getter when this torch has it:
+    0.2 us instead of the 1.9 us it takes to build a torch.cuda.Stream object per launch)"""
+    if _raw_stream is not None:
+        return c_void_p(_raw_stream(device.index if device.index is not None else torch.cuda.current_device()))
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

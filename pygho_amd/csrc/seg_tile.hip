@@ -276,8 +276,12 @@ __global__ __launch_bounds__(kTileWaves * kWave, tile_occupancy(LPR, WROWS, SCAL
     const int n1k = __builtin_amdgcn_readfirstlane((rows * (int)ROWB + 1023) >> 10);
 #pragma unroll
     for (int j = 0; j < WCH; ++j) {
+#ifdef PYGHO_TILE_KO_STAGE
+      if (j < n1k) { pre[j] = u32x4{}; asm volatile("" : "+v"(pre[j]) : "s"(d0.y + j)); }
+#else
       if (j < n1k)
         pre[j] = __builtin_amdgcn_raw_buffer_load_b128(lres, (int)(lane * 16), __builtin_amdgcn_readfirstlane((int)((uint32_t)d0.y * ROWB + (uint32_t)j * 1024u)), 0);
+#endif
     }
   };
 
@@ -309,7 +313,14 @@ __global__ __launch_bounds__(kTileWaves * kWave, tile_occupancy(LPR, WROWS, SCAL
     int seg = sa;                                         // its current segment (index within the tile)
     int seg_beg = ma;
     *reinterpret_cast<int*>(s_rows + (sp_off + lane * 4)) = sp_c;
-    int seg_end = seg < sb - 1 ? *reinterpret_cast<const int*>(s_rows + (sp_off + (uint32_t)seg * 4u)) : kNoEnd;
+    // end of segment j of this stream as the flush sees it: the pointer for all but the stream's last segment (closed by the stream's
+    // end).  The end of the NEXT segment is fetched one flush ahead, so a flush never waits for its LDS read.
+    auto seg_end_of = [&](int j) -> int {
+      const int v = *reinterpret_cast<const int*>(s_rows + (sp_off + (uint32_t)min(j, kTileSegCap - 1) * 4u));
+      return j < sb - 1 ? v : kNoEnd;
+    };
+    int seg_end = seg_end_of(seg);
+    int seg_nx = seg_end_of(seg + 1);
     float acc[N];
 #pragma unroll
     for (int q = 0; q < N; ++q) acc[q] = 0.f;
@@ -331,12 +342,17 @@ __global__ __launch_bounds__(kTileWaves * kWave, tile_occupancy(LPR, WROWS, SCAL
 #pragma unroll
         for (int q = 0; q < N; ++q) acc[q] = rv[q] + acc[q];
       }
+#ifdef PYGHO_TILE_KO_STORE
+      if (seg < -1) __builtin_amdgcn_raw_buffer_store_b128(L16::pack(acc), ores, (int)voff, 0, 0);
+#else
       __builtin_amdgcn_raw_buffer_store_b128(L16::pack(acc), ores, (int)voff, 0, 0);
+#endif
 #pragma unroll
       for (int q = 0; q < N; ++q) acc[q] = 0.f;
       ++seg;
       seg_beg = this_end;
-      seg_end = seg < sb - 1 ? *reinterpret_cast<const int*>(s_rows + (sp_off + (uint32_t)seg * 4u)) : kNoEnd;
+      seg_end = seg_nx;
+      seg_nx = seg_end_of(seg + 1);
     };
     auto accumulate = [&](const u32x4& lv, const u32x4& rv, float sc) {
       float a[N], b[N];
@@ -363,7 +379,12 @@ __global__ __launch_bounds__(kTileWaves * kWave, tile_occupancy(LPR, WROWS, SCAL
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int ri = __builtin_amdgcn_ds_bpermute((int)(b4 + 4u * u), ri_c);
+#ifdef PYGHO_TILE_KO_RHS
+        rv[u] = u32x4{};
+        asm volatile("" : "+v"(rv[u]) : "v"(ri));
+#else
         rv[u] = __builtin_amdgcn_raw_buffer_load_b128(rres, (int)((uint32_t)ri * ROWB + coff), 0, 0);
+#endif
       }
     };
     // the U trips of a batch: lhs rows from the LDS window (G at a time), products accumulated per stream in message order
@@ -374,15 +395,24 @@ __global__ __launch_bounds__(kTileWaves * kWave, tile_occupancy(LPR, WROWS, SCAL
         if (SCALED) sc_c = __float_as_int(lhs_rowscale[li_c]);
       }
       const uint32_t b4 = hb4 + (uint32_t)(t % LPR) * 4u;
+      int lis[U];
+      float scs[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {                       // the batch's lhs indices (and row scales) cross the lanes together
+        lis[u] = __builtin_amdgcn_ds_bpermute((int)(b4 + 4u * u), li_c);
+        scs[u] = SCALED ? __int_as_float(__builtin_amdgcn_ds_bpermute((int)(b4 + 4u * u), sc_c)) : 1.f;
+      }
 #pragma unroll
       for (int g = 0; g < U / G; ++g) {
         u32x4 lv[G];
-        float scs[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-          const int li = __builtin_amdgcn_ds_bpermute((int)(b4 + 4u * (g * G + j)), li_c);
-          lv[j] = *reinterpret_cast<const u32x4*>(s_rows + (win_off + (uint32_t)li * ROWB));
-          scs[j] = SCALED ? __int_as_float(__builtin_amdgcn_ds_bpermute((int)(b4 + 4u * (g * G + j)), sc_c)) : 1.f;
+#ifdef PYGHO_TILE_KO_LDS
+          lv[j] = rv[g * G + j];
+          asm volatile("" : "+v"(lv[j]) : "v"(lis[g * G + j]));
+#else
+          lv[j] = *reinterpret_cast<const u32x4*>(s_rows + (win_off + (uint32_t)lis[g * G + j] * ROWB));
+#endif
         }
 #pragma unroll
         for (int j = 0; j < G; ++j) {
@@ -390,12 +420,12 @@ __global__ __launch_bounds__(kTileWaves * kWave, tile_occupancy(LPR, WROWS, SCAL
           const int tt = t + u;
           if (tt < tmin) {                                // every stream has a message in this trip: no predicate on the product
             while (m == seg_end) flush();                 // per stream (also steps over empty segments; ends at the sentinel)
-            accumulate(lv[j], rv[u], scs[j]);
+            accumulate(lv[j], rv[u], scs[u]);
             ++m;
           } else if (tt < tmax) {
             if (m < mb) {
               while (m == seg_end) flush();
-              accumulate(lv[j], rv[u], scs[j]);
+              accumulate(lv[j], rv[u], scs[u]);
               ++m;
             }
           }
