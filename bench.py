@@ -197,7 +197,10 @@ def side_regimes(args, dev):
         for mode in ("eager", "hipgraph"):
             torch.manual_seed(0)
             model = SpModel(1, args.layers, args.hidden, act_dtype=act).to(dev)
-            step = make_step(model, torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True), lambda: dd)
+            # eager: the fused multi-tensor AdamW (one launch); captured: its capturable form (device-side step counters)
+            optim = (torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True) if mode == "eager"
+                     else torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True))
+            step = make_step(model, optim, lambda: dd)
             if mode == "eager":
                 run = step
                 for _ in range(5):
