@@ -413,14 +413,20 @@ def main():
         if world == 1 and not args.no_regimes:
             del datadict, model, opt, sync, y
             torch.cuda.empty_cache()
-            line["regimes"] = side_regimes(args, dev)
+            try:
+                line["regimes"] = side_regimes(args, dev)
+            except Exception as e:        # a side measurement must never cost the headline line
+                line["regimes"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_configs:
             # BASELINE configs 3 (dense MaskedTensor path) and 5 (3-tuple stress) and one forward + backward of every shipped layer:
             # per-kernel HIP-event times, algorithmic bytes, roofline fraction and committed PMC traffic (tools/bench_configs.py)
             sys.path.insert(0, os.path.join(REPO, "tools"))
             import bench_configs
             torch.cuda.empty_cache()
-            line["configs"] = bench_configs.run(dev)
+            try:
+                line["configs"] = bench_configs.run(dev)
+            except Exception as e:        # a side measurement must never cost the headline line
+                line["configs"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, 1000)
         sys.stdout.flush()

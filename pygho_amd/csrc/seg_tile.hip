@@ -175,7 +175,10 @@ template <> struct Lane16<f16> {
 constexpr int tile_occupancy(int lpr, int wrows, bool scaled = false) {
   const int per_wg = kTileWaves * (wrows * lpr * 16 + 256);
   const int n = (160 * 1024) / per_wg;
-  const int cap = (lpr == 64 ? 2 : 3) - (scaled && lpr < 64 ? 1 : 0);      // the per-message row scale costs registers
+#ifndef PYGHO_TILE_CAP
+#define PYGHO_TILE_CAP 3
+#endif
+  const int cap = (lpr == 64 ? 2 : PYGHO_TILE_CAP) - (scaled && lpr < 64 ? 1 : 0);      // the per-message row scale costs registers
   return n > cap ? cap : (n < 1 ? 1 : n);
 }
 

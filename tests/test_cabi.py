@@ -74,6 +74,18 @@ def test_argument_validation_without_gpu(lib):
     assert lib.pygho_exclusive_scan_i64(None, None, -1, None, 0, None) == 1
     assert lib.pygho_product_hash(None, None, 1, 0, 0, None, 1, 0, 0, None, None, 0, None, None) == 1                          # no remaining coordinate
     assert lib.pygho_gather_cols_i64(None, None, 0, 0, None, 0, 5, None) == 0
+    # the tiled segment kernel and its planner: sizes, null pointers, row widths, dtype and the (scale, residual) combination
+    assert lib.pygho_seg_tile_chunk() == 256
+    assert lib.pygho_seg_tile_plan(None, None, None, None, 0, 24, None) == 0                                                    # empty
+    assert lib.pygho_seg_tile_plan(None, None, None, None, 5, 24, None) == 1 and b"null" in lib.pygho_last_error()
+    assert lib.pygho_seg_tile_plan(one, one, one, one, 5, 40, None) == 1 and b"win_rows" in lib.pygho_last_error()
+    tiled = lib.pygho_seg_gather_mul_reduce_tiled
+    assert tiled(None, None, None, None, None, None, None, None, None, None, 0, 256, 4, 4, 24, 1, 0, None) == 0                 # empty
+    assert tiled(None, None, None, None, None, None, None, None, None, None, 5, 256, 4, 4, 24, 1, 0, None) == 1
+    assert tiled(one, None, one, one, one, one, one, None, one, one, 5, 96, 4, 4, 24, 1, 0, None) == 2 and b"row bytes" in lib.pygho_last_error()
+    assert tiled(one, None, one, one, one, one, one, None, one, one, 5, 256, 4, 4, 24, 3, 0, None) == 2                          # f64
+    assert tiled(one, None, one, one, one, one, one, None, one, one, 5, 256, 4, 4, 24, 1, 2, None) == 2                          # max
+    assert tiled(one, one, one, one, one, one, one, one, one, one, 5, 256, 4, 4, 24, 1, 0, None) == 2 and b"row scale" in lib.pygho_last_error()
 
 
 def test_product_path_refuses_cpu_tensors():
