@@ -453,6 +453,52 @@ def test_baseline_size_elementwise_vs_host_oracle(dev, kind, graphs, d, key, dty
         del xg, ag, out
 
 
+@pytest.mark.parametrize("kind", ["i2", "zinc"])
+@pytest.mark.parametrize("win", [8, 24, 32])
+def test_tile_plan_invariants(dev, kind, win):
+    """`pygho_seg_tile_plan` (integer work, checked exactly on the host): the tiles of every 256-segment chunk partition the chunk
+    in order; a tile holds at most 64 segments; every lhs index of a tile with a window lies inside [row0, row0 + rows) with
+    rows <= win_rows and the window is tight (its first and last row are used); a tile without a window has no messages or is ONE
+    segment whose own row range is wider than the window; first message / message count equal the CSR pointers; the quarter
+    boundaries are segment boundaries, monotone, and the smallest ones with at least j quarters of the messages in front."""
+    from pygho_amd import _ops, synth
+    key = "X___X___1___A___0" if kind == "zinc" else "X___X___2___A___0"
+    hb = synth.make_batch(40 if kind == "zinc" else 6, kind, seed=9)
+    acd = T(hb.acd[key], dev)
+    nt, ne = hb.num_tuples, hb.num_edges
+    plan = _ops.message_plan(acd, nt, nt, ne)
+    pd, a_d, c_d = plan.by_d()
+    for n_seg, sp_t, li_t in ((nt, plan.fwd.seg_ptr, plan.c_fwd), (ne, pd.seg_ptr, a_d)):
+        cnt_t, tiles_t = _ops.tile_plan(sp_t, li_t, n_seg, win)
+        sp, li = sp_t.cpu().numpy().astype(np.int64), li_t.cpu().numpy().astype(np.int64)
+        cnt, tiles = cnt_t.cpu().numpy(), tiles_t.cpu().numpy()
+        chunk = tiles.shape[1]
+        assert cnt.shape[0] == (n_seg + chunk - 1) // chunk
+        for ci in range(cnt.shape[0]):
+            nloc = min(chunk, n_seg - ci * chunk)
+            expect_first = 0
+            for t in range(int(cnt[ci])):
+                d = tiles[ci, t]
+                first, ns, rows, row0, m0, nmsg = d[0] & 0xff, (d[0] >> 8) & 0xff, (d[0] >> 16) & 0xff, d[1], d[2], d[3]
+                assert first == expect_first and 1 <= ns <= 64 and rows <= win
+                expect_first += ns
+                s0 = ci * chunk + first
+                assert m0 == sp[s0] and nmsg == sp[s0 + ns] - sp[s0]
+                idx = li[m0:m0 + nmsg]
+                if rows:
+                    assert nmsg > 0 and idx.min() == row0 and idx.max() == row0 + rows - 1
+                else:
+                    assert nmsg == 0 or (ns == 1 and idx.max() - idx.min() >= win)
+                q = [d[4] & 0xff, (d[4] >> 8) & 0xff, (d[4] >> 16) & 0xff]
+                ms = [d[5], d[6], d[7]]
+                assert 0 <= q[0] <= q[1] <= q[2] <= ns
+                for j in range(3):
+                    assert ms[j] == sp[s0 + q[j]] - m0
+                    assert 4 * ms[j] >= (j + 1) * nmsg or q[j] == ns                    # at least j + 1 quarters in front ...
+                    assert q[j] == 0 or 4 * (sp[s0 + q[j] - 1] - m0) < (j + 1) * nmsg    # ... and no earlier boundary has
+            assert expect_first == nloc
+
+
 @pytest.mark.parametrize("kind,d,dtype", [("i2", 256, torch.bfloat16), ("i2", 128, torch.bfloat16), ("i2", 128, torch.float32),
                                           ("i2", 256, torch.float32), ("zinc", 128, torch.float32), ("i2", 256, torch.float16)])
 def test_tile_kernel_bit_identical_to_fast_kernel(dev, kind, d, dtype):
