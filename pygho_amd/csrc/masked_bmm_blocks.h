@@ -240,7 +240,23 @@ __global__ __launch_bounds__(kWave, NBUF > 1 ? 1 : 2) void masked_bmm_blocks_ker
     [&]<int... Q>(std::integer_sequence<int, Q...>) {
       ((4 * Q < nk_eff ? load_step(std::integral_constant<int, Q>{}, 4 * Q) : (void)0), ...);
     }(std::make_integer_sequence<int, NBUF - 1>{});
+    // A step of 4 k contributes only if SOME row of the tile has an unmasked position in it AND some column has one: with an
+    // adjacency-masked operand (3.6 % dense) most steps of a tile are dead on one side.  Their loads would be free (out-of-range
+    // offsets) but their lane permutations and matrix instructions are not; a dead step adds exact zeros, so skipping it leaves
+    // every accumulator bit as it is.  (Single-buffer form only: the ring of the multi-buffer forms issues loads one step ahead.)
+    uint64_t la_any = 0, lb_any = 0;
+    if constexpr (NBUF == 1) {
+#pragma unroll
+      for (int s = 0; s < TI; ++s) la_any |= a_bits[s];
+#pragma unroll
+      for (int u = 0; u < TJ; ++u) lb_any |= b_bits[u];
+    }
     for (int kb = 0; kb < nk_eff; kb += 4 * NBUF) {
+      if constexpr (NBUF == 1) {
+        const bool a_live = __builtin_amdgcn_ballot_w64((((uint32_t)(la_any >> kb)) & 15u) != 0u) != 0;
+        const bool b_live = __builtin_amdgcn_ballot_w64((((uint32_t)(lb_any >> kb)) & 15u) != 0u) != 0;
+        if (!a_live || !b_live) continue;
+      }
       bool done = false;
       [&]<int... Q>(std::integer_sequence<int, Q...>) {
         (([&] {
