@@ -403,6 +403,16 @@ def main():
                                                  "frac": op_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             "kernels": {k: {"launches": v[0], "avg_ms": v[1], "GBps": v[2] / (v[1] * 1e-3) / 1e9} for k, v in summ.items()},
         }
+        # the segment kernels' XCD-aware sweep assumes workgroup b runs on XCD b % 8: report whether this box dispatches that way
+        try:
+            from pygho_amd._native import check as _check, ptr as _ptr, stream_ptr as _sp
+            ids = torch.empty(2048, dtype=torch.int32, device=dev)
+            _check(_native.lib().pygho_xcc_ids(_ptr(ids), 2048, _sp(dev)), "xcc_ids")
+            want = torch.arange(2048, device=dev, dtype=torch.int32) % 8
+            line["xcd_dispatch"] = {"workgroups": 2048, "xcds_seen": int(ids.unique().numel()),
+                                    "fraction_on_xcd_b_mod_8": float((ids == want).float().mean())}
+        except Exception as e:
+            line["xcd_dispatch"] = {"error": f"{type(e).__name__}: {e}"}
         if use_dist:
             line["collectives"] = {"backend": dist.get_backend(), "allreduce_calls": sync.allreduce_calls,
                                    "allreduce_bytes": sync.flat.numel() * sync.flat.element_size(),

@@ -191,6 +191,11 @@ int pygho_row_gather(void* out, const void* src, const int32_t* idx, const int32
  * Planner (integer, bit-exact)
  * ---------------------------------------------------------------------- */
 
+/* Diagnostic without a reference counterpart: out[b] = the XCD (0..7, HW_REG_XCC_ID) workgroup b of a plain 1-D launch of n_blocks
+ * workgroups ran on.  The segment kernels order their work assuming workgroup b runs on XCD b % 8 (observed dispatch order; a speed
+ * assumption only, results never depend on it); bench.py reports the fraction of workgroups for which it holds on the box. */
+int pygho_xcc_ids(int32_t* out, int64_t n_blocks, void* stream);
+
 /* int64 -> int32 narrowing with range check; *err (device int32) is set to 1 on overflow/negative. */
 int pygho_narrow_i64_i32(int32_t* dst, const int64_t* src, int64_t n, int32_t* err, void* stream);
 

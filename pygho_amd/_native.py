@@ -42,6 +42,7 @@ PROTOTYPES = {
     "pygho_seg_extremum_ties": (I, [P, P, P, P, P, P, P, L, L, I, P]),
     "pygho_seg_extremum_bwd": (I, [P, P, P, P, P, P, P, P, P, L, L, I, P]),
     "pygho_row_gather": (I, [P, P, P, P, L, L, I, P]),
+    "pygho_xcc_ids": (I, [P, L, P]),
     "pygho_narrow_i64_i32": (I, [P, P, L, P, P]),
     "pygho_csr_from_sorted": (I, [P, P, L, L, P, P]),
     "pygho_group_by_key_workspace": (Z, [L, L]),

@@ -240,6 +240,26 @@ using namespace pygho;
 extern "C" int pygho_abi_version(void) { return PYGHO_ABI_VERSION; }
 extern "C" const char* pygho_last_error(void) { return g_err; }
 
+// which XCD (0..7) every workgroup of a plain 1-D launch ran on: the segment kernels map workgroup b to XCD b % 8 for L2 locality
+// (a speed assumption only -- HIP promises no placement); this lets the benchmark REPORT whether the box dispatches that way
+namespace pygho {
+__global__ void xcc_id_kernel(int32_t* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    out[blockIdx.x] = (int32_t)(v & 0xfu);
+  }
+}
+}  // namespace pygho
+
+extern "C" int pygho_xcc_ids(int32_t* out, int64_t n_blocks, void* stream) {
+  if (n_blocks < 0 || n_blocks > (int64_t)kMaxGrid * 64) { set_error("xcc_ids: bad block count"); return PYGHO_ERR_INVALID; }
+  if (n_blocks == 0) return PYGHO_OK;
+  if (!out) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(pygho::xcc_id_kernel, dim3((unsigned)n_blocks), dim3(kBlock), 0, (hipStream_t)stream, out);
+  return check_launch("xcc_ids");
+}
+
 extern "C" int pygho_narrow_i64_i32(int32_t* dst, const int64_t* src, int64_t n, int32_t* err, void* stream) {
   if (n < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
   if (n == 0) return PYGHO_OK;

@@ -1004,3 +1004,12 @@ else:
     env = dict(os.environ, PYGHO_DEBUG="1", PYGHO_ROCTX="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "caught" in r.stdout, r.stderr[-2000:]
+
+
+def test_xcc_ids_reports_a_valid_xcd_per_workgroup(dev):
+    """pygho_xcc_ids (diagnostic): every workgroup reports an XCD in 0..7 and the launch covers all eight; the b % 8 placement the
+    segment kernels exploit for L2 locality is a speed assumption, reported by bench.py (`xcd_dispatch`), not asserted here."""
+    from pygho_amd._native import check, lib, ptr, stream_ptr
+    ids = torch.full((1024,), -1, dtype=torch.int32, device=dev)
+    check(lib().pygho_xcc_ids(ptr(ids), 1024, stream_ptr(dev)), "xcc_ids")
+    assert int(ids.min()) >= 0 and int(ids.max()) <= 7 and ids.unique().numel() == 8
