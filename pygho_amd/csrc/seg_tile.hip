@@ -279,12 +279,8 @@ __global__ __launch_bounds__(kTileWaves * kWave, tile_occupancy(LPR, WROWS, SCAL
     const int n1k = __builtin_amdgcn_readfirstlane((rows * (int)ROWB + 1023) >> 10);
 #pragma unroll
     for (int j = 0; j < WCH; ++j) {
-#ifdef PYGHO_TILE_KO_STAGE
-      if (j < n1k) { pre[j] = u32x4{}; asm volatile("" : "+v"(pre[j]) : "s"(d0.y + j)); }
-#else
       if (j < n1k)
         pre[j] = __builtin_amdgcn_raw_buffer_load_b128(lres, (int)(lane * 16), __builtin_amdgcn_readfirstlane((int)((uint32_t)d0.y * ROWB + (uint32_t)j * 1024u)), 0);
-#endif
     }
   };
 
@@ -345,11 +341,7 @@ __global__ __launch_bounds__(kTileWaves * kWave, tile_occupancy(LPR, WROWS, SCAL
 #pragma unroll
         for (int q = 0; q < N; ++q) acc[q] = rv[q] + acc[q];
       }
-#ifdef PYGHO_TILE_KO_STORE
-      if (seg < -1) __builtin_amdgcn_raw_buffer_store_b128(L16::pack(acc), ores, (int)voff, 0, 0);
-#else
       __builtin_amdgcn_raw_buffer_store_b128(L16::pack(acc), ores, (int)voff, 0, 0);
-#endif
 #pragma unroll
       for (int q = 0; q < N; ++q) acc[q] = 0.f;
       ++seg;
@@ -382,12 +374,7 @@ __global__ __launch_bounds__(kTileWaves * kWave, tile_occupancy(LPR, WROWS, SCAL
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int ri = __builtin_amdgcn_ds_bpermute((int)(b4 + 4u * u), ri_c);
-#ifdef PYGHO_TILE_KO_RHS
-        rv[u] = u32x4{};
-        asm volatile("" : "+v"(rv[u]) : "v"(ri));
-#else
         rv[u] = __builtin_amdgcn_raw_buffer_load_b128(rres, (int)((uint32_t)ri * ROWB + coff), 0, 0);
-#endif
       }
     };
     // the U trips of a batch: lhs rows from the LDS window (G at a time), products accumulated per stream in message order
@@ -410,12 +397,7 @@ __global__ __launch_bounds__(kTileWaves * kWave, tile_occupancy(LPR, WROWS, SCAL
         u32x4 lv[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-#ifdef PYGHO_TILE_KO_LDS
-          lv[j] = rv[g * G + j];
-          asm volatile("" : "+v"(lv[j]) : "v"(lis[g * G + j]));
-#else
           lv[j] = *reinterpret_cast<const u32x4*>(s_rows + (win_off + (uint32_t)lis[g * G + j] * ROWB));
-#endif
         }
 #pragma unroll
         for (int j = 0; j < G; ++j) {
