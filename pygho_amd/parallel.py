@@ -27,7 +27,8 @@ class FlatGradSync:
     moment a range is complete its gradients are packed and its all-reduce is issued on a SIDE stream while backward
     goes on with the earlier layers.  ``sync()`` then only launches what is left (ranges holding parameters without a
     gradient), joins the side stream and scales.  The result is the same buffer as the single collective's: an
-    all-reduce sums element-wise, so the bucket boundaries cannot change a bit."""
+    all-reduce sums element-wise, so the bucket boundaries cannot change a bit.  Contract: ONE backward pass per
+    ``zero_grad()`` / ``sync()`` pair (no gradient accumulation over several backward calls)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional["dist.ProcessGroup"] = None,
                  dtype: torch.dtype = torch.float32, overlap: bool = False, buckets: int = 2):
@@ -134,6 +135,10 @@ class FlatGradSync:
             self.flat.div_(self.world)
         for v, p in zip(self.views, self.params):
             p.grad = v
+        # one backward per zero_grad() / sync() pair: a second backward without zero_grad() would add into the averaged buffer; the
+        # counters are re-armed here so that the next cycle at least exchanges what it finds
+        self._pending = [hi - lo for lo, hi, _, _ in self._ranges]
+        self._launched = [False] * len(self._ranges)
 
     def allreduce_ms(self) -> Optional[float]:
         """mean device time of one side-stream collective so far (after a device synchronisation); None without `overlap`"""
