@@ -79,3 +79,20 @@ def test_bench_self_launches_two_ranks():
     assert r.returncode == 0, r.stderr[-4000:]
     line = _line(r.stdout)
     assert line["n_gpus"] == 2 and line["config"]["graphs_per_gpu"] == 256
+
+
+def test_visible_gpu_count_reads_the_environment_not_the_runtime(monkeypatch):
+    """bench.py counts GPUs from the visibility variables (or the KFD topology) so that the parent of a self-launched run never
+    initialises HIP: the variables win, an empty list means no GPU"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bench_for_count", BENCH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0,1,2")
+    assert mod.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "3")                   # the first variable in HIP's own precedence order
+    assert mod.visible_gpu_count() == 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert mod.visible_gpu_count() == 0
