@@ -28,6 +28,34 @@ __global__ __launch_bounds__(256) void write_kernel(u4* __restrict__ dst, size_t
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = v;
 }
 
+__global__ __launch_bounds__(256) void write_nt_kernel(u4* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const u4 v = {1u, 2u, 3u, (uint32_t)threadIdx.x};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) __builtin_nontemporal_store(v, dst + i);
+}
+
+// every workgroup writes one contiguous share (a "persistent" output stream) instead of grid-strided 4-KB pieces
+__global__ __launch_bounds__(256) void write_chunk_kernel(u4* __restrict__ dst, size_t n) {
+  const size_t per = (n + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+  const u4 v = {1u, 2u, 3u, (uint32_t)threadIdx.x};
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) dst[i] = v;
+}
+
+// grid-strided pieces of `piece` 16-byte units per workgroup (4 KB = 256 units is write_kernel)
+__global__ __launch_bounds__(256) void write_piece_kernel(u4* __restrict__ dst, size_t n, int piece) {
+  const u4 v = {1u, 2u, 3u, (uint32_t)threadIdx.x};
+  for (size_t base = (size_t)blockIdx.x * piece; base < n; base += (size_t)gridDim.x * piece)
+    for (int i = threadIdx.x; i < piece && base + i < n; i += 256) dst[base + i] = v;
+}
+
+// the segment kernels' store shape: 16 lanes write one 256-byte row; a wavefront's 4 rows are `gap` rows apart
+__global__ __launch_bounds__(256) void write_rows_kernel(u4* __restrict__ dst, size_t rows, int rows_per_pass) {
+  const u4 v = {1u, 2u, 3u, (uint32_t)threadIdx.x};
+  const int g = threadIdx.x >> 4, sub = threadIdx.x & 15;         // 16 lane groups per workgroup
+  for (size_t base = (size_t)blockIdx.x * rows_per_pass; base < rows; base += (size_t)gridDim.x * rows_per_pass)
+    for (int r = g; r < rows_per_pass && base + r < rows; r += 16) dst[(base + r) * 16 + sub] = v;
+}
+
 __global__ __launch_bounds__(256) void copy_kernel(const u4* __restrict__ src, u4* __restrict__ dst, size_t n) {
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
@@ -79,8 +107,28 @@ int main() {
     printf("{\"kernel\": \"read_u8\", \"grid\": %d, \"ms\": %.4f, \"TBps\": %.3f}\n", grid, ms, bytes / ms / 1e9);
     ms = median_ms([&] { hipLaunchKernelGGL(write_kernel, dim3(grid), dim3(256), 0, 0, b, n); });
     printf("{\"kernel\": \"write\", \"grid\": %d, \"ms\": %.4f, \"TBps\": %.3f}\n", grid, ms, bytes / ms / 1e9);
+    ms = median_ms([&] { hipLaunchKernelGGL(write_nt_kernel, dim3(grid), dim3(256), 0, 0, b, n); });
+    printf("{\"kernel\": \"write_nontemporal\", \"grid\": %d, \"ms\": %.4f, \"TBps\": %.3f}\n", grid, ms, bytes / ms / 1e9);
+    ms = median_ms([&] { hipLaunchKernelGGL(write_chunk_kernel, dim3(grid), dim3(256), 0, 0, b, n); });
+    printf("{\"kernel\": \"write_contiguous_share\", \"grid\": %d, \"ms\": %.4f, \"TBps\": %.3f}\n", grid, ms, bytes / ms / 1e9);
     ms = median_ms([&] { hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, 0, a, b, n); });
     printf("{\"kernel\": \"copy\", \"grid\": %d, \"ms\": %.4f, \"TBps_read_plus_write\": %.3f}\n", grid, ms, 2.0 * bytes / ms / 1e9);
+  }
+  for (int grid : {1024, 2048})
+    for (int piece : {256, 512, 1024, 2048, 4096, 16384}) {
+      float ms = median_ms([&] { hipLaunchKernelGGL(write_piece_kernel, dim3(grid), dim3(256), 0, 0, b, n, piece); });
+      printf("{\"kernel\": \"write_piece\", \"grid\": %d, \"piece_KB\": %d, \"ms\": %.4f, \"TBps\": %.3f}\n", grid, piece / 64, ms, bytes / ms / 1e9);
+    }
+  for (int grid : {2048})
+    for (int rpp : {16, 32, 64, 128, 512}) {
+      float ms = median_ms([&] { hipLaunchKernelGGL(write_rows_kernel, dim3(grid), dim3(256), 0, 0, b, bytes / 256, rpp); });
+      printf("{\"kernel\": \"write_rows256\", \"grid\": %d, \"rows_per_pass\": %d, \"ms\": %.4f, \"TBps\": %.3f}\n", grid, rpp, ms, bytes / ms / 1e9);
+    }
+  {
+    float ms = median_ms([&] { hipMemsetAsync(b, 3, bytes, 0); });
+    printf("{\"kernel\": \"hipMemsetAsync\", \"ms\": %.4f, \"TBps\": %.3f}\n", ms, bytes / ms / 1e9);
+    ms = median_ms([&] { hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0); });
+    printf("{\"kernel\": \"hipMemcpyAsync_d2d\", \"ms\": %.4f, \"TBps_read_plus_write\": %.3f}\n", ms, 2.0 * bytes / ms / 1e9);
   }
   // gathered rows: permutation of runs of consecutive 256-B rows
   const size_t rows = bytes / 256;
