@@ -479,12 +479,27 @@ __device__ __forceinline__ void rl_lds_barrier() { asm volatile("s_waitcnt lgkmc
 template <int D> struct DwGeom {
   static constexpr int PBX = (RlGeom<D>::PITCH + 8) * 2;   // x tile: 32 B past a multiple of 256 B -> the transpose reads of
                                                            // 8 consecutive rows (one 32-lane half) cover all 64 banks once
-  static constexpr size_t tile_bytes = (size_t)kDwTile * RlGeom<D>::PITCH * 2;
+  static constexpr int PBG = RlGeom<D>::PITCH * 2;                        // gpre / output tile pitch
+  // W (W^T) image: +32 B per row.  Its row fragments are read by ds_read_b128, whose 16-lane groups {0-3, 12-15, 20-27}, ... take
+  // rows 0-3, 12-15 (chunk q) and 4-11 (chunk q + 1): 18 slots of 16 B per row put those 16 lanes on 16 different slots, 17 slots
+  // per row (PITCH) put row 11 / chunk 1 and row 12 / chunk 0 on the same one -- one extra LDS cycle on each of the 32 fragment
+  // reads of a tile (SQ_LDS_BANK_CONFLICT, profiles/r03_lds_conflicts.md).  The streaming forward kernels keep PITCH: the same
+  // change removes their conflicts too (12.5 M -> 5.4 M per launch) without moving their time, they wait on HBM
+  static constexpr int PBW = (D + 16) * 2;
+  static constexpr size_t w_bytes = (size_t)D * PBW;
+  static constexpr size_t tile_bytes = (size_t)kDwTile * PBG;
   static constexpr size_t xtile_bytes = (size_t)kDwTile * PBX;
   static constexpr size_t const_bytes = 7 * (size_t)D * 4;                                   // per-channel BatchNorm constants + the Linear's bias
-  static constexpr size_t lds_bytes = RlGeom<D>::w_bytes + tile_bytes + xtile_bytes + const_bytes;   // 73.7 KB at d = 128: 2 per CU
+  static constexpr size_t lds_bytes = w_bytes + tile_bytes + xtile_bytes + const_bytes;   // 75.7 KB at d = 128: 2 per CU
   static constexpr int NBW = (RlGeom<D>::NB + kDwWaves - 1) / kDwWaves;                      // dW row blocks per wave
 };
+
+// Image row of row k of W^T in the RECOMP form: bits 2 and 3 of k swapped.  The recomputation reads W^T through the LDS transpose
+// with rows 8 q + (0..3) (+ 4) per lane group q, i.e. rows {0-3, 8-11} then {4-7, 12-15} of a 16-row step per 32-lane half; in
+// natural order rows r and r + 8 lie 8 x 288 B = 9 bank rows apart -- the same banks, a two-way conflict on every one of the 64
+// transpose reads of a tile.  With the swap each half reads 8 consecutive image rows (all 64 banks once), and the row-wise
+// fragment reads of the gx product stay conflict-free (profiles/r03_lds_conflicts.md).
+__device__ __forceinline__ int rl_wt_row(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
 
 // RECOMP: `pre` is not read; the wave recomputes the pre-activation of its 16 rows from the x rows it has just staged,
 //   Y[m][n] = bias[n] + sum_k x[m][k] W[n][k], with the SAME fragments in the SAME order as rowblock_linear_kernel (lane (r16, q)
@@ -500,11 +515,11 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
                                                                          const T* __restrict__ lin_bias = nullptr) {
   using G = RlGeom<D>;
   using V = Vec16<T>;
-  constexpr int PB = G::PITCH * 2;                       // LDS row pitch in bytes (W^T, gpre and output tiles)
+  constexpr int PBW = DwGeom<D>::PBW, PBG = DwGeom<D>::PBG;   // LDS row pitch in bytes: W^T image; gpre and output tiles
   constexpr int PBX = DwGeom<D>::PBX;                    // ... of the x tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_w = smem;
-  char* stage_g = smem + G::w_bytes;
+  char* stage_g = smem + DwGeom<D>::w_bytes;
   char* stage_x = stage_g + DwGeom<D>::tile_bytes;
   char* stage_o = stage_g;                               // a wave's output rows reuse ITS OWN gpre rows once every wave is past
                                                          // the tile's dW phase (second barrier)
@@ -512,6 +527,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
                                                                                // needed for the two accumulator sets)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
+  const int r16w = RECOMP ? rl_wt_row(r16) : r16;         // this lane's row of a 16-row block of the W image
   if constexpr (RECOMP) {
     // `wl` is W itself ([n][k] row-major, the operand of the forward passes): transposed into LDS here, once per workgroup,
     // instead of by a transposing copy kernel in front of every launch
@@ -521,12 +537,12 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
       const uint32_t e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        *reinterpret_cast<uint16_t*>(lds_w + (size_t)(ch * 8 + j) * PB + n * 2) = (uint16_t)(e[j >> 1] >> ((j & 1) * 16));
+        *reinterpret_cast<uint16_t*>(lds_w + (size_t)rl_wt_row(ch * 8 + j) * PBW + n * 2) = (uint16_t)(e[j >> 1] >> ((j & 1) * 16));
     }
   } else {
     for (int item = threadIdx.x; item < D * G::CH; item += kDwThreads) {
       const int n = item / G::CH, ch = item - n * G::CH;
-      *reinterpret_cast<uint4*>(lds_w + (size_t)n * PB + ch * 16) = *reinterpret_cast<const uint4*>(wl + (size_t)n * D + ch * 8);
+      *reinterpret_cast<uint4*>(lds_w + (size_t)n * PBW + ch * 16) = *reinterpret_cast<const uint4*>(wl + (size_t)n * D + ch * 8);
     }
   }
   const int64_t n_tiles = (m_rows + kDwTile - 1) / kDwTile;
@@ -600,24 +616,26 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
 #pragma unroll
       for (int ks = 0; ks < G::KS; ++ks) {
         const uint4 fx = *reinterpret_cast<const uint4*>(stage_x + (size_t)(wave * kDwRowsPerWave + r16) * PBX + (ks * 32 + q * 8) * 2);
-        const char* wa = lds_w + (size_t)(ks * 32 + q * 8 + (r16 >> 2)) * PB + (r16 & 3) * 8;
+        // rows k = 32 ks + 8 q + (r16 >> 2) (+ 4 for the second read) of W^T, at their permuted places (rl_wt_row): the two lane
+        // groups of a 32-lane half read 8 CONSECUTIVE image rows per transpose read
+        const char* wa = lds_w + (size_t)(ks * 32 + (q >> 1) * 16 + (q & 1) * 4 + (r16 >> 2)) * PBW + (r16 & 3) * 8;
 #pragma unroll
         for (int nb = 0; nb < G::NB; ++nb) {
           const rl_s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(wa + nb * 32));
-          const rl_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(wa + nb * 32 + 4 * PB));
+          const rl_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(wa + nb * 32 + 8 * PBW));
           const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
           ay[nb] = rl_mfma<T>(make_uint4(a.x, a.y, b.x, b.y), fx, ay[nb]);
         }
       }
 #pragma unroll
       for (int nb = 0; nb < G::NB; ++nb)
-        *reinterpret_cast<uint2*>(stage_g + (size_t)(wave * kDwRowsPerWave + r16) * PB + (nb * 16 + q * 4) * 2) = rl_pack4<T>(ay[nb]);
+        *reinterpret_cast<uint2*>(stage_g + (size_t)(wave * kDwRowsPerWave + r16) * PBG + (nb * 16 + q * 4) * 2) = rl_pack4<T>(ay[nb]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int it = 0; it < EIT; ++it)
-        cy[it] = *reinterpret_cast<const uint4*>(stage_g + (size_t)(wave * kDwRowsPerWave + it * EROWS + erow0) * PB + ech * 16);
+        cy[it] = *reinterpret_cast<const uint4*>(stage_g + (size_t)(wave * kDwRowsPerWave + it * EROWS + erow0) * PBG + ech * 16);
     }
     // ---- prologue: gpre of this wave's 16 rows and the matching x rows -> LDS (rows past the end as zeros) ---------------
     float mu[8], is[8], ww[8], bb[8], k1[8], k2[8];        // re-read per tile: live only here
@@ -646,7 +664,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
       }
       uint4 packed = V::pack(v);
       if (!valid) packed = make_uint4(0u, 0u, 0u, 0u);
-      *reinterpret_cast<uint4*>(stage_g + (size_t)rl * PB + ech * 16) = packed;
+      *reinterpret_cast<uint4*>(stage_g + (size_t)rl * PBG + ech * 16) = packed;
       if (colsum_ws) {
         V::unpack(packed, v);
 #pragma unroll
@@ -665,10 +683,10 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
     for (int nb = 0; nb < G::NB; ++nb) acc[nb] = rl_f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) {
-      const uint4 fb = *reinterpret_cast<const uint4*>(stage_g + (size_t)(wave * kDwRowsPerWave + r16) * PB + (ks * 32 + q * 8) * 2);
+      const uint4 fb = *reinterpret_cast<const uint4*>(stage_g + (size_t)(wave * kDwRowsPerWave + r16) * PBG + (ks * 32 + q * 8) * 2);
 #pragma unroll
       for (int nb = 0; nb < G::NB; ++nb) {
-        const uint4 fa = *reinterpret_cast<const uint4*>(lds_w + (size_t)(nb * 16 + r16) * PB + (ks * 32 + q * 8) * 2);
+        const uint4 fa = *reinterpret_cast<const uint4*>(lds_w + (size_t)(nb * 16 + r16w) * PBW + (ks * 32 + q * 8) * 2);
         acc[nb] = rl_mfma<T>(fa, fb, acc[nb]);
       }
     }
@@ -681,12 +699,12 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
 #pragma unroll
       for (int ms = 0; ms < kDwTile / 32; ++ms) {
         const int row = ms * 32 + rsel;
-        const char* ga = stage_g + (size_t)row * PB + (r16 & 3) * 8 + n0 * 2;
+        const char* ga = stage_g + (size_t)row * PBG + (r16 & 3) * 8 + n0 * 2;
         uint4 fa[NBW];
 #pragma unroll
         for (int u = 0; u < NBW; ++u) {
           const rl_s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(ga + u * 32));
-          const rl_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(ga + u * 32 + 8 * PB));
+          const rl_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(ga + u * 32 + 8 * PBG));
           const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
           fa[u] = make_uint4(a.x, a.y, b.x, b.y);
         }
@@ -706,7 +724,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
     // ---- epilogue: accumulators -> own rows of stage_o -> row-contiguous chunks (+ addend) -> HBM ---------------------------
 #pragma unroll
     for (int nb = 0; nb < G::NB; ++nb)
-      *reinterpret_cast<uint2*>(stage_o + (size_t)(wave * kDwRowsPerWave + r16) * PB + (nb * 16 + q * 4) * 2) = rl_pack4<T>(acc[nb]);
+      *reinterpret_cast<uint2*>(stage_o + (size_t)(wave * kDwRowsPerWave + r16) * PBG + (nb * 16 + q * 4) * 2) = rl_pack4<T>(acc[nb]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -714,7 +732,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
     for (int it = 0; it < EIT; ++it) {
       const int rl = wave * kDwRowsPerWave + it * EROWS + erow0;
       const int64_t row = base + it * EROWS + erow0;
-      uint4 v = *reinterpret_cast<const uint4*>(stage_o + (size_t)rl * PB + ech * 16);
+      uint4 v = *reinterpret_cast<const uint4*>(stage_o + (size_t)rl * PBG + ech * 16);
       if (row < m_rows) {
         if (addend) {
           float a[8], b[8];
@@ -791,7 +809,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __r
                                                                     int64_t m_rows, int64_t ws_stride, int64_t x_ld) {
   using G = RlGeom<D>;
   using V = Vec16<T>;
-  constexpr int PB = G::PITCH * 2, PBX = DwGeom<D>::PBX;
+  constexpr int PBG = DwGeom<D>::PBG, PBX = DwGeom<D>::PBX;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* stage_g = smem;
   char* stage_x = smem + DwGeom<D>::tile_bytes;
@@ -845,7 +863,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __r
       const bool valid = base + it * EROWS + erow0 < m_rows;
       uint4 gv = cg[it];
       if (!valid) gv = make_uint4(0u, 0u, 0u, 0u);      // rows past the end contribute nothing
-      *reinterpret_cast<uint4*>(stage_g + (size_t)rl * PB + ech * 16) = gv;
+      *reinterpret_cast<uint4*>(stage_g + (size_t)rl * PBG + ech * 16) = gv;
       *reinterpret_cast<uint4*>(stage_x + (size_t)rl * PBX + ech * 16) = cx[it];
       if (colsum_ws) {
         float v[8];
@@ -860,12 +878,12 @@ __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __r
 #pragma unroll
       for (int ms = 0; ms < kDwTile / 32; ++ms) {
         const int row = ms * 32 + rsel;
-        const char* ga = stage_g + (size_t)row * PB + (r16 & 3) * 8 + n0 * 2;
+        const char* ga = stage_g + (size_t)row * PBG + (r16 & 3) * 8 + n0 * 2;
         uint4 fa[NBW];
 #pragma unroll
         for (int u = 0; u < NBW; ++u) {
           const rl_s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(ga + u * 32));
-          const rl_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(ga + u * 32 + 8 * PB));
+          const rl_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rl_s4_t*)(ga + u * 32 + 8 * PBG));
           const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
           fa[u] = make_uint4(a.x, a.y, b.x, b.y);
         }
