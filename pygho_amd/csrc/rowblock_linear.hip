@@ -469,6 +469,9 @@ int launch_bn_bwd_linear(void* gx, void* gpre, const void* pre, const void* gh, 
 // reduction index m along the lanes' 8-element fragments, i.e. as COLUMNS of the row-major staged tiles, which is what
 // the LDS transpose read ds_read_b64_tr_b16 delivers (two reads per fragment).  Per-workgroup dW partials are summed by
 // the caller.  HBM traffic per row: pre, gh, x, addend in, gx out -- 5 streams instead of 8 for the three-kernel path.
+#ifndef PYGHO_DW_PREFETCH_X
+#define PYGHO_DW_PREFETCH_X 1
+#endif
 typedef __attribute__((ext_vector_type(4))) short rl_s4_t;
 constexpr int kDwThreads = 256, kDwWaves = 4, kDwRowsPerWave = 16, kDwTile = 64;
 
@@ -581,7 +584,10 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
       int64_t row = base + it * EROWS + erow0;
       if (row >= m_rows) row = m_rows - 1;
       const int64_t off = row * D + ech * 8;
-      if constexpr (!RECOMP) y[it] = *reinterpret_cast<const uint4*>(pre + off);
+      // RECOMP: the slot of `pre` carries the x row instead (the recomputation needs it first thing in the tile: loaded at
+      // the top of its own tile it cost a full memory latency per tile)
+      if constexpr (RECOMP && PYGHO_DW_PREFETCH_X) y[it] = *reinterpret_cast<const uint4*>(x + off);
+      else if constexpr (!RECOMP) y[it] = *reinterpret_cast<const uint4*>(pre + off);
       g[it] = *reinterpret_cast<const uint4*>(gh + off);
     }
   };
@@ -590,12 +596,17 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
   __syncthreads();                                       // W^T staged
   for (; tile < n_tiles; tile += gridDim.x) {
     const int64_t base = tile * kDwTile + wave * kDwRowsPerWave;
-    uint4 cx[EIT];                                       // x rows of THIS tile: only pass through (HBM -> registers -> LDS), so
-#pragma unroll                                           // they are not carried across the MFMA phases like the (pre, gh) prefetch
-    for (int it = 0; it < EIT; ++it) {
-      int64_t row = base + it * EROWS + erow0;
-      if (row >= m_rows) row = m_rows - 1;
-      cx[it] = *reinterpret_cast<const uint4*>(x + row * D + ech * 8);
+    uint4 cx[EIT];                                       // x rows of THIS tile
+    if constexpr (RECOMP && PYGHO_DW_PREFETCH_X) {
+#pragma unroll
+      for (int it = 0; it < EIT; ++it) cx[it] = cy[it];  // prefetched with the previous tile's (x, gh) pair
+    } else {                                             // pass through only (HBM -> registers -> LDS): not carried across the MFMA
+#pragma unroll                                           // phases (the non-recompute form is at 248 of 256 registers)
+      for (int it = 0; it < EIT; ++it) {
+        int64_t row = base + it * EROWS + erow0;
+        if (row >= m_rows) row = m_rows - 1;
+        cx[it] = *reinterpret_cast<const uint4*>(x + row * D + ech * 8);
+      }
     }
     uint4 ny[EIT], ng[EIT];
     // prefetch of the next tile (clamped to the last one: an unconditional load keeps the arrays in registers -- the
@@ -750,6 +761,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
 #pragma unroll
     for (int it = 0; it < EIT; ++it) {
       if constexpr (!RECOMP) cy[it] = ny[it];
+      else if constexpr (PYGHO_DW_PREFETCH_X) cy[it] = ny[it];
       cg[it] = ng[it];
     }
   }
