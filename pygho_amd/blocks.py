@@ -140,10 +140,37 @@ def _fold_momentum(bn) -> Optional[float]:
     return None
 
 
+USE_DEFERRED_COUNTERS = os.environ.get("PYGHO_DEFER_COUNTERS", "1") != "0"
+_PENDING_BATCH_COUNTERS: Optional[list] = None      # set by `deferred_batch_counters`: the counters of one forward pass, bumped together
+
+
+class deferred_batch_counters:
+    """inside this context every BatchNorm's `num_batches_tracked += 1` (one scalar launch per layer: 8 per step in the NGNN model)
+    is collected and applied by ONE `torch._foreach_add_` at exit.  The cumulative-average mode (momentum None) reads its counter
+    on the host and keeps the immediate update."""
+
+    def __enter__(self):
+        global _PENDING_BATCH_COUNTERS
+        self.outer = _PENDING_BATCH_COUNTERS
+        _PENDING_BATCH_COUNTERS = []
+        return self
+
+    def __exit__(self, *exc):
+        global _PENDING_BATCH_COUNTERS
+        pend, _PENDING_BATCH_COUNTERS = _PENDING_BATCH_COUNTERS, self.outer
+        if pend and exc[0] is None:
+            with torch.no_grad():
+                torch._foreach_add_(pend, 1)
+
+
 def _update_running(bn, mean: Tensor, var: Tensor, n: int, folded: bool = False) -> None:
     if bn.training and bn.track_running_stats and bn.running_mean is not None:
         with torch.no_grad():
-            bn.num_batches_tracked += 1
+            if (USE_DEFERRED_COUNTERS and _PENDING_BATCH_COUNTERS is not None and bn.momentum is not None
+                    and bn.num_batches_tracked is not None):
+                _PENDING_BATCH_COUNTERS.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked += 1
             if folded:
                 return
             mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
@@ -166,7 +193,23 @@ def batch_norm_act(x: Tensor, bn: "torch.nn.BatchNorm1d", act: str, residual: Op
 # --------------------------------------------------------------------------
 USE_CAST_ARENA = os.environ.get("PYGHO_CAST_ARENA", "1") != "0"
 _ARENA_OF = {}          # id(parameter) -> (weakref to its arena, position); validated by identity on lookup
-_ARENA_EPOCH = [0]      # bumped by whoever changes parameters behind the version counters' back (a HIP graph replay)
+_ARENA_EPOCH = [0]      # bumped by whoever changes parameters behind the version counters' back (an optimizer step, a HIP graph replay)
+
+
+def _invalidate_after_optimizer_step(*_args, **_kwargs) -> None:
+    _ARENA_EPOCH[0] += 1
+
+
+# Version counters are NOT a reliable staleness signal: the fused multi-tensor optimizers (`torch.optim.AdamW(fused=True)`: one
+# `_fused_adamw_` launch) update the parameters in place WITHOUT moving `p._version` (measured: the arena kept serving the weights
+# of step 0 for a whole training run).  Every optimizer step therefore invalidates every arena (a global post-step hook), and a
+# forward pass under autograd re-casts unconditionally (`ensure_cast_arena`): one `_foreach_copy_` launch per step, which is what
+# the arena is for; the version / address checks remain as the guard for updates between those two events.
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
+    _register_step_hook(_invalidate_after_optimizer_step)
+except ImportError:                                                         # pragma: no cover - older torch
+    _register_step_hook = None
 
 
 def invalidate_cast_arenas() -> None:
@@ -201,13 +244,13 @@ class ParamCastArena:
         for i, p in enumerate(self.params):
             _ARENA_OF[id(p)] = (ref, i)
 
-    def refresh(self) -> None:
+    def refresh(self, force: bool = False) -> None:
         """Freshness is decided by the parameter's version counter and storage address.  Covered update paths: in-place ops on the
         parameter (optimizers, `p.copy_`, `load_state_dict`), `module.to()` / `p.data = t` (new storage), a replayed HIP graph
         (`GraphedStep.replay` bumps the epoch).  NOT visible from here: writes through a `.data` alias (`p.data.mul_(...)` has its
         own version counter) -- call `invalidate_cast_arenas()` after those.  Under stream capture every copy is re-cast INSIDE
         the graph: a graph that captured only forward + backward must not bake in the views of a cast that happened before it."""
-        if self.epoch != _ARENA_EPOCH[0] or (self.flat is not None and torch.cuda.is_current_stream_capturing()):
+        if force or self.epoch != _ARENA_EPOCH[0] or (self.flat is not None and torch.cuda.is_current_stream_capturing()):
             stale = list(range(len(self.params)))
         else:
             stale = [i for i, p in enumerate(self.params) if self.versions[i] != p._version or self.ptrs[i] != p.data_ptr()]
@@ -235,7 +278,9 @@ def ensure_cast_arena(module, dtype: Optional[torch.dtype]) -> None:
             # belt and braces next to the version / address checks: a loaded state dict invalidates every copy
             module.register_load_state_dict_post_hook(lambda _m, _keys: invalidate_cast_arenas())
             module.__dict__["_pygho_cast_hook"] = True
-    arena.refresh()
+    # under autograd (a training forward pass) every copy is re-cast: whatever updated the parameters since the last pass, with or
+    # without touching their version counters, is seen (see the note at _invalidate_after_optimizer_step)
+    arena.refresh(force=torch.is_grad_enabled())
 
 
 def param_as(p: Tensor, dtype: torch.dtype) -> Tensor:

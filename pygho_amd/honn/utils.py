@@ -4,6 +4,7 @@ utils.py:46-142): these are dense ``torch.nn`` stacks (rocBLAS / hipBLASLt GEMMs
 and are not part of the hand-written hot path; module / parameter names match the reference so that
 ``state_dict``s are interchangeable.
 """
+import os
 from typing import Callable, Optional
 
 import torch
@@ -13,8 +14,27 @@ from torch import Tensor
 from .. import _ops
 
 
+USE_ARENA_LINEAR = os.environ.get("PYGHO_ARENA_LINEAR", "1") != "0"    # short 16-bit inputs through _ArenaLinearFn as well
+_MM_OUT_DTYPE = [None]       # does torch.mm take out_dtype here (an f32 weight gradient straight from 16-bit operands)?
+
+
+def _small_weight_grad(g: Tensor, x: Tensor, dtype: torch.dtype) -> Tensor:
+    """dW = g^T x for short operands, in `dtype` without a separate cast launch where the library allows it"""
+    if dtype == torch.float32 and g.dtype in (torch.bfloat16, torch.float16) and _MM_OUT_DTYPE[0] is not False:
+        try:
+            gw = torch.mm(g.t(), x, out_dtype=torch.float32)
+            _MM_OUT_DTYPE[0] = True
+            return gw
+        except (TypeError, RuntimeError):
+            if _MM_OUT_DTYPE[0]:
+                raise
+            _MM_OUT_DTYPE[0] = False
+    return (g.t() @ x).to(dtype)
+
+
 class _SplitKLinearFn(torch.autograd.Function):
-    """y = x W^T + b with the weight gradient computed as a batched split-K product.
+    """y = x W^T + b with the weight gradient computed as a batched split-K product (operands as given: the callers in honn/Conv.py
+    hand in weights they have cast / transposed themselves).
 
     The tuple-wise MLPs see (nnz ~ 10^6, d = 128) activations, so dW = g^T x is a (d x nnz) @ (nnz x d)
     GEMM whose reduction dim is the long one (``_ops.weight_grad_splitk``)."""
@@ -43,17 +63,54 @@ class _SplitKLinearFn(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _ArenaLinearFn(torch.autograd.Function):
+    """y = x W^T + b in the compute dtype `dt`, taking the MASTER parameters: their 16-bit copies come from the cast arena
+    (``_ops.param_as``: one multi-tensor cast per optimizer step, no autograd node), and the gradients go back in the masters' own
+    dtype straight from f32 accumulators -- no cast launch per parameter and direction (autocast's ``nn.Linear`` issues four).
+
+    Tall inputs: the tuple-wise MLPs see (nnz ~ 10^6, d = 128) activations, so dW = g^T x is a (d x nnz) @ (nnz x d) GEMM whose
+    reduction dim is the long one (``_ops.weight_grad_splitk``)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dt):
+        wq = _ops.param_as(w, dt)
+        ctx.save_for_backward(x, wq)
+        ctx.grad_dtypes = (w.dtype, None if b is None else b.dtype)
+        return torch.nn.functional.linear(x, wq, None if b is None else _ops.param_as(b, dt))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        w_dtype, b_dtype = ctx.grad_dtypes
+        g = g.contiguous()
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        want_b = b_dtype is not None and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            if x.shape[0] < 8192:
+                gw = _small_weight_grad(g, x, w_dtype)
+            elif want_b:
+                gw, gb = _ops.weight_grad_splitk(g, x, w_dtype, want_colsum=True)        # the column sums arrive in f32
+                gb = gb.to(b_dtype)
+            else:
+                gw = _ops.weight_grad_splitk(g, x, w_dtype)
+        if want_b and gb is None:
+            gb = g.sum(0, dtype=b_dtype)
+        return gx, gw, gb, None
+
+
 class Linear(nn.Linear):
-    """``nn.Linear`` (same parameters / state_dict) whose backward uses the split-K weight gradient above for
-    tall 2-D inputs on the device; anything else takes the stock path."""
+    """``nn.Linear`` (same parameters / state_dict).  2-D device inputs under autograd go through ``_ArenaLinearFn``: tall ones
+    for the split-K weight gradient, 16-bit ones of any height for the cast arena (at the reference's batch size the step is
+    bound by launches, and autocast's per-use parameter casts were 20 of its 163); anything else takes the stock path."""
 
     def forward(self, x: Tensor) -> Tensor:
-        if x.is_cuda and x.dim() == 2 and x.shape[0] >= 8192 and torch.is_grad_enabled():
+        if x.is_cuda and x.dim() == 2 and torch.is_grad_enabled():
             dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
-            xx = x if x.dtype == dt else x.to(dt)
-            b = None if self.bias is None else _ops.cast_param(self.bias, dt)
-            with torch.autocast("cuda", enabled=False):
-                return _SplitKLinearFn.apply(xx.contiguous(), _ops.cast_param(self.weight, dt), b)
+            if x.shape[0] >= 8192 or (USE_ARENA_LINEAR and dt in (torch.bfloat16, torch.float16) and self.weight.dtype == torch.float32):
+                xx = x if x.dtype == dt else x.to(dt)
+                with torch.autocast("cuda", enabled=False):
+                    return _ArenaLinearFn.apply(xx.contiguous(), self.weight, self.bias, dt)
         return super().forward(x)
 
 

@@ -161,10 +161,11 @@ class SpModel(nn.Module):
         datadict = self.data_encoder(datadict, defer_tuplefeat=fuse)        # a new dict per forward pass
         datadict[GRAD_CHAIN_KEY] = {}           # the layers share A: its gradient is summed inside their by-edge aggregations
         A, X, x = datadict["A"], datadict["X"], datadict["x"]
-        X = self.tupleinit(X, x, datadict.get("X_table"))
-        for conv in self.subggnns:
-            X = conv.forward_residual(A, X, datadict)      # == X.add(conv.forward(A, X, datadict), True), fused
-        x = self.lpool(X)
-        x = self.poolmlp(x)
+        with _ops.deferred_batch_counters():               # the BatchNorm step counters of the pass: one launch instead of one per layer
+            X = self.tupleinit(X, x, datadict.get("X_table"))
+            for conv in self.subggnns:
+                X = conv.forward_residual(A, X, datadict)  # == X.add(conv.forward(A, X, datadict), True), fused
+            x = self.lpool(X)
+            x = self.poolmlp(x)
         h_graph = torch_scatter_reduce(0, x, datadict["batch"], datadict["num_graphs"], self.npool)
         return self.pred_lin(h_graph)

@@ -616,6 +616,105 @@ def test_model_building_blocks_match_torch(dev):
     torch.testing.assert_close(l1.bias.grad, l2.bias.grad, rtol=1e-3, atol=1e-2)
 
 
+@pytest.mark.parametrize("rows", [300, 40_000])
+def test_linear_under_autocast_reads_the_cast_arena(dev, rows):
+    """honn.utils.Linear under bf16 autocast (any height): same output bits as nn.Linear under autocast (the arena's copy is the
+    same rounding of the master weight), gradients in the masters' f32 within bf16 rounding of autocast's (ours skip the bf16
+    rounding of dW / db), with and without a cast arena behind the module; and an optimizer step is seen by the next forward."""
+    from pygho_amd import _ops
+    from pygho_amd.honn.utils import Linear
+    torch.manual_seed(3)
+    l1, l2 = Linear(128, 128).to(dev), torch.nn.Linear(128, 128).to(dev)
+    l2.load_state_dict(l1.state_dict())
+    x = torch.randn(rows, 128, device=dev)
+    g = torch.randn(rows, 128, device=dev)
+    for use_arena in (False, True):
+        l1.zero_grad(set_to_none=True)
+        l2.zero_grad(set_to_none=True)
+        if use_arena:
+            _ops.ensure_cast_arena(l1, torch.bfloat16)
+        x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y1, y2 = l1(x1), l2(x2)
+        assert y1.dtype == y2.dtype == torch.bfloat16 and torch.equal(y1, y2)
+        (y1.float() * g).sum().backward()
+        (y2.float() * g).sum().backward()
+        assert l1.weight.grad.dtype == torch.float32 and l1.bias.grad.dtype == torch.float32
+        torch.testing.assert_close(x1.grad, x2.grad, rtol=2 ** -7, atol=2 ** -7 * float(x2.grad.abs().max()))
+        for a, b in ((l1.weight.grad, l2.weight.grad), (l1.bias.grad, l2.bias.grad)):
+            torch.testing.assert_close(a, b, rtol=2 ** -7, atol=2 ** -7 * float(b.abs().max()))
+        # against f64: ours must be at least as close as autocast's
+        ref = (g.to(torch.bfloat16).double().t() @ x.to(torch.bfloat16).double())
+        assert float((l1.weight.grad.double() - ref).abs().max()) <= float((l2.weight.grad.double() - ref).abs().max()) * 1.01 + 1e-6
+    opt = torch.optim.SGD(l1.parameters(), lr=0.5)
+    opt.step()                                            # in-place update: the arena copy is stale now and must not be used
+    _ops.ensure_cast_arena(l1, torch.bfloat16)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = l1(x)
+    exp = torch.nn.functional.linear(x.to(torch.bfloat16), l1.weight.detach().to(torch.bfloat16), l1.bias.detach().to(torch.bfloat16))
+    assert torch.equal(y, exp)
+
+
+@pytest.mark.parametrize("opt_kind", ["adamw_fused", "adamw_foreach", "sgd_fused"])
+def test_cast_arena_follows_the_optimizer(dev, opt_kind):
+    """The 16-bit parameter copies must be the CURRENT master weights in every forward pass.  torch's fused optimizers update the
+    parameters without moving their version counters (round 3: the arena served the weights of step 0 for a whole run), so the
+    arena is invalidated by a global optimizer post-step hook and re-cast in every pass under autograd.  Checked: after each step
+    + forward every arena view equals a fresh cast, and the loss trajectory equals the one without the arena to 16-bit rounding."""
+    from pygho_amd import _ops, synth
+    from pygho_amd.ngnn import SpModel
+    dd = synth.to_datadict(synth.make_batch(64, "zinc", seed=11), dev)
+
+    def run(use_arena):
+        saved = _ops.USE_CAST_ARENA
+        _ops.USE_CAST_ARENA = use_arena
+        try:
+            torch.manual_seed(0)
+            model = SpModel(1, 3, 64, act_dtype=torch.bfloat16).to(dev)
+            params = list(model.parameters())
+            opt = {"adamw_fused": lambda: torch.optim.AdamW(params, lr=3e-3, fused=True),
+                   "adamw_foreach": lambda: torch.optim.AdamW(params, lr=3e-3, foreach=True),
+                   "sgd_fused": lambda: torch.optim.SGD(params, lr=3e-2, momentum=0.9, fused=True)}[opt_kind]()
+            losses = []
+            for _ in range(8):
+                opt.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    pred = model(dd)
+                if use_arena:
+                    arena = model.__dict__["_pygho_cast_arena"]
+                    assert all(torch.equal(v, p.detach().to(torch.bfloat16)) for v, p in zip(arena.views, arena.params)), "stale 16-bit copy"
+                loss = torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float())
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+            return losses
+        finally:
+            _ops.USE_CAST_ARENA = saved
+
+    with_arena, without = run(True), run(False)
+    assert with_arena[-1] < 0.8 * with_arena[0], f"the model does not learn: {with_arena}"
+    np.testing.assert_allclose(with_arena, without, rtol=0.05, atol=0.02)
+
+
+def test_batchnorm_step_counters_are_bumped_once_per_layer_call(dev):
+    """_ops.deferred_batch_counters: the counters collected during a forward pass move by exactly one per BatchNorm call (one
+    multi-tensor add at exit), like nn.BatchNorm1d's own `num_batches_tracked += 1`; nothing moves in eval mode."""
+    from pygho_amd import synth
+    from pygho_amd.ngnn import SpModel
+    model = SpModel(1, 2, 64, act_dtype=torch.bfloat16).to(dev)
+    dd = synth.to_datadict(synth.make_batch(16, "zinc", seed=2), dev)
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+    assert bns and all(int(b.num_batches_tracked) == 0 for b in bns)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        model(dd)
+        model(dd)
+    assert all(int(b.num_batches_tracked) == 2 for b in bns)
+    model.eval()
+    with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+        model(dd)
+    assert all(int(b.num_batches_tracked) == 2 for b in bns)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_pair_product_matches_elementwise_chain(dev, dtype):
     """tuple initialisation left[root] * right[node] * val as one three-operand kernel vs the unpooling + elementwise

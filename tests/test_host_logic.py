@@ -154,3 +154,20 @@ def test_parsekey_and_parseop():
         parseop("B")
     with pytest.raises(NotImplementedError):
         parsekey("X___B___1___X___0")
+
+
+def test_optimizer_steps_invalidate_the_cast_arenas():
+    """the 16-bit parameter copies of pygho_amd.blocks are invalidated by EVERY optimizer step (global post-step hook): fused
+    optimizers update parameters without moving their version counters, so versions alone cannot tell (tests/test_gpu_sparse.py
+    checks the copies themselves on the device)"""
+    import torch
+    from pygho_amd import blocks
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    for opt in (torch.optim.SGD([p], lr=0.1), torch.optim.AdamW([p], lr=0.1)):
+        before = blocks._ARENA_EPOCH[0]
+        opt.step()
+        assert blocks._ARENA_EPOCH[0] > before
+    before = blocks._ARENA_EPOCH[0]
+    blocks.invalidate_cast_arenas()
+    assert blocks._ARENA_EPOCH[0] == before + 1
