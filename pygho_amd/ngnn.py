@@ -72,7 +72,8 @@ class InputEncoderSp(nn.Module):
         out["x"] = self._cast(self.x_encoder(datadict["x"].flatten()))
         out["A"] = datadict["A"].tuplewiseapply(lambda v: self._cast(self.ea_encoder(v)))
         if defer_tuplefeat:
-            out["X_table"] = self._cast(self.tuplefeat_encoder.weight)
+            w = self.tuplefeat_encoder.weight                 # the table itself: its 16-bit copy comes from the cast arena
+            out["X_table"] = w if self.act_dtype is None else _ops.cast_param(w, self.act_dtype)
         else:
             out["X"] = datadict["X"].tuplewiseapply(lambda v: self._cast(self.tuplefeat_encoder(v)))
         return out
