@@ -144,6 +144,65 @@ def test_ngnn_model_matches_reference_model(dev):
             np.testing.assert_allclose(N(after[k[6:]]), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("dtype,optimizer", [(None, "adamw_fused"), (None, "adamw_foreach"), (None, "sgd_fused"),
+                                             (torch.bfloat16, "adamw_fused"), (torch.bfloat16, "adamw_foreach")])
+def test_ngnn_training_trajectory_matches_the_host_port(dev, dtype, optimizer):
+    """SEVERAL training steps, not one: pygho_amd.ngnn.SpModel on the HIP path against the reference's ATen op sequence on the
+    host (oracle/aten_port.NGNNPort, itself pinned to the reference model's golden outputs in tests/test_oracle_golden.py), same
+    initial state_dict, same 48-graph batch, AdamW(lr 1e-3) in torch's fused and foreach forms and fused SGD(lr 1e-2).  f32: the
+    loss of every step to 1e-4; under SGD also every parameter and buffer after 6 steps to 1e-4 of its tensor's largest entry
+    (under Adam the biases in front of a BatchNorm -- exact gradient zero, computed gradient rounding noise -- receive +-lr
+    updates whose sign is that noise's, so parameters are only compared under SGD).  bf16 activations (f32 masters): the loss
+    trajectory to 2 % -- a run whose 16-bit weight copies do not follow the optimizer (round 3's arena bug) fails this."""
+    from oracle import aten_port as P
+    from pygho_amd import synth
+    from pygho_amd.ngnn import SpModel
+    key = "X___X___1___A___0"
+    hb = synth.make_batch(48, "zinc", seed=23)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    torch.manual_seed(4)
+    model = SpModel(1, 3, 64, act_dtype=dtype)
+    port = P.NGNNPort(64, 3)
+    res = port.load_state_dict({P.port_key(k): v.clone() for k, v in model.state_dict().items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model = model.to(dev).train()
+    port.train()
+    dd = synth.to_datadict(hb, dev)
+    host = (t(hb.x), t(hb.edge_attr), t(hb.tupleid), t(hb.tuplefeat), t(hb.acd[key]), t(hb.batch), hb.num_graphs)
+    y_host = t(hb.y).unsqueeze(-1)
+    if optimizer == "sgd_fused":
+        opt_d, opt_h = torch.optim.SGD(model.parameters(), lr=1e-2, fused=True), torch.optim.SGD(port.parameters(), lr=1e-2)
+    else:
+        opt_d = torch.optim.AdamW(model.parameters(), lr=1e-3, **({"fused": True} if optimizer == "adamw_fused" else {"foreach": True}))
+        opt_h = torch.optim.AdamW(port.parameters(), lr=1e-3)
+    steps = 6
+    got, exp = [], []
+    for _ in range(steps):
+        opt_d.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype is not None):
+            pred = model(dd)
+        loss = torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float())
+        loss.backward()
+        opt_d.step()
+        got.append(float(loss.detach()))
+        opt_h.zero_grad()
+        lh = torch.nn.functional.l1_loss(y_host, port(*host))
+        lh.backward()
+        opt_h.step()
+        exp.append(float(lh.detach()))
+    assert exp[-1] < 0.97 * exp[0], f"the host port does not learn on this batch: {exp}"
+    if dtype is None:
+        np.testing.assert_allclose(got, exp, rtol=1e-4, err_msg="loss trajectory")
+        if optimizer == "sgd_fused":
+            after = {P.port_key(k): v for k, v in model.state_dict().items()}
+            for k, v in port.state_dict().items():
+                if v.dtype.is_floating_point:
+                    scale = max(float(v.abs().max()), 1e-3)
+                    np.testing.assert_allclose(N(after[k]) / scale, v.numpy() / scale, rtol=0, atol=1e-4, err_msg=k)
+    else:
+        np.testing.assert_allclose(got, exp, rtol=0.02, err_msg="loss trajectory (bf16 activations)")
+
+
 def _sun_check(layer, g, name, A_of, X_of, av, xv, dd, dev, fn="forward", amask=1.0):
     xv, av = xv.clone().requires_grad_(True), av.clone().requires_grad_(True)
     res = getattr(layer, fn)(A_of(av), X_of(xv), dd)
