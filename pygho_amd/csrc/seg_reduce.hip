@@ -15,6 +15,8 @@
 //     output rows; edge rows belong to one graph) is captured by L1/L2;
 //   * products are rounded before accumulation and summed in message order,
 //     so f32 sums are bit-identical to the sequential CPU oracle.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace pygho {
@@ -408,6 +410,26 @@ static inline int segs_per_pass(int64_t n_seg, int log2g) {
   if (even < spp) spp = even;        // scarce segments: spread them over the whole chip
   if (spp < gw) spp = gw;
   if (spp > kSegsPerPass) spp = kSegsPerPass;
+  // A few passes per wavefront: the launch takes ceil(passes per wavefront) rounds while the work is passes per wavefront.  The
+  // by-row gradient of the tuple initialisation and the subgraph pooling at 8192 ZINC graphs (188 744 segments of ~9 messages):
+  // 16 segments per pass = 1.44 passes per wavefront, i.e. two rounds for 1.44 rounds of work; 12 per pass = 1.92.  Take the
+  // segment count per pass (a multiple of the lane groups) that fills the last round best; ties go to the larger pass.
+  static const bool balance = [] { const char* e = getenv("PYGHO_SPP_BALANCE"); return !(e && e[0] == '0'); }();
+  if (balance && spp > gw) {
+    const int waves_per_block = kBlock / kWave;
+    double best = -1.0;
+    int64_t pick = spp;
+    for (int64_t c = spp; c >= gw; c -= gw) {
+      const int64_t passes = ceil_div(n_seg, c);
+      int64_t grid = ceil_div(passes, waves_per_block);
+      if (grid > kMaxGrid) grid = kMaxGrid;
+      const double ppw = (double)passes / (double)(grid * waves_per_block);
+      if (ppw >= 6.0 && c == spp) break;                 // many rounds: the tail is small, keep the measured sweet spot
+      const double eff = ppw / (double)(int64_t)(ppw + 0.999999);
+      if (eff > best + 0.03) { best = eff; pick = c; }
+    }
+    spp = pick;
+  }
   return (int)spp;
 }
 
