@@ -186,7 +186,9 @@ def require_device(*tensors) -> torch.device:
 
 
 def ptr(t: Optional[torch.Tensor]):
-    return None if t is None else c_void_p(t.data_ptr())
+    """device address for a `void*` parameter: a plain int (ctypes converts ints and None for c_void_p argtypes itself; wrapping
+    every address in a c_void_p object first cost 0.2 us x ~260 addresses per training step)"""
+    return None if t is None else t.data_ptr()
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -196,8 +198,8 @@ def stream_ptr(device: torch.device):
     """torch's current stream on `device` as the raw hipStream_t the C ABI takes (the private raw getter when this torch has it:
     0.2 us instead of the 1.9 us it takes to build a torch.cuda.Stream object per launch)"""
     if _raw_stream is not None:
-        return c_void_p(_raw_stream(device.index if device.index is not None else torch.cuda.current_device()))
-    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def dtype_code(t: torch.Tensor) -> int:
