@@ -437,22 +437,34 @@ extern "C" int pygho_bn_bwd_fold_sums(float* sum_a, float* sum_b, const float* w
 
 // out[j] = sum_b in[b * n + j]: per-workgroup partial results (weight-gradient slabs, column sums) -> one.  Coalesced along j,
 // the block range split over the 4 waves of a workgroup and combined through LDS in a fixed order (deterministic).
+#ifndef PYGHO_SUM_BLOCKS_UNROLL
+#define PYGHO_SUM_BLOCKS_UNROLL 16
+#endif
 namespace pygho {
 __global__ __launch_bounds__(kBlock) void sum_blocks_kernel(float* __restrict__ out, const float* __restrict__ in, int64_t nblk,
                                                             int64_t n) {
   __shared__ float red[kBlock / kWave][kWave];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t j = (int64_t)blockIdx.x * kWave + lane;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // U independent partial sums per lane = U loads in flight per wavefront: the launch is a few hundred wavefronts reading 256-byte
+  // pieces (the weight-gradient slabs of 512 workgroups: 34 MB), 4 in flight gave 2.9 TB/s
+  constexpr int U = PYGHO_SUM_BLOCKS_UNROLL;
+  float acc[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) acc[u] = 0.f;
   if (j < n) {
     int64_t b = wave;
-    for (; b + 3 * (kBlock / kWave) < nblk; b += 4 * (kBlock / kWave)) {
+    for (; b + (U - 1) * (kBlock / kWave) < nblk; b += U * (kBlock / kWave)) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] += in[(b + u * (kBlock / kWave)) * n + j];
+      for (int u = 0; u < U; ++u) acc[u] += in[(b + u * (kBlock / kWave)) * n + j];
     }
     for (; b < nblk; b += kBlock / kWave) acc[0] += in[b * n + j];
   }
-  red[wave][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+  for (int w = U / 2; w >= 1; w /= 2)                    // fixed pairwise tree: deterministic
+#pragma unroll
+    for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
+  red[wave][lane] = acc[0];
   __syncthreads();
   if (wave == 0 && j < n) out[j] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
