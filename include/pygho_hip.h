@@ -125,6 +125,21 @@ int pygho_seg_gather_mul_reduce_tiled(void* out, const void* addend, const void*
                                       const int32_t* tile_cnt, const int32_t* tiles, int64_t n_seg, int64_t d, int64_t lhs_rows,
                                       int64_t rhs_rows, int64_t win_rows, int dtype, int aggr, void* stream);
 
+/* Backward of the tuple initialisation out[t] = (left[row[t]] * right[col[t]]) * tab[v[t]] (example/minimal.py:30-33 embedding lookup of
+ * the tuple feature, :62-67 the two unpoolings and products; what autograd derives for left, right and the table) in ONE pass over
+ * the output gradient g, for tuple sets sorted by (row, col) that contain (j, i) with every (i, j) and carry a symmetric feature:
+ *   g_left[i] = sum_{t=(i,j)} (g[t] * tab[v[t]]) * right[j],  g_right[i] = sum_{t=(i,j)} (g[mirror[t]] * tab[v[t]]) * left[j],
+ *   tab_ws[b][k] = workgroup b's share of sum_{t: v[t]=k} (g[t] * left[i]) * right[j]   (f32; fold with pygho_sum_blocks)
+ * seg_ptr: (n_nodes + 1) CSR pointers of the tuples by row; col, vidx, mirror: (n_tuples) int32, mirror[t] = position of tuple
+ * (col[t], row[t]).  Every v[t] must be below pygho_pair_bwd_types().  tab_ws: (pygho_pair_bwd_blocks(n_nodes, d, dtype),
+ * pygho_pair_bwd_types(), d) floats.  g_left / g_right are bit-identical to pygho_seg_triple_product over the by-row grouping and
+ * the stable by-column grouping.  bf16 / f16, row bytes a multiple of 16 up to 1024. */
+int pygho_pair_bwd_types(void);
+int pygho_pair_bwd_blocks(int64_t n_nodes, int64_t d, int dtype);
+int pygho_pair_bwd(void* g_left, void* g_right, float* tab_ws, const void* g, const void* left, const void* right, const void* tab,
+                   const int32_t* seg_ptr, const int32_t* col, const int32_t* vidx, const int32_t* mirror, int64_t n_nodes,
+                   int64_t n_tuples, int64_t d, int dtype, void* stream);
+
 /* The same reduction with the layer MLP's BatchNorm + activation applied to one operand AS IT IS LOADED:
  *   act_side 1:  out[s] = [addend[s] +] (+) act(lhs[li] * act_scale + act_shift) * rhs[ri]
  *   act_side 2:  out[s] = [addend[s] +] (+) lhs[li] * act(rhs[ri] * act_scale + act_shift)

@@ -36,6 +36,9 @@ PROTOTYPES = {
     "pygho_seg_tile_chunk": (I, []),
     "pygho_seg_tile_plan": (I, [P, P, P, P, L, L, P]),
     "pygho_seg_gather_mul_reduce_tiled": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, I, I, P]),
+    "pygho_pair_bwd_types": (I, []),
+    "pygho_pair_bwd_blocks": (I, [L, L, I]),
+    "pygho_pair_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, L, I, P]),
     "pygho_seg_gather_mul_reduce_act": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, L, L, I, I, P]),
     "pygho_seg_triple_product": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, I, I, P]),
     "pygho_seg_sum_f32out": (I, [P, P, P, P, L, L, L, I, P]),

@@ -629,6 +629,69 @@ def spmm_values(val: Optional[Tensor], X: Tensor, src: Tensor, tar: Tensor, n_ta
     return out.reshape((n_tar,) + dense)
 
 
+USE_PAIR_BWD = os.environ.get("PYGHO_PAIR_BWD", "1") != "0"     # one-pass backward of the tuple initialisation on symmetric tuple sets
+
+
+def pair_mirror(row32: Tensor, col32: Tensor, vidx32: Tensor, n_nodes: int) -> Optional[Tensor]:
+    """mirror[t] = position of tuple (col[t], row[t]) for a tuple list sorted by (row, col) that is SYMMETRIC -- (j, i) present with
+    every (i, j), equal feature on both, features below `pygho_pair_bwd_types()` -- else None.  K-hop tuple sets with a
+    shortest-path-distance feature (hodata/SpTupleSampler.py:91-126) are.  One host synchronisation per tuple pattern, memoised on
+    the index object; `SpModel.prepare` takes it off the training step for batches collated ahead."""
+    memo = getattr(row32, "_pygho_mirror", None)
+    if memo is not None and memo[0] is col32 and memo[1] is vidx32 and memo[2] == n_nodes:
+        return memo[3]
+    n = row32.numel()
+    res = None
+    if 0 < n < (1 << 31) and col32.numel() == n and vidx32.numel() == n:
+        nt = int(lib().pygho_pair_bwd_types())
+        key = row32.to(torch.int64) * n_nodes + col32
+        key_t = col32.to(torch.int64) * n_nodes + row32
+        pos = torch.searchsorted(key, key_t).clamp_(max=n - 1)
+        lo, hi = torch.aminmax(vidx32)
+        ok = ((key[1:] > key[:-1]).all() & (key[pos] == key_t).all() & (vidx32[pos] == vidx32).all() & (lo >= 0) & (hi < nt)
+              & (col32.max() < n_nodes))
+        if _fetch(ok.to(torch.int32).reshape(1))[0]:
+            res = pos.to(torch.int32)
+    try:
+        row32._pygho_mirror = (col32, vidx32, n_nodes, res)
+    except Exception:
+        pass
+    return res
+
+
+def pair_bwd(g: Tensor, left: Tensor, right: Tensor, tab: Tensor, seg_ptr: Tensor, col32: Tensor, vidx32: Tensor, mirror: Tensor):
+    """(g_left, g_right, g_tab) of `pair_product` with a table operand in one pass over g (`pygho_pair_bwd`)."""
+    dev = require_device(g, left, right, tab, seg_ptr, col32, vidx32, mirror)
+    n_nodes, d = left.shape[0], left.shape[1]
+    g_left, g_right = torch.empty_like(left), torch.empty_like(right)
+    nt = int(lib().pygho_pair_bwd_types())
+    nblk = int(lib().pygho_pair_bwd_blocks(n_nodes, d, dtype_code(g)))
+    ws = torch.empty((nblk, nt * d), dtype=torch.float32, device=dev)
+    timer = LaunchTimer.active
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(dev))
+    check(lib().pygho_pair_bwd(ptr(g_left), ptr(g_right), ptr(ws), ptr(g), ptr(left), ptr(right), ptr(tab), ptr(seg_ptr), ptr(col32),
+                               ptr(vidx32), ptr(mirror), n_nodes, col32.numel(), d, dtype_code(g), stream_ptr(dev)), "pair_bwd")
+    if timer is not None:
+        e1.record(torch.cuda.current_stream(dev))
+        nbytes = g.element_size() * d * (g.shape[0] + 4 * n_nodes) + 12 * col32.numel() + 4 * (n_nodes + 1) + 4 * ws.numel()
+        timer.records.append((f"pair_bwd[{str(g.dtype).split('.')[-1]}]", nbytes, e0, e1))
+    # fold the workgroups' slabs: a (blocks, nt * d) array is only nt * d / 64 workgroups wide for pygho_sum_blocks, so groups of 64 slabs
+    # are folded side by side first
+    width, fan = nt * d, 64
+    if nblk % fan == 0 and nblk > fan:
+        mid = torch.empty((fan * width,), dtype=torch.float32, device=dev)
+        check(lib().pygho_sum_blocks(ptr(mid), ptr(ws), nblk // fan, fan * width, stream_ptr(dev)), "sum_blocks")
+        ws, nblk = mid, fan
+    tot = torch.empty((width,), dtype=torch.float32, device=dev)
+    check(lib().pygho_sum_blocks(ptr(tot), ptr(ws), nblk, width, stream_ptr(dev)), "sum_blocks")
+    g_tab = torch.zeros((tab.shape[0], d), dtype=tab.dtype, device=dev)          # table rows without a tuple get no gradient
+    k = min(nt, tab.shape[0])
+    g_tab[:k] = tot.view(nt, d)[:k].to(tab.dtype)
+    return g_left, g_right, g_tab
+
+
 class _PairProduct(torch.autograd.Function):
     """out[t] = (left[row[t]] * right[col[t]]) * val[vidx[t]] (vidx None = t): the tuple initialisation of
     example/minimal.py:62-67 (two unpoolings of node features onto the tuple pattern and two elementwise products; with
@@ -652,6 +715,15 @@ class _PairProduct(torch.autograd.Function):
         g = g.contiguous()
         n = row32.numel()
         g_left = g_right = g_val = None
+        if (USE_PAIR_BWD and vidx32 is not None and by_row[0].perm is None and g.dtype in (torch.bfloat16, torch.float16)
+                and left.dtype == right.dtype == val.dtype == g.dtype and left.shape == right.shape and g.shape[1] == left.shape[1]
+                and (g.shape[1] * 2) % 16 == 0 and g.shape[1] * 2 <= 1024 and left.is_contiguous() and right.is_contiguous()
+                and val.is_contiguous()):
+            mirror = pair_mirror(row32, col32, vidx32, left.shape[0])
+            if mirror is not None:
+                g_left, g_right, g_val = pair_bwd(g, left, right, val, by_row[0].seg_ptr, col32, vidx32, mirror)
+                return (g_left if ctx.needs_input_grad[0] else None, g_right if ctx.needs_input_grad[1] else None,
+                        g_val if ctx.needs_input_grad[2] else None, None, None, None, None, None, None)
         if ctx.needs_input_grad[0]:
             p, col_p, v_p = by_row
             g_left = seg_triple(p.n_seg, g, val, right, p.seg_ptr, p.perm, v_p if vidx32 is not None else p.perm, col_p)

@@ -782,6 +782,67 @@ def test_pair_product_with_embedding_table(dev, dtype):
     assert torch.equal(out, _ops.pair_product(left, right, table[feat].contiguous(), row, col))   # same kernel, same rounding
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d", [128, 64, 96])
+def test_pair_product_one_pass_backward_equals_three_pass(dev, dtype, d):
+    """pygho_pair_bwd (one pass over the output gradient on symmetric tuple sets) against the three launches of
+    pygho_seg_triple_product it replaces: the node-level gradients bit for bit (same products, same summation order), the table
+    gradient to f32 summation-order tolerance and against autograd in f64; the mirror index of the K-hop tuple set is an involution;
+    an ASYMMETRIC tuple set (one tuple dropped) is detected and keeps the three-launch path."""
+    from pygho_amd import _ops, synth
+    hb = synth.make_batch(64, "zinc", seed=9)
+    n = hb.num_nodes
+    row, col = T(hb.tupleid[0], dev), T(hb.tupleid[1], dev)
+    feat = T(hb.tuplefeat.reshape(-1), dev)
+    torch.manual_seed(5)
+    mk = lambda r: torch.randn(r, d, device=dev).to(dtype)
+    left, right, table, w = mk(n), mk(n), mk(16), torch.randn(hb.num_tuples, d, device=dev).to(dtype)
+
+    def grads(flag, row=row, col=col, feat=feat, w=w):
+        saved = _ops.USE_PAIR_BWD
+        _ops.USE_PAIR_BWD = flag
+        try:
+            a = [t.clone().requires_grad_(True) for t in (left, right, table)]
+            timer = _ops.LaunchTimer()
+            with timer:
+                out = _ops.pair_product(a[0], a[1], a[2], row, col, feat)
+                out.backward(w)
+            torch.cuda.synchronize()
+            return [t.grad for t in a], set(timer.summary())
+        finally:
+            _ops.USE_PAIR_BWD = saved
+
+    (gl1, gr1, gt1), tags1 = grads(True)
+    (gl3, gr3, gt3), tags3 = grads(False)
+    assert any(k.startswith("pair_bwd") for k in tags1) and not any(k.startswith("pair_bwd") for k in tags3)
+    assert torch.equal(gl1, gl3), "g_left must be bit-identical to the by-row reduction"
+    assert torch.equal(gr1, gr3), "g_right must be bit-identical to the by-column reduction"
+    s = float(gt3.float().abs().max())
+    torch.testing.assert_close(gt1.float() / s, gt3.float() / s, rtol=0, atol=2.0 ** -7)
+    assert float(gt1[4:].abs().max()) == 0.0                                   # features 0..3 only: the other table rows get nothing
+    b = [t.double().clone().requires_grad_(True) for t in (left, right, table)]
+    (b[0][row] * b[1][col] * b[2][feat]).backward(w.double())
+    for got, ref in ((gl1, b[0].grad), (gr1, b[1].grad), (gt1, b[2].grad)):
+        sc = float(ref.abs().max())
+        torch.testing.assert_close(got.double() / sc, ref / sc, rtol=0, atol=2.0 ** -7)
+    r32, c32, f32 = _ops.narrow_i32(row), _ops.narrow_i32(col), _ops.narrow_i32(feat)
+    mir = _ops.pair_mirror(r32, c32, f32, n)
+    assert mir is not None and torch.equal(mir[mir.long()], torch.arange(hb.num_tuples, device=dev, dtype=torch.int32))
+    assert torch.equal(r32[mir.long()], c32) and torch.equal(c32[mir.long()], r32)
+    # asymmetric: drop one off-diagonal tuple
+    keep = torch.ones(hb.num_tuples, dtype=torch.bool, device=dev)
+    keep[int((row != col).nonzero()[0])] = False
+    row2, col2, feat2, w2 = row[keep].contiguous(), col[keep].contiguous(), feat[keep].contiguous(), w[keep].contiguous()
+    assert _ops.pair_mirror(_ops.narrow_i32(row2), _ops.narrow_i32(col2), _ops.narrow_i32(feat2), n) is None
+    (gl, gr, gt), tags = grads(True, row2, col2, feat2, w2)
+    assert not any(k.startswith("pair_bwd") for k in tags)
+    b = [t.double().clone().requires_grad_(True) for t in (left, right, table)]
+    (b[0][row2] * b[1][col2] * b[2][feat2]).backward(w2.double())
+    for got, ref in ((gl, b[0].grad), (gr, b[1].grad), (gt, b[2].grad)):
+        sc = float(ref.abs().max())
+        torch.testing.assert_close(got.double() / sc, ref / sc, rtol=0, atol=2.0 ** -7)
+
+
 @pytest.mark.parametrize("kind", ["zinc", "i2"])
 def test_device_collate_bit_exact(dev, kind):
     """on-device mini-batch collation from the int32 graph store == host block-diagonal collate (hodata/SpData.py:56-112
