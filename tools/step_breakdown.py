@@ -28,6 +28,7 @@ FAM = [
     ("Linear + BatchNorm + SiLU (rowblock_linear<1,2>)", "rowblock_linear_kernel<pygho::bf16, 128, 1, 2>", 6, 0, S, S, WR_BIG),
     ("BatchNorm statistics of the Linear's output (rowblock_linear<0,0>)", "rowblock_linear_kernel<pygho::bf16, 128, 0, 0>", 6, 0, S, 0, WR_BIG),
     ("tuple initialisation forward (unit_triple)", "unit_triple_kernel<pygho::bf16", 1, 0, 12 * T, S, WR_SMALL),
+    ("tuple initialisation backward in one pass on symmetric tuple sets (pair_bwd)", "pair_bwd_kernel<pygho::bf16>", 1, S, S + 12 * T, 2 * NODES * row, WR_SMALL),
     ("tuple initialisation backward, by row / by column (seg_gmr_fast, three operands)", "seg_gmr_fast_kernel<pygho::bf16, 0, 0, false, true, false, true, 0>", 2, S / 2, S / 2 + 12 * T, NODES * row, WR_SMALL),
     ("tuple initialisation backward, feature table (seg_gmr_fast, three operands, f32 partials)", "seg_gmr_fast_kernel<pygho::bf16, 0, 0, false, true, true, true, 0>", 1, S, 12 * T, 0, WR_SMALL),
     ("subgraph mean pooling (seg_gmr_fast<bf16,MEAN,LHS>)", "seg_gmr_fast_kernel<pygho::bf16, 1, 1, false, true, false, false, 0>", 1, 0, S + 4 * NODES, NODES * row, WR_SMALL),
