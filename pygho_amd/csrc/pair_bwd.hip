@@ -19,9 +19,7 @@
 
 namespace pygho {
 
-#ifndef PYGHO_PB_GRID_CAP
-#define PYGHO_PB_GRID_CAP (256 * 3)        // 152 registers: three workgroups per CU are resident; 768 / 1024 / 1536 / 2048 workgroups: 245 / 304 / 255 / 260 us
-#endif
+// grid = the resident set (bf16, 152 registers: 3 workgroups per CU; 768 / 1024 / 1536 / 2048 workgroups: 245 / 304 / 255 / 260 us)
 constexpr int kPbTypes = 4;                              // tuple-feature values with a register accumulator
 typedef __attribute__((ext_vector_type(4))) unsigned int pb_u4_t;
 __device__ __forceinline__ uint4 pb_u4(pb_u4_t v) { return make_uint4(v[0], v[1], v[2], v[3]); }
@@ -141,7 +139,20 @@ extern "C" int pygho_pair_bwd_blocks(int64_t n_nodes, int64_t d, int dtype) {
   const int chunks = (int)(d * es / 16);
   int log2g = 0;
   while ((1 << log2g) < chunks && log2g < 6) ++log2g;
-  int gx = grid_for(n_nodes, kBlock >> log2g, PYGHO_PB_GRID_CAP);
+  // resident workgroups per CU from the runtime (bf16: 152 registers -> 3, f16: 170 -> 2): a grid of exactly the resident set has no
+  // second, partially filled round
+  static int per_cu[2][64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& occ = per_cu[dtype == PYGHO_F16 ? 1 : 0][dev & 63];
+  if (occ == 0) {
+    const size_t lds = (size_t)(kBlock >> log2g) * kPbTypes * d * sizeof(float);
+    int n = 0;
+    const hipError_t e = dtype == PYGHO_F16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pair_bwd_kernel<f16>, kBlock, lds)
+                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pair_bwd_kernel<bf16>, kBlock, lds);
+    occ = (e == hipSuccess && n >= 1 && n <= 8) ? n : 3;
+  }
+  int gx = grid_for(n_nodes, kBlock >> log2g, 256 * occ);
   if (gx > 8) gx = (gx + 7) & ~7;
   return gx;
 }
