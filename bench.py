@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--distinct", type=int, default=1024, help="distinct graphs generated per rank (tiled up to --graphs)")
+    ap.add_argument("--distinct", type=int, default=8192,
+                    help="distinct graphs generated per rank (tiled up to --graphs when smaller; the default generates every graph of the batch)")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "foreach"], help="AdamW implementation (same update rule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-regimes", action="store_true", help="skip the fresh-batch / small-batch side measurements")
@@ -60,58 +61,101 @@ def parse():
     ap.add_argument("--global-stream", action="store_true",
                     help="N > 1: ONE global batch of N x --graphs graphs (same seed on every rank), sharded into contiguous graph "
                          "ranges balanced by message count (parallel.shard_ranges) instead of one independent batch per rank")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of the N > 1 run: nccl (= RCCL over xGMI, the product path) or gloo (host-staged; with "
+                         "--ranks-share-gpu it lets the N > 1 branch execute on a one-GPU box)")
+    ap.add_argument("--ranks-share-gpu", action="store_true",
+                    help="every rank computes on cuda:0 (RCCL refuses two ranks on one device: use --dist-backend gloo).  A functional run of "
+                         "the N > 1 code path, not a scaling measurement")
     ap.add_argument("--cpu-graphs", type=int, default=128)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=40.0, help="bound of the CPU baseline's four legs together (each stops early at a quarter of it)")
     return ap.parse_args()
 
 
+def host_cpu():
+    """CPU model and PHYSICAL core count of this host from `lscpu`, plus the CPUs this process may run on."""
+    import subprocess
+    info = {"model": None, "physical_cores": None, "logical_cpus": os.cpu_count(),
+            "usable_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()}
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=20).stdout
+        kv = {l.split(":", 1)[0].strip(): l.split(":", 1)[1].strip() for l in txt.splitlines() if ":" in l}
+        info["model"] = kv.get("Model name")
+        info["physical_cores"] = int(kv["Core(s) per socket"]) * int(kv["Socket(s)"])
+        info["threads_per_core"] = int(kv.get("Thread(s) per core", "1"))
+    except Exception as e:                        # lscpu missing: the counts above still stand
+        info["lscpu_error"] = f"{type(e).__name__}: {e}"
+    return info
+
+
 def cpu_baseline(args, seed):
-    """reference op sequence on the host cores: same 6-layer NGNN train step, f32, bounded sample."""
+    """The reference's op sequence on the host cores, by BASELINE.md section 3's protocol: the same 6-layer NGNN train step (f32,
+    oracle/aten_port.py = the ATen sequence of pygho/backend/Spspmm.py:307-321) on the same seeded generator, with
+    torch.set_num_threads(1) and with ALL physical cores, median of 10 steps after 2 warm-ups, on the reference's batch size (128
+    graphs, example/minimal.py:119) and -- bounded -- on a 1024-graph batch.  A leg that would exceed its share of --cpu-seconds
+    stops early and says how many steps its median is over."""
     from oracle import aten_port as P
     from pygho_amd import synth
-    hb = synth.make_batch(args.cpu_graphs, "zinc", seed=seed)
+    cpu = host_cpu()
+    phys = cpu["physical_cores"] or cpu["logical_cpus"] or 1
+    all_cores = max(1, min(phys, cpu["usable_cpus"] or phys))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-    x, ea, tid, tf = t(hb.x), t(hb.edge_attr), t(hb.tupleid), t(hb.tuplefeat)
-    acd, batch, y = t(hb.acd[KEY]), t(hb.batch), t(hb.y)
-    torch.manual_seed(0)
-    model = P.NGNNPort(args.hidden, args.layers)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    legs = []
 
-    def step():
-        opt.zero_grad()
-        pred = model(x, ea, tid, tf, acd, batch, hb.num_graphs)
-        loss = torch.nn.functional.l1_loss(y.unsqueeze(-1), pred)
-        loss.backward()
-        opt.step()
-
-    # ATen's intra-op threading does not scale on these small scatter-heavy ops (the survey container was
-    # slower with 8 threads than with 1): time 1 thread and a moderate pool, report the faster.
-    avail = os.cpu_count() or 1
-    results = []
-    for threads in sorted({1, min(16, avail)}):
+    def leg(graphs, threads, warm, runs, budget_s):
+        hb = synth.make_batch(graphs, "zinc", seed=seed)
+        x, ea, tid, tf = t(hb.x), t(hb.edge_attr), t(hb.tupleid), t(hb.tuplefeat)
+        acd, batch, y = t(hb.acd[KEY]), t(hb.batch), t(hb.y)
+        torch.manual_seed(0)
+        model = P.NGNNPort(args.hidden, args.layers)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
         torch.set_num_threads(threads)
-        step()                               # warm-up
-        n, t0 = 0, time.perf_counter()
-        while n < 2 or (time.perf_counter() - t0 < args.cpu_seconds / 2 and n < 200):
+
+        def step():
+            opt.zero_grad()
+            pred = model(x, ea, tid, tf, acd, batch, hb.num_graphs)
+            loss = torch.nn.functional.l1_loss(y.unsqueeze(-1), pred)
+            loss.backward()
+            opt.step()
+
+        t_leg = time.perf_counter()
+        for _ in range(warm):
             step()
-            n += 1
-        results.append((hb.num_graphs * n / (time.perf_counter() - t0), threads, n, time.perf_counter() - t0))
-    rate, cores, n, dt = max(results)
-    torch.set_num_threads(cores)
-    # forward-only spspmm rate for the msg-edges figure
-    Xv, Av = torch.randn(hb.num_tuples, args.hidden), torch.randn(hb.num_edges, args.hidden)
-    P.spspmm_values(Xv, Av, acd, hb.num_tuples)
-    reps, t1 = 0, time.perf_counter()
-    while reps < 3 or time.perf_counter() - t1 < 3.0:
-        P.spspmm_values(Xv, Av, acd, hb.num_tuples)
-        reps += 1
-    dts = time.perf_counter() - t1
-    return {"value": rate, "unit": "graphs/s", "cores": cores, "kind": "port",
-            "all_thread_counts": {str(t): r for r, t, _, _ in results},
-            "sample": f"{n} train steps of the same {args.layers}-layer NGNN (h={args.hidden}, f32) on a "
-                      f"{hb.num_graphs}-graph ZINC-shape batch ({hb.num_messages(KEY)} msg-edges), torch-CPU ATen op "
-                      f"sequence of pygho/backend/Spspmm.py:307-321 (oracle/aten_port.py), {cores} threads, {dt:.1f} s",
-            "spspmm_fwd_msg_edges_per_sec": hb.num_messages(KEY) * reps / dts}
+        times = []
+        while len(times) < runs and (len(times) < 1 or time.perf_counter() - t_leg < budget_s):
+            t0 = time.perf_counter()
+            step()
+            times.append(time.perf_counter() - t0)
+        med = float(np.median(times))
+        legs.append({"graphs": hb.num_graphs, "msg_edges": hb.num_messages(KEY), "threads": threads, "warmups": warm,
+                     "steps_in_median": len(times), "median_s_per_step": med, "graphs_per_s": hb.num_graphs / med})
+        return hb, acd
+
+    share = args.cpu_seconds / 4.0
+    hb128, acd128 = leg(args.cpu_graphs, 1, 2, 10, share)
+    leg(args.cpu_graphs, all_cores, 2, 10, share)
+    leg(1024, all_cores, 1, 3, share)
+    leg(1024, 1, 0, 1, share)                 # bounded: ONE un-warmed step (tens of seconds on one core); labelled by its counts
+    best = max(legs, key=lambda r: r["graphs_per_s"])
+    torch.set_num_threads(best["threads"])
+    # forward-only spspmm rate for the msg-edges figure (the reference's batch size)
+    Xv, Av = torch.randn(hb128.num_tuples, args.hidden), torch.randn(hb128.num_edges, args.hidden)
+    for _ in range(2):
+        P.spspmm_values(Xv, Av, acd128, hb128.num_tuples)
+    ts = []
+    for _ in range(10):
+        t1 = time.perf_counter()
+        P.spspmm_values(Xv, Av, acd128, hb128.num_tuples)
+        ts.append(time.perf_counter() - t1)
+    return {"value": best["graphs_per_s"], "unit": "graphs/s", "cores": best["threads"], "kind": "port",
+            "cpu_model": cpu["model"], "physical_cores": cpu["physical_cores"], "logical_cpus": cpu["logical_cpus"],
+            "usable_cpus": cpu["usable_cpus"], "protocol": "BASELINE.md section 3: 1 thread and all physical cores, median after warm-ups, f32",
+            "legs": legs,
+            "sample": f"median of {best['steps_in_median']} train steps (after {best['warmups']} warm-ups) of the same {args.layers}-layer NGNN "
+                      f"(h={args.hidden}, f32) on a {best['graphs']}-graph ZINC-shape batch ({best['msg_edges']} msg-edges), torch-CPU ATen op "
+                      f"sequence of pygho/backend/Spspmm.py:307-321 (oracle/aten_port.py), {best['threads']} threads on {cpu['model']} "
+                      f"({cpu['physical_cores']} physical cores); every (batch, threads) leg is in `legs`",
+            "spspmm_fwd_msg_edges_per_sec": hb128.num_messages(KEY) / float(np.median(ts))}
 
 
 def kernel_source_hash() -> str:
@@ -253,7 +297,11 @@ def launch_ranks(args) -> int:
     import socket
     import subprocess
     have = visible_gpu_count()                           # from the environment / sysfs: no runtime call, the parent stays off the GPU
-    if have is not None and have < args.gpus:
+    need = 1 if args.ranks_share_gpu else args.gpus
+    if args.ranks_share_gpu and args.dist_backend == "nccl":
+        print("bench.py: --ranks-share-gpu needs --dist-backend gloo (RCCL refuses two ranks on one device)", file=sys.stderr)
+        return 2
+    if have is not None and have < need:
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
     with socket.socket() as sock:
@@ -278,6 +326,8 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU fallback)"
+    if args.ranks_share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ          # under torch.distributed.run even a single rank goes through RCCL
@@ -289,7 +339,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from pygho_amd import _native, _ops, synth
     from pygho_amd.ngnn import SpModel
@@ -305,7 +358,7 @@ def main():
         # gradient equals the gradient of the global mean loss whatever the shard sizes are.
         from pygho_amd.parallel import shard_ranges
         rng = np.random.default_rng(1000)
-        recs = [synth.make_graph(rng, "zinc", 3, (KEY,)) for _ in range(distinct)] * (times * world)
+        recs = [synth.make_graph(rng, "zinc", 3, (KEY,)) for _ in range(distinct * world)] * times
         lo, hi = shard_ranges([r.acd[KEY].shape[1] for r in recs], world)[rank]
         hb = synth.collate(recs[lo:hi])
         loss_scale = world * hb.num_graphs / len(recs)
@@ -329,6 +382,7 @@ def main():
             pred = model(datadict)
         loss = torch.nn.functional.l1_loss(y, pred.float())
         (loss if loss_scale == 1.0 else loss * loss_scale).backward()
+        sync.mark_backward_end()
         sync.sync()
         opt.step()
         return loss
@@ -347,7 +401,7 @@ def main():
         for _ in range(args.steps):
             loss = step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = elapsed_own = time.perf_counter() - t0
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -355,6 +409,15 @@ def main():
         gg = torch.tensor([hb.num_graphs, hb.num_messages(KEY)], dtype=torch.float64, device=dev)
         dist.all_reduce(gg, op=dist.ReduceOp.SUM)
         total_graphs, total_msgs = float(gg[0].item()), float(gg[1].item())
+        per_rank = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([hb.num_graphs, elapsed_own], dtype=torch.float64, device=dev))
+        per_rank = [[int(t[0].item()), float(t[1].item())] for t in per_rank]
+        # after the exchange every rank must hold the SAME averaged gradient, bit for bit: element-wise max and min over the ranks agree
+        hi_, lo_ = sync.flat.clone(), sync.flat.clone()
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        grads_equal = bool(torch.equal(hi_, lo_)) and bool(torch.isfinite(hi_).all()) and float(hi_.abs().max()) > 0
+        overlap_rep = sync.overlap_report()
     else:
         total_graphs, total_msgs = float(hb.num_graphs), float(hb.num_messages(KEY))
 
@@ -417,6 +480,9 @@ def main():
             line["collectives"] = {"backend": dist.get_backend(), "allreduce_calls": sync.allreduce_calls,
                                    "allreduce_bytes": sync.flat.numel() * sync.flat.element_size(),
                                    "allreduce_ms": sync.allreduce_ms(), "allreduce_ranges_per_step": len(getattr(sync, "_ranges", [0])),
+                                   "graphs_all_ranks": int(total_graphs), "per_rank_graphs_and_seconds": per_rank,
+                                   "flat_grad_equal_across_ranks": grads_equal, "overlap_last_step": overlap_rep,
+                                   "ranks_share_gpu": bool(args.ranks_share_gpu),
                                    "overlap": "ranges are all-reduced on a side stream as backward completes them (pygho_amd/parallel.py)",
                                    "batch": "global stream sharded by message count" if loss_scale != 1.0 or (args.global_stream and world > 1)
                                    else "one independent batch per rank"}

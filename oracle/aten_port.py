@@ -34,17 +34,23 @@ def spspmm_values(valA, valB, acd: Tensor, n_out: int, aggr: str = "sum") -> Ten
 
 
 def spspmm_values_chunked(valA: Tensor, valB: Tensor, out_idx: Tensor, a_idx: Tensor, b_idx: Tensor, n_out: int, aggr: str = "sum",
-                          chunk: int = 1 << 20) -> Tensor:
+                          chunk: int = 1 << 20, a_rowscale: Tensor = None) -> Tensor:
     """the same value computation (Spspmm.py:309-315: index, index, mul, scatter-reduce) for message counts whose (M, d)
     temporaries do not fit at once: f32 products accumulated with index_add_ chunk by chunk.  index_add_ adds the rows of a chunk in
     index order, so every output row is summed in MESSAGE ORDER exactly like the one-shot scatter_reduce_ (checked against it in
     tests/test_oracle_golden.py); `mean` divides by the message count as scatter_reduce_(include_self=False) does.
-    (out_idx, a_idx, b_idx) = (acd[0], acd[1], acd[2]) for the forward, permuted for the two gradient plans."""
+    (out_idx, a_idx, b_idx) = (acd[0], acd[1], acd[2]) for the forward, permuted for the two gradient plans.
+    `a_rowscale` (f32, one factor per row of valA): every message is a_rowscale[a] * (valA[a] * valB[b]) -- the gradient of `mean`
+    with the division by the count applied PER MESSAGE after the product, which is the association the device kernels use
+    (autograd's own is (g / count) * v: one rounding elsewhere, same value to 1 ulp)."""
     assert aggr in ("sum", "mean") and valA.dtype == torch.float32 and valB.dtype == torch.float32
     out = torch.zeros((n_out, valA.shape[1]), dtype=torch.float32)
     for lo in range(0, out_idx.numel(), chunk):
         sl = slice(lo, lo + chunk)
-        out.index_add_(0, out_idx[sl], valA[a_idx[sl]] * valB[b_idx[sl]])
+        prod = valA[a_idx[sl]] * valB[b_idx[sl]]
+        if a_rowscale is not None:
+            prod = a_rowscale[a_idx[sl]].unsqueeze(1) * prod
+        out.index_add_(0, out_idx[sl], prod)
     if aggr == "mean":
         cnt = torch.bincount(out_idx, minlength=n_out).clamp_min(1).to(torch.float32)
         out = out / cnt.unsqueeze(1)

@@ -199,7 +199,16 @@ class SparseTensor:
         if len(dims) == self.sparse_dim:
             pos = _ops.sorted_match(self._hash(), diag_hash)
             return _ops.gather_rows_matched(self.values, pos)
-        raise NotImplementedError("partial diagonal to dense is not implemented on the HIP backend")
+        # partial diagonal (reference SpTensor.py:337-352; that branch raises TypeError at :346 and would keep one entry per i): the
+        # documented intent -- every entry whose coordinates in `dims` coincide, placed at (kept coordinates), zero elsewhere.  The
+        # kept coordinates of a coalesced pattern are unique, so the scatter below writes every slot at most once.
+        sub = self._diag_to_sparse(dims)
+        sizes = [int(s) for s in sub.shape[:sub.sparse_dim]]
+        assert sub.values is not None, "diag to dense needs values"
+        flat = indicehash_tight(sub.indices, torch.LongTensor(sizes))
+        total = int(np.prod(sizes))
+        dense = _ops.scatter_reduce(sub.values, flat, total, "sum")
+        return dense.reshape(tuple(sizes) + tuple(self.denseshape))
 
     def diag(self, dims: Optional[Iterable[int]], return_sparse: bool = False):
         if isinstance(dims, int):

@@ -202,9 +202,11 @@ def _invalidate_after_optimizer_step(*_args, **_kwargs) -> None:
 
 # Version counters are NOT a reliable staleness signal: the fused multi-tensor optimizers (`torch.optim.AdamW(fused=True)`: one
 # `_fused_adamw_` launch) update the parameters in place WITHOUT moving `p._version` (measured: the arena kept serving the weights
-# of step 0 for a whole training run).  Every optimizer step therefore invalidates every arena (a global post-step hook), and a
-# forward pass under autograd re-casts unconditionally (`ensure_cast_arena`): one `_foreach_copy_` launch per step, which is what
-# the arena is for; the version / address checks remain as the guard for updates between those two events.
+# of step 0 for a whole training run).  Every optimizer step therefore invalidates every arena (a global post-step hook on
+# torch.optim.Optimizer: it fires for every subclass, fused or not): one `_foreach_copy_` launch per step, which is what the arena is
+# for; the version / address checks remain as the guard for updates between two steps.  The copies are NOT rewritten when nothing is
+# known to have changed: autograd saves the arena's views (_ArenaLinearFn, _PairProduct), and a second grad-enabled forward before
+# backward (siamese / contrastive use, a validation pass in between) must not bump their version counters.
 try:
     from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
     _register_step_hook(_invalidate_after_optimizer_step)
@@ -278,9 +280,9 @@ def ensure_cast_arena(module, dtype: Optional[torch.dtype]) -> None:
             # belt and braces next to the version / address checks: a loaded state dict invalidates every copy
             module.register_load_state_dict_post_hook(lambda _m, _keys: invalidate_cast_arenas())
             module.__dict__["_pygho_cast_hook"] = True
-    # under autograd (a training forward pass) every copy is re-cast: whatever updated the parameters since the last pass, with or
-    # without touching their version counters, is seen (see the note at _invalidate_after_optimizer_step)
-    arena.refresh(force=torch.is_grad_enabled())
+    # re-cast what changed: everything after an optimizer step / graph replay / state-dict load (epoch), single parameters after an
+    # in-place update that moved their version counter or storage; nothing otherwise (see the note at _invalidate_after_optimizer_step)
+    arena.refresh()
 
 
 def param_as(p: Tensor, dtype: torch.dtype) -> Tensor:

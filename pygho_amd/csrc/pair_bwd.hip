@@ -15,6 +15,7 @@
 //   * g_tab: NT per-feature accumulators per lane group (features >= NT are refused by the host), kept across the roots a lane group
 //     walks, summed over the workgroup's 16 lane groups through LDS in a fixed order; one (NT, d) f32 slab per workgroup, folded by
 //     pygho_sum_blocks.
+#include <atomic>
 #include "common.h"
 
 namespace pygho {
@@ -140,19 +141,29 @@ extern "C" int pygho_pair_bwd_blocks(int64_t n_nodes, int64_t d, int dtype) {
   int log2g = 0;
   while ((1 << log2g) < chunks && log2g < 6) ++log2g;
   // resident workgroups per CU from the runtime (bf16: 152 registers -> 3, f16: 170 -> 2): a grid of exactly the resident set has no
-  // second, partially filled round
-  static int per_cu[2][64] = {};
+  // second, partially filled round.  The answer depends on the LDS slab ((kBlock >> log2g) * types * d floats), so it is memoised per
+  // (dtype, device, row chunks); entries are written once with the same value whoever computes them (relaxed atomics: no torn read).
+  static std::atomic<int> per_cu[2][16][65];
+  static std::atomic<int> cus_of[16];
   int dev = 0;
   (void)hipGetDevice(&dev);
-  int& occ = per_cu[dtype == PYGHO_F16 ? 1 : 0][dev & 63];
+  std::atomic<int>& slot = per_cu[dtype == PYGHO_F16 ? 1 : 0][dev & 15][chunks <= 64 ? chunks : 64];
+  int occ = slot.load(std::memory_order_relaxed);
   if (occ == 0) {
     const size_t lds = (size_t)(kBlock >> log2g) * kPbTypes * d * sizeof(float);
     int n = 0;
     const hipError_t e = dtype == PYGHO_F16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pair_bwd_kernel<f16>, kBlock, lds)
                                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pair_bwd_kernel<bf16>, kBlock, lds);
     occ = (e == hipSuccess && n >= 1 && n <= 8) ? n : 3;
+    slot.store(occ, std::memory_order_relaxed);
   }
-  int gx = grid_for(n_nodes, kBlock >> log2g, 256 * occ);
+  int cus = cus_of[dev & 15].load(std::memory_order_relaxed);
+  if (cus == 0) {
+    int n = 0;
+    cus = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    cus_of[dev & 15].store(cus, std::memory_order_relaxed);
+  }
+  int gx = grid_for(n_nodes, kBlock >> log2g, cus * occ);
   if (gx > 8) gx = (gx + 7) & ~7;
   return gx;
 }

@@ -372,18 +372,21 @@ class GNNAKConv(Module):
     def forward(self, A: Rep, X: Rep, datadict: dict, residual=False) -> Rep:
         H = self.aggr.forward(A, X.tuplewiseapply(self.lin0), datadict, X)
         block = self.lin.single_block() if isinstance(self.lin, MLP) else None
+        # the node-level path computes in the autocast dtype (u, v and the gathered rows of H are cast to it): every width check is
+        # made on THAT element size (an f32 H under bf16 autocast has 2-byte rows)
+        cdt = None
+        if isinstance(H, SparseTensor) and H.values is not None:
+            cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else H.values.dtype
         if (_ops.USE_NODE_LEVEL_LINEAR and block is not None and self._pool in ("sum", "mean") and isinstance(H, SparseTensor)
                 and H.sparse_dim == 2 and H.values is not None and H.values.is_cuda and H.values.dim() == 2
-                and H.values.is_floating_point() and H.shape[0] == H.shape[1] and _ops.pair_gather_supported(H.values)
+                and H.values.is_floating_point() and H.shape[0] == H.shape[1] and _ops.pair_gather_supported(H.values, dtype=cdt)
                 and block[0].in_features == (3 if self.ctx else 2) * H.values.shape[1]
                 # the pair kernels run on rows of the block's OUTPUT width (u, v): those must be whole 16-byte pieces of at most 4 KB too
-                and (block[0].out_features * H.values.element_size()) % 16 == 0 and block[0].out_features * H.values.element_size() <= 4096
-                and _ops.bn_act_supported_shape(H.nnz, block[0].out_features, torch.get_autocast_dtype("cuda")
-                                                if torch.is_autocast_enabled("cuda") else H.values.dtype)):
+                and _ops.pair_gather_supported(H.values, width=block[0].out_features, dtype=cdt)
+                and _ops.bn_act_supported_shape(H.nnz, block[0].out_features, cdt)):
             res_rows, outer = None, None
             if residual is not False and residual is not None:
                 rep = X if residual is True else residual
-                cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else H.values.dtype
                 if (isinstance(rep, SparseTensor) and rep.values is not None and rep.values.dtype == cdt and rep.nnz == H.nnz
                         and rep.values.shape[1] == block[0].out_features):
                     res_rows = rep.values

@@ -340,9 +340,13 @@ def pair_gather_combine(base: Optional[Tensor], row_term: Optional[Tensor], col_
     return out
 
 
-def pair_gather_supported(values: Tensor) -> bool:
-    return (values.is_cuda and values.dim() == 2 and values.dtype in (torch.float32, torch.bfloat16, torch.float16)
-            and (values.shape[1] * values.element_size()) % 16 == 0 and values.shape[1] * values.element_size() <= 4096)
+def pair_gather_supported(values: Tensor, width: Optional[int] = None, dtype: Optional[torch.dtype] = None) -> bool:
+    """rows of `width` elements of `dtype` (default: `values`' own) are whole 16-byte pieces of at most 4 KB.  Callers that run
+    the pair kernels in the autocast dtype pass it: an f32 `values` under bf16 autocast has 2-byte rows."""
+    dtype = values.dtype if dtype is None else dtype
+    width = values.shape[1] if width is None and values.dim() == 2 else width
+    return (values.is_cuda and values.dim() == 2 and dtype in (torch.float32, torch.bfloat16, torch.float16)
+            and (width * dtype.itemsize) % 16 == 0 and width * dtype.itemsize <= 4096)
 
 
 def _matched_rows(src: Tensor, pos: Tensor) -> Tensor:

@@ -7,6 +7,8 @@ all-reduce.  The reference has no distributed code at all; this is new work.
 a single RCCL all-reduce over xGMI (0.70 MB for the minimal NGNN: latency-bound), or -- ``overlap=True`` -- two
 halves of it issued on a side stream from backward hooks, the later layers' half while backward still runs.
 """
+import time
+import weakref
 from typing import Iterable, List, Optional, Tuple
 
 import numpy as np
@@ -47,6 +49,12 @@ class FlatGradSync:
         self.allreduce_calls = 0
         self.overlap = bool(overlap) and dist.is_available() and dist.is_initialized()
         self._events = []                     # (start, end) device events around every side-stream collective (allreduce_ms)
+        self._handles = []                    # RemovableHandles of the backward hooks (close())
+        self._closed = False
+        # evidence of overlap for the LAST step: host time / device event when each range's collective was issued, and when
+        # backward() returned (mark_backward_end)
+        self._issue_log: List[Tuple[float, int, object]] = []
+        self._bwd_end: Optional[Tuple[float, object]] = None
         if self.overlap:
             # contiguous parameter ranges of about equal size
             nb = max(1, min(int(buckets), len(self.params)))
@@ -61,8 +69,30 @@ class FlatGradSync:
             self._launched = [False] * len(self._ranges)
             self._works = []
             self._side = torch.cuda.Stream(device=dev) if self.flat.is_cuda else None
+            # RCCL work.wait() only makes the calling STREAM wait; any other backend's wait() blocks the host until the collective
+            # is done, so there it is deferred to sync() -- otherwise the hook would stall backward and nothing could overlap
+            self._stream_ordered = self.flat.is_cuda and dist.get_backend(group) == "nccl"
+            # the hooks hold this object only weakly: a syncer that is dropped (or close()d) stops exchanging anything
+            ref = weakref.ref(self)
             for i, p in enumerate(self.params):
-                p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
+                def hook(_p, i=i, ref=ref):
+                    me = ref()
+                    if me is not None and not me._closed:
+                        me._on_grad(i)
+                self._handles.append(p.register_post_accumulate_grad_hook(hook))
+
+    def close(self) -> None:
+        """remove the backward hooks (a second FlatGradSync over the same parameters must not leave this one issuing collectives)"""
+        self._closed = True
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def zero_grad(self) -> None:
         for p in self.params:
@@ -70,6 +100,8 @@ class FlatGradSync:
         if self.overlap:
             self._pending = [hi - lo for lo, hi, _, _ in self._ranges]
             self._launched = [False] * len(self._ranges)
+            self._issue_log = []
+            self._bwd_end = None
 
     def _pack_range(self, lo: int, hi: int) -> None:
         missing = [v for v, p in zip(self.views[lo:hi], self.params[lo:hi]) if p.grad is None]
@@ -89,6 +121,9 @@ class FlatGradSync:
     def _on_grad(self, i: int) -> None:
         b = self._bucket_of[i]
         self._pending[b] -= 1
+        if self._pending[b] < 0:
+            raise RuntimeError("FlatGradSync: a parameter received a second gradient before sync() -- the contract is ONE backward "
+                               "pass per zero_grad() / sync() pair (a second pass would re-reduce an already exchanged range)")
         if self._pending[b] == 0 and not self._launched[b]:
             self._launch(b)
 
@@ -98,7 +133,8 @@ class FlatGradSync:
         self._pack_range(lo, hi)                       # on the stream backward runs on
         piece = self.flat[flo:fhi]
         if self._side is None:                         # host tensors (gloo on CPU): no streams to overlap
-            self._works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._works.append((dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
+            self._issue_log.append((time.perf_counter(), b, None))
         else:
             cur = torch.cuda.current_stream(self.flat.device)
             self._side.wait_stream(cur)                # the packed range is complete on the side stream
@@ -106,11 +142,39 @@ class FlatGradSync:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(self._side)
                 work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                work.wait()                            # RCCL: the SIDE stream waits for the collective (the host does not block)
-                e1.record(self._side)
+                self._issue_log.append((time.perf_counter(), b, e0))
+                if self._stream_ordered:
+                    work.wait()                        # RCCL: the SIDE stream waits for the collective (the host does not block)
+                    e1.record(self._side)
+                else:
+                    self._works.append((work, e1))     # joined in sync()
                 self._events.append((e0, e1))
                 del self._events[:-256]
         self.allreduce_calls += 1
+
+    def mark_backward_end(self) -> None:
+        """call right after loss.backward() returns: host time + an event on the compute stream, against which overlap_report()
+        places the moment the first range's collective was issued"""
+        ev = None
+        if self.flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.flat.device))
+        self._bwd_end = (time.perf_counter(), ev)
+
+    def overlap_report(self) -> Optional[dict]:
+        """for the last step (after a device synchronisation): how long before the END of backward the first collective was issued
+        (host clock) and started on the device (event on the side stream vs the backward-end event on the compute stream).
+        Positive numbers = the exchange of the later layers' range ran while backward was still producing the earlier layers'."""
+        if not self.overlap or not self._issue_log or self._bwd_end is None:
+            return None
+        t_end, ev_end = self._bwd_end
+        t0, b0, e0 = self._issue_log[0]
+        rep = {"ranges_issued_inside_backward": sum(1 for t, _, _ in self._issue_log if t < t_end),
+               "ranges": len(self._ranges), "first_range": b0,
+               "host_ms_first_issue_before_backward_end": (t_end - t0) * 1e3}
+        if e0 is not None and ev_end is not None:
+            rep["device_ms_first_collective_start_before_backward_end"] = e0.elapsed_time(ev_end)
+        return rep
 
     def sync(self) -> None:
         """average the gradient over all ranks (one collective over the flat buffer; with `overlap` one per range, most of them
@@ -126,8 +190,13 @@ class FlatGradSync:
         for b in range(len(self._ranges)):
             if not self._launched[b]:                  # a range with a parameter that received no gradient
                 self._launch(b)
-        for w in self._works:
-            w.wait()
+        for w, e1 in self._works:
+            if self._side is None:
+                w.wait()
+            else:
+                with torch.cuda.stream(self._side):    # the result becomes visible to the SIDE stream, which the compute stream joins
+                    w.wait()
+                    e1.record(self._side)
         self._works = []
         if self._side is not None:
             torch.cuda.current_stream(self.flat.device).wait_stream(self._side)
@@ -135,8 +204,8 @@ class FlatGradSync:
             self.flat.div_(self.world)
         for v, p in zip(self.views, self.params):
             p.grad = v
-        # one backward per zero_grad() / sync() pair: a second backward without zero_grad() would add into the averaged buffer; the
-        # counters are re-armed here so that the next cycle at least exchanges what it finds
+        # one backward per zero_grad() / sync() pair; the counters are re-armed here so that a caller who clears the gradients by
+        # other means (optimizer.zero_grad) still exchanges the next step's
         self._pending = [hi - lo for lo, hi, _, _ in self._ranges]
         self._launched = [False] * len(self._ranges)
 

@@ -636,10 +636,16 @@ def pair_mirror(row32: Tensor, col32: Tensor, vidx32: Tensor, n_nodes: int) -> O
     """mirror[t] = position of tuple (col[t], row[t]) for a tuple list sorted by (row, col) that is SYMMETRIC -- (j, i) present with
     every (i, j), equal feature on both, features below `pygho_pair_bwd_types()` -- else None.  K-hop tuple sets with a
     shortest-path-distance feature (hodata/SpTupleSampler.py:91-126) are.  One host synchronisation per tuple pattern, memoised on
-    the index object; `SpModel.prepare` takes it off the training step for batches collated ahead."""
+    the index object (keyed by the partner objects AND every index tensor's version counter: an in-place edit of the pattern
+    invalidates the verdict); `SpModel.prepare` takes it off the training step for batches collated ahead.  Called from
+    `pair_product`'s FORWARD, where the plans are built -- never from backward; under stream capture without a memo the answer is
+    None (the three-launch backward), because the verdict needs a device-to-host read."""
+    vers = (row32._version, col32._version, vidx32._version)
     memo = getattr(row32, "_pygho_mirror", None)
-    if memo is not None and memo[0] is col32 and memo[1] is vidx32 and memo[2] == n_nodes:
+    if memo is not None and memo[0] is col32 and memo[1] is vidx32 and memo[2] == n_nodes and memo[4] == vers:
         return memo[3]
+    if row32.is_cuda and torch.cuda.is_current_stream_capturing():
+        return None
     n = row32.numel()
     res = None
     if 0 < n < (1 << 31) and col32.numel() == n and vidx32.numel() == n:
@@ -653,7 +659,7 @@ def pair_mirror(row32: Tensor, col32: Tensor, vidx32: Tensor, n_nodes: int) -> O
         if _fetch(ok.to(torch.int32).reshape(1))[0]:
             res = pos.to(torch.int32)
     try:
-        row32._pygho_mirror = (col32, vidx32, n_nodes, res)
+        row32._pygho_mirror = (col32, vidx32, n_nodes, res, vers)
     except Exception:
         pass
     return res
@@ -699,8 +705,9 @@ class _PairProduct(torch.autograd.Function):
     gradients are the same three-operand kernel over the unit / by-row / by-col / by-feature groupings of the tuples."""
 
     @staticmethod
-    def forward(ctx, left, right, val, row32, col32, vidx32, by_row, by_col, by_val):
+    def forward(ctx, left, right, val, row32, col32, vidx32, by_row, by_col, by_val, mirror):
         n = row32.numel()
+        ctx.mirror = mirror
         unit_ok = USE_UNIT_TRIPLE and (left.shape[1] * left.element_size()) % 16 == 0 and left.shape[1] * left.element_size() <= 1024 \
             and left.dtype in (torch.float32, torch.bfloat16, torch.float16)
         out = seg_triple(n, left, right, val, None if unit_ok else unit_ptr(n, val.device), row32, col32, vidx32)
@@ -715,15 +722,12 @@ class _PairProduct(torch.autograd.Function):
         g = g.contiguous()
         n = row32.numel()
         g_left = g_right = g_val = None
-        if (USE_PAIR_BWD and vidx32 is not None and by_row[0].perm is None and g.dtype in (torch.bfloat16, torch.float16)
-                and left.dtype == right.dtype == val.dtype == g.dtype and left.shape == right.shape and g.shape[1] == left.shape[1]
-                and (g.shape[1] * 2) % 16 == 0 and g.shape[1] * 2 <= 1024 and left.is_contiguous() and right.is_contiguous()
-                and val.is_contiguous()):
-            mirror = pair_mirror(row32, col32, vidx32, left.shape[0])
-            if mirror is not None:
-                g_left, g_right, g_val = pair_bwd(g, left, right, val, by_row[0].seg_ptr, col32, vidx32, mirror)
-                return (g_left if ctx.needs_input_grad[0] else None, g_right if ctx.needs_input_grad[1] else None,
-                        g_val if ctx.needs_input_grad[2] else None, None, None, None, None, None, None)
+        mirror = ctx.mirror
+        if (mirror is not None and g.dtype == left.dtype and g.shape[1] == left.shape[1] and left.is_contiguous()
+                and right.is_contiguous() and val.is_contiguous()):
+            g_left, g_right, g_val = pair_bwd(g, left, right, val, by_row[0].seg_ptr, col32, vidx32, mirror)
+            return (g_left if ctx.needs_input_grad[0] else None, g_right if ctx.needs_input_grad[1] else None,
+                    g_val if ctx.needs_input_grad[2] else None, None, None, None, None, None, None, None)
         if ctx.needs_input_grad[0]:
             p, col_p, v_p = by_row
             g_left = seg_triple(p.n_seg, g, val, right, p.seg_ptr, p.perm, v_p if vidx32 is not None else p.perm, col_p)
@@ -741,7 +745,7 @@ class _PairProduct(torch.autograd.Function):
                 for lv in levels[1:]:
                     cur = seg_gmr(lv.numel() - 1, cur, None, lv, None, None, "sum")
                 g_val = cur.to(val.dtype)
-        return g_left, g_right, g_val, None, None, None, None, None, None
+        return g_left, g_right, g_val, None, None, None, None, None, None, None
 
 
 def _grouped(plan: SegPlan, key, *idx32):
@@ -770,4 +774,11 @@ def pair_product(left: Tensor, right: Tensor, val: Tensor, row: Tensor, col: Ten
     if val_index is not None:
         p_val = cached_plan(val_index, val.shape[0], "pair-val", assume_sorted=False)
         by_val = (p_val,) + _grouped(p_val, key, row32, col32)
-    return _PairProduct.apply(left, right, val, row32, col32, vidx32, by_row, by_col, by_val)
+    # the one-pass backward needs the tuple set's mirror permutation: decided HERE (one host read per pattern, memoised), where the
+    # plans are built, so that backward never synchronises
+    mirror = None
+    if (USE_PAIR_BWD and vidx32 is not None and torch.is_grad_enabled() and (left.requires_grad or right.requires_grad or val.requires_grad)
+            and p_row.perm is None and left.dtype in (torch.bfloat16, torch.float16) and left.dtype == right.dtype == val.dtype
+            and left.shape == right.shape and (left.shape[1] * 2) % 16 == 0 and left.shape[1] * 2 <= 1024):
+        mirror = pair_mirror(row32, col32, vidx32, left.shape[0])
+    return _PairProduct.apply(left, right, val, row32, col32, vidx32, by_row, by_col, by_val, mirror)

@@ -81,6 +81,47 @@ def test_bench_self_launches_two_ranks():
     assert line["n_gpus"] == 2 and line["config"]["graphs_per_gpu"] == 256
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("global_stream", [False, True])
+def test_bench_two_ranks_share_one_gpu(global_stream):
+    """bench.py's world > 1 branch on a one-GPU box: `python bench.py --gpus 2 --dist-backend gloo --ranks-share-gpu` goes through
+    launch_ranks (child torch.distributed.run, two ranks, both on cuda:0, the HIP path in each), once with one independent batch per
+    rank and once with --global-stream (one global batch sharded by message count).  Checked: one JSON line; n_gpus; every step
+    exchanged its two ranges; a collective time was measured; value = graphs of BOTH ranks / max-over-ranks time; both ranks end with
+    the same flat gradient; the first range's all-reduce was issued -- host clock AND device timeline -- before backward ended."""
+    steps, warmup = 3, 2
+    extra = ["--global-stream", "--distinct", "256"] if global_stream else []      # 512 distinct graphs: the message-balanced cut is not the middle
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--ranks-share-gpu"] + SMALL + extra,
+                       env=_env(), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = _line(r.stdout)
+    c = line["collectives"]
+    assert line["n_gpus"] == 2 and line["steps"] == steps and c["backend"] == "gloo" and c["ranks_share_gpu"] is True
+    assert c["allreduce_ranges_per_step"] == 2 and c["allreduce_calls"] == 2 * (steps + warmup)
+    assert c["allreduce_ms"] is not None and c["allreduce_ms"] > 0
+    (g0, t0), (g1, t1) = c["per_rank_graphs_and_seconds"]
+    assert g0 + g1 == c["graphs_all_ranks"] == 512
+    if global_stream:
+        assert c["batch"] == "global stream sharded by message count" and g0 != 256 and 200 < g0 < 312   # balanced by messages, not graphs
+    else:
+        assert c["batch"] == "one independent batch per rank" and g0 == g1 == 256
+    elapsed = line["ms_per_step"] * steps / 1e3
+    assert abs(elapsed - max(t0, t1)) < 1e-6 * elapsed                   # the slowest rank's clock
+    assert abs(line["value"] - (g0 + g1) * steps / elapsed) < 1e-6 * line["value"]
+    assert c["flat_grad_equal_across_ranks"] is True
+    ov = c["overlap_last_step"]
+    assert ov["ranges"] == 2 and ov["ranges_issued_inside_backward"] >= 1 and ov["first_range"] == 1   # backward completes the LAST range first
+    assert ov["host_ms_first_issue_before_backward_end"] > 0
+    assert ov["device_ms_first_collective_start_before_backward_end"] > 0
+    assert line["roofline"]["frac"] > 0 and "regimes" not in line
+
+
+def test_ranks_share_gpu_refuses_rccl():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--ranks-share-gpu"], env=_env(HIP_VISIBLE_DEVICES="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "needs --dist-backend gloo" in r.stderr and not r.stdout.strip()
+
+
 def test_visible_gpu_count_reads_the_environment_not_the_runtime(monkeypatch):
     """bench.py counts GPUs from the visibility variables (or the KFD topology) so that the parent of a self-launched run never
     initialises HIP: the variables win, an empty list means no GPU"""

@@ -408,11 +408,12 @@ def test_baseline_size_elementwise_vs_host_oracle(dev, kind, graphs, d, key, dty
     whatever kernel the dispatcher picks for each plan) against the reference's ATen op sequence run on the host in f32
     (oracle.aten_port.spspmm_values_chunked: index, index, mul, index_add_ in message order).  f32: bit-identical.  bf16: the
     kernel's f32 accumulator equals the oracle's (the f32 product of two bf16 values is exact), so the result must equal the
-    oracle rounded ONCE to bf16 -- also bit for bit; `mean` likewise (one f32 division, then the rounding)."""
+    oracle rounded ONCE to bf16 -- also bit for bit; `mean` likewise (one f32 division, then the rounding), and `mean`'s two
+    gradient plans against the port with the per-message scale applied in the kernels' association (f32 and bf16, bit for bit)."""
     from oracle import aten_port as P
     from pygho_amd import synth
     from pygho_amd._ops import message_reduce
-    hb = synth.replicate(synth.make_batch(min(graphs, 1024), kind, seed=1000), max(1, graphs // 1024))
+    hb = synth.make_batch(graphs, kind, seed=1000)                 # every graph distinct: no periodic index structure
     acd_h = torch.from_numpy(hb.acd[key])
     acd = acd_h.to(dev)
     nt, ne = hb.num_tuples, hb.num_edges
@@ -434,8 +435,6 @@ def test_baseline_size_elementwise_vs_host_oracle(dev, kind, graphs, d, key, dty
         ag = ah.to(dev).requires_grad_(True)
         out = message_reduce(xg, ag, acd, nt, nt, ne, aggr)
         same(out, P.spspmm_values_chunked(x32, a32, acd_h[0], acd_h[1], acd_h[2], nt, aggr), f"{kind} {aggr} forward")
-        if aggr == "mean" and dtype != torch.float32:
-            continue            # mean's gradient plans carry a per-row f32 scale inside the product: one more rounding than the port's
         out.backward(gh.to(dev))
         if aggr == "sum":
             gX = P.spspmm_values_chunked(g32, a32, acd_h[1], acd_h[0], acd_h[2], nt, "sum")
@@ -443,13 +442,22 @@ def test_baseline_size_elementwise_vs_host_oracle(dev, kind, graphs, d, key, dty
             same(xg.grad, gX, f"{kind} gradient wrt the tuple values (by-tuple plan)")
             same(ag.grad, gA, f"{kind} gradient wrt the adjacency values (by-edge plan)")
         else:
-            # mean, f32: g / count is applied per message inside the kernel (scale * (a * b)), the port divides the gradient first:
-            # equal up to the f32 rounding of that one product
-            cnt = torch.bincount(acd_h[0], minlength=nt).clamp_min(1).float().unsqueeze(1)
-            gX = P.spspmm_values_chunked(g32 / cnt, a32, acd_h[1], acd_h[0], acd_h[2], nt, "sum")
-            gA = P.spspmm_values_chunked(g32 / cnt, x32, acd_h[2], acd_h[0], acd_h[1], ne, "sum")
-            torch.testing.assert_close(xg.grad.cpu(), gX, rtol=1e-5, atol=1e-5)
-            torch.testing.assert_close(ag.grad.cpu(), gA, rtol=1e-5, atol=1e-4)
+            # mean: the kernels scale every message by 1 / count AFTER forming the product, (1 / count[a]) * (g[a] * v), all in f32;
+            # the port applies the same association (a_rowscale) -> bit-identical for f32 AND for bf16 (one rounding at the store).
+            # 1 / count itself: an f32 reciprocal of a small integer, the same bits on the host and the device (checked)
+            cnt = torch.bincount(acd_h[0], minlength=nt).clamp_min(1).float()
+            inv = cnt.reciprocal()
+            assert torch.equal(cnt.to(dev).reciprocal().cpu(), inv), "f32 reciprocal differs between the host and the device"
+            gX = P.spspmm_values_chunked(g32, a32, acd_h[1], acd_h[0], acd_h[2], nt, "sum", a_rowscale=inv)
+            gA = P.spspmm_values_chunked(g32, x32, acd_h[2], acd_h[0], acd_h[1], ne, "sum", a_rowscale=inv)
+            same(xg.grad, gX, f"{kind} mean: gradient wrt the tuple values (by-tuple plan)")
+            same(ag.grad, gA, f"{kind} mean: gradient wrt the adjacency values (by-edge plan)")
+            if dtype == torch.float32:
+                # and against autograd's own association, (g / count) * v: equal up to the f32 rounding of that one product
+                gX2 = P.spspmm_values_chunked(g32 / cnt.unsqueeze(1), a32, acd_h[1], acd_h[0], acd_h[2], nt, "sum")
+                gA2 = P.spspmm_values_chunked(g32 / cnt.unsqueeze(1), x32, acd_h[2], acd_h[0], acd_h[1], ne, "sum")
+                torch.testing.assert_close(xg.grad.cpu(), gX2, rtol=1e-5, atol=1e-5)
+                torch.testing.assert_close(ag.grad.cpu(), gA2, rtol=1e-5, atol=1e-4)
         del xg, ag, out
 
 
@@ -694,6 +702,78 @@ def test_cast_arena_follows_the_optimizer(dev, opt_kind):
     with_arena, without = run(True), run(False)
     assert with_arena[-1] < 0.8 * with_arena[0], f"the model does not learn: {with_arena}"
     np.testing.assert_allclose(with_arena, without, rtol=0.05, atol=0.02)
+
+
+def _three_dim_pattern(rng, shape, dims, nnz):
+    rows = set()
+    a, b = dims
+    while len(rows) < nnz:
+        t = [int(rng.integers(0, s)) for s in shape]
+        if rng.random() < 0.4:
+            t[b] = t[a]                                  # plenty of entries on the partial diagonal, several per i
+        rows.add(tuple(t))
+    return np.ascontiguousarray(np.array(sorted(rows), dtype=np.int64).T)
+
+
+@pytest.mark.parametrize("dims,shape", [((0, 1), (9, 9, 6)), ((1, 2), (5, 8, 8)), ((0, 2), (7, 4, 7))])
+def test_partial_diag_to_dense(dev, dims, shape):
+    """SparseTensor.diag over SOME sparse dims with a dense result (reference SpTensor.py:337-352: that branch raises TypeError at
+    :346, so no reference output exists -- the documented intent is restated in oracle.np_oracle.sp_diag_partial_to_dense): every
+    entry whose coordinates in `dims` coincide lands at its kept coordinates, zero elsewhere; the gradient is the gather back."""
+    from oracle import np_oracle as O
+    from pygho_amd import SparseTensor
+    rng = np.random.default_rng(31)
+    ind = _three_dim_pattern(rng, shape, dims, 120)
+    val = rng.standard_normal((ind.shape[1], 4)).astype(np.float32)
+    v = torch.from_numpy(val).to(dev).requires_grad_(True)
+    X = SparseTensor(torch.from_numpy(ind).to(dev), v, list(shape) + [4], is_coalesced=True)
+    got = X.diag(list(dims))
+    exp = O.sp_diag_to_dense(ind, val, list(shape) + [4], list(dims))
+    assert tuple(got.shape) == exp.shape and np.array_equal(got.detach().cpu().numpy(), exp)
+    w = torch.randn_like(got)
+    (got * w).sum().backward()
+    on = np.all(ind[list(dims)] == ind[dims[0]], axis=0)
+    keep = [i for i in range(3) if i not in dims[1:]]
+    gexp = np.zeros_like(val)
+    gexp[on] = w.cpu().numpy()[tuple(ind[k][on] for k in keep)]
+    assert np.array_equal(v.grad.cpu().numpy(), gexp)
+
+
+def test_two_forwards_before_one_backward_with_the_cast_arena(dev):
+    """loss = f(model(b1)) + f(model(b2)) (siamese / contrastive use, or a grad-enabled validation pass between forward and
+    backward): autograd has saved the arena's 16-bit views in the first pass, so the second pass must not rewrite them in place when
+    no parameter changed -- backward would raise 'modified by an inplace operation'.  The gradient equals the sum of the two
+    single-pass gradients."""
+    from pygho_amd import synth
+    from pygho_amd.ngnn import SpModel
+    torch.manual_seed(0)
+    model = SpModel(1, 2, 64, act_dtype=torch.bfloat16).to(dev)
+    model.eval()                                    # running statistics: the two passes are independent of each other
+    d1 = synth.to_datadict(synth.make_batch(24, "zinc", seed=3), dev)
+    d2 = synth.to_datadict(synth.make_batch(24, "zinc", seed=4), dev)
+
+    def loss_of(dd):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return model(dd).float().square().mean()
+
+    singles = []
+    for dd in (d1, d2):
+        model.zero_grad(set_to_none=True)
+        loss_of(dd).backward()
+        singles.append([p.grad.clone() for p in model.parameters() if p.grad is not None])
+    model.zero_grad(set_to_none=True)
+    arena = model.__dict__["_pygho_cast_arena"]
+    versions = [v._version for v in arena.views]
+    l1 = loss_of(d1)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        model(d2)                                   # a grad-enabled pass whose result is dropped
+    l2 = loss_of(d2)
+    assert [v._version for v in arena.views] == versions, "the arena was rewritten although no parameter changed"
+    (l1 + l2).backward()
+    both = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(both) == len(singles[0]) == len(singles[1])
+    for g, a, b in zip(both, *singles):
+        torch.testing.assert_close(g, a + b, rtol=1e-4, atol=1e-5 * float((a + b).abs().max()) + 1e-7)
 
 
 def test_batchnorm_step_counters_are_bumped_once_per_layer_call(dev):
