@@ -43,7 +43,17 @@ def spspmm_values_chunked(valA: Tensor, valB: Tensor, out_idx: Tensor, a_idx: Te
     `a_rowscale` (f32, one factor per row of valA): every message is a_rowscale[a] * (valA[a] * valB[b]) -- the gradient of `mean`
     with the division by the count applied PER MESSAGE after the product, which is the association the device kernels use
     (autograd's own is (g / count) * v: one rounding elsewhere, same value to 1 ulp)."""
-    assert aggr in ("sum", "mean") and valA.dtype == torch.float32 and valB.dtype == torch.float32
+    assert aggr in ("sum", "mean", "max", "min") and valA.dtype == torch.float32 and valB.dtype == torch.float32
+    if aggr in ("max", "min"):
+        # scatter_reduce_(amax | amin, include_self=False) into zeros (utils.py:50-55), chunk by chunk: the running extremum starts at
+        # -inf / +inf and rows without a message end as 0, which is what include_self=False leaves in the zero-initialised output
+        assert a_rowscale is None
+        out = torch.full((n_out, valA.shape[1]), float("-inf") if aggr == "max" else float("inf"), dtype=torch.float32)
+        for lo in range(0, out_idx.numel(), chunk):
+            sl = slice(lo, lo + chunk)
+            out.index_reduce_(0, out_idx[sl], valA[a_idx[sl]] * valB[b_idx[sl]], "amax" if aggr == "max" else "amin", include_self=True)
+        out[torch.bincount(out_idx, minlength=n_out) == 0] = 0.0
+        return out
     out = torch.zeros((n_out, valA.shape[1]), dtype=torch.float32)
     for lo in range(0, out_idx.numel(), chunk):
         sl = slice(lo, lo + chunk)
@@ -55,6 +65,34 @@ def spspmm_values_chunked(valA: Tensor, valB: Tensor, out_idx: Tensor, a_idx: Te
         cnt = torch.bincount(out_idx, minlength=n_out).clamp_min(1).to(torch.float32)
         out = out / cnt.unsqueeze(1)
     return out
+
+
+def spspmm_extremum_grads_chunked(valA: Tensor, valB: Tensor, acd: Tensor, n_out: int, fwd: Tensor, gout: Tensor,
+                                  store_dtype: torch.dtype = torch.float32, chunk: int = 1 << 20):
+    """gradients of spspmm_values(..., aggr = max | min) wrt valA and valB, chunk by chunk, as autograd computes them for the
+    reference's op sequence (Spspmm.py:309-315 + utils.py:50-55): scatter_reduce_(amax)'s backward hands every message that attains
+    the extremum grad / N_to_distribute (N = number of ties, the quotient in the gradient's dtype), mul's backward multiplies by the
+    other operand, index's backward adds the rows up in message order.  `fwd` = the forward result AS STORED (rounded to
+    `store_dtype`), `store_dtype` = the dtype the values live in on the device: the message compared with `fwd` and the share
+    grad / N are rounded to it; the sums are f32 (what the device kernels accumulate in)."""
+    rnd = (lambda t: t) if store_dtype == torch.float32 else (lambda t: t.to(store_dtype).float())
+    a, c, d = acd[0], acd[1], acd[2]
+    # N_to_distribute = (self == result) + sum over messages of (src == result[index])  (torch's scatter_reduce_backward): `self` is
+    # the zero-initialised output of utils.py:44-49, so an extremum that is exactly 0 counts one more "tie" -- the (masked-out)
+    # initial value -- although include_self=False.  Part of the reference's numerics; reproduced.
+    ties = (fwd == 0).float()
+    for lo in range(0, a.numel(), chunk):
+        sl = slice(lo, lo + chunk)
+        ties.index_add_(0, a[sl], (rnd(valA[c[sl]] * valB[d[sl]]) == fwd[a[sl]]).float())
+    share = rnd(gout / ties.clamp_min(1.0))
+    gA, gB = torch.zeros_like(valA), torch.zeros_like(valB)
+    for lo in range(0, a.numel(), chunk):
+        sl = slice(lo, lo + chunk)
+        av, bv = valA[c[sl]], valB[d[sl]]
+        hit = (rnd(av * bv) == fwd[a[sl]]).float() * share[a[sl]]
+        gA.index_add_(0, c[sl], hit * bv)
+        gB.index_add_(0, d[sl], hit * av)
+    return gA, gB
 
 
 def spmm_values(valA, X: Tensor, src: Tensor, tar: Tensor, n_tar: int, aggr: str = "sum") -> Tensor:

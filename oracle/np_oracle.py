@@ -288,7 +288,9 @@ def spspmm_values_grad(valA, valB, acd, n_out, aggr, grad_out):
         msg = (valB[d] if valA is None else valA[c] if valB is None else valA[c] * valB[d])
         out = scatter_reduce(msg, a, n_out, aggr)
         hit = (msg == out[a]).astype(grad_out.dtype)
-        ties = np.zeros_like(out)
+        # torch's scatter_reduce_backward: N_to_distribute = (self == result) + scatter_add(src == result[index]); `self` is the
+        # zero-initialised output (utils.py:44-49), so an extremum of exactly 0 has one extra tie although include_self=False
+        ties = (out == 0).astype(out.dtype)
         np.add.at(ties, a, hit)
         gm = gm * hit / np.maximum(ties[a], 1)
     if gA is not None:

@@ -300,7 +300,9 @@ __global__ __launch_bounds__(kBlock) void seg_ties_kernel(
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t s = t / d, c = t - s * d;
     const A ext = load_as_acc<T>(fwd + t);
-    float n = 0.f;
+    // torch's scatter_reduce_backward counts (self == result) into N_to_distribute as well, and `self` is the zero-initialised output
+    // of pygho/backend/utils.py:44-49: an extremum that is exactly 0 has one more "tie" (the reference's numerics, reproduced)
+    float n = ext == (A)0 ? 1.f : 0.f;
     for (int m = seg_ptr[s]; m < seg_ptr[s + 1]; ++m) {
       A p = (A)1;
       if (lhs) p = load_as_acc<T>(lhs + (int64_t)(lhs_idx ? lhs_idx[m] : m) * d + c);
@@ -338,6 +340,132 @@ __global__ __launch_bounds__(kBlock) void seg_extremum_bwd_kernel(
       }
     }
     store_from_acc<T>(gout + t, acc);
+  }
+}
+
+// ---- max / min backward, 16 bytes per lane (the scalar kernels above remain the path for f64 and odd row widths) -----------------
+// A lane group (2^log2g lanes, `chunks` of them active) owns one segment, a wavefront 64 >> log2g segments at a time; kExtTrip
+// messages of a segment are in flight per trip (index loads, then row loads, all independent).
+constexpr int kExtTrip = 4;
+
+// v rounded to the storage type (what the forward stored, what the reference's elementwise product holds)
+template <typename T> __device__ __forceinline__ void round_to_storage(float (&v)[Vec16<T>::N]) {
+  if (sizeof(T) == 2) Vec16<T>::unpack(Vec16<T>::pack(v), v);
+}
+
+// share[s] = gin[s] / #{messages of segment s whose value equals the forward extremum}  (torch splits the gradient evenly among
+// ties: grad / N_to_distribute, rounded to the gradient's dtype -- autograd of scatter_reduce_(amax|amin), pygho/backend/utils.py:50-55)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void seg_extremum_share_kernel(
+    T* __restrict__ share, const T* __restrict__ gin, const T* __restrict__ fwd, const T* __restrict__ lhs, const T* __restrict__ rhs,
+    const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ lhs_idx, const int32_t* __restrict__ rhs_idx,
+    int64_t n_seg, int d, int chunks, int log2g) {
+  using V = Vec16<T>;
+  constexpr int N = V::N;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int gl = lane & ((1 << log2g) - 1), grp = lane >> log2g, gw = kWave >> log2g;
+  const bool active = gl < chunks;
+  const uint32_t row_bytes = (uint32_t)d * sizeof(T), col_bytes = (uint32_t)(active ? gl : 0) * 16u;
+  const char* lbase = reinterpret_cast<const char*>(lhs);
+  const char* rbase = reinterpret_cast<const char*>(rhs);
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave) * gw;
+  for (int64_t s = ((int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * gw + grp; s < n_seg; s += stride) {
+    const int beg = seg_ptr[s], end = seg_ptr[s + 1];
+    float ext[N], cnt[N], g[N];
+    V::unpack(load_row16<true>(reinterpret_cast<const char*>(fwd), (int)s, row_bytes, col_bytes), ext);
+    V::unpack(load_row16<true>(reinterpret_cast<const char*>(gin), (int)s, row_bytes, col_bytes), g);
+    // (self == result) is part of torch's N_to_distribute and `self` is the zero-initialised output: one more tie where the extremum is 0
+#pragma unroll
+    for (int q = 0; q < N; ++q) cnt[q] = ext[q] == 0.f ? 1.f : 0.f;
+    for (int m0 = beg; m0 < end; m0 += kExtTrip) {
+      int li[kExtTrip], ri[kExtTrip];
+#pragma unroll
+      for (int k = 0; k < kExtTrip; ++k) {
+        const int m = min(m0 + k, end - 1);
+        li[k] = lhs_idx ? lhs_idx[m] : m;
+        ri[k] = rhs_idx ? rhs_idx[m] : m;
+      }
+      uint4 la[kExtTrip], rb[kExtTrip];
+#pragma unroll
+      for (int k = 0; k < kExtTrip; ++k) {
+        if (lhs) la[k] = load_row16<true>(lbase, li[k], row_bytes, col_bytes);
+        if (rhs) rb[k] = load_row16<true>(rbase, ri[k], row_bytes, col_bytes);
+      }
+#pragma unroll
+      for (int k = 0; k < kExtTrip; ++k) {
+        float a[N], b[N];
+        if (lhs) V::unpack(la[k], a);
+        if (rhs) V::unpack(rb[k], b);
+#pragma unroll
+        for (int q = 0; q < N; ++q) a[q] = lhs ? (rhs ? a[q] * b[q] : a[q]) : (rhs ? b[q] : 1.f);
+        round_to_storage<T>(a);
+        const bool live = m0 + k < end;
+#pragma unroll
+        for (int q = 0; q < N; ++q) cnt[q] += (live && a[q] == ext[q]) ? 1.f : 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) g[q] = cnt[q] > 0.f ? g[q] / cnt[q] : 0.f;
+    if (active) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(share) + ((uint32_t)s * row_bytes + col_bytes)) = V::pack(g);
+  }
+}
+
+// gout[s] = sum over the messages m of segment s (a plan grouped by the operand being differentiated) of
+//           share[a_m] * other(m) * [round(self[s] * other(m)) == fwd[a_m]],   f32 accumulation, one rounding at the store
+template <typename T>
+__global__ __launch_bounds__(kBlock) void seg_extremum_bwd_vec_kernel(
+    T* __restrict__ gout, const T* __restrict__ share, const T* __restrict__ fwd, const T* __restrict__ self_vals,
+    const T* __restrict__ other, const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ out_idx,
+    const int32_t* __restrict__ other_idx, int64_t n_seg, int d, int chunks, int log2g) {
+  using V = Vec16<T>;
+  constexpr int N = V::N;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int gl = lane & ((1 << log2g) - 1), grp = lane >> log2g, gw = kWave >> log2g;
+  const bool active = gl < chunks;
+  const uint32_t row_bytes = (uint32_t)d * sizeof(T), col_bytes = (uint32_t)(active ? gl : 0) * 16u;
+  const char* sbase = reinterpret_cast<const char*>(share);
+  const char* fbase = reinterpret_cast<const char*>(fwd);
+  const char* obase = reinterpret_cast<const char*>(other);
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave) * gw;
+  for (int64_t s = ((int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * gw + grp; s < n_seg; s += stride) {
+    const int beg = seg_ptr[s], end = seg_ptr[s + 1];
+    float sv[N], acc[N];
+    if (self_vals) V::unpack(load_row16<true>(reinterpret_cast<const char*>(self_vals), (int)s, row_bytes, col_bytes), sv);
+#pragma unroll
+    for (int q = 0; q < N; ++q) acc[q] = 0.f;
+    for (int m0 = beg; m0 < end; m0 += kExtTrip) {
+      int ai[kExtTrip], oi[kExtTrip];
+#pragma unroll
+      for (int k = 0; k < kExtTrip; ++k) {
+        const int m = min(m0 + k, end - 1);
+        ai[k] = out_idx[m];
+        oi[k] = other_idx ? other_idx[m] : m;
+      }
+      uint4 gs[kExtTrip], fw[kExtTrip], ov[kExtTrip];
+#pragma unroll
+      for (int k = 0; k < kExtTrip; ++k) {
+        gs[k] = load_row16<true>(sbase, ai[k], row_bytes, col_bytes);
+        fw[k] = load_row16<true>(fbase, ai[k], row_bytes, col_bytes);
+        if (other) ov[k] = load_row16<true>(obase, oi[k], row_bytes, col_bytes);
+      }
+#pragma unroll
+      for (int k = 0; k < kExtTrip; ++k) {
+        float g[N], f[N], o[N], msg[N];
+        V::unpack(gs[k], g);
+        V::unpack(fw[k], f);
+        if (other) V::unpack(ov[k], o);
+#pragma unroll
+        for (int q = 0; q < N; ++q) msg[q] = self_vals ? (other ? sv[q] * o[q] : sv[q]) : (other ? o[q] : 1.f);
+        round_to_storage<T>(msg);
+        const bool live = m0 + k < end;
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+          const float term = other ? g[q] * o[q] : g[q];
+          acc[q] += (live && msg[q] == f[q]) ? term : 0.f;
+        }
+      }
+    }
+    if (active) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(gout) + ((uint32_t)s * row_bytes + col_bytes)) = V::pack(acc);
   }
 }
 
@@ -677,6 +805,61 @@ extern "C" int pygho_seg_extremum_bwd(void* gout, const void* gin, const void* f
                                                   st, (T*)gout, (const T*)gin, (const T*)fwd_out, tie_cnt, (const T*)self_vals,
                                                   (const T*)other_vals, seg_ptr, out_idx, other_idx, n_seg, d));
   return check_launch("seg_extremum_bwd");
+}
+
+// vector forms: 0 = launched, PYGHO_ERR_UNSUPPORTED = shape / dtype outside their domain (the caller takes the scalar pair)
+static int extremum_vec_shape(int64_t d, int dtype, int64_t max_rows, int* chunks, int* log2g) {
+  const int64_t es = dtype == PYGHO_F32 ? 4 : ((dtype == PYGHO_BF16 || dtype == PYGHO_F16) ? 2 : 0);
+  if (es == 0 || (d * es) % 16 != 0 || d * es > 1024 || max_rows * d * es >= ((int64_t)1 << 32)) return PYGHO_ERR_UNSUPPORTED;
+  *chunks = (int)(d * es / 16);
+  *log2g = 0;
+  while ((1 << *log2g) < *chunks) ++*log2g;
+  return PYGHO_OK;
+}
+
+extern "C" int pygho_seg_extremum_share(void* share, const void* gin, const void* fwd_out, const void* lhs, const void* rhs,
+                                        const int32_t* seg_ptr, const int32_t* lhs_idx, const int32_t* rhs_idx, int64_t n_seg,
+                                        int64_t d, int64_t lhs_rows, int64_t rhs_rows, int dtype, void* stream) {
+  if (n_seg < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n_seg == 0 || d == 0) return PYGHO_OK;
+  if (!share || !gin || !fwd_out || !seg_ptr) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  int chunks = 0, log2g = 0;
+  const int64_t rows = n_seg > lhs_rows ? (n_seg > rhs_rows ? n_seg : rhs_rows) : (lhs_rows > rhs_rows ? lhs_rows : rhs_rows);
+  if (extremum_vec_shape(d, dtype, rows, &chunks, &log2g) != PYGHO_OK ||
+      (((uintptr_t)share | (uintptr_t)gin | (uintptr_t)fwd_out | (uintptr_t)lhs | (uintptr_t)rhs) % 16) != 0) {
+    set_error("seg_extremum_share: f32 / bf16 / f16 rows of 16..1024 bytes in 16-byte pieces, 16-byte aligned, operands below 4 GiB");
+    return PYGHO_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int gx = grid_for(n_seg, (kBlock / kWave) * (kWave >> log2g));
+#define PYGHO_EXT_SHARE(T) hipLaunchKernelGGL((seg_extremum_share_kernel<T>), dim3(gx), dim3(kBlock), 0, st, (T*)share, (const T*)gin, \
+    (const T*)fwd_out, (const T*)lhs, (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, n_seg, (int)d, chunks, log2g)
+  if (dtype == PYGHO_F32) PYGHO_EXT_SHARE(float); else if (dtype == PYGHO_BF16) PYGHO_EXT_SHARE(bf16); else PYGHO_EXT_SHARE(f16);
+#undef PYGHO_EXT_SHARE
+  return check_launch("seg_extremum_share");
+}
+
+extern "C" int pygho_seg_extremum_bwd_shared(void* gout, const void* share, const void* fwd_out, const void* self_vals,
+                                             const void* other_vals, const int32_t* seg_ptr, const int32_t* out_idx,
+                                             const int32_t* other_idx, int64_t n_seg, int64_t d, int64_t out_rows,
+                                             int64_t other_rows, int dtype, void* stream) {
+  if (n_seg < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n_seg == 0 || d == 0) return PYGHO_OK;
+  if (!gout || !share || !fwd_out || !seg_ptr || !out_idx) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  int chunks = 0, log2g = 0;
+  const int64_t rows = n_seg > out_rows ? (n_seg > other_rows ? n_seg : other_rows) : (out_rows > other_rows ? out_rows : other_rows);
+  if (extremum_vec_shape(d, dtype, rows, &chunks, &log2g) != PYGHO_OK ||
+      (((uintptr_t)gout | (uintptr_t)share | (uintptr_t)fwd_out | (uintptr_t)self_vals | (uintptr_t)other_vals) % 16) != 0) {
+    set_error("seg_extremum_bwd_shared: f32 / bf16 / f16 rows of 16..1024 bytes in 16-byte pieces, 16-byte aligned, operands below 4 GiB");
+    return PYGHO_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int gx = grid_for(n_seg, (kBlock / kWave) * (kWave >> log2g));
+#define PYGHO_EXT_BWD(T) hipLaunchKernelGGL((seg_extremum_bwd_vec_kernel<T>), dim3(gx), dim3(kBlock), 0, st, (T*)gout, (const T*)share, \
+    (const T*)fwd_out, (const T*)self_vals, (const T*)other_vals, seg_ptr, out_idx, other_idx, n_seg, (int)d, chunks, log2g)
+  if (dtype == PYGHO_F32) PYGHO_EXT_BWD(float); else if (dtype == PYGHO_BF16) PYGHO_EXT_BWD(bf16); else PYGHO_EXT_BWD(f16);
+#undef PYGHO_EXT_BWD
+  return check_launch("seg_extremum_bwd_shared");
 }
 
 extern "C" int pygho_row_gather(void* out, const void* src, const int32_t* idx, const int32_t* valid, int64_t n_rows,

@@ -275,8 +275,45 @@ def seg_reduce_rows(src: Tensor, plan: SegPlan, aggr: str) -> Tensor:
     return cur.to(src.dtype)
 
 
-def _ties(fwd: Tensor, lhs, rhs, seg_ptr, lhs_idx, rhs_idx) -> Tensor:
+USE_EXTREMUM_VEC = os.environ.get("PYGHO_EXTREMUM_VEC", "1") != "0"     # 16-byte-per-lane max / min backward (A/B switch)
+
+
+def _extremum_vec_ok(*tensors) -> bool:
+    ts = [t for t in tensors if t is not None]
+    ref = ts[0]
+    rb = ref.shape[1] * ref.element_size() if ref.dim() == 2 else 0
+    return (USE_EXTREMUM_VEC and ref.dtype in (torch.float32, torch.bfloat16, torch.float16) and rb > 0 and rb % 16 == 0 and rb <= 1024
+            and all(t.dim() == 2 and t.dtype == ref.dtype and t.shape[1] == ref.shape[1] and t.is_contiguous()
+                    and t.data_ptr() % 16 == 0 and t.shape[0] * rb < (1 << 32) for t in ts))
+
+
+def _timed(name: str, nbytes: int, dev, launch) -> None:
+    timer = LaunchTimer.active
+    if timer is None:
+        launch()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream(dev))
+    launch()
+    e1.record(torch.cuda.current_stream(dev))
+    timer.records.append((name, nbytes, e0, e1))
+
+
+def _ties(fwd: Tensor, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, gin: Optional[Tensor] = None):
+    """tie bookkeeping of the max / min backward.  With `gin` and 16-byte-vector shapes: ("share", gin / ties rounded to the value
+    dtype) from ONE 16-byte-per-lane pass; otherwise the f32 tie counts of the scalar kernel."""
     dev = fwd.device
+    if gin is not None and _extremum_vec_ok(fwd, gin, lhs, rhs):
+        share = torch.empty_like(fwd)
+        es, d = fwd.element_size(), fwd.shape[1]
+        m = int(lhs_idx.numel() if lhs_idx is not None else (rhs_idx.numel() if rhs_idx is not None else fwd.shape[0]))
+        nbytes = es * d * (3 * fwd.shape[0] + (lhs.shape[0] if lhs is not None else 0) + (rhs.shape[0] if rhs is not None else 0)) \
+            + 4 * m * ((lhs_idx is not None) + (rhs_idx is not None)) + 4 * (fwd.shape[0] + 1)
+        _timed(f"seg_ext_share[{str(fwd.dtype).split('.')[-1]}]", nbytes, dev, lambda: check(lib().pygho_seg_extremum_share(
+            ptr(share), ptr(gin), ptr(fwd), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), fwd.shape[0], d,
+            lhs.shape[0] if lhs is not None else 0, rhs.shape[0] if rhs is not None else 0, dtype_code(fwd), stream_ptr(dev)),
+            "seg_extremum_share"))
+        return ("share", share)
     ties = torch.empty(fwd.shape, dtype=torch.float32, device=dev)
     check(lib().pygho_seg_extremum_ties(ptr(ties), ptr(fwd), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx),
                                         ptr(rhs_idx), fwd.shape[0], fwd.shape[1], dtype_code(fwd), stream_ptr(dev)),
@@ -288,6 +325,19 @@ def _extremum_bwd(n_rows, gin, fwd, ties, self_vals, other, seg_ptr, out_idx, ot
     dev = gin.device
     d = gin.shape[1]
     gout = torch.empty((n_rows, d), dtype=gin.dtype, device=dev)
+    if isinstance(ties, tuple):
+        share = ties[1]
+        if _extremum_vec_ok(gout, share, fwd, self_vals, other):
+            es = gin.element_size()
+            nbytes = es * d * (2 * fwd.shape[0] + n_rows * (2 if self_vals is not None else 1) + (other.shape[0] if other is not None else 0)) \
+                + 4 * out_idx.numel() * (2 if other_idx is not None else 1) + 4 * (n_rows + 1)
+            _timed(f"seg_ext_bwd[{str(gin.dtype).split('.')[-1]}]", nbytes, dev, lambda: check(lib().pygho_seg_extremum_bwd_shared(
+                ptr(gout), ptr(share), ptr(fwd), ptr(self_vals), ptr(other), ptr(seg_ptr), ptr(out_idx), ptr(other_idx), n_rows, d,
+                fwd.shape[0], other.shape[0] if other is not None else 0, dtype_code(gin), stream_ptr(dev)), "seg_extremum_bwd_shared"))
+            return gout
+        # an operand of this plan falls outside the vector kernel's domain: the scalar kernel with unit tie counts on the shares
+        ones = torch.ones(fwd.shape, dtype=torch.float32, device=dev)
+        gin, ties = share, ones
     check(lib().pygho_seg_extremum_bwd(ptr(gout), ptr(gin), ptr(fwd), ptr(ties), ptr(self_vals), ptr(other),
                                        ptr(seg_ptr), ptr(out_idx), ptr(other_idx), n_rows, d, dtype_code(gin),
                                        stream_ptr(dev)), "seg_extremum_bwd")
@@ -413,7 +463,7 @@ class _MessageReduce(torch.autograd.Function):
         ties = None
         if aggr in ("max", "min"):
             ties = _ties(fwd, lhs, rhs, plan.fwd.seg_ptr, plan.c_fwd if lhs is not None else None,
-                         plan.d_fwd if rhs is not None else None)
+                         plan.d_fwd if rhs is not None else None, gin=gout)
         if lhs is not None and ctx.needs_input_grad[0]:
             p, a_g, d_g = plan.by_c()
             if ties is None:
@@ -488,7 +538,7 @@ class _ScatterReduce(torch.autograd.Function):
             scaled = gout * plan.inv_count.to(gout.dtype).unsqueeze(-1)
             return row_gather(scaled, ind32), None, None, None
         src, fwd = ctx.saved_tensors
-        ties = _ties(fwd, src, None, plan.seg_ptr, plan.perm, None)
+        ties = _ties(fwd, src, None, plan.seg_ptr, plan.perm, None, gin=gout)
         up = unit_ptr(src.shape[0], src.device)
         return _extremum_bwd(src.shape[0], gout, fwd, ties, src, None, up, ind32, None), None, None, None
 
@@ -599,7 +649,7 @@ class _Spmm(torch.autograd.Function):
         scale = plan.inv_count if aggr == "mean" else None
         ties = None
         if aggr in ("max", "min"):
-            ties = _ties(fwd, val, X, plan.seg_ptr, plan.perm if val is not None else None, src_g)
+            ties = _ties(fwd, val, X, plan.seg_ptr, plan.perm if val is not None else None, src_g, gin=gout)
         if val is not None and ctx.needs_input_grad[0]:
             up = unit_ptr(e, gout.device)
             if ties is None:

@@ -459,6 +459,49 @@ def test_baseline_size_elementwise_vs_host_oracle(dev, kind, graphs, d, key, dty
                 torch.testing.assert_close(xg.grad.cpu(), gX2, rtol=1e-5, atol=1e-5)
                 torch.testing.assert_close(ag.grad.cpu(), gA2, rtol=1e-5, atol=1e-4)
         del xg, ag, out
+    # max (the reference's other first-class aggregation, utils.py:44-56): forward = the extremum of the exact products rounded once;
+    # gradients = torch's scatter_reduce_backward rule restated chunk by chunk (oracle.aten_port.spspmm_extremum_grads_chunked: even
+    # split among ties, the share grad / N rounded to the value dtype, f32 sums in message order) -- bit for bit, f32 and bf16
+    xg = xh.to(dev).requires_grad_(True)
+    ag = ah.to(dev).requires_grad_(True)
+    out = message_reduce(xg, ag, acd, nt, nt, ne, "max")
+    fwd = P.spspmm_values_chunked(x32, a32, acd_h[0], acd_h[1], acd_h[2], nt, "max")
+    same(out, fwd, f"{kind} max forward")
+    out.backward(gh.to(dev))
+    gX, gA = P.spspmm_extremum_grads_chunked(x32, a32, acd_h, nt, cast(fwd), g32, store_dtype=dtype)
+    same(xg.grad, gX, f"{kind} max: gradient wrt the tuple values (by-tuple plan)")
+    same(ag.grad, gA, f"{kind} max: gradient wrt the adjacency values (by-edge plan)")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("aggr", ["max", "min"])
+def test_extremum_backward_with_ties_and_zero_extrema_vs_autograd_of_the_port(dev, dtype, aggr):
+    """values on a small integer grid (many ties, many extrema that are exactly 0): the gradient of max / min against AUTOGRAD through
+    the reference's op sequence on the host (oracle.aten_port.spspmm_values: index, index, mul, scatter_reduce_(amax|amin)).  Torch
+    counts (self == result) into the number of ties, and `self` is the zero-initialised output (utils.py:44-49), so an extremum of
+    exactly 0 shares its gradient with one phantom tie -- reproduced (it is what the reference computes).  Grid values and small
+    tie counts keep every quotient and product exact in bf16 too, so the comparison is to f32 rounding of the sums."""
+    from oracle import aten_port as P
+    from pygho_amd import synth
+    from pygho_amd._ops import message_reduce
+    hb = synth.make_batch(40, "zinc", seed=9)
+    acd_h = torch.from_numpy(hb.acd["X___X___1___A___0"])
+    nt, ne, d = hb.num_tuples, hb.num_edges, 64
+    gen = torch.Generator().manual_seed(1)
+    grid = torch.tensor([-2.0, -1.0, 0.0, 1.0, 2.0])
+    xh = grid[torch.randint(0, 5, (nt, d), generator=gen)].requires_grad_(True)
+    ah = grid[torch.randint(0, 5, (ne, d), generator=gen)].requires_grad_(True)
+    gh = torch.randint(-8, 9, (nt, d), generator=gen).float() * 6.0            # divisible by 1, 2, 3 and 6: exact shares for most tie counts
+    P.spspmm_values(xh, ah, acd_h, nt, aggr).backward(gh)
+    xg = xh.detach().to(dev).to(dtype).requires_grad_(True)
+    ag = ah.detach().to(dev).to(dtype).requires_grad_(True)
+    out = message_reduce(xg, ag, acd_h.to(dev), nt, nt, ne, aggr)
+    assert torch.equal(out.detach().float().cpu(), P.spspmm_values(xh.detach(), ah.detach(), acd_h, nt, aggr))
+    assert int((out == 0).sum()) > 100, "the case must contain extrema that are exactly zero"
+    out.backward(gh.to(dev).to(dtype))
+    tol = dict(rtol=1e-5, atol=1e-4) if dtype == torch.float32 else dict(rtol=2 ** -7, atol=0.3)
+    torch.testing.assert_close(xg.grad.float().cpu(), xh.grad, **tol)
+    torch.testing.assert_close(ag.grad.float().cpu(), ah.grad, **tol)
 
 
 @pytest.mark.parametrize("kind", ["i2", "zinc"])

@@ -93,7 +93,7 @@ def config5(dev, quick=False, kernels_only=False):
     import bench_layers
     graphs, d = (256 if quick else 2048), 256
     key = "X___X___2___A___0"
-    hb = synth.replicate(synth.make_batch(128, "i2", seed=1), graphs // 128)
+    hb = synth.make_batch(graphs, "i2", seed=1)                        # every graph distinct: no tiled index pattern
     acd = torch.from_numpy(hb.acd[key]).to(dev)
     nt, ne, m = hb.num_tuples, hb.num_edges, acd.shape[1]
     X = torch.randn(nt, d, device=dev).to(torch.bfloat16)
@@ -128,11 +128,12 @@ def config3(dev, quick=False, kernels_only=False):
     from pygho_amd.backend.Mamamm import mamamm
     import bench_ops
     b, n, d, dt = (128 if quick else 1024), 37, 128, torch.bfloat16
-    dn = synth.make_dense_batch(min(b, 256), seed=2, hidden=d, nmax=n)
-    rep = max(1, b // min(b, 256))
-    t = lambda a, to=None: (lambda v: v.to(to) if to else v)(torch.from_numpy(a).to(dev).repeat((rep,) + (1,) * (a.ndim - 1)))
-    X = MaskedTensor(t(dn["X"], dt), t(dn["Xmask"]), 0.0, True)
-    A = MaskedTensor(t(dn["A"], dt), t(dn["Amask"]), 0.0, True)
+    dn = synth.make_dense_batch(b, seed=2, hidden=1, nmax=n)           # every graph distinct (the masks; values are drawn on the device)
+    xm, am = torch.from_numpy(dn["Xmask"]).to(dev), torch.from_numpy(dn["Amask"]).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    vals = lambda mask: (torch.randn(mask.shape + (d,), device=dev, generator=gen) * mask.unsqueeze(-1)).to(dt)
+    X = MaskedTensor(vals(xm), xm, 0.0, True)
+    A = MaskedTensor(vals(am), am, 0.0, True)
     Y = MaskedTensor(torch.randn_like(X.raw) * X.mask.unsqueeze(-1).to(dt), X.mask, 0.0, True)
     bb = X.shape[0]
     tensor = bb * n * n * d * 2
@@ -167,6 +168,12 @@ def layers(dev, quick=False):
         r = bench_layers.case(name, graphs, dev)
         out[f"{name}_SS_layer_fwd_bwd"] = {"ms": r["ms"], "graphs": r["graphs"], "graphs_per_s": r["graphs_per_s"], "tuples": r["tuples"],
                                            "d": r["d"], "msg_edges": r["msg_edges"]}
+    # the reference's other first-class aggregation (pygho/backend/utils.py:44-56, --aggr in example/zinc.py): max, with the
+    # per-launch figures of its backward (share pass + the two gradient plans on the 16-byte-per-lane kernels)
+    r = bench_layers.case("NGNNConv", graphs, dev, aggr="max", kernels=True)
+    out["NGNNConv_SS_max_layer_fwd_bwd"] = {"ms": r["ms"], "graphs": r["graphs"], "graphs_per_s": r["graphs_per_s"], "tuples": r["tuples"],
+                                            "d": r["d"], "msg_edges": r["msg_edges"],
+                                            "kernels": {k: v for k, v in r["kernels"].items() if k.startswith(("seg_ext", "seg_gmr"))}}
     return out
 
 

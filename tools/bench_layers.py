@@ -19,10 +19,22 @@ from pygho_amd.honn.SpOperator import parse_precomputekey       # noqa: E402
 MLP = {"numlayer": 1, "tailact": True, "norm": "bn", "act": "silu", "dp": 0.0}
 
 
-def build(name, h, dev):
+_BATCHES = {}
+
+
+def batch(graphs, kind, keys, seed=11):
+    """`graphs` DISTINCT synthetic graphs (no tiled pattern), generated once per (size, kind, keys) and shared by the cases"""
+    k = (graphs, kind, tuple(keys), seed)
+    if k not in _BATCHES:
+        _BATCHES.clear()                                   # one host batch alive at a time
+        _BATCHES[k] = synth.make_batch(graphs, kind, seed=seed, keys=tuple(keys))
+    return _BATCHES[k]
+
+
+def build(name, h, dev, aggr="sum"):
     torch.manual_seed(0)
     if name == "NGNNConv":
-        return Conv.NGNNConv(h, h, "sum", "SS", dict(MLP)).to(dev)
+        return Conv.NGNNConv(h, h, aggr, "SS", dict(MLP)).to(dev)
     if name == "SSWLConv":
         return Conv.SSWLConv(h, h, "sum", "SS", dict(MLP)).to(dev)
     if name == "SUNConv":
@@ -32,13 +44,11 @@ def build(name, h, dev):
     raise ValueError(name)
 
 
-def case(name, graphs, dev, profile=False):
+def case(name, graphs, dev, profile=False, aggr="sum", kernels=False):
     kind, h = ("i2", 256) if name == "I2Conv" else ("zinc", 128)
-    layer = build(name, h, dev)
+    layer = build(name, h, dev, aggr)
     keys = tuple(parse_precomputekey(layer))
-    hb = synth.make_batch(min(graphs, 1024), kind, seed=11, keys=keys)
-    if graphs > 1024:
-        hb = synth.replicate(hb, graphs // 1024)
+    hb = batch(graphs, kind, keys)
     dd = synth.to_datadict(hb, dev, kind)
     from pygho_amd import SparseTensor
     X0, A0 = dd["X"], dd["A"]
@@ -75,8 +85,18 @@ def case(name, graphs, dev, profile=False):
             torch.cuda.synchronize()
         print(pr.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=90), file=sys.stderr)
     msgs = {k: int(dd[k + "___acd"].shape[1]) for k in keys}
-    return {"op": f"{name} SS layer fwd+bwd", "graphs": hb.num_graphs, "tuples": int(X0.nnz), "d": h, "dtype": "bfloat16",
-            "msg_edges": msgs, "ms": ms, "graphs_per_s": hb.num_graphs / ms * 1e3}
+    res = {"op": f"{name} SS layer fwd+bwd" + ("" if aggr == "sum" else f" (aggr={aggr})"), "graphs": hb.num_graphs, "tuples": int(X0.nnz),
+           "d": h, "dtype": "bfloat16", "msg_edges": msgs, "ms": ms, "graphs_per_s": hb.num_graphs / ms * 1e3}
+    if kernels:                                           # per-launch HIP-event times of the segment kernels of one more step
+        from pygho_amd import _ops
+        timer = _ops.LaunchTimer()
+        with timer:
+            for _ in range(3):
+                step()
+        torch.cuda.synchronize()
+        res["kernels"] = {k: {"launches": v[0], "avg_ms": v[1], "algorithmic_bytes": v[2], "GBps": v[2] / (v[1] * 1e-3) / 1e9,
+                              "frac": v[2] / (v[1] * 1e-3) / 1e9 / 8000.0} for k, v in timer.summary().items()}
+    return res
 
 
 def model_case(conv, graphs, dev):
@@ -87,9 +107,7 @@ def model_case(conv, graphs, dev):
     torch.manual_seed(0)
     model = SpModel(conv, num_layer=6, hiddim=128, act_dtype=torch.bfloat16).to(dev)
     keys = tuple(parse_precomputekey(model))
-    hb = synth.make_batch(min(graphs, 1024), kind, seed=11, keys=keys)
-    if graphs > 1024:
-        hb = synth.replicate(hb, graphs // 1024)
+    hb = batch(graphs, kind, keys)
     dd = synth.to_datadict(hb, dev, kind)
     y = dd["y"].unsqueeze(-1)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3)

@@ -175,16 +175,16 @@ def sunconv_case(b, n, d, dtype, dev):
     cores, masked pooling / broadcast kernels, fused BatchNorm MLPs), forward + backward, padded ZINC-shape batch."""
     from pygho_amd import MaskedTensor
     from pygho_amd.honn import Conv
-    dn = synth.make_dense_batch(min(b, 256), seed=2, hidden=d, nmax=n)
-    rep = max(1, b // min(b, 256))
-    t = lambda a, dt=None: (torch.from_numpy(a).to(dev).repeat((rep,) + (1,) * (a.ndim - 1)).to(dt) if dt
-                            else torch.from_numpy(a).to(dev).repeat((rep,) + (1,) * (a.ndim - 1)))
+    dn = synth.make_dense_batch(b, seed=2, hidden=1, nmax=n)           # every graph distinct (masks from the generator, values drawn on the device)
+    xm, am = torch.from_numpy(dn["Xmask"]).to(dev), torch.from_numpy(dn["Amask"]).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    vals = lambda mask: (torch.randn(mask.shape + (d,), device=dev, generator=gen) * mask.unsqueeze(-1)).to(dtype)
     mlp = {"numlayer": 1, "tailact": True, "norm": "bn", "act": "silu", "dp": 0.0}
     torch.manual_seed(0)
     layer = Conv.SUNConv(d, d, "sum", "mean", "DD", dict(mlp), dict(mlp)).to(dev)
-    Xraw = t(dn["X"], dtype).requires_grad_(True)
-    X = MaskedTensor(Xraw, t(dn["Xmask"]), 0.0, True)
-    A = MaskedTensor(t(dn["A"], dtype), t(dn["Amask"]), 0.0, True)
+    Xraw = vals(xm).requires_grad_(True)
+    X = MaskedTensor(Xraw, xm, 0.0, True)
+    A = MaskedTensor(vals(am), am, 0.0, True)
     w = torch.randn_like(Xraw)
 
     def step():
