@@ -202,6 +202,32 @@ int pygho_seg_extremum_bwd_shared(void* gout, const void* share, const void* fwd
                                   const int32_t* other_idx, int64_t n_seg, int64_t d, int64_t out_rows,
                                   int64_t other_rows, int dtype, void* stream);
 
+/*
+ * The by-edge gradient of the tuple product as a SCATTER over the forward message order (csrc/seg_scatter.hip): the gradient of the
+ * second operand's values in out[a] = sum_{(a,c,d)} A[c] * B[d],
+ *   gB[d] = [addend[d] +] sum_{(a,c,d)} g[a] * A[c]          (autograd of pygho/backend/Spspmm.py:309-315: the index / mul / index_put
+ *                                                            chain of the reference, here one launch that fetches every row once)
+ * for block-diagonal batches.  Planner: `block_m` (n_blocks + 1, int32) cuts the message list (acd in forward order, int32 rows
+ * a32 / c32 / d32) into blocks whose d values form pairwise disjoint contiguous ranges;
+ *   pygho_seg_scatter_count  -> n_chunks[b], blk_e[b] = {first edge, edge count}, flags[0] = max edge count (atomic max; zero it first),
+ *                               flags[1] = number of blocks outside the kernel's limits (more than 255 edges, a not ascending inside
+ *                               the block, more than four messages of one edge among 16 consecutive ones)
+ *   pygho_seg_scatter_write  -> chunk records (4 x int32 each, at chunk0[b] + k with chunk0 = exclusive prefix sum of n_chunks, length
+ *                               n_blocks + 1) and one packed word per message
+ *   pygho_seg_scatter_mul_reduce: bf16 / f16 rows of 64..512 bytes in 64-byte pieces, operands below 2 GiB, 16-byte aligned; `max_edges`
+ *                               = flags[0].  Rows of `out` outside every block's edge range are NOT written (the caller pre-fills them).
+ * Bit-identical to pygho_seg_gather_mul_reduce(_add / _window) over the messages grouped by d (f32 sums in message order).
+ */
+int pygho_seg_scatter_limits(int* max_edges_per_block, int* messages_per_chunk, int* rows_per_window);
+int pygho_seg_scatter_count(int32_t* n_chunks, int32_t* blk_e, int32_t* flags, const int32_t* a32, const int32_t* c32,
+                            const int32_t* d32, const int32_t* block_m, int64_t n_blocks, void* stream);
+int pygho_seg_scatter_write(int32_t* chunks, uint32_t* words, const int32_t* chunk0, const int32_t* blk_e, const int32_t* a32,
+                            const int32_t* c32, const int32_t* d32, const int32_t* block_m, int64_t n_blocks, void* stream);
+int pygho_seg_scatter_mul_reduce(void* out, const void* addend, const void* lhs, const void* rhs, const int32_t* chunks,
+                                 const uint32_t* words, const int32_t* chunk0, const int32_t* blk_e, int64_t n_blocks,
+                                 int64_t n_chunks, int64_t n_msg, int64_t max_edges, int64_t n_out, int64_t d,
+                                 int64_t lhs_rows, int64_t rhs_rows, int dtype, void* stream);
+
 /* f32 row sums of a 16-bit (or f32) operand: out[s, :] = sum_{m in seg s} src[idx ? idx[m] : m, :].
  * First level of the hierarchical reduction of LONG segments (e.g. the backward of a row gather from a
  * table with a handful of rows -- nn.Embedding's index_put_(accumulate) over 10^6 messages per row):

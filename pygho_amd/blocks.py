@@ -628,8 +628,7 @@ class _TupleBlock(torch.autograd.Function):
                     if g_chain is not None:
                         g_rhs = g_rhs + g_chain
                 else:
-                    g_rhs = seg_gmr(plan.n_rhs, g, h, p.seg_ptr, a_g, c_g, "sum", scale,
-                                    addend=None if g_chain is None else g_chain.contiguous())
+                    g_rhs = by_edge_product(plan, g, h, scale, addend=g_chain)
             elif g_chain is not None:
                 g_rhs = g_chain
         elif rhs is not None and ctx.needs_input_grad[10]:
@@ -810,8 +809,7 @@ class _SSWLBlock(torch.autograd.Function):
             p, a_g, c_g = plan2.by_d()                      # ... and the right operand of A X
             gx = seg_gmr(plan2.n_rhs, g2, a, p.seg_ptr, a_g, c_g, "sum", sc2, addend=gx)
         if ctx.needs_input_grad[1]:
-            p, a_g, c_g = plan1.by_d()
-            ga = seg_gmr(plan1.n_rhs, g1, x, p.seg_ptr, a_g, c_g, "sum", sc1)
+            ga = by_edge_product(plan1, g1, x, sc1)
             p, a_g, d_g = plan2.by_c()
             ga = seg_gmr(plan2.n_lhs, g2, x, p.seg_ptr, a_g, d_g, "sum", sc2, addend=ga)
         return (gx, ga, None, None, None, None, gw, gb, ggamma, gbeta) + (None,) * 6

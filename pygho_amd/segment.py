@@ -441,6 +441,116 @@ def message_plan(acd: Tensor, n_out: int, n_lhs: int, n_rhs: int) -> MessagePlan
     return plan
 
 
+# --------------------------------------------------------------------------
+# the by-edge gradient as a scatter over the forward message order, every operand row fetched once (csrc/seg_scatter.hip)
+# --------------------------------------------------------------------------
+SEG_SCATTER = os.environ.get("PYGHO_SEG_SCATTER", "auto")      # "0": never, "1" / "auto": whenever a plan's blocks allow
+
+
+class ScatterPlan:
+    """blocks of consecutive messages whose second-operand rows (edges d) form pairwise disjoint contiguous ranges -- the graphs of a
+    block-diagonal batch -- cut into chunks of at most 64 messages over two windows of at most 32 rows, with one packed word per
+    message (`pygho_seg_scatter_count` / `_write`).  Integer work on the device; two host reads per plan (block count; chunk count +
+    eligibility), cached with the MessagePlan."""
+    __slots__ = ("n_blocks", "n_chunks", "chunk0", "blk_e", "chunks", "words", "max_edges", "covers")
+
+
+def _scatter_plan_build(plan: "MessagePlan", block_m: Optional[Tensor] = None) -> Optional[ScatterPlan]:
+    d, dev = plan.d32, plan.d32.device
+    if block_m is None:
+        # a cut after message m where max d[:m+1] < min d[m+1:]
+        pm = torch.cummax(d, 0).values
+        sm = torch.flip(torch.cummin(torch.flip(d, [0]), 0).values, [0])
+        cut = torch.nonzero(pm[:-1] < sm[1:]).flatten() + 1                      # (host read 1: the number of blocks)
+        block_m = torch.cat([cut.new_zeros(1), cut, cut.new_full((1,), plan.m)]).to(_I32)
+    nb = block_m.numel() - 1
+    n_chunks = torch.empty(nb, dtype=_I32, device=dev)
+    blk_e = torch.empty((nb, 2), dtype=_I32, device=dev)
+    flags = torch.zeros(2, dtype=_I32, device=dev)
+    check(lib().pygho_seg_scatter_count(ptr(n_chunks), ptr(blk_e), ptr(flags), ptr(plan.a32), ptr(plan.c32), ptr(d), ptr(block_m), nb,
+                                        stream_ptr(dev)), "seg_scatter_count")
+    chunk0 = torch.zeros(nb + 1, dtype=_I32, device=dev)
+    torch.cumsum(n_chunks, 0, out=chunk0[1:])
+    e0, ne = blk_e[:, 0], blk_e[:, 1]
+    covers = (e0[0] == 0) & (e0[-1] + ne[-1] == plan.n_rhs) & (e0[1:] == e0[:-1] + ne[:-1]).all()
+    max_edges, bad, total, cov = _fetch(torch.stack([flags[0], flags[1], chunk0[-1], covers.to(_I32)]))   # (host read 2)
+    if bad or max_edges > 255 or total == 0:
+        return None
+    sp = ScatterPlan()
+    sp.n_blocks, sp.n_chunks, sp.chunk0, sp.blk_e, sp.max_edges, sp.covers = nb, int(total), chunk0, blk_e, int(max_edges), bool(cov)
+    sp.chunks = torch.empty((sp.n_chunks, 4), dtype=_I32, device=dev)
+    sp.words = torch.empty(plan.m, dtype=_I32, device=dev)
+    check(lib().pygho_seg_scatter_write(ptr(sp.chunks), ptr(sp.words), ptr(chunk0), ptr(blk_e), ptr(plan.a32), ptr(plan.c32), ptr(d),
+                                        ptr(block_m), nb, stream_ptr(dev)), "seg_scatter_write")
+    return sp
+
+
+def scatter_plan(plan: "MessagePlan") -> Optional[ScatterPlan]:
+    """the plan's ScatterPlan, or None when its blocks are outside the kernel's limits (more than 255 edges in a block, a not sorted
+    inside a block, more than four messages of one edge among 16 consecutive ones).  Never built under stream capture (host reads)."""
+    sp = getattr(plan, "_scatter", None)
+    if sp is not None:
+        return sp or None
+    if plan.m == 0 or plan.m >= (1 << 31) or torch.cuda.is_current_stream_capturing():
+        return None
+    plan._scatter = _scatter_plan_build(plan) or False
+    return plan._scatter or None
+
+
+def _scatter_eligible(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], scale, addend) -> bool:
+    if SEG_SCATTER == "0" or h is None or scale is not None or g.dtype not in (torch.bfloat16, torch.float16) or h.dtype != g.dtype:
+        return False
+    rb = g.shape[1] * g.element_size() if g.dim() == 2 else 0
+    if rb == 0 or rb % 64 != 0 or rb > 512 or h.dim() != 2 or h.shape[1] != g.shape[1] or plan.n_rhs < 4096:
+        return False
+    if max(g.shape[0], h.shape[0], plan.n_rhs) * rb >= (1 << 31) or g.shape[0] != plan.n_out or h.shape[0] != plan.n_lhs:
+        return False
+    sp = scatter_plan(plan)
+    if sp is None:
+        return False
+    per_wave = (sp.max_edges + 7) // 8 * 8 * 144 + 2 * 32 * 80 + 256
+    return (rb // 64) * per_wave <= 160 * 1024
+
+
+def by_edge_product(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], scale: Optional[Tensor] = None,
+                    addend: Optional[Tensor] = None) -> Tensor:
+    """out[d] = [addend[d] +] sum over the plan's messages (a, c, d) of [scale[a] *] g[a] * h[c]   (n_rhs rows): the gradient of the
+    SECOND operand's values of `out[a] = (+) A[c] B[d]` with g the output gradient and h the first operand (autograd of
+    pygho/backend/Spspmm.py:309-315).  16-bit rows over a block-diagonal plan go through the scatter form (every row fetched once);
+    everything else through the gather form over the messages grouped by d -- same bits either way."""
+    if not _scatter_eligible(plan, g, h, scale, addend):
+        p, a_g, c_g = plan.by_d()
+        return seg_gmr(plan.n_rhs, g, h, p.seg_ptr, a_g, c_g if h is not None else None, "sum", scale,
+                       addend=None if addend is None else addend.contiguous())
+    sp = scatter_plan(plan)
+    dev = require_device(g, h, addend)
+    g, h = g.contiguous(), h.contiguous()
+    d = g.shape[1]
+    if addend is not None:
+        addend = addend.contiguous()
+        assert addend.shape == (plan.n_rhs, d) and addend.dtype == g.dtype
+    if sp.covers:
+        out = torch.empty((plan.n_rhs, d), dtype=g.dtype, device=dev)
+    else:                                                   # rows outside every block: no message reaches them
+        out = torch.zeros((plan.n_rhs, d), dtype=g.dtype, device=dev) if addend is None else addend.clone()
+    timer = LaunchTimer.active
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(dev))
+    check(lib().pygho_seg_scatter_mul_reduce(ptr(out), ptr(addend), ptr(g), ptr(h), ptr(sp.chunks), ptr(sp.words), ptr(sp.chunk0),
+                                             ptr(sp.blk_e), sp.n_blocks, sp.n_chunks, plan.m, sp.max_edges, plan.n_rhs, d, g.shape[0], h.shape[0],
+                                             dtype_code(g), stream_ptr(dev)), "seg_scatter_mul_reduce")
+    if timer is not None:
+        e1.record(torch.cuda.current_stream(dev))
+        es = g.element_size()
+        # the same algorithmic bytes as the gather form (every operand row once, every output row once, two int32 indices per message,
+        # the CSR pointers): the figures of the two forms compare like for like
+        nbytes = es * d * (g.shape[0] + h.shape[0] + plan.n_rhs * (2 if addend is not None else 1)) + 8 * plan.m + 4 * (plan.n_rhs + 1)
+        timer.records.append((f"seg_gmr[{str(g.dtype).split('.')[-1]},sum,both{',res' if addend is not None else ''},scatter]",
+                              nbytes, e0, e1))
+    return out
+
+
 class _MessageReduce(torch.autograd.Function):
     """out[a] = (+) lhs[c] * rhs[d] over the plan; either operand may be None (pattern only)."""
 
@@ -471,10 +581,10 @@ class _MessageReduce(torch.autograd.Function):
             else:
                 g_lhs = _extremum_bwd(plan.n_lhs, gout, fwd, ties, lhs, rhs, p.seg_ptr, a_g, d_g)
         if rhs is not None and ctx.needs_input_grad[1]:
-            p, a_g, c_g = plan.by_d()
             if ties is None:
-                g_rhs = seg_gmr(plan.n_rhs, gout, lhs, p.seg_ptr, a_g, c_g if lhs is not None else None, "sum", scale)
+                g_rhs = by_edge_product(plan, gout, lhs, scale)
             else:
+                p, a_g, c_g = plan.by_d()
                 g_rhs = _extremum_bwd(plan.n_rhs, gout, fwd, ties, rhs, lhs, p.seg_ptr, a_g, c_g)
         g_add = gout if len(ctx.needs_input_grad) > 4 and ctx.needs_input_grad[4] else None      # out = addend + reduction
         return g_lhs, g_rhs, None, None, g_add

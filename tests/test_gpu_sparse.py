@@ -504,6 +504,89 @@ def test_extremum_backward_with_ties_and_zero_extrema_vs_autograd_of_the_port(de
     torch.testing.assert_close(ag.grad.float().cpu(), ah.grad, **tol)
 
 
+@pytest.mark.parametrize("kind,graphs,d,key", [("zinc", 600, 128, "X___X___1___A___0"), ("zinc", 300, 64, "X___X___1___A___0"),
+                                               ("i2", 96, 256, "X___X___2___A___0"), ("i2", 80, 128, "X___X___2___A___0")])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_addend", [False, True])
+def test_by_edge_scatter_form_is_bit_identical_to_the_gather_form(dev, kind, graphs, d, key, dtype, with_addend):
+    """the by-edge gradient gB[d] = [addend +] sum g[a] * A[c] as a scatter over the forward message order (csrc/seg_scatter.hip: every
+    operand row fetched once, per-block f32 accumulators in LDS) against the gather form over the messages grouped by d
+    (seg_gmr on plan.by_d(), the fast / window kernels): the same f32 sums in the same order, so the same bits -- and against an f64
+    sum of the exact products to one rounding.  Also the planner's invariants: chunks partition every block's messages, windows hold
+    every row a chunk's messages name, and the packed words decode back to (a, c, d)."""
+    from pygho_amd import _ops, synth
+    from pygho_amd import segment as S
+    hb = synth.make_batch(graphs, kind, seed=5)
+    acd = torch.from_numpy(hb.acd[key]).to(dev)
+    nt, ne = hb.num_tuples, hb.num_edges
+    plan = _ops.message_plan(acd, nt, nt, ne)
+    sp = S.scatter_plan(plan)
+    assert sp is not None and sp.covers and sp.n_blocks == graphs, "a block-diagonal batch: one block per graph, every edge row covered"
+    # ---- planner invariants (integer work, exact) ----
+    chunks = sp.chunks.cpu().numpy().astype(np.int64)
+    words = sp.words.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    a, c, dd = (acd[i].cpu().numpy() for i in range(3))
+    chunk0, blk_e = sp.chunk0.cpu().numpy(), sp.blk_e.cpu().numpy()
+    m_lo, n = chunks[:, 0], chunks[:, 3] & 0xFF
+    a_rows, c_rows = (chunks[:, 3] >> 8) & 0xFF, (chunks[:, 3] >> 16) & 0xFF
+    first, last = (chunks[:, 3] >> 24) & 1, (chunks[:, 3] >> 25) & 1
+    assert m_lo[0] == 0 and np.array_equal(m_lo[1:], (m_lo + n)[:-1]) and m_lo[-1] + n[-1] == acd.shape[1]
+    assert n.min() >= 1 and n.max() <= 64 and a_rows.max() <= 32 and c_rows.max() <= 32
+    assert first.sum() == last.sum() == graphs and np.array_equal(np.nonzero(first)[0], chunk0[:-1])
+    blk_of_chunk = np.cumsum(first) - 1
+    ci = np.repeat(np.arange(len(n)), n)                                     # chunk of every message
+    assert np.array_equal((words & 31) + chunks[ci, 1], a) and np.array_equal(((words >> 5) & 31) + chunks[ci, 2], c)
+    assert np.array_equal(((words >> 10) & 255) + blk_e[blk_of_chunk[ci], 0], dd)
+    assert ((words & 31) < a_rows[ci]).all() and (((words >> 5) & 31) < c_rows[ci]).all()
+    pos = np.arange(acd.shape[1]) - m_lo[ci]
+    trip = ci * 4 + pos // 16
+    order = np.lexsort((np.arange(len(dd)), dd, trip))                        # within a trip: by edge, then by message
+    same = (trip[order][1:] == trip[order][:-1]) & (dd[order][1:] == dd[order][:-1])
+    run = np.zeros(len(dd), dtype=np.int64)
+    for i in np.nonzero(same)[0]:
+        run[i + 1] = run[i] + 1
+    phase = np.empty_like(run)
+    phase[order] = run
+    assert np.array_equal((words >> 18) & 3, phase) and phase.max() <= 3
+    # ---- values ----
+    gen = torch.Generator(device=dev).manual_seed(0)
+    g = torch.randn(nt, d, device=dev, generator=gen).to(dtype)
+    h = torch.randn(nt, d, device=dev, generator=gen).to(dtype)
+    add = torch.randn(ne, d, device=dev, generator=gen).to(dtype) if with_addend else None
+    timer = _ops.LaunchTimer()
+    with timer:
+        got = S.by_edge_product(plan, g, h, None, add)
+    torch.cuda.synchronize()
+    assert any(",scatter" in k for k in timer.summary()), f"the scatter kernel was not dispatched: {list(timer.summary())}"
+    p, a_g, c_g = plan.by_d()
+    ref = _ops.seg_gmr(ne, g, h, p.seg_ptr, a_g, c_g, "sum", None, addend=add)
+    assert torch.equal(got, ref), f"{int((got != ref).sum())} of {got.numel()} elements differ from the gather form"
+    exact = torch.zeros(ne, d, dtype=torch.float64, device=dev).index_add_(0, acd[2], g.double()[acd[0]] * h.double()[acd[1]])
+    if add is not None:
+        exact = exact + add.double()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    torch.testing.assert_close(got.double(), exact, rtol=eps, atol=eps * float(exact.abs().max()) * 2.0 ** -6)
+    assert torch.equal(S.by_edge_product(plan, g, h, None, add), got)          # and run to run
+
+
+def test_by_edge_scatter_falls_back_outside_its_limits(dev):
+    """plans the scatter kernel cannot take -- a block with more than 255 edges (one big graph), a pattern that is not block diagonal
+    in message order -- return no ScatterPlan, and by_edge_product gives the gather form's result through the window / fast kernels"""
+    from pygho_amd import _ops
+    from pygho_amd import segment as S
+    gen = torch.Generator().manual_seed(3)
+    nt, ne, m, d = 6000, 5000, 40000, 128
+    a = torch.sort(torch.randint(0, nt, (m,), generator=gen)).values
+    acd = torch.stack([a, torch.randint(0, nt, (m,), generator=gen), torch.randint(0, ne, (m,), generator=gen)]).to(dev)
+    plan = _ops.message_plan(acd, nt, nt, ne)
+    assert S.scatter_plan(plan) is None                                        # one block of 5000 edges
+    g = torch.randn(nt, d, device=dev).to(torch.bfloat16)
+    h = torch.randn(nt, d, device=dev).to(torch.bfloat16)
+    got = S.by_edge_product(plan, g, h)
+    exact = torch.zeros(ne, d, dtype=torch.float64, device=dev).index_add_(0, acd[2], g.double()[acd[0]] * h.double()[acd[1]])
+    torch.testing.assert_close(got.double(), exact, rtol=2.0 ** -8, atol=2.0 ** -8)
+
+
 @pytest.mark.parametrize("kind", ["i2", "zinc"])
 @pytest.mark.parametrize("win", [8, 24, 32])
 def test_tile_plan_invariants(dev, kind, win):
