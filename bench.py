@@ -426,10 +426,11 @@ def main():
         summ = timer.summary()
         # the dominant kernel is ONE template instance (seg_gmr_fast_kernel<T, SUM, BOTH>): the forward launches carry
         # the residual row in their epilogue (",res"), the two backward launches per layer do not
-        # (seg_gmr_window_kernel -- ",window" -- serves the by-edge backward plan since round 2; it is reported beside it)
+        # (the by-edge backward plan runs on its own kernels -- seg_scatter_kernel ",scatter" since round 4, seg_gmr_window_kernel
+        # ",window" where the scatter form does not apply; they are reported beside it, in `spspmm_all_launches` and `kernels`)
         dom = f"seg_gmr[{'bfloat16' if act_dtype is not None else 'float32'},sum,both"
         every = [v for k, v in summ.items() if k.startswith(dom)]
-        parts = [v for k, v in summ.items() if k.startswith(dom) and ",window" not in k]
+        parts = [v for k, v in summ.items() if k.startswith(dom) and ",window" not in k and ",scatter" not in k]
         launches = sum(v[0] for v in parts)
         ms = sum(v[0] * v[1] for v in parts) / launches
         nbytes = sum(v[0] * v[2] for v in parts) / launches

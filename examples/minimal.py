@@ -107,10 +107,9 @@ def train_captured(args, model, store, dev):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         kind = "eager warm-up + capture + replay" if epoch == 0 else "replay"
-        # the epoch statistic is formed on the HOST: an eager kernel between the replays of several captured graphs (even a
-        # one-element fill) makes later replays return NaN on this PyTorch-ROCm build unless the whole device is synchronised
-        # after it -- reproduced with a plain torch.nn model and capturable AdamW, see pygho_amd/graphs.py
-        mean_loss = sum(float(l) for l in losses) / len(losses)
+        # (eager device work between replays is fine: the NaN rounds 2-3 saw here came from torch's own BatchNorm under bf16
+        # autocast inside a captured step, which no shipped model runs any more -- pygho_amd/graphs.py)
+        mean_loss = float(torch.stack(losses).mean())
         print(f"epoch {epoch} ({kind}): mean L1 {mean_loss:.4f}, {len(batches) * args.batch / dt:,.0f} graphs/s, "
               f"{dt / len(batches) * 1e3:.2f} ms per {args.batch}-graph step")
 

@@ -192,14 +192,15 @@ int pygho_seg_extremum_bwd(void* gout, const void* gin, const void* fwd_out, con
  *   share[a, :] = gin[a, :] / ties[a, :]   rounded to the value dtype -- torch's grad / N_to_distribute in the gradient's dtype
  *                                          (autograd of scatter_reduce_(amax|amin), pygho/backend/utils.py:50-55); 0 for empty segments
  *   gout[s, :]  = sum_m share[a_m, :] * other(m) * [msg(m) == fwd_out[a_m]]         f32 accumulation, one rounding at the store
- * `*_rows` = row counts of the gathered operands (range of the 32-bit byte offsets).
+ * `*_rows` = row counts of the gathered operands (range of the 32-bit byte offsets); `n_msg` = seg_ptr[n_seg] (picks the number of
+ * messages a lane group keeps in flight).
  */
 int pygho_seg_extremum_share(void* share, const void* gin, const void* fwd_out, const void* lhs, const void* rhs,
                              const int32_t* seg_ptr, const int32_t* lhs_idx, const int32_t* rhs_idx, int64_t n_seg,
-                             int64_t d, int64_t lhs_rows, int64_t rhs_rows, int dtype, void* stream);
+                             int64_t n_msg, int64_t d, int64_t lhs_rows, int64_t rhs_rows, int dtype, void* stream);
 int pygho_seg_extremum_bwd_shared(void* gout, const void* share, const void* fwd_out, const void* self_vals,
                                   const void* other_vals, const int32_t* seg_ptr, const int32_t* out_idx,
-                                  const int32_t* other_idx, int64_t n_seg, int64_t d, int64_t out_rows,
+                                  const int32_t* other_idx, int64_t n_seg, int64_t n_msg, int64_t d, int64_t out_rows,
                                   int64_t other_rows, int dtype, void* stream);
 
 /*

@@ -69,6 +69,25 @@ class DeviceGraphStore:
                 cnt_d.append(np.bincount(dd_, minlength=rows_of(r, roles[3])).reshape(1, -1))
             self.plan_parts[k] = {"perm_c": _cat32(perm_c, 1, d), "perm_d": _cat32(perm_d, 1, d), "cnt_a": _cat32(cnt_a, 1, d),
                                   "cnt_c": _cat32(cnt_c, 1, d), "cnt_d": _cat32(cnt_d, 1, d)}
+        # the by-edge gradient's scatter plans (csrc/seg_scatter.hip), likewise ONCE for the whole store: the device planner over the
+        # graph-local triples with one block per graph.  A batch's chunks are its graphs' chunks with the message / row offsets added
+        # and its packed words are its graphs' words unchanged (they are relative to chunk windows and block edge ranges)
+        self.scatter_parts = {}
+        for k in self.plan_parts:
+            acd = self.acd[k]
+            if acd.shape[1] == 0 or acd.shape[1] >= (1 << 31):
+                continue
+            block_m = self.acd_ptr[k].to(torch.int32)
+            parts = _ops.scatter_plan_parts(acd[0].contiguous(), acd[1].contiguous(), acd[2].contiguous(), block_m)
+            if parts is None:
+                continue
+            n_chunks, chunk0, blk_e, chunks, words, max_edges = parts
+            roles = parse_key(k)
+            rows3 = (self.tup_ptr if roles[3][0] == "X" else self.edge_ptr)
+            n_rows3 = (rows3[1:] - rows3[:-1]).to(torch.int32)
+            covers = bool(((blk_e[:, 0] == 0) & (blk_e[:, 1] == n_rows3)).all())        # every graph's triples reach all of its rows
+            self.scatter_parts[k] = {"chunk_ptr": chunk0.to(torch.int64), "chunks_t": chunks.t().contiguous(), "words": words.reshape(1, -1),
+                                     "blk_e": blk_e.t().contiguous(), "max_edges": max_edges, "covers": covers}
         self.y = torch.tensor([r.y for r in records], dtype=torch.float32, device=d)
 
     # ------------------------------------------------------------------
@@ -87,7 +106,8 @@ class DeviceGraphStore:
         ids = torch.as_tensor(graph_ids, dtype=torch.int64).to(self.device).contiguous()
         require_device(ids)
         g = ids.numel()
-        lens = {"node": self.node_ptr, "edge": self.edge_ptr, "tup": self.tup_ptr, **{("acd", k): v for k, v in self.acd_ptr.items()}}
+        lens = {"node": self.node_ptr, "edge": self.edge_ptr, "tup": self.tup_ptr, **{("acd", k): v for k, v in self.acd_ptr.items()},
+                **{("sc", k): v["chunk_ptr"] for k, v in self.scatter_parts.items()}}
         ptrs = {}
         for name, sp in lens.items():
             ptrs[name] = _ops.exclusive_scan(_ops.gather_cols(sp, ids + 1) - _ops.gather_cols(sp, ids))
@@ -129,6 +149,18 @@ class DeviceGraphStore:
                                                csr(parts["cnt_a"], roles[0]), csr(parts["cnt_c"], roles[1]), perm("perm_c"),
                                                csr(parts["cnt_d"], roles[3]), perm("perm_d"))
             _ops.install_message_plan(acd, plan)
+            sc = self.scatter_parts.get(k)
+            if sc is not None and total[("sc", k)] > 0:
+                # chunk records {first message, first a row, first c row, packed}: message offset of the graph inside the batch instead
+                # of inside the store, row offsets of the two operands' graphs; the packed field and the words travel unchanged
+                first_m = ptrs[("acd", k)][:-1] - _ops.gather_cols(self.acd_ptr[k], ids)
+                inc = torch.stack([first_m, off[name(roles[0])], off[name(roles[1])], torch.zeros_like(first_m)])
+                ch = self._rows(sc["chunks_t"], sc["chunk_ptr"], ids, ptrs[("sc", k)], total[("sc", k)], inc)
+                words = self._rows(sc["words"], self.acd_ptr[k], ids, ptrs[("acd", k)], total[("acd", k)], None).reshape(-1)
+                e = sc["blk_e"][:, ids].to(torch.int64)
+                blk_e = torch.stack([e[0] + off[name(roles[3])], e[1]], dim=1).to(torch.int32).contiguous()
+                _ops.install_scatter_plan(plan, ptrs[("sc", k)].to(torch.int32), blk_e, ch.t().to(torch.int32).contiguous(),
+                                          words.to(torch.int32), sc["max_edges"], sc["covers"])
         return dd
 
 

@@ -345,8 +345,8 @@ __global__ __launch_bounds__(kBlock) void seg_extremum_bwd_kernel(
 
 // ---- max / min backward, 16 bytes per lane (the scalar kernels above remain the path for f64 and odd row widths) -----------------
 // A lane group (2^log2g lanes, `chunks` of them active) owns one segment, a wavefront 64 >> log2g segments at a time; kExtTrip
-// messages of a segment are in flight per trip (index loads, then row loads, all independent).
-constexpr int kExtTrip = 4;
+// messages of a segment are in flight per trip (index loads, then row loads, all independent): 2 for plans of about two messages per
+// segment (a trip's slots beyond the segment repeat its last message: wasted requests), 4 for longer segments.
 
 // v rounded to the storage type (what the forward stored, what the reference's elementwise product holds)
 template <typename T> __device__ __forceinline__ void round_to_storage(float (&v)[Vec16<T>::N]) {
@@ -355,7 +355,7 @@ template <typename T> __device__ __forceinline__ void round_to_storage(float (&v
 
 // share[s] = gin[s] / #{messages of segment s whose value equals the forward extremum}  (torch splits the gradient evenly among
 // ties: grad / N_to_distribute, rounded to the gradient's dtype -- autograd of scatter_reduce_(amax|amin), pygho/backend/utils.py:50-55)
-template <typename T>
+template <typename T, int kExtTrip>
 __global__ __launch_bounds__(kBlock) void seg_extremum_share_kernel(
     T* __restrict__ share, const T* __restrict__ gin, const T* __restrict__ fwd, const T* __restrict__ lhs, const T* __restrict__ rhs,
     const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ lhs_idx, const int32_t* __restrict__ rhs_idx,
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void seg_extremum_share_kernel(
 
 // gout[s] = sum over the messages m of segment s (a plan grouped by the operand being differentiated) of
 //           share[a_m] * other(m) * [round(self[s] * other(m)) == fwd[a_m]],   f32 accumulation, one rounding at the store
-template <typename T>
+template <typename T, int kExtTrip>
 __global__ __launch_bounds__(kBlock) void seg_extremum_bwd_vec_kernel(
     T* __restrict__ gout, const T* __restrict__ share, const T* __restrict__ fwd, const T* __restrict__ self_vals,
     const T* __restrict__ other, const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ out_idx,
@@ -819,7 +819,7 @@ static int extremum_vec_shape(int64_t d, int dtype, int64_t max_rows, int* chunk
 
 extern "C" int pygho_seg_extremum_share(void* share, const void* gin, const void* fwd_out, const void* lhs, const void* rhs,
                                         const int32_t* seg_ptr, const int32_t* lhs_idx, const int32_t* rhs_idx, int64_t n_seg,
-                                        int64_t d, int64_t lhs_rows, int64_t rhs_rows, int dtype, void* stream) {
+                                        int64_t n_msg, int64_t d, int64_t lhs_rows, int64_t rhs_rows, int dtype, void* stream) {
   if (n_seg < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
   if (n_seg == 0 || d == 0) return PYGHO_OK;
   if (!share || !gin || !fwd_out || !seg_ptr) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
@@ -832,8 +832,12 @@ extern "C" int pygho_seg_extremum_share(void* share, const void* gin, const void
   }
   hipStream_t st = (hipStream_t)stream;
   const int gx = grid_for(n_seg, (kBlock / kWave) * (kWave >> log2g));
-#define PYGHO_EXT_SHARE(T) hipLaunchKernelGGL((seg_extremum_share_kernel<T>), dim3(gx), dim3(kBlock), 0, st, (T*)share, (const T*)gin, \
-    (const T*)fwd_out, (const T*)lhs, (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, n_seg, (int)d, chunks, log2g)
+#define PYGHO_EXT_SHARE(T) do { if (n_msg < 3 * n_seg)                                                                                  \
+      hipLaunchKernelGGL((seg_extremum_share_kernel<T, 2>), dim3(gx), dim3(kBlock), 0, st, (T*)share, (const T*)gin, (const T*)fwd_out, \
+                         (const T*)lhs, (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, n_seg, (int)d, chunks, log2g);                        \
+    else                                                                                                                                \
+      hipLaunchKernelGGL((seg_extremum_share_kernel<T, 4>), dim3(gx), dim3(kBlock), 0, st, (T*)share, (const T*)gin, (const T*)fwd_out, \
+                         (const T*)lhs, (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, n_seg, (int)d, chunks, log2g); } while (0)
   if (dtype == PYGHO_F32) PYGHO_EXT_SHARE(float); else if (dtype == PYGHO_BF16) PYGHO_EXT_SHARE(bf16); else PYGHO_EXT_SHARE(f16);
 #undef PYGHO_EXT_SHARE
   return check_launch("seg_extremum_share");
@@ -841,7 +845,7 @@ extern "C" int pygho_seg_extremum_share(void* share, const void* gin, const void
 
 extern "C" int pygho_seg_extremum_bwd_shared(void* gout, const void* share, const void* fwd_out, const void* self_vals,
                                              const void* other_vals, const int32_t* seg_ptr, const int32_t* out_idx,
-                                             const int32_t* other_idx, int64_t n_seg, int64_t d, int64_t out_rows,
+                                             const int32_t* other_idx, int64_t n_seg, int64_t n_msg, int64_t d, int64_t out_rows,
                                              int64_t other_rows, int dtype, void* stream) {
   if (n_seg < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
   if (n_seg == 0 || d == 0) return PYGHO_OK;
@@ -855,8 +859,12 @@ extern "C" int pygho_seg_extremum_bwd_shared(void* gout, const void* share, cons
   }
   hipStream_t st = (hipStream_t)stream;
   const int gx = grid_for(n_seg, (kBlock / kWave) * (kWave >> log2g));
-#define PYGHO_EXT_BWD(T) hipLaunchKernelGGL((seg_extremum_bwd_vec_kernel<T>), dim3(gx), dim3(kBlock), 0, st, (T*)gout, (const T*)share, \
-    (const T*)fwd_out, (const T*)self_vals, (const T*)other_vals, seg_ptr, out_idx, other_idx, n_seg, (int)d, chunks, log2g)
+#define PYGHO_EXT_BWD(T) do { if (n_msg < 3 * n_seg)                                                                                     \
+      hipLaunchKernelGGL((seg_extremum_bwd_vec_kernel<T, 2>), dim3(gx), dim3(kBlock), 0, st, (T*)gout, (const T*)share, (const T*)fwd_out, \
+                         (const T*)self_vals, (const T*)other_vals, seg_ptr, out_idx, other_idx, n_seg, (int)d, chunks, log2g);          \
+    else                                                                                                                                 \
+      hipLaunchKernelGGL((seg_extremum_bwd_vec_kernel<T, 4>), dim3(gx), dim3(kBlock), 0, st, (T*)gout, (const T*)share, (const T*)fwd_out, \
+                         (const T*)self_vals, (const T*)other_vals, seg_ptr, out_idx, other_idx, n_seg, (int)d, chunks, log2g); } while (0)
   if (dtype == PYGHO_F32) PYGHO_EXT_BWD(float); else if (dtype == PYGHO_BF16) PYGHO_EXT_BWD(bf16); else PYGHO_EXT_BWD(f16);
 #undef PYGHO_EXT_BWD
   return check_launch("seg_extremum_bwd_shared");

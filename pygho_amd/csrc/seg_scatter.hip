@@ -285,11 +285,13 @@ __global__ __launch_bounds__(512) void seg_scatter_kernel(
   auto compute = [&](const int4& dsc) {
     const int n = dsc.w & 0xff;
     if (n == 0) return;
-    if ((dsc.w >> 24) & 1) {                             // first chunk of the next block
-      ++b;
-      const int2 be = blk_e[b];
-      e0 = __builtin_amdgcn_readfirstlane(be.x);
-      ne = __builtin_amdgcn_readfirstlane(be.y);
+    if ((dsc.w >> 24) & 1) {                             // first chunk of the next block that has messages (an empty block -- a graph
+      do {                                               // without a message triple -- has no chunk and no edge row to write)
+        ++b;
+        const int2 be = blk_e[b];
+        e0 = __builtin_amdgcn_readfirstlane(be.x);
+        ne = __builtin_amdgcn_readfirstlane(be.y);
+      } while (ne == 0);
     }
     if (!((dsc.w >> 25) & 1)) {
       trips_of(n);

@@ -15,13 +15,20 @@ through the C ABI and no entry point synchronises or allocates, so a step on sta
 * the optimizer is created with ``capturable=True``; gradients are reset with ``set_to_none=True`` inside the step;
 * no host read-back (``.item()``, ``print(loss)``) inside the step -- return tensors and read them after ``replay()``.
 
-Several captured steps (one per fixed mini-batch, ``examples/minimal.py``): with four or more captured SpModel steps sharing one
-capturable AdamW, an EAGER kernel launched between replays made later replays return NaN in round 2 unless
-``torch.cuda.synchronize()`` (device-wide; a stream synchronisation was not enough) ran after it; ``examples/minimal.py`` therefore
-forms its statistics on the host (``float(loss)``).  Round 2 attributed this to the PyTorch 2.10 / ROCm 7.2 build; the plain
-``torch.nn`` reduction committed as ``tools/repro_graph_nan.py`` does NOT show it on this build (0 non-finite losses of 120 with
-2, 4 and 6 captured steps, with and without the synchronisation), so the cause is not pinned down -- it may as well lie in how
-this package's step interacts with capture.  Keep the device synchronisation after eager work between replays until it is.
+Several captured steps (one per fixed mini-batch, ``examples/minimal.py``) may share one model and one capturable optimizer, with
+eager work between their replays and no device synchronisation (``tests/test_gpu_layers.py::
+test_four_captured_steps_with_eager_work_between_replays``: 0 non-finite losses of 200 replays).
+
+The NaN that rounds 2-3 reported for that regime is root-caused (round 4, ``tools/bisect_graph_nan.py``,
+``tools/repro_graph_nan2.py``): it is NOT a race between replays -- it needs no second graph, no eager work and survives a device
+synchronisation -- and it is not in this package's kernels.  A captured TRAINING STEP THAT RUNS ``torch.nn.BatchNorm1d`` UNDER bf16
+AUTOCAST diverges to NaN within a few replays on this PyTorch 2.10 / ROCm 7.2 build while the same step run eagerly does not; 40 lines
+of plain torch reproduce it (``tools/repro_graph_nan2.py``: 57 of 60 replays non-finite; without autocast, or without the BatchNorm
+module, 0 of 60; MIOpen on or off, training or eval mode, autocast cache on or off, AdamW or SGD make no difference).  In round 2 the
+node-level MLPs of ``SpModel`` still ran torch's BatchNorm; since round 3 every BatchNorm of the shipped models runs on this package's
+own kernels (``_ops.batch_norm_act``) and every Linear on the cast arena (``honn.utils.Linear``), which is why the symptom vanished.
+Consequence for users: a module that falls back to ``torch.nn.BatchNorm1d`` under autocast (``PYGHO_ARENA_LINEAR=0`` provokes it:
+the MLP then keeps torch's Linear + BatchNorm pair for short inputs) must not be captured -- run such a step eagerly.
 """
 from typing import Any, Callable, Iterable
 

@@ -105,7 +105,7 @@ class Linear(nn.Linear):
     bound by launches, and autocast's per-use parameter casts were 20 of its 163); anything else takes the stock path."""
 
     def forward(self, x: Tensor) -> Tensor:
-        if x.is_cuda and x.dim() == 2 and torch.is_grad_enabled():
+        if x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and not self.__dict__.get("_pygho_stock", False):
             dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
             if x.shape[0] >= 8192 or (USE_ARENA_LINEAR and dt in (torch.bfloat16, torch.float16) and self.weight.dtype == torch.float32):
                 xx = x if x.dtype == dt else x.to(dt)

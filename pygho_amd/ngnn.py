@@ -151,6 +151,7 @@ class SpModel(nn.Module):
                 plan = _ops.message_plan(acd, X.nnz, X.nnz, A.nnz)
                 plan.by_c()
                 plan.by_d()
+                _ops.scatter_plan(plan)             # the by-edge gradient's scatter form: blocks / chunks / packed words (two host reads)
                 if "ea" in flats:
                     plan.lookup(flats["ea"])
 

@@ -310,7 +310,7 @@ def _ties(fwd: Tensor, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, gin: Optional[Tensor
         nbytes = es * d * (3 * fwd.shape[0] + (lhs.shape[0] if lhs is not None else 0) + (rhs.shape[0] if rhs is not None else 0)) \
             + 4 * m * ((lhs_idx is not None) + (rhs_idx is not None)) + 4 * (fwd.shape[0] + 1)
         _timed(f"seg_ext_share[{str(fwd.dtype).split('.')[-1]}]", nbytes, dev, lambda: check(lib().pygho_seg_extremum_share(
-            ptr(share), ptr(gin), ptr(fwd), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), fwd.shape[0], d,
+            ptr(share), ptr(gin), ptr(fwd), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), fwd.shape[0], m, d,
             lhs.shape[0] if lhs is not None else 0, rhs.shape[0] if rhs is not None else 0, dtype_code(fwd), stream_ptr(dev)),
             "seg_extremum_share"))
         return ("share", share)
@@ -332,7 +332,7 @@ def _extremum_bwd(n_rows, gin, fwd, ties, self_vals, other, seg_ptr, out_idx, ot
             nbytes = es * d * (2 * fwd.shape[0] + n_rows * (2 if self_vals is not None else 1) + (other.shape[0] if other is not None else 0)) \
                 + 4 * out_idx.numel() * (2 if other_idx is not None else 1) + 4 * (n_rows + 1)
             _timed(f"seg_ext_bwd[{str(gin.dtype).split('.')[-1]}]", nbytes, dev, lambda: check(lib().pygho_seg_extremum_bwd_shared(
-                ptr(gout), ptr(share), ptr(fwd), ptr(self_vals), ptr(other), ptr(seg_ptr), ptr(out_idx), ptr(other_idx), n_rows, d,
+                ptr(gout), ptr(share), ptr(fwd), ptr(self_vals), ptr(other), ptr(seg_ptr), ptr(out_idx), ptr(other_idx), n_rows, out_idx.numel(), d,
                 fwd.shape[0], other.shape[0] if other is not None else 0, dtype_code(gin), stream_ptr(dev)), "seg_extremum_bwd_shared"))
             return gout
         # an operand of this plan falls outside the vector kernel's domain: the scalar kernel with unit tie counts on the shares
@@ -445,6 +445,9 @@ def message_plan(acd: Tensor, n_out: int, n_lhs: int, n_rhs: int) -> MessagePlan
 # the by-edge gradient as a scatter over the forward message order, every operand row fetched once (csrc/seg_scatter.hip)
 # --------------------------------------------------------------------------
 SEG_SCATTER = os.environ.get("PYGHO_SEG_SCATTER", "auto")      # "0": never, "1" / "auto": whenever a plan's blocks allow
+# below ~10^6 messages the launch does not fill the chip's resident set of (blocks x slices) workgroups and the gather form on the
+# window kernel is as fast (128 / 1024-graph ZINC-shape batches: 56 k / 440 k messages)
+SEG_SCATTER_MIN_MESSAGES = int(os.environ.get("PYGHO_SEG_SCATTER_MIN_MESSAGES", str(1 << 20)))
 
 
 class ScatterPlan:
@@ -455,34 +458,56 @@ class ScatterPlan:
     __slots__ = ("n_blocks", "n_chunks", "chunk0", "blk_e", "chunks", "words", "max_edges", "covers")
 
 
-def _scatter_plan_build(plan: "MessagePlan", block_m: Optional[Tensor] = None) -> Optional[ScatterPlan]:
-    d, dev = plan.d32, plan.d32.device
-    if block_m is None:
-        # a cut after message m where max d[:m+1] < min d[m+1:]
-        pm = torch.cummax(d, 0).values
-        sm = torch.flip(torch.cummin(torch.flip(d, [0]), 0).values, [0])
-        cut = torch.nonzero(pm[:-1] < sm[1:]).flatten() + 1                      # (host read 1: the number of blocks)
-        block_m = torch.cat([cut.new_zeros(1), cut, cut.new_full((1,), plan.m)]).to(_I32)
+def scatter_plan_parts(a32: Tensor, c32: Tensor, d32: Tensor, block_m: Tensor):
+    """the planner over given blocks: (n_chunks per block, chunk0 = their exclusive scan (int32, n_blocks + 1), blk_e (n_blocks, 2),
+    chunks (total, 4), words (M), max_edges, bad) -- two kernels and ONE host read (chunk total + flags)"""
+    dev = d32.device
     nb = block_m.numel() - 1
     n_chunks = torch.empty(nb, dtype=_I32, device=dev)
     blk_e = torch.empty((nb, 2), dtype=_I32, device=dev)
     flags = torch.zeros(2, dtype=_I32, device=dev)
-    check(lib().pygho_seg_scatter_count(ptr(n_chunks), ptr(blk_e), ptr(flags), ptr(plan.a32), ptr(plan.c32), ptr(d), ptr(block_m), nb,
+    check(lib().pygho_seg_scatter_count(ptr(n_chunks), ptr(blk_e), ptr(flags), ptr(a32), ptr(c32), ptr(d32), ptr(block_m), nb,
                                         stream_ptr(dev)), "seg_scatter_count")
     chunk0 = torch.zeros(nb + 1, dtype=_I32, device=dev)
     torch.cumsum(n_chunks, 0, out=chunk0[1:])
-    e0, ne = blk_e[:, 0], blk_e[:, 1]
-    covers = (e0[0] == 0) & (e0[-1] + ne[-1] == plan.n_rhs) & (e0[1:] == e0[:-1] + ne[:-1]).all()
-    max_edges, bad, total, cov = _fetch(torch.stack([flags[0], flags[1], chunk0[-1], covers.to(_I32)]))   # (host read 2)
+    max_edges, bad, total = _fetch(torch.stack([flags[0], flags[1], chunk0[-1]]))
     if bad or max_edges > 255 or total == 0:
         return None
+    chunks = torch.empty((int(total), 4), dtype=_I32, device=dev)
+    words = torch.empty(d32.numel(), dtype=_I32, device=dev)
+    check(lib().pygho_seg_scatter_write(ptr(chunks), ptr(words), ptr(chunk0), ptr(blk_e), ptr(a32), ptr(c32), ptr(d32), ptr(block_m), nb,
+                                        stream_ptr(dev)), "seg_scatter_write")
+    return n_chunks, chunk0, blk_e, chunks, words, int(max_edges)
+
+
+def _scatter_plan_build(plan: "MessagePlan") -> Optional[ScatterPlan]:
+    d = plan.d32
+    # a cut after message m where max d[:m+1] < min d[m+1:]
+    pm = torch.cummax(d, 0).values
+    sm = torch.flip(torch.cummin(torch.flip(d, [0]), 0).values, [0])
+    cut = torch.nonzero(pm[:-1] < sm[1:]).flatten() + 1                      # (host read 1: the number of blocks)
+    block_m = torch.cat([cut.new_zeros(1), cut, cut.new_full((1,), plan.m)]).to(_I32)
+    parts = scatter_plan_parts(plan.a32, plan.c32, d, block_m)                # (host read 2)
+    if parts is None:
+        return None
+    _, chunk0, blk_e, chunks, words, max_edges = parts
+    e0, ne = blk_e[:, 0], blk_e[:, 1]
+    covers = (e0[0] == 0) & (e0[-1] + ne[-1] == plan.n_rhs) & (e0[1:] == e0[:-1] + ne[:-1]).all()
     sp = ScatterPlan()
-    sp.n_blocks, sp.n_chunks, sp.chunk0, sp.blk_e, sp.max_edges, sp.covers = nb, int(total), chunk0, blk_e, int(max_edges), bool(cov)
-    sp.chunks = torch.empty((sp.n_chunks, 4), dtype=_I32, device=dev)
-    sp.words = torch.empty(plan.m, dtype=_I32, device=dev)
-    check(lib().pygho_seg_scatter_write(ptr(sp.chunks), ptr(sp.words), ptr(chunk0), ptr(blk_e), ptr(plan.a32), ptr(plan.c32), ptr(d),
-                                        ptr(block_m), nb, stream_ptr(dev)), "seg_scatter_write")
+    sp.n_blocks, sp.n_chunks, sp.chunk0, sp.blk_e, sp.max_edges = block_m.numel() - 1, chunks.shape[0], chunk0, blk_e, max_edges
+    sp.chunks, sp.words = chunks, words
+    sp.covers = bool(_fetch(covers.to(_I32).reshape(1))[0])                  # (host read 3, a single flag)
     return sp
+
+
+def install_scatter_plan(plan: "MessagePlan", chunk0: Tensor, blk_e: Tensor, chunks: Tensor, words: Tensor, max_edges: int,
+                         covers: bool) -> None:
+    """a ScatterPlan that already exists (`collate.DeviceGraphStore`: the chunks of a block-diagonal batch are its graphs' precomputed
+    chunks with the message / row offsets added): no planner launch, no host read.  The caller guarantees the planner's contract."""
+    sp = ScatterPlan()
+    sp.n_blocks, sp.n_chunks, sp.chunk0, sp.blk_e, sp.max_edges, sp.covers = chunk0.numel() - 1, chunks.shape[0], chunk0, blk_e, max_edges, covers
+    sp.chunks, sp.words = chunks, words
+    plan._scatter = sp if sp.n_chunks > 0 else False
 
 
 def scatter_plan(plan: "MessagePlan") -> Optional[ScatterPlan]:
@@ -501,7 +526,7 @@ def _scatter_eligible(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], scale
     if SEG_SCATTER == "0" or h is None or scale is not None or g.dtype not in (torch.bfloat16, torch.float16) or h.dtype != g.dtype:
         return False
     rb = g.shape[1] * g.element_size() if g.dim() == 2 else 0
-    if rb == 0 or rb % 64 != 0 or rb > 512 or h.dim() != 2 or h.shape[1] != g.shape[1] or plan.n_rhs < 4096:
+    if rb == 0 or rb % 64 != 0 or rb > 512 or h.dim() != 2 or h.shape[1] != g.shape[1] or plan.m < SEG_SCATTER_MIN_MESSAGES:
         return False
     if max(g.shape[0], h.shape[0], plan.n_rhs) * rb >= (1 << 31) or g.shape[0] != plan.n_out or h.shape[0] != plan.n_lhs:
         return False

@@ -508,7 +508,7 @@ def test_extremum_backward_with_ties_and_zero_extrema_vs_autograd_of_the_port(de
                                                ("i2", 96, 256, "X___X___2___A___0"), ("i2", 80, 128, "X___X___2___A___0")])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("with_addend", [False, True])
-def test_by_edge_scatter_form_is_bit_identical_to_the_gather_form(dev, kind, graphs, d, key, dtype, with_addend):
+def test_by_edge_scatter_form_is_bit_identical_to_the_gather_form(dev, kind, graphs, d, key, dtype, with_addend, monkeypatch):
     """the by-edge gradient gB[d] = [addend +] sum g[a] * A[c] as a scatter over the forward message order (csrc/seg_scatter.hip: every
     operand row fetched once, per-block f32 accumulators in LDS) against the gather form over the messages grouped by d
     (seg_gmr on plan.by_d(), the fast / window kernels): the same f32 sums in the same order, so the same bits -- and against an f64
@@ -516,6 +516,7 @@ def test_by_edge_scatter_form_is_bit_identical_to_the_gather_form(dev, kind, gra
     every row a chunk's messages name, and the packed words decode back to (a, c, d)."""
     from pygho_amd import _ops, synth
     from pygho_amd import segment as S
+    monkeypatch.setattr(S, "SEG_SCATTER_MIN_MESSAGES", 0)                      # the dispatch threshold (10^6 messages) is a speed matter
     hb = synth.make_batch(graphs, kind, seed=5)
     acd = torch.from_numpy(hb.acd[key]).to(dev)
     nt, ne = hb.num_tuples, hb.num_edges
@@ -1191,6 +1192,16 @@ def test_collated_message_plans_equal_sorted_ones(dev):
         for a, b in ((got.by_c(), ref.by_c()), (got.by_d(), ref.by_d())):
             assert torch.equal(a[0].seg_ptr, b[0].seg_ptr) and torch.equal(a[0].perm, b[0].perm)
             assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        # the by-edge gradient's scatter plan: collated from the store's per-graph chunks == planned on the collated triples
+        sp_got, sp_ref = _ops.scatter_plan(got), _ops.scatter_plan(ref)
+        if key == "X___X___1___A___0":
+            assert sp_got is not None and sp_got.covers
+        if sp_got is not None:                                                # (the other key's blocks -- the graphs' tuple rows -- may exceed 255 rows)
+            assert sp_ref is not None and sp_ref.covers == sp_got.covers
+            assert sp_got.n_blocks == sp_ref.n_blocks == ids.numel() and sp_got.n_chunks == sp_ref.n_chunks
+            assert sp_got.max_edges >= sp_ref.max_edges                       # the store's maximum over ALL its graphs
+            for name in ("chunk0", "blk_e", "chunks", "words"):
+                assert torch.equal(getattr(sp_got, name), getattr(sp_ref, name)), name
 
 
 def test_deferred_index_range_check(dev):
