@@ -107,8 +107,8 @@ def train_captured(args, model, store, dev):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         kind = "eager warm-up + capture + replay" if epoch == 0 else "replay"
-        # (eager device work between replays is fine: the NaN rounds 2-3 saw here came from torch's own BatchNorm under bf16
-        # autocast inside a captured step, which no shipped model runs any more -- pygho_amd/graphs.py)
+        # (eager device work between replays is fine: the NaN rounds 2-3 saw here came from torch's stock nn.Linear under bf16
+        # autocast inside a captured step, which the shipped models no longer use -- pygho_amd/graphs.py)
         mean_loss = float(torch.stack(losses).mean())
         print(f"epoch {epoch} ({kind}): mean L1 {mean_loss:.4f}, {len(batches) * args.batch / dt:,.0f} graphs/s, "
               f"{dt / len(batches) * 1e3:.2f} ms per {args.batch}-graph step")

@@ -19,16 +19,22 @@ Several captured steps (one per fixed mini-batch, ``examples/minimal.py``) may s
 eager work between their replays and no device synchronisation (``tests/test_gpu_layers.py::
 test_four_captured_steps_with_eager_work_between_replays``: 0 non-finite losses of 200 replays).
 
-The NaN that rounds 2-3 reported for that regime is root-caused (round 4, ``tools/bisect_graph_nan.py``,
-``tools/repro_graph_nan2.py``): it is NOT a race between replays -- it needs no second graph, no eager work and survives a device
-synchronisation -- and it is not in this package's kernels.  A captured TRAINING STEP THAT RUNS ``torch.nn.BatchNorm1d`` UNDER bf16
-AUTOCAST diverges to NaN within a few replays on this PyTorch 2.10 / ROCm 7.2 build while the same step run eagerly does not; 40 lines
-of plain torch reproduce it (``tools/repro_graph_nan2.py``: 57 of 60 replays non-finite; without autocast, or without the BatchNorm
-module, 0 of 60; MIOpen on or off, training or eval mode, autocast cache on or off, AdamW or SGD make no difference).  In round 2 the
-node-level MLPs of ``SpModel`` still ran torch's BatchNorm; since round 3 every BatchNorm of the shipped models runs on this package's
-own kernels (``_ops.batch_norm_act``) and every Linear on the cast arena (``honn.utils.Linear``), which is why the symptom vanished.
-Consequence for users: a module that falls back to ``torch.nn.BatchNorm1d`` under autocast (``PYGHO_ARENA_LINEAR=0`` provokes it:
-the MLP then keeps torch's Linear + BatchNorm pair for short inputs) must not be captured -- run such a step eagerly.
+The NaN that rounds 2-3 reported for that regime is traced (round 4; ``tools/bisect_graph_nan.py``, ``tools/repro_graph_nan2.py``,
+outputs under ``profiles/r04_graph_nan.md``).  It is NOT a race between replays: it needs no second graph and no eager work, and it
+survives a device synchronisation after every replay.  It is not in this package's kernels either: swapping single modules shows that
+it appears exactly when a node-level ``Linear`` takes torch's stock ``nn.Linear`` under bf16 autocast inside the captured step
+(``PYGHO_ARENA_LINEAR=0``, or ``module._pygho_stock = True`` on ``lin_tupleinit1`` / ``poolmlp.lins.0`` alone: 45-47 of 50 replays
+non-finite; the same steps run eagerly: 0 of 212), and 40 lines of plain torch reproduce it without this package: ONE captured
+training step of ``Embedding -> nn.Linear -> nn.BatchNorm1d -> SiLU -> nn.Linear`` under bf16 autocast goes non-finite within a few
+replays (57 of 60) while eager execution of the same step does not (0 of 60).  In the reduction the NaN needs autocast (f32: 0 of 60),
+the aten batch_norm behind the autocast Linear (Identity or a hand-written affine map: 0 of 60) and a non-zero learning rate (lr 0: 0
+of 60 -- a gradient goes bad, not the forward); MIOpen on / off, BatchNorm in training or eval mode, the autocast cache on / off, AdamW
+or SGD, and the row count (3000 ... 28509, multiples of 256 included) make no difference.  Which gradient inside torch's autocast
+``nn.Linear`` / ``batch_norm`` backward goes bad under replay on this PyTorch 2.10 / ROCm 7.2 build is not identified.  In rounds 2-3
+the node-level Linears of ``SpModel`` still were autocast ``nn.Linear`` calls; since the end of round 3 they read the cast arena
+(``honn.utils.Linear`` -> ``_ArenaLinearFn``, explicit 16-bit GEMMs outside autocast), which is why the symptom vanished.
+Consequence for users: do not capture a step that sends 16-bit autocast through torch's own ``nn.Linear`` (``PYGHO_ARENA_LINEAR=0``
+provokes it, as would a user module outside this package's layers) -- run such a step eagerly.
 """
 from typing import Any, Callable, Iterable
 

@@ -1584,9 +1584,10 @@ def test_ppgn_forward_residual(dev):
 def test_four_captured_steps_with_eager_work_between_replays(dev):
     """Four captured SpModel training steps (one per fixed mini-batch) sharing ONE model and ONE capturable AdamW, an eager kernel and
     an eager allocation between replays, NO device synchronisation: 0 non-finite losses of 200 replays and finite parameters.  The NaN
-    rounds 2-3 reported for this regime is torch's own BatchNorm1d under bf16 autocast inside a captured step (plain-torch
-    reduction: tools/repro_graph_nan2.py); every BatchNorm / Linear of the shipped models runs on this package's kernels, so the
-    captured step contains no aten batch_norm launch -- asserted here with the profiler on one eager step."""
+    rounds 2-3 reported for this regime comes from torch's stock nn.Linear under bf16 autocast (+ aten batch_norm) inside a captured
+    step (plain-torch reduction: tools/repro_graph_nan2.py; pygho_amd/graphs.py); the shipped models run every Linear on the cast
+    arena and every BatchNorm on this package's kernels -- the step contains no aten batch_norm launch, asserted here with the
+    profiler on one eager step."""
     from pygho_amd import synth
     from pygho_amd.graphs import GraphedStep
     from pygho_amd.ngnn import SpModel

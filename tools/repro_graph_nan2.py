@@ -18,6 +18,9 @@ ap.add_argument("--no-cache", action="store_true", help="torch.autocast(cache_en
 ap.add_argument("--eval-bn", action="store_true", help="BatchNorm in eval mode (running statistics, no update)")
 ap.add_argument("--no-track", action="store_true", help="BatchNorm1d(track_running_stats=False)")
 ap.add_argument("--sgd", action="store_true", help="plain SGD instead of capturable AdamW")
+ap.add_argument("--affine", action="store_true", help="a hand-written per-channel affine map (two f32 parameters) in place of BatchNorm1d")
+ap.add_argument("--single", action="store_true", help="one Linear in front instead of the product of two")
+ap.add_argument("--lr", type=float, default=1e-3)
 ap.add_argument("--no-miopen", action="store_true", help="torch.backends.cudnn.enabled = False: ATen's native batch-norm kernels")
 ap.add_argument("--bn-f32-input", action="store_true", help="cast the BatchNorm input to f32 by hand")
 args = ap.parse_args()
@@ -36,19 +39,23 @@ class M(torch.nn.Module):
         self.p = torch.nn.Linear(W, W)
         self.bn = torch.nn.Identity() if args.no_bn else torch.nn.BatchNorm1d(W, track_running_stats=not args.no_track)
         self.out = torch.nn.Linear(W, 1)
+        self.aw, self.ab = torch.nn.Parameter(torch.ones(W)), torch.nn.Parameter(torch.zeros(W))
 
     def forward(self, idx):
         x = self.emb(idx) if args.f32 else self.emb(idx).to(torch.bfloat16)
-        h = self.l0(x) * self.l1(x)
+        h = self.l0(x) if args.single else self.l0(x) * self.l1(x)
         h = self.p(h)
-        h = torch.nn.functional.silu(self.bn(h.float() if args.bn_f32_input else h))
+        if args.affine:
+            h = torch.nn.functional.silu(h * self.aw + self.ab)
+        else:
+            h = torch.nn.functional.silu(self.bn(h.float() if args.bn_f32_input else h))
         return self.out(h)
 
 
 model = M().to(dev)
 if args.eval_bn:
     model.bn.eval()
-opt = torch.optim.SGD(model.parameters(), lr=1e-3) if args.sgd else torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True)
+opt = torch.optim.SGD(model.parameters(), lr=args.lr) if args.sgd else torch.optim.AdamW(model.parameters(), lr=args.lr, capturable=True)
 idx = torch.randint(0, 32, (args.rows,), device=dev)
 y = torch.randn(args.rows, 1, device=dev)
 
@@ -82,4 +89,4 @@ else:
         torch.cuda.synchronize()
         bad += int(not bool(torch.isfinite(out)))
 print(f"rows {args.rows}, capture {not args.no_capture}, bn {not args.no_bn}, autocast {not args.f32}, miopen {not args.no_miopen}, "
-      f"bn input f32 {args.bn_f32_input}, cache {not args.no_cache}, eval-bn {args.eval_bn}, track {not args.no_track}, sgd {args.sgd}: non-finite losses {bad} of {args.epochs}")
+      f"bn input f32 {args.bn_f32_input}, cache {not args.no_cache}, eval-bn {args.eval_bn}, track {not args.no_track}, sgd {args.sgd}, affine {args.affine}, single {args.single}, lr {args.lr}: non-finite losses {bad} of {args.epochs}")
