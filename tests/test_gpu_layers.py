@@ -144,6 +144,10 @@ def test_ngnn_model_matches_reference_model(dev):
             np.testing.assert_allclose(N(after[k[6:]]), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
 
 
+BF16_TRAJECTORY_RTOL = 0.015     # measured 1.06 % after 6 steps (bf16 activations against the f32 port); round 3 allowed 2 %
+BF16_DELTA_COSINE = 0.95          # measured 0.968 (ea_encoder.weight, the smallest over the weight matrices)
+
+
 @pytest.mark.parametrize("dtype,optimizer", [(None, "adamw_fused"), (None, "adamw_foreach"), (None, "sgd_fused"),
                                              (torch.bfloat16, "adamw_fused"), (torch.bfloat16, "adamw_foreach")])
 def test_ngnn_training_trajectory_matches_the_host_port(dev, dtype, optimizer):
@@ -177,6 +181,7 @@ def test_ngnn_training_trajectory_matches_the_host_port(dev, dtype, optimizer):
         opt_h = torch.optim.AdamW(port.parameters(), lr=1e-3)
     steps = 6
     got, exp = [], []
+    init = {P.port_key(k): v.detach().cpu().clone() for k, v in model.state_dict().items()}
     for _ in range(steps):
         opt_d.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype is not None):
@@ -200,7 +205,19 @@ def test_ngnn_training_trajectory_matches_the_host_port(dev, dtype, optimizer):
                     scale = max(float(v.abs().max()), 1e-3)
                     np.testing.assert_allclose(N(after[k]) / scale, v.numpy() / scale, rtol=0, atol=1e-4, err_msg=k)
     else:
-        np.testing.assert_allclose(got, exp, rtol=0.02, err_msg="loss trajectory (bf16 activations)")
+        rel = max(abs(a - b) / abs(b) for a, b in zip(got, exp))
+        assert rel < BF16_TRAJECTORY_RTOL, f"loss trajectory (bf16 activations): max relative difference {rel:.4f}: {got} vs {exp}"
+        # and the parameters themselves: the 6-step displacement of every weight matrix points where the host port's does (a run whose
+        # 16-bit weight copies do not follow the optimizer keeps differentiating at the initial weights and turns away)
+        after = {P.port_key(k): v.detach().cpu() for k, v in model.state_dict().items()}
+        worst = (1.0, None)
+        for k, v in port.state_dict().items():
+            if v.dtype.is_floating_point and v.dim() == 2 and v.numel() >= 1024:
+                dh, dd_ = (v - init[k]).flatten().double(), (after[k] - init[k]).flatten().double()
+                cos = float(torch.dot(dh, dd_) / (dh.norm() * dd_.norm() + 1e-30))
+                worst = min(worst, (cos, k))
+        print(f"bf16 trajectory: max relative loss difference {rel:.4f}, smallest displacement cosine {worst[0]:.4f} ({worst[1]})")
+        assert worst[0] > BF16_DELTA_COSINE, f"parameter displacement of {worst[1]} deviates from the host port's: cosine {worst[0]:.3f}"
 
 
 def _sun_check(layer, g, name, A_of, X_of, av, xv, dd, dev, fn="forward", amask=1.0):

@@ -51,7 +51,7 @@ def main():
         "rocprof_avg_us": float(row["AverageNs"]) / 1e3, "rocprof_calls": int(row["Calls"]),
         "note": "separate --pmc passes of `rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 3 "
                 "--warmup 1 --no-cpu-baseline`; launches with grid > 100k threads only (the 8192-graph aggregation: forward with "
-                "the residual row + the by-tuple backward launch per layer; the by-edge backward plan runs on seg_gmr_window_kernel); FETCH_SIZE x1.97 per profiles/r01_pmc_seg_gmr.md",
+                "the residual row + the by-tuple backward launch per layer; the by-edge backward plan runs on seg_scatter_kernel); FETCH_SIZE x1.97 per profiles/r01_pmc_seg_gmr.md",
     }, open(out, "w"), indent=1)
     print(open(out).read())
 

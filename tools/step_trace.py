@@ -26,7 +26,8 @@ def main():
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    ends = [i for i, r in enumerate(rows) if "FusedAdam" in r[2] or "fused_adam" in r[2].lower()]
+    opt = [i for i, r in enumerate(rows) if "FusedAdam" in r[2] or "fused_adam" in r[2].lower()]
+    ends = [i for k, i in enumerate(opt) if k + 1 == len(opt) or opt[k + 1] != i + 1]        # the LAST launch of every optimizer step
     if len(ends) < 4:
         print(f"only {len(ends)} optimizer launches found in {len(rows)} kernels")
         return
