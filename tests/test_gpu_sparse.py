@@ -570,6 +570,78 @@ def test_by_edge_scatter_form_is_bit_identical_to_the_gather_form(dev, kind, gra
     assert torch.equal(S.by_edge_product(plan, g, h, None, add), got)          # and run to run
 
 
+def _synthetic_blocks(rng, n_graphs, tuples, edges, msgs_per_tuple, c_spread, skip=(), cyclic=False):
+    """block-diagonal message triples made by hand: graph g owns tuple rows [g * tuples, ...) and edge rows [g * edges, ...); every
+    tuple a sends `msgs_per_tuple` messages whose c lies within `c_spread` rows of a, to random edges of its graph (`cyclic`: to edge
+    (message number) % edges, so that ANY 16 consecutive messages hit every edge equally often); graphs in `skip` send none"""
+    a, c, d = [], [], []
+    for g in range(n_graphs):
+        if g in skip:
+            continue
+        t0, e0, sent = g * tuples, g * edges, 0
+        for t in range(tuples):
+            k = int(rng.integers(max(1, msgs_per_tuple - 1), msgs_per_tuple + 2))
+            a += [t0 + t] * k
+            c += list(t0 + np.clip(t + rng.integers(-c_spread, c_spread + 1, k), 0, tuples - 1))
+            d += [e0 + (sent + i) % edges for i in range(k)] if cyclic else list(e0 + rng.integers(0, edges, k))
+            sent += k
+    return np.stack([np.array(a), np.array(c), np.array(d)]).astype(np.int64)
+
+
+@pytest.mark.parametrize("case", ["many_edges", "empty_blocks", "few_blocks", "hot_edges"])
+def test_by_edge_scatter_edge_cases(dev, case, monkeypatch):
+    """the scatter form outside the benchmark shapes, each against the gather form bit for bit: blocks of 97..255 edges (the 16-load
+    flush variant), graphs without a message (their edge rows are covered by no block: the caller pre-fills them, with and without an
+    addend), fewer blocks than compute units, and a few edges that receive many messages of one trip (phases 1..3; a block whose phase
+    would exceed 3 makes the whole plan fall back)"""
+    from pygho_amd import _ops
+    from pygho_amd import segment as S
+    monkeypatch.setattr(S, "SEG_SCATTER_MIN_MESSAGES", 0)
+    rng = np.random.default_rng(11)
+    if case == "many_edges":
+        n_graphs, tuples, edges, acd = 40, 260, 200, None
+        acd = _synthetic_blocks(rng, n_graphs, tuples, edges, 3, 6)
+    elif case == "empty_blocks":
+        n_graphs, tuples, edges = 60, 120, 90
+        acd = _synthetic_blocks(rng, n_graphs, tuples, edges, 2, 8, skip=(0, 17, 18, 59))
+    elif case == "few_blocks":
+        n_graphs, tuples, edges = 3, 200, 90
+        acd = _synthetic_blocks(rng, n_graphs, tuples, edges, 3, 10)
+    else:
+        n_graphs, tuples, edges = 50, 150, 4                       # 4 edges per graph, hit in turn: every trip holds each edge 4 times
+        acd = _synthetic_blocks(rng, n_graphs, tuples, edges, 2, 5, cyclic=True)
+    nt, ne, d = n_graphs * tuples, n_graphs * edges, 128
+    acd_t = torch.from_numpy(acd).to(dev)
+    plan = _ops.message_plan(acd_t, nt, nt, ne)
+    sp = S.scatter_plan(plan)
+    p, a_g, c_g = plan.by_d()
+    gen = torch.Generator(device=dev).manual_seed(1)
+    g = torch.randn(nt, d, device=dev, generator=gen).to(torch.bfloat16)
+    h = torch.randn(nt, d, device=dev, generator=gen).to(torch.bfloat16)
+    add = torch.randn(ne, d, device=dev, generator=gen).to(torch.bfloat16)
+    assert sp is not None
+    if case == "hot_edges":
+        phases = (sp.words.cpu().numpy().astype(np.int64) >> 18) & 3
+        assert phases.max() == 3 and (phases == 3).sum() > 1000, "the case must exercise every phase"
+        # one more message of an edge inside a trip (five of 16) is beyond the kernel's four phases: that plan must fall back
+        acd5 = acd.copy()
+        acd5[2, :16] = acd5[2, 0]
+        plan5 = _ops.message_plan(torch.from_numpy(acd5).to(dev), nt, nt, ne)
+        assert S.scatter_plan(plan5) is None
+    if case == "many_edges":
+        assert 96 < sp.max_edges <= 255
+    if case == "empty_blocks":
+        assert not sp.covers                                       # the edge rows of graphs 0, 17, 18, 59 belong to no block
+    for addend in (None, add):
+        timer = _ops.LaunchTimer()
+        with timer:
+            got = S.by_edge_product(plan, g, h, None, addend)
+        torch.cuda.synchronize()
+        assert any(",scatter" in k for k in timer.summary()), list(timer.summary())
+        ref = _ops.seg_gmr(ne, g, h, p.seg_ptr, a_g, c_g, "sum", None, addend=addend)
+        assert torch.equal(got, ref), f"{case}: {int((got != ref).sum())} of {got.numel()} elements differ (addend: {addend is not None})"
+
+
 def test_by_edge_scatter_falls_back_outside_its_limits(dev):
     """plans the scatter kernel cannot take -- a block with more than 255 edges (one big graph), a pattern that is not block diagonal
     in message order -- return no ScatterPlan, and by_edge_product gives the gather form's result through the window / fast kernels"""
