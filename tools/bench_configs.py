@@ -177,6 +177,37 @@ def layers(dev, quick=False):
     return out
 
 
+def ops(dev, quick=False):
+    """a17 `spmm` (pygho/backend/Spmm.py:6-44: node-level message passing out[t] = sum_e val[e] * X[src[e]] over the batch adjacency):
+    forward and, through autograd, both gradient launches, ZINC-shape adjacency of 8192 distinct graphs, d = 128 bf16.  The working
+    set (E + 2 N rows = 200 MB) is BELOW the 256 MB Infinity Cache: the fraction is on algorithmic bytes, not an HBM claim."""
+    from pygho_amd import _ops
+    import bench_layers
+    graphs, d = (1024 if quick else 8192), 128
+    hb = bench_layers.batch(graphs, "zinc", ("X___X___1___A___0",))
+    ei = torch.from_numpy(hb.edge_index).to(dev)
+    src, tar = ei[1].contiguous(), ei[0].contiguous()
+    n, e = hb.num_nodes, hb.num_edges
+    val = torch.randn(e, d, device=dev).to(torch.bfloat16).requires_grad_(True)
+    X = torch.randn(n, d, device=dev).to(torch.bfloat16).requires_grad_(True)
+    w = torch.randn(n, d, device=dev).to(torch.bfloat16)
+
+    def step():
+        val.grad = X.grad = None
+        _ops.spmm_values(val, X, src, tar, n, "sum").backward(w)
+    for _ in range(3):
+        step()
+    timer = _ops.LaunchTimer()
+    with timer:
+        for _ in range(10):
+            step()
+    torch.cuda.synchronize()
+    return {"spmm_fwd_bwd": {"graphs": hb.num_graphs, "edges": e, "nodes": n, "d": d, "dtype": "bfloat16",
+                             "working_set_MB": 2 * d * (e + 2 * n) / 1e6,
+                             "launches": {k: {"launches": v[0], "avg_ms": v[1], "algorithmic_bytes": v[2], "frac": v[2] / (v[1] * 1e-3) / 1e9 / PEAK}
+                                          for k, v in timer.summary().items()}}}
+
+
 def run(dev, quick=False, kernels_only=False):
     """`kernels_only`: the three kernel entries alone (the command of the --pmc passes: per-kernel counter means stay unmixed)"""
     out = {"config5": config5(dev, quick, kernels_only)}
@@ -185,6 +216,8 @@ def run(dev, quick=False, kernels_only=False):
     torch.cuda.empty_cache()
     if not kernels_only:
         out["layers"] = layers(dev, quick)
+        torch.cuda.empty_cache()
+        out["ops"] = ops(dev, quick)
         torch.cuda.empty_cache()
     out["note"] = ("outside `value`: per-kernel roofline figures of BASELINE configs 3 and 5 and one forward + backward of every shipped "
                    "layer; HIP events around each launch, tools/bench_configs.py; rocprofv3 summaries of this script under profiles/")
