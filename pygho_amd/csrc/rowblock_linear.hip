@@ -472,6 +472,9 @@ int launch_bn_bwd_linear(void* gx, void* gpre, const void* pre, const void* gh, 
 #ifndef PYGHO_DW_PREFETCH_X
 #define PYGHO_DW_PREFETCH_X 1
 #endif
+#ifndef PYGHO_DW_PREFETCH_ADD
+#define PYGHO_DW_PREFETCH_ADD 1          // the addend rows of a tile are requested at the top of the tile, not where the epilogue adds them
+#endif
 typedef __attribute__((ext_vector_type(4))) short rl_s4_t;
 constexpr int kDwThreads = 256, kDwWaves = 4, kDwRowsPerWave = 16, kDwTile = 64;
 
@@ -731,6 +734,21 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
         }
       }
     }
+    // this tile's addend rows (the residual gradient, one of the four streams) are requested HERE, in front of the barrier and the
+    // accumulator staging, not where the epilogue adds them (there the load cost one exposed memory latency per tile and wavefront
+    // -- 54 tiles per workgroup -- and its wait drained the next tile's prefetch as well).  Any earlier and the eight registers
+    // spill: the dW phase above runs at 246 of 256
+    uint4 ca[EIT];
+    if constexpr (PYGHO_DW_PREFETCH_ADD != 0 && RECOMP) {          // (the stored-pre form has no register to spare: f16 + SiLU spilled)
+      if (addend) {
+#pragma unroll
+        for (int it = 0; it < EIT; ++it) {
+          int64_t row = base + it * EROWS + erow0;
+          if (row >= m_rows) row = m_rows - 1;
+          ca[it] = *reinterpret_cast<const uint4*>(addend + row * D + ech * 8);
+        }
+      }
+    }
     rl_lds_barrier();                                    // every wave is done with stage_g / stage_x of this tile
     // ---- epilogue: accumulators -> own rows of stage_o -> row-contiguous chunks (+ addend) -> HBM ---------------------------
 #pragma unroll
@@ -748,7 +766,8 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
         if (addend) {
           float a[8], b[8];
           V::unpack(v, a);
-          V::unpack(*reinterpret_cast<const uint4*>(addend + row * D + ech * 8), b);
+          if constexpr (PYGHO_DW_PREFETCH_ADD != 0 && RECOMP) V::unpack(ca[it], b);
+          else V::unpack(*reinterpret_cast<const uint4*>(addend + row * D + ech * 8), b);
 #pragma unroll
           for (int j = 0; j < 8; ++j) a[j] += b[j];
           v = V::pack(a);
