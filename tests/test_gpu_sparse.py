@@ -360,7 +360,10 @@ def test_i2_shape_and_large_linearity(dev):
     # checksum of checksums: sum_a out[a] == sum_m x[c_m] * a[d_m]
     c, dd = acd_b[1], acd_b[2]
     direct = (x1.double()[c] * a1.double()[dd]).sum(0)
-    torch.testing.assert_close(f(x1, a1).double().sum(0), direct, rtol=1e-6, atol=1e-6)
+    # f32 rows summed into a checksum: the bound is relative to the sum of MAGNITUDES (the signed sum cancels to ~ sqrt(M); a tolerance
+    # relative to it failed for unlucky draws: 3e-6 at one channel)
+    bound = 1e-6 * (x1.double().abs()[c] * a1.double().abs()[dd]).sum(0)
+    assert bool(((f(x1, a1).double().sum(0) - direct).abs() <= bound).all())
     assert bool((torch.diff(acd_b[0]) >= 0).all())                            # collated plan stays sorted
 
 
