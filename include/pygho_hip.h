@@ -223,7 +223,8 @@ int pygho_seg_scatter_limits(int* max_edges_per_block, int* messages_per_chunk, 
 int pygho_seg_scatter_count(int32_t* n_chunks, int32_t* blk_e, int32_t* flags, const int32_t* a32, const int32_t* c32,
                             const int32_t* d32, const int32_t* block_m, int64_t n_blocks, void* stream);
 int pygho_seg_scatter_write(int32_t* chunks, uint32_t* words, const int32_t* chunk0, const int32_t* blk_e, const int32_t* a32,
-                            const int32_t* c32, const int32_t* d32, const int32_t* block_m, int64_t n_blocks, void* stream);
+                            const int32_t* c32, const int32_t* d32, const int32_t* block_m, int64_t n_blocks, int64_t n_chunks,
+                            int64_t n_msg, void* stream);
 int pygho_seg_scatter_mul_reduce(void* out, const void* addend, const void* lhs, const void* rhs, const int32_t* chunks,
                                  const uint32_t* words, const int32_t* chunk0, const int32_t* blk_e, int64_t n_blocks,
                                  int64_t n_chunks, int64_t n_msg, int64_t max_edges, int64_t n_out, int64_t d,

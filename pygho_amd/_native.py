@@ -46,7 +46,7 @@ PROTOTYPES = {
     "pygho_seg_extremum_bwd": (I, [P, P, P, P, P, P, P, P, P, L, L, I, P]),
     "pygho_seg_scatter_limits": (I, [P, P, P]),
     "pygho_seg_scatter_count": (I, [P, P, P, P, P, P, P, L, P]),
-    "pygho_seg_scatter_write": (I, [P, P, P, P, P, P, P, P, L, P]),
+    "pygho_seg_scatter_write": (I, [P, P, P, P, P, P, P, P, L, L, L, P]),
     "pygho_seg_scatter_mul_reduce": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, P]),
     "pygho_seg_extremum_share": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, I, P]),
     "pygho_seg_extremum_bwd_shared": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, I, P]),

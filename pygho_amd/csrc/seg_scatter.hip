@@ -87,16 +87,14 @@ __global__ __launch_bounds__(kBlock) void seg_scatter_count_kernel(int32_t* __re
   if (bad) atomicAdd(&flags[1], 1);
 }
 
-// pass 2: the chunk records {first message, first a row, first c row, n | a rows << 8 | c rows << 16 | first << 24 | last << 25} at
-// chunk0[b] + k and one packed word per message: a offset | c offset << 5 | edge offset << 10 | phase << 18
-__global__ __launch_bounds__(kBlock) void seg_scatter_write_kernel(int32_t* __restrict__ chunks, uint32_t* __restrict__ words,
-                                                                   const int32_t* __restrict__ chunk0, const int32_t* __restrict__ blk_e,
-                                                                   const int32_t* __restrict__ a32, const int32_t* __restrict__ c32,
-                                                                   const int32_t* __restrict__ d32, const int32_t* __restrict__ block_m,
-                                                                   int n_blocks) {
+// pass 2a: the chunk records {first message, first a row, first c row, n | a rows << 8 | c rows << 16 | first << 24 | last << 25} at
+// chunk0[b] + k, one thread per block (the greedy cut is sequential; 400 messages per block without the phase look-back)
+__global__ __launch_bounds__(kBlock) void seg_scatter_chunks_kernel(int32_t* __restrict__ chunks, const int32_t* __restrict__ chunk0,
+                                                                    const int32_t* __restrict__ a32, const int32_t* __restrict__ c32,
+                                                                    const int32_t* __restrict__ block_m, int n_blocks) {
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= n_blocks) return;
-  const int m0 = block_m[b], m1 = block_m[b + 1], e0 = blk_e[2 * b];
+  const int m0 = block_m[b], m1 = block_m[b + 1];
   int k = chunk0[b] - 1, m_lo = m0;
   ScChunker ck;
   ck.n = 0;
@@ -108,10 +106,6 @@ __global__ __launch_bounds__(kBlock) void seg_scatter_write_kernel(int32_t* __re
     rec[2] = ck.c_min;
     const int a_rows = a32[m_end - 1] - ck.a_lo + 1, c_rows = ck.c_max - ck.c_min + 1;
     rec[3] = ck.n | (a_rows << 8) | (c_rows << 16) | ((m_lo == m0 ? 1 : 0) << 24) | ((last ? 1 : 0) << 25);
-    for (int m = m_lo; m < m_end; ++m) {
-      const uint32_t ph = (uint32_t)min(sc_phase(d32, m, (m - m_lo) & (kScMpt - 1)), kScMaxPhase);
-      words[m] = (uint32_t)(a32[m] - ck.a_lo) | ((uint32_t)(c32[m] - ck.c_min) << 5) | ((uint32_t)(d32[m] - e0) << 10) | (ph << 18);
-    }
   };
   for (int m = m0; m < m1; ++m) {
     const int a = a32[m], c = c32[m];
@@ -123,6 +117,33 @@ __global__ __launch_bounds__(kBlock) void seg_scatter_write_kernel(int32_t* __re
     } else ck.add(c);
   }
   close(m1, true);
+}
+
+// pass 2b: one packed word per message, one THREAD per message (a offset | c offset << 5 | edge offset << 10 | phase << 18): its
+// chunk by binary search over the chunk records' first messages, its block's first edge from the chunk's block (binary search over
+// chunk0).  (The one-thread-per-block form of this pass took 10.5 ms at 8192 graphs: 32 workgroups walking 430 messages each with a
+// 15-deep look-back per message.)
+__global__ __launch_bounds__(kBlock) void seg_scatter_words_kernel(uint32_t* __restrict__ words, const int4* __restrict__ chunks,
+                                                                   const int32_t* __restrict__ chunk0, const int32_t* __restrict__ blk_e,
+                                                                   const int32_t* __restrict__ a32, const int32_t* __restrict__ c32,
+                                                                   const int32_t* __restrict__ d32, int n_chunks, int n_blocks,
+                                                                   int64_t n_msg) {
+  const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (m >= n_msg) return;
+  int lo = 0, hi = n_chunks - 1;                         // last chunk whose first message is <= m
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (chunks[mid].x <= (int)m) lo = mid; else hi = mid - 1;
+  }
+  const int4 ch = chunks[lo];
+  int bl = 0, bh = n_blocks - 1;                         // last block whose first chunk is <= lo (blocks without chunks share a start
+  while (bl < bh) {                                      // with their successor: the LAST such block is the one that owns the chunk)
+    const int mid = (bl + bh + 1) >> 1;
+    if (chunk0[mid] <= lo) bl = mid; else bh = mid - 1;
+  }
+  const int e0 = blk_e[2 * bl];
+  const uint32_t ph = (uint32_t)min(sc_phase(d32, (int)m, ((int)m - ch.x) & (kScMpt - 1)), kScMaxPhase);
+  words[m] = (uint32_t)(a32[m] - ch.y) | ((uint32_t)(c32[m] - ch.z) << 5) | ((uint32_t)(d32[m] - e0) << 10) | (ph << 18);
 }
 
 // ---- kernel ---------------------------------------------------------------------------------------------------------------------------
@@ -425,12 +446,17 @@ extern "C" int pygho_seg_scatter_count(int32_t* n_chunks, int32_t* blk_e, int32_
 }
 
 extern "C" int pygho_seg_scatter_write(int32_t* chunks, uint32_t* words, const int32_t* chunk0, const int32_t* blk_e, const int32_t* a32,
-                                       const int32_t* c32, const int32_t* d32, const int32_t* block_m, int64_t n_blocks, void* stream) {
-  if (n_blocks < 0) { set_error("seg_scatter_write: bad size"); return PYGHO_ERR_INVALID; }
-  if (n_blocks == 0) return PYGHO_OK;
+                                       const int32_t* c32, const int32_t* d32, const int32_t* block_m, int64_t n_blocks, int64_t n_chunks,
+                                       int64_t n_msg, void* stream) {
+  if (n_blocks < 0 || n_chunks < 0 || n_msg < 0 || n_msg >= ((int64_t)1 << 31)) { set_error("seg_scatter_write: bad size"); return PYGHO_ERR_INVALID; }
+  if (n_blocks == 0 || n_chunks == 0 || n_msg == 0) return PYGHO_OK;
   if (!chunks || !words || !chunk0 || !blk_e || !a32 || !c32 || !d32 || !block_m) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
-  hipLaunchKernelGGL(seg_scatter_write_kernel, dim3((unsigned)ceil_div(n_blocks, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, chunks,
-                     words, chunk0, blk_e, a32, c32, d32, block_m, (int)n_blocks);
+  if (((uintptr_t)chunks % 16) != 0) { set_error("seg_scatter_write: the chunk records must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(seg_scatter_chunks_kernel, dim3((unsigned)ceil_div(n_blocks, kBlock)), dim3(kBlock), 0, st, chunks, chunk0, a32, c32,
+                     block_m, (int)n_blocks);
+  hipLaunchKernelGGL(seg_scatter_words_kernel, dim3((unsigned)ceil_div(n_msg, kBlock)), dim3(kBlock), 0, st, words, (const int4*)chunks,
+                     chunk0, blk_e, a32, c32, d32, (int)n_chunks, (int)n_blocks, n_msg);
   return check_launch("seg_scatter_write");
 }
 

@@ -448,6 +448,7 @@ SEG_SCATTER = os.environ.get("PYGHO_SEG_SCATTER", "auto")      # "0": never, "1"
 # below ~10^6 messages the launch does not fill the chip's resident set of (blocks x slices) workgroups and the gather form on the
 # window kernel is as fast (128 / 1024-graph ZINC-shape batches: 56 k / 440 k messages)
 SEG_SCATTER_MIN_MESSAGES = int(os.environ.get("PYGHO_SEG_SCATTER_MIN_MESSAGES", str(1 << 20)))
+SEG_SCATTER_BUILD_AFTER = int(os.environ.get("PYGHO_SEG_SCATTER_BUILD_AFTER", "12"))   # by-edge launches on a pattern before it is planned
 
 
 class ScatterPlan:
@@ -476,7 +477,7 @@ def scatter_plan_parts(a32: Tensor, c32: Tensor, d32: Tensor, block_m: Tensor):
     chunks = torch.empty((int(total), 4), dtype=_I32, device=dev)
     words = torch.empty(d32.numel(), dtype=_I32, device=dev)
     check(lib().pygho_seg_scatter_write(ptr(chunks), ptr(words), ptr(chunk0), ptr(blk_e), ptr(a32), ptr(c32), ptr(d32), ptr(block_m), nb,
-                                        stream_ptr(dev)), "seg_scatter_write")
+                                        int(total), d32.numel(), stream_ptr(dev)), "seg_scatter_write")
     return n_chunks, chunk0, blk_e, chunks, words, int(max_edges)
 
 
@@ -510,14 +511,22 @@ def install_scatter_plan(plan: "MessagePlan", chunk0: Tensor, blk_e: Tensor, chu
     plan._scatter = sp if sp.n_chunks > 0 else False
 
 
-def scatter_plan(plan: "MessagePlan") -> Optional[ScatterPlan]:
+def scatter_plan(plan: "MessagePlan", on_demand: bool = False) -> Optional[ScatterPlan]:
     """the plan's ScatterPlan, or None when its blocks are outside the kernel's limits (more than 255 edges in a block, a not sorted
-    inside a block, more than four messages of one edge among 16 consecutive ones).  Never built under stream capture (host reads)."""
+    inside a block, more than four messages of one edge among 16 consecutive ones).  Never built under stream capture (host reads).
+    `on_demand` (the dispatcher's call): planning costs ~1.3 ms and three host reads while one launch saves ~15 us, so a plan is only
+    built for a pattern that KEEPS COMING BACK -- after `SEG_SCATTER_BUILD_AFTER` by-edge launches on it (two training steps of a
+    6-layer model); until then, and for one-shot batch patterns, the gather form runs.  An explicit call (`SpModel.prepare`, the
+    prefetcher's side stream) builds at once; `collate.DeviceGraphStore` installs plans collated from the dataset's."""
     sp = getattr(plan, "_scatter", None)
     if sp is not None:
         return sp or None
     if plan.m == 0 or plan.m >= (1 << 31) or torch.cuda.is_current_stream_capturing():
         return None
+    if on_demand:
+        plan._byedge_calls = getattr(plan, "_byedge_calls", 0) + 1
+        if plan._byedge_calls <= SEG_SCATTER_BUILD_AFTER:
+            return None
     plan._scatter = _scatter_plan_build(plan) or False
     return plan._scatter or None
 
@@ -530,7 +539,7 @@ def _scatter_eligible(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], scale
         return False
     if max(g.shape[0], h.shape[0], plan.n_rhs) * rb >= (1 << 31) or g.shape[0] != plan.n_out or h.shape[0] != plan.n_lhs:
         return False
-    sp = scatter_plan(plan)
+    sp = scatter_plan(plan, on_demand=True)
     if sp is None:
         return False
     per_wave = (sp.max_edges + 7) // 8 * 8 * 144 + 2 * 32 * 80 + 256
