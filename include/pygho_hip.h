@@ -187,6 +187,16 @@ int pygho_seg_extremum_bwd(void* gout, const void* gin, const void* fwd_out, con
                            int64_t n_seg, int64_t d, int dtype, void* stream);
 
 /*
+ * Forward of max / min that also counts the ties the backward divides by (fast path only: f32 / bf16 / f16 rows in whole 16-byte
+ * pieces; PYGHO_ERR_UNSUPPORTED otherwise): ties[s, :] = #{messages of segment s attaining the stored extremum} + [extremum == 0]
+ * (torch's N_to_distribute of scatter_reduce_(amax|amin) into a zero-initialised output, pygho/backend/utils.py:44-56), as the value
+ * dtype (exact up to 256 in bf16).  The backward then needs no pass over the operands to form  share = gin / ties.
+ */
+int pygho_seg_gather_mul_reduce_ties(void* out, void* ties, const void* lhs, const void* rhs, const int32_t* seg_ptr,
+                                     const int32_t* lhs_idx, const int32_t* rhs_idx, int64_t n_seg, int64_t d,
+                                     int64_t lhs_rows, int64_t rhs_rows, int dtype, int aggr, void* stream);
+
+/*
  * The same backward, 16 bytes per lane (f32 / bf16 / f16 rows that are whole 16-byte pieces, at most 1024 bytes, operands 16-byte
  * aligned and below 4 GiB; anything else returns PYGHO_ERR_UNSUPPORTED and the caller takes the pair above):
  *   share[a, :] = gin[a, :] / ties[a, :]   rounded to the value dtype -- torch's grad / N_to_distribute in the gradient's dtype

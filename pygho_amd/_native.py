@@ -48,6 +48,7 @@ PROTOTYPES = {
     "pygho_seg_scatter_count": (I, [P, P, P, P, P, P, P, L, P]),
     "pygho_seg_scatter_write": (I, [P, P, P, P, P, P, P, P, L, L, L, P]),
     "pygho_seg_scatter_mul_reduce": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, P]),
+    "pygho_seg_gather_mul_reduce_ties": (I, [P, P, P, P, P, P, P, L, L, L, L, I, I, P]),
     "pygho_seg_extremum_share": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, I, P]),
     "pygho_seg_extremum_bwd_shared": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, I, P]),
     "pygho_row_gather": (I, [P, P, P, P, L, L, I, P]),

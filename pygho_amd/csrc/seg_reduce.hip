@@ -92,7 +92,8 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
     const int32_t* __restrict__ rhs_idx, const float* __restrict__ lhs_rowscale, const T* __restrict__ addend,
     int64_t n_seg, int d, int chunks, int log2g, int spp,
     const T* __restrict__ third = nullptr, const int32_t* __restrict__ third_idx = nullptr,
-    const float* __restrict__ act_scale = nullptr, const float* __restrict__ act_shift = nullptr, int act = 0) {
+    const float* __restrict__ act_scale = nullptr, const float* __restrict__ act_shift = nullptr, int act = 0,
+    T* __restrict__ ties = nullptr) {
   using V = Vec16<T>;
   using R = Reduce<AGGR, float>;
   constexpr int N = V::N;
@@ -230,6 +231,42 @@ __global__ __launch_bounds__(kBlock) void seg_gmr_fast_kernel(
       for (int q = 0; q < N; ++q) {
         if (AGGR == PYGHO_MEAN) acc[q] = cnt > 0 ? mean_div(acc[q], cnt) : 0.f;
         if (AGGR == PYGHO_MAX || AGGR == PYGHO_MIN) acc[q] = cnt > 0 ? acc[q] : 0.f;
+      }
+      if constexpr ((AGGR == PYGHO_MAX || AGGR == PYGHO_MIN) && !THIRD && !SCALED && ACTSIDE == 0 && !OUTF32) {
+        // ties[s] = #{messages of segment s whose (rounded) value equals the (rounded) extremum} + [extremum == 0]: what the backward
+        // divides the output gradient by (torch's N_to_distribute: `self == result` counts too, and self is the zero-initialised
+        // output of pygho/backend/utils.py:44-49).  Counted HERE, where the segment's rows have just passed through L1 -- as a pass of
+        // its own (seg_extremum_share) the count re-gathered every operand row: 0.74 ms against 0.35 ms for this whole launch.
+        if (ties) {
+          float ext[N], tc[N];
+#pragma unroll
+          for (int q = 0; q < N; ++q) ext[q] = acc[q];
+          if (sizeof(T) == 2) V::unpack(V::pack(ext), ext);
+#pragma unroll
+          for (int q = 0; q < N; ++q) tc[q] = ext[q] == 0.f ? 1.f : 0.f;
+          for (int m = beg; m < end; ++m) {
+            int l = m, r = m;
+            if (staged) {
+              if (MODE != MODE_RHS && has_li) l = s_li[wv][m - mbeg];
+              if (MODE != MODE_LHS && has_ri) r = s_ri[wv][m - mbeg];
+            } else {
+              if (MODE != MODE_RHS && has_li) l = lhs_idx[m];
+              if (MODE != MODE_LHS && has_ri) r = rhs_idx[m];
+            }
+            float a[N], b[N];
+            if (MODE != MODE_RHS) V::unpack(load_row16<OFF32>(lbase, l, row_bytes, col_bytes), a);
+            if (MODE != MODE_LHS) V::unpack(load_row16<OFF32>(rbase, r, row_bytes, col_bytes), b);
+#pragma unroll
+            for (int q = 0; q < N; ++q) a[q] = MODE == MODE_BOTH ? a[q] * b[q] : (MODE == MODE_LHS ? a[q] : b[q]);
+            if (sizeof(T) == 2) V::unpack(V::pack(a), a);
+#pragma unroll
+            for (int q = 0; q < N; ++q) tc[q] += a[q] == ext[q] ? 1.f : 0.f;
+          }
+          if (active) {
+            if (OFF32) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(ties) + ((uint32_t)(base + i) * row_bytes + col_bytes)) = V::pack(tc);
+            else *reinterpret_cast<uint4*>(reinterpret_cast<char*>(ties) + ((int64_t)(base + i) * (int64_t)row_bytes + col_bytes)) = V::pack(tc);
+          }
+        }
       }
       if (addend) {                                // out = addend + reduction (the layer's residual connection)
         float rv[N];
@@ -590,7 +627,8 @@ static inline int segs_per_pass(int64_t n_seg, int log2g) {
 
 template <typename T, int AGGR, bool OFF32>
 int launch_fast_off(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
-                    const int32_t* rhs_idx, const float* scale, const void* addend, int64_t n_seg, int64_t d, hipStream_t st) {
+                    const int32_t* rhs_idx, const float* scale, const void* addend, int64_t n_seg, int64_t d, hipStream_t st,
+                    void* ties = nullptr) {
   const int chunks = (int)(d * sizeof(T) / 16);
   int log2g = 0;
   while ((1 << log2g) < chunks && log2g < 6) ++log2g;
@@ -600,7 +638,8 @@ int launch_fast_off(void* out, const void* lhs, const void* rhs, const int32_t* 
   dim3 grid(gx, (unsigned)ceil_div(chunks, kWave));
 #define PYGHO_LAUNCH(MODE, SC)                                                                                          \
   hipLaunchKernelGGL((seg_gmr_fast_kernel<T, AGGR, MODE, SC, OFF32>), grid, dim3(kBlock), 0, st, (T*)out, (const T*)lhs, \
-                     (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, (const T*)addend, n_seg, (int)d, chunks, log2g, spp)
+                     (const T*)rhs, seg_ptr, lhs_idx, rhs_idx, scale, (const T*)addend, n_seg, (int)d, chunks, log2g, spp, \
+                     (const T*)nullptr, (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (T*)ties)
   if (lhs && rhs) { if (scale) PYGHO_LAUNCH(MODE_BOTH, true); else PYGHO_LAUNCH(MODE_BOTH, false); }
   else if (lhs)   { if (scale) PYGHO_LAUNCH(MODE_LHS, true);  else PYGHO_LAUNCH(MODE_LHS, false); }
   else            { PYGHO_LAUNCH(MODE_RHS, false); }
@@ -611,12 +650,12 @@ int launch_fast_off(void* out, const void* lhs, const void* rhs, const int32_t* 
 template <typename T, int AGGR>
 int launch_fast(void* out, const void* lhs, const void* rhs, const int32_t* seg_ptr, const int32_t* lhs_idx,
                 const int32_t* rhs_idx, const float* scale, const void* addend, int64_t n_seg, int64_t d, int64_t lhs_rows,
-                int64_t rhs_rows, hipStream_t st) {
+                int64_t rhs_rows, hipStream_t st, void* ties = nullptr) {
   const int64_t rb = d * (int64_t)sizeof(T);
   const int64_t lim = (int64_t)1 << 32;
   const bool off32 = n_seg * rb < lim && (!lhs || (lhs_rows > 0 && lhs_rows * rb < lim)) && (!rhs || (rhs_rows > 0 && rhs_rows * rb < lim));
-  if (off32) return launch_fast_off<T, AGGR, true>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, addend, n_seg, d, st);
-  return launch_fast_off<T, AGGR, false>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, addend, n_seg, d, st);
+  if (off32) return launch_fast_off<T, AGGR, true>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, addend, n_seg, d, st, ties);
+  return launch_fast_off<T, AGGR, false>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, scale, addend, n_seg, d, st, ties);
 }
 
 template <typename T, int AGGR>
@@ -842,6 +881,29 @@ static int extremum_vec_shape(int64_t d, int dtype, int64_t max_rows, int* chunk
   *log2g = 0;
   while ((1 << *log2g) < *chunks) ++*log2g;
   return PYGHO_OK;
+}
+
+// forward of max / min WITH the tie counts the backward needs (see the kernel): the fast (16 bytes per lane) path only
+extern "C" int pygho_seg_gather_mul_reduce_ties(void* out, void* ties, const void* lhs, const void* rhs, const int32_t* seg_ptr,
+                                                const int32_t* lhs_idx, const int32_t* rhs_idx, int64_t n_seg, int64_t d,
+                                                int64_t lhs_rows, int64_t rhs_rows, int dtype, int aggr, void* stream) {
+  if (n_seg < 0 || d <= 0) { set_error("seg_gather_mul_reduce_ties: bad size"); return PYGHO_ERR_INVALID; }
+  if (n_seg == 0) return PYGHO_OK;
+  if (!out || !ties || !seg_ptr || (!lhs && !rhs)) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (aggr != PYGHO_MAX && aggr != PYGHO_MIN) { set_error("seg_gather_mul_reduce_ties: max / min only"); return PYGHO_ERR_INVALID; }
+  const int64_t es = dtype == PYGHO_F32 ? 4 : ((dtype == PYGHO_BF16 || dtype == PYGHO_F16) ? 2 : 0);
+  if (es == 0 || (d * es) % 16 != 0 || (((uintptr_t)out | (uintptr_t)ties | (uintptr_t)lhs | (uintptr_t)rhs) % 16) != 0) {
+    set_error("seg_gather_mul_reduce_ties: f32 / bf16 / f16 rows in whole 16-byte pieces, 16-byte aligned");
+    return PYGHO_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+#define PYGHO_TIES(T)                                                                                                                  \
+  (aggr == PYGHO_MAX ? launch_fast<T, PYGHO_MAX>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, nullptr, nullptr, n_seg, d, lhs_rows, rhs_rows, st, ties) \
+                     : launch_fast<T, PYGHO_MIN>(out, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, nullptr, nullptr, n_seg, d, lhs_rows, rhs_rows, st, ties))
+  if (dtype == PYGHO_F32) return PYGHO_TIES(float);
+  if (dtype == PYGHO_BF16) return PYGHO_TIES(bf16);
+  return PYGHO_TIES(f16);
+#undef PYGHO_TIES
 }
 
 extern "C" int pygho_seg_extremum_share(void* share, const void* gin, const void* fwd_out, const void* lhs, const void* rhs,

@@ -299,6 +299,29 @@ def _timed(name: str, nbytes: int, dev, launch) -> None:
     timer.records.append((name, nbytes, e0, e1))
 
 
+USE_FORWARD_TIES = os.environ.get("PYGHO_FORWARD_TIES", "1") != "0"    # max / min: tie counts from the forward launch (A/B switch)
+
+
+def seg_gmr_ties(out_rows: int, lhs: Optional[Tensor], rhs: Optional[Tensor], seg_ptr: Tensor, lhs_idx, rhs_idx, aggr: str):
+    """(out, ties) of a max / min reduction on the fast kernel: `ties[s]` = number of messages of segment s attaining the stored
+    extremum, + 1 where the extremum is 0 (torch's N_to_distribute, see `_ties`), in the value dtype."""
+    ref = lhs if lhs is not None else rhs
+    dev = require_device(lhs, rhs, seg_ptr, lhs_idx, rhs_idx)
+    d = ref.shape[1]
+    out = torch.empty((out_rows, d), dtype=ref.dtype, device=dev)
+    ties = torch.empty((out_rows, d), dtype=ref.dtype, device=dev)
+    es = ref.element_size()
+    m = lhs_idx.numel() if lhs_idx is not None else (rhs_idx.numel() if rhs_idx is not None else ref.shape[0])
+    rows = (lhs.shape[0] if lhs is not None else 0) + (rhs.shape[0] if rhs is not None else 0) + 2 * out_rows
+    nbytes = es * d * rows + 4 * m * ((lhs_idx is not None) + (rhs_idx is not None)) + 4 * (out_rows + 1)
+    mode = "both" if (lhs is not None and rhs is not None) else ("lhs" if lhs is not None else "rhs")
+    _timed(f"seg_gmr[{str(ref.dtype).split('.')[-1]},{aggr},{mode},ties]", nbytes, dev, lambda: check(lib().pygho_seg_gather_mul_reduce_ties(
+        ptr(out), ptr(ties), ptr(lhs), ptr(rhs), ptr(seg_ptr), ptr(lhs_idx), ptr(rhs_idx), out_rows, d,
+        lhs.shape[0] if lhs is not None else 0, rhs.shape[0] if rhs is not None else 0, dtype_code(ref), AGGR_CODE[aggr], stream_ptr(dev)),
+        "seg_gather_mul_reduce_ties"))
+    return out, ties
+
+
 def _ties(fwd: Tensor, lhs, rhs, seg_ptr, lhs_idx, rhs_idx, gin: Optional[Tensor] = None):
     """tie bookkeeping of the max / min backward.  With `gin` and 16-byte-vector shapes: ("share", gin / ties rounded to the value
     dtype) from ONE 16-byte-per-lane pass; otherwise the f32 tie counts of the scalar kernel."""
@@ -590,24 +613,39 @@ class _MessageReduce(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, lhs: Optional[Tensor], rhs: Optional[Tensor], plan: MessagePlan, aggr: str, addend: Optional[Tensor] = None):
-        out = seg_gmr(plan.n_out, lhs, rhs, plan.fwd.seg_ptr, plan.c_fwd if lhs is not None else None,
-                      plan.d_fwd if rhs is not None else None, aggr, addend=None if addend is None else addend.contiguous())
+        ties = None
+        li, ri = (plan.c_fwd if lhs is not None else None), (plan.d_fwd if rhs is not None else None)
+        if (aggr in ("max", "min") and addend is None and USE_FORWARD_TIES and any(ctx.needs_input_grad[:2])
+                and _extremum_vec_ok(lhs if lhs is not None else rhs, lhs, rhs)
+                and ((lhs if lhs is not None else rhs).dtype == torch.float32 or plan.fwd.max_len < 256)):
+            # the forward also counts the ties its backward divides by (exact in the value dtype: at most 256 per segment in bf16)
+            out, ties = seg_gmr_ties(plan.n_out, lhs, rhs, plan.fwd.seg_ptr, li, ri, aggr)
+        else:
+            out = seg_gmr(plan.n_out, lhs, rhs, plan.fwd.seg_ptr, li, ri, aggr, addend=None if addend is None else addend.contiguous())
         ctx.plan, ctx.aggr = plan, aggr
         ctx.has = (lhs is not None, rhs is not None)
-        ctx.save_for_backward(lhs, rhs, out if aggr in ("max", "min") else None)
+        ctx.save_for_backward(lhs, rhs, out if aggr in ("max", "min") else None, ties)
         return out
 
     @staticmethod
     def backward(ctx, gout: Tensor):
-        lhs, rhs, fwd = ctx.saved_tensors
+        lhs, rhs, fwd, fwd_ties = ctx.saved_tensors
         plan, aggr = ctx.plan, ctx.aggr
         gout = gout.contiguous()
         g_lhs = g_rhs = None
         scale = plan.fwd.inv_count if aggr == "mean" else None
         ties = None
         if aggr in ("max", "min"):
-            ties = _ties(fwd, lhs, rhs, plan.fwd.seg_ptr, plan.c_fwd if lhs is not None else None,
-                         plan.d_fwd if rhs is not None else None, gin=gout)
+            if fwd_ties is not None and gout.dtype == fwd_ties.dtype:
+                # share = grad / N_to_distribute, rounded to the value dtype: one elementwise pass (the forward counted the ties)
+                dev = gout.device
+                share = torch.empty_like(gout)
+                _timed(f"seg_ext_share[{str(gout.dtype).split('.')[-1]},elementwise]", 3 * gout.numel() * gout.element_size(), dev,
+                       lambda: torch.div(gout, fwd_ties, out=share))
+                ties = ("share", share)
+            else:
+                ties = _ties(fwd, lhs, rhs, plan.fwd.seg_ptr, plan.c_fwd if lhs is not None else None,
+                             plan.d_fwd if rhs is not None else None, gin=gout)
         if lhs is not None and ctx.needs_input_grad[0]:
             p, a_g, d_g = plan.by_c()
             if ties is None:
