@@ -220,7 +220,8 @@ def side_regimes(args, dev):
     gen = torch.Generator().manual_seed(0)
     ids = [torch.randperm(store.num_graphs, generator=gen)[:args.graphs] for _ in range(16)]
     n = 0
-    for k, dd in enumerate(BatchPrefetcher(store, ids, model.prepare)):
+    # (no `prepare`: collation installs every plan SpModel asks for -- tests/test_gpu_sparse.py::test_collated_batch_needs_no_plan_building)
+    for k, dd in enumerate(BatchPrefetcher(store, ids)):
         if k == 4:
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
@@ -231,9 +232,10 @@ def side_regimes(args, dev):
     out["fresh_batch_ms_per_step"] = ms
     out["fresh_batch_graphs_per_s"] = args.graphs / ms * 1e3
     out["fresh_batch_note"] = (f"{n - 4} timed steps, every step a different {args.graphs}-graph batch collated on the device from a "
-                               f"resident int32 graph store ({store.num_graphs} graphs), plans prepared one batch ahead on a side stream")
+                               f"resident int32 graph store ({store.num_graphs} graphs) together with its index plans, one batch ahead on a side stream")
     del store, model, step
     # (b) small batches
+    small_store = DeviceGraphStore(recs * max(1, 4096 // len(recs)), dev)
     for graphs in (128, 1024):
         hb = synth.make_batch(graphs, "zinc", seed=7)
         dd = synth.to_datadict(hb, dev)
@@ -261,9 +263,26 @@ def side_regimes(args, dev):
             torch.cuda.synchronize(dev)
             res[mode] = (time.perf_counter() - t0) / reps * 1e3
             assert bool(torch.isfinite(loss))
+        # eager again, but every step a different shuffled batch collated from a resident store (what a training loop does)
+        torch.manual_seed(0)
+        model = SpModel(1, args.layers, args.hidden, act_dtype=act).to(dev)
+        step = make_step(model, torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True), None)
+        sids = [torch.randperm(small_store.num_graphs, generator=gen)[:graphs] for _ in range(60)]
+        n = 0
+        for k, fd in enumerate(BatchPrefetcher(small_store, sids)):
+            if k == 10:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            step(fd)
+            n += 1
+        torch.cuda.synchronize(dev)
+        res["fresh"] = (time.perf_counter() - t0) / (n - 10) * 1e3
         out[f"bs{graphs}"] = {"graphs": graphs, "eager_ms_per_step": res["eager"], "hipgraph_ms_per_step": res["hipgraph"],
-                              "eager_graphs_per_s": graphs / res["eager"] * 1e3, "hipgraph_graphs_per_s": graphs / res["hipgraph"] * 1e3}
-    out["small_batch_note"] = ("same model and full train step on one resident batch; 128 graphs is the reference's batch size "
+                              "eager_fresh_batch_ms_per_step": res["fresh"],
+                              "eager_graphs_per_s": graphs / res["eager"] * 1e3, "hipgraph_graphs_per_s": graphs / res["hipgraph"] * 1e3,
+                              "eager_fresh_batch_graphs_per_s": graphs / res["fresh"] * 1e3}
+    out["small_batch_note"] = ("same model and full train step; eager / hipgraph on one resident batch, eager_fresh_batch on 50 timed steps that "
+                               "each take a different shuffled batch collated on the device from a resident graph store (BatchPrefetcher); 128 graphs is the reference's batch size "
                                "(example/minimal.py:119); hipgraph = the whole step captured once (pygho_amd.graphs.GraphedStep) and replayed")
     return out
 

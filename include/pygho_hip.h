@@ -140,6 +140,17 @@ int pygho_pair_bwd(void* g_left, void* g_right, float* tab_ws, const void* g, co
                    const int32_t* seg_ptr, const int32_t* col, const int32_t* vidx, const int32_t* mirror, int64_t n_nodes,
                    int64_t n_tuples, int64_t d, int dtype, void* stream);
 
+/* Gradient of a row lookup into a SMALL table (autograd of `X[self.indices[dim]]`, pygho/backend/SpTensor.py:476, and of the
+ * nn.Embedding lookups of example/minimal.py:22-34, whose tables have 16-32 rows) without an index plan:
+ *   ws[blk][k][c] = sum over the rows r of workgroup blk with idx[r] == k of g[r][c]     (f32; fold with pygho_sum_blocks)
+ * g: (m, d) f32 / bf16 / f16, idx: (m) int32, ws: (pygho_table_grad_blocks(m), n_table, d) floats.  Needs n_table * d * 4 bytes
+ * <= 64 KiB of LDS (pygho_table_grad_supported).  Rows with idx outside [0, n_table) are skipped and raise *err (nullable) to 1.
+ * Deterministic: a fixed function of (m, d, n_table), no atomics. */
+int pygho_table_grad_supported(int64_t d, int64_t n_table);
+int pygho_table_grad_blocks(int64_t m);
+int pygho_table_grad(float* ws, const void* g, const int32_t* idx, int64_t m, int64_t d, int64_t n_table, int dtype, int32_t* err,
+                     void* stream);
+
 /* The same reduction with the layer MLP's BatchNorm + activation applied to one operand AS IT IS LOADED:
  *   act_side 1:  out[s] = [addend[s] +] (+) act(lhs[li] * act_scale + act_shift) * rhs[ri]
  *   act_side 2:  out[s] = [addend[s] +] (+) lhs[li] * act(rhs[ri] * act_scale + act_shift)
@@ -372,6 +383,11 @@ int pygho_compact_positions(int64_t* pos, const int64_t* offsets, int64_t n, voi
 int pygho_collate_rows(int64_t* out, const int32_t* src, int64_t rows, int64_t src_ld, int64_t out_ld,
                        const int64_t* src_start, const int64_t* out_ptr, const int64_t* inc, int64_t n_sel,
                        int64_t total, void* stream);
+/* The same with int32 output -- plan arrays the kernels read directly (permutations with the message offset added, per-row
+ * counts, chunk records) -- and optionally the TRANSPOSED output layout out[(out_ptr[s] + t) * rows + r]. */
+int pygho_collate_rows_i32(int32_t* out, const int32_t* src, int64_t rows, int64_t src_ld, int64_t out_ld,
+                           const int64_t* src_start, const int64_t* out_ptr, const int64_t* inc, int64_t n_sel,
+                           int64_t total, int transposed, void* stream);
 
 /* Padded-batch builders of the dense path (hodata/MaData.py:108-147 to_dense_x, :150-214 to_dense_tuplefeat): graph b owns a
  * row-major grid of shape[b, 0..nd-1] rows starting at source row ptr[b]; with the grid dims right-aligned in (m0, m1, m2)

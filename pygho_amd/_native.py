@@ -36,6 +36,9 @@ PROTOTYPES = {
     "pygho_seg_tile_chunk": (I, []),
     "pygho_seg_tile_plan": (I, [P, P, P, P, L, L, P]),
     "pygho_seg_gather_mul_reduce_tiled": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, I, I, P]),
+    "pygho_table_grad_supported": (I, [L, L]),
+    "pygho_table_grad_blocks": (I, [L]),
+    "pygho_table_grad": (I, [P, P, P, L, L, L, I, P, P]),
     "pygho_pair_bwd_types": (I, []),
     "pygho_pair_bwd_blocks": (I, [L, L, I]),
     "pygho_pair_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, L, I, P]),
@@ -75,6 +78,7 @@ PROTOTYPES = {
     "pygho_gather_i32_to_i64": (I, [P, P, P, L, P]),
     "pygho_plan_triples": (I, [P, P, P, P, P, L, P]),
     "pygho_collate_rows": (I, [P, P, L, L, L, P, P, P, L, L, P]),
+    "pygho_collate_rows_i32": (I, [P, P, L, L, L, P, P, P, L, L, I, P]),
     "pygho_pad_stack": (I, [P, P, P, P, P, L, I, L, L, L, L, L, P]),
     "pygho_dense_adj": (I, [P, P, P, P, P, P, L, L, L, L, c_uint64, I, P]),
     "pygho_flag_scan_nonneg": (I, [P, P, P, L, P, Z, P]),

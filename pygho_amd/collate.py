@@ -25,6 +25,20 @@ def _cat32(arrs: List[np.ndarray], axis: int, device) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(device)
 
 
+def _mirror_of(r: GraphRecord, n_types: int):
+    """(positions of the transposed tuples, verdict) of one graph, as `segment.pair_mirror` decides for a batch"""
+    row, col = r.tupleid[0].astype(np.int64), r.tupleid[1].astype(np.int64)
+    t = row.size
+    if t == 0:
+        return np.zeros(0, dtype=np.int64), True
+    n, f = int(r.num_nodes), np.asarray(r.tuplefeat).reshape(-1)
+    key, key_t = row * n + col, col * n + row
+    pos = np.minimum(np.searchsorted(key, key_t), t - 1)
+    ok = (np.all(key[1:] > key[:-1]) and np.all(key[pos] == key_t) and np.all(f[pos] == f) and f.min() >= 0 and f.max() < n_types
+          and col.max() < n)
+    return (pos if ok else np.zeros(t, dtype=np.int64)), bool(ok)
+
+
 def _ptr64(lengths: Sequence[int], device) -> torch.Tensor:
     return torch.from_numpy(np.concatenate(([0], np.cumsum(np.asarray(lengths, dtype=np.int64))))).to(device)
 
@@ -89,63 +103,102 @@ class DeviceGraphStore:
             self.scatter_parts[k] = {"chunk_ptr": chunk0.to(torch.int64), "chunks_t": chunks.t().contiguous(), "words": words.reshape(1, -1),
                                      "blk_e": blk_e.t().contiguous(), "max_edges": max_edges, "covers": covers}
         self.y = torch.tensor([r.y for r in records], dtype=torch.float32, device=d)
+        # per-graph lengths on the HOST as well: a batch's output sizes (and the longest segments its plans ask about) are sums /
+        # maxima over the selected graphs, so collation needs no device-to-host read
+        ln = lambda f: np.asarray([f(r) for r in records], dtype=np.int64)
+        self.h_len = {"node": ln(lambda r: r.num_nodes), "edge": ln(lambda r: r.edge_index.shape[1]), "tup": ln(lambda r: r.tupleid.shape[1])}
+        for k in self.keys:
+            self.h_len[("acd", k)] = ln(lambda r: r.acd[k].shape[1])
+        for k, v in self.scatter_parts.items():
+            self.h_len[("sc", k)] = np.diff(v["chunk_ptr"].cpu().numpy())
+        self.h_ptr = {f: np.concatenate(([0], np.cumsum(v))).astype(np.int64) for f, v in self.h_len.items()}
+        # tuples per root node (the pattern is sorted by root, SpTupleSampler.py:91-126): a batch's grouping of its tuples by root --
+        # subgraph pooling, the tuple initialisation's by-row plan -- is the scan of the collated counts
+        self.root_parts = None
+        if all(r.tupleid.shape[1] == 0 or np.all(np.diff(r.tupleid[0]) >= 0) for r in records):
+            cnt = [np.bincount(r.tupleid[0], minlength=r.num_nodes) for r in records]
+            self.root_parts = {"cnt": _cat32([c.reshape(1, -1) for c in cnt], 1, d),
+                               "h_max": np.asarray([c.max() if c.size else 0 for c in cnt], dtype=np.int64)}
+        # mirror positions of symmetric 2-tuple sets (segment.pair_mirror: the one-pass backward of the tuple initialisation):
+        # graph-local here, plus the tuple offset of the graph in a batch; the verdict of a batch is the AND over its graphs
+        self.mirror_parts = None
+        if self.sd == 2 and not self.feat_shape:
+            nt = int(lib().pygho_pair_bwd_types())
+            pos, ok = zip(*(_mirror_of(r, nt) for r in records))
+            self.mirror_parts = {"pos": _cat32([p.reshape(1, -1) for p in pos], 1, d), "h_ok": np.asarray(ok, dtype=bool)}
 
     # ------------------------------------------------------------------
-    def _rows(self, src: torch.Tensor, seg_ptr: torch.Tensor, ids: torch.Tensor, out_ptr: torch.Tensor, total: int,
-              inc: Union[torch.Tensor, None]) -> torch.Tensor:
-        rows = src.shape[0]
-        out = torch.empty((rows, total), dtype=torch.int64, device=self.device)
-        start = _ops.gather_cols(seg_ptr, ids)
-        check(lib().pygho_collate_rows(ptr(out), ptr(src), rows, src.shape[1], total, ptr(start), ptr(out_ptr),
-                                       ptr(None if inc is None else inc.contiguous()), ids.numel(), total,
-                                       stream_ptr(self.device)), "collate_rows")
+    def _rows(self, src: torch.Tensor, lay: "_Layout", fam, inc: Union[torch.Tensor, None] = None, i32: bool = False,
+              transposed: bool = False) -> torch.Tensor:
+        """the columns of `src` (rows, store length of family `fam`) that belong to the selected graphs, concatenated, with
+        `inc[r, s]` added to row r of graph s: int64 (the API's arrays) or int32 (plan arrays), (rows, total) or (total, rows)"""
+        rows, total = src.shape[0], lay.total[fam]
+        out = torch.empty((total, rows) if transposed else (rows, total), dtype=torch.int32 if i32 else torch.int64, device=self.device)
+        args = (ptr(out), ptr(src), rows, src.shape[1], total, ptr(lay.dev[("start", fam)]), ptr(lay.dev[("optr", fam)]),
+                ptr(inc), lay.g, total)
+        if i32:
+            check(lib().pygho_collate_rows_i32(*args, int(transposed), stream_ptr(self.device)), "collate_rows_i32")
+        else:
+            check(lib().pygho_collate_rows(*args, stream_ptr(self.device)), "collate_rows")
         return out
 
+    def _install_node_plans(self, dd, lay: "_Layout") -> None:
+        """the groupings a model step asks for beyond the message plans, installed where the operators look for them: nodes by
+        graph (graph pooling), tuples by root (subgraph pooling, `pair_product`'s by-row plan) with their longest segments, and the
+        mirror verdict of the tuple set (`segment.pair_mirror`).  With these a step on the batch builds no plan and reads nothing back."""
+        g, n, X, ids_h = lay.g, lay.total["node"], dd["X"], lay.ids_h
+        if g == 0:
+            return
+        _ops.install_plan(dd["batch"], _ops.SegPlan(lay.dev[("optr32", "node")], None, g, n), ("scatter",),
+                          max_len=self.h_len["node"][ids_h].max())
+        if self.root_parts is None:
+            return
+        row = X._row(0)
+        cnt = self._rows(self.root_parts["cnt"], lay, "node").reshape(-1)
+        _ops.install_plan(row, _ops.SegPlan(_ops.exclusive_scan(cnt).to(torch.int32), None, n, lay.total["tup"]), ("scatter", "pair-row"),
+                          max_len=self.root_parts["h_max"][ids_h].max())
+        if self.mirror_parts is None or lay.total["tup"] == 0 or lay.total["tup"] >= (1 << 31):
+            return
+        row32, col32, vidx32 = _ops.narrow_i32(row), _ops.narrow_i32(X._row(1)), _ops.narrow_i32(_ops.flat_index(X.values))
+        res = None
+        if bool(self.mirror_parts["h_ok"][ids_h].all()):
+            res = self._rows(self.mirror_parts["pos"], lay, "tup", lay.dev[("off", "tup")], i32=True).reshape(-1)
+        row32._pygho_mirror = (col32, vidx32, n, res, (row32._version, col32._version, vidx32._version))
+
     def collate(self, graph_ids: Union[Sequence[int], torch.Tensor]) -> Dict:
-        """datadict of the block-diagonal batch of ``graph_ids`` (any order, repeats allowed)."""
-        ids = torch.as_tensor(graph_ids, dtype=torch.int64).to(self.device).contiguous()
-        require_device(ids)
-        g = ids.numel()
-        lens = {"node": self.node_ptr, "edge": self.edge_ptr, "tup": self.tup_ptr, **{("acd", k): v for k, v in self.acd_ptr.items()},
-                **{("sc", k): v["chunk_ptr"] for k, v in self.scatter_parts.items()}}
-        ptrs = {}
-        for name, sp in lens.items():
-            ptrs[name] = _ops.exclusive_scan(_ops.gather_cols(sp, ids + 1) - _ops.gather_cols(sp, ids))
-        totals = torch.stack([p[-1] for p in ptrs.values()]).tolist()                   # ONE host sync sizes every output
-        total = dict(zip(ptrs.keys(), (int(t) for t in totals)))
-        off = {name: ptrs[name][:-1] for name in ("node", "edge", "tup")}                # running offsets per selected graph
-        n = total["node"]
-        ei = self._rows(self.edge_index, self.edge_ptr, ids, ptrs["edge"], total["edge"], off["node"].repeat(2, 1))
-        ea = self._rows(self.edge_attr, self.edge_ptr, ids, ptrs["edge"], total["edge"], None).reshape(-1)
-        tid = self._rows(self.tupleid, self.tup_ptr, ids, ptrs["tup"], total["tup"], off["node"].repeat(self.sd, 1))
-        tf = self._rows(self.tuplefeat, self.tup_ptr, ids, ptrs["tup"], total["tup"], None)
+        """datadict of the block-diagonal batch of ``graph_ids`` (any order, repeats allowed; a host sequence / CPU tensor: a
+        device tensor of ids is read back first).  Output sizes, running offsets and per-graph increments are computed on the
+        host from the store's per-graph lengths and reach the device in ONE upload; the rest is one integer kernel per array."""
+        ids_h = (graph_ids.detach().cpu().numpy() if isinstance(graph_ids, torch.Tensor) else np.asarray(graph_ids)).astype(np.int64).reshape(-1)
+        assert ids_h.size == 0 or (ids_h.min() >= 0 and ids_h.max() < self.num_graphs), "graph id out of range"
+        lay = _Layout(self, ids_h)
+        g, n, total = lay.g, lay.total["node"], lay.total
+        fam_of = lambda role: "tup" if role[0] == "X" else "edge"
+        ei = self._rows(self.edge_index, lay, "edge", lay.dev[("inc", "ei")])
+        ea = self._rows(self.edge_attr, lay, "edge").reshape(-1)
+        tid = self._rows(self.tupleid, lay, "tup", lay.dev[("inc", "tid")])
+        tf = self._rows(self.tuplefeat, lay, "tup")
         tf = tf.reshape(-1) if not self.feat_shape else tf.t().contiguous().reshape((total["tup"],) + self.feat_shape)
-        x = self._rows(self.x, self.node_ptr, ids, ptrs["node"], n, None).reshape(-1)
-        counts = ptrs["node"][1:] - ptrs["node"][:-1]
-        batch, _ = _ops.expand_pairs(torch.zeros_like(counts), counts)
+        x = self._rows(self.x, lay, "node").reshape(-1)
+        batch = torch.repeat_interleave(torch.arange(g, dtype=torch.int64, device=self.device), lay.dev[("len", "node")], output_size=n)
         dd = {
-            "x": x, "batch": batch, "num_graphs": g, "y": self.y[ids], "num_nodes": n,
+            "x": x, "batch": batch, "num_graphs": g, "y": self.y[lay.dev[("ids",)]], "num_nodes": n,
             "A": SparseTensor(ei, ea, [n, n], is_coalesced=True),
             "X": SparseTensor(tid, tf, [n] * self.sd + list(self.feat_shape), is_coalesced=True),
         }
+        self._install_node_plans(dd, lay)
         for k in self.keys:
             roles = parse_key(k)
-            inc = torch.stack([off["tup"] if roles[i][0] == "X" else off["edge"] for i in (0, 1, 3)])
-            acd = self._rows(self.acd[k], self.acd_ptr[k], ids, ptrs[("acd", k)], total[("acd", k)], inc)
+            acd = self._rows(self.acd[k], lay, ("acd", k), lay.dev[("inc", "acd", k)])
             dd[k + KEYSEP + "acd"] = acd
             # message plan from the stored per-graph groupings (no sort, no host sync): permutations get the message offset of
             # their graph, the per-row message counts are collated by the operand's rows and scanned into CSR pointers
             if k not in self.plan_parts:
                 continue
-            parts, m_off = self.plan_parts[k], ptrs[("acd", k)][:-1].reshape(1, -1)
-            name = lambda role: "tup" if role[0] == "X" else "edge"
-            sp = {"tup": self.tup_ptr, "edge": self.edge_ptr}
-
-            def csr(cnt, role):
-                c = self._rows(cnt, sp[name(role)], ids, ptrs[name(role)], total[name(role)], None).reshape(-1)
-                return _ops.exclusive_scan(c).to(torch.int32)
-            perm = lambda which: self._rows(parts[which], self.acd_ptr[k], ids, ptrs[("acd", k)], total[("acd", k)], m_off).reshape(-1).to(torch.int32)
-            plan = _ops.MessagePlan.from_parts(acd, total[name(roles[0])], total[name(roles[1])], total[name(roles[3])],
+            parts = self.plan_parts[k]
+            csr = lambda cnt, role: _ops.exclusive_scan(self._rows(cnt, lay, fam_of(role)).reshape(-1)).to(torch.int32)
+            perm = lambda which: self._rows(parts[which], lay, ("acd", k), lay.dev[("off", ("acd", k))], i32=True).reshape(-1)
+            plan = _ops.MessagePlan.from_parts(acd, total[fam_of(roles[0])], total[fam_of(roles[1])], total[fam_of(roles[3])],
                                                csr(parts["cnt_a"], roles[0]), csr(parts["cnt_c"], roles[1]), perm("perm_c"),
                                                csr(parts["cnt_d"], roles[3]), perm("perm_d"))
             _ops.install_message_plan(acd, plan)
@@ -153,15 +206,61 @@ class DeviceGraphStore:
             if sc is not None and total[("sc", k)] > 0:
                 # chunk records {first message, first a row, first c row, packed}: message offset of the graph inside the batch instead
                 # of inside the store, row offsets of the two operands' graphs; the packed field and the words travel unchanged
-                first_m = ptrs[("acd", k)][:-1] - _ops.gather_cols(self.acd_ptr[k], ids)
-                inc = torch.stack([first_m, off[name(roles[0])], off[name(roles[1])], torch.zeros_like(first_m)])
-                ch = self._rows(sc["chunks_t"], sc["chunk_ptr"], ids, ptrs[("sc", k)], total[("sc", k)], inc)
-                words = self._rows(sc["words"], self.acd_ptr[k], ids, ptrs[("acd", k)], total[("acd", k)], None).reshape(-1)
-                e = sc["blk_e"][:, ids].to(torch.int64)
-                blk_e = torch.stack([e[0] + off[name(roles[3])], e[1]], dim=1).to(torch.int32).contiguous()
-                _ops.install_scatter_plan(plan, ptrs[("sc", k)].to(torch.int32), blk_e, ch.t().to(torch.int32).contiguous(),
-                                          words.to(torch.int32), sc["max_edges"], sc["covers"])
+                ch = self._rows(sc["chunks_t"], lay, ("sc", k), lay.dev[("inc", "sc", k)], i32=True, transposed=True)
+                words = self._rows(sc["words"], lay, ("acd", k), i32=True).reshape(-1)
+                blk_e = self._rows(sc["blk_e"], lay, "graph", lay.dev[("inc", "blk", k)], i32=True, transposed=True)
+                _ops.install_scatter_plan(plan, lay.dev[("optr32", ("sc", k))], blk_e, ch, words, sc["max_edges"], sc["covers"])
         return dd
+
+
+class _Layout:
+    """where everything of one batch goes, computed on the host from the store's per-graph lengths: per length family (nodes, edges,
+    tuples, the triples and scatter chunks of every key, and "graph" = one item per graph) the total, the running offsets of the
+    selected graphs in the batch (`optr`) and their first columns in the store (`start`), plus the per-graph increments of every
+    index array.  All of it reaches the device in one upload (`dev[...]` are views of that one tensor)."""
+
+    def __init__(self, store: "DeviceGraphStore", ids_h: np.ndarray):
+        self.ids_h, self.g = ids_h, int(ids_h.size)
+        g = self.g
+        fams = list(store.h_len.keys())
+        optr = {f: np.concatenate(([0], np.cumsum(store.h_len[f][ids_h]))).astype(np.int64) for f in fams}
+        optr["graph"] = np.arange(g + 1, dtype=np.int64)
+        self.total = {f: int(v[-1]) for f, v in optr.items()}
+        off = {f: v[:-1] for f, v in optr.items()}
+        pieces = {("ids",): ids_h, ("len", "node"): store.h_len["node"][ids_h], ("start", "graph"): ids_h}
+        for f in fams:
+            pieces[("start", f)] = store.h_ptr[f][ids_h]
+        for f, v in optr.items():
+            pieces[("optr", f)] = v
+        fam_of = lambda role: "tup" if role[0] == "X" else "edge"
+        pieces[("inc", "ei")] = np.tile(off["node"], (2, 1))
+        pieces[("inc", "tid")] = np.tile(off["node"], (store.sd, 1))
+        for k in store.keys:
+            roles = parse_key(k)
+            pieces[("inc", "acd", k)] = np.stack([off[fam_of(roles[i])] for i in (0, 1, 3)])
+            if k in store.scatter_parts:
+                first_m = off[("acd", k)] - pieces[("start", ("acd", k))]
+                pieces[("inc", "sc", k)] = np.stack([first_m, off[fam_of(roles[0])], off[fam_of(roles[1])], np.zeros(g, dtype=np.int64)])
+                pieces[("inc", "blk", k)] = np.stack([off[fam_of(roles[3])], np.zeros(g, dtype=np.int64)])
+        wide = [np.ascontiguousarray(p, dtype=np.int64).reshape(-1) for p in pieces.values()]
+        # int32 copies of the pointers that ARE plan arrays (nodes by graph; the scatter plans' chunk pointers), behind the int64 part
+        narrow = {("optr32", f): optr[f].astype(np.int32) for f in ["node"] + [("sc", k) for k in store.scatter_parts]}
+        tail = np.concatenate([v for v in narrow.values()]) if narrow else np.zeros(0, dtype=np.int32)
+        if tail.size % 2:
+            tail = np.concatenate((tail, np.zeros(1, dtype=np.int32)))
+        buf = np.concatenate(wide + [tail.view(np.int64)])
+        dev = torch.from_numpy(buf).to(store.device)
+        self.dev, o = {}, 0
+        for name, p in pieces.items():
+            self.dev[name] = dev[o:o + p.size].view(p.shape)
+            o += p.size
+        for f, v in optr.items():
+            self.dev[("off", f)] = self.dev[("optr", f)][:-1].reshape(1, -1)          # running offsets as a (1, g) increment
+        t32 = dev[o:].view(torch.int32)
+        o = 0
+        for name, v in narrow.items():
+            self.dev[name] = t32[o:o + v.size]
+            o += v.size
 
 
 class BatchPrefetcher:

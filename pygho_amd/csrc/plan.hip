@@ -210,7 +210,10 @@ __global__ void plan_triples_kernel(int64_t* __restrict__ out, const int32_t* __
   }
 }
 
-__global__ void collate_rows_kernel(int64_t* __restrict__ out, const int32_t* __restrict__ src, int rows, int64_t src_ld,
+// O = int64_t: the API's index width; O = int32_t: plan arrays the kernels read (permutations, counts, chunk records).  TR: the
+// output is (total, rows) instead of (rows, total)
+template <typename O, bool TR>
+__global__ void collate_rows_kernel(O* __restrict__ out, const int32_t* __restrict__ src, int rows, int64_t src_ld,
                                     int64_t out_ld, const int64_t* __restrict__ src_start, const int64_t* __restrict__ out_ptr,
                                     const int64_t* __restrict__ inc, int64_t n_sel, int64_t total) {
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
@@ -220,8 +223,10 @@ __global__ void collate_rows_kernel(int64_t* __restrict__ out, const int32_t* __
       if (out_ptr[mid] <= j) lo = mid; else hi = mid;
     }
     const int64_t col = src_start[lo] + (j - out_ptr[lo]);
-    for (int r = 0; r < rows; ++r)
-      out[(int64_t)r * out_ld + j] = (int64_t)src[(int64_t)r * src_ld + col] + (inc ? inc[(int64_t)r * n_sel + lo] : 0);
+    for (int r = 0; r < rows; ++r) {
+      const int64_t v = (int64_t)src[(int64_t)r * src_ld + col] + (inc ? inc[(int64_t)r * n_sel + lo] : 0);
+      out[TR ? j * rows + r : (int64_t)r * out_ld + j] = (O)v;
+    }
   }
 }
 
@@ -543,7 +548,23 @@ extern "C" int pygho_collate_rows(int64_t* out, const int32_t* src, int64_t rows
   if (rows < 0 || n_sel < 0 || total < 0 || rows > 64) { set_error("collate_rows: bad size"); return PYGHO_ERR_INVALID; }
   if (rows == 0 || n_sel == 0 || total == 0) return PYGHO_OK;
   if (!out || !src || !src_start || !out_ptr) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
-  hipLaunchKernelGGL(collate_rows_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, src, (int)rows,
-                     src_ld, out_ld, src_start, out_ptr, inc, n_sel, total);
+  hipLaunchKernelGGL((collate_rows_kernel<int64_t, false>), dim3(grid_for(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out,
+                     src, (int)rows, src_ld, out_ld, src_start, out_ptr, inc, n_sel, total);
   return check_launch("collate_rows");
+}
+
+extern "C" int pygho_collate_rows_i32(int32_t* out, const int32_t* src, int64_t rows, int64_t src_ld, int64_t out_ld,
+                                      const int64_t* src_start, const int64_t* out_ptr, const int64_t* inc, int64_t n_sel,
+                                      int64_t total, int transposed, void* stream) {
+  if (rows < 0 || n_sel < 0 || total < 0 || rows > 64) { set_error("collate_rows_i32: bad size"); return PYGHO_ERR_INVALID; }
+  if (rows == 0 || n_sel == 0 || total == 0) return PYGHO_OK;
+  if (!out || !src || !src_start || !out_ptr) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  const dim3 grid(grid_for(total, kBlock));
+  if (transposed)
+    hipLaunchKernelGGL((collate_rows_kernel<int32_t, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, out, src, (int)rows, src_ld,
+                       out_ld, src_start, out_ptr, inc, n_sel, total);
+  else
+    hipLaunchKernelGGL((collate_rows_kernel<int32_t, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, out, src, (int)rows, src_ld,
+                       out_ld, src_start, out_ptr, inc, n_sel, total);
+  return check_launch("collate_rows_i32");
 }

@@ -14,6 +14,7 @@ from torch import Tensor
 from .. import _ops
 
 
+USE_SKINNY_LINEAR = os.environ.get("PYGHO_SKINNY_LINEAR", "1") != "0"  # square 16-bit Linears of width 64 / 128 on the row-block kernel
 USE_ARENA_LINEAR = os.environ.get("PYGHO_ARENA_LINEAR", "1") != "0"    # short 16-bit inputs through _ArenaLinearFn as well
 _MM_OUT_DTYPE = [None]       # does torch.mm take out_dtype here (an f32 weight gradient straight from 16-bit operands)?
 
@@ -76,16 +77,33 @@ class _ArenaLinearFn(torch.autograd.Function):
         wq = _ops.param_as(w, dt)
         ctx.save_for_backward(x, wq)
         ctx.grad_dtypes = (w.dtype, None if b is None else b.dtype)
-        return torch.nn.functional.linear(x, wq, None if b is None else _ops.param_as(b, dt))
+        bq = None if b is None else _ops.param_as(b, dt)
+        # square 16-bit maps of width 64 / 128 (the node-level Linears of example/minimal.py:47-60): the streaming row-block kernel
+        # -- at the reference's batch size a library GEMM call costs ~50 us of HOST time, this launch ~8
+        ctx.skinny = (USE_SKINNY_LINEAR and x.dtype == dt and dt in (torch.bfloat16, torch.float16) and x.shape[0] > 0
+                      and tuple(wq.shape) in ((64, 64), (128, 128)) and x.shape[1] == wq.shape[1] and wq.is_contiguous()
+                      and x.data_ptr() % 16 == 0 and wq.data_ptr() % 16 == 0)
+        if ctx.skinny:
+            return _ops.rowblock_linear(x, wq, bq)[0]
+        return torch.nn.functional.linear(x, wq, bq)
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         w_dtype, b_dtype = ctx.grad_dtypes
         g = g.contiguous()
+        want_b = b_dtype is not None and ctx.needs_input_grad[2]
+        if ctx.skinny and g.dtype == w.dtype and g.data_ptr() % 16 == 0:
+            gx = _ops.rowblock_linear(g, w.t().contiguous())[0] if ctx.needs_input_grad[0] else None
+            gw = gb = None
+            if ctx.needs_input_grad[1]:
+                gw, gb = _ops.weight_grad_splitk(g, x, w_dtype, want_colsum=True, any_height=True)
+                gb = gb.to(b_dtype) if want_b else None
+            elif want_b:
+                gb = g.sum(0, dtype=b_dtype)
+            return gx, gw, gb, None
         gx = g @ w if ctx.needs_input_grad[0] else None
         gw = gb = None
-        want_b = b_dtype is not None and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if x.shape[0] < 8192:
                 gw = _small_weight_grad(g, x, w_dtype)

@@ -18,11 +18,7 @@ from .honn.TensorOp import OpPoolingSubg2D
 from .honn.utils import MLP, Linear
 
 
-def _flat_index(idx: Tensor) -> Tensor:
-    """the 1-D contiguous form of an integer feature tensor as a PERSISTENT object (gather plans are cached on it)"""
-    if not hasattr(idx, "_pygho_flat") or idx._pygho_flat[0] != idx._version:
-        idx._pygho_flat = (idx._version, idx.reshape(-1).contiguous())
-    return idx._pygho_flat[1]
+_flat_index = _ops.flat_index      # the 1-D contiguous form of an integer feature tensor as a persistent object
 
 
 class IndexEmbedding(nn.Embedding):
@@ -101,10 +97,7 @@ class SpModel(nn.Module):
         integer tuple features and the embedding lookup table[X.values] happens inside the same kernel."""
         left, right = self.lin_tupleinit0(x), self.lin_tupleinit1(x)
         if table is not None:
-            vals = X.values
-            if not hasattr(vals, "_pygho_flat") or vals._pygho_flat[0] != vals._version:
-                vals._pygho_flat = (vals._version, vals.reshape(-1).contiguous())   # persistent object: plans are cached on it
-            feat = vals._pygho_flat[1]
+            feat = _flat_index(X.values)                                            # persistent object: plans are cached on it
             return X.tuplewiseapply(lambda _: _ops.pair_product(left, right, table, X._row(0), X._row(1), feat))
         val = X.values
         if val.is_cuda and val.dim() == 2 and left.dtype == right.dtype == val.dtype:
@@ -136,9 +129,7 @@ class SpModel(nn.Module):
             if name != "tf" or idx.numel() != X.nnz:
                 outs.append(_ops.gather_rows(z(rows), flats[name]))
         if "tf" in flats and X.values.numel() == X.nnz:
-            if not hasattr(X.values, "_pygho_flat") or X.values._pygho_flat[0] != X.values._version:
-                X.values._pygho_flat = (X.values._version, X.values.reshape(-1).contiguous())
-            feat = X.values._pygho_flat[1]
+            feat = _flat_index(X.values)
             outs.append(_ops.pair_product(z(n), z(n), z(enc.tuplefeat_encoder.num_embeddings), X._row(0), X._row(1), feat))
         else:
             outs.append(_ops.pair_product(z(n), z(n), z(X.nnz), X._row(0), X._row(1)))

@@ -45,6 +45,13 @@ def narrow_i32(x: Tensor, checked: bool = False) -> Tensor:
     return out
 
 
+def flat_index(idx: Tensor) -> Tensor:
+    """the 1-D contiguous form of an integer feature tensor as a PERSISTENT object (gather plans are cached on it)"""
+    if not hasattr(idx, "_pygho_flat") or idx._pygho_flat[0] != idx._version:
+        idx._pygho_flat = (idx._version, idx.reshape(-1).contiguous())
+    return idx._pygho_flat[1]
+
+
 def gather_i32(table: Tensor, idx: Tensor) -> Tensor:
     dev = require_device(table, idx)
     out = torch.empty(idx.shape, dtype=_I32, device=dev)
@@ -159,21 +166,39 @@ def unit_ptr(m: int, dev) -> Tensor:
     return torch.arange(m + 1, dtype=_I32, device=dev)
 
 
-_PENDING_ERRORS = []     # (flag tensor, message): checks that ride on the next host fetch instead of costing their own sync
+_PENDING_ERRORS = []     # (flag tensor, message, stream): checks that ride on the next host fetch instead of costing their own sync
+
+FETCHES = [0]            # host synchronisations made by the planners so far (tests assert that a collated batch's step makes none)
+
+
+def _stream_id(dev) -> int:
+    return int(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else 0
+
+
+def defer_error(flag: Tensor, msg: str) -> None:
+    """`flag` (one int32, non-zero = error) was written by a launch on the CURRENT stream; report `msg` when it is found set.  It is
+    read by the next planner fetch made on the same stream (whose synchronisation orders the read behind the write -- a fetch on
+    another stream would read a flag that may not even be zero-filled yet), or by `check_deferred_errors()`."""
+    _PENDING_ERRORS.append((flag, msg, _stream_id(flag.device)))
+    if len(_PENDING_ERRORS) > 64:
+        check_deferred_errors()
 
 
 def _fetch(t: Tensor):
-    """host copy of a small device tensor (ONE synchronisation) that also carries every deferred error flag of that device"""
-    mine = [(f, m) for f, m in _PENDING_ERRORS if f.device == t.device]
+    """host copy of a small device tensor (ONE synchronisation of the current stream) that also carries every deferred error flag
+    this stream produced on that device"""
+    FETCHES[0] += 1
+    sid = _stream_id(t.device)
+    mine = [e for e in _PENDING_ERRORS if e[0].device == t.device and e[2] == sid]
     if not mine:
         return t.tolist()
     for e in mine:
         _PENDING_ERRORS.remove(e)
-    vals = torch.cat([t.reshape(-1).to(torch.int64)] + [f.reshape(-1).to(torch.int64) for f, _ in mine]).tolist()
+    vals = torch.cat([t.reshape(-1).to(torch.int64)] + [e[0].reshape(-1).to(torch.int64) for e in mine]).tolist()
     n = t.numel()
-    for (f, msg), v in zip(mine, vals[n:]):
+    for e, v in zip(mine, vals[n:]):
         if v != 0:
-            raise ValueError(msg)
+            raise ValueError(e[1])
     out = vals[:n]
     return out if t.dim() > 0 else out[0]
 
@@ -194,14 +219,25 @@ class deferred_index_checks:
     def __exit__(self, *exc):
         _DEFER_CHECKS[0] = self.prev
         if exc[0] is None:
-            check_deferred_errors()
+            for dev in {e[0].device for e in _PENDING_ERRORS if e[2] == _stream_id(e[0].device)}:    # this stream's flags only:
+                _fetch(torch.zeros(1, dtype=torch.int64, device=dev))                            # no wait for other streams' work
         return False
 
 
 def check_deferred_errors() -> None:
-    """verify the index-range checks that were deferred (one synchronisation per device with pending flags)"""
-    for dev in {f.device for f, _ in _PENDING_ERRORS}:
-        _fetch(torch.zeros(1, dtype=torch.int64, device=dev))
+    """verify EVERY index-range check that was deferred, whichever stream produced it (one device synchronisation per device with
+    pending flags)"""
+    pending = list(_PENDING_ERRORS)
+    _PENDING_ERRORS.clear()
+    for dev in {e[0].device for e in pending}:
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        FETCHES[0] += 1
+    if pending:
+        vals = [int(v) for v in torch.cat([e[0].reshape(-1).to(torch.int64).cpu() for e in pending]).tolist()]
+        for e, v in zip(pending, vals):
+            if v != 0:
+                raise ValueError(e[1])
 
 
 def plan_from_keys(keys: Tensor, n_seg: int, assume_sorted: Optional[bool] = None) -> SegPlan:
@@ -233,10 +269,21 @@ def plan_from_keys(keys: Tensor, n_seg: int, assume_sorted: Optional[bool] = Non
         if int(_fetch(err)[0]) != 0:
             raise ValueError("pygho_amd: scatter index out of range [0, dim_size)")
         return SegPlan(seg_ptr, perm, n_seg, m)
-    _PENDING_ERRORS.append((err, "pygho_amd: scatter index out of range [0, dim_size)"))
-    if len(_PENDING_ERRORS) > 64:
-        check_deferred_errors()
+    defer_error(err, "pygho_amd: scatter index out of range [0, dim_size)")
     return SegPlan(seg_ptr, perm, n_seg, m)
+
+
+def install_plan(keys: Tensor, plan: SegPlan, tags: Tuple[str, ...] = ("scatter",), max_len: Optional[int] = None) -> None:
+    """put a ready grouping of `keys` where `cached_plan` will look for it (`collate.DeviceGraphStore`: a block-diagonal batch's
+    sorted groupings are its graphs' row counts, scanned); `max_len` pre-answers the plan's only host read"""
+    if max_len is not None:
+        plan._memo = dict(plan._memo or {}, max_len=int(max_len))
+    cache = getattr(keys, "_pygho_plans", None)
+    if cache is None:
+        cache = {}
+        keys._pygho_plans = cache
+    for tag in tags:
+        cache[(tag, plan.n_seg, keys._version)] = plan
 
 
 def cached_plan(keys: Tensor, n_seg: int, tag: str = "", assume_sorted: Optional[bool] = None) -> SegPlan:

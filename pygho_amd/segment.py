@@ -385,8 +385,7 @@ class MessagePlan:
             # Spspmm.py:309-311); the flag rides on the synchronisation of the forward plan's sortedness probe below
             lo, hi = torch.aminmax(acd[1:3], dim=1)
             bad = ((lo < 0).any() | (hi[0] >= n_lhs) | (hi[1] >= n_rhs)).to(torch.int32).reshape(1)
-            _PENDING_ERRORS.append((bad, f"pygho_amd: acd operand index out of range (acd[1] must lie in [0, {n_lhs}), "
-                                         f"acd[2] in [0, {n_rhs}))"))
+            defer_error(bad, f"pygho_amd: acd operand index out of range (acd[1] must lie in [0, {n_lhs}), acd[2] in [0, {n_rhs}))")
         self.fwd = plan_from_keys(acd[0], n_out)
         a32, c32, d32 = narrow_i32(acd[0]), narrow_i32(acd[1]), narrow_i32(acd[2])
         self.a32, self.c32, self.d32 = a32, c32, d32                 # message order
@@ -749,6 +748,50 @@ def scatter_reduce_planned(src: Tensor, plan: SegPlan, ind32: Tensor, aggr: str)
     return out.reshape((plan.n_seg,) + tail)
 
 
+USE_TABLE_GRAD = os.environ.get("PYGHO_TABLE_GRAD", "1") != "0"     # plan-free gradient of lookups into small tables (A/B switch)
+
+
+def table_grad_ok(g2: Tensor, n_table: int) -> bool:
+    return (USE_TABLE_GRAD and g2.is_cuda and g2.dim() == 2 and g2.shape[0] > 0 and 0 < n_table <= 64
+            and g2.dtype in (torch.float32, torch.bfloat16, torch.float16)
+            and bool(lib().pygho_table_grad_supported(g2.shape[1], n_table)))
+
+
+def table_grad(g2: Tensor, ind: Tensor, n_table: int) -> Tensor:
+    """sum of the rows of `g2` per value of `ind` (values in [0, n_table)) as an (n_table, d) tensor of g2's dtype: the
+    gradient of ``table[ind]`` for a small table (csrc/table_grad.hip: LDS bins per workgroup + a deterministic fold), accumulated
+    in f32.  An index outside the table is skipped here and reported by the deferred range check of its first use."""
+    dev = require_device(g2, ind)
+    ind32 = narrow_i32(ind)
+    m, d = g2.shape
+    err = None
+    seen = getattr(ind32, "_pygho_table_checked", None)
+    if seen is None or seen != (ind32._version, n_table):
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+    nblk = int(lib().pygho_table_grad_blocks(m))
+    ws = torch.empty((nblk, n_table * d), dtype=torch.float32, device=dev)
+    timer = LaunchTimer.active
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(dev))
+    check(lib().pygho_table_grad(ptr(ws), ptr(g2), ptr(ind32), m, d, n_table, dtype_code(g2), ptr(err), stream_ptr(dev)), "table_grad")
+    if timer is not None:
+        e1.record(torch.cuda.current_stream(dev))
+        timer.records.append((f"table_grad[{str(g2.dtype).split('.')[-1]}]", g2.element_size() * m * d + 4 * m + 4 * ws.numel(), e0, e1))
+    if err is not None:
+        defer_error(err, f"pygho_amd: lookup index out of range [0, {n_table})")
+        try:
+            ind32._pygho_table_checked = (ind32._version, n_table)
+        except Exception:
+            pass
+    if nblk == 1:
+        tot = ws
+    else:
+        tot = torch.empty((n_table * d,), dtype=torch.float32, device=dev)
+        check(lib().pygho_sum_blocks(ptr(tot), ptr(ws), nblk, n_table * d, stream_ptr(dev)), "sum_blocks")
+    return tot.view(n_table, d).to(g2.dtype)
+
+
 class _RowGather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src: Tensor, ind: Tensor):
@@ -758,9 +801,11 @@ class _RowGather(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout: Tensor):
         ind = ctx.ind
-        plan = cached_plan(ind, ctx.n, "scatter")
         g2 = _as2d(gout) if gout.dim() > 1 else gout.contiguous().reshape(-1, 1)
-        g = seg_reduce_rows(g2, plan, "sum")
+        if table_grad_ok(g2, ctx.n):
+            g = table_grad(g2, ind, ctx.n)                  # a handful of table rows: no index plan at all
+        else:
+            g = seg_reduce_rows(g2, cached_plan(ind, ctx.n, "scatter"), "sum")
         return g.reshape((ctx.n,) + tuple(gout.shape[1:])), None
 
 
@@ -937,9 +982,9 @@ class _PairProduct(torch.autograd.Function):
     gradients are the same three-operand kernel over the unit / by-row / by-col / by-feature groupings of the tuples."""
 
     @staticmethod
-    def forward(ctx, left, right, val, row32, col32, vidx32, by_row, by_col, by_val, mirror):
+    def forward(ctx, left, right, val, row32, col32, vidx32, by_row, by_col, by_val, mirror, groupings=None):
         n = row32.numel()
-        ctx.mirror = mirror
+        ctx.mirror, ctx.groupings = mirror, groupings
         unit_ok = USE_UNIT_TRIPLE and (left.shape[1] * left.element_size()) % 16 == 0 and left.shape[1] * left.element_size() <= 1024 \
             and left.dtype in (torch.float32, torch.bfloat16, torch.float16)
         out = seg_triple(n, left, right, val, None if unit_ok else unit_ptr(n, val.device), row32, col32, vidx32)
@@ -959,7 +1004,9 @@ class _PairProduct(torch.autograd.Function):
                 and right.is_contiguous() and val.is_contiguous()):
             g_left, g_right, g_val = pair_bwd(g, left, right, val, by_row[0].seg_ptr, col32, vidx32, mirror)
             return (g_left if ctx.needs_input_grad[0] else None, g_right if ctx.needs_input_grad[1] else None,
-                    g_val if ctx.needs_input_grad[2] else None, None, None, None, None, None, None, None)
+                    g_val if ctx.needs_input_grad[2] else None, None, None, None, None, None, None, None, None)
+        if by_col is None and ctx.groupings is not None:
+            by_col, by_val = ctx.groupings()          # the gradient arrived in another dtype / layout than the forward promised
         if ctx.needs_input_grad[0]:
             p, col_p, v_p = by_row
             g_left = seg_triple(p.n_seg, g, val, right, p.seg_ptr, p.perm, v_p if vidx32 is not None else p.perm, col_p)
@@ -977,7 +1024,7 @@ class _PairProduct(torch.autograd.Function):
                 for lv in levels[1:]:
                     cur = seg_gmr(lv.numel() - 1, cur, None, lv, None, None, "sum")
                 g_val = cur.to(val.dtype)
-        return g_left, g_right, g_val, None, None, None, None, None, None, None
+        return g_left, g_right, g_val, None, None, None, None, None, None, None, None
 
 
 def _grouped(plan: SegPlan, key, *idx32):
@@ -999,18 +1046,27 @@ def pair_product(left: Tensor, right: Tensor, val: Tensor, row: Tensor, col: Ten
     vidx32 = None if val_index is None else narrow_i32(val_index)
     key = (row32, col32, vidx32)
     p_row = cached_plan(row, left.shape[0], "pair-row")
-    p_col = cached_plan(col, right.shape[0], "pair-col", assume_sorted=False)
     by_row = (p_row,) + _grouped(p_row, key, col32, vidx32)
-    by_col = (p_col,) + _grouped(p_col, key, row32, vidx32)
-    by_val = None
-    if val_index is not None:
-        p_val = cached_plan(val_index, val.shape[0], "pair-val", assume_sorted=False)
-        by_val = (p_val,) + _grouped(p_val, key, row32, col32)
-    # the one-pass backward needs the tuple set's mirror permutation: decided HERE (one host read per pattern, memoised), where the
-    # plans are built, so that backward never synchronises
+    # the one-pass backward needs the tuple set's mirror permutation: decided HERE (one host read per pattern, memoised -- or
+    # installed by `collate.DeviceGraphStore`), where the plans are built, so that backward never synchronises
     mirror = None
     if (USE_PAIR_BWD and vidx32 is not None and torch.is_grad_enabled() and (left.requires_grad or right.requires_grad or val.requires_grad)
             and p_row.perm is None and left.dtype in (torch.bfloat16, torch.float16) and left.dtype == right.dtype == val.dtype
-            and left.shape == right.shape and (left.shape[1] * 2) % 16 == 0 and left.shape[1] * 2 <= 1024):
+            and left.shape == right.shape and (left.shape[1] * 2) % 16 == 0 and left.shape[1] * 2 <= 1024
+            and left.is_contiguous() and right.is_contiguous() and val.is_contiguous()):
         mirror = pair_mirror(row32, col32, vidx32, left.shape[0])
-    return _PairProduct.apply(left, right, val, row32, col32, vidx32, by_row, by_col, by_val, mirror)
+
+    n_right, n_val = right.shape[0], val.shape[0]
+
+    def groupings():
+        """the by-column / by-feature groupings of the three-launch backward (two radix sorts per pattern, cached on the index
+        objects): built in forward unless the one-pass backward is certain to run"""
+        p_col = cached_plan(col, n_right, "pair-col", assume_sorted=False)
+        by_col = (p_col,) + _grouped(p_col, key, row32, vidx32)
+        by_val = None
+        if val_index is not None:
+            p_val = cached_plan(val_index, n_val, "pair-val", assume_sorted=False)
+            by_val = (p_val,) + _grouped(p_val, key, row32, col32)
+        return by_col, by_val
+    by_col, by_val = (None, None) if mirror is not None else groupings()
+    return _PairProduct.apply(left, right, val, row32, col32, vidx32, by_row, by_col, by_val, mirror, groupings)

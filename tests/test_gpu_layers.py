@@ -1641,3 +1641,37 @@ def test_four_captured_steps_with_eager_work_between_replays(dev):
     assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
     last = [float(gs.output) for gs in steps]
     assert sum(last) < sum(first), f"the captured steps do not train: {first} -> {last}"
+
+
+def test_prefetched_training_with_deferred_flags_from_two_streams(dev):
+    """range-check flags are produced on two streams when training through BatchPrefetcher (the collation's on the side stream, the
+    small-table gradients' on the training stream): each is read only by a fetch on ITS stream or by the full check, never by the
+    other stream's fetch (which could see it before it was even zero-filled).  70 fresh batches (more than the 64 pending flags
+    that force a full check) train without a spurious error, and a genuinely bad index is still reported."""
+    from pygho_amd import _ops, synth
+    from pygho_amd.collate import BatchPrefetcher, DeviceGraphStore
+    from pygho_amd.ngnn import SpModel
+    rng = np.random.default_rng(21)
+    recs = [synth.make_graph(rng, "zinc", 3, ("X___X___1___A___0",)) for _ in range(64)]
+    store = DeviceGraphStore(recs, dev)
+    torch.manual_seed(0)
+    model = SpModel(1, 2, 64, act_dtype=torch.bfloat16).to(dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+    gen = torch.Generator().manual_seed(2)
+    ids = [torch.randperm(64, generator=gen)[:8] for _ in range(70)]
+    for dd in BatchPrefetcher(store, ids):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = model(dd)
+        loss = torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float())
+        loss.backward()
+        opt.step()
+    _ops.check_deferred_errors()
+    assert bool(torch.isfinite(loss))
+    side = torch.cuda.Stream()
+    g = torch.ones(6, 8, device=dev)
+    _ops.table_grad(g, torch.tensor([0, 1, 5, 1, 0, 2], device=dev), 3)            # flag raised on the current stream ...
+    with torch.cuda.stream(side):
+        assert _ops._fetch(torch.zeros(1, dtype=torch.int64, device=dev)) == [0]   # ... is not this stream's to read
+    with pytest.raises(ValueError, match="out of range"):
+        _ops._fetch(torch.zeros(1, dtype=torch.int64, device=dev))

@@ -171,3 +171,28 @@ def test_optimizer_steps_invalidate_the_cast_arenas():
     before = blocks._ARENA_EPOCH[0]
     blocks.invalidate_cast_arenas()
     assert blocks._ARENA_EPOCH[0] == before + 1
+
+
+def test_store_mirror_verdict_per_graph():
+    """collate._mirror_of (host half of the collated mirror plan): positions of the transposed tuples of a symmetric 2-tuple set
+    with a symmetric feature, and the verdicts for an asymmetric set / an asymmetric feature / a feature beyond the kernel's table."""
+    import numpy as np
+    from pygho_amd import synth
+    from pygho_amd.collate import _mirror_of
+    rng = np.random.default_rng(0)
+    r = synth.make_graph(rng, "zinc", 3)
+    pos, ok = _mirror_of(r, 16)
+    assert ok
+    row, col = r.tupleid
+    assert np.array_equal(row[pos], col) and np.array_equal(col[pos], row) and np.array_equal(r.tuplefeat[pos], r.tuplefeat)
+    assert not _mirror_of(r, int(r.tuplefeat.max()))[1]                          # a feature value the table kernel cannot hold
+    off = int(np.nonzero(row != col)[0][0])
+    feat = r.tuplefeat.copy()
+    feat[off] += 1
+    assert not _mirror_of(synth.GraphRecord(r.num_nodes, r.x, r.edge_index, r.edge_attr, r.tupleid, feat), 16)[1]
+    keep = np.ones(row.size, dtype=bool)
+    keep[off] = False
+    assert not _mirror_of(synth.GraphRecord(r.num_nodes, r.x, r.edge_index, r.edge_attr, r.tupleid[:, keep], r.tuplefeat[keep]), 16)[1]
+    empty = synth.GraphRecord(3, r.x[:3], r.edge_index[:, :0], r.edge_attr[:0], r.tupleid[:, :0], r.tuplefeat[:0])
+    pos, ok = _mirror_of(empty, 16)
+    assert ok and pos.size == 0
