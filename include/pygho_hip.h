@@ -143,11 +143,12 @@ int pygho_pair_bwd(void* g_left, void* g_right, float* tab_ws, const void* g, co
 /* Gradient of a row lookup into a SMALL table (autograd of `X[self.indices[dim]]`, pygho/backend/SpTensor.py:476, and of the
  * nn.Embedding lookups of example/minimal.py:22-34, whose tables have 16-32 rows) without an index plan:
  *   ws[blk][k][c] = sum over the rows r of workgroup blk with idx[r] == k of g[r][c]     (f32; fold with pygho_sum_blocks)
- * g: (m, d) f32 / bf16 / f16, idx: (m) int32, ws: (pygho_table_grad_blocks(m), n_table, d) floats.  Needs n_table * d * 4 bytes
- * <= 64 KiB of LDS (pygho_table_grad_supported).  Rows with idx outside [0, n_table) are skipped and raise *err (nullable) to 1.
- * Deterministic: a fixed function of (m, d, n_table), no atomics. */
+ * g: (m, d) f32 / bf16 / f16, idx: (m) int32, ws: (pygho_table_grad_blocks(m, d, n_table), n_table, d) floats.  Needs n_table * d * 4 bytes
+ * <= 64 KiB (pygho_table_grad_supported).  Tables of up to 32 rows with an even width up to 256 keep the sums in registers (one
+ * wavefront per slab of rows, a scalar branch per row); anything else in LDS bins.  Rows with idx outside [0, n_table) are skipped and
+ * raise *err (nullable) to 1.  Deterministic: a fixed function of (m, d, n_table), no atomics. */
 int pygho_table_grad_supported(int64_t d, int64_t n_table);
-int pygho_table_grad_blocks(int64_t m);
+int pygho_table_grad_blocks(int64_t m, int64_t d, int64_t n_table);
 int pygho_table_grad(float* ws, const void* g, const int32_t* idx, int64_t m, int64_t d, int64_t n_table, int dtype, int32_t* err,
                      void* stream);
 

@@ -37,7 +37,7 @@ PROTOTYPES = {
     "pygho_seg_tile_plan": (I, [P, P, P, P, L, L, P]),
     "pygho_seg_gather_mul_reduce_tiled": (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, I, I, P]),
     "pygho_table_grad_supported": (I, [L, L]),
-    "pygho_table_grad_blocks": (I, [L]),
+    "pygho_table_grad_blocks": (I, [L, L, L]),
     "pygho_table_grad": (I, [P, P, P, L, L, L, I, P, P]),
     "pygho_pair_bwd_types": (I, []),
     "pygho_pair_bwd_blocks": (I, [L, L, I]),

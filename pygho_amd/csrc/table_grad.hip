@@ -7,14 +7,28 @@
 // per batch pattern); here every workgroup walks a contiguous chunk of g with one f32 bin per (table row, column) in LDS.  A thread
 // owns one column, so its read-modify-writes never meet another thread's, and its rows arrive in row order: the result is a fixed
 // function of (m, d, n_table) -- deterministic, no atomics.  `lanes` row lanes (threads / d of them) walk interleaved rows into
-// their own copies of the bins and are folded in lane order at the end.
+// their own copies of the bins and are folded in lane order at the end.  This is the GENERIC form (any width, up to 64 table rows);
+// tables of up to 32 rows and even widths up to 256 take the register form below.
 #include "common.h"
 
 namespace pygho {
 
-constexpr int kTgRows = 512;          // rows of g per workgroup (upper bound on the grid: kTgMaxBlocks)
+#ifndef PYGHO_TG_UNROLL
+#define PYGHO_TG_UNROLL 8
+#endif
+#ifndef PYGHO_TG_WAVES_X
+#define PYGHO_TG_WAVES_X 2
+#endif
+#ifndef PYGHO_TG_ROWS
+#define PYGHO_TG_ROWS 512
+#endif
+constexpr int kTgRows = PYGHO_TG_ROWS;          // rows of g per workgroup (upper bound on the grid: kTgMaxBlocks)
 constexpr int kTgMaxBlocks = 2048;
 constexpr int kTgLds = 64 * 1024;     // bytes of bins per workgroup
+
+// (plain read-modify-write: the LDS add instruction, tried for its fire-and-forget issue, serialises on repeated addresses -- 347 us
+// against 110 us for 410 k rows)
+__device__ __forceinline__ void tg_add(float* p, float v) { *p += v; }
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void table_grad_kernel(float* __restrict__ ws, const T* __restrict__ g,
@@ -31,7 +45,7 @@ __global__ __launch_bounds__(kBlock) void table_grad_kernel(float* __restrict__ 
   const int c0 = d <= kBlock ? t - rl * d : t;         // my (first) column
   if (rl < lanes) {
     float* mine = bins + (size_t)rl * width;
-    constexpr int U = 4;
+    constexpr int U = PYGHO_TG_UNROLL;
     int64_t r = r0 + rl;
     for (; r + (U - 1) * lanes < r1; r += (int64_t)U * lanes) {
       int k[U];
@@ -43,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void table_grad_kernel(float* __restrict__ 
         for (int u = 0; u < U; ++u) v[u] = (float)load_as_acc<T>(g + (r + (int64_t)u * lanes) * d + c);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          if ((unsigned)k[u] < (unsigned)n_table) mine[k[u] * d + c] += v[u];
+          if ((unsigned)k[u] < (unsigned)n_table) tg_add(mine + k[u] * d + c, v[u]);
           else if (err != nullptr) *err = 1;
         }
       }
@@ -51,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void table_grad_kernel(float* __restrict__ 
     for (; r < r1; r += lanes) {
       const int k = idx[r];
       for (int c = c0; c < d; c += kBlock) {
-        if ((unsigned)k < (unsigned)n_table) mine[k * d + c] += (float)load_as_acc<T>(g + r * d + c);
+        if ((unsigned)k < (unsigned)n_table) tg_add(mine + k * d + c, (float)load_as_acc<T>(g + r * d + c));
         else if (err != nullptr) *err = 1;
       }
     }
@@ -63,6 +77,101 @@ __global__ __launch_bounds__(kBlock) void table_grad_kernel(float* __restrict__ 
     for (int l = 1; l < lanes; ++l) s += bins[(size_t)l * width + j];
     out[j] = s;
   }
+}
+
+
+// ---- register form ---------------------------------------------------------------------------------------------------------
+// One WAVEFRONT per slab of consecutive rows; a lane owns CP column pairs and keeps its NT x 2 CP sums in registers.  Registers
+// cannot be indexed dynamically, so "acc[k] += v" is NT selects + adds per value on a wavefront-uniform (scalar) compare: every sum
+// receives v or +0.0 (a select, not a multiplication by 0/1: a non-finite gradient row stays in its own table row).  A scalar branch
+// into NT straight-line adds was 3 x slower (taken branches, and the optimiser's copies where the cases meet); LDS bins serialise on
+// their own read-modify-write latency (110 us for 410 k rows of 256 B).  U rows are in flight per wavefront.  Every wavefront writes
+// its own slab of ws (folded by pygho_sum_blocks like the generic form's).
+template <typename T> struct TgPair;
+template <> struct TgPair<float> {
+  using raw = float2;
+  static __device__ __forceinline__ void unpack(const raw& r, float& a, float& b) { a = r.x; b = r.y; }
+};
+template <> struct TgPair<bf16> {
+  using raw = uint32_t;
+  static __device__ __forceinline__ void unpack(const raw& r, float& a, float& b) { a = __uint_as_float(r << 16); b = __uint_as_float(r & 0xffff0000u); }
+};
+template <> struct TgPair<f16> {
+  using raw = uint32_t;
+  static __device__ __forceinline__ void unpack(const raw& r, float& a, float& b) {
+    union { uint32_t u; _Float16 h[2]; } c; c.u = r;
+    a = (float)c.h[0]; b = (float)c.h[1];
+  }
+};
+
+template <typename T, int NT, int CP>
+__global__ __launch_bounds__(kBlock) void table_grad_reg_kernel(float* __restrict__ ws, const T* __restrict__ g,
+                                                                const int32_t* __restrict__ idx, int64_t m, int d, int n_table,
+                                                                int64_t rows_per_wave, int32_t* __restrict__ err) {
+  using P = TgPair<T>;
+  constexpr int U = PYGHO_TG_UNROLL;
+  const int lane = threadIdx.x & 63;
+  const int64_t slab = (int64_t)blockIdx.x * (kBlock / kWave) + PYGHO_WAVE_INDEX((int)(threadIdx.x >> 6));
+  const int64_t r0 = slab * rows_per_wave;
+  if (r0 >= m) return;
+  const int64_t r1 = r0 + rows_per_wave < m ? r0 + rows_per_wave : m;
+  float acc[NT][CP][2];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < CP; ++j) acc[i][j][0] = acc[i][j][1] = 0.f;
+  bool on[CP];
+#pragma unroll
+  for (int j = 0; j < CP; ++j) on[j] = 2 * (lane + 64 * j) < d;
+  const T* base = g + 2 * lane;
+  bool bad = false;
+  for (int64_t r = r0; r < r1; r += U) {
+    typename P::raw raw[U][CP];
+    int k[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t rr = r + u < r1 ? r + u : r1 - 1;            // (the tail repeats the last row's loads; its adds are skipped)
+      k[u] = __builtin_amdgcn_readfirstlane(idx[rr]);
+#pragma unroll
+      for (int j = 0; j < CP; ++j)
+        raw[u][j] = on[j] ? *reinterpret_cast<const typename P::raw*>(base + rr * d + 128 * j) : typename P::raw{};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r + u >= r1) break;
+      float va[CP], vb[CP];
+#pragma unroll
+      for (int j = 0; j < CP; ++j) P::unpack(raw[u][j], va[j], vb[j]);
+      if ((unsigned)k[u] >= (unsigned)n_table) bad = true;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const bool hit = k[u] == i;                              // wavefront-uniform: a scalar compare feeding vector selects
+#pragma unroll
+        for (int j = 0; j < CP; ++j) {
+          acc[i][j][0] += hit ? va[j] : 0.f;
+          acc[i][j][1] += hit ? vb[j] : 0.f;
+        }
+      }
+    }
+  }
+  if (bad && err != nullptr && lane == 0) *err = 1;
+  float* out = ws + (size_t)slab * n_table * d + 2 * lane;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+#pragma unroll
+    for (int j = 0; j < CP; ++j)
+      if (i < n_table && on[j]) *reinterpret_cast<float2*>(out + (size_t)i * d + 128 * j) = make_float2(acc[i][j][0], acc[i][j][1]);
+  }
+}
+
+static bool tg_reg_ok(int64_t d, int64_t n_table) { return n_table <= 32 && d % 2 == 0 && d <= 256; }
+
+// slabs of the register form: enough wavefronts to keep ~2 MB of loads in flight, few enough that the slabs (n_table * d floats each)
+// stay a fraction of the input
+static int64_t tg_rows_per_wave(int64_t m, int64_t n_table) {
+  const int64_t target = (n_table <= 16 ? 2048 : 1024) * PYGHO_TG_WAVES_X;
+  int64_t rpw = ceil_div(m > 0 ? m : 1, target);
+  return rpw < 64 ? 64 : rpw;
 }
 
 static int tg_lanes(int64_t d, int64_t n_table) {
@@ -80,7 +189,8 @@ extern "C" int pygho_table_grad_supported(int64_t d, int64_t n_table) {
   return d >= 1 && n_table >= 1 && n_table * d * 4 <= kTgLds && d <= (1 << 20);
 }
 
-extern "C" int pygho_table_grad_blocks(int64_t m) {
+extern "C" int pygho_table_grad_blocks(int64_t m, int64_t d, int64_t n_table) {
+  if (tg_reg_ok(d, n_table)) return (int)(ceil_div(ceil_div(m > 0 ? m : 1, tg_rows_per_wave(m, n_table)), kBlock / kWave) * (kBlock / kWave));
   int64_t b = ceil_div(m, kTgRows);
   if (b < 1) b = 1;
   if (b > kTgMaxBlocks) b = kTgMaxBlocks;
@@ -93,11 +203,40 @@ extern "C" int pygho_table_grad(float* ws, const void* g, const int32_t* idx, in
     set_error("pygho_table_grad: bad arguments (m %lld, d %lld, n_table %lld)", (long long)m, (long long)d, (long long)n_table);
     return PYGHO_ERR_INVALID;
   }
-  const int nblk = pygho_table_grad_blocks(m);
+  hipStream_t st = (hipStream_t)stream;
+  if (tg_reg_ok(d, n_table)) {
+    const int slabs = pygho_table_grad_blocks(m, d, n_table);
+    const int64_t rpw = tg_rows_per_wave(m, n_table);
+    // slabs past the last row are never written: the caller folds only ceil(m / rows_per_wave) of them?  No -- keep it simple:
+    // they are written by nobody, so zero them here (a few KB)
+    const int64_t used = ceil_div(m > 0 ? m : 1, rpw);
+    if (used < slabs)
+      (void)hipMemsetAsync(ws + (size_t)used * n_table * d, 0, (size_t)(slabs - used) * n_table * d * sizeof(float), st);
+    if (m == 0) { (void)hipMemsetAsync(ws, 0, (size_t)n_table * d * sizeof(float), st); return check_launch("pygho_table_grad"); }
+    const dim3 grid(slabs / (kBlock / kWave));
+#define PYGHO_TGR(T, NT, CP) \
+    hipLaunchKernelGGL((table_grad_reg_kernel<T, NT, CP>), grid, dim3(kBlock), 0, st, ws, (const T*)g, idx, m, (int)d, (int)n_table, rpw, err)
+#define PYGHO_TGR_T(T)                                                                        \
+    do {                                                                                      \
+      if (n_table <= 16) { if (d <= 128) PYGHO_TGR(T, 16, 1); else PYGHO_TGR(T, 16, 2); }     \
+      else { if (d <= 128) PYGHO_TGR(T, 32, 1); else PYGHO_TGR(T, 32, 2); }                   \
+    } while (0)
+    switch (dtype) {
+      case PYGHO_F32: PYGHO_TGR_T(float); break;
+      case PYGHO_BF16: PYGHO_TGR_T(bf16); break;
+      case PYGHO_F16: PYGHO_TGR_T(f16); break;
+      default:
+        set_error("pygho_table_grad: dtype %d not supported (f32, bf16, f16)", dtype);
+        return PYGHO_ERR_UNSUPPORTED;
+    }
+#undef PYGHO_TGR_T
+#undef PYGHO_TGR
+    return check_launch("pygho_table_grad");
+  }
+  const int nblk = pygho_table_grad_blocks(m, d, n_table);
   const int lanes = tg_lanes(d, n_table);
   const int64_t rpb = ceil_div(m > 0 ? m : 1, nblk);
   const size_t lds = (size_t)lanes * n_table * d * sizeof(float);
-  hipStream_t st = (hipStream_t)stream;
 #define PYGHO_TG(T)                                                                                                           \
   do {                                                                                                                        \
     static bool set_[64];                                                                                                     \

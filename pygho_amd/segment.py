@@ -757,6 +757,30 @@ def table_grad_ok(g2: Tensor, n_table: int) -> bool:
             and bool(lib().pygho_table_grad_supported(g2.shape[1], n_table)))
 
 
+# The plan-free kernel is VALU-bound (n_table selects + adds per value: 60 us for 410 k rows of 256 B against 39 us for the planned
+# hierarchy), so a LARGE pattern that keeps coming back (a resident batch) is planned after a few uses, like the by-edge scatter
+# plans; small batches (launch-bound) and fresh batches (one use) never pay for a sort and its host reads.
+TABLE_GRAD_PLAN_ROWS = int(os.environ.get("PYGHO_TABLE_GRAD_PLAN_ROWS", str(1 << 16)))
+TABLE_GRAD_PLAN_AFTER = int(os.environ.get("PYGHO_TABLE_GRAD_PLAN_AFTER", "3"))
+
+
+def _table_grad_now(g2: Tensor, ind: Tensor, n_table: int) -> bool:
+    if not table_grad_ok(g2, n_table):
+        return False
+    cache = getattr(ind, "_pygho_plans", None)
+    if cache is not None and ("scatter", n_table, ind._version) in cache:
+        return g2.shape[0] < TABLE_GRAD_PLAN_ROWS          # a plan exists (someone built or installed it): use it where it is faster
+    if g2.shape[0] < TABLE_GRAD_PLAN_ROWS or torch.cuda.is_current_stream_capturing():
+        return True
+    uses = getattr(ind, "_pygho_table_uses", (ind._version, 0))
+    uses = (ind._version, (uses[1] if uses[0] == ind._version else 0) + 1)
+    try:
+        ind._pygho_table_uses = uses
+    except Exception:
+        return True
+    return uses[1] <= TABLE_GRAD_PLAN_AFTER
+
+
 def table_grad(g2: Tensor, ind: Tensor, n_table: int) -> Tensor:
     """sum of the rows of `g2` per value of `ind` (values in [0, n_table)) as an (n_table, d) tensor of g2's dtype: the
     gradient of ``table[ind]`` for a small table (csrc/table_grad.hip: LDS bins per workgroup + a deterministic fold), accumulated
@@ -768,7 +792,7 @@ def table_grad(g2: Tensor, ind: Tensor, n_table: int) -> Tensor:
     seen = getattr(ind32, "_pygho_table_checked", None)
     if seen is None or seen != (ind32._version, n_table):
         err = torch.zeros(1, dtype=torch.int32, device=dev)
-    nblk = int(lib().pygho_table_grad_blocks(m))
+    nblk = int(lib().pygho_table_grad_blocks(m, d, n_table))
     ws = torch.empty((nblk, n_table * d), dtype=torch.float32, device=dev)
     timer = LaunchTimer.active
     if timer is not None:
@@ -802,7 +826,7 @@ class _RowGather(torch.autograd.Function):
     def backward(ctx, gout: Tensor):
         ind = ctx.ind
         g2 = _as2d(gout) if gout.dim() > 1 else gout.contiguous().reshape(-1, 1)
-        if table_grad_ok(g2, ctx.n):
+        if _table_grad_now(g2, ind, ctx.n):
             g = table_grad(g2, ind, ctx.n)                  # a handful of table rows: no index plan at all
         else:
             g = seg_reduce_rows(g2, cached_plan(ind, ctx.n, "scatter"), "sum")

@@ -1622,3 +1622,26 @@ def test_collated_batch_needs_no_plan_building(dev):
                                           _ops.narrow_i32(_ops.flat_index(d1["X"].values)), int(d1["num_nodes"])))(s2.collate([0, 3]))) is not None
     assert _ops.FETCHES[0] == f0
     step(d2)                                                            # the three-launch backward still trains
+
+
+def test_table_grad_plans_large_recurring_patterns(dev):
+    """policy of the small-table gradient: a large index pattern (>= TABLE_GRAD_PLAN_ROWS rows) that keeps coming back is planned
+    after TABLE_GRAD_PLAN_AFTER plan-free uses (the planned hierarchy is faster there); small ones never are; the gradients of both
+    routes agree to f32 accumulation error."""
+    from pygho_amd import _ops
+    n_table, d = 16, 128
+    for m, planned_expected in ((_ops.TABLE_GRAD_PLAN_ROWS + 5, True), (4096, False)):
+        idx = torch.randint(0, n_table, (m,), device=dev)
+        g = torch.randn(m, d, device=dev).to(torch.bfloat16)
+        grads = []
+        for use in range(_ops.TABLE_GRAD_PLAN_AFTER + 2):
+            table = torch.randn(n_table, d, device=dev).to(torch.bfloat16).requires_grad_(True)
+            _ops.gather_rows(table, idx).backward(g)
+            grads.append(table.grad)
+            has_plan = ("scatter", n_table, idx._version) in getattr(idx, "_pygho_plans", {})
+            assert has_plan == (planned_expected and use >= _ops.TABLE_GRAD_PLAN_AFTER), (m, use, has_plan)
+        ref = torch.zeros(n_table, d, dtype=torch.float64, device=dev).index_add_(0, idx, g.double())
+        mag = torch.zeros(n_table, d, dtype=torch.float64, device=dev).index_add_(0, idx, g.double().abs())
+        for got in grads:
+            assert bool(((got.double() - ref).abs() <= 64 * 2.0 ** -24 * mag + 2.0 ** -8 * ref.abs() + 1e-30).all())
+        assert torch.equal(grads[0], grads[1])
