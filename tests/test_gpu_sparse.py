@@ -1645,3 +1645,44 @@ def test_table_grad_plans_large_recurring_patterns(dev):
         for got in grads:
             assert bool(((got.double() - ref).abs() <= 64 * 2.0 ** -24 * mag + 2.0 ** -8 * ref.abs() + 1e-30).all())
         assert torch.equal(grads[0], grads[1])
+
+
+def test_device_collate_edge_cases(dev):
+    """collation of degenerate selections: an empty selection, a single graph, a graph without edges (no messages either) in the
+    middle of a batch, ids given as list / numpy / CPU tensor / device tensor -- same arrays as the host collate, plans installed
+    for every non-empty family."""
+    from pygho_amd import SparseTensor, _ops, synth
+    from pygho_amd.collate import DeviceGraphStore
+    key = "X___X___1___A___0"
+    rng = np.random.default_rng(31)
+    recs = [synth.make_graph(rng, "zinc", 3, (key,)) for _ in range(6)]
+    lone = recs[2]
+    iso = synth.GraphRecord(lone.num_nodes, lone.x, lone.edge_index[:, :0], lone.edge_attr[:0],
+                            np.stack([np.arange(lone.num_nodes)] * 2).astype(np.int64), np.zeros(lone.num_nodes, dtype=np.int64),
+                            {key: np.zeros((3, 0), dtype=np.int64)}, 0.5)             # isolated nodes: diagonal tuples only
+    recs[2] = iso
+    store = DeviceGraphStore(recs, dev)
+    for sel in ([1, 2, 3], [2], [2, 2], np.asarray([5, 0]), torch.tensor([4, 2, 1]), torch.tensor([3, 3, 0], device=dev)):
+        got = store.collate(sel)
+        ids = [int(i) for i in (sel.tolist() if hasattr(sel, "tolist") else sel)]
+        ref = synth.to_datadict(synth.collate([recs[i] for i in ids]), dev, "zinc")
+        for k, v in ref.items():
+            g = got[k]
+            if isinstance(v, SparseTensor):
+                assert torch.equal(g.indices, v.indices) and torch.equal(g.values, v.values), (k, ids)
+            elif torch.is_tensor(v):
+                assert torch.equal(g, v), (k, ids)
+            else:
+                assert g == v, (k, ids)
+        acd = got[key + "___acd"]
+        plan = _ops.message_plan(acd, got["X"].nnz, got["X"].nnz, got["A"].nnz)
+        ref_plan = _ops.MessagePlan(ref[key + "___acd"], got["X"].nnz, got["X"].nnz, got["A"].nnz)
+        assert torch.equal(plan.fwd.seg_ptr, ref_plan.fwd.seg_ptr)
+        if acd.shape[1]:
+            assert torch.equal(plan.by_c()[0].perm, ref_plan.by_c()[0].perm) and torch.equal(plan.by_d()[0].seg_ptr, ref_plan.by_d()[0].seg_ptr)
+        row = got["X"]._row(0)
+        assert torch.equal(_ops.cached_plan(row, int(got["num_nodes"]), "scatter").seg_ptr,
+                           _ops.plan_from_keys(row.clone(), int(got["num_nodes"])).seg_ptr)
+    empty = store.collate([])
+    assert empty["num_graphs"] == 0 and empty["num_nodes"] == 0 and empty["x"].numel() == 0 and empty["X"].nnz == 0
+    assert empty[key + "___acd"].shape == (3, 0)
