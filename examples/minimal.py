@@ -60,8 +60,9 @@ def main():
         tot, nb = 0.0, 0
         t0 = time.perf_counter()
         batches = [perm[i:i + args.batch] for i in range(0, args.graphs, args.batch)]
-        # block-diagonal batches built by device kernels, one batch ahead on a side stream, index plans included
-        for dd in BatchPrefetcher(store, batches, model.prepare):
+        # block-diagonal batches built by device kernels, one batch ahead on a side stream; a collated batch arrives with every
+        # index plan this model's step asks for (other models: pass `model.prepare` as the third argument)
+        for dd in BatchPrefetcher(store, batches):
             opt.zero_grad(set_to_none=True)
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 pred = model(dd)

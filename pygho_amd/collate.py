@@ -273,8 +273,11 @@ class BatchPrefetcher:
     stream while the consumer trains on batch k and its plans are built there, so the synchronisations wait for the side stream's
     own few kernels instead of the training step's queue.
 
-    ``prepare(datadict)`` builds the plans (``SpModel.prepare``: the model's index-consuming operators run once on width-8 dummy
-    features; the plans depend on the index tensors only, so they land in the caches the real step will hit).  Batches are kept
+    Since round 4 a collated batch carries the plans of the shipped sparse layers' steps itself (message / scatter plans per key,
+    tuples by root, nodes by graph, the tuple set's mirror; `DeviceGraphStore.collate`), and collation reads nothing back, so for
+    those models `prepare` is not needed.  ``prepare(datadict)`` remains for anything else that groups by a batch's index tensors
+    (``SpModel.prepare``: the model's index-consuming operators run once on width-8 dummy features; the plans depend on the index
+    tensors only, so they land in the caches the real step will hit) -- it runs on the side stream as well.  Batches are kept
     alive until the consumer's stream has passed the point where the next batch was requested (their memory belongs to the side
     stream's allocator pool).
     """
