@@ -22,7 +22,9 @@ def indicehash(indice: LongTensor) -> LongTensor:
     """(sparse_dim, nnz) -> (nnz) order-preserving bit pack, ``63 // sparse_dim`` bits per
     coordinate.  Reference: SpTensor.py:10-44 (asserts on negative / too large indices)."""
     assert indice.ndim == 2
-    return _ops.hash_pack(indice, validate=__debug__)
+    # (index arrays collated from `collate.DeviceGraphStore` are range-checked when the store is built and carry a mark: the
+    # reference's two asserts cost a device-to-host read each, SpTensor.py:32,37)
+    return _ops.hash_pack(indice, validate=__debug__ and getattr(indice, "_pygho_hash_ok", None) != indice._version)
 
 
 def decodehash(indhash: LongTensor, sparse_dim: int) -> LongTensor:

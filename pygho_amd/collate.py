@@ -119,6 +119,18 @@ class DeviceGraphStore:
             cnt = [np.bincount(r.tupleid[0], minlength=r.num_nodes) for r in records]
             self.root_parts = {"cnt": _cat32([c.reshape(1, -1) for c in cnt], 1, d),
                                "h_max": np.asarray([c.max() if c.size else 0 for c in cnt], dtype=np.int64)}
+        # groupings of the tuples by their OTHER coordinates and of the edges by either endpoint (cross-subgraph pooling, unpooling
+        # gradients, spmm): per-graph counts per node and, where the coordinate is not sorted, the stable order -- assembled per batch
+        # only when an operator asks (`plans.cached_plan` -> `_pygho_plan_factory`)
+        self.group_parts = {}
+        for name, rows_of in [(("X", dim), (lambda r, dim=dim: r.tupleid[dim])) for dim in range(1, self.sd)] + \
+                             [(("A", dim), (lambda r, dim=dim: r.edge_index[dim])) for dim in (0, 1)]:
+            arrs = [rows_of(r) for r in records]
+            cnt = [np.bincount(a, minlength=r.num_nodes) for a, r in zip(arrs, records)]
+            part = {"cnt": _cat32([c.reshape(1, -1) for c in cnt], 1, d), "h_max": np.asarray([c.max() if c.size else 0 for c in cnt], dtype=np.int64)}
+            if not all(a.size == 0 or np.all(np.diff(a) >= 0) for a in arrs):
+                part["perm"] = _cat32([np.argsort(a, kind="stable").reshape(1, -1) for a in arrs], 1, d)
+            self.group_parts[name] = part
         # mirror positions of symmetric 2-tuple sets (segment.pair_mirror: the one-pass backward of the tuple initialisation):
         # graph-local here, plus the tuple offset of the graph in a batch; the verdict of a batch is the AND over its graphs
         self.mirror_parts = None
@@ -151,6 +163,11 @@ class DeviceGraphStore:
             return
         _ops.install_plan(dd["batch"], _ops.SegPlan(lay.dev[("optr32", "node")], None, g, n), ("scatter",),
                           max_len=self.h_len["node"][ids_h].max())
+        for (which, dim), part in self.group_parts.items():
+            sp = X if which == "X" else dd["A"]
+            fam = "tup" if which == "X" else "edge"
+            keys = sp._row(dim)
+            keys._pygho_plan_factory = (keys._version, self._group_factory(part, lay, fam))
         if self.root_parts is None:
             return
         row = X._row(0)
@@ -164,6 +181,19 @@ class DeviceGraphStore:
         if bool(self.mirror_parts["h_ok"][ids_h].all()):
             res = self._rows(self.mirror_parts["pos"], lay, "tup", lay.dev[("off", "tup")], i32=True).reshape(-1)
         row32._pygho_mirror = (col32, vidx32, n, res, (row32._version, col32._version, vidx32._version))
+
+    def _group_factory(self, part, lay: "_Layout", fam):
+        def build(n_seg: int):
+            if n_seg != lay.total["node"] or lay.total[fam] >= (1 << 31):
+                return None
+            cnt = self._rows(part["cnt"], lay, "node").reshape(-1)
+            perm = None
+            if "perm" in part:
+                perm = self._rows(part["perm"], lay, fam, lay.dev[("off", fam)], i32=True).reshape(-1)
+            plan = _ops.SegPlan(_ops.exclusive_scan(cnt).to(torch.int32), perm, n_seg, lay.total[fam])
+            plan._memo = {"max_len": int(part["h_max"][lay.ids_h].max()) if lay.g else 0}
+            return plan
+        return build
 
     def collate(self, graph_ids: Union[Sequence[int], torch.Tensor]) -> Dict:
         """datadict of the block-diagonal batch of ``graph_ids`` (any order, repeats allowed; a host sequence / CPU tensor: a
@@ -181,6 +211,9 @@ class DeviceGraphStore:
         tf = tf.reshape(-1) if not self.feat_shape else tf.t().contiguous().reshape((total["tup"],) + self.feat_shape)
         x = self._rows(self.x, lay, "node").reshape(-1)
         batch = torch.repeat_interleave(torch.arange(g, dtype=torch.int64, device=self.device), lay.dev[("len", "node")], output_size=n)
+        for ind in (ei, tid):                       # non-negative and below n by construction: the hash asserts need no read-back
+            if n < (1 << (63 // ind.shape[0])):
+                ind._pygho_hash_ok = ind._version
         dd = {
             "x": x, "batch": batch, "num_graphs": g, "y": self.y[lay.dev[("ids",)]], "num_nodes": n,
             "A": SparseTensor(ei, ea, [n, n], is_coalesced=True),

@@ -348,7 +348,7 @@ class GNNAKConv(Module):
         cache = H._cache()
         if "sun_views" not in cache:
             diag_idx = torch.arange(n, device=ri.device)
-            pos = _ops.sorted_match(H._hash(), indicehash(diag_idx.reshape(1, -1).expand(2, -1).contiguous()))
+            pos = _ops.sorted_match(H._hash(), _ops.hash_pack(diag_idx.reshape(1, -1).expand(2, -1).contiguous(), validate=n >= (1 << 31)))
             cnt = lambda r: torch.bincount(r, minlength=n).clamp_min(1).unsqueeze(-1)
             cache["sun_views"] = (pos, cnt(ri), cnt(ci))
         pos, cnt_r, cnt_c = cache["sun_views"]
@@ -562,7 +562,7 @@ class SUNConv(Module):
             cache = X._cache()
             if "sun_views" not in cache:
                 diag_idx = torch.arange(n, device=ri.device)
-                pos = _ops.sorted_match(X._hash(), indicehash(diag_idx.reshape(1, -1).expand(2, -1).contiguous()))
+                pos = _ops.sorted_match(X._hash(), _ops.hash_pack(diag_idx.reshape(1, -1).expand(2, -1).contiguous(), validate=n >= (1 << 31)))
                 cnt = lambda r: torch.bincount(r, minlength=n).clamp_min(1).unsqueeze(-1)
                 cache["sun_views"] = (pos, cnt(ri), cnt(ci))
             pos, cnt_r, cnt_c = cache["sun_views"]

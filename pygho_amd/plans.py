@@ -300,7 +300,13 @@ def cached_plan(keys: Tensor, n_seg: int, tag: str = "", assume_sorted: Optional
     k = (tag, n_seg, keys._version)
     plan = cache.get(k)
     if plan is None:
-        plan = plan_from_keys(keys, n_seg, assume_sorted)
+        # a batch collated from `collate.DeviceGraphStore` knows how to assemble the groupings of its index rows from per-graph parts
+        # (no sort, no host read): asked only when somebody needs one
+        factory = getattr(keys, "_pygho_plan_factory", None)
+        if factory is not None and factory[0] == keys._version:
+            plan = factory[1](n_seg)
+        if plan is None:
+            plan = plan_from_keys(keys, n_seg, assume_sorted)
         cache[k] = plan
     return plan
 

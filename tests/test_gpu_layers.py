@@ -1675,3 +1675,42 @@ def test_prefetched_training_with_deferred_flags_from_two_streams(dev):
         assert _ops._fetch(torch.zeros(1, dtype=torch.int64, device=dev)) == [0]   # ... is not this stream's to read
     with pytest.raises(ValueError, match="out of range"):
         _ops._fetch(torch.zeros(1, dtype=torch.int64, device=dev))
+
+
+@pytest.mark.parametrize("conv", ["NGNN", "SSWL", "SUN", "GNNAK", "DSSGNN"])
+def test_fresh_collated_batch_trains_without_host_reads(dev, conv):
+    """a training step of every 2-tuple sparse model family on a batch it has never seen, collated from the device graph store,
+    makes no device-to-host read (planner fetches, `.item()`, `.tolist()`): the batch arrives with its message / scatter plans, the
+    groupings of its index rows are assembled from per-graph parts on demand, small-table gradients need no plan, and the store's
+    range checks stand in for the hash asserts.  (3-tuple models still plan their merged patterns: an inherent size read.)"""
+    from pygho_amd import _ops, synth
+    from pygho_amd.collate import DeviceGraphStore
+    from pygho_amd.honn.SpOperator import parse_precomputekey
+    from pygho_amd.models import SpModel
+    torch.manual_seed(0)
+    model = SpModel(conv, num_layer=2, hiddim=64, act_dtype=torch.bfloat16).to(dev)
+    keys = tuple(parse_precomputekey(model))
+    rng = np.random.default_rng(1)
+    store = DeviceGraphStore([synth.make_graph(rng, "zinc", 3, keys) for _ in range(24)], dev)
+
+    def step(dd):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = model(dd)
+        loss = torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float())
+        loss.backward()
+        return loss.detach()
+
+    step(store.collate(list(range(8))))
+    torch.cuda.synchronize()
+    reads = []
+    oi, ol = torch.Tensor.item, torch.Tensor.tolist
+    torch.Tensor.item = lambda self: (reads.append("item") if self.is_cuda else None, oi(self))[1]
+    torch.Tensor.tolist = lambda self: (reads.append("tolist") if self.is_cuda else None, ol(self))[1]
+    f0 = _ops.FETCHES[0]
+    try:
+        loss = step(store.collate([9, 3, 17, 20, 5, 5, 11, 23]))
+    finally:
+        torch.Tensor.item, torch.Tensor.tolist = oi, ol
+    assert _ops.FETCHES[0] == f0 and not reads, (conv, _ops.FETCHES[0] - f0, reads)
+    assert bool(torch.isfinite(loss))

@@ -1686,3 +1686,29 @@ def test_device_collate_edge_cases(dev):
     empty = store.collate([])
     assert empty["num_graphs"] == 0 and empty["num_nodes"] == 0 and empty["x"].numel() == 0 and empty["X"].nnz == 0
     assert empty[key + "___acd"].shape == (3, 0)
+
+
+@pytest.mark.parametrize("kind", ["zinc", "i2"])
+def test_collated_groupings_on_demand(dev, kind):
+    """the groupings of a collated batch's tuples by their other coordinates and of its edges by either endpoint (cross-subgraph
+    pooling, unpooling gradients, spmm) are assembled from the store's per-graph parts when an operator asks for them: equal to
+    the planner's sort of the collated index rows, without a host read; pooling through them matches pooling through sorted plans."""
+    from pygho_amd import _ops, synth
+    from pygho_amd.collate import DeviceGraphStore
+    rng = np.random.default_rng(17)
+    recs = [synth.make_graph(rng, kind) for _ in range(12)]
+    store = DeviceGraphStore(recs, dev)
+    dd = store.collate([4, 4, 0, 11, 7, 2])
+    n, X, A = int(dd["num_nodes"]), dd["X"], dd["A"]
+    f0 = _ops.FETCHES[0]
+    got = [(_ops.cached_plan(sp._row(dim), n, "scatter"), sp._row(dim)) for sp, dim in
+           [(X, k) for k in range(1, X.sparse_dim)] + [(A, 0), (A, 1)]]
+    vals = torch.randn(X.nnz, 16, device=dev)
+    pooled = _ops.scatter_reduce(vals, X._row(1), n, "mean")
+    assert _ops.FETCHES[0] == f0, "assembling the groupings read something back"
+    for plan, keys in got:
+        ref = _ops.plan_from_keys(keys.clone(), n)
+        assert torch.equal(plan.seg_ptr, ref.seg_ptr) and plan.max_len == ref.max_len
+        assert (plan.perm is None) == (ref.perm is None) and (plan.perm is None or torch.equal(plan.perm, ref.perm))
+    ref_pooled = _ops.scatter_reduce(vals, X._row(1).clone(), n, "mean")
+    assert torch.equal(pooled, ref_pooled)
