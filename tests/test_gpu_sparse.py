@@ -1712,3 +1712,28 @@ def test_collated_groupings_on_demand(dev, kind):
         assert (plan.perm is None) == (ref.perm is None) and (plan.perm is None or torch.equal(plan.perm, ref.perm))
     ref_pooled = _ops.scatter_reduce(vals, X._row(1).clone(), n, "mean")
     assert torch.equal(pooled, ref_pooled)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_table_grad_keeps_non_finite_rows_in_their_table_row(dev, dtype):
+    """rows of the small-table gradient are accumulated with a 0 / 1 factor while they are finite; a row holding inf / nan must
+    reach ONLY its own table row (a factor of 0 would spread nan to all of them)."""
+    from pygho_amd import _ops
+    m, d, n_table = 5000, 128, 16
+    gen = torch.Generator(device=dev).manual_seed(3)
+    g = torch.randn(m, d, device=dev, generator=gen).to(dtype)
+    idx = torch.randint(0, n_table, (m,), device=dev, generator=gen)
+    idx[1234], idx[4000] = 3, 9
+    g[1234, 7] = float("inf")
+    g[4000, 100] = float("nan")
+    got = _ops.table_grad(g, idx, n_table).float()
+    assert torch.isinf(got[3, 7]) and torch.isnan(got[9, 100])
+    bad = ~torch.isfinite(got)
+    bad[3, 7] = bad[9, 100] = False
+    assert not bool(bad.any())
+    clean = g.clone()
+    clean[1234, 7] = clean[4000, 100] = 0
+    ref = _ops.table_grad(clean, idx, n_table).float()
+    mask = torch.ones_like(got, dtype=torch.bool)
+    mask[3, 7] = mask[9, 100] = False
+    assert torch.equal(got[mask], ref[mask])
