@@ -171,11 +171,19 @@ class SparseTensor:
             c[k] = self.__indices[dim].contiguous()
         return c[k]
 
+    def _sub_indices(self, dims) -> Tensor:
+        """rows `dims` of the indices, contiguous; range-checked rows stay range-checked (fewer coordinates leave MORE hash bits each)"""
+        ind = self.__indices
+        sub = ind[dims].contiguous()
+        if getattr(ind, "_pygho_hash_ok", None) == ind._version:
+            sub._pygho_hash_ok = sub._version
+        return sub
+
     def _hash(self, dims: Optional[Tuple[int, ...]] = None) -> Tensor:
         c = self._cache()
         k = ("hash", dims)
         if k not in c:
-            c[k] = indicehash(self.__indices if dims is None else self.__indices[list(dims)])
+            c[k] = indicehash(self.__indices if dims is None else self._sub_indices(list(dims)))
         return c[k]
 
     # ---- diagonal (SpTensor.py:304-366) --------------------------------------
@@ -231,7 +239,7 @@ class SparseTensor:
         c = self._cache()
         k = ("pool_sparse", tuple(idx))
         if k not in c:       # the merged pattern depends on the indices only: plan it once per pattern
-            uniq, plan, inv = _ops.unique_plan(indicehash(self.indices[idx].contiguous()))
+            uniq, plan, inv = _ops.unique_plan(indicehash(self._sub_indices(idx)))
             c[k] = (decodehash(uniq, len(idx)), plan, inv)
         new_ind, plan, inv = c[k]
         val = _ops.scatter_reduce_planned(self.values, plan, inv, reduce)
