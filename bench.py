@@ -12,8 +12,12 @@ of example/minimal.py (hidden 128, bf16 activations / f32 master weights) over o
 that is already resident in HBM.  Every rank owns its own batch of --graphs graphs (weak scaling, graphs shard
 with no data-path collective); value = graphs of all ranks / max-over-ranks time.  The batch's index plans (int32 / CSR
 views and transposed groupings of its index tensors, cached on them) are part of the resident input, like the reference's
-precomputed ___acd triples; training with a NEW batch every step, plans built one batch ahead on a side stream, is measured by
-tools/bench_ops.py (fresh_batch_case: 14.3-14.8 ms per step against 13.1-13.4 ms here).
+precomputed ___acd triples.
+
+`regimes` (N == 1): the same step with a NEW batch every step (collated on the device from a resident graph store together with
+every index plan, one batch ahead on a side stream: `fresh_batch_ms_per_step`), and the launch-bound sizes 128 / 1024 graphs --
+eager on a resident batch, eager on a fresh shuffled batch every step (`eager_fresh_batch_ms_per_step`, what a training loop with the
+reference's batch size does), and the whole step captured into a HIP graph.
 
 `configs` (N == 1): the other measured configurations of BASELINE.json in the same line -- config 5 (I2-shape 3-tuple spspmm
 launch, d = 256 bf16, and an I2Conv layer step), config 3 (mamamm X A / X Y at (1024, 37, 37, 128) bf16 and a SUNConv DD layer step)
