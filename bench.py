@@ -222,21 +222,25 @@ def side_regimes(args, dev):
     model = SpModel(1, args.layers, args.hidden, act_dtype=act).to(dev)
     step = make_step(model, torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True), None)
     gen = torch.Generator().manual_seed(0)
-    ids = [torch.randperm(store.num_graphs, generator=gen)[:args.graphs] for _ in range(16)]
-    n = 0
     # (no `prepare`: collation installs every plan SpModel asks for -- tests/test_gpu_sparse.py::test_collated_batch_needs_no_plan_building)
-    for k, dd in enumerate(BatchPrefetcher(store, ids)):
-        if k == 4:
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-        step(dd)
-        n += 1
-    torch.cuda.synchronize(dev)
-    ms = (time.perf_counter() - t0) / (n - 4) * 1e3
+    passes = []
+    for _ in range(2):                     # the boxes are shared: a host stall of a few ms in a 12-step loop shows; both passes are reported
+        ids = [torch.randperm(store.num_graphs, generator=gen)[:args.graphs] for _ in range(16)]
+        n = 0
+        for k, dd in enumerate(BatchPrefetcher(store, ids)):
+            if k == 4:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            step(dd)
+            n += 1
+        torch.cuda.synchronize(dev)
+        passes.append((time.perf_counter() - t0) / (n - 4) * 1e3)
+    ms = min(passes)
     out["fresh_batch_ms_per_step"] = ms
+    out["fresh_batch_ms_per_step_passes"] = passes
     out["fresh_batch_graphs_per_s"] = args.graphs / ms * 1e3
-    out["fresh_batch_note"] = (f"{n - 4} timed steps, every step a different {args.graphs}-graph batch collated on the device from a "
-                               f"resident int32 graph store ({store.num_graphs} graphs) together with its index plans, one batch ahead on a side stream")
+    out["fresh_batch_note"] = (f"better of 2 passes of {n - 4} timed steps (both listed), every step a different {args.graphs}-graph batch collated on the "
+                               f"device from a resident int32 graph store ({store.num_graphs} graphs) together with its index plans, one batch ahead on a side stream")
     del store, model, step
     # (b) small batches
     small_store = DeviceGraphStore(recs * max(1, 4096 // len(recs)), dev)
