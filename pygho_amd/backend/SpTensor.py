@@ -168,7 +168,7 @@ class SparseTensor:
         c = self._cache()
         k = ("row", dim)
         if k not in c:
-            c[k] = self.__indices[dim].contiguous()
+            c[k] = _ops.unbased(self.__indices[dim].contiguous())     # (a view cached on its own base would never be freed)
         return c[k]
 
     def _sub_indices(self, dims) -> Tensor:

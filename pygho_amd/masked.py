@@ -31,7 +31,9 @@ def _mask_u8(mask: Tensor) -> Tensor:
     """bool mask as a uint8 view (no copy), cached on the mask tensor object."""
     c = getattr(mask, "_pygho_u8", None)
     if c is None:
-        c = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.contiguous().to(torch.uint8)
+        c = unbased(mask.contiguous().view(torch.uint8)) if mask.dtype == torch.bool else mask.contiguous().to(torch.uint8)
+        if c is mask:
+            return c                                         # already uint8 and contiguous: nothing to cache (not on itself)
         try:
             mask._pygho_u8 = c
         except Exception:
@@ -463,8 +465,11 @@ USE_BMM_EXTENTS = True        # matrix-core contraction: stage / multiply only u
 
 
 def _mask_extents(amask, bmask, omask, nb, ni, nk, nj, a_kfirst: bool, b_kfirst: bool) -> Optional[Tensor]:
-    """(nb, 3) int32 (ei, ek, ej) per batch element (`pygho_mask_extents`), cached on the first mask of the triple (the cache
-    entry keeps the masks alive, so their identities cannot be recycled); None when no mask is given."""
+    """(nb, 3) int32 (ei, ek, ej) per batch element (`pygho_mask_extents`), cached on the first mask of the triple.  An entry holds
+    its other masks WEAKLY (strong references between two masks' caches -- forward keyed on one, backward on the other -- were a
+    cycle that kept both masks' memory until the cyclic collector ran) and is valid only while those references are alive and are
+    the very objects asked about (so a recycled `id` cannot hit); None when no mask is given."""
+    import weakref
     holder = amask if amask is not None else (bmask if bmask is not None else omask)
     if holder is None:
         return None
@@ -475,9 +480,12 @@ def _mask_extents(amask, bmask, omask, nb, ni, nk, nj, a_kfirst: bool, b_kfirst:
             holder._pygho_extents = cache
         except Exception:
             pass
+    masks = (amask, bmask, omask)
     ver = lambda m: None if m is None else (id(m), m._version)
     key = (ver(amask), ver(bmask), ver(omask), ni, nk, nj, a_kfirst, b_kfirst)
     hit = cache.get(key)
+    if hit is not None and not all((r is None and (m is None or m is holder)) or (r is not None and r() is m) for r, m in zip(hit[1], masks)):
+        hit = None
     if hit is None:
         dev = holder.device
         ext = torch.empty((nb, 3), dtype=torch.int32, device=dev)
@@ -485,7 +493,7 @@ def _mask_extents(amask, bmask, omask, nb, ni, nk, nj, a_kfirst: bool, b_kfirst:
                                        1 if b_kfirst else 0, stream_ptr(dev)), "mask_extents")
         if len(cache) > 8:
             cache.clear()
-        hit = cache[key] = (ext, amask, bmask, omask)
+        hit = cache[key] = (ext, tuple(None if (m is None or m is holder) else weakref.ref(m) for m in masks))
     return hit[0]
 
 

@@ -44,7 +44,7 @@ class IndexEmbedding(nn.Embedding):
         if idx.dim() == 1:
             # provenance for consumers that can index the (tiny, cache-resident) table themselves instead of streaming the
             # gathered rows: the fused layer block reads A's values this way (honn/Conv._residual_update)
-            out._pygho_lookup = (table, idx._pygho_flat[1])
+            out._pygho_lookup = (table, _flat_index(idx))
         return out
 
 

@@ -379,7 +379,7 @@ class MessagePlan:
         assert acd.dim() == 2 and acd.shape[0] == 3, "acd must be (3, M)"
         self.m = acd.shape[1]
         self.n_out, self.n_lhs, self.n_rhs = n_out, n_lhs, n_rhs
-        self._a64, self._c64, self._d64 = acd[0], acd[1], acd[2]
+        self._a64, self._c64, self._d64 = unbased(acd[0]), unbased(acd[1]), unbased(acd[2])   # (cached on acd: no view links)
         if self.m > 0:
             # operand indices must address rows of the operands (the reference's gathers raise IndexError,
             # Spspmm.py:309-311); the flag rides on the synchronisation of the forward plan's sortedness probe below
@@ -404,7 +404,7 @@ class MessagePlan:
         self = cls.__new__(cls)
         self.m = acd.shape[1]
         self.n_out, self.n_lhs, self.n_rhs = n_out, n_lhs, n_rhs
-        self._a64, self._c64, self._d64 = acd[0], acd[1], acd[2]
+        self._a64, self._c64, self._d64 = unbased(acd[0]), unbased(acd[1]), unbased(acd[2])   # (cached on acd: no view links)
         self.fwd = SegPlan(fwd_ptr, None, n_out, self.m)
         self.a32, self.c32, self.d32 = narrow_i32(acd[0]), narrow_i32(acd[1]), narrow_i32(acd[2])
         self.c_fwd, self.d_fwd = self.c32, self.d32

@@ -1714,3 +1714,124 @@ def test_fresh_collated_batch_trains_without_host_reads(dev, conv):
         torch.Tensor.item, torch.Tensor.tolist = oi, ol
     assert _ops.FETCHES[0] == f0 and not reads, (conv, _ops.FETCHES[0] - f0, reads)
     assert bool(torch.isfinite(loss))
+
+
+def _allocated_growth(make_and_use, warm=6, iters=24):
+    """bytes of device memory that stay allocated per iteration of `make_and_use()` with the cyclic collector OFF (so both kinds of
+    leak show: cycles Python could collect later, and cycles through a view's C++-side `_base` pointer that it never can)"""
+    import gc
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(warm):
+            make_and_use()
+        torch.cuda.synchronize()
+        a = torch.cuda.memory_allocated()
+        for _ in range(iters):
+            make_and_use()
+        torch.cuda.synchronize()
+        return (torch.cuda.memory_allocated() - a) / iters
+    finally:
+        gc.enable()
+
+
+def test_fresh_batches_do_not_leak_device_memory(dev):
+    """Every batch's index arrays carry caches (int32 copies, rows, plans) as attributes.  A VIEW of a tensor cached on that tensor
+    is a reference cycle through the view's `_base` that no collector sees: until round 4 every fresh batch stayed allocated for the
+    life of the process (4.6 MB per 128-graph batch, 330 MB per 8192-graph batch).  Three loops -- batches collated from the device
+    store, batches planned the ordinary way, fresh masks through the dense contraction -- must leave allocated memory flat."""
+    from pygho_amd import MaskedTensor, synth
+    from pygho_amd.backend.Mamamm import mamamm
+    from pygho_amd.collate import DeviceGraphStore
+    from pygho_amd.ngnn import SpModel
+    key = "X___X___1___A___0"
+    rng = np.random.default_rng(4)
+    recs = [synth.make_graph(rng, "zinc", 3, (key,)) for _ in range(64)]
+    store = DeviceGraphStore(recs, dev)
+    torch.manual_seed(0)
+    model = SpModel(1, 2, 64, act_dtype=torch.bfloat16).to(dev)
+    gen = torch.Generator().manual_seed(0)
+
+    def step(dd):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = model(dd)
+        torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float()).backward()
+
+    per_batch = 24 * 3 * 50 * 20 * 8          # ~ the int64 triples of one 24-graph batch: a leaked batch is several times this
+    g1 = _allocated_growth(lambda: step(store.collate(torch.randperm(64, generator=gen)[:24])))
+    assert g1 < 0.05 * per_batch, f"collated batches leak {g1:.0f} B per batch"
+    g2 = _allocated_growth(lambda: step(synth.to_datadict(synth.collate([recs[i] for i in torch.randperm(64, generator=gen)[:24].tolist()]), dev, "zinc")))
+    assert g2 < 0.05 * per_batch, f"ordinarily planned batches leak {g2:.0f} B per batch"
+
+    def dense():
+        b, n, d = 16, 20, 64
+        mask = torch.rand(b, n, n, device=dev) < 0.4
+        amask = torch.rand(b, n, n, device=dev) < 0.1
+        X = MaskedTensor(torch.randn(b, n, n, d, device=dev, requires_grad=True), mask, 0.0, False)
+        A = MaskedTensor(torch.randn(b, n, n, d, device=dev), amask, 0.0, False)
+        mamamm(X, 2, A, 1, mask).data.sum().backward()
+    g3 = _allocated_growth(dense)
+    assert g3 < 16 * 20 * 20 * 2, f"fresh masks leak {g3:.0f} B per batch"
+
+
+def _tensors_in(obj, depth=0, seen=None):
+    """tensors reachable from a cache value through tuples / lists / dicts / plain objects' attributes (bounded depth)"""
+    seen = set() if seen is None else seen
+    if id(obj) in seen or depth > 5:
+        return
+    seen.add(id(obj))
+    if torch.is_tensor(obj):
+        yield obj
+        return
+    if isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_in(v, depth + 1, seen)
+    elif isinstance(obj, (tuple, list)):
+        for v in obj:
+            yield from _tensors_in(v, depth + 1, seen)
+    elif hasattr(obj, "__dict__") or hasattr(obj, "__slots__"):
+        names = list(getattr(obj, "__dict__", {})) + [s for s in getattr(type(obj), "__slots__", ()) if hasattr(obj, s)]
+        for nme in names:
+            yield from _tensors_in(getattr(obj, nme, None), depth + 1, seen)
+
+
+def test_no_cache_holds_a_view_of_its_owner(dev):
+    """structural form of the leak test: after a training step on a collated batch and a dense contraction, no tensor's `_pygho_*`
+    caches contain a tensor whose `_base` is that tensor (the uncollectable cycle), nor the tensor itself (a collectable one that
+    still pins device memory until the cyclic collector runs)."""
+    import gc
+    from pygho_amd import MaskedTensor, synth
+    from pygho_amd.backend.Mamamm import mamamm
+    from pygho_amd.collate import DeviceGraphStore
+    from pygho_amd.models import SpModel
+    from pygho_amd.honn.SpOperator import parse_precomputekey
+    rng = np.random.default_rng(6)
+    keep = []
+    for conv in ("NGNN", "SUN", "SSWL"):
+        torch.manual_seed(0)
+        model = SpModel(conv, num_layer=2, hiddim=64, act_dtype=torch.bfloat16).to(dev)
+        keys = tuple(parse_precomputekey(model))
+        recs = [synth.make_graph(rng, "zinc", 3, keys) for _ in range(12)]
+        for dd in (DeviceGraphStore(recs, dev).collate([3, 1, 7, 7, 10]), synth.to_datadict(synth.collate(recs[:5]), dev, "zinc")):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                pred = model(dd)
+            torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float()).backward()
+            keep.append(dd)
+    b, n, d = 8, 12, 64
+    mask, amask = torch.rand(b, n, n, device=dev) < 0.4, torch.rand(b, n, n, device=dev) < 0.2
+    X = MaskedTensor(torch.randn(b, n, n, d, device=dev, requires_grad=True), mask, 0.0, False)
+    A = MaskedTensor(torch.randn(b, n, n, d, device=dev), amask, 0.0, False)
+    mamamm(X, 2, A, 1, mask).data.sum().backward()
+    keep += [mask, amask]
+    bad = []
+    for owner in [o for o in gc.get_objects() if torch.is_tensor(o)]:
+        for name, val in list(getattr(owner, "__dict__", {}).items()):
+            if not name.startswith("_pygho"):
+                continue
+            for t in _tensors_in(val):
+                if t is owner:
+                    bad.append((name, tuple(owner.shape), "holds itself"))
+                elif t._base is owner:
+                    bad.append((name, tuple(owner.shape), "holds a view of itself"))
+    assert not bad, bad[:10]
