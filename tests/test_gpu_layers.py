@@ -1808,12 +1808,13 @@ def test_no_cache_holds_a_view_of_its_owner(dev):
     from pygho_amd.honn.SpOperator import parse_precomputekey
     rng = np.random.default_rng(6)
     keep = []
-    for conv in ("NGNN", "SUN", "SSWL"):
+    for conv in ("NGNN", "SUN", "SSWL", "GNNAK", "DSSGNN", "I2GNN"):
         torch.manual_seed(0)
         model = SpModel(conv, num_layer=2, hiddim=64, act_dtype=torch.bfloat16).to(dev)
         keys = tuple(parse_precomputekey(model))
-        recs = [synth.make_graph(rng, "zinc", 3, keys) for _ in range(12)]
-        for dd in (DeviceGraphStore(recs, dev).collate([3, 1, 7, 7, 10]), synth.to_datadict(synth.collate(recs[:5]), dev, "zinc")):
+        kind = "i2" if conv == "I2GNN" else "zinc"
+        recs = [synth.make_graph(rng, kind, 3, keys) for _ in range(12)]
+        for dd in (DeviceGraphStore(recs, dev).collate([3, 1, 7, 7, 10]), synth.to_datadict(synth.collate(recs[:5]), dev, kind)):
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 pred = model(dd)
             torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float()).backward()
@@ -1824,6 +1825,16 @@ def test_no_cache_holds_a_view_of_its_owner(dev):
     A = MaskedTensor(torch.randn(b, n, n, d, device=dev), amask, 0.0, False)
     mamamm(X, 2, A, 1, mask).data.sum().backward()
     keep += [mask, amask]
+    from pygho_amd.models import MaModel
+    hb = synth.make_batch(6, "zinc", seed=3)
+    for conv in ("SUN", "PPGN"):                               # the dense layout's models (padded MaskedTensors)
+        torch.manual_seed(0)
+        ma = MaModel(conv, num_layer=2, hiddim=64, act_dtype=torch.bfloat16).to(dev)
+        ddd = _dense_inputs_of(hb, dev)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = ma(ddd)
+        pred.float().sum().backward()
+        keep.append(ddd)
     bad = []
     for owner in [o for o in gc.get_objects() if torch.is_tensor(o)]:
         for name, val in list(getattr(owner, "__dict__", {}).items()):
