@@ -103,6 +103,9 @@ class DeviceGraphStore:
             self.scatter_parts[k] = {"chunk_ptr": chunk0.to(torch.int64), "chunks_t": chunks.t().contiguous(), "words": words.reshape(1, -1),
                                      "blk_e": blk_e.t().contiguous(), "max_edges": max_edges, "covers": covers}
         self.y = torch.tensor([r.y for r in records], dtype=torch.float32, device=d)
+        # largest integer feature of the store per array: a lookup into a table with more rows than that needs no range flag
+        vmax = lambda f: max((int(np.max(f(r))) for r in records if np.size(f(r))), default=-1)
+        self.h_vmax = {"x": vmax(lambda r: r.x), "ea": vmax(lambda r: r.edge_attr), "tf": vmax(lambda r: r.tuplefeat)}
         # per-graph lengths on the HOST as well: a batch's output sizes (and the longest segments its plans ask about) are sums /
         # maxima over the selected graphs, so collation needs no device-to-host read
         ln = lambda f: np.asarray([f(r) for r in records], dtype=np.int64)
@@ -211,6 +214,8 @@ class DeviceGraphStore:
         tf = tf.reshape(-1) if not self.feat_shape else tf.t().contiguous().reshape((total["tup"],) + self.feat_shape)
         x = self._rows(self.x, lay, "node").reshape(-1)
         batch = torch.repeat_interleave(torch.arange(g, dtype=torch.int64, device=self.device), lay.dev[("len", "node")], output_size=n)
+        for name, t in (("x", x), ("ea", ea), ("tf", tf)):      # values below this bound (the store checked them when it was built)
+            t._pygho_value_bound = (t._version, self.h_vmax[name] + 1)
         for ind in (ei, tid):                       # non-negative and below n by construction: the hash asserts need no read-back
             if n < (1 << (63 // ind.shape[0])):
                 ind._pygho_hash_ok = ind._version

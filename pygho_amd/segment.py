@@ -790,7 +790,9 @@ def table_grad(g2: Tensor, ind: Tensor, n_table: int) -> Tensor:
     m, d = g2.shape
     err = None
     seen = getattr(ind32, "_pygho_table_checked", None)
-    if seen is None or seen != (ind32._version, n_table):
+    bound = getattr(ind, "_pygho_value_bound", None)         # set by `collate.DeviceGraphStore`: the values were range-checked there
+    known = bound is not None and bound[0] == ind._version and bound[1] <= n_table
+    if not known and (seen is None or seen != (ind32._version, n_table)):
         err = torch.zeros(1, dtype=torch.int32, device=dev)
     nblk = int(lib().pygho_table_grad_blocks(m, d, n_table))
     ws = torch.empty((nblk, n_table * d), dtype=torch.float32, device=dev)
