@@ -1505,7 +1505,8 @@ def test_xcc_ids_reports_a_valid_xcd_per_workgroup(dev):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("m,d,n_table", [(1, 8, 1), (777, 64, 4), (100_003, 128, 32), (40_000, 256, 64), (5_000, 100, 7),
-                                         (1_200_000, 128, 16), (3_000, 300, 5)])
+                                         (1_200_000, 128, 16), (3_000, 300, 5), (1_000, 33, 5), (2_000, 1, 3), (700, 254, 32),
+                                         (900, 256, 33)])
 def test_table_grad_matches_index_add(dev, dtype, m, d, n_table):
     """plan-free gradient of a lookup into a small table (csrc/table_grad.hip; autograd of SpTensor.py:476 / the embeddings of
     example/minimal.py:22-34) == index_add in f64 within f32 accumulation error, == the planned path (sort + chunk hierarchy),
