@@ -652,6 +652,72 @@ int pygho_pair_emit(int64_t* tupleid, int64_t* feat, const int64_t* offset, int6
                     const int32_t* dst, int64_t n_edges, const uint8_t* dist, const int64_t* sq_ptr,
                     const int32_t* node_ptr, const int32_t* node_graph, int hop, void* stream);
 
+/* ---- row counts that live on the device: the "_dyn" forms ------------------------------------------------------------------
+ * The reference's training loop draws a NEW shuffled mini-batch every step (example/minimal.py:119, :141-149), so the number of
+ * nodes / tuples / edges changes from step to step.  A HIP graph captured once can still serve every batch when its launches are
+ * sized for a fixed CAPACITY of rows and the kernels take the TRUE row count from device memory.  Each "_dyn" entry point is its
+ * namesake with `m` split into (m_cap, m_dev): grid, workspaces and partial-sum slabs are sized for m_cap rows; the kernel reads
+ * m = *m_dev (0 <= m <= m_cap, int32; NULL = m_cap) and treats rows >= m exactly as rows past the end -- never read, never
+ * written, no share in any sum or in the 1/m of a BatchNorm.  Workgroups without rows write all-zero slabs, and every fold of the
+ * library adds trailing zeros without changing a bit, so a capacity-sized launch returns the bits of a launch sized for m.
+ * Row-wise entry points (pygho_rowblock_linear, pygho_rowblock_linear_bn_act, pygho_bn_act_fwd, the segment kernels over CSR
+ * plans whose pad segments are empty) need no such form: rows past m hold don't-care values that nothing reads. */
+int pygho_rowblock_linear_autoshift_dyn(void* out, const void* in, const void* wl, const void* bias, const void* addend,
+                                        float* stats_ws, float* shift_out, int64_t m_cap, const int32_t* m_dev, int64_t d, int dtype,
+                                        void* stream);
+int pygho_rowblock_linear_bwd_sums_dyn(float* sum_dz, float* sum_dz_xhat, const void* in, const void* wl, const void* bias,
+                                       const void* gh, const float* mean, const float* invstd, const float* w, const float* b,
+                                       int64_t m_cap, const int32_t* m_dev, int64_t d, int act, float* workspace, int dtype,
+                                       void* stream);
+int pygho_bn_bwd_linear_dw_dyn(void* gx, float* dw_ws, const void* pre, const void* gh, const void* x, const void* wl,
+                               const void* addend, float* colsum_ws, const float* mean, const float* invstd, const float* w,
+                               const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m_cap, const int32_t* m_dev,
+                               int64_t d, int act, int training, int dtype, int64_t ws_stride, void* stream);
+int pygho_bn_bwd_linear_dw_recompute_dyn(void* gx, float* dw_ws, const void* gh, const void* x, const void* wl, const void* bias,
+                                         const void* addend, float* colsum_ws, const float* mean, const float* invstd,
+                                         const float* w, const float* b, const float* sum_dz, const float* sum_dz_xhat,
+                                         int64_t m_cap, const int32_t* m_dev, int64_t d, int act, int training, int dtype,
+                                         int64_t ws_stride, void* stream);
+int pygho_weight_grad_dyn(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t x_ld, int64_t m_cap,
+                          const int32_t* m_dev, int64_t d, int dtype, int64_t ws_stride, void* stream);
+int pygho_bn_prepare_dyn(float* mean, float* var, float* invstd, float* scale, float* shift, const void* x, int64_t m_cap,
+                         const int32_t* m_dev, int64_t c, const float* weight, const float* bias, double eps, float* running_mean,
+                         float* running_var, double momentum, void* workspace, int dtype, void* stream);
+int pygho_bn_finalize_dyn(float* mean, float* var, float* invstd, float* scale, float* shift, const float* partial_sums,
+                          int64_t n_blocks, const float* sum_shift, int64_t m_cap, const int32_t* m_dev, int64_t c,
+                          const float* weight, const float* bias, double eps, float* running_mean, float* running_var,
+                          double momentum, void* stream);
+int pygho_bn_act_bwd_dyn(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
+                         const float* invstd, const float* w, const float* b, int64_t m_cap, const int32_t* m_dev, int64_t c, int act,
+                         int training, void* workspace, int dtype, float* sum_dx, void* stream);
+int pygho_bn_act_bwd_sums_dyn(float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
+                              const float* invstd, const float* w, const float* b, int64_t m_cap, const int32_t* m_dev, int64_t c,
+                              int act, void* workspace, int dtype, void* stream);
+int pygho_table_grad_dyn(float* ws, const void* g, const int32_t* idx, int64_t m_cap, const int32_t* m_dev, int64_t d,
+                         int64_t n_table, int dtype, int32_t* err, void* stream);
+
+/* ---- a whole batch collated by ONE launch (hodata/SpData.py:56-112 again, for the fixed-capacity batch slots) ----------------
+ * pygho_collate_rows once per array costs ~25 launches per batch.  Here a table of descriptors in DEVICE memory names every output
+ * array of the batch; blockIdx.y walks the table.  Per descriptor, for output columns j < out_ld:
+ *     j <  out_ptr[n_sel]:  out[r, j] = src[r, src_start[s] + (j - out_ptr[s])] + (inc[r] ? inc[r][s] : 0)   (s = graph of column j)
+ *     j >= out_ptr[n_sel]:  out[r, j] = pad ? *pad : 0
+ * so an output wider than the selected graphs' total -- a fixed-capacity buffer, or a CSR pointer array with its closing entry --
+ * is completed with a value read from the device (for a pointer array: the batch's message total, which makes the pad rows empty
+ * segments).  `out` is int64 or int32 (out_i32), (rows, out_ld) or transposed (out_ld, rows); rows <= 64, increments for r < 4.
+ * src_start / out_ptr / inc / pad point into one small per-batch upload; nothing else changes between batches. */
+typedef struct pygho_collate_desc {
+  void* out;
+  const int32_t* src;
+  const int64_t* src_start;
+  const int64_t* out_ptr;
+  const int64_t* inc[4];
+  const int64_t* pad;
+  int64_t src_ld, out_ld;
+  int32_t rows, out_i32, transposed, reserved;
+} pygho_collate_desc;
+size_t pygho_collate_desc_bytes(void);
+int pygho_collate_batch(const void* descs, int64_t n_desc, int64_t n_sel, int64_t max_cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,18 @@ PROTOTYPES = {
     "pygho_rowblock_linear_bwd_sums": (I, [P, P, P, P, P, P, P, P, P, P, L, L, I, P, I, P]),
     "pygho_bn_bwd_linear_dw_recompute": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, L, P]),
     "pygho_bn_bwd_fold_sums": (I, [P, P, P, L, L, P]),
+    "pygho_rowblock_linear_autoshift_dyn": (I, [P, P, P, P, P, P, P, L, P, L, I, P]),
+    "pygho_rowblock_linear_bwd_sums_dyn": (I, [P, P, P, P, P, P, P, P, P, P, L, P, L, I, P, I, P]),
+    "pygho_bn_bwd_linear_dw_dyn": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, L, P]),
+    "pygho_bn_bwd_linear_dw_recompute_dyn": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, L, P]),
+    "pygho_weight_grad_dyn": (I, [P, P, P, P, L, L, P, L, I, L, P]),
+    "pygho_bn_prepare_dyn": (I, [P, P, P, P, P, P, L, P, L, P, P, D, P, P, D, P, I, P]),
+    "pygho_bn_finalize_dyn": (I, [P, P, P, P, P, P, L, P, L, P, L, P, P, D, P, P, D, P]),
+    "pygho_bn_act_bwd_dyn": (I, [P, P, P, P, P, P, P, P, P, L, P, L, I, I, P, I, P, P]),
+    "pygho_bn_act_bwd_sums_dyn": (I, [P, P, P, P, P, P, P, P, L, P, L, I, P, I, P]),
+    "pygho_table_grad_dyn": (I, [P, P, P, L, P, L, L, I, P, P]),
+    "pygho_collate_desc_bytes": (Z, []),
+    "pygho_collate_batch": (I, [P, L, L, L, P]),
     "pygho_graph_bfs_dist": (I, [P, P, P, P, P, L, L, I, P]),
     "pygho_khop_count": (I, [P, P, P, P, P, L, I, P]),
     "pygho_khop_emit": (I, [P, P, P, L, P, P, P, P, L, I, P]),

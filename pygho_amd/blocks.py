@@ -60,11 +60,23 @@ def _bn_forward(x: Optional[Tensor], weight, bias, running_mean, running_var, tr
         mean, var = running_mean.float().clone(), running_var.float().clone()
     invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(3))
     fold = training and fold_momentum is not None
+    m_dev = dyn_rows(m) if training else None        # the batch statistics divide by the TRUE row count (a device value in a slot)
     if training and partial is not None:
         sums, sum_shift = partial
-        check(lib().pygho_bn_finalize(ptr(mean), ptr(var), ptr(invstd), ptr(scale), ptr(shift), ptr(sums), sums.shape[0],
-                                      ptr(sum_shift), m, c, ptr(w32), ptr(b32), float(eps), ptr(running_mean) if fold else None,
-                                      ptr(running_var) if fold else None, float(fold_momentum or 0.0), st), "bn_finalize")
+        if m_dev is not None:
+            check(lib().pygho_bn_finalize_dyn(ptr(mean), ptr(var), ptr(invstd), ptr(scale), ptr(shift), ptr(sums), sums.shape[0],
+                                              ptr(sum_shift), m, ptr(m_dev), c, ptr(w32), ptr(b32), float(eps),
+                                              ptr(running_mean) if fold else None, ptr(running_var) if fold else None,
+                                              float(fold_momentum or 0.0), st), "bn_finalize_dyn")
+        else:
+            check(lib().pygho_bn_finalize(ptr(mean), ptr(var), ptr(invstd), ptr(scale), ptr(shift), ptr(sums), sums.shape[0],
+                                          ptr(sum_shift), m, c, ptr(w32), ptr(b32), float(eps), ptr(running_mean) if fold else None,
+                                          ptr(running_var) if fold else None, float(fold_momentum or 0.0), st), "bn_finalize")
+    elif m_dev is not None:
+        check(lib().pygho_bn_prepare_dyn(ptr(mean), ptr(var), ptr(invstd), ptr(scale), ptr(shift), ptr(x), m, ptr(m_dev), c,
+                                         ptr(w32), ptr(b32), float(eps), ptr(running_mean) if fold else None,
+                                         ptr(running_var) if fold else None, float(fold_momentum or 0.0), ptr(ws), dt, st),
+              "bn_prepare_dyn")
     else:
         check(lib().pygho_bn_prepare(ptr(mean), ptr(var), ptr(invstd), ptr(scale), ptr(shift), ptr(x) if training else None, m, c,
                                      ptr(w32), ptr(b32), float(eps), ptr(running_mean) if fold else None,
@@ -93,6 +105,12 @@ def _bn_backward(x: Tensor, gy: Tensor, saved, training: bool, act: str, want_co
     s1 = torch.empty(c, dtype=torch.float32, device=dev)
     s2 = torch.empty(c, dtype=torch.float32, device=dev)
     sdx = torch.empty(c, dtype=torch.float32, device=dev) if want_colsum else None
+    m_dev = dyn_rows(m)
+    if m_dev is not None:
+        check(lib().pygho_bn_act_bwd_dyn(ptr(dx), ptr(s1), ptr(s2), ptr(x), ptr(gy), ptr(mean), ptr(invstd), ptr(w32), ptr(b32),
+                                         m, ptr(m_dev), c, ACT_CODE[act], 1 if training else 0, ptr(ws), dtype_code(x), ptr(sdx),
+                                         stream_ptr(dev)), "bn_act_bwd_dyn")
+        return dx, s1, s2, sdx
     check(lib().pygho_bn_act_bwd(ptr(dx), ptr(s1), ptr(s2), ptr(x), ptr(gy), ptr(mean), ptr(invstd), ptr(w32), ptr(b32),
                                  m, c, ACT_CODE[act], 1 if training else 0, ptr(ws), dtype_code(x), ptr(sdx),
                                  stream_ptr(dev)), "bn_act_bwd")
@@ -173,6 +191,7 @@ def _update_running(bn, mean: Tensor, var: Tensor, n: int, folded: bool = False)
                 bn.num_batches_tracked += 1
             if folded:
                 return
+            require_static_rows(n, "the running-average update of a BatchNorm without a fixed momentum")
             mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
             bn.running_var.mul_(1 - mom).add_(var.to(bn.running_var.dtype), alpha=mom * n / max(n - 1, 1))
@@ -363,6 +382,9 @@ def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype, want_colsum
     128 x 128 output, 2.9 ms at 1.8 M rows, but the batched call costs ~3.7 ms of host time, so it only pays for huge m)."""
     m, n, k = g.shape[0], g.shape[1], x.shape[1]
     cs = None
+    m_dev = dyn_rows(m)
+    if m_dev is not None:
+        any_height = True                      # the library GEMMs below would sum the pad rows of a batch slot
     if (g.is_cuda and g.dtype in (torch.bfloat16, torch.float16) and x.dtype == g.dtype and n in (64, 128) and k % n == 0
             and k // n <= 8 and (m >= 8192 or (any_height and m > 0))):      # (`any_height`: short inputs too -- launch-bound callers)
         g, x = g.contiguous(), x.contiguous()
@@ -374,14 +396,19 @@ def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype, want_colsum
             width = n * n + (2 * n if cs_here else 0)                 # one interleaved workspace, one folding launch
             ws = torch.empty((nblk, width), dtype=torch.float32, device=dev)
             cws_ptr = c_void_p(ws.data_ptr() + 4 * n * n) if cs_here else None
-            check(lib().pygho_weight_grad(ptr(ws), cws_ptr, ptr(g), c_void_p(x.data_ptr() + j * n * x.element_size()), k, m, n,
-                                          dtype_code(g), width, stream_ptr(dev)), "weight_grad")
+            if m_dev is not None:
+                check(lib().pygho_weight_grad_dyn(ptr(ws), cws_ptr, ptr(g), c_void_p(x.data_ptr() + j * n * x.element_size()), k, m,
+                                                  ptr(m_dev), n, dtype_code(g), width, stream_ptr(dev)), "weight_grad_dyn")
+            else:
+                check(lib().pygho_weight_grad(ptr(ws), cws_ptr, ptr(g), c_void_p(x.data_ptr() + j * n * x.element_size()), k, m, n,
+                                              dtype_code(g), width, stream_ptr(dev)), "weight_grad")
             tot = sum_blocks(ws)
             parts.append(tot[:n * n].reshape(n, n))
             if cs_here:
                 cs = tot[n * n:n * n + n]
         gw = (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)).to(out_dtype)
     else:
+        require_static_rows(m, "the library weight-gradient GEMM (widths other than 64 / 128, f32)")
         slabs = min(256, m // 2048)
         if slabs < 4 or m < (1 << 19):
             gw = (g.t() @ x).to(out_dtype)
@@ -436,9 +463,16 @@ def rowblock_linear(x: Tensor, wl: Tensor, bias: Optional[Tensor] = None, addend
         addend = addend.contiguous()
     if stats_shift is True:
         shift = torch.empty(d, dtype=torch.float32, device=dev)
-        check(lib().pygho_rowblock_linear_autoshift(ptr(out), ptr(x), ptr(wl), ptr(bias), ptr(addend), ptr(ws), ptr(shift), m, d,
-                                                    dtype_code(x), stream_ptr(dev)), "rowblock_linear")
+        m_dev = dyn_rows(m)
+        if m_dev is not None:
+            check(lib().pygho_rowblock_linear_autoshift_dyn(ptr(out), ptr(x), ptr(wl), ptr(bias), ptr(addend), ptr(ws), ptr(shift), m,
+                                                            ptr(m_dev), d, dtype_code(x), stream_ptr(dev)), "rowblock_linear_dyn")
+        else:
+            check(lib().pygho_rowblock_linear_autoshift(ptr(out), ptr(x), ptr(wl), ptr(bias), ptr(addend), ptr(ws), ptr(shift), m, d,
+                                                        dtype_code(x), stream_ptr(dev)), "rowblock_linear")
         return out, (ws, shift)
+    if stats_shift is not None:
+        require_static_rows(m, "rowblock_linear with a caller-given statistics shift")
     check(lib().pygho_rowblock_linear(ptr(out), ptr(x), ptr(wl), ptr(bias), ptr(addend), ptr(ws), ptr(stats_shift), m, d,
                                       dtype_code(x), stream_ptr(dev)), "rowblock_linear")
     return out, ws
@@ -470,6 +504,12 @@ def rowblock_linear_bwd_sums(x: Tensor, wl: Tensor, bias: Optional[Tensor], gh: 
     s2 = torch.empty(d, dtype=torch.float32, device=dev)
     nblk = int(lib().pygho_rowblock_linear_blocks(m))
     ws = torch.empty((nblk, 2, d), dtype=torch.float32, device=dev)
+    m_dev = dyn_rows(m)
+    if m_dev is not None:
+        check(lib().pygho_rowblock_linear_bwd_sums_dyn(ptr(s1), ptr(s2), ptr(x), ptr(wl.contiguous()), ptr(bias), ptr(gh.contiguous()),
+                                                       ptr(mean), ptr(invstd), ptr(w32), ptr(b32), m, ptr(m_dev), d, ACT_CODE[act], ptr(ws),
+                                                       dtype_code(x), stream_ptr(dev)), "rowblock_linear_bwd_sums_dyn")
+        return s1, s2
     check(lib().pygho_rowblock_linear_bwd_sums(ptr(s1), ptr(s2), ptr(x), ptr(wl.contiguous()), ptr(bias), ptr(gh.contiguous()), ptr(mean),
                                                ptr(invstd), ptr(w32), ptr(b32), m, d, ACT_CODE[act], ptr(ws), dtype_code(x),
                                                stream_ptr(dev)), "rowblock_linear_bwd_sums")
@@ -492,6 +532,11 @@ def bn_bwd_sums(pre: Tensor, gh: Tensor, saved, act: str):
     dev = pre.device
     s1 = torch.empty(c, dtype=torch.float32, device=dev)
     s2 = torch.empty(c, dtype=torch.float32, device=dev)
+    m_dev = dyn_rows(m)
+    if m_dev is not None:
+        check(lib().pygho_bn_act_bwd_sums_dyn(ptr(s1), ptr(s2), ptr(pre), ptr(gh), ptr(mean), ptr(invstd), ptr(w32), ptr(b32), m,
+                                              ptr(m_dev), c, ACT_CODE[act], ptr(ws), dtype_code(pre), stream_ptr(dev)), "bn_act_bwd_sums_dyn")
+        return s1, s2
     check(lib().pygho_bn_act_bwd_sums(ptr(s1), ptr(s2), ptr(pre), ptr(gh), ptr(mean), ptr(invstd), ptr(w32), ptr(b32), m, c,
                                       ACT_CODE[act], ptr(ws), dtype_code(pre), stream_ptr(dev)), "bn_act_bwd_sums")
     return s1, s2
@@ -518,10 +563,17 @@ def bn_bwd_linear(pre: Optional[Tensor], gh: Tensor, saved, training: bool, act:
         width = c * c + (2 * c if want_colsum else 0)
         ws = torch.empty((nblk, width), dtype=torch.float32, device=dev)
         cws_ptr = c_void_p(ws.data_ptr() + 4 * c * c) if want_colsum else None
-        check(lib().pygho_bn_bwd_linear_dw_recompute(ptr(gx), ptr(ws), ptr(gh), ptr(x), ptr(w.contiguous()), ptr(lin_bias), ptr(addend), cws_ptr,
-                                                     ptr(mean), ptr(invstd), ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act],
-                                                     1 if training else 0, dtype_code(x), width, stream_ptr(dev)),
-              "bn_bwd_linear_dw_recompute")
+        m_dev = dyn_rows(m)
+        if m_dev is not None:
+            check(lib().pygho_bn_bwd_linear_dw_recompute_dyn(ptr(gx), ptr(ws), ptr(gh), ptr(x), ptr(w.contiguous()), ptr(lin_bias), ptr(addend),
+                                                             cws_ptr, ptr(mean), ptr(invstd), ptr(w32), ptr(b32), ptr(s1), ptr(s2), m,
+                                                             ptr(m_dev), c, ACT_CODE[act], 1 if training else 0, dtype_code(x), width,
+                                                             stream_ptr(dev)), "bn_bwd_linear_dw_recompute_dyn")
+        else:
+            check(lib().pygho_bn_bwd_linear_dw_recompute(ptr(gx), ptr(ws), ptr(gh), ptr(x), ptr(w.contiguous()), ptr(lin_bias), ptr(addend), cws_ptr,
+                                                         ptr(mean), ptr(invstd), ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act],
+                                                         1 if training else 0, dtype_code(x), width, stream_ptr(dev)),
+                  "bn_bwd_linear_dw_recompute")
         tot = sum_blocks(ws)
         return gx, tot[:c * c].reshape(c, c), s1, s2, (tot[c * c:c * c + c] if want_colsum else None)
     m, c = pre.shape
@@ -538,11 +590,18 @@ def bn_bwd_linear(pre: Optional[Tensor], gh: Tensor, saved, training: bool, act:
         width = c * c + (2 * c if want_colsum else 0)              # dW slabs and column sums interleaved: one folding launch
         ws = torch.empty((nblk, width), dtype=torch.float32, device=dev)
         cws_ptr = c_void_p(ws.data_ptr() + 4 * c * c) if want_colsum else None
-        check(lib().pygho_bn_bwd_linear_dw(ptr(gx), ptr(ws), ptr(pre), ptr(gh), ptr(x), ptr(wl), ptr(addend), cws_ptr, ptr(mean),
-                                           ptr(invstd), ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act],
-                                           1 if training else 0, dt, width, st), "bn_bwd_linear_dw")
+        m_dev = dyn_rows(m)
+        if m_dev is not None:
+            check(lib().pygho_bn_bwd_linear_dw_dyn(ptr(gx), ptr(ws), ptr(pre), ptr(gh), ptr(x), ptr(wl), ptr(addend), cws_ptr, ptr(mean),
+                                                   ptr(invstd), ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, ptr(m_dev), c, ACT_CODE[act],
+                                                   1 if training else 0, dt, width, st), "bn_bwd_linear_dw_dyn")
+        else:
+            check(lib().pygho_bn_bwd_linear_dw(ptr(gx), ptr(ws), ptr(pre), ptr(gh), ptr(x), ptr(wl), ptr(addend), cws_ptr, ptr(mean),
+                                               ptr(invstd), ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, c, ACT_CODE[act],
+                                               1 if training else 0, dt, width, st), "bn_bwd_linear_dw")
         tot = sum_blocks(ws)
         return gx, tot[:c * c].reshape(c, c), s1, s2, (tot[c * c:c * c + c] if want_colsum else None)
+    require_static_rows(m, "the two-kernel BatchNorm backward + input-gradient GEMM (PYGHO fused weight gradient switched off)")
     cws = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev) if want_colsum else None
     second = torch.empty_like(pre)
     check(lib().pygho_bn_bwd_linear(ptr(gx), ptr(second), ptr(pre), ptr(gh), ptr(wl), ptr(addend), ptr(cws), ptr(mean), ptr(invstd),

@@ -74,15 +74,33 @@ class DeviceGraphStore:
             if not all(r.acd[k].shape[1] == 0 or np.all(np.diff(r.acd[k][0]) >= 0) for r in records):
                 continue                                         # triples not sorted by target (not from filterind): plan by sorting
             perm_c, perm_d, cnt_a, cnt_c, cnt_d = [], [], [], [], []
+            # for the fixed-capacity batch slots (`slots.BatchSlot`): graph-LOCAL CSR pointers (a batch's pointers are these plus the
+            # graph's message offset -- collated like any index array, no scan per batch), the triples' other two coordinates already
+            # in by-c / by-d order, and the edge feature each message looks up (forward and by-c order) when the second operand is A
+            ptr_a, ptr_c, ptr_d, by_c, by_d, look = [], [], [], [], [], []
+            want_look = roles[3][0] != "X" and all(np.ndim(r.edge_attr) == 1 for r in records)
+            excl = lambda cnt: (np.cumsum(cnt) - cnt).reshape(1, -1)
             for r in records:
                 a, c, dd_ = r.acd[k]
-                perm_c.append(np.argsort(c, kind="stable").reshape(1, -1))
-                perm_d.append(np.argsort(dd_, kind="stable").reshape(1, -1))
+                pc, pd = np.argsort(c, kind="stable"), np.argsort(dd_, kind="stable")
+                perm_c.append(pc.reshape(1, -1))
+                perm_d.append(pd.reshape(1, -1))
                 cnt_a.append(np.bincount(a, minlength=rows_of(r, roles[0])).reshape(1, -1))
                 cnt_c.append(np.bincount(c, minlength=rows_of(r, roles[1])).reshape(1, -1))
                 cnt_d.append(np.bincount(dd_, minlength=rows_of(r, roles[3])).reshape(1, -1))
+                ptr_a.append(excl(cnt_a[-1][0]))
+                ptr_c.append(excl(cnt_c[-1][0]))
+                ptr_d.append(excl(cnt_d[-1][0]))
+                by_c.append(np.stack((a[pc], dd_[pc])))
+                by_d.append(np.stack((a[pd], c[pd])))
+                if want_look:
+                    look.append(np.stack((r.edge_attr[dd_], r.edge_attr[dd_[pc]])))
             self.plan_parts[k] = {"perm_c": _cat32(perm_c, 1, d), "perm_d": _cat32(perm_d, 1, d), "cnt_a": _cat32(cnt_a, 1, d),
-                                  "cnt_c": _cat32(cnt_c, 1, d), "cnt_d": _cat32(cnt_d, 1, d)}
+                                  "cnt_c": _cat32(cnt_c, 1, d), "cnt_d": _cat32(cnt_d, 1, d),
+                                  "ptr_a": _cat32(ptr_a, 1, d), "ptr_c": _cat32(ptr_c, 1, d), "ptr_d": _cat32(ptr_d, 1, d),
+                                  "by_c": _cat32(by_c, 1, d), "by_d": _cat32(by_d, 1, d)}
+            if want_look:
+                self.plan_parts[k]["look"] = _cat32(look, 1, d)
         # the by-edge gradient's scatter plans (csrc/seg_scatter.hip), likewise ONCE for the whole store: the device planner over the
         # graph-local triples with one block per graph.  A batch's chunks are its graphs' chunks with the message / row offsets added
         # and its packed words are its graphs' words unchanged (they are relative to chunk windows and block edge ranges)
@@ -121,6 +139,7 @@ class DeviceGraphStore:
         if all(r.tupleid.shape[1] == 0 or np.all(np.diff(r.tupleid[0]) >= 0) for r in records):
             cnt = [np.bincount(r.tupleid[0], minlength=r.num_nodes) for r in records]
             self.root_parts = {"cnt": _cat32([c.reshape(1, -1) for c in cnt], 1, d),
+                               "ptr": _cat32([(np.cumsum(c) - c).reshape(1, -1) for c in cnt], 1, d),
                                "h_max": np.asarray([c.max() if c.size else 0 for c in cnt], dtype=np.int64)}
         # groupings of the tuples by their OTHER coordinates and of the edges by either endpoint (cross-subgraph pooling, unpooling
         # gradients, spmm): per-graph counts per node and, where the coordinate is not sorted, the stable order -- assembled per batch
@@ -130,7 +149,8 @@ class DeviceGraphStore:
                              [(("A", dim), (lambda r, dim=dim: r.edge_index[dim])) for dim in (0, 1)]:
             arrs = [rows_of(r) for r in records]
             cnt = [np.bincount(a, minlength=r.num_nodes) for a, r in zip(arrs, records)]
-            part = {"cnt": _cat32([c.reshape(1, -1) for c in cnt], 1, d), "h_max": np.asarray([c.max() if c.size else 0 for c in cnt], dtype=np.int64)}
+            part = {"cnt": _cat32([c.reshape(1, -1) for c in cnt], 1, d), "h_max": np.asarray([c.max() if c.size else 0 for c in cnt], dtype=np.int64),
+                    "ptr": _cat32([(np.cumsum(c) - c).reshape(1, -1) for c in cnt], 1, d)}
             if not all(a.size == 0 or np.all(np.diff(a) >= 0) for a in arrs):
                 part["perm"] = _cat32([np.argsort(a, kind="stable").reshape(1, -1) for a in arrs], 1, d)
             self.group_parts[name] = part

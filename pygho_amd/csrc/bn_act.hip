@@ -6,7 +6,10 @@
 // against 5 + 8 passes for ATen's batch_norm / silu / their backward kernels (BN output never materialised,
 // recomputed from x in the backward).  Channel sums are reduced without atomics: per-thread f32 partials over a
 // fixed set of channels -> per-workgroup LDS tree -> per-channel double-precision finalisation, so results are
-// run-to-run bit-identical.
+// run-to-run bit-identical.  Rows are dealt to workgroups in CONTIGUOUS chunks of 8 row groups (chunk k -> workgroup k % grid), so a
+// workgroup's partial sums depend on the rows of its chunks only -- not on how many chunks follow: a launch sized for a CAPACITY of
+// rows whose true count is read from the device (`m_dyn`, the "_dyn" entry points of pygho_hip.h) produces the same partial sums,
+// followed by zeros, as a launch sized for the true count, and the folds below add trailing zeros without changing a bit.
 #include "common.h"
 
 namespace pygho {
@@ -31,11 +34,23 @@ __device__ __forceinline__ float act_grad(float z) {      // d act(z) / dz
   return 1.f;
 }
 
+// row walk of the streaming kernels: workgroup b takes chunks b, b + grid, ... of kBnChunk row groups (a row group = the
+// rows_per_it rows one iteration of the workgroup covers); within a chunk the row groups are consecutive
+constexpr int kBnChunk = 8;                  // (a power of two)
+__device__ __forceinline__ int64_t bn_first_row(int rows_per_it, int rlane) {
+  return (int64_t)blockIdx.x * kBnChunk * rows_per_it + rlane;
+}
+__device__ __forceinline__ int64_t bn_next_row(int64_t r, int64_t& k, int rows_per_it) {      // k = row groups walked so far
+  ++k;
+  return r + rows_per_it + ((k & (kBnChunk - 1)) == 0 ? (int64_t)(gridDim.x - 1) * kBnChunk * rows_per_it : 0);
+}
+
 // ---- per-channel shifted sums: ws[blk][0][c] = sum(x - shift), ws[blk][1][c] = sum((x - shift)^2) -------------
 template <typename T>
 __global__ __launch_bounds__(kBlock) void bn_stats_partial_kernel(float* __restrict__ ws, const T* __restrict__ x,
-                                                                  int64_t m, int c, int chunks) {
+                                                                  int64_t m, int c, int chunks, const int32_t* __restrict__ m_dyn) {
   constexpr int N = Vec16<T>::N;
+  if (m_dyn) m = *m_dyn;
   __shared__ float red[2][kBlock][Vec16<T>::N];
   const int tpr = chunks;                       // threads per row (divides kBlock)
   const int rows_per_it = kBlock / tpr;
@@ -47,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void bn_stats_partial_kernel(float* __restr
 #pragma unroll
     for (int q = 0; q < N; ++q) { shift[q] = tmp[q]; s1[q] = 0.f; s2[q] = 0.f; }
   }
-  for (int64_t r = (int64_t)blockIdx.x * rows_per_it + rlane; r < m; r += (int64_t)gridDim.x * rows_per_it) {
+  for (int64_t r = bn_first_row(rows_per_it, rlane), kk = 0; r < m; r = bn_next_row(r, kk, rows_per_it)) {
     float v[N];
     Vec16<T>::unpack(*reinterpret_cast<const uint4*>(x + r * c + (int64_t)chunk * N), v);
 #pragma unroll
@@ -113,7 +128,9 @@ template <typename T>
 __global__ __launch_bounds__(kFinParts * kFinCh) void bn_stats_final_kernel(float* __restrict__ mean, float* __restrict__ var,
                                                                             const float* __restrict__ ws, const T* __restrict__ x,
                                                                             int64_t m, int c, int nblk, BnDerived dv,
-                                                                            const float* __restrict__ shiftf = nullptr) {
+                                                                            const float* __restrict__ shiftf = nullptr,
+                                                                            const int32_t* __restrict__ m_dyn = nullptr) {
+  if (m_dyn) m = *m_dyn > 0 ? *m_dyn : 1;
   double a, b;
   final_sums(a, b, ws, c, nblk, blockIdx.x * kFinCh);
   const int ch = blockIdx.x * kFinCh + threadIdx.x % kFinCh;
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void bn_act_fwd_kernel(T* __restrict__ y, c
   float sc[N], bi[N];                          // scale = invstd * w, bias = b - mean * scale
 #pragma unroll
   for (int q = 0; q < N; ++q) { sc[q] = scale[chunk * N + q]; bi[q] = bias[chunk * N + q]; }
-  for (int64_t r = (int64_t)blockIdx.x * rows_per_it + rlane; r < m; r += (int64_t)gridDim.x * rows_per_it) {
+  for (int64_t r = bn_first_row(rows_per_it, rlane), kk = 0; r < m; r = bn_next_row(r, kk, rows_per_it)) {
     float v[N];
     Vec16<T>::unpack(*reinterpret_cast<const uint4*>(x + r * c + (int64_t)chunk * N), v);
 #pragma unroll
@@ -164,8 +181,10 @@ template <typename T, int ACT>
 __global__ __launch_bounds__(kBlock) void bn_act_bwd_reduce_kernel(float* __restrict__ ws, const T* __restrict__ x,
                                                                    const T* __restrict__ gy, const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd, const float* __restrict__ w,
-                                                                   const float* __restrict__ b, int64_t m, int c, int chunks) {
+                                                                   const float* __restrict__ b, int64_t m, int c, int chunks,
+                                                                   const int32_t* __restrict__ m_dyn) {
   constexpr int N = Vec16<T>::N;
+  if (m_dyn) m = *m_dyn;
   __shared__ float red[2][kBlock][Vec16<T>::N];
   const int tpr = chunks, rows_per_it = kBlock / tpr;
   const int chunk = threadIdx.x % tpr, rlane = threadIdx.x / tpr;
@@ -175,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void bn_act_bwd_reduce_kernel(float* __rest
     mu[q] = mean[chunk * N + q]; is[q] = invstd[chunk * N + q]; ww[q] = w ? w[chunk * N + q] : 1.f; bb[q] = b ? b[chunk * N + q] : 0.f;
     s1[q] = 0.f; s2[q] = 0.f;
   }
-  for (int64_t r = (int64_t)blockIdx.x * rows_per_it + rlane; r < m; r += (int64_t)gridDim.x * rows_per_it) {
+  for (int64_t r = bn_first_row(rows_per_it, rlane), kk = 0; r < m; r = bn_next_row(r, kk, rows_per_it)) {
     float v[N], g[N];
     Vec16<T>::unpack(*reinterpret_cast<const uint4*>(x + r * c + (int64_t)chunk * N), v);
     Vec16<T>::unpack(*reinterpret_cast<const uint4*>(gy + r * c + (int64_t)chunk * N), g);
@@ -216,8 +235,10 @@ __global__ __launch_bounds__(kBlock) void bn_act_bwd_kernel(T* __restrict__ dx, 
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             const float* __restrict__ sum_dz, const float* __restrict__ sum_dz_xhat,
-                                                            float* __restrict__ colsum_ws, int64_t m, int c, int chunks, int training) {
+                                                            float* __restrict__ colsum_ws, int64_t m, int c, int chunks, int training,
+                                                            const int32_t* __restrict__ m_dyn) {
   constexpr int N = Vec16<T>::N;
+  if (m_dyn) m = *m_dyn;
   __shared__ float red[kBlock][Vec16<T>::N];
   const int tpr = chunks, rows_per_it = kBlock / tpr;
   const int chunk = threadIdx.x % tpr, rlane = threadIdx.x / tpr;
@@ -230,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void bn_act_bwd_kernel(T* __restrict__ dx, 
     k1[q] = training ? sum_dz[chunk * N + q] * inv_m : 0.f;
     k2[q] = training ? sum_dz_xhat[chunk * N + q] * inv_m : 0.f;
   }
-  for (int64_t r = (int64_t)blockIdx.x * rows_per_it + rlane; r < m; r += (int64_t)gridDim.x * rows_per_it) {
+  for (int64_t r = bn_first_row(rows_per_it, rlane), kk = 0; r < m; r = bn_next_row(r, kk, rows_per_it)) {
     float v[N], g[N];
     Vec16<T>::unpack(*reinterpret_cast<const uint4*>(x + r * c + (int64_t)chunk * N), v);
     Vec16<T>::unpack(*reinterpret_cast<const uint4*>(gy + r * c + (int64_t)chunk * N), g);
@@ -281,7 +302,7 @@ static int bn_geometry(int64_t m, int64_t c, int dtype, int* chunks, int* grid) 
   if (ch < 1 || ch > kBlock || (kBlock % ch) != 0) { set_error("bn_act: %d 16-byte chunks per row must divide %d", ch, kBlock); return PYGHO_ERR_UNSUPPORTED; }
   *chunks = ch;
   const int rows_per_it = kBlock / ch;
-  *grid = grid_for(m, rows_per_it * 8);
+  *grid = grid_for(m, rows_per_it * kBnChunk);
   return PYGHO_OK;
 }
 
@@ -317,16 +338,17 @@ extern "C" int pygho_bn_stats(float* mean, float* var, const void* x, int64_t m,
   if (int rc = bn_geometry(m, c, dtype, &chunks, &grid)) return rc;
   hipStream_t st = (hipStream_t)stream;
   PYGHO_BN_T(dtype, {
-    hipLaunchKernelGGL((bn_stats_partial_kernel<T>), dim3(grid), dim3(kBlock), 0, st, (float*)workspace, (const T*)x, m, (int)c, chunks);
+    hipLaunchKernelGGL((bn_stats_partial_kernel<T>), dim3(grid), dim3(kBlock), 0, st, (float*)workspace, (const T*)x, m, (int)c, chunks,
+                       (const int32_t*)nullptr);
     hipLaunchKernelGGL((bn_stats_final_kernel<T>), dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, st, mean, var,
                        (const float*)workspace, (const T*)x, m, (int)c, grid, BnDerived{});
   });
   return check_launch("bn_stats");
 }
 
-extern "C" int pygho_bn_prepare(float* mean, float* var, float* invstd, float* scale, float* shift, const void* x, int64_t m,
-                                int64_t c, const float* weight, const float* bias, double eps, float* running_mean,
-                                float* running_var, double momentum, void* workspace, int dtype, void* stream) {
+static int bn_prepare_entry(float* mean, float* var, float* invstd, float* scale, float* shift, const void* x, int64_t m,
+                            int64_t c, const float* weight, const float* bias, double eps, float* running_mean,
+                            float* running_var, double momentum, void* workspace, int dtype, void* stream, const int32_t* m_dyn) {
   if (c <= 0) { set_error("bn_prepare: empty input"); return PYGHO_ERR_INVALID; }
   if (!mean || !var || !invstd || !scale || !shift) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if ((running_mean == nullptr) != (running_var == nullptr)) { set_error("bn_prepare: running_mean / running_var go together"); return PYGHO_ERR_INVALID; }
@@ -341,11 +363,26 @@ extern "C" int pygho_bn_prepare(float* mean, float* var, float* invstd, float* s
   int chunks, grid;
   if (int rc = bn_geometry(m, c, dtype, &chunks, &grid)) return rc;
   PYGHO_BN_T(dtype, {
-    hipLaunchKernelGGL((bn_stats_partial_kernel<T>), dim3(grid), dim3(kBlock), 0, st, (float*)workspace, (const T*)x, m, (int)c, chunks);
+    hipLaunchKernelGGL((bn_stats_partial_kernel<T>), dim3(grid), dim3(kBlock), 0, st, (float*)workspace, (const T*)x, m, (int)c, chunks, m_dyn);
     hipLaunchKernelGGL((bn_stats_final_kernel<T>), dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, st, mean, var,
-                       (const float*)workspace, (const T*)x, m, (int)c, grid, dv);
+                       (const float*)workspace, (const T*)x, m, (int)c, grid, dv, (const float*)nullptr, m_dyn);
   });
   return check_launch("bn_prepare");
+}
+
+extern "C" int pygho_bn_prepare(float* mean, float* var, float* invstd, float* scale, float* shift, const void* x, int64_t m,
+                                int64_t c, const float* weight, const float* bias, double eps, float* running_mean,
+                                float* running_var, double momentum, void* workspace, int dtype, void* stream) {
+  return bn_prepare_entry(mean, var, invstd, scale, shift, x, m, c, weight, bias, eps, running_mean, running_var, momentum, workspace, dtype,
+                          stream, nullptr);
+}
+
+extern "C" int pygho_bn_prepare_dyn(float* mean, float* var, float* invstd, float* scale, float* shift, const void* x, int64_t m_cap,
+                                    const int32_t* m_dev, int64_t c, const float* weight, const float* bias, double eps,
+                                    float* running_mean, float* running_var, double momentum, void* workspace, int dtype, void* stream) {
+  if (!x || !m_dev) { set_error("bn_prepare_dyn: needs the input and the device-side row count"); return PYGHO_ERR_INVALID; }
+  return bn_prepare_entry(mean, var, invstd, scale, shift, x, m_cap, c, weight, bias, eps, running_mean, running_var, momentum, workspace,
+                          dtype, stream, m_dev);
 }
 
 extern "C" int pygho_bn_act_fwd(void* y, const void* x, const float* scale, const float* bias, int64_t m, int64_t c, int act,
@@ -374,9 +411,9 @@ extern "C" int pygho_bn_act_fwd_add(void* y, const void* x, const void* addend, 
   return check_launch("bn_act_fwd_add");
 }
 
-extern "C" int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
-                                const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act, int training,
-                                void* workspace, int dtype, float* sum_dx, void* stream) {
+static int bn_act_bwd_entry(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
+                            const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act, int training,
+                            void* workspace, int dtype, float* sum_dx, void* stream, const int32_t* m_dyn) {
   if (m <= 0 || c <= 0) { set_error("bn_act_bwd: empty input"); return PYGHO_ERR_INVALID; }
   if (!dx || !sum_dz || !sum_dz_xhat || !x || !gy || !mean || !invstd || !workspace) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   int chunks, grid;
@@ -384,12 +421,12 @@ extern "C" int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, con
   hipStream_t st = (hipStream_t)stream;
   PYGHO_BN_T(dtype, PYGHO_BN_ACT(act, {
     hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, A>), dim3(grid), dim3(kBlock), 0, st, (float*)workspace, (const T*)x,
-                       (const T*)gy, mean, invstd, w, b, m, (int)c, chunks);
+                       (const T*)gy, mean, invstd, w, b, m, (int)c, chunks, m_dyn);
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, st, sum_dz, sum_dz_xhat,
                        (const float*)workspace, (int)c, grid);
     hipLaunchKernelGGL((bn_act_bwd_kernel<T, A>), dim3(grid), dim3(kBlock), 0, st, (T*)dx, (const T*)x, (const T*)gy, mean, invstd,
                        w, b, (const float*)sum_dz, (const float*)sum_dz_xhat, sum_dx ? (float*)workspace : (float*)nullptr, m, (int)c,
-                       chunks, training);
+                       chunks, training, m_dyn);
     if (sum_dx)
       hipLaunchKernelGGL(bn_colsum_final_kernel, dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, st, sum_dx,
                          (const float*)workspace, (int)c, grid);
@@ -397,22 +434,52 @@ extern "C" int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, con
   return check_launch("bn_act_bwd");
 }
 
-extern "C" int pygho_bn_finalize(float* mean, float* var, float* invstd, float* scale, float* shift, const float* partial_sums,
-                                 int64_t n_blocks, const float* sum_shift, int64_t m, int64_t c, const float* weight,
-                                 const float* bias, double eps, float* running_mean, float* running_var, double momentum,
-                                 void* stream) {
+extern "C" int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
+                                const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act, int training,
+                                void* workspace, int dtype, float* sum_dx, void* stream) {
+  return bn_act_bwd_entry(dx, sum_dz, sum_dz_xhat, x, gy, mean, invstd, w, b, m, c, act, training, workspace, dtype, sum_dx, stream, nullptr);
+}
+
+extern "C" int pygho_bn_act_bwd_dyn(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
+                                    const float* invstd, const float* w, const float* b, int64_t m_cap, const int32_t* m_dev, int64_t c,
+                                    int act, int training, void* workspace, int dtype, float* sum_dx, void* stream) {
+  if (!m_dev) { set_error("bn_act_bwd_dyn: null device-side row count"); return PYGHO_ERR_INVALID; }
+  return bn_act_bwd_entry(dx, sum_dz, sum_dz_xhat, x, gy, mean, invstd, w, b, m_cap, c, act, training, workspace, dtype, sum_dx, stream, m_dev);
+}
+
+static int bn_finalize_entry(float* mean, float* var, float* invstd, float* scale, float* shift, const float* partial_sums,
+                             int64_t n_blocks, const float* sum_shift, int64_t m, int64_t c, const float* weight,
+                             const float* bias, double eps, float* running_mean, float* running_var, double momentum,
+                             void* stream, const int32_t* m_dyn) {
   if (m <= 0 || c <= 0 || n_blocks <= 0) { set_error("bn_finalize: empty input"); return PYGHO_ERR_INVALID; }
   if (!mean || !var || !invstd || !scale || !shift || !partial_sums || !sum_shift) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if ((running_mean == nullptr) != (running_var == nullptr)) { set_error("bn_finalize: running_mean / running_var go together"); return PYGHO_ERR_INVALID; }
   BnDerived dv{invstd, scale, shift, weight, bias, running_mean, running_var, eps, momentum};
   hipLaunchKernelGGL((bn_stats_final_kernel<float>), dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, (hipStream_t)stream,
-                     mean, var, partial_sums, (const float*)nullptr, m, (int)c, (int)n_blocks, dv, sum_shift);
+                     mean, var, partial_sums, (const float*)nullptr, m, (int)c, (int)n_blocks, dv, sum_shift, m_dyn);
   return check_launch("bn_finalize");
 }
 
-extern "C" int pygho_bn_act_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
-                                     const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act,
-                                     void* workspace, int dtype, void* stream) {
+extern "C" int pygho_bn_finalize(float* mean, float* var, float* invstd, float* scale, float* shift, const float* partial_sums,
+                                 int64_t n_blocks, const float* sum_shift, int64_t m, int64_t c, const float* weight,
+                                 const float* bias, double eps, float* running_mean, float* running_var, double momentum,
+                                 void* stream) {
+  return bn_finalize_entry(mean, var, invstd, scale, shift, partial_sums, n_blocks, sum_shift, m, c, weight, bias, eps, running_mean,
+                           running_var, momentum, stream, nullptr);
+}
+
+extern "C" int pygho_bn_finalize_dyn(float* mean, float* var, float* invstd, float* scale, float* shift, const float* partial_sums,
+                                     int64_t n_blocks, const float* sum_shift, int64_t m_cap, const int32_t* m_dev, int64_t c,
+                                     const float* weight, const float* bias, double eps, float* running_mean, float* running_var,
+                                     double momentum, void* stream) {
+  if (!m_dev) { set_error("bn_finalize_dyn: null device-side row count"); return PYGHO_ERR_INVALID; }
+  return bn_finalize_entry(mean, var, invstd, scale, shift, partial_sums, n_blocks, sum_shift, m_cap, c, weight, bias, eps, running_mean,
+                           running_var, momentum, stream, m_dev);
+}
+
+static int bn_act_bwd_sums_entry(float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
+                                 const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act,
+                                 void* workspace, int dtype, void* stream, const int32_t* m_dyn) {
   if (m <= 0 || c <= 0) { set_error("bn_act_bwd_sums: empty input"); return PYGHO_ERR_INVALID; }
   if (!sum_dz || !sum_dz_xhat || !x || !gy || !mean || !invstd || !workspace) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   int chunks, grid;
@@ -420,11 +487,24 @@ extern "C" int pygho_bn_act_bwd_sums(float* sum_dz, float* sum_dz_xhat, const vo
   hipStream_t st = (hipStream_t)stream;
   PYGHO_BN_T(dtype, PYGHO_BN_ACT(act, {
     hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, A>), dim3(grid), dim3(kBlock), 0, st, (float*)workspace, (const T*)x,
-                       (const T*)gy, mean, invstd, w, b, m, (int)c, chunks);
+                       (const T*)gy, mean, invstd, w, b, m, (int)c, chunks, m_dyn);
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)ceil_div(c, kFinCh)), dim3(kFinParts * kFinCh), 0, st, sum_dz, sum_dz_xhat,
                        (const float*)workspace, (int)c, grid);
   }));
   return check_launch("bn_act_bwd_sums");
+}
+
+extern "C" int pygho_bn_act_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
+                                     const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act,
+                                     void* workspace, int dtype, void* stream) {
+  return bn_act_bwd_sums_entry(sum_dz, sum_dz_xhat, x, gy, mean, invstd, w, b, m, c, act, workspace, dtype, stream, nullptr);
+}
+
+extern "C" int pygho_bn_act_bwd_sums_dyn(float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
+                                         const float* invstd, const float* w, const float* b, int64_t m_cap, const int32_t* m_dev,
+                                         int64_t c, int act, void* workspace, int dtype, void* stream) {
+  if (!m_dev) { set_error("bn_act_bwd_sums_dyn: null device-side row count"); return PYGHO_ERR_INVALID; }
+  return bn_act_bwd_sums_entry(sum_dz, sum_dz_xhat, x, gy, mean, invstd, w, b, m_cap, c, act, workspace, dtype, stream, m_dev);
 }
 
 extern "C" int pygho_bn_bwd_fold_sums(float* sum_a, float* sum_b, const float* ws, int64_t c, int64_t n_blocks, void* stream) {
@@ -458,7 +538,11 @@ __global__ __launch_bounds__(kBlock) void sum_blocks_kernel(float* __restrict__ 
 #pragma unroll
       for (int u = 0; u < U; ++u) acc[u] += in[(b + u * (kBlock / kWave)) * n + j];
     }
-    for (; b < nblk; b += kBlock / kWave) acc[0] += in[b * n + j];
+    // the rest keeps the main loop's dealing (partial sum u takes every U-th block of this wave): which partial sum a block lands in
+    // does not depend on how many blocks follow, so trailing all-zero blocks leave every bit of the result alone
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u)
+      if (b + u * (kBlock / kWave) < nblk) acc[u] += in[(b + u * (kBlock / kWave)) * n + j];
   }
 #pragma unroll
   for (int w = U / 2; w >= 1; w /= 2)                    // fixed pairwise tree: deterministic

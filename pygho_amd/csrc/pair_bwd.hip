@@ -124,7 +124,9 @@ __global__ __launch_bounds__(kBlock) void pair_bwd_kernel(T* __restrict__ g_left
   for (int item = threadIdx.x; item < kPbTypes * d; item += kBlock) {
     float a = 0.f;
     for (int gidx = 0; gidx < groups; ++gidx) a += s_tab[(size_t)gidx * kPbTypes * d + item];
-    tab_ws[(size_t)blockIdx.x * kPbTypes * d + item] = a;
+    // slab of the SWEEP position wb (= which roots this workgroup walked), not of the hardware workgroup id: the fold then adds the
+    // slabs in root order whatever the grid was, and a launch sized for more roots than there are only appends all-zero slabs
+    tab_ws[(size_t)wb * kPbTypes * d + item] = a;
   }
 }
 
@@ -163,9 +165,11 @@ extern "C" int pygho_pair_bwd_blocks(int64_t n_nodes, int64_t d, int dtype) {
     cus = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
     cus_of[dev & 15].store(cus, std::memory_order_relaxed);
   }
-  int gx = grid_for(n_nodes, kBlock >> log2g, cus * occ);
-  if (gx > 8) gx = (gx + 7) & ~7;
-  return gx;
+  // a multiple of 64 workgroups: the caller folds the slabs 64 side by side (segment.pair_bwd), and that fold must not change shape
+  // with the number of roots (workgroups without roots write zero slabs)
+  const int cap = (cus * occ) / 64 * 64;
+  int gx = grid_for(n_nodes, kBlock >> log2g, cap >= 64 ? cap : 64);
+  return (gx + 63) & ~63;
 }
 
 extern "C" int pygho_pair_bwd(void* g_left, void* g_right, float* tab_ws, const void* g, const void* left, const void* right,

@@ -230,6 +230,39 @@ __global__ void collate_rows_kernel(O* __restrict__ out, const int32_t* __restri
   }
 }
 
+// every array of a batch in ONE launch: blockIdx.y picks the descriptor, the workgroups of a row walk the output columns.  Columns past
+// the selected graphs' total (a fixed-capacity output, or the closing entry of a CSR pointer array) take the descriptor's pad value,
+// read from the device -- e.g. the batch's message total for a pointer array, so that pad rows are empty segments.
+template <typename O>
+__device__ __forceinline__ void collate_desc_cols(const pygho_collate_desc& ds, int64_t n_sel) {
+  O* out = reinterpret_cast<O*>(ds.out);
+  const int64_t total = ds.out_ptr[n_sel];
+  const int64_t pad = ds.pad ? *ds.pad : 0;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ds.out_ld; j += (int64_t)gridDim.x * blockDim.x) {
+    if (j >= total) {
+      for (int r = 0; r < ds.rows; ++r) out[ds.transposed ? j * ds.rows + r : (int64_t)r * ds.out_ld + j] = (O)pad;
+      continue;
+    }
+    int64_t lo = 0, hi = n_sel;                  // last s with out_ptr[s] <= j
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (ds.out_ptr[mid] <= j) lo = mid; else hi = mid;
+    }
+    const int64_t col = ds.src_start[lo] + (j - ds.out_ptr[lo]);
+    for (int r = 0; r < ds.rows; ++r) {
+      const int64_t* inc = r < 4 ? ds.inc[r] : nullptr;
+      const int64_t v = (int64_t)ds.src[(int64_t)r * ds.src_ld + col] + (inc ? inc[lo] : 0);
+      out[ds.transposed ? j * ds.rows + r : (int64_t)r * ds.out_ld + j] = (O)v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void collate_batch_kernel(const pygho_collate_desc* __restrict__ descs, int64_t n_sel) {
+  const pygho_collate_desc ds = descs[blockIdx.y];
+  if (ds.out_i32) collate_desc_cols<int32_t>(ds, n_sel);
+  else collate_desc_cols<int64_t>(ds, n_sel);
+}
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int key_bits(int64_t n_keys) {
@@ -567,4 +600,16 @@ extern "C" int pygho_collate_rows_i32(int32_t* out, const int32_t* src, int64_t 
     hipLaunchKernelGGL((collate_rows_kernel<int32_t, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, out, src, (int)rows, src_ld,
                        out_ld, src_start, out_ptr, inc, n_sel, total);
   return check_launch("collate_rows_i32");
+}
+
+extern "C" size_t pygho_collate_desc_bytes(void) { return sizeof(pygho_collate_desc); }
+
+extern "C" int pygho_collate_batch(const void* descs, int64_t n_desc, int64_t n_sel, int64_t max_cols, void* stream) {
+  if (n_desc < 0 || n_sel < 0 || max_cols < 0 || n_desc > 65535) { set_error("collate_batch: bad size"); return PYGHO_ERR_INVALID; }
+  if (n_desc == 0 || max_cols == 0) return PYGHO_OK;
+  if (!descs) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  int gx = grid_for(max_cols, kBlock, 4 * kMaxGrid / (int)(n_desc < 16 ? n_desc : 16));
+  hipLaunchKernelGGL(collate_batch_kernel, dim3(gx, (unsigned)n_desc), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const pygho_collate_desc*)descs, n_sel);
+  return check_launch("collate_batch");
 }

@@ -63,6 +63,7 @@ enum { RL_STORE = 0, RL_BN_ACT = 1, RL_BWD_SUMS = 2 };
 struct RlEpi {
   const float* scale; const float* shift;                                     // RL_BN_ACT
   const void* gh; const float* mean; const float* invstd; const float* w; const float* b;   // RL_BWD_SUMS (w / b nullable)
+  const int32_t* m_dyn;      // non-null: the row count is READ FROM THE DEVICE (<= the m_rows the grid was sized for), see pygho_hip.h "_dyn"
 };
 
 template <int ACT> __device__ __forceinline__ float rl_act_fwd(float z) {       // = bn_act.hip
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restric
                                                                     int self_shift, int64_t m_rows, RlEpi epi) {
   using G = RlGeom<D>;
   using V = Vec16<T>;
+  if (epi.m_dyn) m_rows = *epi.m_dyn;                      // (scalar load; the launch was sized for the capacity)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_w = smem;
   char* lds_stage = smem + G::w_bytes;
@@ -275,6 +277,7 @@ struct BnBwdArgs {
   const float* mean; const float* invstd; const float* w; const float* b;    // w / b nullable (1 / 0)
   const float* sum_dz; const float* sum_dz_xhat;
   int act; int training;
+  const int32_t* m_dyn;      // non-null: row count read from the device (see RlEpi)
 };
 
 template <typename T, int D, int ACT>
@@ -284,6 +287,7 @@ __global__ __launch_bounds__(kBlock, 2) void bn_bwd_linear_kernel(T* __restrict_
                                                                   BnBwdArgs bn, int64_t m_rows) {
   using G = RlGeom<D>;
   using V = Vec16<T>;
+  if (bn.m_dyn) m_rows = *bn.m_dyn;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_w = smem;
   char* lds_stage = smem + G::w_bytes;
@@ -521,6 +525,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
                                                                          const T* __restrict__ lin_bias = nullptr) {
   using G = RlGeom<D>;
   using V = Vec16<T>;
+  if (bn.m_dyn) m_rows = *bn.m_dyn;
   constexpr int PBW = DwGeom<D>::PBW, PBG = DwGeom<D>::PBG;   // LDS row pitch in bytes: W^T image; gpre and output tiles
   constexpr int PBX = DwGeom<D>::PBX;                    // ... of the x tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -837,9 +842,11 @@ int launch_bn_bwd_linear_dw(void* gx, const void* pre, const void* gh, const voi
 template <typename T, int D>
 __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __restrict__ g, const T* __restrict__ x,
                                                                     float* __restrict__ dw_ws, float* __restrict__ colsum_ws,
-                                                                    int64_t m_rows, int64_t ws_stride, int64_t x_ld) {
+                                                                    int64_t m_rows, int64_t ws_stride, int64_t x_ld,
+                                                                    const int32_t* __restrict__ m_dyn) {
   using G = RlGeom<D>;
   using V = Vec16<T>;
+  if (m_dyn) m_rows = *m_dyn;
   constexpr int PBG = DwGeom<D>::PBG, PBX = DwGeom<D>::PBX;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* stage_g = smem;
@@ -961,7 +968,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __r
 
 template <typename T, int D>
 int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum_ws, int64_t m, int grid, int64_t ws_stride, int64_t x_ld,
-                       hipStream_t st) {
+                       hipStream_t st, const int32_t* m_dyn) {
   const size_t lds = DwGeom<D>::tile_bytes + DwGeom<D>::xtile_bytes;
   static bool attr_set_dev[64] = {};
   bool& attr_set = per_device_flag(attr_set_dev);
@@ -970,7 +977,7 @@ int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum
     if (e != hipSuccess) { set_error("weight_grad: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((weight_grad_kernel<T, D>), dim3(grid), dim3(kDwThreads), lds, st, (const T*)g, (const T*)x, dw_ws, colsum_ws, m, ws_stride, x_ld);
+  hipLaunchKernelGGL((weight_grad_kernel<T, D>), dim3(grid), dim3(kDwThreads), lds, st, (const T*)g, (const T*)x, dw_ws, colsum_ws, m, ws_stride, x_ld, m_dyn);
   return check_launch("weight_grad");
 }
 
@@ -1001,7 +1008,7 @@ extern "C" int pygho_rowblock_linear_blocks(int64_t m) {
 }
 
 static int rowblock_entry(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws,
-                          float* shift, int self_shift, int64_t m, int64_t d, int dtype, void* stream) {
+                          float* shift, int self_shift, int64_t m, int64_t d, int dtype, void* stream, const int32_t* m_dyn = nullptr) {
   if (m < 0 || d <= 0) { set_error("rowblock_linear: bad size"); return PYGHO_ERR_INVALID; }
   if (m == 0) return PYGHO_OK;
   if ((!out && !stats_ws) || !in || !wl) { set_error("null pointer"); return PYGHO_ERR_INVALID; }      // out may be null: sums only
@@ -1011,9 +1018,11 @@ static int rowblock_entry(void* out, const void* in, const void* wl, const void*
   if (self_shift && (!stats_ws || !shift)) { set_error("rowblock_linear: the in-kernel shift needs stats_ws and a shift buffer"); return PYGHO_ERR_INVALID; }
   const int grid = pygho_rowblock_linear_blocks(m);
   hipStream_t st = (hipStream_t)stream;
+  RlEpi epi{};
+  epi.m_dyn = m_dyn;
 #define PYGHO_RL(T)                                                                                               \
-  (d == 128 ? launch_rowblock<T, 128>(out, in, wl, bias, addend, stats_ws, shift, self_shift, m, grid, st)         \
-            : launch_rowblock<T, 64>(out, in, wl, bias, addend, stats_ws, shift, self_shift, m, grid, st))
+  (d == 128 ? launch_rowblock<T, 128>(out, in, wl, bias, addend, stats_ws, shift, self_shift, m, grid, st, epi)    \
+            : launch_rowblock<T, 64>(out, in, wl, bias, addend, stats_ws, shift, self_shift, m, grid, st, epi))
   return dtype == PYGHO_BF16 ? PYGHO_RL(bf16) : PYGHO_RL(f16);
 #undef PYGHO_RL
 }
@@ -1026,6 +1035,12 @@ extern "C" int pygho_rowblock_linear(void* out, const void* in, const void* wl, 
 extern "C" int pygho_rowblock_linear_autoshift(void* out, const void* in, const void* wl, const void* bias, const void* addend,
                                                float* stats_ws, float* shift_out, int64_t m, int64_t d, int dtype, void* stream) {
   return rowblock_entry(out, in, wl, bias, addend, stats_ws, shift_out, 1, m, d, dtype, stream);
+}
+
+extern "C" int pygho_rowblock_linear_autoshift_dyn(void* out, const void* in, const void* wl, const void* bias, const void* addend,
+                                                   float* stats_ws, float* shift_out, int64_t m_cap, const int32_t* m_dev, int64_t d,
+                                                   int dtype, void* stream) {
+  return rowblock_entry(out, in, wl, bias, addend, stats_ws, shift_out, 1, m_cap, d, dtype, stream, m_dev);
 }
 
 static int rowblock_check(const char* what, const void* a, const void* b, const void* c, const void* d4, int64_t m, int64_t d, int act,
@@ -1057,17 +1072,30 @@ extern "C" int pygho_rowblock_linear_bn_act(void* out, const void* in, const voi
   return PYGHO_RL_EPI_T(RL_BN_ACT, out, in, wl, bias, addend, nullptr, nullptr, 0, m, grid, st, epi);
 }
 
-extern "C" int pygho_rowblock_linear_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* in, const void* wl, const void* bias,
-                                              const void* gh, const float* mean, const float* invstd, const float* w, const float* b,
-                                              int64_t m, int64_t d, int act, float* workspace, int dtype, void* stream) {
+static int rowblock_bwd_sums_entry(float* sum_dz, float* sum_dz_xhat, const void* in, const void* wl, const void* bias,
+                                   const void* gh, const float* mean, const float* invstd, const float* w, const float* b,
+                                   int64_t m, int64_t d, int act, float* workspace, int dtype, void* stream, const int32_t* m_dyn) {
   if (!sum_dz || !sum_dz_xhat || !in || !wl || !gh || !mean || !invstd || !workspace) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if (int rc = rowblock_check("rowblock_linear_bwd_sums", in, wl, gh, nullptr, m, d, act, dtype)) return rc;
   const int grid = pygho_rowblock_linear_blocks(m);
   hipStream_t st = (hipStream_t)stream;
   RlEpi epi{};
-  epi.gh = gh; epi.mean = mean; epi.invstd = invstd; epi.w = w; epi.b = b;
+  epi.gh = gh; epi.mean = mean; epi.invstd = invstd; epi.w = w; epi.b = b; epi.m_dyn = m_dyn;
   if (int rc = PYGHO_RL_EPI_T(RL_BWD_SUMS, nullptr, in, wl, bias, nullptr, workspace, nullptr, 0, m, grid, st, epi)) return rc;
   return pygho_bn_bwd_fold_sums(sum_dz, sum_dz_xhat, workspace, d, grid, stream);
+}
+
+extern "C" int pygho_rowblock_linear_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* in, const void* wl, const void* bias,
+                                              const void* gh, const float* mean, const float* invstd, const float* w, const float* b,
+                                              int64_t m, int64_t d, int act, float* workspace, int dtype, void* stream) {
+  return rowblock_bwd_sums_entry(sum_dz, sum_dz_xhat, in, wl, bias, gh, mean, invstd, w, b, m, d, act, workspace, dtype, stream, nullptr);
+}
+
+extern "C" int pygho_rowblock_linear_bwd_sums_dyn(float* sum_dz, float* sum_dz_xhat, const void* in, const void* wl, const void* bias,
+                                                  const void* gh, const float* mean, const float* invstd, const float* w, const float* b,
+                                                  int64_t m_cap, const int32_t* m_dev, int64_t d, int act, float* workspace, int dtype,
+                                                  void* stream) {
+  return rowblock_bwd_sums_entry(sum_dz, sum_dz_xhat, in, wl, bias, gh, mean, invstd, w, b, m_cap, d, act, workspace, dtype, stream, m_dev);
 }
 #undef PYGHO_RL_EPI_T
 #undef PYGHO_RL_EPI
@@ -1084,7 +1112,7 @@ extern "C" int pygho_bn_bwd_linear(void* gx, void* gpre, const void* pre, const 
   if ((((uintptr_t)gx | (uintptr_t)gpre | (uintptr_t)pre | (uintptr_t)gh | (uintptr_t)wl | (uintptr_t)addend) % 16) != 0) { set_error("bn_bwd_linear: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
   const int grid = pygho_rowblock_linear_blocks(m);
   hipStream_t st = (hipStream_t)stream;
-  const BnBwdArgs bn{mean, invstd, w, b, sum_dz, sum_dz_xhat, act, training};
+  const BnBwdArgs bn{mean, invstd, w, b, sum_dz, sum_dz_xhat, act, training, nullptr};
 #define PYGHO_BL(T, DD)                                                                                                  \
   (act == 0 ? launch_bn_bwd_linear<T, DD, 0>(gx, gpre, pre, gh, wl, addend, colsum_ws, bn, m, grid, st)                   \
    : act == 1 ? launch_bn_bwd_linear<T, DD, 1>(gx, gpre, pre, gh, wl, addend, colsum_ws, bn, m, grid, st)                 \
@@ -1099,10 +1127,10 @@ extern "C" int pygho_bn_bwd_linear_dw_blocks(int64_t m) {
   return grid_for(m, kDwTile, 512);          // two resident 256-thread workgroups per CU (70.6 KB of LDS each at d = 128)
 }
 
-extern "C" int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, const void* gh, const void* x, const void* wl,
-                                      const void* addend, float* colsum_ws, const float* mean, const float* invstd, const float* w,
-                                      const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m, int64_t d, int act,
-                                      int training, int dtype, int64_t ws_stride, void* stream) {
+static int bn_bwd_linear_dw_entry(void* gx, float* dw_ws, const void* pre, const void* gh, const void* x, const void* wl,
+                                  const void* addend, float* colsum_ws, const float* mean, const float* invstd, const float* w,
+                                  const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m, int64_t d, int act,
+                                  int training, int dtype, int64_t ws_stride, void* stream, const int32_t* m_dyn) {
   if (m <= 0 || d <= 0) { set_error("bn_bwd_linear_dw: empty input"); return PYGHO_ERR_INVALID; }
   if (!gx || !dw_ws || !pre || !gh || !x || !wl || !mean || !invstd || (training && (!sum_dz || !sum_dz_xhat))) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("bn_bwd_linear_dw: bf16 / f16 only"); return PYGHO_ERR_UNSUPPORTED; }
@@ -1111,7 +1139,7 @@ extern "C" int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, c
   if ((((uintptr_t)gx | (uintptr_t)pre | (uintptr_t)gh | (uintptr_t)x | (uintptr_t)wl | (uintptr_t)addend) % 16) != 0) { set_error("bn_bwd_linear_dw: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
   const int grid = pygho_bn_bwd_linear_dw_blocks(m);
   hipStream_t st = (hipStream_t)stream;
-  const BnBwdArgs bn{mean, invstd, w, b, sum_dz, sum_dz_xhat, act, training};
+  const BnBwdArgs bn{mean, invstd, w, b, sum_dz, sum_dz_xhat, act, training, m_dyn};
 #define PYGHO_BLW(T, DD)                                                                                                        \
   (act == 0 ? launch_bn_bwd_linear_dw<T, DD, 0>(gx, pre, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st)                   \
    : act == 1 ? launch_bn_bwd_linear_dw<T, DD, 1>(gx, pre, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st)                 \
@@ -1121,10 +1149,28 @@ extern "C" int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, c
 #undef PYGHO_BLW
 }
 
-extern "C" int pygho_bn_bwd_linear_dw_recompute(void* gx, float* dw_ws, const void* gh, const void* x, const void* wl, const void* bias,
-                                                const void* addend, float* colsum_ws, const float* mean, const float* invstd,
-                                                const float* w, const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m,
-                                                int64_t d, int act, int training, int dtype, int64_t ws_stride, void* stream) {
+extern "C" int pygho_bn_bwd_linear_dw(void* gx, float* dw_ws, const void* pre, const void* gh, const void* x, const void* wl,
+                                      const void* addend, float* colsum_ws, const float* mean, const float* invstd, const float* w,
+                                      const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m, int64_t d, int act,
+                                      int training, int dtype, int64_t ws_stride, void* stream) {
+  return bn_bwd_linear_dw_entry(gx, dw_ws, pre, gh, x, wl, addend, colsum_ws, mean, invstd, w, b, sum_dz, sum_dz_xhat, m, d, act, training,
+                                dtype, ws_stride, stream, nullptr);
+}
+
+extern "C" int pygho_bn_bwd_linear_dw_dyn(void* gx, float* dw_ws, const void* pre, const void* gh, const void* x, const void* wl,
+                                          const void* addend, float* colsum_ws, const float* mean, const float* invstd, const float* w,
+                                          const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m_cap,
+                                          const int32_t* m_dev, int64_t d, int act, int training, int dtype, int64_t ws_stride,
+                                          void* stream) {
+  return bn_bwd_linear_dw_entry(gx, dw_ws, pre, gh, x, wl, addend, colsum_ws, mean, invstd, w, b, sum_dz, sum_dz_xhat, m_cap, d, act,
+                                training, dtype, ws_stride, stream, m_dev);
+}
+
+static int bn_bwd_linear_dw_recompute_entry(void* gx, float* dw_ws, const void* gh, const void* x, const void* wl, const void* bias,
+                                            const void* addend, float* colsum_ws, const float* mean, const float* invstd,
+                                            const float* w, const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m,
+                                            int64_t d, int act, int training, int dtype, int64_t ws_stride, void* stream,
+                                            const int32_t* m_dyn) {
   if (m <= 0 || d <= 0) { set_error("bn_bwd_linear_dw_recompute: empty input"); return PYGHO_ERR_INVALID; }
   if (!gx || !dw_ws || !gh || !x || !wl || !mean || !invstd || (training && (!sum_dz || !sum_dz_xhat))) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("bn_bwd_linear_dw_recompute: bf16 / f16 only"); return PYGHO_ERR_UNSUPPORTED; }
@@ -1133,7 +1179,7 @@ extern "C" int pygho_bn_bwd_linear_dw_recompute(void* gx, float* dw_ws, const vo
   if ((((uintptr_t)gx | (uintptr_t)gh | (uintptr_t)x | (uintptr_t)wl | (uintptr_t)addend) % 16) != 0) { set_error("bn_bwd_linear_dw_recompute: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
   const int grid = pygho_bn_bwd_linear_dw_blocks(m);
   hipStream_t st = (hipStream_t)stream;
-  const BnBwdArgs bn{mean, invstd, w, b, sum_dz, sum_dz_xhat, act, training};
+  const BnBwdArgs bn{mean, invstd, w, b, sum_dz, sum_dz_xhat, act, training, m_dyn};
 #define PYGHO_BLR(T, DD)                                                                                                                \
   (act == 0 ? launch_bn_bwd_linear_dw<T, DD, 0, true>(gx, nullptr, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st, bias)   \
    : act == 1 ? launch_bn_bwd_linear_dw<T, DD, 1, true>(gx, nullptr, gh, x, wl, addend, colsum_ws, dw_ws, bn, m, grid, ws_stride, st, bias) \
@@ -1143,8 +1189,25 @@ extern "C" int pygho_bn_bwd_linear_dw_recompute(void* gx, float* dw_ws, const vo
 #undef PYGHO_BLR
 }
 
-extern "C" int pygho_weight_grad(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t x_ld, int64_t m, int64_t d,
-                                 int dtype, int64_t ws_stride, void* stream) {
+extern "C" int pygho_bn_bwd_linear_dw_recompute(void* gx, float* dw_ws, const void* gh, const void* x, const void* wl, const void* bias,
+                                                const void* addend, float* colsum_ws, const float* mean, const float* invstd,
+                                                const float* w, const float* b, const float* sum_dz, const float* sum_dz_xhat, int64_t m,
+                                                int64_t d, int act, int training, int dtype, int64_t ws_stride, void* stream) {
+  return bn_bwd_linear_dw_recompute_entry(gx, dw_ws, gh, x, wl, bias, addend, colsum_ws, mean, invstd, w, b, sum_dz, sum_dz_xhat, m, d, act,
+                                          training, dtype, ws_stride, stream, nullptr);
+}
+
+extern "C" int pygho_bn_bwd_linear_dw_recompute_dyn(void* gx, float* dw_ws, const void* gh, const void* x, const void* wl, const void* bias,
+                                                    const void* addend, float* colsum_ws, const float* mean, const float* invstd,
+                                                    const float* w, const float* b, const float* sum_dz, const float* sum_dz_xhat,
+                                                    int64_t m_cap, const int32_t* m_dev, int64_t d, int act, int training, int dtype,
+                                                    int64_t ws_stride, void* stream) {
+  return bn_bwd_linear_dw_recompute_entry(gx, dw_ws, gh, x, wl, bias, addend, colsum_ws, mean, invstd, w, b, sum_dz, sum_dz_xhat, m_cap, d,
+                                          act, training, dtype, ws_stride, stream, m_dev);
+}
+
+static int weight_grad_entry(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t x_ld, int64_t m, int64_t d,
+                             int dtype, int64_t ws_stride, void* stream, const int32_t* m_dyn) {
   if (m <= 0 || d <= 0) { set_error("weight_grad: empty input"); return PYGHO_ERR_INVALID; }
   if (!dw_ws || !g || !x) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("weight_grad: bf16 / f16 only"); return PYGHO_ERR_UNSUPPORTED; }
@@ -1153,8 +1216,18 @@ extern "C" int pygho_weight_grad(float* dw_ws, float* colsum_ws, const void* g, 
   const int grid = pygho_bn_bwd_linear_dw_blocks(m);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == PYGHO_BF16)
-    return d == 128 ? launch_weight_grad<bf16, 128>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st)
-                    : launch_weight_grad<bf16, 64>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st);
-  return d == 128 ? launch_weight_grad<f16, 128>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st)
-                  : launch_weight_grad<f16, 64>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st);
+    return d == 128 ? launch_weight_grad<bf16, 128>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st, m_dyn)
+                    : launch_weight_grad<bf16, 64>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st, m_dyn);
+  return d == 128 ? launch_weight_grad<f16, 128>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st, m_dyn)
+                  : launch_weight_grad<f16, 64>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st, m_dyn);
+}
+
+extern "C" int pygho_weight_grad(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t x_ld, int64_t m, int64_t d,
+                                 int dtype, int64_t ws_stride, void* stream) {
+  return weight_grad_entry(dw_ws, colsum_ws, g, x, x_ld, m, d, dtype, ws_stride, stream, nullptr);
+}
+
+extern "C" int pygho_weight_grad_dyn(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t x_ld, int64_t m_cap,
+                                     const int32_t* m_dev, int64_t d, int dtype, int64_t ws_stride, void* stream) {
+  return weight_grad_entry(dw_ws, colsum_ws, g, x, x_ld, m_cap, d, dtype, ws_stride, stream, m_dev);
 }

@@ -33,14 +33,16 @@ __device__ __forceinline__ void tg_add(float* p, float v) { *p += v; }
 template <typename T>
 __global__ __launch_bounds__(kBlock) void table_grad_kernel(float* __restrict__ ws, const T* __restrict__ g,
                                                             const int32_t* __restrict__ idx, int64_t m, int d, int n_table,
-                                                            int lanes, int64_t rows_per_block, int32_t* __restrict__ err) {
+                                                            int lanes, int64_t rows_per_block, int32_t* __restrict__ err,
+                                                            const int32_t* __restrict__ m_dyn) {
+  if (m_dyn) m = *m_dyn;               // row count read from the device: the launch (and rows_per_block) was sized for a capacity
   extern __shared__ float bins[];      // [lanes][n_table][d]
   const int t = threadIdx.x;
   const int width = n_table * d;
   for (int j = t; j < lanes * width; j += kBlock) bins[j] = 0.f;
   __syncthreads();
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = r0 + rows_per_block < m ? r0 + rows_per_block : m;
+  const int64_t r1 = r0 + rows_per_block < m ? r0 + rows_per_block : (m > r0 ? m : r0);
   const int rl = d <= kBlock ? t / d : 0;              // my row lane
   const int c0 = d <= kBlock ? t - rl * d : t;         // my (first) column
   if (rl < lanes) {
@@ -107,14 +109,16 @@ template <> struct TgPair<f16> {
 template <typename T, int NT, int CP>
 __global__ __launch_bounds__(kBlock) void table_grad_reg_kernel(float* __restrict__ ws, const T* __restrict__ g,
                                                                 const int32_t* __restrict__ idx, int64_t m, int d, int n_table,
-                                                                int64_t rows_per_wave, int32_t* __restrict__ err) {
+                                                                int64_t rows_per_wave, int32_t* __restrict__ err,
+                                                                const int32_t* __restrict__ m_dyn) {
   using P = TgPair<T>;
   constexpr int U = PYGHO_TG_UNROLL;
   const int lane = threadIdx.x & 63;
   const int64_t slab = (int64_t)blockIdx.x * (kBlock / kWave) + PYGHO_WAVE_INDEX((int)(threadIdx.x >> 6));
   const int64_t r0 = slab * rows_per_wave;
-  if (r0 >= m) return;
-  const int64_t r1 = r0 + rows_per_wave < m ? r0 + rows_per_wave : m;
+  if (m_dyn == nullptr && r0 >= m) return;               // (static count: the host zeroes the slabs past the last row)
+  if (m_dyn) m = *m_dyn;                                 // device count: a slab past the last row is written as zeros below
+  const int64_t r1 = r0 + rows_per_wave < m ? r0 + rows_per_wave : (m > r0 ? m : r0);
   float acc[NT][CP][2];
 #pragma unroll
   for (int i = 0; i < NT; ++i)
@@ -197,8 +201,8 @@ extern "C" int pygho_table_grad_blocks(int64_t m, int64_t d, int64_t n_table) {
   return (int)b;
 }
 
-extern "C" int pygho_table_grad(float* ws, const void* g, const int32_t* idx, int64_t m, int64_t d, int64_t n_table, int dtype,
-                                int32_t* err, void* stream) {
+static int table_grad_entry(float* ws, const void* g, const int32_t* idx, int64_t m, int64_t d, int64_t n_table, int dtype,
+                            int32_t* err, void* stream, const int32_t* m_dyn) {
   if (m < 0 || !pygho_table_grad_supported(d, n_table) || (m > 0 && (ws == nullptr || g == nullptr || idx == nullptr))) {
     set_error("pygho_table_grad: bad arguments (m %lld, d %lld, n_table %lld)", (long long)m, (long long)d, (long long)n_table);
     return PYGHO_ERR_INVALID;
@@ -210,12 +214,12 @@ extern "C" int pygho_table_grad(float* ws, const void* g, const int32_t* idx, in
     // slabs past the last row are never written: the caller folds only ceil(m / rows_per_wave) of them?  No -- keep it simple:
     // they are written by nobody, so zero them here (a few KB)
     const int64_t used = ceil_div(m > 0 ? m : 1, rpw);
-    if (used < slabs)
+    if (used < slabs && m_dyn == nullptr)
       (void)hipMemsetAsync(ws + (size_t)used * n_table * d, 0, (size_t)(slabs - used) * n_table * d * sizeof(float), st);
-    if (m == 0) { (void)hipMemsetAsync(ws, 0, (size_t)n_table * d * sizeof(float), st); return check_launch("pygho_table_grad"); }
+    if (m == 0 && m_dyn == nullptr) { (void)hipMemsetAsync(ws, 0, (size_t)n_table * d * sizeof(float), st); return check_launch("pygho_table_grad"); }
     const dim3 grid(slabs / (kBlock / kWave));
 #define PYGHO_TGR(T, NT, CP) \
-    hipLaunchKernelGGL((table_grad_reg_kernel<T, NT, CP>), grid, dim3(kBlock), 0, st, ws, (const T*)g, idx, m, (int)d, (int)n_table, rpw, err)
+    hipLaunchKernelGGL((table_grad_reg_kernel<T, NT, CP>), grid, dim3(kBlock), 0, st, ws, (const T*)g, idx, m, (int)d, (int)n_table, rpw, err, m_dyn)
 #define PYGHO_TGR_T(T)                                                                        \
     do {                                                                                      \
       if (n_table <= 16) { if (d <= 128) PYGHO_TGR(T, 16, 1); else PYGHO_TGR(T, 16, 2); }     \
@@ -246,7 +250,7 @@ extern "C" int pygho_table_grad(float* ws, const void* g, const int32_t* idx, in
       done = true;                                                                                                            \
     }                                                                                                                         \
     hipLaunchKernelGGL(table_grad_kernel<T>, dim3(nblk), dim3(kBlock), lds, st, ws, (const T*)g, idx, m, (int)d,              \
-                       (int)n_table, lanes, rpb, err);                                                                        \
+                       (int)n_table, lanes, rpb, err, m_dyn);                                                                 \
   } while (0)
   switch (dtype) {
     case PYGHO_F32: PYGHO_TG(float); break;
@@ -258,4 +262,15 @@ extern "C" int pygho_table_grad(float* ws, const void* g, const int32_t* idx, in
   }
 #undef PYGHO_TG
   return check_launch("pygho_table_grad");
+}
+
+extern "C" int pygho_table_grad(float* ws, const void* g, const int32_t* idx, int64_t m, int64_t d, int64_t n_table, int dtype,
+                                int32_t* err, void* stream) {
+  return table_grad_entry(ws, g, idx, m, d, n_table, dtype, err, stream, nullptr);
+}
+
+extern "C" int pygho_table_grad_dyn(float* ws, const void* g, const int32_t* idx, int64_t m_cap, const int32_t* m_dev, int64_t d,
+                                    int64_t n_table, int dtype, int32_t* err, void* stream) {
+  if (m_cap <= 0 || !m_dev) { set_error("pygho_table_grad_dyn: needs a positive capacity and the device-side row count"); return PYGHO_ERR_INVALID; }
+  return table_grad_entry(ws, g, idx, m_cap, d, n_table, dtype, err, stream, m_dev);
 }

@@ -9,8 +9,8 @@ through the C ABI and no entry point synchronises or allocates, so a step on sta
 * the same tensors (batch, indices, targets) are reused across replays.  New FEATURE / TARGET values may be copied into them;
   the INDEX PATTERN must stay what it was at capture: the graph bakes in the plans built from the index tensors during warm-up
   (CSR pointers, permutations, grid sizes, output row counts).  Pass the index tensors as ``static_indices`` and ``replay()``
-  raises if one of them was written to since capture; a new batch pattern needs a new capture (or the eager
-  ``collate.BatchPrefetcher`` path);
+  raises if one of them was written to since capture.  A NEW batch every step -- the reference's loop, example/minimal.py:141-149 --
+  is served by ``SlotStep`` below: one capture over a fixed-capacity ``slots.BatchSlot`` whose sizes are read on the device;
 * the plans are built before capture (the warm-up steps below do that: plan construction reads sizes back to the host);
 * the optimizer is created with ``capturable=True``; gradients are reset with ``set_to_none=True`` inside the step;
 * no host read-back (``.item()``, ``print(loss)``) inside the step -- return tensors and read them after ``replay()``.
@@ -67,3 +67,71 @@ class GraphedStep:
         from . import _ops
         _ops.invalidate_cast_arenas()      # a captured optimizer step moved the parameters without moving their version counters
         return self.output
+
+
+class SlotStep:
+    """ONE captured training step that serves every mini-batch of ``batch_graphs`` graphs drawn from a ``DeviceGraphStore``
+    (the reference's loop: a fresh shuffled batch per step, example/minimal.py:119, :141-149).
+
+    ``step_fn(datadict)`` is the whole step -- zero_grad(set_to_none=True), forward, loss, backward, optimizer step (capturable) --
+    and returns the tensors to read afterwards (e.g. the loss).  It is warmed up on the slot, then captured together with the
+    slot's collate kernel; ``run(graph_ids)`` uploads the batch's offsets (one small asynchronous copy) and replays the graph.  A
+    batch that does not fit the slot's capacities (or has another number of graphs) runs ``step_fn`` eagerly on
+    ``store.collate(graph_ids)`` instead (counted in ``eager_steps``): same model, same optimizer, same result semantics.
+
+    The captured step and an eager step on the SAME slot contents compute bit-identical results; against an eager step on the
+    exactly sized batch the results are bit-identical as well wherever a reduction's partition does not depend on the row count
+    (all BatchNorm / weight-gradient / embedding-gradient folds are written that way; ``tests/test_gpu_slots.py`` pins it)."""
+
+    def __init__(self, store, batch_graphs: int, step_fn: Callable[[dict], Any], warmup_ids=None, warmup: int = 3,
+                 capacities=None, capacity_sigmas: float = 4.5):
+        from . import _ops
+        from .slots import BatchSlot
+        assert torch.cuda.is_available(), "HIP graph capture needs the ROCm device"
+        self.store, self.step_fn = store, step_fn
+        self.slot = BatchSlot(store, batch_graphs, capacities, capacity_sigmas)
+        self.eager_steps = self.replays = 0
+        if warmup_ids is None:
+            warmup_ids = self._first_fitting()
+        slot, dd = self.slot, self.slot.datadict
+        if not slot.upload(warmup_ids):
+            raise ValueError("SlotStep: the warm-up batch does not fit the slot")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), slot.rows():
+            slot.launch()
+            slot.reset_caches()
+            for _ in range(warmup):
+                step_fn(dd)
+        torch.cuda.current_stream().wait_stream(side)
+        # what the warm-up derived from the slot's arrays (narrowed copies, lookups, reciprocal counts ...) is dropped: the captured
+        # step derives it again INSIDE the graph, so every replay derives it for the batch that is in the slot
+        slot.reset_caches()
+        self.graph = torch.cuda.CUDAGraph()
+        with slot.rows(), torch.cuda.graph(self.graph):
+            slot.launch()
+            self.output = step_fn(dd)
+        _ops.invalidate_cast_arenas()
+
+    def _first_fitting(self):
+        import numpy as np
+        rng = np.random.default_rng(0)
+        for _ in range(64):
+            ids = rng.permutation(self.store.num_graphs)[:self.slot.g]
+            if ids.shape[0] == self.slot.g and self.slot.fits(ids):
+                return ids
+        raise ValueError("SlotStep: no random batch of the store fits the slot's capacities")
+
+    def run(self, graph_ids) -> Any:
+        """one training step on the batch `graph_ids`; returns step_fn's outputs (the captured call's static tensors, or the
+        eager call's own)"""
+        from . import _ops
+        slot = self.slot
+        n = len(graph_ids)
+        if n == slot.g and slot.upload(graph_ids):
+            self.graph.replay()
+            self.replays += 1
+            _ops.invalidate_cast_arenas()          # the captured optimizer step moved the parameters behind their version counters
+            return self.output
+        self.eager_steps += 1
+        return self.step_fn(self.store.collate(graph_ids))

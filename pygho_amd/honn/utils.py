@@ -100,10 +100,13 @@ class _ArenaLinearFn(torch.autograd.Function):
                 gw, gb = _ops.weight_grad_splitk(g, x, w_dtype, want_colsum=True, any_height=True)
                 gb = gb.to(b_dtype) if want_b else None
             elif want_b:
+                _ops.require_static_rows(x.shape[0], "the bias gradient of a Linear whose weight needs no gradient")
                 gb = g.sum(0, dtype=b_dtype)
             return gx, gw, gb, None
         gx = g @ w if ctx.needs_input_grad[0] else None
         gw = gb = None
+        if ctx.needs_input_grad[1] or want_b:
+            _ops.require_static_rows(x.shape[0], "the library-GEMM backward of a Linear (not a square 16-bit map of width 64 / 128)")
         if ctx.needs_input_grad[1]:
             if x.shape[0] < 8192:
                 gw = _small_weight_grad(g, x, w_dtype)

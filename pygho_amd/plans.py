@@ -24,6 +24,48 @@ def _flag(dev) -> Tensor:
     return torch.zeros(1, dtype=_I32, device=dev)
 
 
+# --------------------------------------------------------------------------
+# row families: row counts that live on the device (fixed-capacity batch slots, `collate.BatchSlot` / `graphs.SlotStep`)
+# --------------------------------------------------------------------------
+# A HIP graph captured once serves every mini-batch when its tensors have a fixed CAPACITY of rows per family (nodes, edges, tuples,
+# messages of a key) and the kernels that reduce over rows read the TRUE count from the device (the "_dyn" entry points of
+# include/pygho_hip.h).  Inside `with row_families({capacity: count}):` a launch wrapper that is handed `capacity` rows passes the
+# family's device-side count along; capacities are made pairwise distinct (and distinct from the batch's graph count) by the slot,
+# so the extent of dim 0 names the family.  Rows past the count hold don't-care values: row-wise kernels compute them, nothing
+# that sums over rows reads them.
+_ROW_FAMILIES = {}      # capacity (int) -> one-element int32 device tensor with the true row count
+
+
+class row_families:
+    def __init__(self, families):
+        self.families = dict(families)
+
+    def __enter__(self):
+        self.prev = dict(_ROW_FAMILIES)
+        for cap, cnt in self.families.items():
+            assert cnt.dtype == _I32 and cnt.numel() >= 1 and cnt.is_cuda
+            _ROW_FAMILIES[int(cap)] = cnt
+        return self
+
+    def __exit__(self, *exc):
+        _ROW_FAMILIES.clear()
+        _ROW_FAMILIES.update(self.prev)
+        return False
+
+
+def dyn_rows(m: int) -> Optional[Tensor]:
+    """the device-side row count behind a dim-0 extent of `m` (None: `m` is the true count)"""
+    return _ROW_FAMILIES.get(m) if _ROW_FAMILIES else None
+
+
+def require_static_rows(m: int, what: str) -> None:
+    """a path that sums over rows WITHOUT a device-count form was reached with a capacity-sized tensor: fail loudly (the pad rows
+    would enter the sum)"""
+    if _ROW_FAMILIES and m in _ROW_FAMILIES:
+        raise RuntimeError(f"pygho_amd: {what} has no device-side row-count form, but its input has the capacity ({m} rows) of a "
+                           "batch slot's row family; run this step eagerly on `DeviceGraphStore.collate` batches instead")
+
+
 def narrow_i32(x: Tensor, checked: bool = False) -> Tensor:
     """int64 -> int32 copy on the device (cached on the source tensor object)."""
     if x.dtype == _I32:
@@ -73,20 +115,24 @@ class SegPlan:
     """CSR grouping of `m` messages into `n_seg` segments: ``seg_ptr`` (n_seg+1) int32 and
     ``perm`` (m) int32 = message ids in grouped order (None when the key array was already
     sorted, i.e. grouped order == message order)."""
-    __slots__ = ("seg_ptr", "perm", "n_seg", "m", "_inv_cnt", "_memo", "_partner")
+    __slots__ = ("seg_ptr", "perm", "n_seg", "m", "_inv_cnt", "_memo", "_partner", "volatile")
 
     def __init__(self, seg_ptr: Tensor, perm: Optional[Tensor], n_seg: int, m: int):
         self.seg_ptr, self.perm, self.n_seg, self.m = seg_ptr, perm, n_seg, m
         self._inv_cnt = None
         self._memo = None
         self._partner = None         # (key, index arrays in grouped order) of the last three-operand user
+        self.volatile = False        # the arrays are REWRITTEN IN PLACE per batch (a batch slot): nothing derived from them is kept
 
     @property
     def inv_count(self) -> Tensor:
         """1 / max(segment length, 1) as f32 (mean backward)."""
-        if self._inv_cnt is None:
+        if self._inv_cnt is None or self.volatile:
             cnt = (self.seg_ptr[1:] - self.seg_ptr[:-1]).clamp_min(1)
-            self._inv_cnt = cnt.to(torch.float32).reciprocal()
+            inv = cnt.to(torch.float32).reciprocal()
+            if self.volatile:
+                return inv
+            self._inv_cnt = inv
         return self._inv_cnt
 
     def take(self, idx32: Tensor) -> Tensor:

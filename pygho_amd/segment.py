@@ -414,6 +414,27 @@ class MessagePlan:
         self._lookup = None
         return self
 
+    @classmethod
+    def from_arrays(cls, acd: Tensor, n_out: int, n_lhs: int, n_rhs: int, acd32: Tensor, fwd_ptr: Tensor, ptr_c: Tensor, perm_c: Tensor,
+                    by_c: Tensor, ptr_d: Tensor, perm_d: Tensor, by_d: Tensor) -> "MessagePlan":
+        """the plan over arrays that are ALL given and rewritten in place per batch (`slots.BatchSlot`): `acd32` (3, M) the narrowed
+        triples, `by_c` (2, M) = (a, d) in by-c order, `by_d` (2, M) = (a, c) in by-d order.  Nothing is computed or cached here."""
+        self = cls.__new__(cls)
+        self.m = acd.shape[1]
+        self.n_out, self.n_lhs, self.n_rhs = n_out, n_lhs, n_rhs
+        self._a64, self._c64, self._d64 = unbased(acd[0]), unbased(acd[1]), unbased(acd[2])
+        self.fwd = SegPlan(fwd_ptr, None, n_out, self.m)
+        self.a32, self.c32, self.d32 = acd32[0], acd32[1], acd32[2]
+        self.c_fwd, self.d_fwd = self.c32, self.d32
+        pc, pd = SegPlan(ptr_c, perm_c, n_lhs, self.m), SegPlan(ptr_d, perm_d, n_rhs, self.m)
+        for p in (self.fwd, pc, pd):
+            p.volatile = True
+        self._by_c = (pc, by_c[0], by_c[1])
+        self._by_d = (pd, by_d[0], by_d[1])
+        self._lookup = None
+        self._scatter = False               # the by-edge gradient of a slot runs the gather form (its chunk list has no fixed length)
+        return self
+
     def by_c(self):
         """(plan, a-in-grouped-order, d-in-grouped-order) for the gradient wrt the first operand."""
         if self._by_c is None:
@@ -758,27 +779,23 @@ def table_grad_ok(g2: Tensor, n_table: int) -> bool:
 
 
 # The plan-free kernel is VALU-bound (n_table selects + adds per value: 60 us for 410 k rows of 256 B against 39 us for the planned
-# hierarchy), so a LARGE pattern that keeps coming back (a resident batch) is planned after a few uses, like the by-edge scatter
-# plans; small batches (launch-bound) and fresh batches (one use) never pay for a sort and its host reads.
+# hierarchy), but the planned route needs a radix sort and two host reads per index pattern and sums in another order.  Which route
+# runs is a pure function of the call (shapes, and whether the CALLER installed / built a plan for the index array): round 4 switched
+# a recurring large pattern to the planned route "after 3 uses", which made the bits of an embedding gradient depend on how often a
+# batch had been seen -- step 3 and step 4 of a resident-batch run differed, and a resumed run diverged bitwise from a continuous one.
 TABLE_GRAD_PLAN_ROWS = int(os.environ.get("PYGHO_TABLE_GRAD_PLAN_ROWS", str(1 << 16)))
-TABLE_GRAD_PLAN_AFTER = int(os.environ.get("PYGHO_TABLE_GRAD_PLAN_AFTER", "3"))
 
 
 def _table_grad_now(g2: Tensor, ind: Tensor, n_table: int) -> bool:
     if not table_grad_ok(g2, n_table):
+        require_static_rows(g2.shape[0], "the sorted-segment gradient of a row gather (tables of more than 64 rows)")
         return False
+    if dyn_rows(g2.shape[0]) is not None:
+        return True                                            # a batch slot's rows: the count is on the device, no plan can exist
     cache = getattr(ind, "_pygho_plans", None)
     if cache is not None and ("scatter", n_table, ind._version) in cache:
-        return g2.shape[0] < TABLE_GRAD_PLAN_ROWS          # a plan exists (someone built or installed it): use it where it is faster
-    if g2.shape[0] < TABLE_GRAD_PLAN_ROWS or torch.cuda.is_current_stream_capturing():
-        return True
-    uses = getattr(ind, "_pygho_table_uses", (ind._version, 0))
-    uses = (ind._version, (uses[1] if uses[0] == ind._version else 0) + 1)
-    try:
-        ind._pygho_table_uses = uses
-    except Exception:
-        return True
-    return uses[1] <= TABLE_GRAD_PLAN_AFTER
+        return g2.shape[0] < TABLE_GRAD_PLAN_ROWS          # a plan exists (the caller built or installed it): use it where it is faster
+    return True
 
 
 def table_grad(g2: Tensor, ind: Tensor, n_table: int) -> Tensor:
@@ -800,7 +817,12 @@ def table_grad(g2: Tensor, ind: Tensor, n_table: int) -> Tensor:
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(dev))
-    check(lib().pygho_table_grad(ptr(ws), ptr(g2), ptr(ind32), m, d, n_table, dtype_code(g2), ptr(err), stream_ptr(dev)), "table_grad")
+    m_dev = dyn_rows(m)
+    if m_dev is not None:
+        check(lib().pygho_table_grad_dyn(ptr(ws), ptr(g2), ptr(ind32), m, ptr(m_dev), d, n_table, dtype_code(g2), ptr(err), stream_ptr(dev)),
+              "table_grad_dyn")
+    else:
+        check(lib().pygho_table_grad(ptr(ws), ptr(g2), ptr(ind32), m, d, n_table, dtype_code(g2), ptr(err), stream_ptr(dev)), "table_grad")
     if timer is not None:
         e1.record(torch.cuda.current_stream(dev))
         timer.records.append((f"table_grad[{str(g2.dtype).split('.')[-1]}]", g2.element_size() * m * d + 4 * m + 4 * ws.numel(), e0, e1))
