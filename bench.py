@@ -8,16 +8,18 @@ roofline" on config[1] "NGNNConv 2-tuple sparse spspmm on ZINC, hidden=128 bf16,
         bench.py --gpus N --steps K --warmup W
 
 A step = one full training step (forward, backward, gradient all-reduce when N > 1, AdamW) of the 6-layer NGNN
-of example/minimal.py (hidden 128, bf16 activations / f32 master weights) over one synthetic ZINC-shape batch
-that is already resident in HBM.  Every rank owns its own batch of --graphs graphs (weak scaling, graphs shard
-with no data-path collective); value = graphs of all ranks / max-over-ranks time.  The batch's index plans (int32 / CSR
-views and transposed groupings of its index tensors, cached on them) are part of the resident input, like the reference's
-precomputed ___acd triples.
+of example/minimal.py (hidden 128, bf16 activations / f32 master weights) over a NEW shuffled synthetic ZINC-shape batch
+EVERY step -- the reference's loop, example/minimal.py:141-149.  The dataset (--store-graphs, default 16384 distinct graphs
+per rank) is resident in HBM as a graph-local int32 store; a step's batch is collated on the device together with every
+index plan (int32 / CSR views, transposed groupings, scatter plans), one batch ahead on a side stream, so the step's inputs
+are resident when it starts and nothing crosses PCIe.  Every rank draws its own stream of --graphs graphs per step (weak
+scaling, graphs shard with no data-path collective); value = graphs of all ranks over all timed steps / max-over-ranks time.
+`--resident-batch` times ONE resident batch instead (the headline of rounds 1-4; also `regimes.resident_ms_per_step`).
 
-`regimes` (N == 1): the same step with a NEW batch every step (collated on the device from a resident graph store together with
-every index plan, one batch ahead on a side stream: `fresh_batch_ms_per_step`), and the launch-bound sizes 128 / 1024 graphs --
-eager on a resident batch, eager on a fresh shuffled batch every step (`eager_fresh_batch_ms_per_step`, what a training loop with the
-reference's batch size does), and the whole step captured into a HIP graph.
+`regimes` (N == 1): the resident-batch step, and the launch-bound sizes 128 / 1024 graphs -- eager on a resident batch, eager on
+a fresh shuffled batch every step (`eager_fresh_batch_ms_per_step`), one resident batch captured into a HIP graph, and ONE
+captured step over a fixed-capacity batch slot that serves a different shuffled batch every step
+(`captured_fresh_batch_ms_per_step`, pygho_amd.graphs.SlotStep).
 
 `configs` (N == 1): the other measured configurations of BASELINE.json in the same line -- config 5 (I2-shape 3-tuple spspmm
 launch, d = 256 bf16, and an I2Conv layer step), config 3 (mamamm X A / X Y at (1024, 37, 37, 128) bf16 and a SUNConv DD layer step)
@@ -56,8 +58,13 @@ def parse():
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--distinct", type=int, default=8192,
-                    help="distinct graphs generated per rank (tiled up to --graphs when smaller; the default generates every graph of the batch)")
+    ap.add_argument("--store-graphs", type=int, default=0,
+                    help="graphs in the rank's device-resident store the batches are drawn from (0: twice the graphs drawn per step, i.e. "
+                         "16384 at the default batch size)")
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="distinct graphs generated for the store (0: every graph of the store is distinct; fewer are tiled)")
+    ap.add_argument("--resident-batch", action="store_true",
+                    help="time ONE resident batch every step (rounds 1-4's headline; profiling and A/B runs) instead of a new batch per step")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "foreach"], help="AdamW implementation (same update rule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-regimes", action="store_true", help="skip the fresh-batch / small-batch side measurements")
@@ -214,35 +221,30 @@ def side_regimes(args, dev):
             return loss.detach()
         return step
 
-    # (a) fresh batch every step
+    # (a) ONE resident batch every step (rounds 1-4's headline regime; the headline is now a new batch every step)
     rng = np.random.default_rng(0)
-    recs = [synth.make_graph(rng, "zinc", 3, (KEY,)) for _ in range(min(1024, args.graphs))]
-    store = DeviceGraphStore(recs * max(2, 2 * args.graphs // len(recs)), dev)
+    recs = [synth.make_graph(rng, "zinc", 3, (KEY,)) for _ in range(min(2048, args.graphs))]
+    store = DeviceGraphStore(recs * max(1, args.graphs // len(recs)), dev)
     torch.manual_seed(0)
     model = SpModel(1, args.layers, args.hidden, act_dtype=act).to(dev)
     step = make_step(model, torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True), None)
+    dd = store.collate(np.random.default_rng(1).permutation(store.num_graphs)[:args.graphs])
+    for _ in range(6):
+        step(dd)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        step(dd)
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / 20 * 1e3
+    out["resident_ms_per_step"] = ms
+    out["resident_graphs_per_s"] = args.graphs / ms * 1e3
+    out["resident_note"] = (f"20 timed steps on ONE {args.graphs}-graph batch that stays resident with its index plans (the headline of rounds 1-4); "
+                            "the headline `value` is measured with a NEW batch every step")
+    del store, model, step, dd
     gen = torch.Generator().manual_seed(0)
-    # (no `prepare`: collation installs every plan SpModel asks for -- tests/test_gpu_sparse.py::test_collated_batch_needs_no_plan_building)
-    passes = []
-    for _ in range(2):                     # the boxes are shared: a host stall of a few ms in a 12-step loop shows; both passes are reported
-        ids = [torch.randperm(store.num_graphs, generator=gen)[:args.graphs] for _ in range(16)]
-        n = 0
-        for k, dd in enumerate(BatchPrefetcher(store, ids)):
-            if k == 4:
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-            step(dd)
-            n += 1
-        torch.cuda.synchronize(dev)
-        passes.append((time.perf_counter() - t0) / (n - 4) * 1e3)
-    ms = min(passes)
-    out["fresh_batch_ms_per_step"] = ms
-    out["fresh_batch_ms_per_step_passes"] = passes
-    out["fresh_batch_graphs_per_s"] = args.graphs / ms * 1e3
-    out["fresh_batch_note"] = (f"better of 2 passes of {n - 4} timed steps (both listed), every step a different {args.graphs}-graph batch collated on the "
-                               f"device from a resident int32 graph store ({store.num_graphs} graphs) together with its index plans, one batch ahead on a side stream")
-    del store, model, step
     # (b) small batches
+    from pygho_amd.graphs import SlotStep
     small_store = DeviceGraphStore(recs * max(1, 4096 // len(recs)), dev)
     for graphs in (128, 1024):
         hb = synth.make_batch(graphs, "zinc", seed=7)
@@ -285,13 +287,33 @@ def side_regimes(args, dev):
             n += 1
         torch.cuda.synchronize(dev)
         res["fresh"] = (time.perf_counter() - t0) / (n - 10) * 1e3
+        # ONE captured step over a fixed-capacity batch slot, a different shuffled batch EVERY step (graphs.SlotStep: the collate kernel
+        # and the step in one HIP graph, row counts read on the device; per batch one small upload + one replay)
+        torch.manual_seed(0)
+        model = SpModel(1, args.layers, args.hidden, act_dtype=act).to(dev)
+        ss = SlotStep(small_store, graphs, make_step(model, torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True), None))
+        cids = [torch.randperm(small_store.num_graphs, generator=gen)[:graphs].numpy() for _ in range(210)]
+        for k, ids in enumerate(cids):
+            if k == 10:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            loss = ss.run(ids)
+        torch.cuda.synchronize(dev)
+        res["captured_fresh"] = (time.perf_counter() - t0) / (len(cids) - 10) * 1e3
+        assert bool(torch.isfinite(loss))
         out[f"bs{graphs}"] = {"graphs": graphs, "eager_ms_per_step": res["eager"], "hipgraph_ms_per_step": res["hipgraph"],
                               "eager_fresh_batch_ms_per_step": res["fresh"],
+                              "captured_fresh_batch_ms_per_step": res["captured_fresh"],
+                              "captured_fresh_batch_graphs_per_s": graphs / res["captured_fresh"] * 1e3,
+                              "captured_fresh_batch_replays": ss.replays, "captured_fresh_batch_eager_fallbacks": ss.eager_steps,
+                              "slot_capacities": {str(k): v for k, v in ss.slot.caps.items()},
                               "eager_graphs_per_s": graphs / res["eager"] * 1e3, "hipgraph_graphs_per_s": graphs / res["hipgraph"] * 1e3,
                               "eager_fresh_batch_graphs_per_s": graphs / res["fresh"] * 1e3}
     out["small_batch_note"] = ("same model and full train step; eager / hipgraph on one resident batch, eager_fresh_batch on 50 timed steps that "
                                "each take a different shuffled batch collated on the device from a resident graph store (BatchPrefetcher); 128 graphs is the reference's batch size "
-                               "(example/minimal.py:119); hipgraph = the whole step captured once (pygho_amd.graphs.GraphedStep) and replayed")
+                               "(example/minimal.py:119); hipgraph = the whole step captured once on ONE batch (pygho_amd.graphs.GraphedStep) and replayed; "
+                               "captured_fresh_batch = ONE captured step over a fixed-capacity batch slot serving 200 different shuffled batches "
+                               "(pygho_amd.graphs.SlotStep: a batch that would not fit the capacities runs eagerly and is counted)")
     return out
 
 
@@ -376,23 +398,37 @@ def main():
     from pygho_amd.parallel import FlatGradSync
     _native.lib()
 
-    # ---- synthetic ZINC-shape batch of this rank, resident in HBM before timing ------------------------
-    distinct = min(args.distinct, args.graphs)
-    times = max(1, args.graphs // distinct)
-    if args.global_stream and world > 1:
-        # BASELINE config 4's wording: a fixed global batch, sharded by graph.  Every rank generates the same records
-        # and keeps its contiguous range (balanced by message count); the loss below is weighted so that the averaged
-        # gradient equals the gradient of the global mean loss whatever the shard sizes are.
-        from pygho_amd.parallel import shard_ranges
-        rng = np.random.default_rng(1000)
-        recs = [synth.make_graph(rng, "zinc", 3, (KEY,)) for _ in range(distinct * world)] * times
-        lo, hi = shard_ranges([r.acd[KEY].shape[1] for r in recs], world)[rank]
-        hb = synth.collate(recs[lo:hi])
-        loss_scale = world * hb.num_graphs / len(recs)
-    else:
-        hb = synth.replicate(synth.make_batch(distinct, "zinc", seed=1000 + rank), times)
-        loss_scale = 1.0
-    datadict = synth.to_datadict(hb, dev)
+    # ---- the dataset of this rank: a device-resident int32 graph store.  EVERY step takes a NEW shuffled batch from it -- the
+    # reference's loop (example/minimal.py:141-149) -- collated on the device together with its index plans, one batch ahead on a
+    # side stream (collate.BatchPrefetcher).  The inputs of a step are resident in HBM when the step starts; nothing crosses PCIe.
+    from pygho_amd.collate import BatchPrefetcher, DeviceGraphStore
+    from pygho_amd.parallel import shard_ranges
+    global_stream = args.global_stream and world > 1
+    per_step = args.graphs * (world if global_stream else 1)                 # graphs drawn per step from THIS rank's store
+    store_graphs = args.store_graphs if args.store_graphs > 0 else 2 * per_step
+    distinct = min(args.distinct if args.distinct > 0 else store_graphs, store_graphs)
+    rng = np.random.default_rng(1000 if global_stream else 1000 + rank)      # (global stream: the same store on every rank)
+    recs = [synth.make_graph(rng, "zinc", 3, (KEY,)) for _ in range(distinct)]
+    recs = (recs * ((store_graphs + distinct - 1) // distinct))[:store_graphs]
+    store = DeviceGraphStore(recs, dev)
+    msgs_of = np.asarray(store.h_len[("acd", KEY)])
+    id_rng = np.random.default_rng(2000 if global_stream else 2000 + rank)
+    n_batches = args.warmup + args.steps
+    id_batches, scales = [], []
+    resident_ids = id_rng.permutation(store.num_graphs)[:per_step]
+    for _ in range(n_batches):
+        ids = resident_ids if args.resident_batch else id_rng.permutation(store.num_graphs)[:per_step]
+        if global_stream:
+            # BASELINE config 4's wording: a fixed global stream, sharded by graph.  Every rank draws the same global batch and keeps
+            # its contiguous range (balanced by message count); the loss is weighted so that the averaged gradient equals the
+            # gradient of the global mean loss whatever the shard sizes are.
+            lo, hi = shard_ranges(msgs_of[ids], world)[rank]
+            scales.append(world * (hi - lo) / len(ids))
+            ids = ids[lo:hi]
+        else:
+            scales.append(1.0)
+        id_batches.append(ids)
+    del recs
     act_dtype = torch.bfloat16 if args.dtype == "bf16" else None
     torch.manual_seed(0)
     model = SpModel(1, args.layers, args.hidden, act_dtype=act_dtype).to(dev)
@@ -401,13 +437,12 @@ def main():
     sync = FlatGradSync(model.parameters(), overlap=use_dist, buckets=2)
     sync.broadcast_params(0)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=args.optimizer == "fused")
-    y = datadict["y"].unsqueeze(-1)
 
-    def step():
+    def step(datadict, loss_scale):
         sync.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=act_dtype is not None):
             pred = model(datadict)
-        loss = torch.nn.functional.l1_loss(y, pred.float())
+        loss = torch.nn.functional.l1_loss(datadict["y"].unsqueeze(-1), pred.float())
         (loss if loss_scale == 1.0 else loss * loss_scale).backward()
         sync.mark_backward_end()
         sync.sync()
@@ -419,26 +454,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
+    def batches():
+        if args.resident_batch:                       # A/B and profiling: one batch, resident with its plans, every step
+            dd = store.collate(id_batches[0])
+            for _ in range(n_batches):
+                yield dd
+        else:
+            yield from BatchPrefetcher(store, id_batches)
+
     timer = _ops.LaunchTimer()
-    t0 = time.perf_counter()
-    with timer:
-        for _ in range(args.steps):
-            loss = step()
+    t0 = None
+    for k, dd in enumerate(batches()):
+        if k == args.warmup:
+            barrier()
+            timer.__enter__()
+            t0 = time.perf_counter()
+        loss = step(dd, scales[k])
     barrier()
     elapsed = elapsed_own = time.perf_counter() - t0
+    timer.__exit__(None, None, None)
+    timed = id_batches[args.warmup:]
+    fam_total = lambda fam: float(sum(np.asarray(store.h_len[fam])[ids].sum() for ids in timed))
+    own_graphs, own_msgs = float(sum(len(ids) for ids in timed)), fam_total(("acd", KEY))
+    mean = {"graphs": own_graphs / args.steps, "nodes": fam_total("node") / args.steps, "edges": fam_total("edge") / args.steps,
+            "tuples": fam_total("tup") / args.steps, "msg_edges": own_msgs / args.steps}
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        gg = torch.tensor([hb.num_graphs, hb.num_messages(KEY)], dtype=torch.float64, device=dev)
+        gg = torch.tensor([own_graphs, own_msgs], dtype=torch.float64, device=dev)
         dist.all_reduce(gg, op=dist.ReduceOp.SUM)
-        total_graphs, total_msgs = float(gg[0].item()), float(gg[1].item())
+        total_graphs, total_msgs = float(gg[0].item()), float(gg[1].item())          # over all ranks and all timed steps
         per_rank = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(per_rank, torch.tensor([hb.num_graphs, elapsed_own], dtype=torch.float64, device=dev))
-        per_rank = [[int(t[0].item()), float(t[1].item())] for t in per_rank]
+        dist.all_gather(per_rank, torch.tensor([own_graphs / args.steps, elapsed_own], dtype=torch.float64, device=dev))
+        per_rank = [[float(t[0].item()), float(t[1].item())] for t in per_rank]
         # after the exchange every rank must hold the SAME averaged gradient, bit for bit: element-wise max and min over the ranks agree
         hi_, lo_ = sync.flat.clone(), sync.flat.clone()
         dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
@@ -446,7 +495,7 @@ def main():
         grads_equal = bool(torch.equal(hi_, lo_)) and bool(torch.isfinite(hi_).all()) and float(hi_.abs().max()) > 0
         overlap_rep = sync.overlap_report()
     else:
-        total_graphs, total_msgs = float(hb.num_graphs), float(hb.num_messages(KEY))
+        total_graphs, total_msgs = own_graphs, own_msgs
 
     if rank == 0:
         assert bool(torch.isfinite(loss)), "loss is not finite"
@@ -466,28 +515,33 @@ def main():
         op_ms = sum(v[0] * v[1] for v in every) / op_launches
         op_bytes = sum(v[0] * v[2] for v in every) / op_launches
         es = 2 if act_dtype is not None else 4
-        fwd_bytes = es * args.hidden * (2 * hb.num_tuples + hb.num_edges) + 8 * hb.num_messages(KEY) + 4 * (hb.num_tuples + 1)
+        fwd_bytes = es * args.hidden * (2 * mean["tuples"] + mean["edges"]) + 8 * mean["msg_edges"] + 4 * (mean["tuples"] + 1)
         # HBM traffic of the dominant kernel: collected OUTSIDE this process in separate rocprofv3 --pmc passes of
         # this very command (FETCH_SIZE corrected by the calibrated gfx950 factor, WRITE_SIZE as is) and committed
         # under profiles/ with the hash of the kernel sources it was measured on; null when configuration or sources differ.
-        traffic, traffic_src = committed_traffic({"graphs_per_gpu": hb.num_graphs, "hidden": args.hidden, "dtype": args.dtype})
+        traffic, traffic_src = committed_traffic({"graphs_per_gpu": args.graphs, "hidden": args.hidden, "dtype": args.dtype})
         line = {
             "metric": "graphs/sec, ZINC-shape NGNN train step (+ 2-tuple msg-edges/sec and HBM roofline fraction of the spspmm kernel)",
-            "value": total_graphs * args.steps / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+            "value": total_graphs / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype if args.dtype == "f32" else "bf16", "data": "synthetic",
             "config": {"workload": "NGNNConv 2-tuple sparse spspmm on ZINC-shape synthetic batches, hidden=128 bf16 "
-                                   "(6-layer NGNN of example/minimal.py, full train step)",
-                       "graphs_per_gpu": hb.num_graphs, "nodes": hb.num_nodes, "edges": hb.num_edges,
-                       "tuples": hb.num_tuples, "msg_edges": hb.num_messages(KEY), "hidden": args.hidden,
+                                   "(6-layer NGNN of example/minimal.py, full train step)"
+                                   + (", ONE resident batch every step (--resident-batch)" if args.resident_batch else
+                                      ", a NEW shuffled batch every step, collated on the device from a resident graph store "
+                                      "(the reference's loop, example/minimal.py:141-149)"),
+                       "batch": "resident" if args.resident_batch else "fresh every step",
+                       "graphs_per_gpu": mean["graphs"], "store_graphs": store.num_graphs, "store_distinct_graphs": distinct,
+                       "nodes": mean["nodes"], "edges": mean["edges"], "tuples": mean["tuples"], "msg_edges": mean["msg_edges"],
+                       "sizes": "means over the timed steps of rank 0", "hidden": args.hidden,
                        "layers": args.layers, "parallelism": f"graph-sharded data parallel x{world}"},
-            "msg_edges_per_sec_train": total_msgs * args.layers * args.steps / elapsed,
-            "msg_edges_per_sec_kernel": hb.num_messages(KEY) / (ms * 1e-3),
+            "msg_edges_per_sec_train": total_msgs * args.layers / elapsed,
+            "msg_edges_per_sec_kernel": mean["msg_edges"] / (ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "seg_gmr_fast_kernel<bf16,SUM,BOTH>"
                          if act_dtype is not None else "seg_gmr_fast_kernel<float,SUM,BOTH>",
                          "launches": launches, "avg_ms": ms, "algorithmic_bytes_per_launch": nbytes,
-                         "forward_bytes_per_msg_edge": fwd_bytes / hb.num_messages(KEY),
+                         "forward_bytes_per_msg_edge": fwd_bytes / mean["msg_edges"],
                          # every spspmm launch of the step (forward + both backward plans, BOTH kernels), same definition
                          "spspmm_all_launches": {"launches": op_launches, "avg_ms": op_ms, "algorithmic_bytes_per_launch": op_bytes,
                                                  "achieved": op_bytes / (op_ms * 1e-3) / 1e9,
@@ -508,14 +562,15 @@ def main():
             line["collectives"] = {"backend": dist.get_backend(), "allreduce_calls": sync.allreduce_calls,
                                    "allreduce_bytes": sync.flat.numel() * sync.flat.element_size(),
                                    "allreduce_ms": sync.allreduce_ms(), "allreduce_ranges_per_step": len(getattr(sync, "_ranges", [0])),
-                                   "graphs_all_ranks": int(total_graphs), "per_rank_graphs_and_seconds": per_rank,
+                                   "graphs_all_ranks": int(round(total_graphs / args.steps)), "graphs_all_ranks_all_steps": int(total_graphs),
+                                   "per_rank_graphs_and_seconds": per_rank,
                                    "flat_grad_equal_across_ranks": grads_equal, "overlap_last_step": overlap_rep,
                                    "ranks_share_gpu": bool(args.ranks_share_gpu),
                                    "overlap": "ranges are all-reduced on a side stream as backward completes them (pygho_amd/parallel.py)",
-                                   "batch": "global stream sharded by message count" if loss_scale != 1.0 or (args.global_stream and world > 1)
-                                   else "one independent batch per rank"}
+                                   "batch": "global stream sharded by message count" if global_stream
+                                   else "one independent batch stream per rank"}
         if world == 1 and not args.no_regimes:
-            del datadict, model, opt, sync, y
+            del model, opt, sync, store, dd
             torch.cuda.empty_cache()
             try:
                 line["regimes"] = side_regimes(args, dev)

@@ -454,13 +454,29 @@ def ma_reduce(data, mask, dims, op: str, keepdim: bool = False):
 
 
 def ma_diag(data, mask, dims):
-    """diagonal over masked dims, result placed at dims[0]; MaTensor.py:208-223."""
+    """diagonal over masked dims, result placed at dims[0]; MaTensor.py:208-223.  Two dims: what the reference computes (pinned by
+    masked_ops.npz).  MORE than two dims: the reference's loop (:218-220) keeps using the ORIGINAL dim numbers after the first
+    diagonal has removed two dims and appended one, and raises for every input tried (`diagonal dimensions cannot be identical` /
+    `Dimension out of range`); restated here is the documented intent -- out[.., i at dims[0], ..] = x[.., i, .., i, .., i, ..] --
+    by direct indexing (no reference output exists: pinned by construction)."""
     dims = sorted(dims)
     assert len(dims) >= 2
-    assert len(dims) == 2, "oracle covers 2-dim diagonals (the operators' use)"
-    td = np.diagonal(data, 0, dims[0], dims[1])
-    tm = np.diagonal(mask, 0, dims[0], dims[1])
-    return np.moveaxis(td, -1, dims[0]), np.moveaxis(tm, -1, dims[0])
+    if len(dims) == 2:
+        td = np.diagonal(data, 0, dims[0], dims[1])
+        tm = np.diagonal(mask, 0, dims[0], dims[1])
+        return np.moveaxis(td, -1, dims[0]), np.moveaxis(tm, -1, dims[0])
+    n = data.shape[dims[0]]
+    assert all(data.shape[d] == n for d in dims)
+
+    def take(a, nd):
+        keep = [d for d in range(nd) if d not in dims[1:]]                 # dims[0] keeps its place and carries the diagonal
+        out = np.empty([a.shape[d] for d in keep] + list(a.shape[nd:]), dtype=a.dtype)
+        for i in range(n):
+            src = tuple(i if d in dims else slice(None) for d in range(nd))
+            dst = tuple(i if d == dims[0] else slice(None) for d in keep)
+            out[dst] = a[src]
+        return out
+    return take(data, mask.ndim), take(mask, mask.ndim)
 
 
 def ma_unpooling(data, dims, tar_shape):

@@ -115,6 +115,9 @@ PROTOTYPES = {
     "pygho_rowblock_linear_bwd_sums": (I, [P, P, P, P, P, P, P, P, P, P, L, L, I, P, I, P]),
     "pygho_bn_bwd_linear_dw_recompute": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, L, P]),
     "pygho_bn_bwd_fold_sums": (I, [P, P, P, L, L, P]),
+    "pygho_narrow_i64_i32_bounded": (I, [P, P, L, L, P, P]),
+    "pygho_block_cuts_workspace": (Z, [L]),
+    "pygho_block_cuts": (I, [P, P, P, L, P, Z, P]),
     "pygho_rowblock_linear_autoshift_dyn": (I, [P, P, P, P, P, P, P, L, P, L, I, P]),
     "pygho_rowblock_linear_bwd_sums_dyn": (I, [P, P, P, P, P, P, P, P, P, P, L, P, L, I, P, I, P]),
     "pygho_bn_bwd_linear_dw_dyn": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, L, P]),

@@ -149,10 +149,14 @@ class MaskedTensor:
         assert len(dims) >= 2, "must diag several dims"
         dims = sorted(list(dims))
         tdata, tmask = self.__raw, self.__mask
-        if len(dims) > 2:
-            raise NotImplementedError("diagonal over more than two masked dims")
         tdata = torch.diagonal(tdata, 0, dims[0], dims[1])
         tmask = torch.diagonal(tmask, 0, dims[0], dims[1])
+        for i in range(2, len(dims)):
+            # the reference's loop (MaTensor.py:218-220) keeps the ORIGINAL dim numbers here and raises for every input
+            # ("diagonal dimensions cannot be identical" / "Dimension out of range"): i smaller dims are gone by now, the running
+            # diagonal sits last -- the documented intent, x[.., k, .., k, .., k, ..] at dims[0] (deviations)
+            tdata = torch.diagonal(tdata, 0, dims[i] - i, -1)
+            tmask = torch.diagonal(tmask, 0, dims[i] - i, -1)
         tdata = torch.movedim(tdata, -1, dims[0])
         tmask = torch.movedim(tmask, -1, dims[0])
         filled = self.__filled is not None

@@ -256,6 +256,11 @@ class ParamCastArena:
         dev = self.params[0].device if self.params else None
         self.flat = torch.empty(total, dtype=dtype, device=dev) if self.params else None
         self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
+        # aliases with their OWN version counters, for the refresh to write through: autograd saves `views` (_ArenaLinearFn,
+        # _PairProduct), and a re-cast between a forward and its backward -- a second grad-enabled forward first: siamese use, a
+        # validation pass -- must not trip the saved tensors' version check.  With unchanged parameters the re-cast writes the same
+        # bits, so that backward reads what its forward read.
+        self.raw_views = [v.data for v in self.views]
         self.versions = [-1] * len(self.params)
         self.ptrs = [0] * len(self.params)          # storage address at the last refresh: `module.to()` / `p.data = ...` swap it
         self.epoch = -1
@@ -302,10 +307,18 @@ class ParamCastArena:
         if not stale:
             return
         with torch.no_grad():
-            torch._foreach_copy_([self.views[i] for i in stale], [self.params[i].detach() for i in stale])
+            torch._foreach_copy_([self.raw_views[i] for i in stale], [self.params[i].detach() for i in stale])
         for i in stale:
             self.versions[i] = self.params[i]._version
             self.ptrs[i] = self.params[i].data_ptr()
+
+
+# Every forward re-casts every parameter: ONE multi-tensor launch, which is what the arena is for.  Round 4 re-cast only what version
+# counters / the optimizer hook reported as changed; updates that bypass both were then served STALE 16-bit weights in training
+# forwards, silently: `p.data.mul_(...)` / `p.data.copy_(...)` (EMA, weight tying, manual SGD on .data), a user's own captured graph
+# that contains the optimizer step, optimizers not derived from torch.optim.Optimizer, broadcasts into .data.  PYGHO_ARENA_LAZY=1
+# restores the lazy policy (then call `invalidate_cast_arenas()` after such updates).
+ARENA_LAZY = os.environ.get("PYGHO_ARENA_LAZY", "0") not in ("", "0")
 
 
 def ensure_cast_arena(module, dtype: Optional[torch.dtype]) -> None:
@@ -314,7 +327,7 @@ def ensure_cast_arena(module, dtype: Optional[torch.dtype]) -> None:
         return
     arena = module.__dict__.get("_pygho_cast_arena")
     if arena is not None and arena.dtype == dtype and arena.same_parameters():
-        arena.refresh()
+        arena.refresh(force=not ARENA_LAZY)
         return
     params = list(module.parameters())
     if (arena is None or arena.dtype != dtype or len(arena.params) != sum(1 for p in params if p.is_cuda and p.dtype == torch.float32)
@@ -326,9 +339,7 @@ def ensure_cast_arena(module, dtype: Optional[torch.dtype]) -> None:
             # belt and braces next to the version / address checks: a loaded state dict invalidates every copy
             module.register_load_state_dict_post_hook(lambda _m, _keys: invalidate_cast_arenas())
             module.__dict__["_pygho_cast_hook"] = True
-    # re-cast what changed: everything after an optimizer step / graph replay / state-dict load (epoch), single parameters after an
-    # in-place update that moved their version counter or storage; nothing otherwise (see the note at _invalidate_after_optimizer_step)
-    arena.refresh()
+    arena.refresh(force=not ARENA_LAZY)
 
 
 def rebuild_cast_arena(module) -> None:

@@ -39,6 +39,36 @@ def _mirror_of(r: GraphRecord, n_types: int):
     return (pos if ok else np.zeros(t, dtype=np.int64)), bool(ok)
 
 
+def _validate_records(records: List[GraphRecord], keys) -> None:
+    """Every batch collated from the store is marked range-checked (`_pygho_value_bound`, `_pygho_hash_ok`, plans installed without
+    the planners' range flags), so the checks the reference makes per batch -- its gathers raise IndexError, its hash asserts
+    refuse negative indices (SpTensor.py:32,37, Spspmm.py:309-311) -- happen HERE, once per dataset: integer features are
+    non-negative, every node id addresses a node of its graph, every triple addresses rows of its operands.  A node id >= num_nodes
+    would also lengthen a `bincount(..., minlength=num_nodes)` row and silently misalign every later graph's plans."""
+    for gi, r in enumerate(records):
+        n = int(r.num_nodes)
+        where = f"graph {gi}"
+        if n < 0 or np.shape(r.x)[0] != n:
+            raise ValueError(f"pygho_amd: {where}: x has {np.shape(r.x)[0]} rows for {n} nodes")
+        for name, a in (("x", r.x), ("edge_attr", r.edge_attr), ("tuplefeat", r.tuplefeat)):
+            if np.size(a) and int(np.min(a)) < 0:
+                raise ValueError(f"pygho_amd: {where}: negative integer feature in {name} (features index embedding tables)")
+        for name, ind in (("edge_index", r.edge_index), ("tupleid", r.tupleid)):
+            if np.size(ind) and (int(np.min(ind)) < 0 or int(np.max(ind)) >= n):
+                raise ValueError(f"pygho_amd: {where}: {name} addresses a node outside [0, {n})")
+        if np.shape(r.edge_attr)[0] != r.edge_index.shape[1] or np.shape(r.tuplefeat)[0] != r.tupleid.shape[1]:
+            raise ValueError(f"pygho_amd: {where}: feature rows do not match the index columns")
+        for k in keys:
+            roles = parse_key(k)
+            acd = r.acd[k]
+            if acd.shape[0] != 3:
+                raise ValueError(f"pygho_amd: {where}: acd of {k} must be (3, M)")
+            for row, role in zip(acd, (roles[0], roles[1], roles[3])):
+                rows = r.tupleid.shape[1] if role[0] == "X" else r.edge_index.shape[1]
+                if row.size and (int(row.min()) < 0 or int(row.max()) >= rows):
+                    raise ValueError(f"pygho_amd: {where}: acd of {k} addresses a row outside [0, {rows}) of operand {role}")
+
+
 def _ptr64(lengths: Sequence[int], device) -> torch.Tensor:
     return torch.from_numpy(np.concatenate(([0], np.cumsum(np.asarray(lengths, dtype=np.int64))))).to(device)
 
@@ -51,6 +81,7 @@ class DeviceGraphStore:
         self.num_graphs = len(records)
         self.keys = list(records[0].acd.keys())
         self.sd = records[0].tupleid.shape[0]
+        _validate_records(records, self.keys)       # ONCE, on the host: what the per-batch range flags used to catch (see below)
         d = self.device
         self.node_ptr = _ptr64([r.num_nodes for r in records], d)
         self.edge_ptr = _ptr64([r.edge_index.shape[1] for r in records], d)
@@ -113,7 +144,7 @@ class DeviceGraphStore:
             parts = _ops.scatter_plan_parts(acd[0].contiguous(), acd[1].contiguous(), acd[2].contiguous(), block_m)
             if parts is None:
                 continue
-            n_chunks, chunk0, blk_e, chunks, words, max_edges = parts
+            n_chunks, chunk0, blk_e, chunks, words, max_edges, _ = parts
             roles = parse_key(k)
             rows3 = (self.tup_ptr if roles[3][0] == "X" else self.edge_ptr)
             n_rows3 = (rows3[1:] - rows3[:-1]).to(torch.int32)

@@ -2,6 +2,8 @@
 // sorted matching.  All results are bit-exact functions of their inputs (no atomics whose order
 // could leak into the output).
 #include <hipcub/hipcub.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/reverse_iterator.hpp>
 
 #include "common.h"
 
@@ -16,12 +18,22 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-__global__ void narrow_kernel(int32_t* __restrict__ dst, const int64_t* __restrict__ src, int64_t n, int32_t* err) {
+__global__ void narrow_kernel(int32_t* __restrict__ dst, const int64_t* __restrict__ src, int64_t n, int32_t* err, int64_t bound) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t v = src[i];
-    if ((v < 0 || v > INT32_MAX) && err) *err = 1;
+    if ((v < 0 || v >= bound) && err) *err = 1;
     dst[i] = (int32_t)v;
   }
+}
+
+// block cuts of a message list over second-operand rows d: message m starts a block when every earlier d is smaller than every d from m
+// on (prefix maximum < suffix minimum) -- the graphs of a block-diagonal batch (csrc/seg_scatter.hip's planner works per block)
+struct BlockStart {
+  const int32_t* pm; const int32_t* sm;
+  __device__ bool operator()(int m) const { return m == 0 || pm[m - 1] < sm[m]; }
+};
+__global__ void block_sentinel_kernel(int32_t* __restrict__ block_m, const int32_t* __restrict__ n_blocks, int32_t n_msg) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) block_m[*n_blocks] = n_msg;
 }
 
 template <typename K>
@@ -302,8 +314,60 @@ extern "C" int pygho_narrow_i64_i32(int32_t* dst, const int64_t* src, int64_t n,
   if (n < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
   if (n == 0) return PYGHO_OK;
   if (!dst || !src) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
-  hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, dst, src, n, err);
+  hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, dst, src, n, err,
+                     (int64_t)INT32_MAX + 1);
   return check_launch("narrow_i64_i32");
+}
+
+extern "C" int pygho_narrow_i64_i32_bounded(int32_t* dst, const int64_t* src, int64_t n, int64_t bound, int32_t* err, void* stream) {
+  if (n < 0 || bound < 0 || bound > (int64_t)INT32_MAX + 1) { set_error("narrow_i64_i32_bounded: bad size / bound"); return PYGHO_ERR_INVALID; }
+  if (n == 0) return PYGHO_OK;
+  if (!dst || !src) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, dst, src, n, err, bound);
+  return check_launch("narrow_i64_i32_bounded");
+}
+
+static size_t block_cuts_temp(int64_t n) {
+  size_t t1 = 0, t2 = 0;
+  (void)hipcub::DeviceScan::InclusiveScan(nullptr, t1, (const int32_t*)nullptr, (int32_t*)nullptr, hipcub::Max(), (int)n);
+  BlockStart pred{nullptr, nullptr};
+  (void)hipcub::DeviceSelect::If(nullptr, t2, rocprim::counting_iterator<int32_t>(0), (int32_t*)nullptr, (int32_t*)nullptr, (int)n, pred);
+  return t1 > t2 ? t1 : t2;
+}
+
+extern "C" size_t pygho_block_cuts_workspace(int64_t n_msg) {
+  if (n_msg <= 0) return 256;
+  return 2 * align256((size_t)n_msg * sizeof(int32_t)) + align256(block_cuts_temp(n_msg)) + 256;
+}
+
+extern "C" int pygho_block_cuts(int32_t* block_m, int32_t* n_blocks, const int32_t* d32, int64_t n_msg, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  if (n_msg < 0 || n_msg > INT32_MAX) { set_error("block_cuts: bad size"); return PYGHO_ERR_INVALID; }
+  if (!block_m || !n_blocks) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  if (n_msg == 0) {
+    (void)hipMemsetAsync(n_blocks, 0, sizeof(int32_t), st);
+    (void)hipMemsetAsync(block_m, 0, sizeof(int32_t), st);
+    return check_launch("block_cuts(empty)");
+  }
+  if (!d32 || !workspace) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (workspace_bytes < pygho_block_cuts_workspace(n_msg)) { set_error("workspace too small"); return PYGHO_ERR_INVALID; }
+  char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  int32_t* pm = (int32_t*)ws;
+  int32_t* sm = (int32_t*)(ws + align256((size_t)n_msg * sizeof(int32_t)));
+  void* temp = ws + 2 * align256((size_t)n_msg * sizeof(int32_t));
+  size_t temp_bytes = block_cuts_temp(n_msg);
+  hipError_t e = hipcub::DeviceScan::InclusiveScan(temp, temp_bytes, d32, pm, hipcub::Max(), (int)n_msg, st);
+  if (e == hipSuccess)
+    e = hipcub::DeviceScan::InclusiveScan(temp, temp_bytes, rocprim::make_reverse_iterator(d32 + n_msg), rocprim::make_reverse_iterator(sm + n_msg),
+                                          hipcub::Min(), (int)n_msg, st);
+  if (e == hipSuccess) {
+    BlockStart pred{pm, sm};
+    e = hipcub::DeviceSelect::If(temp, temp_bytes, rocprim::counting_iterator<int32_t>(0), block_m, n_blocks, (int)n_msg, pred, st);
+  }
+  if (e != hipSuccess) { set_error("block_cuts: %s", hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
+  hipLaunchKernelGGL(block_sentinel_kernel, dim3(1), dim3(64), 0, st, block_m, (const int32_t*)n_blocks, (int32_t)n_msg);
+  return check_launch("block_cuts");
 }
 
 extern "C" int pygho_csr_from_sorted(int32_t* seg_ptr, const int64_t* keys, int64_t m, int64_t n_seg, int32_t* err,

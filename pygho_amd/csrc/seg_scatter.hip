@@ -217,11 +217,6 @@ __global__ __launch_bounds__(512) void seg_scatter_kernel(
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = j * 16 + q;
-#ifdef PYGHO_SC_KO_LOADS                                 // knock-out build: the arithmetic alone (no row ever requested)
-      rw.g[j] = __builtin_amdgcn_raw_buffer_load_b128(lres, (int)0x80000000, 0, 0);
-      rw.x[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, (int)0x80000000, 0, 0);
-      continue;
-#endif
       rw.g[j] = __builtin_amdgcn_raw_buffer_load_b128(lres, r < a_rows ? (int)((uint32_t)(dsc.y + r) * row_bytes + slice_off) : (int)0x80000000, 0, 0);
       rw.x[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, r < c_rows ? (int)((uint32_t)(dsc.z + r) * row_bytes + slice_off) : (int)0x80000000, 0, 0);
     }
@@ -269,9 +264,6 @@ __global__ __launch_bounds__(512) void seg_scatter_kernel(
   // on the accumulators: one pipelined burst of LDS reads instead of a word -> rows -> accumulator chain per trip, which at two
   // wavefronts per SIMD was 500 cycles per trip); what stays serial is read-modify-write of the accumulator rows, trip by trip
   auto trips_of = [&](int n) {
-#ifdef PYGHO_SC_KO_TRIPS                                 // knock-out build (tools/byedge_ab.py): the memory pipeline alone
-    if (n < 1000) return;
-#endif
     constexpr int TMAX = kScMsgs / kScMpt;
     const int trips = (n + kScMpt - 1) / kScMpt;
     uint32_t w[TMAX];

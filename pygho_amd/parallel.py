@@ -29,8 +29,9 @@ class FlatGradSync:
     moment a range is complete its gradients are packed and its all-reduce is issued on a SIDE stream while backward
     goes on with the earlier layers.  ``sync()`` then only launches what is left (ranges holding parameters without a
     gradient), joins the side stream and scales.  The result is the same buffer as the single collective's: an
-    all-reduce sums element-wise, so the bucket boundaries cannot change a bit.  Contract: ONE backward pass per
-    ``zero_grad()`` / ``sync()`` pair (no gradient accumulation over several backward calls)."""
+    all-reduce sums element-wise, so the bucket boundaries cannot change a bit.  Contract: ONE exchanging backward pass per
+    ``zero_grad()`` / ``sync()`` pair; gradient accumulation over micro-batches runs the earlier passes under ``no_sync()``
+    (the hooks stay quiet, the gradients accumulate in ``param.grad``) and only the last pass outside it."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional["dist.ProcessGroup"] = None,
                  dtype: torch.dtype = torch.float32, overlap: bool = False, buckets: int = 2):
@@ -48,6 +49,7 @@ class FlatGradSync:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.allreduce_calls = 0
         self.overlap = bool(overlap) and dist.is_available() and dist.is_initialized()
+        self._quiet = False                   # inside no_sync(): backward passes accumulate, nothing is exchanged
         self._events = []                     # (start, end) device events around every side-stream collective (allreduce_ms)
         self._handles = []                    # RemovableHandles of the backward hooks (close())
         self._closed = False
@@ -118,12 +120,30 @@ class FlatGradSync:
         for v, p in zip(self.views, self.params):
             p.grad = v
 
+    def no_sync(self):
+        """``with sync.no_sync(): loss.backward()`` -- a backward pass of a micro-batch that is NOT the last one before ``sync()``:
+        its gradients accumulate in ``param.grad`` and no range is exchanged.  The last pass runs outside the context (its hooks
+        launch the ranges as they complete, now holding the accumulated gradients); ``sync()`` launches whatever is left."""
+        me = self
+
+        class _Quiet:
+            def __enter__(self):
+                self.prev, me._quiet = me._quiet, True
+
+            def __exit__(self, *exc):
+                me._quiet = self.prev
+                return False
+        return _Quiet()
+
     def _on_grad(self, i: int) -> None:
+        if self._quiet:
+            return
         b = self._bucket_of[i]
         self._pending[b] -= 1
         if self._pending[b] < 0:
-            raise RuntimeError("FlatGradSync: a parameter received a second gradient before sync() -- the contract is ONE backward "
-                               "pass per zero_grad() / sync() pair (a second pass would re-reduce an already exchanged range)")
+            raise RuntimeError("FlatGradSync: a parameter received a second gradient before sync() -- ONE exchanging backward pass "
+                               "per zero_grad() / sync() pair (a second pass would re-reduce an already exchanged range); run the "
+                               "earlier passes of a gradient accumulation under `with sync.no_sync():`")
         if self._pending[b] == 0 and not self._launched[b]:
             self._launch(b)
 
@@ -216,9 +236,26 @@ class FlatGradSync:
         return sum(a.elapsed_time(b) for a, b in self._events) / len(self._events)
 
     def broadcast_params(self, src: int = 0) -> None:
-        if dist.is_available() and dist.is_initialized():
-            for p in self.params:
-                dist.broadcast(p.data, src=src, group=self.group)
+        """every rank starts from rank `src`'s parameters: ONE broadcast per parameter dtype over a flat staging buffer (round 4
+        issued one collective per parameter, ~70 latency-bound calls for the minimal NGNN)"""
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        by_dtype = {}
+        for p in self.params:
+            by_dtype.setdefault(p.dtype, []).append(p)
+        with torch.no_grad():
+            for dtype, ps in by_dtype.items():
+                flat = torch.empty(sum(p.numel() for p in ps), dtype=dtype, device=ps[0].device)
+                views, off = [], 0
+                for p in ps:
+                    views.append(flat[off:off + p.numel()].view_as(p))
+                    off += p.numel()
+                torch._foreach_copy_(views, [p.detach() for p in ps])
+                dist.broadcast(flat, src=src, group=self.group)
+                torch._foreach_copy_([p.detach() for p in ps], views)
+                self.broadcast_calls = getattr(self, "broadcast_calls", 0) + 1
+        from . import _ops
+        _ops.invalidate_cast_arenas()              # the parameters changed underneath any 16-bit copies
 
 
 def shard_ranges(weights, world_size: int) -> List[Tuple[int, int]]:

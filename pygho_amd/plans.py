@@ -66,16 +66,33 @@ def require_static_rows(m: int, what: str) -> None:
                            "batch slot's row family; run this step eagerly on `DeviceGraphStore.collate` batches instead")
 
 
-def narrow_i32(x: Tensor, checked: bool = False) -> Tensor:
-    """int64 -> int32 copy on the device (cached on the source tensor object)."""
+def narrow_i32(x: Tensor, checked: bool = False, bound: Optional[int] = None, bound_msg: str = "") -> Tensor:
+    """int64 -> int32 copy on the device (cached on the source tensor object).  `bound`: the values must lie in [0, bound) -- checked
+    by the narrowing pass itself, reported as a DEFERRED error (`defer_error`: the flag rides on the next host fetch)."""
     if x.dtype == _I32:
+        if bound is not None and x.numel():
+            lo, hi = torch.aminmax(x)
+            defer_error(((lo < 0) | (hi >= bound)).to(_I32).reshape(1), bound_msg or f"pygho_amd: index outside [0, {bound})")
         return x.contiguous()
     cache = getattr(x, "_pygho_i32", None)
     if cache is not None and cache[0] == x._version:
+        if bound is not None and x.numel():                  # narrowed earlier without this bound: a check of its own
+            lo, hi = torch.aminmax(cache[1])
+            defer_error(((lo < 0) | (hi >= bound)).to(_I32).reshape(1), bound_msg or f"pygho_amd: index outside [0, {bound})")
         return cache[1]
     dev = require_device(x)
     x = x.contiguous()
     out = torch.empty(x.shape, dtype=_I32, device=dev)
+    if bound is not None and 0 <= bound <= (1 << 31):
+        err = _flag(dev)
+        check(lib().pygho_narrow_i64_i32_bounded(ptr(out), ptr(x), x.numel(), int(bound), ptr(err), stream_ptr(dev)), "narrow_i64_i32_bounded")
+        if x.numel():
+            defer_error(err, bound_msg or f"pygho_amd: index outside [0, {bound})")
+        try:
+            x._pygho_i32 = (x._version, out)
+        except Exception:
+            pass
+        return out
     err = _flag(dev) if checked else None
     check(lib().pygho_narrow_i64_i32(ptr(out), ptr(x), x.numel(), ptr(err), stream_ptr(dev)), "narrow_i64_i32")
     if checked and int(err.item()) != 0:

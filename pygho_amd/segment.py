@@ -380,14 +380,13 @@ class MessagePlan:
         self.m = acd.shape[1]
         self.n_out, self.n_lhs, self.n_rhs = n_out, n_lhs, n_rhs
         self._a64, self._c64, self._d64 = unbased(acd[0]), unbased(acd[1]), unbased(acd[2])   # (cached on acd: no view links)
-        if self.m > 0:
-            # operand indices must address rows of the operands (the reference's gathers raise IndexError,
-            # Spspmm.py:309-311); the flag rides on the synchronisation of the forward plan's sortedness probe below
-            lo, hi = torch.aminmax(acd[1:3], dim=1)
-            bad = ((lo < 0).any() | (hi[0] >= n_lhs) | (hi[1] >= n_rhs)).to(torch.int32).reshape(1)
-            defer_error(bad, f"pygho_amd: acd operand index out of range (acd[1] must lie in [0, {n_lhs}), acd[2] in [0, {n_rhs}))")
+        # operand indices must address rows of the operands (the reference's gathers raise IndexError, Spspmm.py:309-311): checked
+        # by the narrowing pass itself (round 4: a separate aminmax over the int64 rows, 1.0-1.4 ms at BASELINE shapes); the flags
+        # ride on the synchronisation of the forward plan's sortedness probe below
+        msg = f"pygho_amd: acd operand index out of range (acd[1] must lie in [0, {n_lhs}), acd[2] in [0, {n_rhs}))"
+        c32, d32 = narrow_i32(acd[1], bound=n_lhs, bound_msg=msg), narrow_i32(acd[2], bound=n_rhs, bound_msg=msg)
         self.fwd = plan_from_keys(acd[0], n_out)
-        a32, c32, d32 = narrow_i32(acd[0]), narrow_i32(acd[1]), narrow_i32(acd[2])
+        a32 = narrow_i32(acd[0])
         self.a32, self.c32, self.d32 = a32, c32, d32                 # message order
         self.c_fwd, self.d_fwd = self.fwd.take(c32), self.fwd.take(d32)   # grouped-by-a order
         self._by_c = None
@@ -491,7 +490,6 @@ SEG_SCATTER = os.environ.get("PYGHO_SEG_SCATTER", "auto")      # "0": never, "1"
 # below ~10^6 messages the launch does not fill the chip's resident set of (blocks x slices) workgroups and the gather form on the
 # window kernel is as fast (128 / 1024-graph ZINC-shape batches: 56 k / 440 k messages)
 SEG_SCATTER_MIN_MESSAGES = int(os.environ.get("PYGHO_SEG_SCATTER_MIN_MESSAGES", str(1 << 20)))
-SEG_SCATTER_BUILD_AFTER = int(os.environ.get("PYGHO_SEG_SCATTER_BUILD_AFTER", "12"))   # by-edge launches on a pattern before it is planned
 
 
 class ScatterPlan:
@@ -502,9 +500,10 @@ class ScatterPlan:
     __slots__ = ("n_blocks", "n_chunks", "chunk0", "blk_e", "chunks", "words", "max_edges", "covers")
 
 
-def scatter_plan_parts(a32: Tensor, c32: Tensor, d32: Tensor, block_m: Tensor):
+def scatter_plan_parts(a32: Tensor, c32: Tensor, d32: Tensor, block_m: Tensor, n_rhs: Optional[int] = None):
     """the planner over given blocks: (n_chunks per block, chunk0 = their exclusive scan (int32, n_blocks + 1), blk_e (n_blocks, 2),
-    chunks (total, 4), words (M), max_edges, bad) -- two kernels and ONE host read (chunk total + flags)"""
+    chunks (total, 4), words (M), max_edges, covers) -- two kernels and ONE host read (chunk total + flags + whether the blocks' edge
+    ranges tile [0, n_rhs)); `n_rhs` None: covers is not asked for"""
     dev = d32.device
     nb = block_m.numel() - 1
     n_chunks = torch.empty(nb, dtype=_I32, device=dev)
@@ -514,33 +513,43 @@ def scatter_plan_parts(a32: Tensor, c32: Tensor, d32: Tensor, block_m: Tensor):
                                         stream_ptr(dev)), "seg_scatter_count")
     chunk0 = torch.zeros(nb + 1, dtype=_I32, device=dev)
     torch.cumsum(n_chunks, 0, out=chunk0[1:])
-    max_edges, bad, total = _fetch(torch.stack([flags[0], flags[1], chunk0[-1]]))
+    covers = torch.ones((), dtype=torch.bool, device=dev)
+    if n_rhs is not None and nb > 0:
+        e0, ne = blk_e[:, 0], blk_e[:, 1]
+        covers = (e0[0] == 0) & (e0[-1] + ne[-1] == n_rhs) & (e0[1:] == e0[:-1] + ne[:-1]).all()
+    max_edges, bad, total, covers = _fetch(torch.stack([flags[0], flags[1], chunk0[-1], covers.to(_I32)]))
     if bad or max_edges > 255 or total == 0:
         return None
     chunks = torch.empty((int(total), 4), dtype=_I32, device=dev)
     words = torch.empty(d32.numel(), dtype=_I32, device=dev)
     check(lib().pygho_seg_scatter_write(ptr(chunks), ptr(words), ptr(chunk0), ptr(blk_e), ptr(a32), ptr(c32), ptr(d32), ptr(block_m), nb,
                                         int(total), d32.numel(), stream_ptr(dev)), "seg_scatter_write")
-    return n_chunks, chunk0, blk_e, chunks, words, int(max_edges)
+    return n_chunks, chunk0, blk_e, chunks, words, int(max_edges), bool(covers)
+
+
+def block_cuts(d32: Tensor) -> Tensor:
+    """(n_blocks + 1) int32 block starts of a message list over second-operand rows `d32` (+ the closing M): a block starts where
+    every earlier d is smaller than every later one (`pygho_block_cuts`: two device scans + one selection; ONE host read, the count)"""
+    dev = require_device(d32)
+    m = d32.numel()
+    block_m = torch.empty(m + 1, dtype=_I32, device=dev)
+    nb = torch.empty(1, dtype=_I32, device=dev)
+    nbytes = int(lib().pygho_block_cuts_workspace(m))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib().pygho_block_cuts(ptr(block_m), ptr(nb), ptr(d32.contiguous()), m, ptr(ws), nbytes, stream_ptr(dev)), "block_cuts")
+    n_blocks = int(_fetch(nb)[0])
+    return block_m[:n_blocks + 1]
 
 
 def _scatter_plan_build(plan: "MessagePlan") -> Optional[ScatterPlan]:
-    d = plan.d32
-    # a cut after message m where max d[:m+1] < min d[m+1:]
-    pm = torch.cummax(d, 0).values
-    sm = torch.flip(torch.cummin(torch.flip(d, [0]), 0).values, [0])
-    cut = torch.nonzero(pm[:-1] < sm[1:]).flatten() + 1                      # (host read 1: the number of blocks)
-    block_m = torch.cat([cut.new_zeros(1), cut, cut.new_full((1,), plan.m)]).to(_I32)
-    parts = scatter_plan_parts(plan.a32, plan.c32, d, block_m)                # (host read 2)
+    block_m = block_cuts(plan.d32)                                                        # (host read 1: the number of blocks)
+    parts = scatter_plan_parts(plan.a32, plan.c32, plan.d32, block_m, plan.n_rhs)         # (host read 2: chunk total + verdicts)
     if parts is None:
         return None
-    _, chunk0, blk_e, chunks, words, max_edges = parts
-    e0, ne = blk_e[:, 0], blk_e[:, 1]
-    covers = (e0[0] == 0) & (e0[-1] + ne[-1] == plan.n_rhs) & (e0[1:] == e0[:-1] + ne[:-1]).all()
+    _, chunk0, blk_e, chunks, words, max_edges, covers = parts
     sp = ScatterPlan()
     sp.n_blocks, sp.n_chunks, sp.chunk0, sp.blk_e, sp.max_edges = block_m.numel() - 1, chunks.shape[0], chunk0, blk_e, max_edges
-    sp.chunks, sp.words = chunks, words
-    sp.covers = bool(_fetch(covers.to(_I32).reshape(1))[0])                  # (host read 3, a single flag)
+    sp.chunks, sp.words, sp.covers = chunks, words, covers
     return sp
 
 
@@ -557,19 +566,16 @@ def install_scatter_plan(plan: "MessagePlan", chunk0: Tensor, blk_e: Tensor, chu
 def scatter_plan(plan: "MessagePlan", on_demand: bool = False) -> Optional[ScatterPlan]:
     """the plan's ScatterPlan, or None when its blocks are outside the kernel's limits (more than 255 edges in a block, a not sorted
     inside a block, more than four messages of one edge among 16 consecutive ones).  Never built under stream capture (host reads).
-    `on_demand` (the dispatcher's call): planning costs ~1.3 ms and three host reads while one launch saves ~15 us, so a plan is only
-    built for a pattern that KEEPS COMING BACK -- after `SEG_SCATTER_BUILD_AFTER` by-edge launches on it (two training steps of a
-    6-layer model); until then, and for one-shot batch patterns, the gather form runs.  An explicit call (`SpModel.prepare`, the
-    prefetcher's side stream) builds at once; `collate.DeviceGraphStore` installs plans collated from the dataset's."""
+    Built on an EXPLICIT call only (`SpModel.prepare`, the prefetcher's side stream) or installed with the batch
+    (`collate.DeviceGraphStore`): planning costs ~0.5 ms and two host reads while one launch saves ~15 us, so the dispatcher's call
+    (`on_demand`) never builds -- it takes the plan when there is one and the gather form otherwise.  (Round 4 built on demand after
+    12 by-edge launches on a pattern: hidden state that made WHICH kernel ran depend on a batch's history; the two forms return the
+    same bits, but a step's time and its host reads should not depend on how often a batch was seen.)"""
     sp = getattr(plan, "_scatter", None)
     if sp is not None:
         return sp or None
-    if plan.m == 0 or plan.m >= (1 << 31) or torch.cuda.is_current_stream_capturing():
+    if on_demand or plan.m == 0 or plan.m >= (1 << 31) or torch.cuda.is_current_stream_capturing():
         return None
-    if on_demand:
-        plan._byedge_calls = getattr(plan, "_byedge_calls", 0) + 1
-        if plan._byedge_calls <= SEG_SCATTER_BUILD_AFTER:
-            return None
     plan._scatter = _scatter_plan_build(plan) or False
     return plan._scatter or None
 

@@ -62,6 +62,25 @@ def slot_capacities(store: DeviceGraphStore, n_graphs: int, sigmas: float = 4.5,
     return caps
 
 
+def batch_layout(h_len: np.ndarray, h_ptr: np.ndarray, cap_vec: np.ndarray, ids: np.ndarray) -> Optional[np.ndarray]:
+    """the per-batch upload of a slot, computed on the host from per-graph lengths: rows [ids | 0..G | running offsets of every family
+    (G + 1 entries, the last one = the batch's true total) | first store column of every selected graph per family], each row G + 1
+    int64 -- or None when a family's total exceeds its capacity.  `h_len` / `h_ptr` are (families, store graphs): lengths and first
+    columns.  Everything the collate kernel and the "_dyn" kernels need about a batch is in here (hodata/SpData.py:60-77's increments
+    are the running offsets)."""
+    g, nf = ids.shape[0], h_len.shape[0]
+    optr = np.zeros((nf, g + 1), dtype=np.int64)
+    np.cumsum(h_len[:, ids], axis=1, out=optr[:, 1:])
+    if np.any(optr[:, -1] > cap_vec):
+        return None
+    lay = np.zeros((2 + 2 * nf, g + 1), dtype=np.int64)
+    lay[0, :g] = ids
+    lay[1] = np.arange(g + 1)
+    lay[2:2 + nf] = optr
+    lay[2 + nf:, :g] = h_ptr[:, ids]
+    return lay
+
+
 class BatchSlot:
     """static buffers for one mini-batch of exactly `n_graphs` graphs of `store` + the datadict over them (`.datadict`).
 
@@ -287,22 +306,8 @@ class BatchSlot:
     # ------------------------------------------------------------------
     def layout(self, ids: np.ndarray) -> Optional[np.ndarray]:
         """(rows, G + 1) int64 upload of the batch `ids`, or None when it does not fit the capacities"""
-        g = self.g
-        assert ids.shape == (g,), f"a slot of {g} graphs was given {ids.shape[0]}"
-        sel = self._h_len[:, ids]                                        # (F, G)
-        optr = np.zeros((len(self.fams), g + 1), dtype=np.int64)
-        np.cumsum(sel, axis=1, out=optr[:, 1:])
-        if np.any(optr[:, -1] > self._cap_vec):
-            return None
-        lay = np.zeros((len(self.row_of), g + 1), dtype=np.int64)
-        lay[self.row_of["ids"], :g] = ids
-        lay[self.row_of["arange"]] = np.arange(g + 1)
-        nf = len(self.fams)
-        r0 = self.row_of[("optr", self.fams[0])]
-        lay[r0:r0 + nf] = optr
-        r1 = self.row_of[("start", self.fams[0])]
-        lay[r1:r1 + nf, :g] = self._h_ptr[:, ids]
-        return lay
+        assert ids.shape == (self.g,), f"a slot of {self.g} graphs was given {ids.shape[0]}"
+        return batch_layout(self._h_len, self._h_ptr, self._cap_vec, ids)
 
     def fits(self, graph_ids) -> bool:
         ids = _as_ids(graph_ids, self.store.num_graphs)

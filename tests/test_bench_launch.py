@@ -104,7 +104,7 @@ def test_bench_two_ranks_share_one_gpu(global_stream):
     if global_stream:
         assert c["batch"] == "global stream sharded by message count" and g0 != 256 and 200 < g0 < 312   # balanced by messages, not graphs
     else:
-        assert c["batch"] == "one independent batch per rank" and g0 == g1 == 256
+        assert c["batch"] == "one independent batch stream per rank" and g0 == g1 == 256
     elapsed = line["ms_per_step"] * steps / 1e3
     assert abs(elapsed - max(t0, t1)) < 1e-6 * elapsed                   # the slowest rank's clock
     assert abs(line["value"] - (g0 + g1) * steps / elapsed) < 1e-6 * line["value"]
@@ -114,6 +114,10 @@ def test_bench_two_ranks_share_one_gpu(global_stream):
     assert ov["host_ms_first_issue_before_backward_end"] > 0
     assert ov["device_ms_first_collective_start_before_backward_end"] > 0
     assert line["roofline"]["frac"] > 0 and "regimes" not in line
+    # the wording the driver's scaling table is built from, and the regime: a new batch every step from a resident store
+    assert line["scaling"] == "weak" and line["config"]["parallelism"] == "graph-sharded data parallel x2"
+    assert line["config"]["batch"] == "fresh every step" and line["config"]["store_graphs"] == (1024 if global_stream else 512)
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1            # rank 1 (and every library banner) stays off stdout
 
 
 def test_ranks_share_gpu_refuses_rccl():

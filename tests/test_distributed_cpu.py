@@ -158,3 +158,61 @@ def test_global_stream_sharded_by_message_count_equals_single_process():
     torch.nn.functional.l1_loss(torch.from_numpy(hb.y).unsqueeze(-1), model(*args)).backward()
     sync.sync()
     torch.testing.assert_close(flat0, sync.flat, rtol=1e-5, atol=1e-6)
+
+
+def _accum_worker(rank, world, port, ret):
+    """gradient accumulation over two micro-batches with overlap: the first backward runs under no_sync(); rank 1 starts from
+    DIFFERENT parameters, so the flat broadcast must bring them in line first"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x, y = _data()
+    lo, hi = shard_ranges(np.ones(40), world)[rank]
+    mid = (lo + hi) // 2
+    model = _model()
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)                                   # not rank 0's parameters
+    sync = FlatGradSync(model.parameters(), overlap=True, buckets=2)
+    sync.broadcast_params(0)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    for _ in range(3):
+        sync.zero_grad()
+        with sync.no_sync():
+            (torch.nn.functional.mse_loss(model(x[lo:mid]), y[lo:mid], reduction="sum") / 20.0).backward()
+        (torch.nn.functional.mse_loss(model(x[mid:hi]), y[mid:hi], reduction="sum") / 20.0).backward()
+        sync.sync()
+        opt.step()
+    ret[f"params{rank}"] = [p.detach().clone() for p in model.parameters()]
+    if rank == 0:
+        ret["calls"], ret["broadcasts"] = sync.allreduce_calls, sync.broadcast_calls
+    # without no_sync() the second backward is refused, with a pointer to it
+    sync.zero_grad()
+    model(x[lo:mid]).sum().backward()
+    try:
+        model(x[mid:hi]).sum().backward()
+        ret[f"raised{rank}"] = False
+    except RuntimeError as e:
+        ret[f"raised{rank}"] = "no_sync" in str(e)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_under_no_sync_and_the_flat_broadcast():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_accum_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["calls"] == 6 and ret["broadcasts"] == 1              # two ranges per step; ONE broadcast for all (f32) parameters
+    assert ret["raised0"] and ret["raised1"]
+    x, y = _data()
+    model = _model()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    for _ in range(3):
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(model(x), y, reduction="sum").div(40.0).backward()
+        opt.step()
+    for a, b, c in zip(ret["params0"], ret["params1"], model.parameters()):
+        torch.testing.assert_close(a, c.detach(), rtol=1e-5, atol=1e-6)
+        assert torch.equal(a, b)

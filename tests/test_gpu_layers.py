@@ -144,8 +144,15 @@ def test_ngnn_model_matches_reference_model(dev):
             np.testing.assert_allclose(N(after[k[6:]]), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
 
 
-BF16_TRAJECTORY_RTOL = 0.015     # measured 1.06 % after 6 steps (bf16 activations against the f32 port); round 3 allowed 2 %
+# free-running bf16 trajectory against the f32 port: six AdamW steps amplify rounding noise (Adam's early updates are ~ lr * sign(g): a
+# gradient component at the noise level flips a whole +-lr update), so the figure moves with any change of a summation order --
+# measured 1.06 % in round 4, 1.89 % after round 5 re-dealt the BatchNorm / fold partitions.  It catches a run that stops following
+# the optimizer (round 3's stale 16-bit copies: > 10 %), not a 1 % drift; THAT is the teacher-forced test below.
+BF16_TRAJECTORY_RTOL = 0.03
 BF16_DELTA_COSINE = 0.95          # measured 0.968 (ea_encoder.weight, the smallest over the weight matrices)
+# teacher-forced (both sides take every step from the SAME parameters): what bf16 activations cost in ONE step, no amplification
+BF16_STEP_LOSS_RTOL = 0.006
+BF16_STEP_GRAD_COSINE = 0.985
 
 
 @pytest.mark.parametrize("dtype,optimizer", [(None, "adamw_fused"), (None, "adamw_foreach"), (None, "sgd_fused"),
@@ -218,6 +225,61 @@ def test_ngnn_training_trajectory_matches_the_host_port(dev, dtype, optimizer):
                 worst = min(worst, (cos, k))
         print(f"bf16 trajectory: max relative loss difference {rel:.4f}, smallest displacement cosine {worst[0]:.4f} ({worst[1]})")
         assert worst[0] > BF16_DELTA_COSINE, f"parameter displacement of {worst[1]} deviates from the host port's: cosine {worst[0]:.3f}"
+
+
+def test_ngnn_bf16_steps_from_the_same_parameters_match_the_host_port(dev):
+    """The tight half of the bf16 parity claim (the free-running trajectory 'catches a frozen arena, not a 1 %
+    drift').  Six steps, TEACHER-FORCED: before every step the device model takes the host port's current parameters and buffers,
+    so both sides differentiate at the same point and rounding noise is not amplified by the optimizer.  Per step: the loss within
+    BF16_STEP_LOSS_RTOL of the f32 port's, and the gradient of every weight matrix within cosine BF16_STEP_GRAD_COSINE of the port's
+    (bf16 activations, f32 masters); the BatchNorm running statistics after the step within 1 %."""
+    from oracle import aten_port as P
+    from pygho_amd import _ops, synth
+    from pygho_amd.ngnn import SpModel
+    key = "X___X___1___A___0"
+    hb = synth.make_batch(48, "zinc", seed=23)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    torch.manual_seed(4)
+    model = SpModel(1, 3, 64, act_dtype=torch.bfloat16)
+    port = P.NGNNPort(64, 3)
+    port.load_state_dict({P.port_key(k): v.clone() for k, v in model.state_dict().items()}, strict=True)
+    model = model.to(dev).train()
+    port.train()
+    dd = synth.to_datadict(hb, dev)
+    host = (t(hb.x), t(hb.edge_attr), t(hb.tupleid), t(hb.tuplefeat), t(hb.acd[key]), t(hb.batch), hb.num_graphs)
+    y_host = t(hb.y).unsqueeze(-1)
+    opt_h = torch.optim.AdamW(port.parameters(), lr=1e-3)
+    names = {P.port_key(k): k for k in model.state_dict()}
+    worst_loss, worst_cos = 0.0, (1.0, None)
+    for step in range(6):
+        with torch.no_grad():                                   # the device model starts the step where the port stands
+            sd = model.state_dict()
+            for pk, v in port.state_dict().items():
+                sd[names[pk]].copy_(v.to(dev))
+        _ops.invalidate_cast_arenas()
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = model(dd)
+        loss = torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float())
+        loss.backward()
+        opt_h.zero_grad()
+        lh = torch.nn.functional.l1_loss(y_host, port(*host))
+        lh.backward()
+        worst_loss = max(worst_loss, abs(float(loss) - float(lh)) / abs(float(lh)))
+        got = {P.port_key(k): p.grad.detach().cpu().double() for k, p in model.named_parameters() if p.grad is not None}
+        for k, p in port.named_parameters():
+            if p.grad is not None and p.dim() == 2 and p.numel() >= 1024:
+                a, b = got[k].flatten(), p.grad.double().flatten()
+                worst_cos = min(worst_cos, (float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)), f"{k} step {step}"))
+        after = {P.port_key(k): v.detach().cpu() for k, v in model.state_dict().items() if "running" in k}
+        for k, v in port.state_dict().items():
+            if "running" in k:
+                scale = max(float(v.abs().max()), 1e-3)
+                np.testing.assert_allclose(after[k].numpy() / scale, v.numpy() / scale, rtol=0, atol=1e-2, err_msg=f"{k} step {step}")
+        opt_h.step()
+    print(f"bf16 teacher-forced: max relative loss difference {worst_loss:.5f}, smallest gradient cosine {worst_cos[0]:.5f} ({worst_cos[1]})")
+    assert worst_loss < BF16_STEP_LOSS_RTOL, f"per-step loss (bf16 activations, same parameters): {worst_loss:.5f}"
+    assert worst_cos[0] > BF16_STEP_GRAD_COSINE, f"gradient of {worst_cos[1]}: cosine {worst_cos[0]:.4f} against the f32 port"
 
 
 def _sun_check(layer, g, name, A_of, X_of, av, xv, dd, dev, fn="forward", amask=1.0):

@@ -649,29 +649,58 @@ def test_by_edge_scatter_edge_cases(dev, case, monkeypatch):
         assert torch.equal(got, ref), f"{case}: {int((got != ref).sum())} of {got.numel()} elements differ (addend: {addend is not None})"
 
 
-def test_by_edge_scatter_plan_is_built_only_for_recurring_patterns(dev, monkeypatch):
-    """planning costs ~1.3 ms and three host reads, a launch saves ~15 us: the dispatcher runs the gather form until a pattern has been
-    used SEG_SCATTER_BUILD_AFTER times and only then plans it (explicit `scatter_plan(plan)` / `SpModel.prepare` / the graph store build
-    or install at once) -- same bits before and after"""
+def test_by_edge_scatter_plan_is_built_only_on_request(dev, monkeypatch):
+    """round 5 policy: the dispatcher never plans on its own (round 4 planned a pattern after 12 by-edge launches -- hidden state that made
+    WHICH kernel ran, and whether a step read back from the device, depend on a batch's history).  A plan exists when the caller asked
+    (`scatter_plan(plan)` / `SpModel.prepare`) or the batch came with one (`DeviceGraphStore.collate`); until then the gather form runs,
+    however often the pattern comes back, with no planner fetch -- and both forms return the same bits.  Building it takes two host
+    reads (block count; chunk total + verdicts) and no ATen scan (`pygho_block_cuts`: cuts bit-identical to the cummax / cummin rule)."""
     from pygho_amd import _ops, synth
     from pygho_amd import segment as S
     monkeypatch.setattr(S, "SEG_SCATTER_MIN_MESSAGES", 0)
-    monkeypatch.setattr(S, "SEG_SCATTER_BUILD_AFTER", 3)
     hb = synth.make_batch(200, "zinc", seed=12)
     acd = torch.from_numpy(hb.acd["X___X___1___A___0"]).to(dev)
     nt, ne = hb.num_tuples, hb.num_edges
     plan = _ops.message_plan(acd, nt, nt, ne)
     g = torch.randn(nt, 128, device=dev).to(torch.bfloat16)
     h = torch.randn(nt, 128, device=dev).to(torch.bfloat16)
-    outs, kinds = [], []
-    for _ in range(5):
+
+    def run():
         timer = _ops.LaunchTimer()
         with timer:
-            outs.append(S.by_edge_product(plan, g, h))
+            out = S.by_edge_product(plan, g, h)
         torch.cuda.synchronize()
-        kinds.append(any(",scatter" in k for k in timer.summary()))
-    assert kinds == [False, False, False, True, True]
-    assert all(torch.equal(outs[0], o) for o in outs[1:])
+        return out, any(",scatter" in k for k in timer.summary())
+    f0 = _ops.FETCHES[0]
+    outs = [run() for _ in range(20)]
+    assert not any(kind for _, kind in outs) and _ops.FETCHES[0] == f0           # 20 uses: still the gather form, nothing read back
+    sp = S.scatter_plan(plan)                                                     # the caller asks
+    assert sp is not None and _ops.FETCHES[0] == f0 + 2
+    # the device cut finder against the rule it restates: a block starts where max d[:m] < min d[m:]
+    d = plan.d32
+    pm = torch.cummax(d, 0).values
+    sm = torch.flip(torch.cummin(torch.flip(d, [0]), 0).values, [0])
+    cut = torch.nonzero(pm[:-1] < sm[1:]).flatten() + 1
+    want = torch.cat([cut.new_zeros(1), cut, cut.new_full((1,), plan.m)]).to(torch.int32)
+    assert torch.equal(S.block_cuts(d), want) and sp.n_blocks == want.numel() - 1 == 200
+    after, kind = run()
+    assert kind and torch.equal(after, outs[0][0]) and all(torch.equal(outs[0][0], o) for o, _ in outs[1:])
+
+
+def test_message_plan_range_check_rides_on_the_narrowing_pass(dev):
+    """an operand index outside its operand's rows (the reference's gather raises IndexError, Spspmm.py:309-311) is reported by the
+    plan's construction -- through the flag of the narrowing kernel (`pygho_narrow_i64_i32_bounded`), not a separate reduction"""
+    from pygho_amd import _ops, synth
+    hb = synth.make_batch(20, "zinc", seed=13)
+    nt, ne = hb.num_tuples, hb.num_edges
+    good = torch.from_numpy(hb.acd["X___X___1___A___0"]).to(dev)
+    _ops.message_plan(good, nt, nt, ne)
+    for row, val in ((1, nt), (2, ne), (1, -1), (2, -5)):
+        bad = good.clone()
+        bad[row, 7] = val
+        with pytest.raises(ValueError, match="acd operand index out of range"):
+            _ops.message_plan(bad, nt, nt, ne)
+            _ops.check_deferred_errors()
 
 
 def test_by_edge_scatter_falls_back_outside_its_limits(dev):
@@ -942,6 +971,41 @@ def test_cast_arena_follows_the_optimizer(dev, opt_kind):
     np.testing.assert_allclose(with_arena, without, rtol=0.05, atol=0.02)
 
 
+def test_cast_arena_sees_updates_that_bypass_version_counters(dev):
+    """parameter updates through a `.data` alias (EMA, weight tying, manual SGD on .data, a broadcast into .data) move
+    neither the parameter's version counter nor the optimizer hook; the lazily refreshed arena of round 4 then served STALE 16-bit
+    weights in training forwards, silently.  Every forward now re-casts (one multi-tensor launch): the output follows the update."""
+    from pygho_amd import _ops, synth
+    from pygho_amd.ngnn import SpModel
+    assert not _ops.ARENA_LAZY
+    dd = synth.to_datadict(synth.make_batch(32, "zinc", seed=5), dev)
+    torch.manual_seed(0)
+    model = SpModel(1, 2, 64, act_dtype=torch.bfloat16).to(dev)
+    model.eval()
+
+    def fwd(grad):
+        with torch.set_grad_enabled(grad), torch.autocast("cuda", dtype=torch.bfloat16):
+            return model(dd).float().detach().clone()
+    for grad in (True, False):
+        before = fwd(grad)
+        versions = [p._version for p in model.parameters()]
+        with torch.no_grad():
+            for p in model.parameters():
+                p.data.mul_(0.5)                                       # behind every counter and hook
+        assert [p._version for p in model.parameters()] == versions
+        after = fwd(grad)
+        arena = model.__dict__["_pygho_cast_arena"]
+        assert all(torch.equal(v, p.detach().to(torch.bfloat16)) for v, p in zip(arena.views, arena.params)), "stale 16-bit copy"
+        assert not torch.equal(before, after)
+        saved = _ops.USE_CAST_ARENA
+        try:
+            _ops.USE_CAST_ARENA = False
+            want = fwd(grad)
+        finally:
+            _ops.USE_CAST_ARENA = saved
+        assert torch.equal(after, want)
+
+
 def _three_dim_pattern(rng, shape, dims, nnz):
     rows = set()
     a, b = dims
@@ -979,8 +1043,9 @@ def test_partial_diag_to_dense(dev, dims, shape):
 
 def test_two_forwards_before_one_backward_with_the_cast_arena(dev):
     """loss = f(model(b1)) + f(model(b2)) (siamese / contrastive use, or a grad-enabled validation pass between forward and
-    backward): autograd has saved the arena's 16-bit views in the first pass, so the second pass must not rewrite them in place when
-    no parameter changed -- backward would raise 'modified by an inplace operation'.  The gradient equals the sum of the two
+    backward): autograd has saved the arena's 16-bit views in the first pass, so the second pass's re-cast must not move their
+    version counters -- backward would raise 'modified by an inplace operation'.  (Round 5: every forward re-casts, through aliases
+    with their own version counters; with unchanged parameters it writes the same bits.)  The gradient equals the sum of the two
     single-pass gradients."""
     from pygho_amd import synth
     from pygho_amd.ngnn import SpModel
@@ -1006,7 +1071,7 @@ def test_two_forwards_before_one_backward_with_the_cast_arena(dev):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         model(d2)                                   # a grad-enabled pass whose result is dropped
     l2 = loss_of(d2)
-    assert [v._version for v in arena.views] == versions, "the arena was rewritten although no parameter changed"
+    assert [v._version for v in arena.views] == versions, "the re-cast moved the version counters of views autograd has saved"
     (l1 + l2).backward()
     both = [p.grad for p in model.parameters() if p.grad is not None]
     assert len(both) == len(singles[0]) == len(singles[1])
@@ -1625,27 +1690,34 @@ def test_collated_batch_needs_no_plan_building(dev):
     step(d2)                                                            # the three-launch backward still trains
 
 
-def test_table_grad_plans_large_recurring_patterns(dev):
-    """policy of the small-table gradient: a large index pattern (>= TABLE_GRAD_PLAN_ROWS rows) that keeps coming back is planned
-    after TABLE_GRAD_PLAN_AFTER plan-free uses (the planned hierarchy is faster there); small ones never are; the gradients of both
-    routes agree to f32 accumulation error."""
+def test_table_grad_route_does_not_depend_on_history(dev):
+    """policy of the small-table gradient (round 5): which route runs is a pure function of the call -- the plan-free kernel unless
+    the CALLER built / installed a grouping of the index array AND the pattern is large -- never of how often a pattern was seen
+    (round 4 planned a large recurring pattern "after 3 uses", so step 3 and step 4 of a resident-batch run differed bitwise and a
+    resumed run diverged from a continuous one).  Eight uses of the same pattern: no plan appears, bit-identical gradients; an
+    explicitly built plan switches a large pattern to the planned route, whose result agrees to f32 accumulation error."""
     from pygho_amd import _ops
     n_table, d = 16, 128
-    for m, planned_expected in ((_ops.TABLE_GRAD_PLAN_ROWS + 5, True), (4096, False)):
+    for m in (_ops.TABLE_GRAD_PLAN_ROWS + 5, 4096):
         idx = torch.randint(0, n_table, (m,), device=dev)
         g = torch.randn(m, d, device=dev).to(torch.bfloat16)
         grads = []
-        for use in range(_ops.TABLE_GRAD_PLAN_AFTER + 2):
+        for use in range(8):
             table = torch.randn(n_table, d, device=dev).to(torch.bfloat16).requires_grad_(True)
             _ops.gather_rows(table, idx).backward(g)
             grads.append(table.grad)
-            has_plan = ("scatter", n_table, idx._version) in getattr(idx, "_pygho_plans", {})
-            assert has_plan == (planned_expected and use >= _ops.TABLE_GRAD_PLAN_AFTER), (m, use, has_plan)
+            assert ("scatter", n_table, idx._version) not in getattr(idx, "_pygho_plans", {}), (m, use)
+        assert all(torch.equal(grads[0], got) for got in grads[1:])
+        _ops.cached_plan(idx, n_table, "scatter")                       # the caller's explicit plan
+        table = torch.randn(n_table, d, device=dev).to(torch.bfloat16).requires_grad_(True)
+        _ops.gather_rows(table, idx).backward(g)
+        planned = table.grad
         ref = torch.zeros(n_table, d, dtype=torch.float64, device=dev).index_add_(0, idx, g.double())
         mag = torch.zeros(n_table, d, dtype=torch.float64, device=dev).index_add_(0, idx, g.double().abs())
-        for got in grads:
+        for got in (grads[0], planned):
             assert bool(((got.double() - ref).abs() <= 64 * 2.0 ** -24 * mag + 2.0 ** -8 * ref.abs() + 1e-30).all())
-        assert torch.equal(grads[0], grads[1])
+        if m < _ops.TABLE_GRAD_PLAN_ROWS:
+            assert torch.equal(planned, grads[0])                       # small patterns stay on the plan-free kernel
 
 
 def test_device_collate_edge_cases(dev):

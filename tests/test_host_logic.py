@@ -196,3 +196,78 @@ def test_store_mirror_verdict_per_graph():
     empty = synth.GraphRecord(3, r.x[:3], r.edge_index[:, :0], r.edge_attr[:0], r.tupleid[:, :0], r.tuplefeat[:0])
     pos, ok = _mirror_of(empty, 16)
     assert ok and pos.size == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fixed-capacity batch slots (pygho_amd.slots): the host side -- capacities, the per-batch upload, the store's validation
+# ---------------------------------------------------------------------------------------------------------------------
+def test_batch_layout_is_the_running_offsets_of_the_selected_graphs():
+    """the upload of a slot: per family the exclusive running offsets of the selected graphs (= the increments of
+    hodata/SpData.py:60-77), their first store columns, the batch's true totals in entry G; None when a capacity is exceeded"""
+    from pygho_amd.slots import batch_layout
+    rng = np.random.default_rng(0)
+    n_store, g = 50, 7
+    h_len = rng.integers(0, 9, size=(3, n_store)).astype(np.int64)
+    h_ptr = np.concatenate((np.zeros((3, 1), dtype=np.int64), np.cumsum(h_len, axis=1)[:, :-1]), axis=1)
+    ids = rng.permutation(n_store)[:g]
+    caps = np.asarray([100, 100, 100], dtype=np.int64)
+    lay = batch_layout(h_len, h_ptr, caps, ids)
+    assert lay.shape == (2 + 6, g + 1) and lay.dtype == np.int64
+    assert np.array_equal(lay[0, :g], ids) and np.array_equal(lay[1], np.arange(g + 1))
+    for f in range(3):
+        run = 0
+        for s, gid in enumerate(ids):
+            assert lay[2 + f, s] == run and lay[5 + f, s] == h_ptr[f, gid]
+            run += h_len[f, gid]
+        assert lay[2 + f, g] == run                                   # the true total, what the "_dyn" kernels read
+    tight = h_len[:, ids].sum(axis=1)
+    assert batch_layout(h_len, h_ptr, tight, ids) is not None
+    assert batch_layout(h_len, h_ptr, tight - np.asarray([0, 1, 0]), ids) is None
+
+
+def test_slot_capacities_are_distinct_and_cover_random_batches():
+    from types import SimpleNamespace
+    from pygho_amd.slots import slot_capacities
+    rng = np.random.default_rng(1)
+    lens = {"node": rng.integers(9, 38, 4000), "edge": rng.integers(20, 90, 4000), "tup": rng.integers(100, 400, 4000),
+            ("acd", "k"): rng.integers(200, 900, 4000), ("sc", "k"): rng.integers(3, 9, 4000)}
+    store = SimpleNamespace(h_len=lens)
+    for g in (8, 128, 1024):
+        caps = slot_capacities(store, g)
+        assert set(caps) == {"node", "edge", "tup", ("acd", "k")}            # (scatter chunks have no capacity: the slot runs the gather form)
+        vals = list(caps.values())
+        assert len(set(vals)) == len(vals) and g not in vals and all(v % 64 == 0 for v in vals)
+        worst = {f: np.sort(lens[f])[::-1][:g].sum() for f in caps}
+        assert all(caps[f] <= worst[f] + 64 * len(vals) for f in caps)
+        misses = 0
+        for _ in range(300):
+            ids = rng.permutation(4000)[:g]
+            misses += any(lens[f][ids].sum() > caps[f] for f in caps)
+        assert misses == 0                                                   # 4.5 sigma: one batch in ~10^5 would overflow
+        # and the capacity is close to the typical batch (the pad rows are wasted launches' width)
+        assert all(caps[f] <= 1.35 * g * lens[f].mean() + 128 for f in caps) or g == 8
+
+
+def test_graph_store_validation_catches_what_the_per_batch_flags_caught():
+    """collated batches skip the per-batch range flags because 'the store checked them' -- so the store has to."""
+    import copy
+    from pygho_amd import synth
+    from pygho_amd.collate import _validate_records
+    rng = np.random.default_rng(2)
+    key = "X___X___1___A___0"
+    recs = [synth.make_graph(rng, "zinc", 3, (key,)) for _ in range(4)]
+    _validate_records(recs, [key])
+
+    def broken(mutate):
+        bad = copy.deepcopy(recs)
+        mutate(bad[2])
+        with pytest.raises(ValueError, match="graph 2"):
+            _validate_records(bad, [key])
+    broken(lambda r: r.x.__setitem__(0, -1))
+    broken(lambda r: r.edge_attr.__setitem__(1, -3))
+    broken(lambda r: r.tuplefeat.__setitem__(0, -1))
+    broken(lambda r: r.edge_index.__setitem__((0, 0), r.num_nodes))
+    broken(lambda r: r.tupleid.__setitem__((1, 2), -1))
+    broken(lambda r: r.acd[key].__setitem__((1, 0), r.tupleid.shape[1]))
+    broken(lambda r: r.acd[key].__setitem__((2, 0), r.edge_index.shape[1]))
+    broken(lambda r: setattr(r, "x", r.x[:-1]))
