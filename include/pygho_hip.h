@@ -549,15 +549,20 @@ int pygho_bn_act_bwd(void* dx, float* sum_dz, float* sum_dz_xhat, const void* x,
                      const float* mean, const float* invstd, const float* w, const float* b, int64_t m,
                      int64_t c, int act, int training, void* workspace, int dtype, float* sum_dx, void* stream);
 
-/* Tuple-wise linear map with the neighbouring passes fused into its epilogue (bf16 / f16, d = 64 or 128):
+/* Tuple-wise linear map with the neighbouring passes fused into its epilogue (bf16 / f16, d = 64, 128 or 256):
  *   out[m, d] = in[m, d] . wl[d, d]^T (+ bias[d]) (+ addend[m, d])            wl row-major, row = output channel
  *   pygho/honn/utils.py:126-131 (the Linear of every MLP, applied per tuple, Conv.py:56) and its input gradient
  *   (wl = W^T, addend = the residual gradient of example/minimal.py:76-79).
  * stats_ws (nullable): pygho_rowblock_linear_blocks(m) x 2 x d floats receive the per-block sums of (out - shift) and
  *   (out - shift)^2 of the rounded output, to be finalised by pygho_bn_finalize -- the BatchNorm statistics pass is
  *   folded into the GEMM epilogue.  f32 accumulation on the matrix cores, one rounding of acc + bias; the addend is
- *   added to the rounded product (as product-then-add would). */
+ *   added to the rounded product (as product-then-add would).
+ *   d = 256 (I2Conv at BASELINE config 5's hidden size, Conv.py:107-147): W is 128 KB, so a row tile is formed by TWO workgroups, one
+ *   per half of the output columns (W half resident in LDS, the tile's rows read by both -- the second time out of L2);
+ *   pygho_rowblock_linear_slots(m, d) = rows of the per-slot workspaces of this and the two following entry points at width d
+ *   (= pygho_rowblock_linear_blocks(m) for d <= 128). */
 int pygho_rowblock_linear_blocks(int64_t m);
+int pygho_rowblock_linear_slots(int64_t m, int64_t d);
 int pygho_rowblock_linear(void* out, const void* in, const void* wl, const void* bias, const void* addend,
                           float* stats_ws, const float* shift, int64_t m, int64_t d, int dtype, void* stream);
 /* The same launch with the statistics' shift taken inside the kernel: shift_out[n] = row 0 of the output (bias + in[0] . wl[n] +
@@ -615,6 +620,19 @@ int pygho_bn_act_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* x, cons
  * workspace of _bwd_sums: pygho_rowblock_linear_blocks(m) x 2 x d floats. */
 int pygho_rowblock_linear_bn_act(void* out, const void* in, const void* wl, const void* bias, const float* scale,
                                  const float* shift, const void* addend, int64_t m, int64_t d, int act, int dtype, void* stream);
+/* d = 256 has no one-workgroup backward (W, W^T and a 256 x 256 f32 weight-gradient accumulator do not fit a CU): its backward is
+ *   pygho_rowblock_linear_bwd_sums      the two channel sums (Y recomputed)                      in, gh
+ *   pygho_rowblock_linear_bwd_apply     gpre = BatchNorm / act backward of (Y, gh) (Y recomputed; the apply half of pygho_bn_act_bwd,
+ *                                       same formula and rounding) + optionally its column sums (the Linear's bias gradient)
+ *                                                                                                 in, gh -> gpre
+ *   pygho_rowblock_linear               gx = gpre . W + addend (wl = W^T, addend = the residual gradient)   gpre, addend -> gx
+ *   and the library's GEMM for dW = gpre^T x.  pygho_rowblock_linear_bwd_apply works at every supported width; m_dev (nullable): the
+ *   row count on the device (see the "_dyn" forms below).  workspace: pygho_rowblock_linear_slots(m_cap, d) x 2 x d + d floats,
+ *   needed only with colsum. */
+int pygho_rowblock_linear_bwd_apply(void* gpre, float* colsum, const void* in, const void* wl, const void* bias, const void* gh,
+                                    const float* mean, const float* invstd, const float* w, const float* b, const float* sum_dz,
+                                    const float* sum_dz_xhat, int64_t m_cap, const int32_t* m_dev, int64_t d, int act, int training,
+                                    float* workspace, int dtype, void* stream);
 int pygho_rowblock_linear_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* in, const void* wl, const void* bias,
                                    const void* gh, const float* mean, const float* invstd, const float* w, const float* b,
                                    int64_t m, int64_t d, int act, float* workspace, int dtype, void* stream);

@@ -103,6 +103,8 @@ PROTOTYPES = {
     "pygho_bn_act_fwd_add": (I, [P, P, P, P, P, L, L, I, I, P]),
     "pygho_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, P, I, P, P]),
     "pygho_rowblock_linear_blocks": (I, [L]),
+    "pygho_rowblock_linear_slots": (I, [L, L]),
+    "pygho_rowblock_linear_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, P, I, P]),
     "pygho_rowblock_linear": (I, [P, P, P, P, P, P, P, L, L, I, P]),
     "pygho_rowblock_linear_autoshift": (I, [P, P, P, P, P, P, P, L, L, I, P]),
     "pygho_bn_bwd_linear": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, P]),

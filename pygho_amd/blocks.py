@@ -450,9 +450,12 @@ USE_PAIR_COMBINE = True   # SUNConv on the padded layout: fused node-view / reco
 USE_NODE_LEVEL_LINEAR = os.environ.get("PYGHO_NODE_LEVEL_LINEAR", "1") != "0"   # GNNAKConv (sparse): the 3 d -> d map applied before the broadcasts
 
 
+USE_ROWBLOCK_256 = os.environ.get("PYGHO_ROWBLOCK_256", "1") != "0"     # width 256 on the column-split streaming kernels (A/B switch)
+
+
 def rowblock_linear_supported(x: Tensor, out_features: int) -> bool:
     return (USE_ROWBLOCK_LINEAR and x.is_cuda and x.dim() == 2 and x.dtype in (torch.bfloat16, torch.float16) and x.shape[1] == out_features
-            and out_features in (64, 128) and x.shape[0] >= 8192)
+            and (out_features in (64, 128) or (out_features == 256 and USE_ROWBLOCK_256)) and x.shape[0] >= 8192)
 
 
 def rowblock_linear(x: Tensor, wl: Tensor, bias: Optional[Tensor] = None, addend: Optional[Tensor] = None,
@@ -468,7 +471,7 @@ def rowblock_linear(x: Tensor, wl: Tensor, bias: Optional[Tensor] = None, addend
     out = torch.empty_like(x) if store else None
     ws = None
     if stats_shift is not None:
-        nblk = int(lib().pygho_rowblock_linear_blocks(m))
+        nblk = int(lib().pygho_rowblock_linear_slots(m, d))
         ws = torch.empty((nblk, 2, d), dtype=torch.float32, device=dev)
     if addend is not None:
         addend = addend.contiguous()
@@ -513,7 +516,7 @@ def rowblock_linear_bwd_sums(x: Tensor, wl: Tensor, bias: Optional[Tensor], gh: 
     m, d = x.shape
     s1 = torch.empty(d, dtype=torch.float32, device=dev)
     s2 = torch.empty(d, dtype=torch.float32, device=dev)
-    nblk = int(lib().pygho_rowblock_linear_blocks(m))
+    nblk = int(lib().pygho_rowblock_linear_slots(m, d))
     ws = torch.empty((nblk, 2, d), dtype=torch.float32, device=dev)
     m_dev = dyn_rows(m)
     if m_dev is not None:
@@ -527,6 +530,27 @@ def rowblock_linear_bwd_sums(x: Tensor, wl: Tensor, bias: Optional[Tensor], gh: 
     return s1, s2
 
 
+def rowblock_linear_bwd_apply(x: Tensor, wl: Tensor, bias: Optional[Tensor], gh: Tensor, saved, sums, act: str, training: bool,
+                              want_colsum: bool):
+    """(gpre, column sums of gpre or None): the BatchNorm + activation backward of pre = x @ wl^T + bias, recomputed (same bits as the
+    forward's), given the two channel sums -- the apply half of `_bn_backward` without a stored pre-activation.  Width 256 builds its
+    backward from this pass (`bn_bwd_linear`)."""
+    mean, invstd, w32, b32, _ws = saved
+    s1, s2 = sums
+    dev = require_device(x, wl, bias, gh)
+    m, d = x.shape
+    gpre = torch.empty_like(x)
+    cs = ws = None
+    if want_colsum:
+        nblk = int(lib().pygho_rowblock_linear_slots(m, d))
+        cs = torch.empty(d, dtype=torch.float32, device=dev)
+        ws = torch.empty(nblk * 2 * d + d, dtype=torch.float32, device=dev)
+    check(lib().pygho_rowblock_linear_bwd_apply(ptr(gpre), ptr(cs), ptr(x), ptr(wl.contiguous()), ptr(bias), ptr(gh.contiguous()), ptr(mean),
+                                                ptr(invstd), ptr(w32), ptr(b32), ptr(s1), ptr(s2), m, ptr(dyn_rows(m)), d, ACT_CODE[act],
+                                                1 if training else 0, ptr(ws), dtype_code(x), stream_ptr(dev)), "rowblock_linear_bwd_apply")
+    return gpre, cs
+
+
 def sum_blocks(partials: Tensor) -> Tensor:
     """(n_blocks, ...) f32 per-workgroup partial results -> their sum over the first dim (one deterministic kernel)."""
     dev = require_device(partials)
@@ -534,6 +558,21 @@ def sum_blocks(partials: Tensor) -> Tensor:
     out = torch.empty(partials.shape[1:], dtype=torch.float32, device=dev)
     check(lib().pygho_sum_blocks(ptr(out), ptr(partials), partials.shape[0], out.numel(), stream_ptr(dev)), "sum_blocks")
     return out
+
+
+_MM_OUT = [None]
+
+
+def _mm_out_dtype_ok() -> bool:
+    """does torch.mm take out_dtype here (an f32 weight gradient straight from 16-bit operands, no cast pass)?"""
+    if _MM_OUT[0] is None:
+        try:
+            a = torch.zeros((8, 8), dtype=torch.bfloat16, device="cuda")
+            torch.mm(a, a, out_dtype=torch.float32)
+            _MM_OUT[0] = True
+        except (TypeError, RuntimeError):
+            _MM_OUT[0] = False
+    return _MM_OUT[0]
 
 
 def bn_bwd_sums(pre: Tensor, gh: Tensor, saved, act: str):
@@ -568,6 +607,15 @@ def bn_bwd_linear(pre: Optional[Tensor], gh: Tensor, saved, training: bool, act:
         if sums is None:
             sums = rowblock_linear_bwd_sums(x, w, lin_bias, gh, saved, act)
         s1, s2 = sums
+        if c == 256:
+            # no one-workgroup backward at this width (W, W^T and a 256 x 256 f32 accumulator do not fit a CU): gpre from a third
+            # recomputing pass, gx = gpre W + addend on the forward kernel (the residual gradient rides in its epilogue), dW from the
+            # library (one 256 x 256 output tile, K = m: 2 streams).  10 streams against 12 for the library path + separate passes
+            gpre, cs = rowblock_linear_bwd_apply(x, w, lin_bias, gh, saved, sums, act, training, want_colsum)
+            gx, _ = rowblock_linear(gpre, w.t().contiguous(), None, addend=None if addend is None else addend.contiguous())
+            require_static_rows(m, "the library weight-gradient GEMM of a width-256 block")
+            gw = torch.mm(gpre.t(), x, out_dtype=torch.float32) if _mm_out_dtype_ok() else (gpre.t() @ x).float()
+            return gx, gw, s1, s2, cs
         gx = torch.empty_like(x)
         addend = None if addend is None else addend.contiguous()
         nblk = int(lib().pygho_bn_bwd_linear_dw_blocks(m))
@@ -737,11 +785,12 @@ class _TupleBlock(torch.autograd.Function):
             g_rhs = g if g_chain is None else g + g_chain      # residual row operand: receives the output gradient as it is
         want_cs = b_dtype is not None and ctx.needs_input_grad[2]
         gx = gw = gb = None
-        if pre is None or (skinny and USE_BN_BWD_LINEAR and USE_FUSED_DW and ctx.needs_input_grad[1]):
+        one_wg = skinny and x.shape[1] <= 128           # the one-workgroup backward kernels exist for widths 64 / 128 (see bn_bwd_linear)
+        if pre is None or (one_wg and USE_BN_BWD_LINEAR and USE_FUSED_DW and ctx.needs_input_grad[1]):
             gx, gw32, s1, s2, sdx = bn_bwd_linear(pre, gh.contiguous(), saved, training, act, w, res_g, want_cs, x=x,
                                                   lin_bias=bc)
             gw = gw32.to(w_dtype)
-        elif skinny and USE_BN_BWD_LINEAR:
+        elif one_wg and USE_BN_BWD_LINEAR:
             gx, gpre, s1, s2, sdx = bn_bwd_linear(pre, gh.contiguous(), saved, training, act, w, res_g, want_cs)
         else:
             gpre, s1, s2, sdx = _bn_backward(pre, gh, saved, training, act, want_colsum=want_cs)
@@ -931,7 +980,7 @@ def concat_block_supported(xs, lin: "torch.nn.Linear") -> bool:
     d = xs[0].shape[1] if xs and xs[0].dim() == 2 else -1
     return (USE_CONCAT_BLOCK and USE_ROWBLOCK_LINEAR and USE_BN_BWD_LINEAR and len(xs) >= 2
             and all(x.dim() == 2 and x.shape == xs[0].shape and x.dtype == xs[0].dtype and x.is_cuda for x in xs)
-            and lin.in_features == len(xs) * d and lin.out_features == d and rowblock_linear_supported(xs[0], d)
+            and lin.in_features == len(xs) * d and lin.out_features == d and d <= 128 and rowblock_linear_supported(xs[0], d)
             and bn_act_supported_shape(xs[0].shape[0], d, xs[0].dtype))
 
 

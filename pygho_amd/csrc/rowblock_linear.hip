@@ -59,10 +59,15 @@ template <int D> struct RlGeom {
 //   RL_BN_ACT    out = act(Y * scale + shift) (+ addend): Linear -> BatchNorm -> activation in one pass over `in`
 //   RL_BWD_SUMS  nothing stored: the two channel sums of the BatchNorm / activation backward (sum dz, sum dz * xhat) of
 //                (Y, gh) -- the reduction pass of the backward reads `in` and recomputes Y instead of reading a stored Y
-enum { RL_STORE = 0, RL_BN_ACT = 1, RL_BWD_SUMS = 2 };
+//   RL_BWD_APPLY out = gpre = the BatchNorm / activation backward of (Y, gh) given the two channel sums (the apply half of
+//                pygho_bn_act_bwd, same formula and rounding), Y recomputed; optionally the column sums of the rounded gpre (the bias
+//                gradient of the Linear) as per-slot partial sums.  The d = 256 backward is built from this pass, RL_STORE with the
+//                residual gradient as addend (gx = gpre . W + g) and the library's weight-gradient GEMM.
+enum { RL_STORE = 0, RL_BN_ACT = 1, RL_BWD_SUMS = 2, RL_BWD_APPLY = 3 };
 struct RlEpi {
   const float* scale; const float* shift;                                     // RL_BN_ACT
-  const void* gh; const float* mean; const float* invstd; const float* w; const float* b;   // RL_BWD_SUMS (w / b nullable)
+  const void* gh; const float* mean; const float* invstd; const float* w; const float* b;   // RL_BWD_SUMS / RL_BWD_APPLY (w / b nullable)
+  const float* sum_dz; const float* sum_dz_xhat; int training;               // RL_BWD_APPLY
   const int32_t* m_dyn;      // non-null: the row count is READ FROM THE DEVICE (<= the m_rows the grid was sized for), see pygho_hip.h "_dyn"
 };
 
@@ -77,53 +82,81 @@ template <int ACT> __device__ __forceinline__ float rl_act_grad(float z) {
   return 1.f;
 }
 
+// Geometry of the streaming forward product.  Widths 64 / 128: one workgroup forms all D output columns of its row tiles (NW = D).
+// Width 256 (config 5: I2Conv, reference Conv.py:107-147 at hidden 256): W alone would be 128 KB of the 160 KB of LDS, so the output
+// columns are split in HALVES (NW = 128): a workgroup keeps 128 rows of W (all 256 k, 67.6 KB) and forms columns [n0, n0 + 128) of its
+// row tiles; the two halves of a tile are workgroups b and b + 8 -- the same XCD under round-robin dispatch, a few microseconds apart --
+// so the second read of the tile's rows comes out of that XCD's L2.  Everything the epilogues do is per channel, hence per half.
+template <int D> struct RlFwdGeom {
+  static constexpr int K = D;                              // input width = contraction length
+  static constexpr int NW = D > 128 ? 128 : D;             // output columns per workgroup
+  static constexpr int HALVES = D / NW;
+  static constexpr int KS = K / 32;                        // k steps of the MFMA
+  static constexpr int NB = NW / 16;                       // 16-column output blocks per workgroup
+  static constexpr int PITCH_W = K + 8;                    // elements; +16 B per row: fragment reads spread over the banks
+  static constexpr int PITCH_S = NW + 8;                   // stage rows hold the workgroup's NW outputs
+  static constexpr int CH = NW / 8;                        // 16-B chunks per (half) output row
+  static constexpr size_t w_bytes = (size_t)NW * PITCH_W * 2;
+  static constexpr size_t stage_bytes = (size_t)kRlTile * PITCH_S * 2;
+  static constexpr size_t lds_bytes = w_bytes + stage_bytes + 6 * (size_t)NW * 4;   // + bias / shift
+  static constexpr int WG_PER_CU = D > 128 ? 1 : 2;        // 105 KB of LDS per workgroup at D = 256
+};
+
 template <typename T, int D, int EPI = RL_STORE, int ACT = 0>
-__global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ wl,
+__global__ __launch_bounds__(kBlock, RlFwdGeom<D>::WG_PER_CU) void rowblock_linear_kernel(T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ wl,
                                                                     const T* __restrict__ bias, const T* __restrict__ addend,
                                                                     float* __restrict__ stats_ws, float* __restrict__ shift,
                                                                     int self_shift, int64_t m_rows, RlEpi epi) {
-  using G = RlGeom<D>;
+  using G = RlFwdGeom<D>;
   using V = Vec16<T>;
   if (epi.m_dyn) m_rows = *epi.m_dyn;                      // (scalar load; the launch was sized for the capacity)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_w = smem;
   char* lds_stage = smem + G::w_bytes;
   float* lds_bias = reinterpret_cast<float*>(smem + G::w_bytes + G::stage_bytes);
-  float* lds_shift = lds_bias + D;
+  float* lds_shift = lds_bias + G::NW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
-
-  // ---- Wl[n][k] (row-major, k contiguous) -> LDS with padded pitch; bias as f32 -------------------------------
-  for (int item = threadIdx.x; item < D * G::CH; item += kBlock) {
-    const int n = item / G::CH, ch = item - n * G::CH;
-    *reinterpret_cast<uint4*>(lds_w + ((size_t)n * G::PITCH + ch * 8) * 2) = *reinterpret_cast<const uint4*>(wl + (size_t)n * D + ch * 8);
+  // which column half, and which slot of the tile sweep: halves of one tile are workgroups b and b + 8 (see RlFwdGeom)
+  int half = 0, slot = blockIdx.x, n_slots = gridDim.x;
+  if constexpr (G::HALVES == 2) {
+    half = (blockIdx.x >> 3) & 1;
+    slot = (int)((blockIdx.x >> 4) << 3) + (int)(blockIdx.x & 7);
+    n_slots = gridDim.x >> 1;
   }
-  for (int n = threadIdx.x; n < D; n += kBlock) lds_bias[n] = bias ? load_as_acc<T>(bias + n) : 0.f;
+  const int n0 = half * G::NW;
+
+  // ---- rows n0 .. n0 + NW of Wl[n][k] (row-major, k contiguous) -> LDS with padded pitch; bias as f32 ------------------
+  for (int item = threadIdx.x; item < G::NW * (G::K / 8); item += kBlock) {
+    const int n = item / (G::K / 8), ch = item - n * (G::K / 8);
+    *reinterpret_cast<uint4*>(lds_w + ((size_t)n * G::PITCH_W + ch * 8) * 2) = *reinterpret_cast<const uint4*>(wl + (size_t)(n0 + n) * G::K + ch * 8);
+  }
+  for (int n = threadIdx.x; n < G::NW; n += kBlock) lds_bias[n] = bias ? load_as_acc<T>(bias + n0 + n) : 0.f;
   __syncthreads();
 
-  char* my_stage = lds_stage + (size_t)wave * kRlRowsPerWave * G::PITCH * 2;
+  char* my_stage = lds_stage + (size_t)wave * kRlRowsPerWave * G::PITCH_S * 2;
   const int64_t n_tiles = (m_rows + kRlTile - 1) / kRlTile;
   const int ech = lane % G::CH;                          // epilogue: this lane's 16-B channel chunk (fixed: 64 % CH == 0)
   const int erow0 = lane / G::CH;                        // ... and its first row inside the wave's 32
   constexpr int EROWS = 64 / G::CH;                      // rows covered per epilogue iteration
   // self_shift: the shift of the statistics is row 0 of the output, computed HERE by every workgroup from the W it has just
-  // staged (128 x 128 multiply-adds, the same instruction sequence everywhere, so every workgroup and the finalisation kernel
+  // staged (D multiply-adds per channel, the same instruction sequence everywhere, so every workgroup and the finalisation kernel
   // see the same bits) instead of by a 1-row library GEMM in front of the launch (14.5 us of launch latency, 8x per step)
   if (stats_ws && self_shift) {
-    for (int n = threadIdx.x; n < D; n += kBlock) {
+    for (int n = threadIdx.x; n < G::NW; n += kBlock) {
       float a = lds_bias[n];
-      const T* wrow = reinterpret_cast<const T*>(lds_w + (size_t)n * G::PITCH * 2);
-      for (int k = 0; k < D; ++k) a += load_as_acc<T>(in + k) * load_as_acc<T>(wrow + k);
-      if (addend) a += load_as_acc<T>(addend + n);
+      const T* wrow = reinterpret_cast<const T*>(lds_w + (size_t)n * G::PITCH_W * 2);
+      for (int k = 0; k < G::K; ++k) a += load_as_acc<T>(in + k) * load_as_acc<T>(wrow + k);
+      if (addend) a += load_as_acc<T>(addend + n0 + n);
       lds_shift[n] = a;
-      if (blockIdx.x == 0) shift[n] = a;
+      if (slot == 0) shift[n0 + n] = a;
     }
     __syncthreads();
   }
   float sh[8], s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    sh[j] = (!stats_ws || EPI != RL_STORE) ? 0.f : (self_shift ? lds_shift[ech * 8 + j] : (shift ? shift[ech * 8 + j] : 0.f));
+    sh[j] = (!stats_ws || EPI != RL_STORE) ? 0.f : (self_shift ? lds_shift[ech * 8 + j] : (shift ? shift[n0 + ech * 8 + j] : 0.f));
     s1[j] = 0.f;
     s2[j] = 0.f;
   }
@@ -132,11 +165,22 @@ __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restric
   float c0[8], c1[8], c2[8], c3[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int c = ech * 8 + j;
-    c0[j] = EPI == RL_BN_ACT ? epi.scale[c] : (EPI == RL_BWD_SUMS ? epi.mean[c] : 0.f);
-    c1[j] = EPI == RL_BN_ACT ? epi.shift[c] : (EPI == RL_BWD_SUMS ? epi.invstd[c] : 0.f);
-    c2[j] = (EPI == RL_BWD_SUMS && epi.w) ? epi.w[c] : 1.f;
-    c3[j] = (EPI == RL_BWD_SUMS && epi.b) ? epi.b[c] : 0.f;
+    const int c = n0 + ech * 8 + j;
+    constexpr bool BWD = EPI == RL_BWD_SUMS || EPI == RL_BWD_APPLY;
+    c0[j] = EPI == RL_BN_ACT ? epi.scale[c] : (BWD ? epi.mean[c] : 0.f);
+    c1[j] = EPI == RL_BN_ACT ? epi.shift[c] : (BWD ? epi.invstd[c] : 0.f);
+    c2[j] = (BWD && epi.w) ? epi.w[c] : 1.f;
+    c3[j] = (BWD && epi.b) ? epi.b[c] : 0.f;
+  }
+  float k1[8], k2[8];                                    // RL_BWD_APPLY: sum_dz / M, sum_dz_xhat / M (0 in eval mode)
+  if constexpr (EPI == RL_BWD_APPLY) {
+    const float inv_m = 1.f / (float)m_rows;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = n0 + ech * 8 + j;
+      k1[j] = epi.training ? epi.sum_dz[c] * inv_m : 0.f;
+      k2[j] = epi.training ? epi.sum_dz_xhat[c] * inv_m : 0.f;
+    }
   }
   const T* gh = reinterpret_cast<const T*>(epi.gh);
 
@@ -147,27 +191,27 @@ __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restric
     for (int mb = 0; mb < 2; ++mb) {
       int64_t row = base + mb * 16 + r16;
       if (row >= m_rows) row = m_rows - 1;               // clamped; never stored
-      const T* p = in + row * D + q * 8;
+      const T* p = in + row * G::K + q * 8;
 #pragma unroll
       for (int ks = 0; ks < G::KS; ++ks) dst[mb][ks] = *reinterpret_cast<const uint4*>(p + ks * 32);
     }
   };
-  int64_t tile = blockIdx.x;
+  int64_t tile = slot;
   if (tile < n_tiles) load_tile(tile, fb);
-  for (; tile < n_tiles; tile += gridDim.x) {
+  for (; tile < n_tiles; tile += n_slots) {
     uint4 nxt[2][G::KS];
     // prefetch of the next tile (clamped to the last one: an unconditional load keeps the arrays in registers -- the
     // compiler demoted conditionally initialised prefetch arrays to scratch)
-    const int64_t tn = min((int64_t)(tile + gridDim.x), n_tiles - 1);
+    const int64_t tn = min((int64_t)(tile + n_slots), n_tiles - 1);
     load_tile(tn, nxt);                // prefetch: in flight during this tile's MFMAs and epilogue
-    uint4 cgh[kRlRowsPerWave / EROWS];  // RL_BWD_SUMS: this tile's gh chunks (row-contiguous), in flight during the MFMAs
-    if constexpr (EPI == RL_BWD_SUMS) {
+    uint4 cgh[kRlRowsPerWave / EROWS];  // RL_BWD_SUMS / _APPLY: this tile's gh chunks (row-contiguous), in flight during the MFMAs
+    if constexpr (EPI == RL_BWD_SUMS || EPI == RL_BWD_APPLY) {
       const int64_t b0 = tile * kRlTile + wave * kRlRowsPerWave;
 #pragma unroll
       for (int it = 0; it < kRlRowsPerWave / EROWS; ++it) {
         int64_t row = b0 + it * EROWS + erow0;
         if (row >= m_rows) row = m_rows - 1;
-        cgh[it] = *reinterpret_cast<const uint4*>(gh + row * D + ech * 8);
+        cgh[it] = *reinterpret_cast<const uint4*>(gh + row * D + n0 + ech * 8);
       }
     }
 
@@ -181,7 +225,7 @@ __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restric
     for (int ks = 0; ks < G::KS; ++ks)
 #pragma unroll
       for (int nb = 0; nb < G::NB; ++nb) {
-        const uint4 fa = *reinterpret_cast<const uint4*>(lds_w + ((size_t)(nb * 16 + r16) * G::PITCH + ks * 32 + q * 8) * 2);
+        const uint4 fa = *reinterpret_cast<const uint4*>(lds_w + ((size_t)(nb * 16 + r16) * G::PITCH_W + ks * 32 + q * 8) * 2);
         acc[0][nb] = rl_mfma<T>(fa, fb[0][ks], acc[0][nb]);
         acc[1][nb] = rl_mfma<T>(fa, fb[1][ks], acc[1][nb]);
       }
@@ -190,7 +234,7 @@ __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restric
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int nb = 0; nb < G::NB; ++nb)
-        *reinterpret_cast<uint2*>(my_stage + ((size_t)(mb * 16 + r16) * G::PITCH + nb * 16 + q * 4) * 2) = rl_pack4<T>(acc[mb][nb]);
+        *reinterpret_cast<uint2*>(my_stage + ((size_t)(mb * 16 + r16) * G::PITCH_S + nb * 16 + q * 4) * 2) = rl_pack4<T>(acc[mb][nb]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -200,18 +244,18 @@ __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restric
     for (int it = 0; it < kRlRowsPerWave / EROWS; ++it) {
       const int rl = it * EROWS + erow0;
       const int64_t row = base + rl;
-      uint4 v = *reinterpret_cast<const uint4*>(my_stage + ((size_t)rl * G::PITCH + ech * 8) * 2);
+      uint4 v = *reinterpret_cast<const uint4*>(my_stage + ((size_t)rl * G::PITCH_S + ech * 8) * 2);
       if (row < m_rows) {
         if constexpr (EPI == RL_STORE) {
           if (addend) {
             float a[8], b[8];
             V::unpack(v, a);
-            V::unpack(*reinterpret_cast<const uint4*>(addend + row * D + ech * 8), b);
+            V::unpack(*reinterpret_cast<const uint4*>(addend + row * D + n0 + ech * 8), b);
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] += b[j];
             v = V::pack(a);
           }
-          if (out) *reinterpret_cast<uint4*>(out + row * D + ech * 8) = v;
+          if (out) *reinterpret_cast<uint4*>(out + row * D + n0 + ech * 8) = v;
           if (stats_ws) {
             float a[8];
             V::unpack(v, a);
@@ -225,11 +269,28 @@ __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restric
           for (int j = 0; j < 8; ++j) a[j] = rl_act_fwd<ACT>(a[j] * c0[j] + c1[j]);
           if (addend) {
             float b[8];
-            V::unpack(*reinterpret_cast<const uint4*>(addend + row * D + ech * 8), b);
+            V::unpack(*reinterpret_cast<const uint4*>(addend + row * D + n0 + ech * 8), b);
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] += b[j];
           }
-          *reinterpret_cast<uint4*>(out + row * D + ech * 8) = V::pack(a);
+          *reinterpret_cast<uint4*>(out + row * D + n0 + ech * 8) = V::pack(a);
+        } else if constexpr (EPI == RL_BWD_APPLY) {       // = bn_act_bwd_kernel on the rounded Y (bn_act.hip), same formula
+          float a[8], g[8];
+          V::unpack(v, a);
+          V::unpack(cgh[it], g);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xh = (a[j] - c0[j]) * c1[j];
+            const float dz = g[j] * rl_act_grad<ACT>(xh * c2[j] + c3[j]);
+            a[j] = c2[j] * c1[j] * (dz - k1[j] - xh * k2[j]);
+          }
+          const uint4 packed = V::pack(a);
+          *reinterpret_cast<uint4*>(out + row * D + n0 + ech * 8) = packed;
+          if (stats_ws) {                                 // column sums of the ROUNDED gpre: the bias gradient of the Linear
+            V::unpack(packed, a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s1[j] += a[j];
+          }
         } else {                                          // = bn_act_bwd_reduce_kernel on the rounded Y
           float a[8], g[8];
           V::unpack(v, a);
@@ -251,19 +312,19 @@ __global__ __launch_bounds__(kBlock, 2) void rowblock_linear_kernel(T* __restric
       for (int ks = 0; ks < G::KS; ++ks) fb[mb][ks] = nxt[mb][ks];
   }
 
-  // ---- per-workgroup partial sums: ws[blk][0][c] = sum(y - shift), ws[blk][1][c] = sum((y - shift)^2) -------------
+  // ---- per-slot partial sums: ws[slot][0][c] = sum(y - shift), ws[slot][1][c] = sum((y - shift)^2); a half writes its channels ----
   if (stats_ws) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds_stage);       // [2][kBlock][8] floats = 16 KB (stage is >= 34 KB)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { red[(0 * kBlock + threadIdx.x) * 8 + j] = s1[j]; red[(1 * kBlock + threadIdx.x) * 8 + j] = s2[j]; }
     __syncthreads();
-    for (int item = threadIdx.x; item < 2 * D; item += kBlock) {
-      const int which = item / D, c = item - which * D;
+    for (int item = threadIdx.x; item < 2 * G::NW; item += kBlock) {
+      const int which = item / G::NW, c = item - which * G::NW;
       const int ch = c / 8, j = c - ch * 8;
       float a = 0.f;
       for (int t = ch; t < kBlock; t += G::CH) a += red[(which * kBlock + t) * 8 + j];     // fixed order: deterministic
-      stats_ws[((size_t)blockIdx.x * 2 + which) * D + c] = a;
+      stats_ws[((size_t)slot * 2 + which) * D + n0 + c] = a;
     }
   }
 }
@@ -984,7 +1045,8 @@ int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum
 template <typename T, int D, int EPI = RL_STORE, int ACT = 0>
 int launch_rowblock(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws, float* shift,
                     int self_shift, int64_t m, int grid, hipStream_t st, const RlEpi& epi = RlEpi{}) {
-  using G = RlGeom<D>;
+  using G = RlFwdGeom<D>;
+  grid *= G::HALVES;                                     // (`grid` counts tile slots; at D = 256 every slot is two workgroups)
   static bool attr_set_dev[64] = {};
   bool& attr_set = per_device_flag(attr_set_dev);
   if (!attr_set) {
@@ -1007,22 +1069,32 @@ extern "C" int pygho_rowblock_linear_blocks(int64_t m) {
   return grid_for(m, kRlTile, 512);          // 2 resident workgroups per CU (70 KB of LDS each)
 }
 
+// tile slots of a launch at width d (= rows of the per-slot statistics workspace): widths 64 / 128 as above; width 256 runs TWO
+// workgroups per slot (the column halves, paired as workgroups b and b + 8), one workgroup per CU, slots a multiple of 8
+extern "C" int pygho_rowblock_linear_slots(int64_t m, int64_t d) {
+  if (m <= 0) return 0;
+  if (d <= 128) return pygho_rowblock_linear_blocks(m);
+  const int slots = grid_for(m, kRlTile, 128);
+  return (slots + 7) & ~7;
+}
+
 static int rowblock_entry(void* out, const void* in, const void* wl, const void* bias, const void* addend, float* stats_ws,
                           float* shift, int self_shift, int64_t m, int64_t d, int dtype, void* stream, const int32_t* m_dyn = nullptr) {
   if (m < 0 || d <= 0) { set_error("rowblock_linear: bad size"); return PYGHO_ERR_INVALID; }
   if (m == 0) return PYGHO_OK;
   if ((!out && !stats_ws) || !in || !wl) { set_error("null pointer"); return PYGHO_ERR_INVALID; }      // out may be null: sums only
   if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("rowblock_linear: bf16 / f16 only (f32 takes the library GEMM)"); return PYGHO_ERR_UNSUPPORTED; }
-  if (d != 64 && d != 128) { set_error("rowblock_linear: width %lld not supported (64, 128)", (long long)d); return PYGHO_ERR_UNSUPPORTED; }
+  if (d != 64 && d != 128 && d != 256) { set_error("rowblock_linear: width %lld not supported (64, 128, 256)", (long long)d); return PYGHO_ERR_UNSUPPORTED; }
   if ((((uintptr_t)out | (uintptr_t)in | (uintptr_t)wl | (uintptr_t)addend) % 16) != 0) { set_error("rowblock_linear: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
   if (self_shift && (!stats_ws || !shift)) { set_error("rowblock_linear: the in-kernel shift needs stats_ws and a shift buffer"); return PYGHO_ERR_INVALID; }
-  const int grid = pygho_rowblock_linear_blocks(m);
+  const int grid = pygho_rowblock_linear_slots(m, d);
   hipStream_t st = (hipStream_t)stream;
   RlEpi epi{};
   epi.m_dyn = m_dyn;
 #define PYGHO_RL(T)                                                                                               \
-  (d == 128 ? launch_rowblock<T, 128>(out, in, wl, bias, addend, stats_ws, shift, self_shift, m, grid, st, epi)    \
-            : launch_rowblock<T, 64>(out, in, wl, bias, addend, stats_ws, shift, self_shift, m, grid, st, epi))
+  (d == 256 ? launch_rowblock<T, 256>(out, in, wl, bias, addend, stats_ws, shift, self_shift, m, grid, st, epi)    \
+   : d == 128 ? launch_rowblock<T, 128>(out, in, wl, bias, addend, stats_ws, shift, self_shift, m, grid, st, epi)  \
+              : launch_rowblock<T, 64>(out, in, wl, bias, addend, stats_ws, shift, self_shift, m, grid, st, epi))
   return dtype == PYGHO_BF16 ? PYGHO_RL(bf16) : PYGHO_RL(f16);
 #undef PYGHO_RL
 }
@@ -1047,7 +1119,7 @@ static int rowblock_check(const char* what, const void* a, const void* b, const 
                           int dtype) {
   if (m <= 0 || d <= 0) { set_error("%s: empty input", what); return PYGHO_ERR_INVALID; }
   if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("%s: bf16 / f16 only", what); return PYGHO_ERR_UNSUPPORTED; }
-  if (d != 64 && d != 128) { set_error("%s: width %lld not supported (64, 128)", what, (long long)d); return PYGHO_ERR_UNSUPPORTED; }
+  if (d != 64 && d != 128 && d != 256) { set_error("%s: width %lld not supported (64, 128, 256)", what, (long long)d); return PYGHO_ERR_UNSUPPORTED; }
   if (act < 0 || act > 2) { set_error("%s: unknown activation %d", what, act); return PYGHO_ERR_INVALID; }
   if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d4) % 16) != 0) { set_error("%s: operands must be 16-byte aligned", what); return PYGHO_ERR_INVALID; }
   return PYGHO_OK;
@@ -1056,16 +1128,17 @@ static int rowblock_check(const char* what, const void* a, const void* b, const 
 #define PYGHO_RL_EPI(T, DD, EPI, ...)                                                           \
   (act == 0 ? launch_rowblock<T, DD, EPI, 0>(__VA_ARGS__) : act == 1 ? launch_rowblock<T, DD, EPI, 1>(__VA_ARGS__) \
                                                                      : launch_rowblock<T, DD, EPI, 2>(__VA_ARGS__))
+#define PYGHO_RL_EPI_D(T, EPI, ...)                                                                               \
+  (d == 256 ? PYGHO_RL_EPI(T, 256, EPI, __VA_ARGS__) : d == 128 ? PYGHO_RL_EPI(T, 128, EPI, __VA_ARGS__) : PYGHO_RL_EPI(T, 64, EPI, __VA_ARGS__))
 #define PYGHO_RL_EPI_T(EPI, ...)                                                                                  \
-  (dtype == PYGHO_BF16 ? (d == 128 ? PYGHO_RL_EPI(bf16, 128, EPI, __VA_ARGS__) : PYGHO_RL_EPI(bf16, 64, EPI, __VA_ARGS__)) \
-                       : (d == 128 ? PYGHO_RL_EPI(f16, 128, EPI, __VA_ARGS__) : PYGHO_RL_EPI(f16, 64, EPI, __VA_ARGS__)))
+  (dtype == PYGHO_BF16 ? PYGHO_RL_EPI_D(bf16, EPI, __VA_ARGS__) : PYGHO_RL_EPI_D(f16, EPI, __VA_ARGS__))
 
 extern "C" int pygho_rowblock_linear_bn_act(void* out, const void* in, const void* wl, const void* bias, const float* scale,
                                             const float* shift, const void* addend, int64_t m, int64_t d, int act, int dtype,
                                             void* stream) {
   if (!out || !in || !wl || !scale || !shift) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if (int rc = rowblock_check("rowblock_linear_bn_act", out, in, wl, addend, m, d, act, dtype)) return rc;
-  const int grid = pygho_rowblock_linear_blocks(m);
+  const int grid = pygho_rowblock_linear_slots(m, d);
   hipStream_t st = (hipStream_t)stream;
   RlEpi epi{};
   epi.scale = scale; epi.shift = shift;
@@ -1077,12 +1150,29 @@ static int rowblock_bwd_sums_entry(float* sum_dz, float* sum_dz_xhat, const void
                                    int64_t m, int64_t d, int act, float* workspace, int dtype, void* stream, const int32_t* m_dyn) {
   if (!sum_dz || !sum_dz_xhat || !in || !wl || !gh || !mean || !invstd || !workspace) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if (int rc = rowblock_check("rowblock_linear_bwd_sums", in, wl, gh, nullptr, m, d, act, dtype)) return rc;
-  const int grid = pygho_rowblock_linear_blocks(m);
+  const int grid = pygho_rowblock_linear_slots(m, d);
   hipStream_t st = (hipStream_t)stream;
   RlEpi epi{};
   epi.gh = gh; epi.mean = mean; epi.invstd = invstd; epi.w = w; epi.b = b; epi.m_dyn = m_dyn;
   if (int rc = PYGHO_RL_EPI_T(RL_BWD_SUMS, nullptr, in, wl, bias, nullptr, workspace, nullptr, 0, m, grid, st, epi)) return rc;
   return pygho_bn_bwd_fold_sums(sum_dz, sum_dz_xhat, workspace, d, grid, stream);
+}
+
+extern "C" int pygho_rowblock_linear_bwd_apply(void* gpre, float* colsum, const void* in, const void* wl, const void* bias, const void* gh,
+                                               const float* mean, const float* invstd, const float* w, const float* b,
+                                               const float* sum_dz, const float* sum_dz_xhat, int64_t m_cap, const int32_t* m_dev, int64_t d,
+                                               int act, int training, float* workspace, int dtype, void* stream) {
+  if (!gpre || !in || !wl || !gh || !mean || !invstd || (training && (!sum_dz || !sum_dz_xhat)) || (colsum && !workspace)) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (int rc = rowblock_check("rowblock_linear_bwd_apply", gpre, in, wl, gh, m_cap, d, act, dtype)) return rc;
+  const int grid = pygho_rowblock_linear_slots(m_cap, d);
+  hipStream_t st = (hipStream_t)stream;
+  RlEpi epi{};
+  epi.gh = gh; epi.mean = mean; epi.invstd = invstd; epi.w = w; epi.b = b; epi.m_dyn = m_dev;
+  epi.sum_dz = sum_dz; epi.sum_dz_xhat = sum_dz_xhat; epi.training = training;
+  float* ws = colsum ? workspace : nullptr;
+  if (int rc = PYGHO_RL_EPI_T(RL_BWD_APPLY, gpre, in, wl, bias, nullptr, ws, nullptr, 0, m_cap, grid, st, epi)) return rc;
+  if (!colsum) return PYGHO_OK;
+  return pygho_bn_bwd_fold_sums(colsum, workspace + (size_t)grid * 2 * d, workspace, d, grid, stream);   // (second sum: zeros, discarded)
 }
 
 extern "C" int pygho_rowblock_linear_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* in, const void* wl, const void* bias,
@@ -1098,6 +1188,7 @@ extern "C" int pygho_rowblock_linear_bwd_sums_dyn(float* sum_dz, float* sum_dz_x
   return rowblock_bwd_sums_entry(sum_dz, sum_dz_xhat, in, wl, bias, gh, mean, invstd, w, b, m_cap, d, act, workspace, dtype, stream, m_dev);
 }
 #undef PYGHO_RL_EPI_T
+#undef PYGHO_RL_EPI_D
 #undef PYGHO_RL_EPI
 
 extern "C" int pygho_bn_bwd_linear(void* gx, void* gpre, const void* pre, const void* gh, const void* wl, const void* addend,
