@@ -709,6 +709,11 @@ int pygho_bn_bwd_linear_dw_recompute_dyn(void* gx, float* dw_ws, const void* gh,
                                          const float* w, const float* b, const float* sum_dz, const float* sum_dz_xhat,
                                          int64_t m_cap, const int32_t* m_dev, int64_t d, int act, int training, int dtype,
                                          int64_t ws_stride, void* stream);
+/* pygho_weight_grad on a d-wide column block of BOTH operands (row strides g_ld / x_ld in elements): one d x d block of the weight
+ * gradient of a wider Linear -- width 256 = four 128 x 128 blocks (rowblock_linear.hip: a 256 x 256 f32 accumulator does not fit).
+ * m_dev nullable (the "_dyn" convention above). */
+int pygho_weight_grad_strided(float* dw_ws, float* colsum_ws, const void* g, int64_t g_ld, const void* x, int64_t x_ld, int64_t m_cap,
+                              const int32_t* m_dev, int64_t d, int dtype, int64_t ws_stride, void* stream);
 int pygho_weight_grad_dyn(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t x_ld, int64_t m_cap,
                           const int32_t* m_dev, int64_t d, int dtype, int64_t ws_stride, void* stream);
 int pygho_bn_prepare_dyn(float* mean, float* var, float* invstd, float* scale, float* shift, const void* x, int64_t m_cap,

@@ -124,6 +124,7 @@ PROTOTYPES = {
     "pygho_rowblock_linear_bwd_sums_dyn": (I, [P, P, P, P, P, P, P, P, P, P, L, P, L, I, P, I, P]),
     "pygho_bn_bwd_linear_dw_dyn": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, L, P]),
     "pygho_bn_bwd_linear_dw_recompute_dyn": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, L, P]),
+    "pygho_weight_grad_strided": (I, [P, P, P, L, P, L, L, P, L, I, L, P]),
     "pygho_weight_grad_dyn": (I, [P, P, P, P, L, L, P, L, I, L, P]),
     "pygho_bn_prepare_dyn": (I, [P, P, P, P, P, P, L, P, L, P, P, D, P, P, D, P, I, P]),
     "pygho_bn_finalize_dyn": (I, [P, P, P, P, P, P, L, P, L, P, L, P, P, D, P, P, D, P]),

@@ -386,6 +386,24 @@ def cast_param(p: Tensor, dtype: torch.dtype) -> Tensor:
 # --------------------------------------------------------------------------
 # one tuple-wise block: Linear -> BatchNorm -> act [-> message passing [+ residual]]   
 # --------------------------------------------------------------------------
+_BMM_OUT_DTYPE = [None]
+
+
+def _bmm_f32(a: Tensor, b: Tensor) -> Tensor:
+    """batched product with f32 OUTPUT where the library offers it (the slabs of a split-K weight gradient are summed afterwards: 256
+    partial products rounded to bf16 first cost 3 decimal digits), else in the operands' dtype"""
+    if a.dtype in (torch.bfloat16, torch.float16) and _BMM_OUT_DTYPE[0] is not False:
+        try:
+            out = torch.bmm(a, b, out_dtype=torch.float32)
+            _BMM_OUT_DTYPE[0] = True
+            return out
+        except (TypeError, RuntimeError, NotImplementedError):
+            if _BMM_OUT_DTYPE[0]:
+                raise
+            _BMM_OUT_DTYPE[0] = False
+    return torch.bmm(a, b)
+
+
 def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype, want_colsum: bool = False, any_height: bool = False):
     """dW = g^T x for tall (nnz ~ 10^5..10^6) operands; with `want_colsum` returns (dW, g.sum(0)).
     Square 16-bit Linears of width 64 / 128 run on the transpose-read MFMA kernel (`pygho_weight_grad`); the rest falls back
@@ -396,28 +414,34 @@ def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype, want_colsum
     m_dev = dyn_rows(m)
     if m_dev is not None:
         any_height = True                      # the library GEMMs below would sum the pad rows of a batch slot
-    if (g.is_cuda and g.dtype in (torch.bfloat16, torch.float16) and x.dtype == g.dtype and n in (64, 128) and k % n == 0
-            and k // n <= 8 and (m >= 8192 or (any_height and m > 0))):      # (`any_height`: short inputs too -- launch-bound callers)
+    kernel_dtype = g.is_cuda and g.dtype in (torch.bfloat16, torch.float16) and x.dtype == g.dtype
+    nb = 128 if (n % 128 == 0 and k % 128 == 0) else (64 if (n % 64 == 0 and k % 64 == 0) else 0)     # block width of the kernel
+    if (kernel_dtype and nb and n // nb <= 2 and k // nb <= 8 and (n == nb or m_dev is not None or FORCE_DW_BLOCKS)
+            and (m >= 8192 or (any_height and m > 0))):      # (`any_height`: short inputs too -- launch-bound callers)
+        # `pygho_weight_grad` forms one nb x nb block of dW per launch from an nb-wide column block of g and one of x: square Linears of
+        # width 64 / 128 are one block, in_features = j nb are j blocks side by side.  A g wider than one block (width 256 = 2 x 2
+        # blocks) reads each operand half twice: 1.11 ms against 0.57 ms for the library's batched split-K at 2.4 M rows
+        # (tools/rb256_bench.py), so that form only runs where the library cannot -- rows counted on the device (a batch slot)
         g, x = g.contiguous(), x.contiguous()
         dev = g.device
         nblk = int(lib().pygho_bn_bwd_linear_dw_blocks(m))
-        parts = []
-        for j in range(k // n):                                       # one launch per n-wide column block of x (in_features = j n)
-            cs_here = want_colsum and j == 0
-            width = n * n + (2 * n if cs_here else 0)                 # one interleaved workspace, one folding launch
-            ws = torch.empty((nblk, width), dtype=torch.float32, device=dev)
-            cws_ptr = c_void_p(ws.data_ptr() + 4 * n * n) if cs_here else None
-            if m_dev is not None:
-                check(lib().pygho_weight_grad_dyn(ptr(ws), cws_ptr, ptr(g), c_void_p(x.data_ptr() + j * n * x.element_size()), k, m,
-                                                  ptr(m_dev), n, dtype_code(g), width, stream_ptr(dev)), "weight_grad_dyn")
-            else:
-                check(lib().pygho_weight_grad(ptr(ws), cws_ptr, ptr(g), c_void_p(x.data_ptr() + j * n * x.element_size()), k, m, n,
-                                              dtype_code(g), width, stream_ptr(dev)), "weight_grad")
-            tot = sum_blocks(ws)
-            parts.append(tot[:n * n].reshape(n, n))
-            if cs_here:
-                cs = tot[n * n:n * n + n]
-        gw = (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)).to(out_dtype)
+        rows = []
+        for i in range(n // nb):                                          # row block of dW = column block of g
+            parts = []
+            for j in range(k // nb):                                      # column block of dW = column block of x
+                cs_here = want_colsum and j == 0
+                width = nb * nb + (2 * nb if cs_here else 0)              # one interleaved workspace, one folding launch
+                ws = torch.empty((nblk, width), dtype=torch.float32, device=dev)
+                cws_ptr = c_void_p(ws.data_ptr() + 4 * nb * nb) if cs_here else None
+                check(lib().pygho_weight_grad_strided(ptr(ws), cws_ptr, c_void_p(g.data_ptr() + i * nb * g.element_size()), n,
+                                                      c_void_p(x.data_ptr() + j * nb * x.element_size()), k, m, ptr(m_dev), nb,
+                                                      dtype_code(g), width, stream_ptr(dev)), "weight_grad")
+                tot = sum_blocks(ws)
+                parts.append(tot[:nb * nb].reshape(nb, nb))
+                if cs_here:
+                    cs = tot[nb * nb:nb * nb + nb] if cs is None else torch.cat((cs, tot[nb * nb:nb * nb + nb]))
+            rows.append(parts[0] if len(parts) == 1 else torch.cat(parts, dim=1))
+        gw = (rows[0] if len(rows) == 1 else torch.cat(rows, dim=0)).to(out_dtype)
     else:
         require_static_rows(m, "the library weight-gradient GEMM (widths other than 64 / 128, f32)")
         slabs = min(256, m // 2048)
@@ -426,7 +450,7 @@ def weight_grad_splitk(g: Tensor, x: Tensor, out_dtype: torch.dtype, want_colsum
         else:
             rows = m // slabs
             main = rows * slabs
-            part = torch.bmm(g[:main].view(slabs, rows, n).transpose(1, 2), x[:main].view(slabs, rows, k))
+            part = _bmm_f32(g[:main].view(slabs, rows, n).transpose(1, 2), x[:main].view(slabs, rows, k))
             gw = part.float().sum(0)
             if main < m:
                 gw = gw + (g[main:].t() @ x[main:]).float()
@@ -451,6 +475,7 @@ USE_NODE_LEVEL_LINEAR = os.environ.get("PYGHO_NODE_LEVEL_LINEAR", "1") != "0"   
 
 
 USE_ROWBLOCK_256 = os.environ.get("PYGHO_ROWBLOCK_256", "1") != "0"     # width 256 on the column-split streaming kernels (A/B switch)
+FORCE_DW_BLOCKS = False      # tests / tools: the blocked weight-gradient kernel also where the library would be faster
 
 
 def rowblock_linear_supported(x: Tensor, out_features: int) -> bool:
@@ -560,21 +585,6 @@ def sum_blocks(partials: Tensor) -> Tensor:
     return out
 
 
-_MM_OUT = [None]
-
-
-def _mm_out_dtype_ok() -> bool:
-    """does torch.mm take out_dtype here (an f32 weight gradient straight from 16-bit operands, no cast pass)?"""
-    if _MM_OUT[0] is None:
-        try:
-            a = torch.zeros((8, 8), dtype=torch.bfloat16, device="cuda")
-            torch.mm(a, a, out_dtype=torch.float32)
-            _MM_OUT[0] = True
-        except (TypeError, RuntimeError):
-            _MM_OUT[0] = False
-    return _MM_OUT[0]
-
-
 def bn_bwd_sums(pre: Tensor, gh: Tensor, saved, act: str):
     """the two channel sums of the BatchNorm + activation backward (sum dy, sum dy * xhat), two-stage and deterministic."""
     mean, invstd, w32, b32, ws = saved
@@ -609,12 +619,11 @@ def bn_bwd_linear(pre: Optional[Tensor], gh: Tensor, saved, training: bool, act:
         s1, s2 = sums
         if c == 256:
             # no one-workgroup backward at this width (W, W^T and a 256 x 256 f32 accumulator do not fit a CU): gpre from a third
-            # recomputing pass, gx = gpre W + addend on the forward kernel (the residual gradient rides in its epilogue), dW from the
-            # library (one 256 x 256 output tile, K = m: 2 streams).  10 streams against 12 for the library path + separate passes
+            # recomputing pass, gx = gpre W + addend on the forward kernel (the residual gradient rides in its epilogue), dW as 2 x 2
+            # blocks of the weight-gradient kernel
             gpre, cs = rowblock_linear_bwd_apply(x, w, lin_bias, gh, saved, sums, act, training, want_colsum)
             gx, _ = rowblock_linear(gpre, w.t().contiguous(), None, addend=None if addend is None else addend.contiguous())
-            require_static_rows(m, "the library weight-gradient GEMM of a width-256 block")
-            gw = torch.mm(gpre.t(), x, out_dtype=torch.float32) if _mm_out_dtype_ok() else (gpre.t() @ x).float()
+            gw = weight_grad_splitk(gpre, x, torch.float32)
             return gx, gw, s1, s2, cs
         gx = torch.empty_like(x)
         addend = None if addend is None else addend.contiguous()
@@ -691,7 +700,9 @@ class _TupleBlock(torch.autograd.Function):
         # the pre-activation is kept only when a backward pass will read it: with the weight gradient folded into the backward
         # kernel every pass recomputes it from x (same bits), and without a backward nobody needs it
         needs = ctx.needs_input_grad
-        recompute = (USE_RECOMPUTE_PRE and skinny and USE_BN_BWD_LINEAR and USE_FUSED_DW
+        # (width 256: the pre-activation IS kept -- every recomputing pass pays the product again, ~0.45 ms of LDS-bound MFMA work at
+        # 2.4 M rows, which only the one-workgroup backward of widths 64 / 128 earns back; measured in tools/rb256_bench.py)
+        recompute = (USE_RECOMPUTE_PRE and skinny and USE_BN_BWD_LINEAR and USE_FUSED_DW and x.shape[1] <= 128
                      and (needs[1] or not any(needs[i] for i in (0, 2, 3, 4, 10))))
         if recompute:
             pre = None

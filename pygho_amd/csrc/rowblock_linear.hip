@@ -96,14 +96,31 @@ template <int D> struct RlFwdGeom {
   static constexpr int PITCH_W = K + 8;                    // elements; +16 B per row: fragment reads spread over the banks
   static constexpr int PITCH_S = NW + 8;                   // stage rows hold the workgroup's NW outputs
   static constexpr int CH = NW / 8;                        // 16-B chunks per (half) output row
+  // widths 64 / 128: 4 wavefronts x 32 rows (two 16-row MFMA blocks per wavefront share every W fragment), 2 workgroups per CU.
+  // width 256: ONE workgroup per CU (105 KB of LDS) of 8 wavefronts x 16 rows -- two wavefronts per SIMD, so that a wavefront waiting
+  // for its rows / its LDS fragments leaves the SIMD to the other one (4 x 32 rows at one wavefront per SIMD: every load latency was
+  // exposed, 0.54 ms for the statistics pass over 1.2 GB); per wavefront 32 + 32 fragment registers and 32 accumulators
+#ifndef PYGHO_RL256_MB
+#define PYGHO_RL256_MB 2
+#endif
+  static constexpr int WAVES = D > 128 ? 8 : 4;
+  static constexpr int MB = D > 128 ? PYGHO_RL256_MB : 2;  // 16-row MFMA blocks per wavefront (each W fragment read from LDS serves MB MFMAs)
+  // width 256: no second set of fragment registers for the next tile (two wavefronts per SIMD leave 256 registers each) -- the next
+  // tile's rows are requested into the SAME registers as soon as this tile's MFMAs have consumed them, and travel during the epilogue
+  // and the other wavefront's MFMA phase
+  static constexpr bool REG_PREFETCH = D <= 128;
+  static constexpr int THREADS = WAVES * kWave;
+  static constexpr int RPW = MB * 16;                      // rows per wavefront
+  static constexpr int TILE = WAVES * RPW;                 // 128 rows per workgroup tile
   static constexpr size_t w_bytes = (size_t)NW * PITCH_W * 2;
-  static constexpr size_t stage_bytes = (size_t)kRlTile * PITCH_S * 2;
-  static constexpr size_t lds_bytes = w_bytes + stage_bytes + 6 * (size_t)NW * 4;   // + bias / shift
-  static constexpr int WG_PER_CU = D > 128 ? 1 : 2;        // 105 KB of LDS per workgroup at D = 256
+  static constexpr size_t stage_bytes = (size_t)TILE * PITCH_S * 2;
+  static constexpr size_t lds_bytes = w_bytes + stage_bytes + 8 * (size_t)NW * 4;   // + bias, shift, six backward constants
+  static constexpr int WG_PER_CU = D > 128 ? 1 : 2;
 };
+static_assert(RlFwdGeom<128>::TILE == kRlTile && RlFwdGeom<64>::TILE == kRlTile, "row tile");
 
 template <typename T, int D, int EPI = RL_STORE, int ACT = 0>
-__global__ __launch_bounds__(kBlock, RlFwdGeom<D>::WG_PER_CU) void rowblock_linear_kernel(T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ wl,
+__global__ __launch_bounds__(RlFwdGeom<D>::THREADS, RlFwdGeom<D>::WG_PER_CU) void rowblock_linear_kernel(T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ wl,
                                                                     const T* __restrict__ bias, const T* __restrict__ addend,
                                                                     float* __restrict__ stats_ws, float* __restrict__ shift,
                                                                     int self_shift, int64_t m_rows, RlEpi epi) {
@@ -127,15 +144,15 @@ __global__ __launch_bounds__(kBlock, RlFwdGeom<D>::WG_PER_CU) void rowblock_line
   const int n0 = half * G::NW;
 
   // ---- rows n0 .. n0 + NW of Wl[n][k] (row-major, k contiguous) -> LDS with padded pitch; bias as f32 ------------------
-  for (int item = threadIdx.x; item < G::NW * (G::K / 8); item += kBlock) {
+  for (int item = threadIdx.x; item < G::NW * (G::K / 8); item += G::THREADS) {
     const int n = item / (G::K / 8), ch = item - n * (G::K / 8);
     *reinterpret_cast<uint4*>(lds_w + ((size_t)n * G::PITCH_W + ch * 8) * 2) = *reinterpret_cast<const uint4*>(wl + (size_t)(n0 + n) * G::K + ch * 8);
   }
-  for (int n = threadIdx.x; n < G::NW; n += kBlock) lds_bias[n] = bias ? load_as_acc<T>(bias + n0 + n) : 0.f;
+  for (int n = threadIdx.x; n < G::NW; n += G::THREADS) lds_bias[n] = bias ? load_as_acc<T>(bias + n0 + n) : 0.f;
   __syncthreads();
 
-  char* my_stage = lds_stage + (size_t)wave * kRlRowsPerWave * G::PITCH_S * 2;
-  const int64_t n_tiles = (m_rows + kRlTile - 1) / kRlTile;
+  char* my_stage = lds_stage + (size_t)wave * G::RPW * G::PITCH_S * 2;
+  const int64_t n_tiles = (m_rows + G::TILE - 1) / G::TILE;
   const int ech = lane % G::CH;                          // epilogue: this lane's 16-B channel chunk (fixed: 64 % CH == 0)
   const int erow0 = lane / G::CH;                        // ... and its first row inside the wave's 32
   constexpr int EROWS = 64 / G::CH;                      // rows covered per epilogue iteration
@@ -143,7 +160,7 @@ __global__ __launch_bounds__(kBlock, RlFwdGeom<D>::WG_PER_CU) void rowblock_line
   // staged (D multiply-adds per channel, the same instruction sequence everywhere, so every workgroup and the finalisation kernel
   // see the same bits) instead of by a 1-row library GEMM in front of the launch (14.5 us of launch latency, 8x per step)
   if (stats_ws && self_shift) {
-    for (int n = threadIdx.x; n < G::NW; n += kBlock) {
+    for (int n = threadIdx.x; n < G::NW; n += G::THREADS) {
       float a = lds_bias[n];
       const T* wrow = reinterpret_cast<const T*>(lds_w + (size_t)n * G::PITCH_W * 2);
       for (int k = 0; k < G::K; ++k) a += load_as_acc<T>(in + k) * load_as_acc<T>(wrow + k);
@@ -160,35 +177,62 @@ __global__ __launch_bounds__(kBlock, RlFwdGeom<D>::WG_PER_CU) void rowblock_line
     s1[j] = 0.f;
     s2[j] = 0.f;
   }
-  // per-channel constants of the fused epilogues, for this lane's fixed channel chunk: c0 / c1 = scale / shift (RL_BN_ACT) or
-  // mean / invstd (RL_BWD_SUMS), c2 / c3 = BatchNorm weight / bias (RL_BWD_SUMS)
-  float c0[8], c1[8], c2[8], c3[8];
+  // per-channel constants of the fused epilogues.  RL_BN_ACT: scale / shift of this lane's fixed channel chunk in registers.  The
+  // backward epilogues need six per channel (mean, invstd, BatchNorm weight / bias, sum_dz / M, sum_dz_xhat / M): those stay in LDS and
+  // are re-read per row chunk -- in registers they spilled at width 256 (two wavefronts per SIMD: 256 registers)
+  float c0[8], c1[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = n0 + ech * 8 + j;
-    constexpr bool BWD = EPI == RL_BWD_SUMS || EPI == RL_BWD_APPLY;
-    c0[j] = EPI == RL_BN_ACT ? epi.scale[c] : (BWD ? epi.mean[c] : 0.f);
-    c1[j] = EPI == RL_BN_ACT ? epi.shift[c] : (BWD ? epi.invstd[c] : 0.f);
-    c2[j] = (BWD && epi.w) ? epi.w[c] : 1.f;
-    c3[j] = (BWD && epi.b) ? epi.b[c] : 0.f;
+    c0[j] = EPI == RL_BN_ACT ? epi.scale[c] : 0.f;
+    c1[j] = EPI == RL_BN_ACT ? epi.shift[c] : 0.f;
   }
-  float k1[8], k2[8];                                    // RL_BWD_APPLY: sum_dz / M, sum_dz_xhat / M (0 in eval mode)
-  if constexpr (EPI == RL_BWD_APPLY) {
+  constexpr bool BWD = EPI == RL_BWD_SUMS || EPI == RL_BWD_APPLY;
+  constexpr bool LDS_CONSTS = BWD && D > 128;            // (widths 64 / 128 keep them in registers: from LDS the 128 form spilled instead)
+  float* lds_c = lds_shift + G::NW;                      // [6][NW]: mean, invstd, w, b, k1, k2
+  float rc[6][8];                                        // the same six for this lane's channel chunk, in registers
+  if constexpr (BWD) {
     const float inv_m = 1.f / (float)m_rows;
+    const bool tr = EPI == RL_BWD_APPLY && epi.training;
+    if constexpr (LDS_CONSTS) {
+      for (int n = threadIdx.x; n < G::NW; n += G::THREADS) {
+        lds_c[0 * G::NW + n] = epi.mean[n0 + n];
+        lds_c[1 * G::NW + n] = epi.invstd[n0 + n];
+        lds_c[2 * G::NW + n] = epi.w ? epi.w[n0 + n] : 1.f;
+        lds_c[3 * G::NW + n] = epi.b ? epi.b[n0 + n] : 0.f;
+        lds_c[4 * G::NW + n] = tr ? epi.sum_dz[n0 + n] * inv_m : 0.f;
+        lds_c[5 * G::NW + n] = tr ? epi.sum_dz_xhat[n0 + n] * inv_m : 0.f;
+      }
+      __syncthreads();
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = n0 + ech * 8 + j;
-      k1[j] = epi.training ? epi.sum_dz[c] * inv_m : 0.f;
-      k2[j] = epi.training ? epi.sum_dz_xhat[c] * inv_m : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        const int c = n0 + ech * 8 + j;
+        rc[0][j] = epi.mean[c];
+        rc[1][j] = epi.invstd[c];
+        rc[2][j] = epi.w ? epi.w[c] : 1.f;
+        rc[3][j] = epi.b ? epi.b[c] : 0.f;
+        rc[4][j] = tr ? epi.sum_dz[c] * inv_m : 0.f;
+        rc[5][j] = tr ? epi.sum_dz_xhat[c] * inv_m : 0.f;
+      }
     }
   }
+  auto bwd_consts = [&](int which, float (&dst)[8]) {
+    if constexpr (LDS_CONSTS) {
+      *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(lds_c + which * G::NW + ech * 8);
+      *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(lds_c + which * G::NW + ech * 8 + 4);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[j] = rc[which][j];
+    }
+  };
   const T* gh = reinterpret_cast<const T*>(epi.gh);
 
-  uint4 fb[2][G::KS];                                    // `in` fragments of the current tile
-  auto load_tile = [&](int64_t tile, uint4 (&dst)[2][G::KS]) {
-    const int64_t base = tile * kRlTile + wave * kRlRowsPerWave;
+  uint4 fb[G::MB][G::KS];                                    // `in` fragments of the current tile
+  auto load_tile = [&](int64_t tile, uint4 (&dst)[G::MB][G::KS]) {
+    const int64_t base = tile * G::TILE + wave * G::RPW;
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < G::MB; ++mb) {
       int64_t row = base + mb * 16 + r16;
       if (row >= m_rows) row = m_rows - 1;               // clamped; never stored
       const T* p = in + row * G::K + q * 8;
@@ -199,39 +243,41 @@ __global__ __launch_bounds__(kBlock, RlFwdGeom<D>::WG_PER_CU) void rowblock_line
   int64_t tile = slot;
   if (tile < n_tiles) load_tile(tile, fb);
   for (; tile < n_tiles; tile += n_slots) {
-    uint4 nxt[2][G::KS];
+    uint4 nxt[G::REG_PREFETCH ? G::MB : 1][G::REG_PREFETCH ? G::KS : 1];
     // prefetch of the next tile (clamped to the last one: an unconditional load keeps the arrays in registers -- the
     // compiler demoted conditionally initialised prefetch arrays to scratch)
     const int64_t tn = min((int64_t)(tile + n_slots), n_tiles - 1);
-    load_tile(tn, nxt);                // prefetch: in flight during this tile's MFMAs and epilogue
-    uint4 cgh[kRlRowsPerWave / EROWS];  // RL_BWD_SUMS / _APPLY: this tile's gh chunks (row-contiguous), in flight during the MFMAs
+    if constexpr (G::REG_PREFETCH) load_tile(tn, nxt);                // prefetch: in flight during this tile's MFMAs and epilogue
+    uint4 cgh[G::RPW / EROWS];  // RL_BWD_SUMS / _APPLY: this tile's gh chunks (row-contiguous), in flight during the MFMAs
     if constexpr (EPI == RL_BWD_SUMS || EPI == RL_BWD_APPLY) {
-      const int64_t b0 = tile * kRlTile + wave * kRlRowsPerWave;
+      const int64_t b0 = tile * G::TILE + wave * G::RPW;
 #pragma unroll
-      for (int it = 0; it < kRlRowsPerWave / EROWS; ++it) {
+      for (int it = 0; it < G::RPW / EROWS; ++it) {
         int64_t row = b0 + it * EROWS + erow0;
         if (row >= m_rows) row = m_rows - 1;
         cgh[it] = *reinterpret_cast<const uint4*>(gh + row * D + n0 + ech * 8);
       }
     }
 
-    rl_f32x4_t acc[2][G::NB];
+    rl_f32x4_t acc[G::MB][G::NB];
 #pragma unroll
     for (int nb = 0; nb < G::NB; ++nb) {
       const rl_f32x4_t b4 = *reinterpret_cast<const rl_f32x4_t*>(lds_bias + nb * 16 + q * 4);
-      acc[0][nb] = b4; acc[1][nb] = b4;
+#pragma unroll
+      for (int mb = 0; mb < G::MB; ++mb) acc[mb][nb] = b4;
     }
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks)
 #pragma unroll
       for (int nb = 0; nb < G::NB; ++nb) {
         const uint4 fa = *reinterpret_cast<const uint4*>(lds_w + ((size_t)(nb * 16 + r16) * G::PITCH_W + ks * 32 + q * 8) * 2);
-        acc[0][nb] = rl_mfma<T>(fa, fb[0][ks], acc[0][nb]);
-        acc[1][nb] = rl_mfma<T>(fa, fb[1][ks], acc[1][nb]);
+#pragma unroll
+        for (int mb = 0; mb < G::MB; ++mb) acc[mb][nb] = rl_mfma<T>(fa, fb[mb][ks], acc[mb][nb]);
       }
+    if constexpr (!G::REG_PREFETCH) load_tile(tn, fb);   // the fragments are consumed: the next tile's rows travel during the epilogue
     // ---- accumulators (lane: row m = mb*16 + r16, columns nb*16 + q*4 .. +3) -> per-wave stage, rounded to T -------
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < G::MB; ++mb)
 #pragma unroll
       for (int nb = 0; nb < G::NB; ++nb)
         *reinterpret_cast<uint2*>(my_stage + ((size_t)(mb * 16 + r16) * G::PITCH_S + nb * 16 + q * 4) * 2) = rl_pack4<T>(acc[mb][nb]);
@@ -239,9 +285,9 @@ __global__ __launch_bounds__(kBlock, RlFwdGeom<D>::WG_PER_CU) void rowblock_line
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- epilogue on row-contiguous 16-B chunks ----------------------------------------------------------------
-    const int64_t base = tile * kRlTile + wave * kRlRowsPerWave;
+    const int64_t base = tile * G::TILE + wave * G::RPW;
 #pragma unroll
-    for (int it = 0; it < kRlRowsPerWave / EROWS; ++it) {
+    for (int it = 0; it < G::RPW / EROWS; ++it) {
       const int rl = it * EROWS + erow0;
       const int64_t row = base + rl;
       uint4 v = *reinterpret_cast<const uint4*>(my_stage + ((size_t)rl * G::PITCH_S + ech * 8) * 2);
@@ -275,14 +321,15 @@ __global__ __launch_bounds__(kBlock, RlFwdGeom<D>::WG_PER_CU) void rowblock_line
           }
           *reinterpret_cast<uint4*>(out + row * D + n0 + ech * 8) = V::pack(a);
         } else if constexpr (EPI == RL_BWD_APPLY) {       // = bn_act_bwd_kernel on the rounded Y (bn_act.hip), same formula
-          float a[8], g[8];
+          float a[8], g[8], mu[8], is[8], ww[8], bb[8], k1[8], k2[8];
           V::unpack(v, a);
           V::unpack(cgh[it], g);
+          bwd_consts(0, mu); bwd_consts(1, is); bwd_consts(2, ww); bwd_consts(3, bb); bwd_consts(4, k1); bwd_consts(5, k2);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float xh = (a[j] - c0[j]) * c1[j];
-            const float dz = g[j] * rl_act_grad<ACT>(xh * c2[j] + c3[j]);
-            a[j] = c2[j] * c1[j] * (dz - k1[j] - xh * k2[j]);
+            const float xh = (a[j] - mu[j]) * is[j];
+            const float dz = g[j] * rl_act_grad<ACT>(xh * ww[j] + bb[j]);
+            a[j] = ww[j] * is[j] * (dz - k1[j] - xh * k2[j]);
           }
           const uint4 packed = V::pack(a);
           *reinterpret_cast<uint4*>(out + row * D + n0 + ech * 8) = packed;
@@ -292,13 +339,14 @@ __global__ __launch_bounds__(kBlock, RlFwdGeom<D>::WG_PER_CU) void rowblock_line
             for (int j = 0; j < 8; ++j) s1[j] += a[j];
           }
         } else {                                          // = bn_act_bwd_reduce_kernel on the rounded Y
-          float a[8], g[8];
+          float a[8], g[8], mu[8], is[8], ww[8], bb[8];
           V::unpack(v, a);
           V::unpack(cgh[it], g);
+          bwd_consts(0, mu); bwd_consts(1, is); bwd_consts(2, ww); bwd_consts(3, bb);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float xh = (a[j] - c0[j]) * c1[j];
-            const float dz = g[j] * rl_act_grad<ACT>(xh * c2[j] + c3[j]);
+            const float xh = (a[j] - mu[j]) * is[j];
+            const float dz = g[j] * rl_act_grad<ACT>(xh * ww[j] + bb[j]);
             s1[j] += dz; s2[j] += dz * xh;
           }
         }
@@ -306,24 +354,26 @@ __global__ __launch_bounds__(kBlock, RlFwdGeom<D>::WG_PER_CU) void rowblock_line
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (G::REG_PREFETCH) {
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+      for (int mb = 0; mb < G::MB; ++mb)
 #pragma unroll
-      for (int ks = 0; ks < G::KS; ++ks) fb[mb][ks] = nxt[mb][ks];
+        for (int ks = 0; ks < G::KS; ++ks) fb[mb][ks] = nxt[mb][ks];
+    }
   }
 
   // ---- per-slot partial sums: ws[slot][0][c] = sum(y - shift), ws[slot][1][c] = sum((y - shift)^2); a half writes its channels ----
   if (stats_ws) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(lds_stage);       // [2][kBlock][8] floats = 16 KB (stage is >= 34 KB)
+    float* red = reinterpret_cast<float*>(lds_stage);       // [2][THREADS][8] floats = 16 / 32 KB (stage is >= 34 KB; 18 KB at D = 64: see below)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { red[(0 * kBlock + threadIdx.x) * 8 + j] = s1[j]; red[(1 * kBlock + threadIdx.x) * 8 + j] = s2[j]; }
+    for (int j = 0; j < 8; ++j) { red[(0 * G::THREADS + threadIdx.x) * 8 + j] = s1[j]; red[(1 * G::THREADS + threadIdx.x) * 8 + j] = s2[j]; }
     __syncthreads();
-    for (int item = threadIdx.x; item < 2 * G::NW; item += kBlock) {
+    for (int item = threadIdx.x; item < 2 * G::NW; item += G::THREADS) {
       const int which = item / G::NW, c = item - which * G::NW;
       const int ch = c / 8, j = c - ch * 8;
       float a = 0.f;
-      for (int t = ch; t < kBlock; t += G::CH) a += red[(which * kBlock + t) * 8 + j];     // fixed order: deterministic
+      for (int t = ch; t < G::THREADS; t += G::CH) a += red[(which * G::THREADS + t) * 8 + j];     // fixed order: deterministic
       stats_ws[((size_t)slot * 2 + which) * D + n0 + c] = a;
     }
   }
@@ -904,7 +954,7 @@ template <typename T, int D>
 __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __restrict__ g, const T* __restrict__ x,
                                                                     float* __restrict__ dw_ws, float* __restrict__ colsum_ws,
                                                                     int64_t m_rows, int64_t ws_stride, int64_t x_ld,
-                                                                    const int32_t* __restrict__ m_dyn) {
+                                                                    const int32_t* __restrict__ m_dyn, int64_t g_ld) {
   using G = RlGeom<D>;
   using V = Vec16<T>;
   if (m_dyn) m_rows = *m_dyn;
@@ -937,7 +987,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __r
     for (int it = 0; it < EIT; ++it) {
       int64_t row = base + it * EROWS + erow0;
       if (row >= m_rows) row = m_rows - 1;
-      gg[it] = *reinterpret_cast<const uint4*>(g + row * D + ech * 8);
+      gg[it] = *reinterpret_cast<const uint4*>(g + row * g_ld + ech * 8);
     }
   };
   int64_t tile = blockIdx.x;
@@ -1029,7 +1079,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void weight_grad_kernel(const T* __r
 
 template <typename T, int D>
 int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum_ws, int64_t m, int grid, int64_t ws_stride, int64_t x_ld,
-                       hipStream_t st, const int32_t* m_dyn) {
+                       hipStream_t st, const int32_t* m_dyn, int64_t g_ld) {
   const size_t lds = DwGeom<D>::tile_bytes + DwGeom<D>::xtile_bytes;
   static bool attr_set_dev[64] = {};
   bool& attr_set = per_device_flag(attr_set_dev);
@@ -1038,7 +1088,7 @@ int launch_weight_grad(const void* g, const void* x, float* dw_ws, float* colsum
     if (e != hipSuccess) { set_error("weight_grad: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((weight_grad_kernel<T, D>), dim3(grid), dim3(kDwThreads), lds, st, (const T*)g, (const T*)x, dw_ws, colsum_ws, m, ws_stride, x_ld, m_dyn);
+  hipLaunchKernelGGL((weight_grad_kernel<T, D>), dim3(grid), dim3(kDwThreads), lds, st, (const T*)g, (const T*)x, dw_ws, colsum_ws, m, ws_stride, x_ld, m_dyn, g_ld);
   return check_launch("weight_grad");
 }
 
@@ -1055,7 +1105,7 @@ int launch_rowblock(void* out, const void* in, const void* wl, const void* bias,
     if (e != hipSuccess) { set_error("rowblock_linear: cannot reserve %zu B of LDS: %s", G::lds_bytes, hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((rowblock_linear_kernel<T, D, EPI, ACT>), dim3(grid), dim3(kBlock), G::lds_bytes, st, (T*)out, (const T*)in,
+  hipLaunchKernelGGL((rowblock_linear_kernel<T, D, EPI, ACT>), dim3(grid), dim3(G::THREADS), G::lds_bytes, st, (T*)out, (const T*)in,
                      (const T*)wl, (const T*)bias, (const T*)addend, stats_ws, shift, self_shift, m, epi);
   return check_launch("rowblock_linear");
 }
@@ -1074,7 +1124,7 @@ extern "C" int pygho_rowblock_linear_blocks(int64_t m) {
 extern "C" int pygho_rowblock_linear_slots(int64_t m, int64_t d) {
   if (m <= 0) return 0;
   if (d <= 128) return pygho_rowblock_linear_blocks(m);
-  const int slots = grid_for(m, kRlTile, 128);
+  const int slots = grid_for(m, RlFwdGeom<256>::TILE, 128);
   return (slots + 7) & ~7;
 }
 
@@ -1298,7 +1348,9 @@ extern "C" int pygho_bn_bwd_linear_dw_recompute_dyn(void* gx, float* dw_ws, cons
 }
 
 static int weight_grad_entry(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t x_ld, int64_t m, int64_t d,
-                             int dtype, int64_t ws_stride, void* stream, const int32_t* m_dyn) {
+                             int dtype, int64_t ws_stride, void* stream, const int32_t* m_dyn, int64_t g_ld = 0) {
+  if (g_ld == 0) g_ld = d;
+  if (g_ld < d || (g_ld % 8) != 0) { set_error("weight_grad: g_ld >= d, a multiple of 8"); return PYGHO_ERR_INVALID; }
   if (m <= 0 || d <= 0) { set_error("weight_grad: empty input"); return PYGHO_ERR_INVALID; }
   if (!dw_ws || !g || !x) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
   if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("weight_grad: bf16 / f16 only"); return PYGHO_ERR_UNSUPPORTED; }
@@ -1307,15 +1359,20 @@ static int weight_grad_entry(float* dw_ws, float* colsum_ws, const void* g, cons
   const int grid = pygho_bn_bwd_linear_dw_blocks(m);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == PYGHO_BF16)
-    return d == 128 ? launch_weight_grad<bf16, 128>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st, m_dyn)
-                    : launch_weight_grad<bf16, 64>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st, m_dyn);
-  return d == 128 ? launch_weight_grad<f16, 128>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st, m_dyn)
-                  : launch_weight_grad<f16, 64>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st, m_dyn);
+    return d == 128 ? launch_weight_grad<bf16, 128>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st, m_dyn, g_ld)
+                    : launch_weight_grad<bf16, 64>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st, m_dyn, g_ld);
+  return d == 128 ? launch_weight_grad<f16, 128>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st, m_dyn, g_ld)
+                  : launch_weight_grad<f16, 64>(g, x, dw_ws, colsum_ws, m, grid, ws_stride, x_ld, st, m_dyn, g_ld);
 }
 
 extern "C" int pygho_weight_grad(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t x_ld, int64_t m, int64_t d,
                                  int dtype, int64_t ws_stride, void* stream) {
   return weight_grad_entry(dw_ws, colsum_ws, g, x, x_ld, m, d, dtype, ws_stride, stream, nullptr);
+}
+
+extern "C" int pygho_weight_grad_strided(float* dw_ws, float* colsum_ws, const void* g, int64_t g_ld, const void* x, int64_t x_ld, int64_t m_cap,
+                                         const int32_t* m_dev, int64_t d, int dtype, int64_t ws_stride, void* stream) {
+  return weight_grad_entry(dw_ws, colsum_ws, g, x, x_ld, m_cap, d, dtype, ws_stride, stream, m_dev, g_ld);
 }
 
 extern "C" int pygho_weight_grad_dyn(float* dw_ws, float* colsum_ws, const void* g, const void* x, int64_t x_ld, int64_t m_cap,

@@ -738,7 +738,14 @@ def test_width_256_split_passes_equal_the_stored_preactivation_passes(dev, dtype
         torch.testing.assert_close(sdx1, sdx0, rtol=1e-5, atol=1e-3)
         dw_ref = gpre0.double().t() @ x.double()
         sc = float(dw_ref.abs().max())
-        torch.testing.assert_close(dw1.double() / sc, dw_ref / sc, rtol=0, atol=1e-5)
+        # (the library's batched split-K at this width: f32 slabs where torch.bmm takes out_dtype, else 16-bit slabs)
+        torch.testing.assert_close(dw1.double() / sc, dw_ref / sc, rtol=0, atol=1e-5 if _ops._BMM_OUT_DTYPE[0] else 4e-3)
+        _ops.FORCE_DW_BLOCKS = True                                            # and the 2 x 2 blocks of the weight-gradient kernel
+        try:
+            dw2 = _ops.weight_grad_splitk(gpre0, x, torch.float32)
+        finally:
+            _ops.FORCE_DW_BLOCKS = False
+        torch.testing.assert_close(dw2.double() / sc, dw_ref / sc, rtol=0, atol=1e-5)
 
 
 def test_tuple_block_without_stored_preactivation_equals_stored(dev):

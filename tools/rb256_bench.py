@@ -61,7 +61,12 @@ def main():
     rec("lib_bn_backward", timed(lambda: _ops._bn_backward(pre, gh, saved, True, "silu", want_colsum=True)), 5)
     rec("lib_gx", timed(lambda: gh @ w), 2)
     rec("lib_gx_add", timed(lambda: (gh @ w).add_(g)), 5)
-    rec("lib_dw", timed(lambda: torch.mm(gh.t(), x, out_dtype=torch.float32)), 2)
+    rec("lib_dw", timed(lambda: torch.mm(gh.t(), x, out_dtype=torch.float32), reps=5), 2)
+    _ops.FORCE_DW_BLOCKS = True
+    rec("dw_2x2_blocks", timed(lambda: _ops.weight_grad_splitk(gh, x, torch.float32)), 4)
+    _ops.FORCE_DW_BLOCKS = False
+    rec("lib_dw_batched_splitk", timed(lambda: _ops.weight_grad_splitk(gh, x, torch.float32), reps=5), 2)
+    rec("bn_act_fwd_generic", timed(lambda: _ops._bn_forward(pre, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, bn.eps, "silu", None, partial)), 2)
     print(json.dumps(out))
 
 
