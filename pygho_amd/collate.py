@@ -108,7 +108,7 @@ class DeviceGraphStore:
             # for the fixed-capacity batch slots (`slots.BatchSlot`): graph-LOCAL CSR pointers (a batch's pointers are these plus the
             # graph's message offset -- collated like any index array, no scan per batch), the triples' other two coordinates already
             # in by-c / by-d order, and the edge feature each message looks up (forward and by-c order) when the second operand is A
-            ptr_a, ptr_c, ptr_d, by_c, by_d, look = [], [], [], [], [], []
+            ptr_a, ptr_c, ptr_d, by_c, by_d, look, max_a = [], [], [], [], [], [], []
             want_look = roles[3][0] != "X" and all(np.ndim(r.edge_attr) == 1 for r in records)
             excl = lambda cnt: (np.cumsum(cnt) - cnt).reshape(1, -1)
             for r in records:
@@ -117,6 +117,7 @@ class DeviceGraphStore:
                 perm_c.append(pc.reshape(1, -1))
                 perm_d.append(pd.reshape(1, -1))
                 cnt_a.append(np.bincount(a, minlength=rows_of(r, roles[0])).reshape(1, -1))
+                max_a.append(int(cnt_a[-1].max()) if cnt_a[-1].size else 0)
                 cnt_c.append(np.bincount(c, minlength=rows_of(r, roles[1])).reshape(1, -1))
                 cnt_d.append(np.bincount(dd_, minlength=rows_of(r, roles[3])).reshape(1, -1))
                 ptr_a.append(excl(cnt_a[-1][0]))
@@ -132,6 +133,9 @@ class DeviceGraphStore:
                                   "by_c": _cat32(by_c, 1, d), "by_d": _cat32(by_d, 1, d)}
             if want_look:
                 self.plan_parts[k]["look"] = _cat32(look, 1, d)
+            # longest forward segment per graph: a batch's `plan.fwd.max_len` (asked by the max / min forward: do the tie counts fit the
+            # value dtype?) is a maximum over the selected graphs -- answered on the host, no device read
+            self.plan_parts[k]["h_max_a"] = np.asarray(max_a, dtype=np.int64)
         # the by-edge gradient's scatter plans (csrc/seg_scatter.hip), likewise ONCE for the whole store: the device planner over the
         # graph-local triples with one block per graph.  A batch's chunks are its graphs' chunks with the message / row offsets added
         # and its packed words are its graphs' words unchanged (they are relative to chunk windows and block edge ranges)
@@ -290,6 +294,7 @@ class DeviceGraphStore:
             plan = _ops.MessagePlan.from_parts(acd, total[fam_of(roles[0])], total[fam_of(roles[1])], total[fam_of(roles[3])],
                                                csr(parts["cnt_a"], roles[0]), csr(parts["cnt_c"], roles[1]), perm("perm_c"),
                                                csr(parts["cnt_d"], roles[3]), perm("perm_d"))
+            plan.fwd._memo = {"max_len": int(parts["h_max_a"][lay.ids_h].max()) if lay.g else 0}
             _ops.install_message_plan(acd, plan)
             sc = self.scatter_parts.get(k)
             if sc is not None and total[("sc", k)] > 0:

@@ -253,8 +253,8 @@ def defer_error(flag: Tensor, msg: str) -> None:
     read by the next planner fetch made on the same stream (whose synchronisation orders the read behind the write -- a fetch on
     another stream would read a flag that may not even be zero-filled yet), or by `check_deferred_errors()`."""
     _PENDING_ERRORS.append((flag, msg, _stream_id(flag.device)))
-    if len(_PENDING_ERRORS) > 64:
-        check_deferred_errors()
+    if len(_PENDING_ERRORS) > 64 and not (flag.is_cuda and torch.cuda.is_current_stream_capturing()):
+        check_deferred_errors()              # (a device synchronisation: not legal while a stream is capturing -- the list waits)
 
 
 def _fetch(t: Tensor):
@@ -300,6 +300,8 @@ class deferred_index_checks:
 def check_deferred_errors() -> None:
     """verify EVERY index-range check that was deferred, whichever stream produced it (one device synchronisation per device with
     pending flags)"""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("pygho_amd: check_deferred_errors() synchronises the device; call it outside the stream capture")
     pending = list(_PENDING_ERRORS)
     _PENDING_ERRORS.clear()
     for dev in {e[0].device for e in pending}:
@@ -308,9 +310,12 @@ def check_deferred_errors() -> None:
         FETCHES[0] += 1
     if pending:
         vals = [int(v) for v in torch.cat([e[0].reshape(-1).to(torch.int64).cpu() for e in pending]).tolist()]
+        bad = []
         for e, v in zip(pending, vals):
-            if v != 0:
-                raise ValueError(e[1])
+            if v != 0 and e[1] not in bad:
+                bad.append(e[1])
+        if bad:                                  # EVERY failed check is reported (the list was cleared above)
+            raise ValueError("; ".join(bad))
 
 
 def plan_from_keys(keys: Tensor, n_seg: int, assume_sorted: Optional[bool] = None) -> SegPlan:

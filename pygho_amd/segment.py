@@ -815,7 +815,9 @@ def table_grad(g2: Tensor, ind: Tensor, n_table: int) -> Tensor:
     seen = getattr(ind32, "_pygho_table_checked", None)
     bound = getattr(ind, "_pygho_value_bound", None)         # set by `collate.DeviceGraphStore`: the values were range-checked there
     known = bound is not None and bound[0] == ind._version and bound[1] <= n_table
-    if not known and (seen is None or seen != (ind32._version, n_table)):
+    if not known and (seen is None or seen != (ind32._version, n_table)) and not torch.cuda.is_current_stream_capturing():
+        # (under capture no flag: a flag allocated and zero-filled INSIDE a graph is uninitialised pool memory until the first replay,
+        # and a fetch on this stream before that would read it -- the index was either checked in warm-up or stays unchecked here)
         err = torch.zeros(1, dtype=torch.int32, device=dev)
     nblk = int(lib().pygho_table_grad_blocks(m, d, n_table))
     ws = torch.empty((nblk, n_table * d), dtype=torch.float32, device=dev)

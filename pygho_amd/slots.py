@@ -278,8 +278,7 @@ class BatchSlot:
             na, nc, nd = (self.caps[fam_of(roles[i])] for i in (0, 1, 3))
             plan = _ops.MessagePlan.from_arrays(ent["acd"], na, nc, nd, ent["acd32"], ent["ptr_a"], ent["ptr_c"], ent["perm_c"], ent["by_c"],
                                                 ent["ptr_d"], ent["perm_d"], ent["by_d"])
-            lens = np.asarray(st.h_len[("acd", k)])
-            plan.fwd._memo = {"max_len": h_max(lens)}            # (a bound: no segment is longer than its graph's message count)
+            plan.fwd._memo = {"max_len": h_max(st.plan_parts[k]["h_max_a"])}     # the store's longest forward segment (a bound for any batch)
             if "look" in ent and fam_of(roles[3]) == "edge":
                 plan._lookup = (self.ea, (ent["look"][0], ent["look"][1]))      # A's values as a lookup of the edge feature
             _ops.install_message_plan(ent["acd"], plan)

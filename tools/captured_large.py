@@ -29,13 +29,14 @@ for mode in ("eager", "hipgraph", "eager", "hipgraph"):
         loss.backward()
         opt.step()
         return loss.detach()
+    model.prepare(dd)                        # every plan of the batch, the by-edge scatter plans included (the dispatcher never plans)
     if mode == "eager":
         run = step
         for _ in range(16):
             run()
     else:
-        for _ in range(14):
-            step()                           # plans of the recurring pattern (scatter plans, table plans) exist before capture
+        for _ in range(4):
+            step()
         gs = GraphedStep(step, warmup=2)
         run = gs.replay
         run()
