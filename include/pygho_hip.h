@@ -651,7 +651,8 @@ int pygho_bn_bwd_fold_sums(float* sum_a, float* sum_b, const float* ws, int64_t 
  *
  * pygho_graph_bfs_dist (SpTupleSampler.py:12-88 for every root at once; with max_hop >= 254 also the all-pairs matrix of :145-150):
  *   dist + sq_ptr[g] = the (n_g x n_g) matrix of graph g, row = root, as bytes: hop distance if <= max_hop, else 255.
- *   sq_ptr (n_graphs + 1) int64 = exclusive sum of n_g^2; max_nodes = max n_g <= 255 (the matrix of a graph lives in LDS). */
+ *   sq_ptr (n_graphs + 1) int64 = exclusive sum of n_g^2; max_nodes = max n_g (up to 255 nodes a graph's matrix lives in LDS, a larger
+ *   graph searches in its slice of `dist`; the reference has no bound on the node count). */
 int pygho_graph_bfs_dist(uint8_t* dist, const int64_t* sq_ptr, const int32_t* node_ptr, const int32_t* rowptr,
                          const int32_t* col, int64_t n_graphs, int64_t max_nodes, int max_hop, void* stream);
 /* KhopSampler (SpTupleSampler.py:91-126): count[i] = #{v : dist(i, v) <= hop};  with offset = its exclusive scan,

@@ -19,6 +19,66 @@ from .backend.SpTensor import SparseTensor
 from .synth import KEYSEP, GraphRecord, parse_key
 
 
+import ctypes
+
+
+class CollateDesc(ctypes.Structure):
+    """`pygho_collate_desc` of include/pygho_hip.h: one output array of a batch"""
+    _fields_ = [("out", ctypes.c_void_p), ("src", ctypes.c_void_p), ("src_start", ctypes.c_void_p), ("out_ptr", ctypes.c_void_p),
+                ("inc", ctypes.c_void_p * 4), ("pad", ctypes.c_void_p), ("src_ld", ctypes.c_int64), ("out_ld", ctypes.c_int64),
+                ("rows", ctypes.c_int32), ("out_i32", ctypes.c_int32), ("transposed", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+def launch_collate(descs, n_sel: int, device) -> None:
+    """every array of a batch in ONE launch (`pygho_collate_batch`): the descriptor table goes to the device in one small copy"""
+    if not descs:
+        return
+    assert int(lib().pygho_collate_desc_bytes()) == ctypes.sizeof(CollateDesc)
+    table = (CollateDesc * len(descs))(*descs)
+    raw = torch.frombuffer(bytearray(memoryview(table).cast("B")), dtype=torch.uint8).to(device, non_blocking=True)
+    check(lib().pygho_collate_batch(raw.data_ptr(), len(descs), n_sel, max(int(d.out_ld) for d in descs), stream_ptr(device)), "collate_batch")
+
+
+class _BatchBuilder:
+    """collects the output arrays of one exactly sized batch over a `_Layout`; `launch()` writes them all with one kernel"""
+
+    def __init__(self, store: "DeviceGraphStore", lay: "_Layout"):
+        self.store, self.lay, self.descs = store, lay, []
+
+    def off(self, fam) -> int:
+        """device address of the running offsets of family `fam` (an increment row: entry s = offset of graph s)"""
+        return self.lay.dev[("optr", fam)].data_ptr()
+
+    def total(self, fam) -> int:
+        """device address of the batch's total of family `fam` (a pad value: the closing entry of a pointer array)"""
+        return self.lay.dev[("optr", fam)].data_ptr() + 8 * self.lay.g
+
+    def rows_of(self, inc: torch.Tensor):
+        """row addresses of a (rows, g) increment piece of the layout"""
+        return tuple(inc.data_ptr() + 8 * self.lay.g * r for r in range(inc.shape[0]))
+
+    def add(self, src: torch.Tensor, fam, incs=(), pad=None, i32: bool = False, transposed: bool = False, extra: int = 0) -> torch.Tensor:
+        lay = self.lay
+        rows, cols = src.shape[0], lay.total[fam] + extra
+        out = torch.empty((cols, rows) if transposed else (rows, cols), dtype=torch.int32 if i32 else torch.int64, device=self.store.device)
+        if cols == 0 or rows == 0:
+            return out
+        d = CollateDesc()
+        d.out, d.src = out.data_ptr(), src.data_ptr()
+        d.src_start, d.out_ptr = lay.dev[("start", fam)].data_ptr(), lay.dev[("optr", fam)].data_ptr()
+        for r, a in enumerate(incs):
+            d.inc[r] = a
+        d.pad = pad
+        d.src_ld, d.out_ld, d.rows = src.shape[1], cols, rows
+        d.out_i32, d.transposed = int(i32), int(transposed)
+        self.descs.append(d)
+        return out
+
+    def launch(self) -> None:
+        launch_collate(self.descs, self.lay.g, self.store.device)
+        self.descs = []
+
+
 def _cat32(arrs: List[np.ndarray], axis: int, device) -> torch.Tensor:
     a = np.concatenate(arrs, axis=axis)
     assert a.size == 0 or (a.min() >= 0 and a.max() < 2 ** 31)
@@ -87,6 +147,7 @@ class DeviceGraphStore:
         self.edge_ptr = _ptr64([r.edge_index.shape[1] for r in records], d)
         self.tup_ptr = _ptr64([r.tupleid.shape[1] for r in records], d)
         self.x = _cat32([r.x.reshape(1, -1) for r in records], 1, d)
+        self._zeros_node = torch.zeros((1, max(int(self.node_ptr[-1]), 1)), dtype=torch.int32, device=d)     # + a per-graph increment = the batch vector
         self.edge_index = _cat32([r.edge_index for r in records], 1, d)
         self.edge_attr = _cat32([r.edge_attr.reshape(1, -1) for r in records], 1, d)
         self.tupleid = _cat32([r.tupleid for r in records], 1, d)
@@ -212,13 +273,15 @@ class DeviceGraphStore:
             check(lib().pygho_collate_rows(*args, stream_ptr(self.device)), "collate_rows")
         return out
 
-    def _install_node_plans(self, dd, lay: "_Layout") -> None:
+    def _install_node_plans(self, dd, lay: "_Layout", B: "_BatchBuilder"):
         """the groupings a model step asks for beyond the message plans, installed where the operators look for them: nodes by
         graph (graph pooling), tuples by root (subgraph pooling, `pair_product`'s by-row plan) with their longest segments, and the
-        mirror verdict of the tuple set (`segment.pair_mirror`).  With these a step on the batch builds no plan and reads nothing back."""
+        mirror verdict of the tuple set (`segment.pair_mirror`).  With these a step on the batch builds no plan and reads nothing back.
+        The arrays are only REQUESTED from the builder here; the returned closure installs what needs the narrowed index rows, after
+        the batch's one kernel has been launched."""
         g, n, X, ids_h = lay.g, lay.total["node"], dd["X"], lay.ids_h
         if g == 0:
-            return
+            return lambda: None
         _ops.install_plan(dd["batch"], _ops.SegPlan(lay.dev[("optr32", "node")], None, g, n), ("scatter",),
                           max_len=self.h_len["node"][ids_h].max())
         for (which, dim), part in self.group_parts.items():
@@ -227,18 +290,22 @@ class DeviceGraphStore:
             keys = sp._row(dim)
             keys._pygho_plan_factory = (keys._version, self._group_factory(part, lay, fam))
         if self.root_parts is None:
-            return
+            return lambda: None
         row = X._row(0)
-        cnt = self._rows(self.root_parts["cnt"], lay, "node").reshape(-1)
-        _ops.install_plan(row, _ops.SegPlan(_ops.exclusive_scan(cnt).to(torch.int32), None, n, lay.total["tup"]), ("scatter", "pair-row"),
+        # tuples by root: the graph-local CSR pointers + the graph's tuple offset, closed by the batch's tuple total (no scan)
+        root_ptr = B.add(self.root_parts["ptr"], "node", incs=(B.off("tup"),), pad=B.total("tup"), i32=True, extra=1).reshape(-1)
+        _ops.install_plan(row, _ops.SegPlan(root_ptr, None, n, lay.total["tup"]), ("scatter", "pair-row"),
                           max_len=self.root_parts["h_max"][ids_h].max())
         if self.mirror_parts is None or lay.total["tup"] == 0 or lay.total["tup"] >= (1 << 31):
-            return
-        row32, col32, vidx32 = _ops.narrow_i32(row), _ops.narrow_i32(X._row(1)), _ops.narrow_i32(_ops.flat_index(X.values))
+            return lambda: None
         res = None
         if bool(self.mirror_parts["h_ok"][ids_h].all()):
-            res = self._rows(self.mirror_parts["pos"], lay, "tup", lay.dev[("off", "tup")], i32=True).reshape(-1)
-        row32._pygho_mirror = (col32, vidx32, n, res, (row32._version, col32._version, vidx32._version))
+            res = B.add(self.mirror_parts["pos"], "tup", incs=(B.off("tup"),), i32=True).reshape(-1)
+
+        def finish():
+            row32, col32, vidx32 = _ops.narrow_i32(row), _ops.narrow_i32(X._row(1)), _ops.narrow_i32(_ops.flat_index(X.values))
+            row32._pygho_mirror = (col32, vidx32, n, res, (row32._version, col32._version, vidx32._version))
+        return finish
 
     def _group_factory(self, part, lay: "_Layout", fam):
         def build(n_seg: int):
@@ -256,19 +323,24 @@ class DeviceGraphStore:
     def collate(self, graph_ids: Union[Sequence[int], torch.Tensor]) -> Dict:
         """datadict of the block-diagonal batch of ``graph_ids`` (any order, repeats allowed; a host sequence / CPU tensor: a
         device tensor of ids is read back first).  Output sizes, running offsets and per-graph increments are computed on the
-        host from the store's per-graph lengths and reach the device in ONE upload; the rest is one integer kernel per array."""
+        host from the store's per-graph lengths and reach the device in ONE upload; every array of the batch -- the API's int64 index
+        arrays and all plan arrays -- is then written by ONE kernel from a descriptor table (`pygho_collate_batch`; round 4: one
+        kernel per array and a scan per CSR pointer array, ~45 launches per batch)."""
         ids_h = (graph_ids.detach().cpu().numpy() if isinstance(graph_ids, torch.Tensor) else np.asarray(graph_ids)).astype(np.int64).reshape(-1)
         assert ids_h.size == 0 or (ids_h.min() >= 0 and ids_h.max() < self.num_graphs), "graph id out of range"
         lay = _Layout(self, ids_h)
+        B = _BatchBuilder(self, lay)
         g, n, total = lay.g, lay.total["node"], lay.total
         fam_of = lambda role: "tup" if role[0] == "X" else "edge"
-        ei = self._rows(self.edge_index, lay, "edge", lay.dev[("inc", "ei")])
-        ea = self._rows(self.edge_attr, lay, "edge").reshape(-1)
-        tid = self._rows(self.tupleid, lay, "tup", lay.dev[("inc", "tid")])
-        tf = self._rows(self.tuplefeat, lay, "tup")
-        tf = tf.reshape(-1) if not self.feat_shape else tf.t().contiguous().reshape((total["tup"],) + self.feat_shape)
-        x = self._rows(self.x, lay, "node").reshape(-1)
-        batch = torch.repeat_interleave(torch.arange(g, dtype=torch.int64, device=self.device), lay.dev[("len", "node")], output_size=n)
+        ei = B.add(self.edge_index, "edge", incs=B.rows_of(lay.dev[("inc", "ei")]))
+        ea = B.add(self.edge_attr, "edge").reshape(-1)
+        tid = B.add(self.tupleid, "tup", incs=B.rows_of(lay.dev[("inc", "tid")]))
+        if self.feat_shape:
+            tf = B.add(self.tuplefeat, "tup", transposed=True).reshape((total["tup"],) + self.feat_shape)
+        else:
+            tf = B.add(self.tuplefeat, "tup").reshape(-1)
+        x = B.add(self.x, "node").reshape(-1)
+        batch = B.add(self._zeros_node, "node", incs=(B.off("graph"),)).reshape(-1)         # 0 + the graph's position in the batch
         for name, t in (("x", x), ("ea", ea), ("tf", tf)):      # values below this bound (the store checked them when it was built)
             t._pygho_value_bound = (t._version, self.h_vmax[name] + 1)
         for ind in (ei, tid):                       # non-negative and below n by construction: the hash asserts need no read-back
@@ -279,31 +351,60 @@ class DeviceGraphStore:
             "A": SparseTensor(ei, ea, [n, n], is_coalesced=True),
             "X": SparseTensor(tid, tf, [n] * self.sd + list(self.feat_shape), is_coalesced=True),
         }
-        self._install_node_plans(dd, lay)
+        # the int32 copies the kernels read (a fresh batch used to narrow them inside the step: ~8 launches), from the same launch
+        seeds = [(x, B.add(self.x, "node", i32=True).reshape(-1)), (ea, B.add(self.edge_attr, "edge", i32=True).reshape(-1)),
+                 (batch, B.add(self._zeros_node, "node", incs=(B.off("graph"),), i32=True).reshape(-1))]
+        if not self.feat_shape:
+            seeds.append((tf, B.add(self.tuplefeat, "tup", i32=True).reshape(-1)))
+        tid32 = B.add(self.tupleid, "tup", incs=B.rows_of(lay.dev[("inc", "tid")]), i32=True)
+        ei32 = B.add(self.edge_index, "edge", incs=B.rows_of(lay.dev[("inc", "ei")]), i32=True)
+        seeds += [(dd["X"]._row(dim), tid32[dim]) for dim in range(self.sd)] + [(dd["A"]._row(dim), ei32[dim]) for dim in range(2)]
+        for t64, t32 in seeds:
+            if t64.numel():
+                t64._pygho_i32 = (t64._version, t32)
+        finish = [self._install_node_plans(dd, lay, B)]
         for k in self.keys:
             roles = parse_key(k)
-            acd = self._rows(self.acd[k], lay, ("acd", k), lay.dev[("inc", "acd", k)])
+            fm = ("acd", k)
+            acd = B.add(self.acd[k], fm, incs=B.rows_of(lay.dev[("inc", "acd", k)]))
             dd[k + KEYSEP + "acd"] = acd
-            # message plan from the stored per-graph groupings (no sort, no host sync): permutations get the message offset of
-            # their graph, the per-row message counts are collated by the operand's rows and scanned into CSR pointers
+            # message plan from the stored per-graph groupings (no sort, no scan, no host sync): graph-local CSR pointers and
+            # permutations get the graph's message offset, the triples' coordinates in by-c / by-d order their rows' offsets
             if k not in self.plan_parts:
                 continue
             parts = self.plan_parts[k]
-            csr = lambda cnt, role: _ops.exclusive_scan(self._rows(cnt, lay, fam_of(role)).reshape(-1)).to(torch.int32)
-            perm = lambda which: self._rows(parts[which], lay, ("acd", k), lay.dev[("off", ("acd", k))], i32=True).reshape(-1)
-            plan = _ops.MessagePlan.from_parts(acd, total[fam_of(roles[0])], total[fam_of(roles[1])], total[fam_of(roles[3])],
-                                               csr(parts["cnt_a"], roles[0]), csr(parts["cnt_c"], roles[1]), perm("perm_c"),
-                                               csr(parts["cnt_d"], roles[3]), perm("perm_d"))
-            plan.fwd._memo = {"max_len": int(parts["h_max_a"][lay.ids_h].max()) if lay.g else 0}
-            _ops.install_message_plan(acd, plan)
+            fa, fc, fd = fam_of(roles[0]), fam_of(roles[1]), fam_of(roles[3])
+            csr = lambda which, fam: B.add(parts[which], fam, incs=(B.off(fm),), pad=B.total(fm), i32=True, extra=1).reshape(-1)
+            perm = lambda which: B.add(parts[which], fm, incs=(B.off(fm),), i32=True).reshape(-1)
+            arrs = dict(acd32=B.add(self.acd[k], fm, incs=B.rows_of(lay.dev[("inc", "acd", k)]), i32=True),
+                        ptr_a=csr("ptr_a", fa), ptr_c=csr("ptr_c", fc), ptr_d=csr("ptr_d", fd), perm_c=perm("perm_c"), perm_d=perm("perm_d"),
+                        by_c=B.add(parts["by_c"], fm, incs=(B.off(fa), B.off(fd)), i32=True),
+                        by_d=B.add(parts["by_d"], fm, incs=(B.off(fa), B.off(fc)), i32=True))
+            if "look" in parts and fd == "edge":                # the edge feature every message looks up (forward and by-c order)
+                arrs["look"] = B.add(parts["look"], fm, i32=True)
             sc = self.scatter_parts.get(k)
+            sc_arrs = None
             if sc is not None and total[("sc", k)] > 0:
                 # chunk records {first message, first a row, first c row, packed}: message offset of the graph inside the batch instead
                 # of inside the store, row offsets of the two operands' graphs; the packed field and the words travel unchanged
-                ch = self._rows(sc["chunks_t"], lay, ("sc", k), lay.dev[("inc", "sc", k)], i32=True, transposed=True)
-                words = self._rows(sc["words"], lay, ("acd", k), i32=True).reshape(-1)
-                blk_e = self._rows(sc["blk_e"], lay, "graph", lay.dev[("inc", "blk", k)], i32=True, transposed=True)
-                _ops.install_scatter_plan(plan, lay.dev[("optr32", ("sc", k))], blk_e, ch, words, sc["max_edges"], sc["covers"])
+                sc_arrs = (B.add(sc["chunks_t"], ("sc", k), incs=B.rows_of(lay.dev[("inc", "sc", k)]), i32=True, transposed=True),
+                           B.add(sc["words"], fm, i32=True).reshape(-1),
+                           B.add(sc["blk_e"], "graph", incs=B.rows_of(lay.dev[("inc", "blk", k)]), i32=True, transposed=True))
+
+            def install(k=k, acd=acd, arrs=arrs, sc=sc, sc_arrs=sc_arrs, sizes=(total[fa], total[fc], total[fd]), parts=parts):
+                plan = _ops.MessagePlan.from_arrays(acd, *sizes, arrs["acd32"], arrs["ptr_a"], arrs["ptr_c"], arrs["perm_c"], arrs["by_c"],
+                                                    arrs["ptr_d"], arrs["perm_d"], arrs["by_d"], volatile=False)
+                plan.fwd._memo = {"max_len": int(parts["h_max_a"][lay.ids_h].max()) if lay.g else 0}
+                if "look" in arrs and arrs["look"].shape[1]:
+                    plan._lookup = (ea, (arrs["look"][0], arrs["look"][1]))     # A's values as a lookup of the edge feature
+                _ops.install_message_plan(acd, plan)
+                if sc_arrs is not None:
+                    ch, words, blk_e = sc_arrs
+                    _ops.install_scatter_plan(plan, lay.dev[("optr32", ("sc", k))], blk_e, ch, words, sc["max_edges"], sc["covers"])
+            finish.append(install)
+        B.launch()                                  # every array requested above: ONE kernel
+        for f in finish:
+            f()
         return dd
 
 

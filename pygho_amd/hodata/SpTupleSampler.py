@@ -12,7 +12,8 @@ reference's samplers (``tests/golden/samplers.npz``).
 Edges are walked from target to source like the reference's ``k_hop_subgraph`` (flow = 'source_to_target', :47-51).  ``I2Sampler``'s
 features are shortest-path distances of the UNDIRECTED graph in the reference (scipy ``shortest_path(directed=False)``, :145-150);
 here they come from the same search as the subsets, which is the same thing for the symmetric edge lists of every shipped dataset.
-Graphs of up to 255 nodes.
+Graphs of any size (up to 255 nodes the search runs in LDS, larger graphs in global memory); hop distances are bytes, so a
+search reaches at most 254 hops (`FULL`): in a graph of larger diameter the I2 features of farther nodes read "not reached".
 """
 from __future__ import annotations
 
@@ -42,8 +43,6 @@ class _GraphBatch:
         self.n_graphs = int(node_graph.max().item()) + 1 if self.n else 0
         sizes = torch.bincount(node_graph, minlength=self.n_graphs)
         self.max_nodes = int(sizes.max().item()) if self.n_graphs else 0
-        if self.max_nodes > 255:
-            raise NotImplementedError(f"pygho_amd samplers: graphs of more than 255 nodes ({self.max_nodes}) are not supported")
         zero = torch.zeros(1, dtype=torch.int64, device=dev)
         self.node_ptr = torch.cat((zero, torch.cumsum(sizes, 0))).to(torch.int32)
         self.sq_ptr = torch.cat((zero, torch.cumsum(sizes * sizes, 0)))

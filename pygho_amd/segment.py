@@ -415,9 +415,11 @@ class MessagePlan:
 
     @classmethod
     def from_arrays(cls, acd: Tensor, n_out: int, n_lhs: int, n_rhs: int, acd32: Tensor, fwd_ptr: Tensor, ptr_c: Tensor, perm_c: Tensor,
-                    by_c: Tensor, ptr_d: Tensor, perm_d: Tensor, by_d: Tensor) -> "MessagePlan":
-        """the plan over arrays that are ALL given and rewritten in place per batch (`slots.BatchSlot`): `acd32` (3, M) the narrowed
-        triples, `by_c` (2, M) = (a, d) in by-c order, `by_d` (2, M) = (a, c) in by-d order.  Nothing is computed or cached here."""
+                    by_c: Tensor, ptr_d: Tensor, perm_d: Tensor, by_d: Tensor, volatile: bool = True) -> "MessagePlan":
+        """the plan over arrays that are ALL given (`collate.DeviceGraphStore.collate`, `slots.BatchSlot`): `acd32` (3, M) the narrowed
+        triples, `by_c` (2, M) = (a, d) in by-c order, `by_d` (2, M) = (a, c) in by-d order.  Nothing is computed here.  `volatile`:
+        the arrays are rewritten in place per batch (a slot) -- nothing derived from them is cached, and the by-edge gradient runs the
+        gather form (its chunk list has no fixed length)."""
         self = cls.__new__(cls)
         self.m = acd.shape[1]
         self.n_out, self.n_lhs, self.n_rhs = n_out, n_lhs, n_rhs
@@ -427,11 +429,12 @@ class MessagePlan:
         self.c_fwd, self.d_fwd = self.c32, self.d32
         pc, pd = SegPlan(ptr_c, perm_c, n_lhs, self.m), SegPlan(ptr_d, perm_d, n_rhs, self.m)
         for p in (self.fwd, pc, pd):
-            p.volatile = True
+            p.volatile = volatile
         self._by_c = (pc, by_c[0], by_c[1])
         self._by_d = (pd, by_d[0], by_d[1])
         self._lookup = None
-        self._scatter = False               # the by-edge gradient of a slot runs the gather form (its chunk list has no fixed length)
+        if volatile:
+            self._scatter = False
         return self
 
     def by_c(self):

@@ -30,17 +30,10 @@ import torch
 from . import _ops
 from ._native import check, lib, stream_ptr
 from .backend.SpTensor import SparseTensor
-from .collate import DeviceGraphStore
+from .collate import CollateDesc as _Desc, DeviceGraphStore
 from .synth import KEYSEP, parse_key
 
 _I32, _I64 = torch.int32, torch.int64
-
-
-class _Desc(ctypes.Structure):
-    """`pygho_collate_desc` of include/pygho_hip.h"""
-    _fields_ = [("out", ctypes.c_void_p), ("src", ctypes.c_void_p), ("src_start", ctypes.c_void_p), ("out_ptr", ctypes.c_void_p),
-                ("inc", ctypes.c_void_p * 4), ("pad", ctypes.c_void_p), ("src_ld", ctypes.c_int64), ("out_ld", ctypes.c_int64),
-                ("rows", ctypes.c_int32), ("out_i32", ctypes.c_int32), ("transposed", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 def slot_capacities(store: DeviceGraphStore, n_graphs: int, sigmas: float = 4.5, align: int = 64) -> Dict:

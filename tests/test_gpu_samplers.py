@@ -87,6 +87,49 @@ def test_sampler_edge_cases(dev):
     ring = torch.tensor([[0, 1, 1, 2, 2, 0], [1, 0, 2, 1, 0, 2]], device=dev)
     k0 = KhopSampler(SimpleNamespace(edge_index=ring, num_nodes=3), 0)
     assert N(k0.indices).tolist() == [[0, 1, 2], [0, 1, 2]]
-    # too large a graph is refused loudly
-    with pytest.raises(NotImplementedError):
-        khop_sample(torch.zeros((2, 0), dtype=torch.int64, device=dev), 300, 2)
+    # a graph without edges beyond the LDS limit: the global-memory search (round 4 refused graphs of more than 255 nodes)
+    tid, tf = khop_sample(torch.zeros((2, 0), dtype=torch.int64, device=dev), 300, 2)
+    assert N(tid).tolist() == [list(range(300))] * 2 and int(tf.abs().sum()) == 0
+
+
+def _sparse_graph(rng, n, extra):
+    """connected sparse graph of n nodes: a random spanning tree + `extra` chords, symmetric, sorted, duplicate-free"""
+    perm = rng.permutation(n)
+    pairs = {(int(perm[t]), int(perm[rng.integers(t)])) for t in range(1, n)}
+    while len(pairs) < n - 1 + extra:
+        u, v = int(rng.integers(n)), int(rng.integers(n))
+        if u != v and (v, u) not in pairs:
+            pairs.add((u, v))
+    und = np.array(sorted(pairs)).T
+    ei = np.concatenate((und, und[::-1]), axis=1)
+    order = np.lexsort((ei[1], ei[0]))
+    return np.unique(ei[:, order], axis=1).astype(np.int64)
+
+
+def test_samplers_on_graphs_beyond_the_lds_limit(dev):
+    """graphs of 300 and 700 nodes (the reference, hodata/SpTupleSampler.py:91-173, has no bound on the node count; up to 255 nodes the
+    hop-distance matrix of a graph lives in LDS, larger graphs search in global memory) next to small ones in ONE block-diagonal batch:
+    tuples and distance features equal the oracle's (itself pinned to the reference's samplers), sorted output."""
+    from oracle import np_oracle as O
+    from pygho_amd import _ops
+    from pygho_amd.hodata import i2_sample, khop_sample
+    rng = np.random.default_rng(17)
+    sizes = [40, 300, 12, 700, 255, 256]
+    eis, batch, kid, kval, iid, ival, off = [], [], [], [], [], [], 0
+    for gi, n in enumerate(sizes):
+        ei = _sparse_graph(rng, n, n // 10)
+        a, b = O.khop_sampler(ei, n, 3)
+        eis.append(ei + off); batch.append(np.full(n, gi)); kid.append(a + off); kval.append(b)
+        if n <= 300:                                      # (the I2 oracle enumerates per edge: keep it to the moderate graphs)
+            c, d = O.i2_sampler(ei, n, 2)
+            iid.append((c + off, gi)); ival.append(d)
+        off += n
+    ei, nb = T(np.concatenate(eis, axis=1), dev), T(np.concatenate(batch).astype(np.int64), dev)
+    tid, tf = khop_sample(ei, off, 3, nb)
+    assert np.array_equal(N(tid), np.concatenate(kid, axis=1)) and np.array_equal(N(tf), np.concatenate(kval))
+    assert bool(torch.all(torch.diff(_ops.hash_pack(tid)) > 0))
+    tid3, tf3 = i2_sample(ei, off, 2, nb)
+    got_graph = np.concatenate(batch)[N(tid3)[0]]
+    for (want, gi), feat in zip(iid, ival):
+        sel = got_graph == gi
+        assert np.array_equal(N(tid3)[:, sel], want) and np.array_equal(N(tf3)[sel], feat), sizes[gi]
