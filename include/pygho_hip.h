@@ -735,7 +735,8 @@ int pygho_table_grad_dyn(float* ws, const void* g, const int32_t* idx, int64_t m
 
 /* ---- a whole batch collated by ONE launch (hodata/SpData.py:56-112 again, for the fixed-capacity batch slots) ----------------
  * pygho_collate_rows once per array costs ~25 launches per batch.  Here a table of descriptors in DEVICE memory names every output
- * array of the batch; blockIdx.y walks the table.  Per descriptor, for output columns j < out_ld:
+ * array of the batch; blockIdx.y walks the table, one wavefront copies one selected graph's columns.  Per descriptor, for output
+ * columns j < out_ld:
  *     j <  out_ptr[n_sel]:  out[r, j] = src[r, src_start[s] + (j - out_ptr[s])] + (inc[r] ? inc[r][s] : 0)   (s = graph of column j)
  *     j >= out_ptr[n_sel]:  out[r, j] = pad ? *pad : 0
  * so an output wider than the selected graphs' total -- a fixed-capacity buffer, or a CSR pointer array with its closing entry --

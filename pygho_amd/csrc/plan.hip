@@ -242,28 +242,30 @@ __global__ void collate_rows_kernel(O* __restrict__ out, const int32_t* __restri
   }
 }
 
-// every array of a batch in ONE launch: blockIdx.y picks the descriptor, the workgroups of a row walk the output columns.  Columns past
-// the selected graphs' total (a fixed-capacity output, or the closing entry of a CSR pointer array) take the descriptor's pad value,
-// read from the device -- e.g. the batch's message total for a pointer array, so that pad rows are empty segments.
+// every array of a batch in ONE launch: blockIdx.y picks the descriptor, ONE WAVEFRONT PER SELECTED GRAPH copies that graph's columns
+// (its first store column, its offset in the batch and its increments are wavefront-uniform scalars -- the first form searched the
+// graph of every output column in the offsets array, 13 dependent loads per element at 8192 graphs: the launch held the whole chip for
+// ~0.5 ms and delayed the training stream).  The wavefront after the last graph writes the columns past the selected graphs' total (a
+// fixed-capacity output, or the closing entry of a CSR pointer array) with the descriptor's pad value, read from the device -- e.g.
+// the batch's message total for a pointer array, so that pad rows are empty segments.
 template <typename O>
-__device__ __forceinline__ void collate_desc_cols(const pygho_collate_desc& ds, int64_t n_sel) {
+__device__ __forceinline__ void collate_desc_graph(const pygho_collate_desc& ds, int64_t n_sel, int64_t s, int lane) {
   O* out = reinterpret_cast<O*>(ds.out);
-  const int64_t total = ds.out_ptr[n_sel];
-  const int64_t pad = ds.pad ? *ds.pad : 0;
-  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ds.out_ld; j += (int64_t)gridDim.x * blockDim.x) {
-    if (j >= total) {
+  if (s == n_sel) {                                   // pad columns
+    const int64_t total = ds.out_ptr[n_sel];
+    const int64_t pad = ds.pad ? *ds.pad : 0;
+    for (int64_t j = total + lane; j < ds.out_ld; j += kWave)
       for (int r = 0; r < ds.rows; ++r) out[ds.transposed ? j * ds.rows + r : (int64_t)r * ds.out_ld + j] = (O)pad;
-      continue;
-    }
-    int64_t lo = 0, hi = n_sel;                  // last s with out_ptr[s] <= j
-    while (hi - lo > 1) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (ds.out_ptr[mid] <= j) lo = mid; else hi = mid;
-    }
-    const int64_t col = ds.src_start[lo] + (j - ds.out_ptr[lo]);
+    return;
+  }
+  const int64_t o0 = ds.out_ptr[s], len = ds.out_ptr[s + 1] - o0, c0 = ds.src_start[s];
+  int64_t inc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) inc[r] = (r < ds.rows && ds.inc[r]) ? ds.inc[r][s] : 0;
+  for (int64_t c = lane; c < len; c += kWave) {
+    const int64_t j = o0 + c;
     for (int r = 0; r < ds.rows; ++r) {
-      const int64_t* inc = r < 4 ? ds.inc[r] : nullptr;
-      const int64_t v = (int64_t)ds.src[(int64_t)r * ds.src_ld + col] + (inc ? inc[lo] : 0);
+      const int64_t v = (int64_t)ds.src[(int64_t)r * ds.src_ld + c0 + c] + (r < 4 ? inc[r] : 0);
       out[ds.transposed ? j * ds.rows + r : (int64_t)r * ds.out_ld + j] = (O)v;
     }
   }
@@ -271,8 +273,11 @@ __device__ __forceinline__ void collate_desc_cols(const pygho_collate_desc& ds, 
 
 __global__ __launch_bounds__(kBlock) void collate_batch_kernel(const pygho_collate_desc* __restrict__ descs, int64_t n_sel) {
   const pygho_collate_desc ds = descs[blockIdx.y];
-  if (ds.out_i32) collate_desc_cols<int32_t>(ds, n_sel);
-  else collate_desc_cols<int64_t>(ds, n_sel);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t s = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  if (s > n_sel) return;
+  if (ds.out_i32) collate_desc_graph<int32_t>(ds, n_sel, s, lane);
+  else collate_desc_graph<int64_t>(ds, n_sel, s, lane);
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -672,8 +677,10 @@ extern "C" int pygho_collate_batch(const void* descs, int64_t n_desc, int64_t n_
   if (n_desc < 0 || n_sel < 0 || max_cols < 0 || n_desc > 65535) { set_error("collate_batch: bad size"); return PYGHO_ERR_INVALID; }
   if (n_desc == 0 || max_cols == 0) return PYGHO_OK;
   if (!descs) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
-  int gx = grid_for(max_cols, kBlock, 4 * kMaxGrid / (int)(n_desc < 16 ? n_desc : 16));
-  hipLaunchKernelGGL(collate_batch_kernel, dim3(gx, (unsigned)n_desc), dim3(kBlock), 0, (hipStream_t)stream,
+  (void)max_cols;
+  const int64_t gx = ceil_div(n_sel + 1, kBlock / kWave);          // one wavefront per selected graph + one for the pad columns
+  if (gx > INT32_MAX) { set_error("collate_batch: too many graphs"); return PYGHO_ERR_UNSUPPORTED; }
+  hipLaunchKernelGGL(collate_batch_kernel, dim3((unsigned)gx, (unsigned)n_desc), dim3(kBlock), 0, (hipStream_t)stream,
                      (const pygho_collate_desc*)descs, n_sel);
   return check_launch("collate_batch");
 }
