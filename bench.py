@@ -553,9 +553,12 @@ def main():
             from pygho_amd._native import check as _check, ptr as _ptr, stream_ptr as _sp
             ids = torch.empty(2048, dtype=torch.int32, device=dev)
             _check(_native.lib().pygho_xcc_ids(_ptr(ids), 2048, _sp(dev)), "xcc_ids")
-            want = torch.arange(2048, device=dev, dtype=torch.int32) % 8
-            line["xcd_dispatch"] = {"workgroups": 2048, "xcds_seen": int(ids.unique().numel()),
-                                    "fraction_on_xcd_b_mod_8": float((ids == want).float().mean())}
+            # workgroup b on XCD (b + shift) % 8: the dispatcher continues its round-robin from wherever the previous launch stopped, so
+            # the kernels' locality assumption (the 8 residue classes of b are the 8 XCDs) holds for any constant shift
+            shift = int(ids[0])
+            want = (torch.arange(2048, device=dev, dtype=torch.int32) + shift) % 8
+            line["xcd_dispatch"] = {"workgroups": 2048, "xcds_seen": int(ids.unique().numel()), "shift": shift,
+                                    "fraction_on_xcd_b_plus_shift_mod_8": float((ids == want).float().mean())}
         except Exception as e:
             line["xcd_dispatch"] = {"error": f"{type(e).__name__}: {e}"}
         if use_dist:

@@ -180,6 +180,11 @@ class SparseTensor:
         return sub
 
     def _hash(self, dims: Optional[Tuple[int, ...]] = None) -> Tensor:
+        if getattr(self.__indices, "_pygho_slot", False):
+            # a fixed-capacity batch slot pads its index columns with (0, .., 0): the hashes are neither sorted nor distinct, and every
+            # operator that SEARCHES them (diag, sparse unpooling, coalesce) would be silently wrong -- refuse (slots.BatchSlot)
+            raise RuntimeError("pygho_amd: this operator matches index tuples by hash, which a fixed-capacity batch slot's padded index "
+                               "arrays do not support; run the step eagerly on `DeviceGraphStore.collate` batches")
         c = self._cache()
         k = ("hash", dims)
         if k not in c:

@@ -237,6 +237,20 @@ class DeviceGraphStore:
             self.root_parts = {"cnt": _cat32([c.reshape(1, -1) for c in cnt], 1, d),
                                "ptr": _cat32([(np.cumsum(c) - c).reshape(1, -1) for c in cnt], 1, d),
                                "h_max": np.asarray([c.max() if c.size else 0 for c in cnt], dtype=np.int64)}
+        # position of every node's diagonal tuple (i, i) inside its graph's tuple list (GNNAKConv / SUNConv look it up by hash search per
+        # batch, honn/Conv.py "sun_views"): collated with the graph's tuple offset when every node of every graph has one
+        self.diag_parts = None
+        if self.sd == 2:
+            pos, ok = [], True
+            for r in records:
+                row, col = r.tupleid
+                where = np.nonzero(row == col)[0]
+                if where.size != r.num_nodes or not np.array_equal(row[where], np.arange(r.num_nodes)):
+                    ok = False
+                    break
+                pos.append(where.reshape(1, -1))
+            if ok:
+                self.diag_parts = {"pos": _cat32(pos, 1, d)}
         # groupings of the tuples by their OTHER coordinates and of the edges by either endpoint (cross-subgraph pooling, unpooling
         # gradients, spmm): per-graph counts per node and, where the coordinate is not sorted, the stable order -- assembled per batch
         # only when an operator asks (`plans.cached_plan` -> `_pygho_plan_factory`)

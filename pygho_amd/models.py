@@ -23,7 +23,7 @@ from .backend.utils import torch_scatter_reduce
 from .honn.Conv import GRAD_CHAIN_KEY, DSSGNNConv, GNNAKConv, I2Conv, NGNNConv, PPGNConv, SSWLConv, SUNConv
 from .honn.MaOperator import OpPooling
 from .honn.TensorOp import OpPoolingSubg2D, OpPoolingSubg3D
-from .honn.utils import MLP
+from .honn.utils import MLP, Linear
 from .ngnn import IndexEmbedding
 
 
@@ -77,9 +77,11 @@ class SpModel(nn.Module):
         mlp = dict(mlp or {"norm": "bn", "act": "silu", "dp": 0.0})
         self.three = conv == "I2GNN"
         factory = conv_table("SS", aggr, cpool)[conv] if isinstance(conv, str) else conv
-        self.lin_tupleinit0 = nn.Linear(hiddim, hiddim)
-        self.lin_tupleinit1 = nn.Linear(hiddim, hiddim)
-        self.lin_tupleinit2 = nn.Linear(hiddim, hiddim)
+        # (honn.utils.Linear = nn.Linear with the same parameters: 16-bit inputs read the cast arena and run on the row-block kernels --
+        # torch's own autocast nn.Linear inside a captured step is what produced the NaN of rounds 2-3, graphs.py)
+        self.lin_tupleinit0 = Linear(hiddim, hiddim)
+        self.lin_tupleinit1 = Linear(hiddim, hiddim)
+        self.lin_tupleinit2 = Linear(hiddim, hiddim)
         self.residual = residual
         self.subggnns = nn.ModuleList([factory(hiddim, mlp) for _ in range(num_layer)])
         self.npool = npool

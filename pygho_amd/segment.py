@@ -797,7 +797,12 @@ TABLE_GRAD_PLAN_ROWS = int(os.environ.get("PYGHO_TABLE_GRAD_PLAN_ROWS", str(1 <<
 
 def _table_grad_now(g2: Tensor, ind: Tensor, n_table: int) -> bool:
     if not table_grad_ok(g2, n_table):
-        require_static_rows(g2.shape[0], "the sorted-segment gradient of a row gather (tables of more than 64 rows)")
+        if dyn_rows(g2.shape[0]) is not None:
+            # rows of a batch slot: the segment route is safe when the slot SERVES the grouping (pad rows lie outside every segment);
+            # a grouping built from the padded index array would not be
+            fac = getattr(ind, "_pygho_plan_factory", None)
+            if fac is None or fac[0] != ind._version:
+                require_static_rows(g2.shape[0], "the sorted-segment gradient of a row gather whose grouping the slot does not hold")
         return False
     if dyn_rows(g2.shape[0]) is not None:
         return True                                            # a batch slot's rows: the count is on the device, no plan can exist

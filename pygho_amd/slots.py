@@ -173,6 +173,16 @@ class BatchSlot:
             gp = desc(out(1, "node", True, extra=1), part["ptr"], "node", incs=(off(fam),), pad=total(fam)).reshape(-1)
             perm = desc(out(1, fam, True), part["perm"], fam, incs=(off(fam),)).reshape(-1) if "perm" in part else None
             self.group[(which, dim)] = (gp, perm)
+        # diagonal positions + tuples per root / per second coordinate: the "sun_views" GNNAKConv / SUNConv cache on the tuple pattern
+        # (honn/Conv.py; there a hash search and two bincounts over the index rows -- which a padded pattern cannot answer)
+        self.diag_pos = self.cnt_r = self.cnt_c = None
+        if getattr(store, "diag_parts", None) is not None and self.root_ptr is not None and ("X", 1) in self.group:
+            # (pad nodes have NO diagonal tuple: position -1, so their diagonal rows read as zeros and receive a zero gradient -- the
+            # node-level products of SUNConv are plain GEMMs over all capacity rows, which zero gradient rows leave alone)
+            self._neg1 = torch.full((1,), -1, dtype=_I64, device=dev)
+            self.diag_pos = desc(out(1, "node", False), store.diag_parts["pos"], "node", incs=(off("tup"),), pad=self._neg1.data_ptr()).reshape(-1)
+            self.cnt_r = torch.ones((self.caps["node"], 1), dtype=_I64, device=dev)
+            self.cnt_c = torch.ones((self.caps["node"], 1), dtype=_I64, device=dev)
         self.mirror = None
         if store.mirror_parts is not None and bool(store.mirror_parts["h_ok"].all()):
             self.mirror = desc(out(1, "tup", True), store.mirror_parts["pos"], "tup", incs=(off("tup"),)).reshape(-1)
@@ -206,7 +216,7 @@ class BatchSlot:
     # ------------------------------------------------------------------
     def _all_tensors(self):
         ts = [self.x, self.x32, self.batch, self.batch32, self.ei, self.ei32, self.ea, self.ea32, self.tid, self.tid32, self.tf, self.tf32,
-              self.y, self.graph_ptr, self.root_ptr, self.mirror]
+              self.y, self.graph_ptr, self.root_ptr, self.mirror, self.diag_pos, self.cnt_r, self.cnt_c]
         for gp, perm in self.group.values():
             ts += [gp, perm]
         for ent in self.msg.values():
@@ -236,6 +246,7 @@ class BatchSlot:
         for ind in (self.ei, self.tid):
             if n < (1 << (63 // ind.shape[0])):
                 ind._pygho_hash_ok = ind._version
+            ind._pygho_slot = True                      # hash-searching operators refuse padded index arrays (backend/SpTensor._hash)
         seed32(self.x, self.x32)
         seed32(self.ea, self.ea32)
         seed32(self.batch, self.batch32)
@@ -253,14 +264,27 @@ class BatchSlot:
             p.volatile = True
             p._memo = {"max_len": int(max_len)}
             return p
+
+        def serve(keys, plan):
+            """the slot's grouping of `keys` under WHATEVER tag an operator asks for (`plans.cached_plan`: "scatter", "pair-row",
+            "pair-col" ...): a plan built from the padded keys instead would count the pad columns into row 0's segment, and
+            building one reads back from the device (not possible under capture)"""
+            def factory(n_seg, plan=plan):
+                if n_seg != plan.n_seg:
+                    raise RuntimeError(f"pygho_amd: a grouping of a batch slot's index row into {n_seg} segments was asked for; the slot "
+                                       f"holds its grouping into {plan.n_seg} (the node capacity)")
+                return plan
+            keys._pygho_plan_factory = (keys._version, factory)
         h_max = lambda lens: int(np.max(lens)) if np.size(lens) else 0
-        _ops.install_plan(self.batch, seg(self.graph_ptr, None, g, n, h_max(st.h_len["node"])), ("scatter",))
+        serve(self.batch, seg(self.graph_ptr, None, g, n, h_max(st.h_len["node"])))
         for (which, dim), (gp, perm) in self.group.items():
             keys = (rows_x if which == "X" else rows_a)[dim]
             m = self.caps["tup" if which == "X" else "edge"]
-            _ops.install_plan(keys, seg(gp, perm, n, m, h_max(st.group_parts[(which, dim)]["h_max"])), ("scatter",))
+            serve(keys, seg(gp, perm, n, m, h_max(st.group_parts[(which, dim)]["h_max"])))
+        if self.diag_pos is not None:
+            self._X._cache()["sun_views"] = (self.diag_pos, self.cnt_r, self.cnt_c)
         if self.root_ptr is not None:
-            _ops.install_plan(rows_x[0], seg(self.root_ptr, None, n, self.caps["tup"], h_max(st.root_parts["h_max"])), ("scatter", "pair-row"))
+            serve(rows_x[0], seg(self.root_ptr, None, n, self.caps["tup"], h_max(st.root_parts["h_max"])))
             if self.mirror is not None and self.tf32 is not None and st.sd == 2:
                 row32, col32, vidx32 = self._rows32_x[0], self._rows32_x[1], self.tf32
                 row32._pygho_mirror = (col32, vidx32, n, self.mirror, (row32._version, col32._version, vidx32._version))
@@ -327,6 +351,9 @@ class BatchSlot:
         check(lib().pygho_collate_batch(self.desc_dev.data_ptr(), len(self._descs), self.g, self.max_cols, stream_ptr(self.device)),
               "collate_batch")
         torch.index_select(self.store.y, 0, self.ids_dev, out=self.y)
+        if self.diag_pos is not None:              # tuples per root / per second coordinate (clamped like honn/Conv.py's bincounts)
+            for cnt, ptr in ((self.cnt_r, self.root_ptr), (self.cnt_c, self.group[("X", 1)][0])):
+                cnt.copy_((ptr[1:] - ptr[:-1]).clamp_min_(1).unsqueeze(-1))
 
     def collate(self, graph_ids) -> Dict:
         """eager use of the slot: write the batch, drop what earlier batches left in the caches; returns `.datadict`"""

@@ -186,3 +186,51 @@ def test_row_reduction_without_a_device_count_form_refuses_slot_rows(dev, store)
         with pytest.raises(RuntimeError, match="device-side row-count"):
             _ops.weight_grad_splitk(g, x, torch.float32)
     _ops.weight_grad_splitk(g, x, torch.float32)           # outside a slot context the capacity is just a row count
+
+
+@pytest.mark.parametrize("family", ["NGNN", "SSWL", "DSSGNN", "GNNAK", "SUN"])
+def test_captured_slot_step_serves_every_two_tuple_family(dev, family):
+    """the model of example/zinc.py:222-297 for each 2-tuple layer family (`pygho_amd.models.SpModel`: max subgraph pooling, mean graph
+    pooling, cross-subgraph pooling / unpooling, GNNAK's and SUN's diagonal views): ONE captured step, 6 different batches, bit for bit
+    against the eager loop on exactly sized batches -- loss, every gradient, the model state after AdamW.  (The diagonal positions and
+    per-node tuple counts those two layers search by hash / bincount per batch come with the slot; hash-searching operators on a
+    padded pattern raise instead of answering wrongly.)"""
+    from pygho_amd import synth
+    from pygho_amd.collate import DeviceGraphStore
+    from pygho_amd.graphs import SlotStep
+    from pygho_amd.honn.SpOperator import parse_precomputekey
+    from pygho_amd.models import SpModel
+    g = 48
+
+    def make():
+        torch.manual_seed(1)
+        return SpModel(family, num_layer=2, hiddim=128, act_dtype=torch.bfloat16).to(dev)
+    keys = tuple(parse_precomputekey(make()))
+    rng = np.random.default_rng(9)
+    st = DeviceGraphStore([synth.make_graph(rng, "zinc", 3, keys) for _ in range(192)], dev)
+    batches = _batches(st.num_graphs, g, 6, seed=13)
+    warm = _batches(st.num_graphs, g, 1, seed=77)[0]
+    ref_model = make()
+    ref_step = _make_step(ref_model, torch.optim.AdamW(ref_model.parameters(), lr=1e-3, capturable=True))
+    for _ in range(3):
+        ref_step(st.collate(warm))
+    ref = []
+    for ids in batches:
+        loss = ref_step(st.collate(ids))
+        ref.append((loss.clone(), _grads(ref_model), {k: v.detach().clone() for k, v in ref_model.state_dict().items()}))
+    model = make()
+    ss = SlotStep(st, g, _make_step(model, torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True)), warmup_ids=warm, warmup=3)
+    for k, ids in enumerate(batches):
+        loss = ss.run(ids)
+        assert torch.equal(loss, ref[k][0]), (family, k, float(loss), float(ref[k][0]))
+        _assert_same(_grads(model), ref[k][1], f"{family}: gradients at step {k}")
+        _assert_same({kk: v.detach() for kk, v in model.state_dict().items()}, ref[k][2], f"{family}: model state after step {k}")
+    assert ss.replays == len(batches) and ss.eager_steps == 0
+
+
+def test_hash_searching_operators_refuse_a_padded_pattern(dev, store):
+    from pygho_amd.slots import BatchSlot
+    slot = BatchSlot(store, 48)
+    dd = slot.collate(_batches(store.num_graphs, 48, 1)[0])
+    with pytest.raises(RuntimeError, match="matches index tuples by hash"):
+        dd["X"].diag([0, 1])
