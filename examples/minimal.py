@@ -7,11 +7,12 @@ THE DEVICE -> 6-layer NGNN (bf16 activations, f32 master weights) -> L1 loss -> 
     python examples/minimal.py [--graphs 8192] [--batch 2048] [--epochs 3]
     python examples/minimal.py --graphs 4096 --batch 128 --epochs 4        # the reference's batch size: captured steps (below)
 
-Small batches are bound by host issue time, not by the GPU (~270 launches per step: 4.2 ms eager against 1.4 ms of GPU work at
-the reference's batch_size = 128, example/minimal.py:119).  Below --capture-below graphs per batch (default 2048) the dataset is
-therefore cut into FIXED mini-batches once; each batch's whole training step (forward, backward, AdamW) is captured into a HIP
-graph during the first epoch and replayed in the following ones (the ORDER of the batches is still shuffled every epoch, their
-composition is not: a captured graph bakes in the batch's index plans).
+Small batches are bound by host issue time, not by the GPU (~135 launches per step: 3.6-4.0 ms eager against 1.2 ms of GPU work at
+the reference's batch_size = 128, example/minimal.py:119).  Below --capture-below graphs per batch (default 2048) the whole training
+step (device collation, forward, backward, AdamW) is therefore captured ONCE into a HIP graph over a fixed-capacity batch slot
+(`pygho_amd.graphs.SlotStep`) and replayed for every batch: the dataset is re-shuffled every epoch like the reference's DataLoader
+(example/minimal.py:132-140), a batch costs one small upload + one replay (1.2 ms per 128-graph step), and the results equal the eager
+loop's bit for bit.  The last, smaller batch of an epoch (and any batch that would not fit the slot's capacities) runs eagerly.
 
 Reference lines: dataset + Sppretransform (example/minimal.py:100-130) -> synth.make_graph (k-hop tuple sampler and the
 precomputed "X___X___1___A___0" message triples, as hodata/SpTupleSampler.py:91-126 + SpData.py:115-171 produce them);
@@ -28,7 +29,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygho_amd import synth                                   # noqa: E402
 from pygho_amd.collate import BatchPrefetcher, DeviceGraphStore  # noqa: E402
-from pygho_amd.graphs import GraphedStep                       # noqa: E402
+from pygho_amd.graphs import SlotStep                          # noqa: E402
 from pygho_amd.honn.SpOperator import parse_precomputekey      # noqa: E402
 from pygho_amd.ngnn import SpModel                             # noqa: E402
 
@@ -77,42 +78,32 @@ def main():
 
 
 def train_captured(args, model, store, dev):
-    """fixed mini-batches, one captured training step per batch (first epoch: eager warm-up + capture; later epochs: replay)"""
+    """ONE captured training step for every mini-batch: fresh shuffled batches each epoch, as the reference's loader draws them"""
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True)
-    order = torch.randperm(args.graphs, generator=torch.Generator().manual_seed(0))
-    batches = [store.collate(order[i:i + args.batch]) for i in range(0, args.graphs - args.batch + 1, args.batch)]   # drop_last
 
-    def make_step(dd):
-        y = dd["y"].unsqueeze(-1)
+    def step(dd):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = model(dd)
+        loss = torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float())
+        loss.backward()
+        opt.step()
+        return loss.detach()
 
-        def step():
-            opt.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                pred = model(dd)
-            loss = torch.nn.functional.l1_loss(y, pred.float())
-            loss.backward()
-            opt.step()
-            return loss.detach()
-        return step
-
-    steps = [None] * len(batches)
+    t0 = time.perf_counter()
+    ss = SlotStep(store, args.batch, step)                       # 3 warm-up steps, then the capture
+    torch.cuda.synchronize()
+    print(f"captured one {args.batch}-graph step in {time.perf_counter() - t0:.2f} s; capacities {ss.slot.caps}")
     for epoch in range(args.epochs):
+        perm = np.random.default_rng(epoch).permutation(args.graphs)
+        batches = [perm[i:i + args.batch] for i in range(0, args.graphs, args.batch)]
         t0 = time.perf_counter()
-        losses = []
-        for b in torch.randperm(len(batches), generator=torch.Generator().manual_seed(epoch)).tolist():
-            if steps[b] is None:          # first visit: 2 eager warm-up steps build the batch's plans, the third call is captured
-                dd = batches[b]
-                idx = [t for t in (dd["X"].indices, dd["A"].indices) if torch.is_tensor(t)]
-                steps[b] = GraphedStep(make_step(dd), warmup=2, static_indices=idx)
-            losses.append(steps[b].replay().clone())
+        losses = [ss.run(ids).clone() for ids in batches]        # (the loss tensor of a replay is static: keep a copy)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        kind = "eager warm-up + capture + replay" if epoch == 0 else "replay"
-        # (eager device work between replays is fine: the NaN rounds 2-3 saw here came from torch's stock nn.Linear under bf16
-        # autocast inside a captured step, which the shipped models no longer use -- pygho_amd/graphs.py)
-        mean_loss = float(torch.stack(losses).mean())
-        print(f"epoch {epoch} ({kind}): mean L1 {mean_loss:.4f}, {len(batches) * args.batch / dt:,.0f} graphs/s, "
-              f"{dt / len(batches) * 1e3:.2f} ms per {args.batch}-graph step")
+        mean_loss = float(torch.stack([l.reshape(()) for l in losses]).mean())
+        print(f"epoch {epoch}: mean L1 {mean_loss:.4f}, {args.graphs / dt:,.0f} graphs/s, {dt / len(batches) * 1e3:.2f} ms per step "
+              f"({ss.replays} replays, {ss.eager_steps} eager steps so far)")
 
 
 if __name__ == "__main__":
