@@ -252,6 +252,32 @@ int pygho_seg_scatter_mul_reduce(void* out, const void* addend, const void* lhs,
                                  int64_t n_chunks, int64_t n_msg, int64_t max_edges, int64_t n_out, int64_t d,
                                  int64_t lhs_rows, int64_t rhs_rows, int dtype, void* stream);
 
+/*
+ * A subgraph layer's tuple-wise Linear -> BatchNorm -> activation folded into the load path of its aggregation (csrc/seg_fused.hip):
+ *   out[a] = [x[a] +] (sum | mean)_{(a,c,d)} H[c] * table[look[m]],     H = act((x . wl^T + bias) * scale + shift)  (rounded like the
+ *   materialised tensors: pre-activation, then H, in the storage type)
+ * = NGNNConv.forward (pygho/honn/Conv.py:53-58: X.tuplewiseapply(self.lin), then the subgraph message passing of
+ * pygho/backend/Spspmm.py:309-315) plus the model loop's residual add (example/minimal.py:76-79) in ONE launch that reads x once and
+ * never reads H.  Messages in forward order (CSR `seg_ptr` over the output rows, first-operand row c32[m] and table row look[m] per
+ * message, int32).  Planner: `row_cut` (n_blocks + 1) cuts the output rows into blocks (the graphs of a batch);
+ *   pygho_seg_fused_count -> n_chunks[b]; flags[0] += blocks holding a row outside the limits (more than 64 messages, or first-operand
+ *                            rows more than 31 apart): the caller must then take the separate kernels
+ *   pygho_seg_fused_write -> chunk records (4 x int32 at chunk0[b] + k, chunk0 = exclusive prefix sum of n_chunks) and own[k] = the rows of
+ *                            chunk k's window that no earlier chunk covers (they are the H rows chunk k stores); owner_ws: n_rows int32
+ *   pygho_seg_fused_fwd   -> out (and, when hout != NULL, every H row that some message reads -- other rows of hout stay unwritten).
+ * Width 128, bf16 / f16, tables of at most 32 rows.  Bit-identical to pygho_rowblock_linear_bn_act followed by
+ * pygho_seg_gather_mul_reduce_add over the same plan.
+ */
+int pygho_seg_fused_limits(int* messages_per_chunk, int* rows_per_chunk, int* table_rows, int* width);
+int pygho_seg_fused_count(int32_t* n_chunks, int32_t* flags, const int32_t* seg_ptr, const int32_t* c32, const int32_t* row_cut,
+                          int64_t n_blocks, void* stream);
+int pygho_seg_fused_write(int32_t* chunks, uint32_t* own, int32_t* owner_ws, const int32_t* chunk0, const int32_t* seg_ptr,
+                          const int32_t* c32, const int32_t* row_cut, int64_t n_blocks, int64_t n_chunks, int64_t n_rows, void* stream);
+int pygho_seg_fused_fwd(void* out, void* hout, const void* x, const void* wl, const void* bias, const float* scale, const float* shift,
+                        const void* table, int64_t table_rows, int residual, const int32_t* seg_ptr, const int32_t* c32,
+                        const int32_t* look, const int32_t* chunks, const uint32_t* own, int64_t n_chunks, int64_t n_rows,
+                        int64_t n_msg, int64_t d, int act, int mean, int dtype, void* stream);
+
 /* f32 row sums of a 16-bit (or f32) operand: out[s, :] = sum_{m in seg s} src[idx ? idx[m] : m, :].
  * First level of the hierarchical reduction of LONG segments (e.g. the backward of a row gather from a
  * table with a handful of rows -- nn.Embedding's index_put_(accumulate) over 10^6 messages per row):

@@ -51,6 +51,10 @@ PROTOTYPES = {
     "pygho_seg_scatter_count": (I, [P, P, P, P, P, P, P, L, P]),
     "pygho_seg_scatter_write": (I, [P, P, P, P, P, P, P, P, L, L, L, P]),
     "pygho_seg_scatter_mul_reduce": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, P]),
+    "pygho_seg_fused_limits": (I, [P, P, P, P]),
+    "pygho_seg_fused_count": (I, [P, P, P, P, P, L, P]),
+    "pygho_seg_fused_write": (I, [P, P, P, P, P, P, P, L, L, L, P]),
+    "pygho_seg_fused_fwd": (I, [P, P, P, P, P, P, P, P, L, I, P, P, P, P, P, L, L, L, L, I, I, I, P]),
     "pygho_seg_gather_mul_reduce_ties": (I, [P, P, P, P, P, P, P, L, L, L, L, I, I, P]),
     "pygho_seg_extremum_share": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, I, P]),
     "pygho_seg_extremum_bwd_shared": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, I, P]),

@@ -50,7 +50,7 @@ def _bn_forward(x: Optional[Tensor], weight, bias, running_mean, running_var, tr
         nbytes = int(lib().pygho_bn_workspace(m, c, dt))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     else:
-        assert apply and (partial is not None or not training)
+        assert partial is not None or not training
     w32 = None if weight is None else weight.detach().float().contiguous()
     b32 = None if bias is None else bias.detach().float().contiguous()
     if training:
@@ -720,6 +720,31 @@ class _TupleBlock(torch.autograd.Function):
                    and (x.shape[1] * 4) % 16 == 0 and rhs.dtype == x.dtype and rhs.shape[1] == x.shape[1])
         # without a plan `rhs` is a residual row operand: out = H + rhs, added inside the activation pass
         row_res = rhs.contiguous() if (plan is None and rhs is not None) else None
+        # the whole block forward in ONE launch after the statistics pass (csrc/seg_fused.hip): the product is formed again per chunk of
+        # output rows and activated into LDS, where the chunk's messages read it -- H is stored only for the by-edge gradient
+        fp = None
+        if (recompute and FUSED_FWD and plan is not None and rhs is not None and rhs_lookup is not None and aggr in ("sum", "mean")
+                and x.shape[1] == 128 and x.dtype in (torch.bfloat16, torch.float16) and rhs_lookup[0].shape[0] <= 32
+                and rhs_lookup[0].dtype == x.dtype):
+            fp = fused_plan(plan, on_demand=True)
+        if fp is not None:
+            (scale, shift), mean, var, saved = _bn_forward(None, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum,
+                                                           partial, apply=False, producer=(x, wc, bc))
+            look = (rhs_lookup[0].detach(),) + plan.lookup(rhs_lookup[1])
+            out, h = fused_forward(x, wc, bc, scale, shift, act, look[0], look[1], plan, fp, aggr, residual, bool(needs[10]))
+            ctx.affine, ctx.look = None, look
+            ctx.save_for_backward(x, wc, None, h, rhs, bc, *saved)
+            ctx.meta = (training, act, None if b is None else b.dtype, gamma is not None, beta is not None, plan, aggr, residual, w.dtype,
+                        skinny)
+            ctx.mark_non_differentiable(mean, var)
+            ctx.set_materialize_grads(False)
+            ctx.chain = (bool(chain), bool(chain_x))
+            extra = ()
+            if chain:
+                extra += (rhs.view_as(rhs),)
+            if chain_x:
+                extra += (x.view_as(x),)
+            return (out, mean, var) + extra
         h, mean, var, saved = _bn_forward(pre, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum, partial,
                                           apply=not on_load, addend=row_res, producer=(x, wc, bc) if recompute else None)
         affine = look = None

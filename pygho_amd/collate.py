@@ -216,6 +216,30 @@ class DeviceGraphStore:
             covers = bool(((blk_e[:, 0] == 0) & (blk_e[:, 1] == n_rows3)).all())        # every graph's triples reach all of its rows
             self.scatter_parts[k] = {"chunk_ptr": chunk0.to(torch.int64), "chunks_t": chunks.t().contiguous(), "words": words.reshape(1, -1),
                                      "blk_e": blk_e.t().contiguous(), "max_edges": max_edges, "covers": covers}
+        # the fused block forward's chunk plans (csrc/seg_fused.hip: Linear -> BatchNorm -> act inside the aggregation), ONCE for the whole
+        # store: the device planner over the store's rows with one block per graph.  A batch's chunks are its graphs' chunks with the
+        # message / row offsets added; the ownership masks travel unchanged (a chunk's window never leaves its graph)
+        self.fused_parts = {}
+        for k, parts in self.plan_parts.items():
+            roles = parse_key(k)
+            acd = self.acd[k]
+            if not (roles[0][0] == "X" and roles[1][0] == "X" and "look" in parts) or acd.shape[1] == 0 or acd.shape[1] >= (1 << 31):
+                continue
+            tup32, msg_len = self.tup_ptr.to(torch.int32), self.acd_ptr[k][1:] - self.acd_ptr[k][:-1]
+            seg_ptr = torch.zeros(parts["cnt_a"].shape[1] + 1, dtype=torch.int32, device=d)
+            torch.cumsum(parts["cnt_a"].reshape(-1), 0, out=seg_ptr[1:])
+            c_rows = (acd[1] + torch.repeat_interleave(tup32[:-1], msg_len)).contiguous()             # store-wide row of every message's c
+            fu = _ops.fused_plan_parts(seg_ptr, c_rows, tup32, int(self.tup_ptr[-1]))
+            if fu is None:
+                continue
+            n_chunks, chunk0, chunks, own = fu
+            g_of = torch.repeat_interleave(torch.arange(self.num_graphs, device=d), n_chunks.long())      # graph of every chunk
+            base = tup32[g_of]
+            chunks = chunks.clone()
+            chunks[:, 0] -= self.acd_ptr[k][g_of].to(torch.int32)  # first message and rows graph-local: a batch adds the graph's offsets
+            chunks[:, 1] -= base
+            chunks[:, 2] = torch.where((chunks[:, 3] >> 16) > 0, chunks[:, 2] - base, torch.zeros_like(base))
+            self.fused_parts[k] = {"chunk_ptr": chunk0.to(torch.int64), "chunks_t": chunks.t().contiguous(), "own": own.reshape(1, -1)}
         self.y = torch.tensor([r.y for r in records], dtype=torch.float32, device=d)
         # largest integer feature of the store per array: a lookup into a table with more rows than that needs no range flag
         vmax = lambda f: max((int(np.max(f(r))) for r in records if np.size(f(r))), default=-1)
@@ -228,6 +252,8 @@ class DeviceGraphStore:
             self.h_len[("acd", k)] = ln(lambda r: r.acd[k].shape[1])
         for k, v in self.scatter_parts.items():
             self.h_len[("sc", k)] = np.diff(v["chunk_ptr"].cpu().numpy())
+        for k, v in self.fused_parts.items():
+            self.h_len[("fu", k)] = np.diff(v["chunk_ptr"].cpu().numpy())
         self.h_ptr = {f: np.concatenate(([0], np.cumsum(v))).astype(np.int64) for f, v in self.h_len.items()}
         # tuples per root node (the pattern is sorted by root, SpTupleSampler.py:91-126): a batch's grouping of its tuples by root --
         # subgraph pooling, the tuple initialisation's by-row plan -- is the scan of the collated counts
@@ -405,7 +431,13 @@ class DeviceGraphStore:
                            B.add(sc["words"], fm, i32=True).reshape(-1),
                            B.add(sc["blk_e"], "graph", incs=B.rows_of(lay.dev[("inc", "blk", k)]), i32=True, transposed=True))
 
-            def install(k=k, acd=acd, arrs=arrs, sc=sc, sc_arrs=sc_arrs, sizes=(total[fa], total[fc], total[fd]), parts=parts):
+            fu = self.fused_parts.get(k)
+            fu_arrs = None
+            if fu is not None and total[("fu", k)] > 0:
+                fu_arrs = (B.add(fu["chunks_t"], ("fu", k), incs=(B.off(fm), B.off("tup"), B.off("tup")), i32=True, transposed=True),
+                           B.add(fu["own"], ("fu", k), i32=True).reshape(-1))
+
+            def install(k=k, acd=acd, arrs=arrs, sc=sc, sc_arrs=sc_arrs, fu_arrs=fu_arrs, sizes=(total[fa], total[fc], total[fd]), parts=parts):
                 plan = _ops.MessagePlan.from_arrays(acd, *sizes, arrs["acd32"], arrs["ptr_a"], arrs["ptr_c"], arrs["perm_c"], arrs["by_c"],
                                                     arrs["ptr_d"], arrs["perm_d"], arrs["by_d"], volatile=False)
                 plan.fwd._memo = {"max_len": int(parts["h_max_a"][lay.ids_h].max()) if lay.g else 0}
@@ -415,6 +447,8 @@ class DeviceGraphStore:
                 if sc_arrs is not None:
                     ch, words, blk_e = sc_arrs
                     _ops.install_scatter_plan(plan, lay.dev[("optr32", ("sc", k))], blk_e, ch, words, sc["max_edges"], sc["covers"])
+                if fu_arrs is not None:
+                    _ops.install_fused_plan(plan, *fu_arrs)
             finish.append(install)
         B.launch()                                  # every array requested above: ONE kernel
         for f in finish:

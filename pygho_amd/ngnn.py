@@ -143,6 +143,8 @@ class SpModel(nn.Module):
                 plan.by_c()
                 plan.by_d()
                 _ops.scatter_plan(plan)             # the by-edge gradient's scatter form: blocks / chunks / packed words (two host reads)
+                if _ops.FUSED_FWD:
+                    _ops.fused_plan(plan)           # the fused block forward's chunks (one host read)
                 if "ea" in flats:
                     plan.lookup(flats["ea"])
 

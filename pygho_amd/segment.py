@@ -583,6 +583,97 @@ def scatter_plan(plan: "MessagePlan", on_demand: bool = False) -> Optional[Scatt
     return plan._scatter or None
 
 
+# --------------------------------------------------------------------------
+# the layer MLP folded into the forward aggregation's load path (csrc/seg_fused.hip)
+# --------------------------------------------------------------------------
+FUSED_FWD = os.environ.get("PYGHO_FUSED_FWD", "1") != "0"       # A/B switch
+FUSED_BLOCK_ROWS = 512          # planner blocks of a plan that brings no graph cuts: chunks never cross them
+
+
+class FusedPlan:
+    """chunks of consecutive output rows (at most 32 rows / 64 messages / a 32-row first-operand window) of a plan's forward order, and
+    per chunk the window rows it is the first to cover (`pygho_seg_fused_count` / `_write`); one host read, cached with the MessagePlan"""
+    __slots__ = ("n_chunks", "chunks", "own")
+
+
+def fused_plan_parts(seg_ptr: Tensor, c_fwd: Tensor, row_cut: Tensor, n_rows: int):
+    """(n_chunks per block, chunk0, chunks (total, 4), own (total)) over the row blocks `row_cut`, or None when a row is outside the
+    kernel's limits -- three kernels and ONE host read (chunk total + verdict)"""
+    dev = require_device(seg_ptr, c_fwd, row_cut)
+    nb = row_cut.numel() - 1
+    n_chunks = torch.empty(nb, dtype=_I32, device=dev)
+    flags = torch.zeros(1, dtype=_I32, device=dev)
+    check(lib().pygho_seg_fused_count(ptr(n_chunks), ptr(flags), ptr(seg_ptr), ptr(c_fwd), ptr(row_cut), nb, stream_ptr(dev)),
+          "seg_fused_count")
+    chunk0 = torch.zeros(nb + 1, dtype=_I32, device=dev)
+    torch.cumsum(n_chunks, 0, out=chunk0[1:])
+    bad, total = _fetch(torch.stack([flags[0], chunk0[-1]]))
+    if bad or total == 0:
+        return None
+    chunks = torch.empty((int(total), 4), dtype=_I32, device=dev)
+    own = torch.empty(int(total), dtype=_I32, device=dev)
+    owner_ws = torch.empty(n_rows, dtype=_I32, device=dev)
+    check(lib().pygho_seg_fused_write(ptr(chunks), ptr(own), ptr(owner_ws), ptr(chunk0), ptr(seg_ptr), ptr(c_fwd), ptr(row_cut), nb,
+                                      int(total), n_rows, stream_ptr(dev)), "seg_fused_write")
+    return n_chunks, chunk0, chunks, own
+
+
+def fused_plan(plan: "MessagePlan", on_demand: bool = False, row_cut: Optional[Tensor] = None) -> Optional[FusedPlan]:
+    """the plan's FusedPlan, or None (never asked for / a row outside the limits: more than 64 messages or first-operand rows more than
+    31 apart).  Built on an explicit call only, like `scatter_plan`."""
+    fp = getattr(plan, "_fused", None)
+    if fp is not None:
+        return fp or None
+    if on_demand or plan.m == 0 or plan.m >= (1 << 31) or plan.n_lhs != plan.n_out or torch.cuda.is_current_stream_capturing():
+        return None
+    if row_cut is None:
+        dev = plan.c_fwd.device
+        row_cut = torch.arange(0, plan.n_out + FUSED_BLOCK_ROWS, FUSED_BLOCK_ROWS, dtype=_I32, device=dev).clamp_(max=plan.n_out)
+    parts = fused_plan_parts(plan.fwd.seg_ptr, plan.c_fwd, row_cut, plan.n_lhs)
+    if parts is None:
+        plan._fused = False
+        return None
+    fp = FusedPlan()
+    fp.chunks, fp.own = parts[2], parts[3]
+    fp.n_chunks = fp.chunks.shape[0]
+    plan._fused = fp
+    return fp
+
+
+def install_fused_plan(plan: "MessagePlan", chunks: Tensor, own: Tensor) -> None:
+    """a FusedPlan that already exists (`collate.DeviceGraphStore`: a batch's chunks are its graphs' precomputed chunks with the message
+    / row offsets added): no planner launch, no host read.  Trailing all-zero records (a fixed-capacity slot's padding) end a
+    workgroup's share of the list."""
+    fp = FusedPlan()
+    fp.chunks, fp.own, fp.n_chunks = chunks, own, chunks.shape[0]
+    plan._fused = fp if fp.n_chunks > 0 else False
+
+
+def fused_forward(x: Tensor, wl: Tensor, bias: Optional[Tensor], scale: Tensor, shift: Tensor, act: str, table: Tensor, look_fwd: Tensor,
+                  plan: "MessagePlan", fp: FusedPlan, aggr: str, residual: bool, want_h: bool):
+    """(out, H or None): out[a] = [x[a] +] aggr_{(a,c,d)} H[c] * table[look[m]] with H = act((x wl^T + bias) * scale + shift) formed per
+    chunk on the matrix cores and never read from memory; `want_h`: the H rows that messages read are also stored (the by-edge gradient
+    reads them; rows no message reads stay uninitialised)"""
+    dev = require_device(x, wl, bias, scale, shift, table, look_fwd)
+    n, d = x.shape
+    assert plan.n_out == n and plan.n_lhs == n and wl.shape == (d, d) and wl.dtype == x.dtype and table.dtype == x.dtype
+    out = torch.empty_like(x)
+    h = torch.empty_like(x) if want_h else None
+    # has-to-move bytes: x once, out once, the stored H once, two int32 indices per message, the CSR pointers, the chunk records
+    nbytes = x.element_size() * d * n * (3 if want_h else 2) + 8 * plan.m + 4 * (n + 1) + 20 * fp.n_chunks
+    name = f"seg_fused[{str(x.dtype).split('.')[-1]},{aggr}{',res' if residual else ''}{',h' if want_h else ''}]"
+    _timed(name, nbytes, dev, lambda: _fused_launch(out, h, x, wl, bias, scale, shift, act, table, look_fwd, plan, fp, aggr, residual))
+    return out, h
+
+
+def _fused_launch(out, h, x, wl, bias, scale, shift, act, table, look_fwd, plan, fp, aggr, residual):
+    dev, (n, d) = x.device, x.shape
+    check(lib().pygho_seg_fused_fwd(ptr(out), ptr(h), ptr(x), ptr(wl.contiguous()), ptr(bias), ptr(scale), ptr(shift), ptr(table.contiguous()),
+                                    table.shape[0], 1 if residual else 0, ptr(plan.fwd.seg_ptr), ptr(plan.c_fwd), ptr(look_fwd), ptr(fp.chunks),
+                                    ptr(fp.own), fp.n_chunks, n, plan.m, d, ACT_CODE[act], 1 if aggr == "mean" else 0, dtype_code(x),
+                                    stream_ptr(dev)), "seg_fused_fwd")
+
+
 def _scatter_eligible(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], scale, addend) -> bool:
     if SEG_SCATTER == "0" or h is None or scale is not None or g.dtype not in (torch.bfloat16, torch.float16) or h.dtype != g.dtype:
         return False

@@ -203,6 +203,14 @@ class BatchSlot:
                 ent["by_d"] = desc(out(2, fm, True), parts["by_d"], fm, incs=(off(fa), off(fc)))
                 if "look" in parts:
                     ent["look"] = desc(out(2, fm, True), parts["look"], fm)
+                fu = store.fused_parts.get(k)
+                if fu is not None:
+                    # the fused block forward's chunk list (csrc/seg_fused.hip): graph-local records + the graph's message / tuple offsets;
+                    # the columns beyond the batch's chunk count stay all-zero records, which end a workgroup's share of the list
+                    ff = ("fu", k)
+                    ent["fu_chunks"] = desc(out(4, ff, True, transposed=True), fu["chunks_t"], ff, incs=(off(fm), off("tup"), off("tup")),
+                                            transposed=True)
+                    ent["fu_own"] = desc(out(1, ff, True), fu["own"], ff).reshape(-1)
             self.msg[k] = ent
         assert int(lib().pygho_collate_desc_bytes()) == ctypes.sizeof(_Desc)
         table = (_Desc * len(self._descs))(*self._descs)
@@ -298,6 +306,8 @@ class BatchSlot:
             plan.fwd._memo = {"max_len": h_max(st.plan_parts[k]["h_max_a"])}     # the store's longest forward segment (a bound for any batch)
             if "look" in ent and fam_of(roles[3]) == "edge":
                 plan._lookup = (self.ea, (ent["look"][0], ent["look"][1]))      # A's values as a lookup of the edge feature
+            if "fu_chunks" in ent:
+                _ops.install_fused_plan(plan, ent["fu_chunks"], ent["fu_own"])
             _ops.install_message_plan(ent["acd"], plan)
 
     def reset_caches(self) -> None:
