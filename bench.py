@@ -169,27 +169,30 @@ def cpu_baseline(args, seed):
             "spspmm_fwd_msg_edges_per_sec": hb128.num_messages(KEY) / float(np.median(ts))}
 
 
-def kernel_source_hash() -> str:
-    """sha256 over the sources of the dominant kernel: a committed PMC traffic figure is only reported for the code it was measured on."""
+KERNEL_SOURCES = {"seg_gmr_fast_kernel": ("common.h", "seg_reduce.hip"), "seg_fused_fwd_kernel": ("common.h", "seg_fused.hip")}
+
+
+def kernel_source_hash(kernel: str = "seg_gmr_fast_kernel") -> str:
+    """sha256 over the sources of a kernel: a committed PMC traffic figure is only reported for the code it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("common.h", "seg_reduce.hip"):
+    for name in KERNEL_SOURCES[kernel.split("<")[0]]:
         h.update(open(os.path.join(REPO, "pygho_amd", "csrc", name), "rb").read())
     return h.hexdigest()
 
 
-def committed_traffic(config):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (tools/collect_traffic.py), or
-    (None, reason) when no file matches this configuration AND the current kernel sources."""
+def committed_traffic(config, kernel: str = "seg_gmr_fast_kernel<bf16,SUM,BOTH>"):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (tools/collect_traffic.py), or (None, reason) when
+    no file matches this configuration, this kernel AND the current kernel sources."""
     import glob
-    want = kernel_source_hash()
-    reason = "no profiles/*_traffic.json for this configuration"
-    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_traffic.json")), reverse=True):
+    want = kernel_source_hash(kernel)
+    reason = "no profiles/*_traffic*.json for this configuration and kernel"
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_traffic*.json")), reverse=True):
         try:
             tj = json.load(open(f))
         except Exception:
             continue
-        if tj.get("config") != config:
+        if tj.get("config") != config or tj.get("kernel", "").split("<")[0] != kernel.split("<")[0]:
             continue
         if tj.get("kernel_source_sha256") != want:
             reason = f"{os.path.basename(f)} was measured on other kernel sources (stale)"
@@ -504,13 +507,32 @@ def main():
         # the residual row in their epilogue (",res"), the two backward launches per layer do not
         # (the by-edge backward plan runs on its own kernels -- seg_scatter_kernel ",scatter" since round 4, seg_gmr_window_kernel
         # ",window" where the scatter form does not apply; they are reported beside it, in `spspmm_all_launches` and `kernels`)
+        # (round 5: with 16-bit activations the FORWARD launch of a layer is the fused block kernel seg_fused_fwd_kernel -- Linear ->
+        # BatchNorm -> act formed per chunk on the matrix cores inside the aggregation, csrc/seg_fused.hip; its bytes are what HAS to move:
+        # x once, the output once, the stored H once, the indices.  Whichever of the two carries more of the step's time is `roofline`;
+        # the other one is reported beside it under `roofline.other`)
         dom = f"seg_gmr[{'bfloat16' if act_dtype is not None else 'float32'},sum,both"
-        every = [v for k, v in summ.items() if k.startswith(dom)]
+        fused = [v for k, v in summ.items() if k.startswith("seg_fused[")]
+        every = [v for k, v in summ.items() if k.startswith(dom)] + fused
         parts = [v for k, v in summ.items() if k.startswith(dom) and ",window" not in k and ",scatter" not in k]
-        launches = sum(v[0] for v in parts)
-        ms = sum(v[0] * v[1] for v in parts) / launches
-        nbytes = sum(v[0] * v[2] for v in parts) / launches
+
+        def agg(vs):
+            n_ = sum(v[0] for v in vs)
+            return n_, sum(v[0] * v[1] for v in vs) / n_, sum(v[0] * v[2] for v in vs) / n_
+        tname = "bf16" if act_dtype is not None else "float"
+        cands = {f"seg_gmr_fast_kernel<{tname},SUM,BOTH>": parts}
+        if fused:
+            cands[f"seg_fused_fwd_kernel<{tname},SILU,SUM>"] = fused
+        dom_name = max(cands, key=lambda k: sum(v[0] * v[1] for v in cands[k]))
+        launches, ms, nbytes = agg(cands[dom_name])
         achieved = nbytes / (ms * 1e-3) / 1e9
+        others = {}
+        for k, vs in cands.items():
+            if k != dom_name:
+                n_, ms_, nb_ = agg(vs)
+                t_, src_ = committed_traffic({"graphs_per_gpu": args.graphs, "hidden": args.hidden, "dtype": args.dtype}, k)
+                others[k] = {"launches": n_, "avg_ms": ms_, "algorithmic_bytes_per_launch": nb_, "achieved": nb_ / (ms_ * 1e-3) / 1e9,
+                             "frac": nb_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": t_, "traffic_source": src_}
         op_launches = sum(v[0] for v in every)
         op_ms = sum(v[0] * v[1] for v in every) / op_launches
         op_bytes = sum(v[0] * v[2] for v in every) / op_launches
@@ -519,7 +541,7 @@ def main():
         # HBM traffic of the dominant kernel: collected OUTSIDE this process in separate rocprofv3 --pmc passes of
         # this very command (FETCH_SIZE corrected by the calibrated gfx950 factor, WRITE_SIZE as is) and committed
         # under profiles/ with the hash of the kernel sources it was measured on; null when configuration or sources differ.
-        traffic, traffic_src = committed_traffic({"graphs_per_gpu": args.graphs, "hidden": args.hidden, "dtype": args.dtype})
+        traffic, traffic_src = committed_traffic({"graphs_per_gpu": args.graphs, "hidden": args.hidden, "dtype": args.dtype}, dom_name)
         line = {
             "metric": "graphs/sec, ZINC-shape NGNN train step (+ 2-tuple msg-edges/sec and HBM roofline fraction of the spspmm kernel)",
             "value": total_graphs / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
@@ -538,8 +560,7 @@ def main():
             "msg_edges_per_sec_train": total_msgs * args.layers / elapsed,
             "msg_edges_per_sec_kernel": mean["msg_edges"] / (ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "seg_gmr_fast_kernel<bf16,SUM,BOTH>"
-                         if act_dtype is not None else "seg_gmr_fast_kernel<float,SUM,BOTH>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": dom_name, "other": others,
                          "launches": launches, "avg_ms": ms, "algorithmic_bytes_per_launch": nbytes,
                          "forward_bytes_per_msg_edge": fwd_bytes / mean["msg_edges"],
                          # every spspmm launch of the step (forward + both backward plans, BOTH kernels), same definition
