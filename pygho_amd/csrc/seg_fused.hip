@@ -212,6 +212,7 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
   // BatchNorm scale / shift of its accumulator columns (nb * 16 + qq * 4 + j) ------------------------------------------------------------
   fu_u4_t wf[2][4];
   float b4[2][4], c0[2][4], c1[2][4];
+  fu_f32x4_t bb4[2];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
       c0[nb][j] = scale[ch];
       c1[nb][j] = shift[ch];
     }
+    bb4[nb] = fu_f32x4_t{b4[nb][0], b4[nb][1], b4[nb][2], b4[nb][3]};
   }
   for (int r = q; r <= kFuRows; r += 16) {               // the table slice as f32; rows beyond the table (and row 32) are zeros
     float tv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -301,19 +303,17 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
     }                                                                                                                                  \
     __syncthreads();              /* the four column slices of this chunk's window are in LDS (one barrier per chunk, two buffers) */  \
     fu_f32x4_t acc[2][2];                                                                                                              \
-    _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                                                                 \
-      const fu_f32x4_t bb = {b4[nb][0], b4[nb][1], b4[nb][2], b4[nb][3]};                                                              \
-      acc[0][nb] = bb;                                                                                                                 \
-      acc[1][nb] = bb;                                                                                                                 \
-    }                                                                                                                                  \
-    if (c_rows > 0 && !kFuKoMfma) {                                                                                                    \
+    {                                                                                                                                  \
       fu_u4_t xf[2][4];                                                                                                                \
       _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                                                 \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                               \
           xf[mb][ks] = *reinterpret_cast<const fu_u4_t*>(sx + (mb * 16 + r16) * kFuXPitch + ks * 64 + qq * 16);                       \
-      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                 \
+      _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)         /* the bias is the first step's C operand: no accumulator copies */     \
+        _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = kFuKoMfma ? bb4[nb] : fu_mfma<T>(wf[nb][0], xf[mb][0], bb4[nb]); \
+      _Pragma("unroll") for (int ks = 1; ks < 4; ++ks)                                                                                 \
         _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                                                               \
-          _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = fu_mfma<T>(wf[nb][ks], xf[mb][ks], acc[mb][nb]);              \
+          _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                                             \
+            if (!kFuKoMfma) acc[mb][nb] = fu_mfma<T>(wf[nb][ks], xf[mb][ks], acc[mb][nb]);                                            \
     }                                                                                                                                  \
     chunk_tail(acc, keep0, keep1, n, a_rows, a_lo, c_lo, own_rows);                                                                    \
   }
@@ -362,7 +362,10 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
     // ---- output rows: lane group q sums the messages of rows q and 16 + q in message order.  The control words and both operand
     // pieces of the first kFuBurst messages of a row are read from LDS up front (one pipelined burst: word -> rows is a dependent
     // chain per message otherwise, and two wavefronts per SIMD do not hide it); longer rows continue message by message
-    constexpr int kFuBurst = 4;
+#ifndef PYGHO_FU_BURST
+#define PYGHO_FU_BURST 3
+#endif
+    constexpr int kFuBurst = PYGHO_FU_BURST;
     int beg[2], cnt[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
