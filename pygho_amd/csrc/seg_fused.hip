@@ -36,6 +36,11 @@ constexpr int kFuSlice = 64;                     // bytes of a row per wavefront
 constexpr int kFuPitch = kFuSlice + 16;          // staged row
 constexpr int kFuTabRows = 32;
 constexpr int kFuXPitch = kFuRowBytes + 16;      // staged full row (MFMA operand reads of 16 rows at one column spread over the banks)
+#ifdef PYGHO_FU_KO_BARRIER
+constexpr bool kFuKoBarrier = true;
+#else
+constexpr bool kFuKoBarrier = false;
+#endif
 #ifdef PYGHO_FU_KO_MFMA
 constexpr bool kFuKoMfma = true;
 #else
@@ -43,7 +48,12 @@ constexpr bool kFuKoMfma = false;
 #endif
 constexpr int kFuFPitch = 2 * kFuSlice + 16;      // staged row of f32 values (the slice's 32 channels)
 // per wavefront: H as f32 (+ an all-zero row), the table as f32 (+ an all-zero row), H in the storage type, control words, row pointers
-constexpr int kFuWaveLds = 2 * (kFuRows + 1) * kFuFPitch + kFuRows * kFuPitch + kFuMsgs * 4 + 40 * 4;
+// LDS of a workgroup (dynamic: the table's row count sizes it): the X window twice | scale, shift | per wavefront: H as f32 (+ an
+// all-zero row), the table as f32 (+ an all-zero row), control words, row pointers.  16 table rows: 47.9 KB -> three workgroups per CU
+constexpr int kFuXStage = kFuRows * kFuXPitch;
+constexpr int kFuWaveFixed = (kFuRows + 1) * kFuFPitch + kFuMsgs * 4 + 40 * 4;
+__host__ __device__ constexpr int fu_wave_lds(int table_rows) { return kFuWaveFixed + (table_rows + 1) * kFuFPitch; }
+__host__ __device__ constexpr int fu_lds_bytes(int table_rows) { return 2 * kFuXStage + 2 * kFuD * 4 + (kBlock / kWave) * fu_wave_lds(table_rows); }
 
 // ---- planner: greedy chunks of consecutive output rows inside row blocks (the graphs of a batch) ----------------------------------------
 // A chunk closes when the next row would make it 33 rows, 65 messages or a first-operand window of more than 32 rows.  `emit(a_lo,
@@ -178,10 +188,10 @@ template <typename T> __device__ __forceinline__ void fu_round4(const fu_f32x4_t
 }
 
 #ifndef PYGHO_FU_WG_PER_CU
-#define PYGHO_FU_WG_PER_CU 2
+#define PYGHO_FU_WG_PER_CU 3
 #endif
 #ifndef PYGHO_FU_DEPTH
-#define PYGHO_FU_DEPTH 4
+#define PYGHO_FU_DEPTH 2
 #endif
 
 template <typename T, int ACT, bool MEAN, int DEPTH>
@@ -192,16 +202,16 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
     const int4* __restrict__ chunks, const uint32_t* __restrict__ own, int n_chunks, uint32_t x_bytes, uint32_t msg_bytes,
     uint32_t ptr_bytes) {
   using V = Vec16<T>;
-  __shared__ __attribute__((aligned(16))) char s_mem[kBlock / kWave][kFuWaveLds];
-  __shared__ __attribute__((aligned(16))) char s_x[2][kFuRows * kFuXPitch];       // the chunk's X window, all 256 bytes of its rows (two buffers)
+  extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+  char* s_x = s_dyn;                                      // the chunk's X window, all 256 bytes of its rows (two buffers)
+  float* s_c = reinterpret_cast<float*>(s_dyn + 2 * kFuXStage);              // BatchNorm scale [128], shift [128]
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);            // channel slice of this wavefront
   const int r16 = lane & 15, qq = lane >> 4;             // MFMA operand layout: row / n index, 8-element k group
   const int q = lane >> 2, p = lane & 3;                 // row layout: row of a 16-row pass, 16-byte piece of the slice
-  char* s_hf = s_mem[wv];                                 // rows 0 .. 31 of the window + row 32 = zeros (what a message slot past its
-  char* s_tab = s_hf + (kFuRows + 1) * kFuFPitch;         // row's end multiplies: no select per product)
-  char* s_h = s_tab + (kFuRows + 1) * kFuFPitch;
-  uint32_t* s_w = reinterpret_cast<uint32_t*>(s_h + kFuRows * kFuPitch);
+  char* s_hf = s_dyn + 2 * kFuXStage + 2 * kFuD * 4 + wv * fu_wave_lds(table_rows);     // rows 0 .. 31 of the window + row 32 = zeros (what
+  char* s_tab = s_hf + (kFuRows + 1) * kFuFPitch;         // a message slot past its row's end multiplies: no select per product)
+  uint32_t* s_w = reinterpret_cast<uint32_t*>(s_tab + (table_rows + 1) * kFuFPitch);
   int32_t* s_p = reinterpret_cast<int32_t*>(s_w + kFuMsgs);
   const uint32_t slice_off = (uint32_t)wv * kFuSlice + (uint32_t)p * 16u;
   const __amdgpu_buffer_rsrc_t xres = fu_rsrc(x, x_bytes), ores = fu_rsrc(out, x_bytes), hres = fu_rsrc(hout, hout ? x_bytes : 0u),
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
   // ---- this wavefront's 32 rows of Wl as MFMA operands (lane: row n = nb * 16 + r16, k = ks * 32 + qq * 8 ..), bias and the
   // BatchNorm scale / shift of its accumulator columns (nb * 16 + qq * 4 + j) ------------------------------------------------------------
   fu_u4_t wf[2][4];
-  float b4[2][4], c0[2][4], c1[2][4];
+  float b4[2][4];
   fu_f32x4_t bb4[2];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
@@ -222,12 +232,14 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
     for (int j = 0; j < 4; ++j) {
       const int ch = wv * 32 + nb * 16 + qq * 4 + j;
       b4[nb][j] = bias ? load_as_acc<T>(bias + ch) : 0.f;
-      c0[nb][j] = scale[ch];
-      c1[nb][j] = shift[ch];
     }
     bb4[nb] = fu_f32x4_t{b4[nb][0], b4[nb][1], b4[nb][2], b4[nb][3]};
   }
-  for (int r = q; r <= kFuRows; r += 16) {               // the table slice as f32; rows beyond the table (and row 32) are zeros
+  if (threadIdx.x < kFuD) {
+    s_c[threadIdx.x] = scale[threadIdx.x];
+    s_c[kFuD + threadIdx.x] = shift[threadIdx.x];
+  }
+  for (int r = q; r <= table_rows; r += 16) {             // the table slice as f32; the row behind the table is zeros
     float tv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (r < table_rows) V::unpack(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(table) + (size_t)r * kFuRowBytes + slice_off), tv);
     *reinterpret_cast<float4*>(s_tab + r * kFuFPitch + p * 32) = make_float4(tv[0], tv[1], tv[2], tv[3]);
@@ -267,7 +279,14 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = j * 16 + q;
+#ifdef PYGHO_FU_SLICE_X
       rw.xs[j] = __builtin_amdgcn_raw_buffer_load_b128(xres, r < c_rows ? (int)((uint32_t)(dsc.d.z + r) * kFuRowBytes + slice_off) : kOob, 0, 0);
+#else
+      // the window is staged cooperatively, so any partition does: this wavefront takes 8 WHOLE rows (16 lanes x 16 B = one row: full
+      // cache lines per request instead of four wavefronts asking for a quarter of every row)
+      const int xr = wv * 8 + j * 4 + (lane >> 4);
+      rw.xs[j] = __builtin_amdgcn_raw_buffer_load_b128(xres, xr < c_rows ? (int)((uint32_t)(dsc.d.z + xr) * kFuRowBytes + (uint32_t)(lane & 15) * 16u) : kOob, 0, 0);
+#endif
       rw.res[j] = __builtin_amdgcn_raw_buffer_load_b128(xres, residual && r < a_rows ? (int)((uint32_t)(dsc.d.y + r) * kFuRowBytes + slice_off) : kOob, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -283,16 +302,21 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
 
   // one chunk: control words -> LDS, the product, [the registers go back to the loader], activation -> LDS stage, the owned H rows,
   // the output rows
+#ifdef PYGHO_FU_SLICE_X
+#define FU_XS_OFFSET(j) ((j * 16 + q) * kFuXPitch + slice_off)
+#else
+#define FU_XS_OFFSET(j) ((wv * 8 + j * 4 + (lane >> 4)) * kFuXPitch + (lane & 15) * 16)
+#endif
 #define PYGHO_FU_STEP(R, D)                                                                                                            \
   {                                                                                                                                    \
     const int n = D.d.w & 0xff, a_rows = (D.d.w >> 8) & 0xff, c_rows = (D.d.w >> 16) & 0xff;                                           \
     if (a_rows == 0) break;                                                                                                            \
     const int m_lo = D.d.x, a_lo = D.d.y, c_lo = D.d.z;                                                                                \
     const uint32_t own_rows = D.own;                                                                                                   \
-    char* sx = s_x[buf];                                                                                                               \
+    char* sx = s_x + buf * kFuXStage;                                                                                                  \
     buf ^= 1;                                                                                                                          \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                                      \
-      *reinterpret_cast<fu_u4_t*>(sx + (j * 16 + q) * kFuXPitch + slice_off) = R.xs[j];                                                \
+      *reinterpret_cast<fu_u4_t*>(sx + FU_XS_OFFSET(j)) = R.xs[j];                                                                     \
     s_w[lane] = (uint32_t)(R.cw - c_lo) | ((uint32_t)R.lk << 8);                                                                       \
     if (lane <= kFuRows) s_p[lane] = R.sp - m_lo;                                                                                      \
     const fu_u4_t keep0 = R.res[0], keep1 = R.res[1];                                                                                  \
@@ -301,7 +325,7 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
       issue(R, dn);                                                                                                                    \
       D = dn;                                                                                                                          \
     }                                                                                                                                  \
-    __syncthreads();              /* the four column slices of this chunk's window are in LDS (one barrier per chunk, two buffers) */  \
+    if (!kFuKoBarrier) __syncthreads();   /* the four column slices of this chunk's window are in LDS (one barrier per chunk, two buffers) */ \
     fu_f32x4_t acc[2][2];                                                                                                              \
     {                                                                                                                                  \
       fu_u4_t xf[2][4];                                                                                                                \
@@ -328,11 +352,14 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
       for (int nb = 0; nb < 2; ++nb) {
         float v[4];
         fu_round4<T>(acc[mb][nb], v);
+        const float4 c0 = *reinterpret_cast<const float4*>(s_c + wv * 32 + nb * 16 + qq * 4);
+        const float4 c1 = *reinterpret_cast<const float4*>(s_c + kFuD + wv * 32 + nb * 16 + qq * 4);
+        const float c0v[4] = {c0.x, c0.y, c0.z, c0.w}, c1v[4] = {c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
 #ifdef PYGHO_FU_KO_ACT
-        for (int j = 0; j < 4; ++j) v[j] = v[j] * c0[nb][j] + c1[nb][j];
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * c0v[j] + c1v[j];
 #else
-        for (int j = 0; j < 4; ++j) v[j] = fu_act<ACT>(v[j] * c0[nb][j] + c1[nb][j]);
+        for (int j = 0; j < 4; ++j) v[j] = fu_act<ACT>(v[j] * c0v[j] + c1v[j]);
 #endif
         if constexpr (std::is_same<T, f16>::value) {
           // the activation's last multiply and the conversion must round TWICE (f32, then f16) like the kernels this one replaces:
@@ -344,7 +371,6 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
         float vr[4];
         fu_unpack4<T>(pk, vr);
         *reinterpret_cast<float4*>(s_hf + (mb * 16 + r16) * kFuFPitch + nb * 64 + qq * 16) = make_float4(vr[0], vr[1], vr[2], vr[3]);
-        if (own_rows != 0u) *reinterpret_cast<uint2*>(s_h + (mb * 16 + r16) * kFuPitch + nb * 32 + qq * 8) = pk;
       }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -354,9 +380,13 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int r = j * 16 + q;
-        if ((own_rows >> r) & 1u)
-          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const fu_u4_t*>(s_h + r * kFuPitch + p * 16), hres,
-                                                 (int)((uint32_t)(c_lo + r) * kFuRowBytes + slice_off), 0, 0);
+        if ((own_rows >> r) & 1u) {                     // (the staged f32 values are storage-type values: packing them is exact)
+          const float4 h0 = *reinterpret_cast<const float4*>(s_hf + r * kFuFPitch + p * 32);
+          const float4 h1 = *reinterpret_cast<const float4*>(s_hf + r * kFuFPitch + p * 32 + 16);
+          const float hv8[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+          const uint4 hp = V::pack(hv8);
+          __builtin_amdgcn_raw_buffer_store_b128(fu_u4_t{hp.x, hp.y, hp.z, hp.w}, hres, (int)((uint32_t)(c_lo + r) * kFuRowBytes + slice_off), 0, 0);
+        }
       }
     }
     // ---- output rows: lane group q sums the messages of rows q and 16 + q in message order.  The control words and both operand
@@ -381,7 +411,7 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
 #pragma unroll
       for (int i = 0; i < 8; ++i) sum[i] = 0.f;
 #ifndef PYGHO_FU_KO_MSG
-      constexpr uint32_t kNone = (uint32_t)kFuRows | ((uint32_t)kFuRows << 8);       // the two zero rows
+      const uint32_t kNone = (uint32_t)kFuRows | ((uint32_t)table_rows << 8);         // the two zero rows
       uint32_t w[kFuBurst];
       float4 hv[kFuBurst][2], av[kFuBurst][2];
 #pragma unroll
@@ -459,10 +489,13 @@ int launch_fused(void* out, void* hout, const void* x, const void* wl, const voi
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
   }
-  int gx = cus * PYGHO_FU_WG_PER_CU;
+  const int lds = fu_lds_bytes(table_rows);
+  int per_cu = (160 * 1024) / lds;
+  if (per_cu > PYGHO_FU_WG_PER_CU) per_cu = PYGHO_FU_WG_PER_CU;
+  int gx = cus * per_cu;
   if (gx > n_chunks) gx = (int)n_chunks;
 #define PYGHO_FU(ACT, MEAN)                                                                                                            \
-  hipLaunchKernelGGL((seg_fused_fwd_kernel<T, ACT, MEAN, PYGHO_FU_DEPTH>), dim3(gx), dim3(kBlock), 0, st, (T*)out, (T*)hout,           \
+  hipLaunchKernelGGL((seg_fused_fwd_kernel<T, ACT, MEAN, PYGHO_FU_DEPTH>), dim3(gx), dim3(kBlock), lds, st, (T*)out, (T*)hout,           \
                      (const T*)x, (const T*)wl, (const T*)bias, scale, shift, (const T*)table, table_rows, residual, seg_ptr, c32,    \
                      look, (const int4*)chunks, own, (int)n_chunks, (uint32_t)(n_rows * kFuRowBytes), (uint32_t)(n_msg * 4),          \
                      (uint32_t)((n_rows + 1) * 4))
