@@ -725,7 +725,7 @@ class _TupleBlock(torch.autograd.Function):
         fp = None
         if (recompute and FUSED_FWD and plan is not None and rhs is not None and rhs_lookup is not None and aggr in ("sum", "mean")
                 and x.shape[1] == 128 and x.dtype in (torch.bfloat16, torch.float16) and rhs_lookup[0].shape[0] <= 32
-                and rhs_lookup[0].dtype == x.dtype):
+                and rhs_lookup[0].dtype == x.dtype and x.shape[0] * 256 < (1 << 31) and plan.m * 4 < (1 << 31)):
             fp = fused_plan(plan, on_demand=True)
         if fp is not None:
             (scale, shift), mean, var, saved = _bn_forward(None, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum,

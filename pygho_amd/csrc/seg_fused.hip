@@ -5,20 +5,24 @@
 // (reference: NGNNConv.forward, pygho/honn/Conv.py:53-58 = X.tuplewiseapply(lin) then the subgraph message passing of
 // pygho/backend/Spspmm.py:309-315; the model loop's residual add, example/minimal.py:76-79).  The separate passes read X and write H
 // (rowblock_linear_bn_act), then gather H per message and read X again for the residual (seg_gmr_fast): five (nnz, d) streams.  Here
-// the messages are walked in FORWARD order in chunks of consecutive OUTPUT ROWS (<= 32 rows, <= 64 messages) whose first-operand rows c
-// lie in a window of <= 32 consecutive rows -- in a subgraph layer the c rows of a root's outputs are that root's own tuples.  Per chunk:
+// the messages are walked in FORWARD order in chunks of consecutive OUTPUT ROWS (<= 32 rows, <= 64 messages, whole rows only) whose
+// first-operand rows c lie in a window of <= 32 consecutive rows -- in a subgraph layer the c rows of a root's outputs are that root's
+// own tuples.  A workgroup = 4 wavefronts, wavefront w = the 64-byte channel slice [32 w, 32 w + 32) of every row.  Per chunk:
 //
-//   * every wavefront of the workgroup loads the chunk's X window (<= 32 rows x 256 B) straight into MFMA operand registers
-//     (the rows a second, third, fourth time out of L1 / L2: HBM sees them once) and forms ITS 32 output channels of
-//     H = X . Wl^T + bias with 16 v_mfma_f32_16x16x32 (its 32 rows of Wl stay in registers for the whole kernel): the same instruction,
-//     the same k order and the same rounding as rowblock_linear_bn_act, so H has the same bits;
-//   * scale / shift / activation in the accumulator layout, rounded to the storage type, into the wavefront's LDS stage (32 rows x
-//     64 B); the rows this chunk OWNS (the first chunk whose window covers them) also go to `hout` for the backward pass;
-//   * the chunk's output rows: one lane group (4 lanes x 16 B = the wavefront's 64-byte channel slice) per row, its messages summed in
-//     message order out of LDS (H row piece x table row piece, exact products in f32), + the residual piece, one store.
+//   * the window's rows (<= 32 x 256 B) are staged in LDS cooperatively, each wavefront loading 8 WHOLE rows (full cache lines); ONE
+//     barrier per chunk, two buffers (without it the wavefronts drift apart and lose each other's L1 lines: 7 % slower);
+//   * each wavefront forms ITS 32 output channels of H = X . Wl^T + bias for the 32 window rows with 16 v_mfma_f32_16x16x32 (its 32
+//     rows of Wl stay in registers for the whole kernel, the bias is the first step's C operand): the same instruction, the same k
+//     order and the same rounding as rowblock_linear_bn_act, so H has the same bits;
+//   * scale / shift / activation in the accumulator layout, rounded to the storage type, kept as f32 in the wavefront's own LDS stage
+//     (32 rows x 128 B); the rows this chunk OWNS (the first chunk whose window covers them) also go to `hout` for the backward pass;
+//   * the chunk's output rows: one lane group (4 lanes x 8 channels = the wavefront's slice) per row, its messages summed in message
+//     order out of LDS (H row piece x table row piece, both f32: exact products, no unpacking; three message slots are read as one
+//     burst, a slot past the row's end reads all-zero rows instead of being predicated), + the residual piece, one store.
 //
-// A wavefront owns a 64-byte channel slice of every row, as in the by-edge scatter kernel (seg_scatter.hip): no workgroup barrier
-// anywhere, a register pipeline over the workgroup's contiguous share of the chunk list.  Width 128, 16-bit rows, tables of <= 32 rows.
+// No data crosses wavefronts except the staged window; a register pipeline keeps the next chunks' loads in flight over the
+// workgroup's contiguous share of the chunk list.  162 VGPRs, 47.9 KB of dynamic LDS at 16 table rows: three workgroups per CU.
+// Width 128, 16-bit rows, tables of <= 32 rows.  Measurement switches (knock-outs): tools/experiments/seg_fused_knockouts.patch.txt.
 #include "common.h"
 
 namespace pygho {
@@ -33,19 +37,8 @@ constexpr int kFuRows = 32;                      // output rows per chunk / rows
 constexpr int kFuD = 128;                        // row width (elements)
 constexpr int kFuRowBytes = kFuD * 2;
 constexpr int kFuSlice = 64;                     // bytes of a row per wavefront
-constexpr int kFuPitch = kFuSlice + 16;          // staged row
 constexpr int kFuTabRows = 32;
 constexpr int kFuXPitch = kFuRowBytes + 16;      // staged full row (MFMA operand reads of 16 rows at one column spread over the banks)
-#ifdef PYGHO_FU_KO_BARRIER
-constexpr bool kFuKoBarrier = true;
-#else
-constexpr bool kFuKoBarrier = false;
-#endif
-#ifdef PYGHO_FU_KO_MFMA
-constexpr bool kFuKoMfma = true;
-#else
-constexpr bool kFuKoMfma = false;
-#endif
 constexpr int kFuFPitch = 2 * kFuSlice + 16;      // staged row of f32 values (the slice's 32 channels)
 // per wavefront: H as f32 (+ an all-zero row), the table as f32 (+ an all-zero row), H in the storage type, control words, row pointers
 // LDS of a workgroup (dynamic: the table's row count sizes it): the X window twice | scale, shift | per wavefront: H as f32 (+ an
@@ -268,8 +261,8 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
     }
     return dsc;
   };
-  // a chunk's loads of this wavefront: ITS 64-byte column slice of the window rows (the four wavefronts together stage whole rows) and
-  // of the residual rows, 16 rows per load; one message's two indices per lane; one row pointer per lane
+  // a chunk's loads of this wavefront: 8 whole rows of the window (the four wavefronts together stage it), ITS 64-byte column slice of
+  // the residual rows (16 rows per load), one message's two indices per lane, one row pointer per lane
   auto issue = [&](Regs& rw, const Desc& dsc) {
     const int n = dsc.d.w & 0xff, a_rows = (dsc.d.w >> 8) & 0xff, c_rows = (dsc.d.w >> 16) & 0xff;
     __builtin_amdgcn_sched_barrier(0);
@@ -279,14 +272,10 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = j * 16 + q;
-#ifdef PYGHO_FU_SLICE_X
-      rw.xs[j] = __builtin_amdgcn_raw_buffer_load_b128(xres, r < c_rows ? (int)((uint32_t)(dsc.d.z + r) * kFuRowBytes + slice_off) : kOob, 0, 0);
-#else
       // the window is staged cooperatively, so any partition does: this wavefront takes 8 WHOLE rows (16 lanes x 16 B = one row: full
       // cache lines per request instead of four wavefronts asking for a quarter of every row)
       const int xr = wv * 8 + j * 4 + (lane >> 4);
       rw.xs[j] = __builtin_amdgcn_raw_buffer_load_b128(xres, xr < c_rows ? (int)((uint32_t)(dsc.d.z + xr) * kFuRowBytes + (uint32_t)(lane & 15) * 16u) : kOob, 0, 0);
-#endif
       rw.res[j] = __builtin_amdgcn_raw_buffer_load_b128(xres, residual && r < a_rows ? (int)((uint32_t)(dsc.d.y + r) * kFuRowBytes + slice_off) : kOob, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -302,11 +291,7 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
 
   // one chunk: control words -> LDS, the product, [the registers go back to the loader], activation -> LDS stage, the owned H rows,
   // the output rows
-#ifdef PYGHO_FU_SLICE_X
-#define FU_XS_OFFSET(j) ((j * 16 + q) * kFuXPitch + slice_off)
-#else
 #define FU_XS_OFFSET(j) ((wv * 8 + j * 4 + (lane >> 4)) * kFuXPitch + (lane & 15) * 16)
-#endif
 #define PYGHO_FU_STEP(R, D)                                                                                                            \
   {                                                                                                                                    \
     const int n = D.d.w & 0xff, a_rows = (D.d.w >> 8) & 0xff, c_rows = (D.d.w >> 16) & 0xff;                                           \
@@ -325,7 +310,7 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
       issue(R, dn);                                                                                                                    \
       D = dn;                                                                                                                          \
     }                                                                                                                                  \
-    if (!kFuKoBarrier) __syncthreads();   /* the four column slices of this chunk's window are in LDS (one barrier per chunk, two buffers) */ \
+    __syncthreads();              /* the whole window of this chunk is in LDS (one barrier per chunk, two buffers) */                  \
     fu_f32x4_t acc[2][2];                                                                                                              \
     {                                                                                                                                  \
       fu_u4_t xf[2][4];                                                                                                                \
@@ -333,11 +318,10 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                               \
           xf[mb][ks] = *reinterpret_cast<const fu_u4_t*>(sx + (mb * 16 + r16) * kFuXPitch + ks * 64 + qq * 16);                       \
       _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)         /* the bias is the first step's C operand: no accumulator copies */     \
-        _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = kFuKoMfma ? bb4[nb] : fu_mfma<T>(wf[nb][0], xf[mb][0], bb4[nb]); \
+        _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = fu_mfma<T>(wf[nb][0], xf[mb][0], bb4[nb]);                      \
       _Pragma("unroll") for (int ks = 1; ks < 4; ++ks)                                                                                 \
         _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                                                               \
-          _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                                             \
-            if (!kFuKoMfma) acc[mb][nb] = fu_mfma<T>(wf[nb][ks], xf[mb][ks], acc[mb][nb]);                                            \
+          _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = fu_mfma<T>(wf[nb][ks], xf[mb][ks], acc[mb][nb]);              \
     }                                                                                                                                  \
     chunk_tail(acc, keep0, keep1, n, a_rows, a_lo, c_lo, own_rows);                                                                    \
   }
@@ -356,11 +340,7 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
         const float4 c1 = *reinterpret_cast<const float4*>(s_c + kFuD + wv * 32 + nb * 16 + qq * 4);
         const float c0v[4] = {c0.x, c0.y, c0.z, c0.w}, c1v[4] = {c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-#ifdef PYGHO_FU_KO_ACT
-        for (int j = 0; j < 4; ++j) v[j] = v[j] * c0v[j] + c1v[j];
-#else
         for (int j = 0; j < 4; ++j) v[j] = fu_act<ACT>(v[j] * c0v[j] + c1v[j]);
-#endif
         if constexpr (std::is_same<T, f16>::value) {
           // the activation's last multiply and the conversion must round TWICE (f32, then f16) like the kernels this one replaces:
           // the compiler otherwise merges them into v_fma_mixlo_f16, one rounding -- 1 ulp off in ~1e-5 of the elements
@@ -410,7 +390,6 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
       float sum[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) sum[i] = 0.f;
-#ifndef PYGHO_FU_KO_MSG
       const uint32_t kNone = (uint32_t)kFuRows | ((uint32_t)table_rows << 8);         // the two zero rows
       uint32_t w[kFuBurst];
       float4 hv[kFuBurst][2], av[kFuBurst][2];
@@ -448,7 +427,6 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
           sum[6] = __builtin_fmaf(h1.z, a1.z, sum[6]); sum[7] = __builtin_fmaf(h1.w, a1.w, sum[7]);
         }
       }
-#endif
       if (MEAN) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) sum[i] = cnt[j] > 0 ? mean_div(sum[i], cnt[j]) : 0.f;
