@@ -26,9 +26,11 @@ launch, d = 256 bf16, and an I2Conv layer step), config 3 (mamamm X A / X Y at (
 and one forward + backward of the other shipped sparse layers -- each kernel with HIP-event time, algorithmic bytes, roofline
 fraction and committed PMC traffic (tools/bench_configs.py; rocprofv3 summaries under profiles/).
 
-Alongside: msg-edges/s and the HBM roofline fraction of the dominant kernel (the fused gather*gather->segment
-reduce of spspmm, forward and both backward plans), measured live with HIP events around every launch in the
-timed region; and the CPU baseline = the reference's ATen op sequence (oracle/aten_port.py) on the host cores
+Alongside: msg-edges/s and the HBM roofline fraction of the spspmm kernel that carries most of the step's time, measured live
+with HIP events around every launch in the timed region -- with 16-bit activations the FORWARD launch of a layer
+(seg_fused_fwd_kernel: the aggregation with the layer's Linear -> BatchNorm -> act formed inside it, csrc/seg_fused.hip; bytes =
+what has to move: x, out, the stored H, indices), with the by-tuple backward's seg_gmr_fast_kernel under `roofline.other` and every
+spspmm launch of the step (both of them + the by-edge scatter) under `roofline.spspmm_all_launches`; and the CPU baseline = the reference's ATen op sequence (oracle/aten_port.py) on the host cores
 for a bounded sample of the same workload (rank 0, N == 1 only).
 """
 import argparse
