@@ -540,6 +540,7 @@ def main():
         op_bytes = sum(v[0] * v[2] for v in every) / op_launches
         es = 2 if act_dtype is not None else 4
         fwd_bytes = es * args.hidden * (2 * mean["tuples"] + mean["edges"]) + 8 * mean["msg_edges"] + 4 * (mean["tuples"] + 1)
+        replaced_bytes = fwd_bytes + es * args.hidden * mean["tuples"] + 2 * es * args.hidden * mean["tuples"]
         # HBM traffic of the dominant kernel: collected OUTSIDE this process in separate rocprofv3 --pmc passes of
         # this very command (FETCH_SIZE corrected by the calibrated gfx950 factor, WRITE_SIZE as is) and committed
         # under profiles/ with the hash of the kernel sources it was measured on; null when configuration or sources differ.
@@ -564,6 +565,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": dom_name, "other": others,
                          "launches": launches, "avg_ms": ms, "algorithmic_bytes_per_launch": nbytes,
+                         **({"replaced_launches": {
+                             "what": "the two launches the fused forward kernel replaces (rounds 1-4): Linear+BatchNorm+act over the tuples "
+                                     "(x in, H out) and the spspmm forward with the residual row (H, x in, out; edge rows; indices)",
+                             "algorithmic_bytes": replaced_bytes,
+                             "frac_at_this_kernels_time": replaced_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                            if dom_name.startswith("seg_fused") else {}),
                          "forward_bytes_per_msg_edge": fwd_bytes / mean["msg_edges"],
                          # every spspmm launch of the step (forward + both backward plans, BOTH kernels), same definition
                          "spspmm_all_launches": {"launches": op_launches, "avg_ms": op_ms, "algorithmic_bytes_per_launch": op_bytes,
