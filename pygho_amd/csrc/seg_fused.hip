@@ -32,7 +32,12 @@ typedef __attribute__((ext_vector_type(8))) _Float16 fu_f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float fu_f32x4_t;
 typedef uint32_t fu_u4_t __attribute__((ext_vector_type(4)));
 
-constexpr int kFuMsgs = 64;                      // messages per chunk
+#ifndef PYGHO_FU_MSGS
+#define PYGHO_FU_MSGS 64
+#endif
+constexpr int kFuMsgs = PYGHO_FU_MSGS;           // messages per chunk (a multiple of 64: one or two control words per lane)
+constexpr int kFuMW = kFuMsgs / kWave;
+static_assert(kFuMsgs % kWave == 0 && kFuMsgs <= 192, "the chunk record packs the message count in 8 bits");
 constexpr int kFuRows = 32;                      // output rows per chunk / rows of the first-operand window
 constexpr int kFuD = 128;                        // row width (elements)
 constexpr int kFuRowBytes = kFuD * 2;
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
   int pci = (int)((int64_t)n_chunks * g / G);
   const int ci_end = (int)((int64_t)n_chunks * (g + 1) / G);
 
-  struct Regs { fu_u4_t xs[2], res[2]; int cw, lk, sp; };
+  struct Regs { fu_u4_t xs[2], res[2]; int cw[kFuMW], lk[kFuMW], sp; };
   struct Desc { int4 d; uint32_t own; };
   auto next_desc = [&]() {
     Desc dsc;
@@ -267,8 +272,12 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
     const int n = dsc.d.w & 0xff, a_rows = (dsc.d.w >> 8) & 0xff, c_rows = (dsc.d.w >> 16) & 0xff;
     __builtin_amdgcn_sched_barrier(0);
     rw.sp = __builtin_amdgcn_raw_buffer_load_b32(pres, lane <= a_rows && a_rows > 0 ? (int)((uint32_t)(dsc.d.y + lane) * 4u) : kOob, 0, 0);
-    rw.cw = __builtin_amdgcn_raw_buffer_load_b32(cres, lane < n ? (int)((uint32_t)(dsc.d.x + lane) * 4u) : kOob, 0, 0);
-    rw.lk = __builtin_amdgcn_raw_buffer_load_b32(lres, lane < n ? (int)((uint32_t)(dsc.d.x + lane) * 4u) : kOob, 0, 0);
+#pragma unroll
+    for (int t = 0; t < kFuMW; ++t) {
+      const int mo = lane + t * kWave < n ? (int)((uint32_t)(dsc.d.x + lane + t * kWave) * 4u) : kOob;
+      rw.cw[t] = __builtin_amdgcn_raw_buffer_load_b32(cres, mo, 0, 0);
+      rw.lk[t] = __builtin_amdgcn_raw_buffer_load_b32(lres, mo, 0, 0);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = j * 16 + q;
@@ -302,7 +311,8 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
     buf ^= 1;                                                                                                                          \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                                      \
       *reinterpret_cast<fu_u4_t*>(sx + FU_XS_OFFSET(j)) = R.xs[j];                                                                     \
-    s_w[lane] = (uint32_t)(R.cw - c_lo) | ((uint32_t)R.lk << 8);                                                                       \
+    _Pragma("unroll") for (int t = 0; t < kFuMW; ++t)                                                                                  \
+      s_w[lane + t * kWave] = (uint32_t)(R.cw[t] - c_lo) | ((uint32_t)R.lk[t] << 8);                                                   \
     if (lane <= kFuRows) s_p[lane] = R.sp - m_lo;                                                                                      \
     const fu_u4_t keep0 = R.res[0], keep1 = R.res[1];                                                                                  \
     {                                                                                                                                  \

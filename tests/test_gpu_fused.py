@@ -47,8 +47,17 @@ def _operands(dev, n, d, dtype, table_rows, bias=True, seed=0):
     return x, wl, b, scale, shift, table
 
 
+def _limits():
+    import ctypes
+    from pygho_amd._native import lib
+    v = [ctypes.c_int(0) for _ in range(4)]
+    assert lib().pygho_seg_fused_limits(*[ctypes.byref(x) for x in v]) == 0
+    return tuple(int(x.value) for x in v)          # messages per chunk, rows per chunk, table rows, width
+
+
 def test_planner_chunks_tile_the_rows_within_the_limits(dev, batch):
     from pygho_amd import _ops
+    max_msgs, max_rows, _, _ = _limits()
     hb, plan, _ = batch
     fp = _ops.fused_plan(plan)
     assert fp is not None
@@ -58,7 +67,7 @@ def test_planner_chunks_tile_the_rows_within_the_limits(dev, batch):
     c = plan.c_fwd.cpu().numpy().astype(np.int64)
     m_lo, a_lo, c_lo = ch[:, 0], ch[:, 1], ch[:, 2]
     msgs, rows, crow = ch[:, 3] & 0xff, (ch[:, 3] >> 8) & 0xff, (ch[:, 3] >> 16) & 0xff
-    assert rows.min() >= 1 and rows.max() <= 32 and msgs.max() <= 64 and crow.max() <= 32
+    assert rows.min() >= 1 and rows.max() <= max_rows and msgs.max() <= max_msgs and crow.max() <= max_rows
     assert a_lo[0] == 0 and np.array_equal(a_lo[1:], (a_lo + rows)[:-1]) and a_lo[-1] + rows[-1] == plan.n_out       # tile [0, n)
     assert np.array_equal(m_lo, seg[a_lo]) and np.array_equal(m_lo + msgs, seg[a_lo + rows])                          # whole rows only
     owner_count = np.zeros(plan.n_lhs, dtype=np.int64)
@@ -97,10 +106,10 @@ def test_fused_forward_equals_the_two_launches_bitwise(dev, batch, dtype, act, a
 
 
 def test_rows_outside_the_limits_keep_the_separate_kernels(dev):
-    """one output row with 70 messages (> 64), and one whose first-operand rows are 40 apart (> 31): no fused plan"""
+    """one output row with more messages than a chunk holds, and one whose first-operand rows are 40 apart (> 31): no fused plan"""
     from pygho_amd import _ops
-    n = 200
-    for a, c in (([5] * 70, list(range(70))), ([7, 7], [3, 43])):
+    n, over = 400, _limits()[0] + 6
+    for a, c in (([5] * over, list(range(over))), ([7, 7], [3, 43])):
         acd = torch.tensor([a, c, [0] * len(a)], dtype=torch.int64, device=dev)
         plan = _ops.message_plan(acd, n, n, 4)
         assert _ops.fused_plan(plan) is None
