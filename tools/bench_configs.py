@@ -168,6 +168,12 @@ def layers(dev, quick=False):
         r = bench_layers.case(name, graphs, dev)
         out[f"{name}_SS_layer_fwd_bwd"] = {"ms": r["ms"], "graphs": r["graphs"], "graphs_per_s": r["graphs_per_s"], "tuples": r["tuples"],
                                            "d": r["d"], "msg_edges": r["msg_edges"]}
+    # NGNNConv as the model loop runs it (example/minimal.py:76-79): + residual, edge values = an embedding lookup -- the fused block
+    # kernels (round 5: Linear -> BatchNorm -> act inside the forward aggregation, csrc/seg_fused.hip), with their per-launch figures
+    r = bench_layers.case("NGNNConv", graphs, dev, kernels=True, residual_lookup=True)
+    out["NGNNConv_SS_residual_lookup_layer_fwd_bwd"] = {"ms": r["ms"], "graphs": r["graphs"], "graphs_per_s": r["graphs_per_s"], "tuples": r["tuples"],
+                                                        "d": r["d"], "msg_edges": r["msg_edges"],
+                                                        "kernels": {k: v for k, v in r["kernels"].items() if k.startswith(("seg_fused", "seg_gmr"))}}
     # the reference's other first-class aggregation (pygho/backend/utils.py:44-56, --aggr in example/zinc.py): max, with the
     # per-launch figures of its backward (share pass + the two gradient plans on the 16-byte-per-lane kernels)
     r = bench_layers.case("NGNNConv", graphs, dev, aggr="max", kernels=True)

@@ -44,7 +44,10 @@ def build(name, h, dev, aggr="sum"):
     raise ValueError(name)
 
 
-def case(name, graphs, dev, profile=False, aggr="sum", kernels=False):
+def case(name, graphs, dev, profile=False, aggr="sum", kernels=False, residual_lookup=False):
+    """`residual_lookup`: the layer as the MODEL LOOP runs it -- `X.add(layer(A, X), True)` through `forward_residual`, with A's values
+    an embedding lookup of the edge feature (what `InputEncoderSp` produces): the form that takes the fused block kernels
+    (csrc/seg_fused.hip for NGNNConv); otherwise `layer.forward` on random edge values (the operator path alone)"""
     kind, h = ("i2", 256) if name == "I2Conv" else ("zinc", 128)
     layer = build(name, h, dev, aggr)
     keys = tuple(parse_precomputekey(layer))
@@ -54,6 +57,10 @@ def case(name, graphs, dev, profile=False, aggr="sum", kernels=False):
     X0, A0 = dd["X"], dd["A"]
     xv = torch.randn(X0.nnz, h, device=dev).to(torch.bfloat16).requires_grad_(True)
     av = torch.randn(A0.nnz, h, device=dev).to(torch.bfloat16)
+    if residual_lookup:
+        from pygho_amd.ngnn import IndexEmbedding
+        torch.manual_seed(1)
+        emb = IndexEmbedding(16, h, torch.bfloat16).to(dev)
     A = SparseTensor(A0.indices, av, list(A0.shape[:A0.sparse_dim]) + [h], True)
     w = torch.randn(X0.nnz, h, device=dev).to(torch.bfloat16)
     # the batch's message plans, INCLUDING the by-edge gradient's scatter plans, exist before the timed region -- as for a batch collated
@@ -63,7 +70,10 @@ def case(name, graphs, dev, profile=False, aggr="sum", kernels=False):
     for k in keys:
         roles = parse_key(k)
         rows = lambda r: int(X0.nnz) if r[0] == "X" else int(A0.nnz)
-        _ops.scatter_plan(_ops.message_plan(dd[k + "___acd"], rows(roles[0]), rows(roles[1]), rows(roles[3])))
+        plan = _ops.message_plan(dd[k + "___acd"], rows(roles[0]), rows(roles[1]), rows(roles[3]))
+        _ops.scatter_plan(plan)
+        if residual_lookup:
+            _ops.fused_plan(plan)                  # the fused block forward's chunk list (None when the pattern is outside its limits)
 
     def step():
         xv.grad = None
@@ -71,7 +81,12 @@ def case(name, graphs, dev, profile=False, aggr="sum", kernels=False):
             p.grad = None
         X = SparseTensor(X0.indices, xv, list(X0.shape[:X0.sparse_dim]) + [h], True)
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            out = layer(A, X, dd)
+            if residual_lookup:
+                emb.weight.grad = None
+                Al = A0.tuplewiseapply(lambda v: emb(v))            # values carry their provenance (table, index): honn/Conv._residual_update
+                out = layer.forward_residual(Al, X, dd)
+            else:
+                out = layer(A, X, dd)
         out.values.backward(w)
 
     for _ in range(6):
@@ -93,7 +108,8 @@ def case(name, graphs, dev, profile=False, aggr="sum", kernels=False):
             torch.cuda.synchronize()
         print(pr.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=90), file=sys.stderr)
     msgs = {k: int(dd[k + "___acd"].shape[1]) for k in keys}
-    res = {"op": f"{name} SS layer fwd+bwd" + ("" if aggr == "sum" else f" (aggr={aggr})"), "graphs": hb.num_graphs, "tuples": int(X0.nnz),
+    res = {"op": f"{name} SS layer fwd+bwd" + ("" if aggr == "sum" else f" (aggr={aggr})") + (" + residual, edge values = embedding lookup" if residual_lookup else ""),
+           "graphs": hb.num_graphs, "tuples": int(X0.nnz),
            "d": h, "dtype": "bfloat16", "msg_edges": msgs, "ms": ms, "graphs_per_s": hb.num_graphs / ms * 1e3}
     if kernels:                                           # per-launch HIP-event times of the segment kernels of one more step
         from pygho_amd import _ops
