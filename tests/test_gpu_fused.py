@@ -116,6 +116,29 @@ def test_rows_outside_the_limits_keep_the_separate_kernels(dev):
         assert _ops.fused_plan(plan, on_demand=True) is None
 
 
+def test_rows_without_messages_and_sparse_patterns(dev):
+    """most output rows have no message at all (they are the residual row alone), chunks without any message, one row with the maximum
+    number of messages, a table with a single row"""
+    from pygho_amd import _ops
+    max_msgs = _limits()[0]
+    n, d = 1500, 128
+    a = [3, 3, 10, 50, 51, 51, 51, 700] + [900] * max_msgs + [1499]
+    c = [0, 7, 12, 40, 60, 61, 52, 690] + [880 + (i % 30) for i in range(max_msgs)] + [1490]
+    acd = torch.tensor([a, c, [0] * len(a)], dtype=torch.int64, device=dev)
+    plan = _ops.message_plan(acd, n, n, 3)
+    fp = _ops.fused_plan(plan)
+    assert fp is not None
+    x, wl, b, scale, shift, table = _operands(dev, n, d, torch.bfloat16, 1)
+    look_fwd = torch.zeros(len(a), dtype=torch.int32, device=dev)
+    h_ref = _ops.rowblock_linear_bn_act(x, wl, b, scale, shift, "silu")
+    for aggr in ("sum", "mean"):
+        o_ref = _ops.seg_gmr(n, h_ref, table, plan.fwd.seg_ptr, plan.c_fwd, look_fwd, aggr, addend=x)
+        o, h = _ops.fused_forward(x, wl, b, scale, shift, "silu", table, look_fwd, plan, fp, aggr, True, True)
+        assert torch.equal(o, o_ref)
+        read = torch.unique(plan.c_fwd.long())
+        assert torch.equal(h[read], h_ref[read])
+
+
 def _train_step(model, dd):
     for p in model.parameters():
         p.grad = None
