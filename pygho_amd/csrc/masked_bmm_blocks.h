@@ -332,10 +332,12 @@ int launch_bmm_blocks_t(const BmmArgs& p, int64_t nb, hipStream_t st) {
   return check_launch("masked_bmm_blocks");
 }
 
-// variant selection for A/B measurements: PYGHO_BMM_VARIANT = "tiles" (the 16x16x32 LDS kernel), "blocks" (default where the
-// shape allows: d a multiple of 16 pieces, nk <= 64), "blocks-2x1" (8 x 4 tiles, 3 wavefronts per SIMD: 191 vs 168 us at
-// (1024, 37, 37, 128) bf16), "blocks-pf1" (operand loads one step ahead in a second register buffer, 1 wavefront per SIMD:
-// 287 vs 227 us -- resident wavefronts beat loads in flight per wavefront once more)
+// variant selection for A/B measurements: PYGHO_BMM_VARIANT = "tiles" (the 16x16x32 LDS kernel) or "blocks" (default where the shape
+// allows: d a multiple of 16 pieces, nk <= 64).  The shipped blocks kernel is <T, 2, 2, 1>: 8 x 8 tiles, one register buffer,
+// 222-224 VGPRs = TWO wavefronts per SIMD.  Two more instantiations exist only in builds with -DPYGHO_BMM_AB_VARIANTS (they are not
+// compiled into the product library): "blocks-2x1" (8 x 4 tiles, 138 VGPRs, 3 wavefronts per SIMD: 191 vs 168 us at (1024, 37, 37,
+// 128) bf16) and "blocks-pf1" (operand loads one step ahead in a second register buffer: 256 + 152 registers, ONE wavefront per
+// SIMD, 287 vs 227 us -- resident wavefronts beat loads in flight per wavefront once more)
 inline int bmm_variant() {
   static int v = -1;
   if (v < 0) {
@@ -343,8 +345,10 @@ inline int bmm_variant() {
     v = 1;
     if (e) {
       if (!strcmp(e, "tiles")) v = 0;
+#ifdef PYGHO_BMM_AB_VARIANTS
       else if (!strcmp(e, "blocks-2x1")) v = 3;
       else if (!strcmp(e, "blocks-pf1")) v = 4;
+#endif
     }
   }
   return v;
@@ -356,8 +360,10 @@ template <typename T> bool bmm_blocks_eligible(const BmmArgs& p) {
 
 template <typename T> int launch_bmm_blocks(const BmmArgs& p, int64_t nb, hipStream_t st) {
   switch (bmm_variant()) {
+#ifdef PYGHO_BMM_AB_VARIANTS
     case 3: return launch_bmm_blocks_t<T, 2, 1, 1>(p, nb, st);
     case 4: return launch_bmm_blocks_t<T, 2, 2, 2>(p, nb, st);     // one step of register prefetch, one wavefront per SIMD
+#endif
     default: return launch_bmm_blocks_t<T, 2, 2, 1>(p, nb, st);
   }
 }
