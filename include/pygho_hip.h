@@ -181,6 +181,18 @@ int pygho_seg_triple_product(void* out, const void* a, const void* b, const void
                              void* stream);
 
 /*
+ * aggr = "prod" of the segment reduction (csrc/seg_prod.hip): pygho/backend/utils.py:44-56 with reduce = "prod" (zeros +
+ * scatter_reduce_(include_self=False): an empty segment stays 0) and coalesce(reduce = "prod"), pygho/backend/SpTensor.py:167-197.
+ *   out[s, :] = prod_{m in [seg_ptr[s], seg_ptr[s+1])} src[perm[m], :]       (perm NULL = identity), products in message order
+ * and its gradient by torch's scatter_reduce_backward rule (z = exact zeros among a segment's values: z == 0 -> gout * out / src,
+ * z == 1 -> the zero element receives gout * product of the others, z >= 2 -> 0).  f32 / f64 / bf16 / f16; forward also int64.
+ */
+int pygho_seg_prod(void* out, const void* src, const int32_t* seg_ptr, const int32_t* perm, int64_t n_seg, int64_t d, int dtype,
+                   void* stream);
+int pygho_seg_prod_bwd(void* gsrc, const void* gout, const void* out, const void* src, const int32_t* seg_ptr, const int32_t* perm,
+                       int64_t n_seg, int64_t d, int dtype, void* stream);
+
+/*
  * Backward of the max / min aggregation (autograd of scatter_reduce_(amax|amin),
  * pygho/backend/utils.py:50-55): along a plan grouped by the operand being
  * differentiated,

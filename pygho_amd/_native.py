@@ -45,6 +45,8 @@ PROTOTYPES = {
     "pygho_seg_gather_mul_reduce_act": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, L, L, I, I, P]),
     "pygho_seg_triple_product": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, I, I, P]),
     "pygho_seg_sum_f32out": (I, [P, P, P, P, L, L, L, I, P]),
+    "pygho_seg_prod": (I, [P, P, P, P, L, L, I, P]),
+    "pygho_seg_prod_bwd": (I, [P, P, P, P, P, P, L, L, I, P]),
     "pygho_seg_extremum_ties": (I, [P, P, P, P, P, P, P, L, L, I, P]),
     "pygho_seg_extremum_bwd": (I, [P, P, P, P, P, P, P, P, P, L, L, I, P]),
     "pygho_seg_scatter_limits": (I, [P, P, P]),

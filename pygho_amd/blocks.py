@@ -256,10 +256,10 @@ class ParamCastArena:
         dev = self.params[0].device if self.params else None
         self.flat = torch.empty(total, dtype=dtype, device=dev) if self.params else None
         self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
-        # aliases with their OWN version counters, for the refresh to write through: autograd saves `views` (_ArenaLinearFn,
-        # _PairProduct), and a re-cast between a forward and its backward -- a second grad-enabled forward first: siamese use, a
-        # validation pass -- must not trip the saved tensors' version check.  With unchanged parameters the re-cast writes the same
-        # bits, so that backward reads what its forward read.
+        # aliases with their OWN version counters, for the re-cast of UNCHANGED parameters to write through: autograd saves `views`
+        # (_ArenaLinearFn, _PairProduct, _TupleBlock), and a re-cast between a forward and its backward -- a second grad-enabled
+        # forward first: siamese use, a validation pass -- must not trip the saved tensors' version check; it writes the same bits.
+        # Parameters known to have changed are written through `views` themselves (`refresh`).
         self.raw_views = [v.data for v in self.views]
         self.versions = [-1] * len(self.params)
         self.ptrs = [0] * len(self.params)          # storage address at the last refresh: `module.to()` / `p.data = ...` swap it
@@ -299,15 +299,25 @@ class ParamCastArena:
         (`GraphedStep.replay` bumps the epoch).  NOT visible from here: writes through a `.data` alias (`p.data.mul_(...)` has its
         own version counter) -- call `invalidate_cast_arenas()` after those.  Under stream capture every copy is re-cast INSIDE
         the graph: a graph that captured only forward + backward must not bake in the views of a cast that happened before it."""
-        if force or self.epoch != _ARENA_EPOCH[0] or (self.flat is not None and torch.cuda.is_current_stream_capturing()):
+        # KNOWN to have changed since the last cast (an optimizer step / `invalidate_cast_arenas()` moved the epoch, a version counter or
+        # a storage address moved): those copies are rewritten through the views autograd may have SAVED, so their version counter
+        # moves and the backward of a graph recorded BEFORE the update raises torch's usual "modified by an inplace operation" error
+        # instead of silently reading the new 16-bit weights (ADVICE r5: forward, optimizer step, forward, backward of the FIRST graph).
+        # Copies re-cast only because every forward re-casts (`force`: updates nobody can see, e.g. through `.data`) go through the
+        # aliases with their own counters: with unchanged parameters they receive the same bits, and a second grad-enabled forward
+        # before backward (siamese use, a validation pass) must not invalidate what the first one saved.
+        moved = self.epoch != _ARENA_EPOCH[0]
+        changed = [i for i, p in enumerate(self.params) if moved or self.versions[i] != p._version or self.ptrs[i] != p.data_ptr()]
+        if force or (self.flat is not None and torch.cuda.is_current_stream_capturing()):
             stale = list(range(len(self.params)))
         else:
-            stale = [i for i, p in enumerate(self.params) if self.versions[i] != p._version or self.ptrs[i] != p.data_ptr()]
+            stale = changed
         self.epoch = _ARENA_EPOCH[0]
         if not stale:
             return
+        seen = set(changed)
         with torch.no_grad():
-            torch._foreach_copy_([self.raw_views[i] for i in stale], [self.params[i].detach() for i in stale])
+            torch._foreach_copy_([self.views[i] if i in seen else self.raw_views[i] for i in stale], [self.params[i].detach() for i in stale])
         for i in stale:
             self.versions[i] = self.params[i]._version
             self.ptrs[i] = self.params[i].data_ptr()

@@ -72,21 +72,36 @@ def build(force: bool = False, verbose: bool = True, variant: str = "", defines=
     """`variant` + `defines`: an A/B build of the same sources with extra -D flags into _lib/variants/<variant>/ (loaded with
     PYGHO_AMD_LIB=<path>, see _native.py) so that two kernel versions can be timed on the SAME box in one gpurun call."""
     if variant:
-        return _build_into(os.path.join(LIBDIR, "variants", variant), list(defines), verbose)
+        return _build_into(os.path.join(LIBDIR, "variants", variant), list(defines), verbose, force=True)
     if not force and up_to_date():
         return LIB
-    return _build_into(LIBDIR, [], verbose)
+    return _build_into(LIBDIR, [], verbose, force)
 
 
-def _build_into(libdir: str, defines, verbose: bool) -> str:
+def _build_into(libdir: str, defines, verbose: bool, force: bool = True) -> str:
+    """`force` False: objects newer than their source and every header are kept (their resource-usage record is kept beside
+    them), so that a one-file change recompiles one file; `__graft_entry__.build()` compiles everything."""
     os.makedirs(libdir, exist_ok=True)
     objdir = os.path.join(libdir, "obj")
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
     lib, usage_path = os.path.join(libdir, "libpygho_hip.so"), os.path.join(libdir, "resource_usage.json")
+    # objects of sources that no longer exist (a shelved experiment's .o stayed beside the live ones for a round) are removed: obj/
+    # holds exactly what the library is linked from
+    live = {os.path.basename(src) + ".o" for src in sources()}
+    live |= {name + ".usage.json" for name in live}
+    for name in os.listdir(objdir):
+        if name not in live:
+            os.remove(os.path.join(objdir, name))
+
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        rec = obj + ".usage.json"
+        if not force and os.path.exists(obj) and os.path.exists(rec) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [src, *headers]):
+            with open(rec) as f:
+                return obj, json.load(f)
         cmd = [cc, *FLAGS, *defines, "-Rpass-analysis=kernel-resource-usage", f"-I{INCLUDE}", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -94,7 +109,10 @@ def _build_into(libdir: str, defines, verbose: bool) -> str:
         if proc.returncode != 0:
             sys.stderr.write(proc.stderr)
             raise subprocess.CalledProcessError(proc.returncode, cmd)
-        return obj, _resource_usage(proc.stderr, os.path.basename(src))
+        usage = _resource_usage(proc.stderr, os.path.basename(src))
+        with open(rec, "w") as f:
+            json.dump(usage, f)
+        return obj, usage
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         results = list(ex.map(compile_one, sources()))

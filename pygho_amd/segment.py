@@ -845,11 +845,50 @@ class _ScatterReduce(torch.autograd.Function):
         return _extremum_bwd(src.shape[0], gout, fwd, ties, src, None, up, ind32, None), None, None, None
 
 
+class _ScatterProd(torch.autograd.Function):
+    """aggr = "prod" (utils.py:44-56 with reduce="prod"; coalesce(reduce="prod"), SpTensor.py:167-197): csrc/seg_prod.hip"""
+
+    @staticmethod
+    def forward(ctx, src: Tensor, plan: SegPlan):
+        dev = require_device(src, plan.seg_ptr, plan.perm)
+        src = src.contiguous()
+        out = torch.empty((plan.n_seg, src.shape[1]), dtype=src.dtype, device=dev)
+        check(lib().pygho_seg_prod(ptr(out), ptr(src), ptr(plan.seg_ptr), ptr(plan.perm), plan.n_seg, src.shape[1], dtype_code(src),
+                                   stream_ptr(dev)), "seg_prod")
+        ctx.plan = plan
+        ctx.save_for_backward(src, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        src, out = ctx.saved_tensors
+        plan, dev = ctx.plan, src.device
+        gsrc = torch.empty_like(src)
+        check(lib().pygho_seg_prod_bwd(ptr(gsrc), ptr(gout.contiguous()), ptr(out), ptr(src), ptr(plan.seg_ptr), ptr(plan.perm), plan.n_seg,
+                                       src.shape[1], dtype_code(src), stream_ptr(dev)), "seg_prod_bwd")
+        return gsrc, None
+
+
+_PROD_DTYPES = (torch.float32, torch.float64, torch.bfloat16, torch.float16, torch.int64)
+
+
+def _scatter_prod(src2: Tensor, plan: SegPlan) -> Tensor:
+    if src2.dtype not in _PROD_DTYPES:
+        raise NotImplementedError(f"aggr 'prod' on {src2.dtype} values")
+    require_static_rows(src2.shape[0], "aggr = 'prod'")
+    return _ScatterProd.apply(src2, plan)
+
+
 def scatter_reduce(src: Tensor, ind: Tensor, dim_size: int, aggr: str) -> Tensor:
     """torch_scatter_reduce(dim=0) (utils.py:44-56) on the HIP path."""
     require_device(src, ind)
+    if aggr == "prod":
+        assert ind.dim() == 1, "indice must be 1-d"
+        assert src.shape[0] == ind.shape[0], "src and index length differ"
+        src2 = _as2d(src) if src.dim() > 1 else src.contiguous().reshape(-1, 1)
+        return _scatter_prod(src2, cached_plan(ind, dim_size, "scatter")).reshape((dim_size,) + tuple(src.shape[1:]))
     if aggr not in AGGR_CODE:
-        raise NotImplementedError(f"aggr {aggr!r} is not supported (sum, mean, max, min)")
+        raise NotImplementedError(f"aggr {aggr!r} is not supported (sum, mean, max, min, prod)")
     assert ind.dim() == 1, "indice must be 1-d"
     assert src.shape[0] == ind.shape[0], "src and index length differ"
     plan = cached_plan(ind, dim_size, "scatter")
@@ -861,8 +900,11 @@ def scatter_reduce(src: Tensor, ind: Tensor, dim_size: int, aggr: str) -> Tensor
 
 def scatter_reduce_planned(src: Tensor, plan: SegPlan, ind32: Tensor, aggr: str) -> Tensor:
     """scatter-reduce along a prebuilt plan (coalesce / sparse pooling)."""
+    if aggr == "prod":
+        src2 = _as2d(src) if src.dim() > 1 else src.contiguous().reshape(-1, 1)
+        return _scatter_prod(src2, plan).reshape((plan.n_seg,) + tuple(src.shape[1:]))
     if aggr not in AGGR_CODE:
-        raise NotImplementedError(f"aggr {aggr!r} is not supported (sum, mean, max, min)")
+        raise NotImplementedError(f"aggr {aggr!r} is not supported (sum, mean, max, min, prod)")
     tail = tuple(src.shape[1:])
     src2 = _as2d(src) if src.dim() > 1 else src.contiguous().reshape(-1, 1)
     out = _ScatterReduce.apply(src2, plan, ind32, aggr)

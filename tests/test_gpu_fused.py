@@ -227,3 +227,114 @@ def test_captured_slot_step_runs_the_fused_forward_and_matches_the_unfused_eager
         assert torch.equal(a, b)
     for p, q in zip(model.parameters(), ref.parameters()):
         assert torch.equal(p, q)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# the fused forward against the ORACLE at BASELINE size: not against the launches it replaces
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _ordered(t):
+    """storage-type values (bf16 / f16) as integers in value order: neighbouring representable values differ by 1 (-0 == +0)"""
+    bits = t.contiguous().view(torch.int16).to(torch.int32) & 0xffff
+    return torch.where(bits >= 0x8000, 0x8000 - bits, bits)
+
+
+def _neighbours(v64, dtype):
+    """the two storage-type values that bracket the f64 values (equal where v64 is representable)"""
+    near = v64.to(dtype)
+    nf = near.double()
+    bits = near.view(torch.int16)
+    # one ulp towards the other side of v64: +1 on the bit pattern moves away from zero, -1 towards it
+    away = (nf.abs() < v64.abs())
+    other = torch.where(nf == v64, bits, torch.where(away, bits + 1, bits - 1))
+    # crossing zero (near == +-0 and v64 on the other side does not happen: near is the NEAREST value); bits - 1 on +-0 never taken
+    # because |near| < |v64| whenever near == 0 and v64 != 0
+    return near, other.view(dtype)
+
+
+@pytest.fixture(scope="module")
+def baseline_store(dev):
+    """BASELINE config 2's batch: 8192 distinct ZINC-shape graphs, collated by the device store WITH every plan (the fused chunks
+    are the store's precomputed per-graph chunks with offsets added -- the plan the benchmark's step runs on)"""
+    from pygho_amd import synth
+    from pygho_amd.collate import DeviceGraphStore
+    rng = np.random.default_rng(1000)
+    store = DeviceGraphStore([synth.make_graph(rng, "zinc", 3, (KEY,)) for _ in range(8192)], dev)
+    dd = store.collate(np.random.default_rng(7).permutation(8192))
+    return store, dd
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_forward_at_baseline_size_vs_host_oracle(dev, baseline_store, dtype):
+    """`seg_fused_fwd_kernel` (the kernel bench.py's roofline reports) at 8192 ZINC-shape graphs, width 128, on the store-collated
+    plan, against the HOST:
+
+    * the stored H rows against act(bn(x W^T + b)) (reference honn/utils.py:126-142 via Conv.py:56) evaluated in f64.  The device
+      rounds the Linear's output to the storage type before BatchNorm (as the reference's autocast does: the Linear's output IS a
+      16-bit tensor), so the f64 pre-activation's TWO neighbouring storage values are the admissible roundings: every H element must be
+      within 1 storage-ulp of H evaluated at one of them, and >= 99.9 % within 1 ulp of H evaluated at the NEAREST one;
+    * `out` BIT FOR BIT against round(x + aggr_{(a,c,d)} H_dev[c] * table[look[d]]) where the aggregation is the reference's ATen
+      sequence on the host (oracle.aten_port.spspmm_values_chunked, Spspmm.py:309-315: index, index, mul, index_add_ in message
+      order) over the DEVICE's stored H: f32 products of two 16-bit values are exact, so the f32 sums must agree exactly and the
+      result is their single rounding; sum and mean; the residual add of example/minimal.py:80."""
+    from oracle import aten_port as P
+    from pygho_amd import _ops
+    _store, dd = baseline_store
+    acd = dd[KEY + "___acd"]
+    nt, ne, d = dd["X"].nnz, dd["A"].nnz, 128
+    plan = _ops.message_plan(acd, nt, nt, ne)
+    fp = _ops.fused_plan(plan, on_demand=True)
+    assert fp is not None and fp.n_chunks > 0, "the store-collated batch must come with its fused chunks"
+    gen = torch.Generator().manual_seed(3)
+    xh = torch.randn(nt, d, generator=gen).to(dtype)
+    wh = (torch.randn(d, d, generator=gen) / d ** 0.5).to(dtype)
+    bh = (torch.randn(d, generator=gen) * 0.1).to(dtype)
+    scale_h = (torch.rand(d, generator=gen) + 0.5).float()
+    shift_h = (torch.randn(d, generator=gen) * 0.3).float()
+    table_h = torch.randn(16, d, generator=gen).to(dtype)
+    x, wl, b, scale, shift, table = (t.to(dev) for t in (xh, wh, bh, scale_h, shift_h, table_h))
+    ea = _ops.flat_index(dd["A"].values)
+    look_fwd = plan.lookup(ea)[0]
+    acd_h = acd.cpu()
+    ea_h = dd["A"].values.cpu().long()
+    read = torch.unique(acd_h[1])
+    timer = _ops.LaunchTimer()
+    res = {}
+    with timer:
+        for aggr in ("sum", "mean"):
+            res[aggr] = _ops.fused_forward(x, wl, b, scale, shift, "silu", table, look_fwd, plan, fp, aggr, True, True)
+    torch.cuda.synchronize()
+    assert any(k.startswith("seg_fused[") for k in timer.summary())
+    h_dev = res["sum"][1].cpu()
+    assert torch.equal(res["mean"][1].cpu()[read], h_dev[read])
+    # ---- H against the f64 evaluation, in slabs of rows
+    ulp_near_bad, worst, n_checked = 0, 0, 0
+    w64, b64, s64, t64 = wh.double(), bh.double(), scale_h.double(), shift_h.double()
+    silu = lambda z: z / (1.0 + torch.exp(-z))
+    for lo in range(0, read.numel(), 1 << 17):
+        rows = read[lo:lo + (1 << 17)]
+        pre = xh[rows].double() @ w64.t() + b64
+        near, other = _neighbours(pre, dtype)
+        got = _ordered(h_dev[rows])
+        dist = []
+        for cand in (near, other):
+            want = silu(cand.double() * s64 + t64).to(dtype)
+            dist.append((got - _ordered(want)).abs())
+        ulp_near_bad += int((dist[0] > 1).sum())
+        worst = max(worst, int(torch.minimum(dist[0], dist[1]).max()))
+        n_checked += rows.numel() * d
+    frac_bad = ulp_near_bad / n_checked
+    print(f"fused forward {dtype}: H over {n_checked} elements: {frac_bad:.2e} beyond 1 ulp of the nearest-rounding evaluation, "
+          f"worst distance to an admissible evaluation {worst} ulp")
+    assert worst <= 1, f"H: an element {worst} storage-ulps from both admissible f64 evaluations"
+    assert frac_bad <= 1e-3, f"H: {frac_bad:.2e} of the elements beyond 1 ulp of the f64 evaluation"
+    # ---- out against the ATen sequence over the device's H (rows no message reads are never stored: zero them for the host gather)
+    h32 = torch.zeros(nt, d)
+    h32[read] = h_dev[read].float()
+    b32 = table_h.float()[ea_h]
+    for aggr in ("sum", "mean"):
+        agg = P.spspmm_values_chunked(h32, b32, acd_h[0], acd_h[1], acd_h[2], nt, aggr)
+        want = (xh.float() + agg).to(dtype)
+        got = res[aggr][0].cpu()
+        if not torch.equal(got, want):
+            bad = got != want
+            raise AssertionError(f"{aggr}: {int(bad.sum())} of {bad.numel()} output elements differ from the host oracle over the device's H")

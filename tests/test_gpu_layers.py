@@ -151,7 +151,8 @@ def test_ngnn_model_matches_reference_model(dev):
 BF16_TRAJECTORY_RTOL = 0.03
 BF16_DELTA_COSINE = 0.95          # measured 0.968 (ea_encoder.weight, the smallest over the weight matrices)
 # teacher-forced (both sides take every step from the SAME parameters): what bf16 activations cost in ONE step, no amplification
-BF16_STEP_LOSS_RTOL = 0.004      # measured 0.16 %
+BF16_STEP_LOSS_RTOL = {64: 0.004, 128: 0.008}      # measured 0.16 % at hidden 64 and 0.40 % at hidden 128 (its own batch and parameters; the fused
+                                                   # forward is bit-identical to the launches it replaces, tests/test_gpu_fused.py, so the width, not the kernel)
 BF16_STEP_GRAD_COSINE = 0.93      # measured 0.951 for the WORST weight matrix (lin_tupleinit0 at step 0: its gradient is what is left after
                                   # heavy cancellation over the tuples of a root, so 16-bit rounding of the summands shows) ...
 BF16_STEP_GRAD_COSINE_MEDIAN = 0.99   # ... while the typical weight matrix agrees far better
@@ -229,27 +230,33 @@ def test_ngnn_training_trajectory_matches_the_host_port(dev, dtype, optimizer):
         assert worst[0] > BF16_DELTA_COSINE, f"parameter displacement of {worst[1]} deviates from the host port's: cosine {worst[0]:.3f}"
 
 
-def test_ngnn_bf16_steps_from_the_same_parameters_match_the_host_port(dev):
+@pytest.mark.parametrize("hidden", [64, 128])
+def test_ngnn_bf16_steps_from_the_same_parameters_match_the_host_port(dev, hidden):
     """The tight half of the bf16 parity claim (the free-running trajectory 'catches a frozen arena, not a 1 %
     drift').  Six steps, TEACHER-FORCED: before every step the device model takes the host port's current parameters and buffers,
     so both sides differentiate at the same point and rounding noise is not amplified by the optimizer.  Per step: the loss within
     BF16_STEP_LOSS_RTOL of the f32 port's, and the gradient of every weight matrix within cosine BF16_STEP_GRAD_COSINE of the port's
-    (bf16 activations, f32 masters); the BatchNorm running statistics after the step within 1 %."""
+    (bf16 activations, f32 masters); the BatchNorm running statistics after the step within 1 %.
+    The batch is collated by the device store (every plan installed, incl. the fused forward's chunks), so at hidden = 128 the layers'
+    forward IS `seg_fused_fwd_kernel` (asserted through the launch names): the kernel the benchmark reports sits on this test's path."""
     from oracle import aten_port as P
     from pygho_amd import _ops, synth
+    from pygho_amd.collate import DeviceGraphStore
     from pygho_amd.ngnn import SpModel
     key = "X___X___1___A___0"
-    hb = synth.make_batch(48, "zinc", seed=23)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    rng = np.random.default_rng(23)
+    store = DeviceGraphStore([synth.make_graph(rng, "zinc", 3, (key,)) for _ in range(64)], dev)
     torch.manual_seed(4)
-    model = SpModel(1, 3, 64, act_dtype=torch.bfloat16)
-    port = P.NGNNPort(64, 3)
+    model = SpModel(1, 3, hidden, act_dtype=torch.bfloat16)
+    port = P.NGNNPort(hidden, 3)
     port.load_state_dict({P.port_key(k): v.clone() for k, v in model.state_dict().items()}, strict=True)
     model = model.to(dev).train()
     port.train()
-    dd = synth.to_datadict(hb, dev)
-    host = (t(hb.x), t(hb.edge_attr), t(hb.tupleid), t(hb.tuplefeat), t(hb.acd[key]), t(hb.batch), hb.num_graphs)
-    y_host = t(hb.y).unsqueeze(-1)
+    dd = store.collate(np.random.default_rng(5).permutation(64)[:48])
+    host = (dd["x"].cpu(), dd["A"].values.cpu(), dd["X"].indices.cpu(), dd["X"].values.cpu(), dd[key + "___acd"].cpu(), dd["batch"].cpu(),
+            int(dd["num_graphs"]))
+    y_host = dd["y"].cpu().unsqueeze(-1)
+    timer = _ops.LaunchTimer()
     opt_h = torch.optim.AdamW(port.parameters(), lr=1e-3)
     names = {P.port_key(k): k for k in model.state_dict()}
     worst_loss, worst_cos, all_cos = 0.0, (1.0, None), []
@@ -260,7 +267,7 @@ def test_ngnn_bf16_steps_from_the_same_parameters_match_the_host_port(dev):
                 sd[names[pk]].copy_(v.to(dev))
         _ops.invalidate_cast_arenas()
         model.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with timer, torch.autocast("cuda", dtype=torch.bfloat16):
             pred = model(dd)
         loss = torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float())
         loss.backward()
@@ -282,9 +289,12 @@ def test_ngnn_bf16_steps_from_the_same_parameters_match_the_host_port(dev):
                 np.testing.assert_allclose(after[k].numpy() / scale, v.numpy() / scale, rtol=0, atol=1e-2, err_msg=f"{k} step {step}")
         opt_h.step()
     med = float(np.median(all_cos))
-    print(f"bf16 teacher-forced: max relative loss difference {worst_loss:.5f}, smallest gradient cosine {worst_cos[0]:.5f} ({worst_cos[1]}), "
+    torch.cuda.synchronize()
+    fused_ran = any(k.startswith("seg_fused[") for k in timer.summary())
+    assert fused_ran == (hidden == 128 and _ops.FUSED_FWD), sorted(timer.summary())
+    print(f"bf16 teacher-forced (hidden {hidden}, fused forward {'ran' if fused_ran else 'not eligible'}): max relative loss difference {worst_loss:.5f}, smallest gradient cosine {worst_cos[0]:.5f} ({worst_cos[1]}), "
           f"median {med:.5f} over {len(all_cos)} (matrix, step) pairs")
-    assert worst_loss < BF16_STEP_LOSS_RTOL, f"per-step loss (bf16 activations, same parameters): {worst_loss:.5f}"
+    assert worst_loss < BF16_STEP_LOSS_RTOL[hidden], f"per-step loss (bf16 activations, same parameters): {worst_loss:.5f}"
     assert worst_cos[0] > BF16_STEP_GRAD_COSINE, f"gradient of {worst_cos[1]}: cosine {worst_cos[0]:.4f} against the f32 port"
     assert med > BF16_STEP_GRAD_COSINE_MEDIAN, f"median gradient cosine {med:.4f} against the f32 port"
 

@@ -122,6 +122,35 @@ def test_scatter_reduce_golden(dev):
                 np.testing.assert_allclose(N(got), exp, **TOL)
 
 
+def test_prod_aggregation_golden(dev):
+    """aggr = "prod" of torch_scatter_reduce and coalesce (reference utils.py:44-56, SpTensor.py:167-197; VERDICT r5: it raised):
+    forward and autograd gradient against outputs of the reference (prod.npz) -- segments with one exact zero (that element
+    receives the product of the others), with two (all zero), empty segments, an unsorted index, int64 values; 16-bit rows to
+    their rounding."""
+    from pygho_amd.backend import SpTensor
+    from pygho_amd.backend.utils import torch_scatter_reduce
+    g = load_golden("prod.npz")
+    for tag in ("p0", "p1", "p2"):
+        got = torch_scatter_reduce(0, T(g[f"{tag}_src"], dev), T(g[f"{tag}_ind"], dev), int(g[f"{tag}_size"]), "prod")
+        exp = g[f"{tag}_prod"]
+        assert tuple(got.shape) == exp.shape
+        if np.issubdtype(exp.dtype, np.integer):
+            assert np.array_equal(N(got), exp), tag
+        else:
+            np.testing.assert_allclose(N(got), exp, **TOL)
+    src = T(g["p1_src"], dev).requires_grad_(True)
+    out = torch_scatter_reduce(0, src, T(g["p1_ind"], dev), int(g["p1_size"]), "prod")
+    (out * T(g["p1_w"], dev)).sum().backward()
+    np.testing.assert_allclose(N(src.grad), g["p1_grad"], **TOL)
+    assert int((g["p1_grad"] == 0).sum()) > 8               # the planted zeros do exercise the zero rules
+    for dt, tol in ((torch.bfloat16, 2.0 ** -6), (torch.float16, 2.0 ** -9)):
+        got = torch_scatter_reduce(0, T(g["p1_src"], dev).to(dt), T(g["p1_ind"], dev), int(g["p1_size"]), "prod")
+        np.testing.assert_allclose(N(got.float()), g["p1_prod"], rtol=tol, atol=tol)
+    ci, cv = SpTensor.coalesce(T(g["co_ind"], dev), T(g["co_val"], dev), "prod")
+    assert np.array_equal(N(ci), g["co_ind_out"])
+    np.testing.assert_allclose(N(cv), g["co_val_prod"], **TOL)
+
+
 def _sp(dev, ind, val, n, sd=2):
     from pygho_amd import SparseTensor
     shape = [n] * sd + ([] if val is None else list(val.shape[1:]))
@@ -1005,6 +1034,32 @@ def test_cast_arena_sees_updates_that_bypass_version_counters(dev):
         finally:
             _ops.USE_CAST_ARENA = saved
         assert torch.equal(after, want)
+
+
+def test_backward_of_a_graph_recorded_before_a_parameter_update_raises(dev):
+    """the per-forward re-cast wrote through aliases with their own version counters, so `forward, optimizer step, forward,
+    backward of the FIRST graph` silently differentiated the first graph with the NEW 16-bit weights (stock PyTorch raises the
+    in-place-modification error there).  Copies of parameters known to have changed are now rewritten through the views autograd
+    saved: that backward raises; two grad-enabled forwards on UNCHANGED parameters before one backward (siamese use) stay legal."""
+    from pygho_amd import synth
+    from pygho_amd.ngnn import SpModel
+    dd = synth.to_datadict(synth.make_batch(24, "zinc", seed=6), dev)
+    torch.manual_seed(0)
+    model = SpModel(1, 2, 64, act_dtype=torch.bfloat16).to(dev).train()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+
+    def loss():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), model(dd).float())
+    la, lb = loss(), loss()                      # unchanged parameters: the second forward's re-cast must not invalidate the first graph
+    (la + lb).backward()
+    first = loss()
+    opt.zero_grad(set_to_none=True)
+    loss().backward()
+    opt.step()
+    loss()                                       # re-casts the updated parameters
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        first.backward()
 
 
 def _three_dim_pattern(rng, shape, dims, nnz):
