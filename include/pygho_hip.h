@@ -265,6 +265,37 @@ int pygho_seg_scatter_mul_reduce(void* out, const void* addend, const void* lhs,
                                  int64_t lhs_rows, int64_t rhs_rows, int dtype, void* stream);
 
 /*
+ * BOTH gradients of a subgraph layer's aggregation out[a] = sum_{(a,c,d)} H[c] * table[look[d]] in one pass over the forward message
+ * order (csrc/seg_dual.hip; autograd of pygho/backend/Spspmm.py:309-315 inside NGNNConv, pygho/honn/Conv.py:53-58):
+ *   gh[c]  = sum_{(a,c,d)} g[a] * table[look[d]]      (= pygho_seg_gather_mul_reduce over the grouping by c: same order, same bits)
+ *   out[d] = [addend[d] +] sum_{(a,c,d)} g[a] * H[c]  (= pygho_seg_scatter_mul_reduce: same bits)
+ * with g = `lhs` and H = `rhs` staged once per chunk for both sums.  Needs ALIGNED chunks: a chunk holds every message of the c rows
+ * it touches.  Planner over blocks `block_m` whose c rows lie in the pairwise disjoint ascending ranges [row_cut[b], row_cut[b + 1]):
+ *   pygho_seg_scatter_count_aligned -> as pygho_seg_scatter_count (`sufmin`: int32 workspace of n_msg entries, kept for the write
+ *                                      pass); flags[1] also counts blocks with a group of messages (the messages between two cuts
+ *                                      where every earlier c is smaller than every later c) outside the chunk limits; flags[2] =
+ *                                      blocks that have rows but no message (nobody writes their gh rows: the caller pre-fills)
+ *   pygho_seg_scatter_write_aligned -> chunk records + packed words as pygho_seg_scatter_write, and cgap[k] = rows without messages
+ *                                      in front of chunk k's window that it owns | rows behind the window of a block's last chunk << 16
+ *   pygho_seg_dual: `ptr_c` (rhs_rows + 1), `a_byc`, `look_byc` (n_msg each) = the by-c CSR pointers, output rows and table rows of
+ *                   the by-tuple launch it replaces; bf16 / f16 rows of 64..512 bytes, tables of at most 32 rows, sum.
+ * The aligned chunk records also serve pygho_seg_scatter_mul_reduce.
+ */
+int pygho_seg_scatter_count_aligned(int32_t* n_chunks, int32_t* blk_e, int32_t* flags, int32_t* sufmin, const int32_t* a32,
+                                    const int32_t* c32, const int32_t* d32, const int32_t* block_m, const int32_t* row_cut,
+                                    int64_t n_blocks, void* stream);
+int pygho_seg_scatter_write_aligned(int32_t* chunks, uint32_t* words, int32_t* cgap, const int32_t* chunk0, const int32_t* blk_e,
+                                    const int32_t* sufmin, const int32_t* a32, const int32_t* c32, const int32_t* d32,
+                                    const int32_t* block_m, const int32_t* row_cut, int64_t n_blocks, int64_t n_chunks, int64_t n_msg,
+                                    void* stream);
+int pygho_seg_dual_limits(int* max_edges_per_block, int* table_rows);
+int pygho_seg_dual(void* out, void* gh, const void* addend, const void* lhs, const void* rhs, const void* table, int64_t table_rows,
+                   const int32_t* chunks, const uint32_t* words, const int32_t* cgap, const int32_t* chunk0, const int32_t* blk_e,
+                   const int32_t* ptr_c, const int32_t* a_byc, const int32_t* look_byc, int64_t n_blocks, int64_t n_chunks,
+                   int64_t n_msg, int64_t max_edges, int64_t n_out, int64_t d, int64_t lhs_rows, int64_t rhs_rows, int dtype,
+                   void* stream);
+
+/*
  * A subgraph layer's tuple-wise Linear -> BatchNorm -> activation folded into the load path of its aggregation (csrc/seg_fused.hip):
  *   out[a] = [x[a] +] (sum | mean)_{(a,c,d)} H[c] * table[look[m]],     H = act((x . wl^T + bias) * scale + shift)  (rounded like the
  *   materialised tensors: pre-activation, then H, in the storage type)

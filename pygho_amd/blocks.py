@@ -815,8 +815,16 @@ class _TupleBlock(torch.autograd.Function):
             rhs_read = rhs
             if ctx.look is not None:
                 rhs_read, d_g = ctx.look[0], ctx.look[2]
-            gh = seg_gmr(plan.n_lhs, g, rhs_read, p.seg_ptr, a_g, d_g if rhs is not None else None, "sum", scale)
-            if rhs is not None and ctx.needs_input_grad[10]:
+            if (rhs is not None and ctx.needs_input_grad[10] and ctx.look is not None and ctx.affine is None
+                    and dual_eligible(plan, g, h, rhs_read, scale)):
+                # both gradients of the aggregation from ONE pass over the forward message order (csrc/seg_dual.hip): g and H rows are
+                # fetched once for the by-tuple sum gh and the by-edge sum g_rhs -- the bits of the two launches below
+                gh, g_rhs = dual_backward(plan, g, h, rhs_read, d_g, addend=g_chain)
+            else:
+                gh = seg_gmr(plan.n_lhs, g, rhs_read, p.seg_ptr, a_g, d_g if rhs is not None else None, "sum", scale)
+            if g_rhs is not None:
+                pass
+            elif rhs is not None and ctx.needs_input_grad[10]:
                 p, a_g, c_g = plan.by_d()
                 if ctx.affine is not None:
                     g_rhs = seg_gmr(plan.n_rhs, g, pre, p.seg_ptr, a_g, c_g, "sum", scale,

@@ -206,16 +206,40 @@ class DeviceGraphStore:
             if acd.shape[1] == 0 or acd.shape[1] >= (1 << 31):
                 continue
             block_m = self.acd_ptr[k].to(torch.int32)
-            parts = _ops.scatter_plan_parts(acd[0].contiguous(), acd[1].contiguous(), acd[2].contiguous(), block_m)
+            roles = parse_key(k)
+            parts = None
+            if _ops.DUAL_BWD and roles[0][0] == roles[1][0]:
+                # ALIGNED chunks (every message of a chunk's first-operand rows inside the chunk) also serve the fused backward
+                # (csrc/seg_dual.hip); a graph with a group of messages outside the chunk limits leaves the store with the plain chunks
+                # (the planner wants the first-operand rows of all blocks in ONE ascending numbering: store-wide rows here, the
+                # chunk records' window starts made graph-local again below)
+                rows1 = (self.tup_ptr if roles[1][0] == "X" else self.edge_ptr)
+                if int(rows1[-1]) < (1 << 31):
+                    msg_len = self.acd_ptr[k][1:] - self.acd_ptr[k][:-1]
+                    cut1 = rows1.to(torch.int32)
+                    c_store = (acd[1] + torch.repeat_interleave(cut1[:-1], msg_len)).contiguous()
+                    parts = _ops.scatter_plan_parts_aligned(acd[0].contiguous(), c_store, acd[2].contiguous(), block_m, cut1)
+                    if parts is not None:
+                        g_of = torch.repeat_interleave(torch.arange(self.num_graphs, device=d), parts[0].long())     # graph of every chunk
+                        parts[3][:, 2] -= cut1[g_of]
+            aligned = parts is not None
+            if parts is None:
+                parts = _ops.scatter_plan_parts(acd[0].contiguous(), acd[1].contiguous(), acd[2].contiguous(), block_m)
             if parts is None:
                 continue
-            n_chunks, chunk0, blk_e, chunks, words, max_edges, _ = parts
-            roles = parse_key(k)
+            n_chunks, chunk0, blk_e, chunks, words, max_edges = parts[:6]
             rows3 = (self.tup_ptr if roles[3][0] == "X" else self.edge_ptr)
             n_rows3 = (rows3[1:] - rows3[:-1]).to(torch.int32)
             covers = bool(((blk_e[:, 0] == 0) & (blk_e[:, 1] == n_rows3)).all())        # every graph's triples reach all of its rows
             self.scatter_parts[k] = {"chunk_ptr": chunk0.to(torch.int64), "chunks_t": chunks.t().contiguous(), "words": words.reshape(1, -1),
                                      "blk_e": blk_e.t().contiguous(), "max_edges": max_edges, "covers": covers}
+            if aligned:
+                # rows without messages are written by the chunk that owns them; a graph with rows but NO message has no chunk: a batch
+                # that selects one pre-fills the by-tuple gradient
+                has_rows = (rows1[1:] - rows1[:-1]) > 0
+                has_msgs = (self.acd_ptr[k][1:] - self.acd_ptr[k][:-1]) > 0
+                self.scatter_parts[k]["cgap"] = parts[7].reshape(1, -1)
+                self.scatter_parts[k]["h_cok"] = (has_msgs | ~has_rows).cpu().numpy()
         # the fused block forward's chunk plans (csrc/seg_fused.hip: Linear -> BatchNorm -> act inside the aggregation), ONCE for the whole
         # store: the device planner over the store's rows with one block per graph.  A batch's chunks are its graphs' chunks with the
         # message / row offsets added; the ownership masks travel unchanged (a chunk's window never leaves its graph)
@@ -429,7 +453,8 @@ class DeviceGraphStore:
                 # of inside the store, row offsets of the two operands' graphs; the packed field and the words travel unchanged
                 sc_arrs = (B.add(sc["chunks_t"], ("sc", k), incs=B.rows_of(lay.dev[("inc", "sc", k)]), i32=True, transposed=True),
                            B.add(sc["words"], fm, i32=True).reshape(-1),
-                           B.add(sc["blk_e"], "graph", incs=B.rows_of(lay.dev[("inc", "blk", k)]), i32=True, transposed=True))
+                           B.add(sc["blk_e"], "graph", incs=B.rows_of(lay.dev[("inc", "blk", k)]), i32=True, transposed=True),
+                           B.add(sc["cgap"], ("sc", k), i32=True).reshape(-1) if "cgap" in sc else None)
 
             fu = self.fused_parts.get(k)
             fu_arrs = None
@@ -445,8 +470,9 @@ class DeviceGraphStore:
                     plan._lookup = (ea, (arrs["look"][0], arrs["look"][1]))     # A's values as a lookup of the edge feature
                 _ops.install_message_plan(acd, plan)
                 if sc_arrs is not None:
-                    ch, words, blk_e = sc_arrs
-                    _ops.install_scatter_plan(plan, lay.dev[("optr32", ("sc", k))], blk_e, ch, words, sc["max_edges"], sc["covers"])
+                    ch, words, blk_e, cgap = sc_arrs
+                    _ops.install_scatter_plan(plan, lay.dev[("optr32", ("sc", k))], blk_e, ch, words, sc["max_edges"], sc["covers"], cgap,
+                                              bool(sc["h_cok"][lay.ids_h].all()) if cgap is not None else False)
                 if fu_arrs is not None:
                     _ops.install_fused_plan(plan, *fu_arrs)
             finish.append(install)

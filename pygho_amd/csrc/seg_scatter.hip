@@ -119,6 +119,125 @@ __global__ __launch_bounds__(kBlock) void seg_scatter_chunks_kernel(int32_t* __r
   close(m1, true);
 }
 
+// ---- ALIGNED chunks (the fused backward, csrc/seg_dual.hip) ---------------------------------------------------------------------------
+// The by-tuple gradient gA[c] = sum_{(a,c,d)} g[a] * B[d] can ride on the same pass when a chunk holds ALL messages of the c rows it
+// touches: then the chunk's window rows are complete sums and go out once, in by-c order, with no accumulation across chunks.  A cut
+// in front of message m is CLOSED when every earlier c of the block is smaller than every later one (`sufmin`, written by the
+// first pass); messages between two closed cuts form a group (in a subgraph layer: one root's rows), and a chunk is a run of whole
+// groups within the same limits as above.  A group that alone exceeds them makes the plan unaligned (flags[2]); the plain chunks
+// still serve the by-edge scatter.  Chunk records are the same; `cgap` = rows without messages in front of a chunk's window that it
+// owns (| rows behind the window of a block's last chunk << 16): every c row of the blocks' ranges `row_cut` belongs to one chunk.
+__global__ __launch_bounds__(kBlock) void seg_scatter_sufmin_kernel(int32_t* __restrict__ sufmin, const int32_t* __restrict__ c32,
+                                                                    const int32_t* __restrict__ block_m, int n_blocks) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= n_blocks) return;
+  int run = 0x7fffffff;
+  for (int m = block_m[b + 1] - 1; m >= block_m[b]; --m) {
+    run = min(run, c32[m]);
+    sufmin[m] = run;
+  }
+}
+
+struct ScGroup { int n, a_lo, a_hi, c_min, c_max; };
+
+// the aligned walk of one block, identical in both passes: `emit(m_lo, n, a_lo, a_hi, c_min, c_max, last)` per closed chunk; returns the
+// chunk count; `bad` = a group outside the limits, a phase above 3 (checked once a group's place in its chunk is known), rows outside
+// the block's c range, a not sorted
+template <typename Emit>
+__device__ __forceinline__ int sc_aligned_block(const int32_t* __restrict__ a32, const int32_t* __restrict__ c32, const int32_t* __restrict__ d32,
+                                                const int32_t* __restrict__ sufmin, int m0, int m1, int r0, int r1, bool check, int& bad, Emit emit) {
+  int chunks = 0, cmax_run = -1, prev_a = -1;
+  int ch_m = m0, ch_n = 0, ch_a_lo = 0, ch_a_hi = 0, ch_cmin = 0, ch_cmax = 0;     // the open chunk
+  int gs = m0;
+  ScGroup g{0, 0, 0, 0x7fffffff, -1};
+  auto flush = [&](int m_end) {
+    if (g.n == 0) return;
+    bad |= g.n > kScMsgs || g.a_hi - g.a_lo >= kScRows || g.c_max - g.c_min >= kScRows || g.c_min < r0 || g.c_max >= r1;
+    const bool fits = ch_n > 0 && ch_n + g.n <= kScMsgs && g.a_hi - ch_a_lo < kScRows && max(ch_cmax, g.c_max) - min(ch_cmin, g.c_min) < kScRows;
+    if (!fits) {
+      if (ch_n > 0) { emit(ch_m, ch_n, ch_a_lo, ch_a_hi, ch_cmin, ch_cmax, false); ++chunks; }
+      ch_m = gs; ch_n = 0; ch_a_lo = g.a_lo; ch_cmin = g.c_min; ch_cmax = g.c_max;
+    }
+    if (check) {                                         // phases of the group's messages at their final place in the chunk
+      for (int m = gs; m < m_end; ++m) bad |= sc_phase(d32, m, (m - ch_m) & (kScMpt - 1)) > kScMaxPhase;
+    }
+    ch_n += g.n;
+    ch_a_hi = g.a_hi;
+    ch_cmin = min(ch_cmin, g.c_min);
+    ch_cmax = max(ch_cmax, g.c_max);
+    g = ScGroup{0, 0, 0, 0x7fffffff, -1};
+    gs = m_end;
+  };
+  for (int m = m0; m < m1; ++m) {
+    const int a = a32[m], c = c32[m];
+    if (m > m0 && cmax_run < sufmin[m]) flush(m);
+    bad |= a < prev_a;
+    prev_a = a;
+    if (g.n == 0) g.a_lo = a;
+    g.a_hi = a;
+    g.c_min = min(g.c_min, c);
+    g.c_max = max(g.c_max, c);
+    ++g.n;
+    cmax_run = max(cmax_run, c);
+  }
+  flush(m1);
+  if (ch_n > 0) { emit(ch_m, ch_n, ch_a_lo, ch_a_hi, ch_cmin, ch_cmax, true); ++chunks; }
+  return chunks;
+}
+
+__global__ __launch_bounds__(kBlock) void seg_scatter_count_aligned_kernel(int32_t* __restrict__ n_chunks, int32_t* __restrict__ blk_e,
+                                                                           int32_t* __restrict__ flags, const int32_t* __restrict__ a32,
+                                                                           const int32_t* __restrict__ c32, const int32_t* __restrict__ d32,
+                                                                           const int32_t* __restrict__ sufmin, const int32_t* __restrict__ block_m,
+                                                                           const int32_t* __restrict__ row_cut, int n_blocks) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= n_blocks) return;
+  const int m0 = block_m[b], m1 = block_m[b + 1];
+  int e0 = 0x7fffffff, e1 = -1, bad = 0;
+  for (int m = m0; m < m1; ++m) {
+    const int dd = d32[m];
+    e0 = min(e0, dd);
+    e1 = max(e1, dd);
+  }
+  const int r1 = row_cut[b + 1];
+  int next_row = row_cut[b];
+  n_chunks[b] = sc_aligned_block(a32, c32, d32, sufmin, m0, m1, row_cut[b], r1, true, bad, [&](int, int, int, int, int c_min, int c_max, bool last) {
+    const int before = c_min - next_row, after = last ? r1 - (c_max + 1) : 0;        // what `cgap` has to hold (16 bits each)
+    bad |= before < 0 || before > 0xffff || after > 0xffff;
+    next_row = c_max + 1;
+  });
+  const int ne = e1 >= e0 ? e1 - e0 + 1 : 0;
+  bad |= ne > kScMaxEdges || r1 < row_cut[b];
+  if (m0 == m1 && r1 > row_cut[b]) atomicAdd(&flags[2], 1);      // rows of a block without messages: nobody writes them
+  blk_e[2 * b] = ne > 0 ? e0 : 0;
+  blk_e[2 * b + 1] = ne;
+  atomicMax(&flags[0], ne);
+  if (bad) atomicAdd(&flags[1], 1);
+}
+
+__global__ __launch_bounds__(kBlock) void seg_scatter_chunks_aligned_kernel(int32_t* __restrict__ chunks, int32_t* __restrict__ cgap,
+                                                                            const int32_t* __restrict__ chunk0, const int32_t* __restrict__ a32,
+                                                                            const int32_t* __restrict__ c32, const int32_t* __restrict__ d32,
+                                                                            const int32_t* __restrict__ sufmin, const int32_t* __restrict__ block_m,
+                                                                            const int32_t* __restrict__ row_cut, int n_blocks) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= n_blocks) return;
+  const int m0 = block_m[b], m1 = block_m[b + 1];
+  int bad = 0, k = chunk0[b], next_row = row_cut[b];
+  const int r1 = row_cut[b + 1];
+  sc_aligned_block(a32, c32, d32, sufmin, m0, m1, row_cut[b], r1, false, bad, [&](int m_lo, int n, int a_lo, int a_hi, int c_min, int c_max, bool last) {
+    int32_t* rec = chunks + 4 * (int64_t)k;
+    rec[0] = m_lo;
+    rec[1] = a_lo;
+    rec[2] = c_min;
+    rec[3] = n | ((a_hi - a_lo + 1) << 8) | ((c_max - c_min + 1) << 16) | ((m_lo == m0 ? 1 : 0) << 24) | ((last ? 1 : 0) << 25);
+    const int before = c_min - next_row, after = last ? r1 - (c_max + 1) : 0;
+    cgap[k] = min(before, 0xffff) | (min(after, 0xffff) << 16);
+    next_row = c_max + 1;
+    ++k;
+  });
+}
+
 // pass 2b: one packed word per message, one THREAD per message (a offset | c offset << 5 | edge offset << 10 | phase << 18): its
 // chunk by binary search over the chunk records' first messages, its block's first edge from the chunk's block (binary search over
 // chunk0).  (The one-thread-per-block form of this pass took 10.5 ms at 8192 graphs: 32 workgroups walking 430 messages each with a
@@ -450,6 +569,36 @@ extern "C" int pygho_seg_scatter_write(int32_t* chunks, uint32_t* words, const i
   hipLaunchKernelGGL(seg_scatter_words_kernel, dim3((unsigned)ceil_div(n_msg, kBlock)), dim3(kBlock), 0, st, words, (const int4*)chunks,
                      chunk0, blk_e, a32, c32, d32, (int)n_chunks, (int)n_blocks, n_msg);
   return check_launch("seg_scatter_write");
+}
+
+extern "C" int pygho_seg_scatter_count_aligned(int32_t* n_chunks, int32_t* blk_e, int32_t* flags, int32_t* sufmin, const int32_t* a32,
+                                               const int32_t* c32, const int32_t* d32, const int32_t* block_m, const int32_t* row_cut,
+                                               int64_t n_blocks, void* stream) {
+  if (n_blocks < 0) { set_error("seg_scatter_count_aligned: bad size"); return PYGHO_ERR_INVALID; }
+  if (n_blocks == 0) return PYGHO_OK;
+  if (!n_chunks || !blk_e || !flags || !sufmin || !a32 || !c32 || !d32 || !block_m || !row_cut) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)ceil_div(n_blocks, kBlock));
+  hipLaunchKernelGGL(seg_scatter_sufmin_kernel, grid, dim3(kBlock), 0, st, sufmin, c32, block_m, (int)n_blocks);
+  hipLaunchKernelGGL(seg_scatter_count_aligned_kernel, grid, dim3(kBlock), 0, st, n_chunks, blk_e, flags, a32, c32, d32, sufmin, block_m,
+                     row_cut, (int)n_blocks);
+  return check_launch("seg_scatter_count_aligned");
+}
+
+extern "C" int pygho_seg_scatter_write_aligned(int32_t* chunks, uint32_t* words, int32_t* cgap, const int32_t* chunk0, const int32_t* blk_e,
+                                               const int32_t* sufmin, const int32_t* a32, const int32_t* c32, const int32_t* d32,
+                                               const int32_t* block_m, const int32_t* row_cut, int64_t n_blocks, int64_t n_chunks,
+                                               int64_t n_msg, void* stream) {
+  if (n_blocks < 0 || n_chunks < 0 || n_msg < 0 || n_msg >= ((int64_t)1 << 31)) { set_error("seg_scatter_write_aligned: bad size"); return PYGHO_ERR_INVALID; }
+  if (n_blocks == 0 || n_chunks == 0 || n_msg == 0) return PYGHO_OK;
+  if (!chunks || !words || !cgap || !chunk0 || !blk_e || !sufmin || !a32 || !c32 || !d32 || !block_m || !row_cut) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (((uintptr_t)chunks % 16) != 0) { set_error("seg_scatter_write_aligned: the chunk records must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(seg_scatter_chunks_aligned_kernel, dim3((unsigned)ceil_div(n_blocks, kBlock)), dim3(kBlock), 0, st, chunks, cgap, chunk0,
+                     a32, c32, d32, sufmin, block_m, row_cut, (int)n_blocks);
+  hipLaunchKernelGGL(seg_scatter_words_kernel, dim3((unsigned)ceil_div(n_msg, kBlock)), dim3(kBlock), 0, st, words, (const int4*)chunks,
+                     chunk0, blk_e, a32, c32, d32, (int)n_chunks, (int)n_blocks, n_msg);
+  return check_launch("seg_scatter_write_aligned");
 }
 
 extern "C" int pygho_seg_scatter_mul_reduce(void* out, const void* addend, const void* lhs, const void* rhs, const int32_t* chunks,

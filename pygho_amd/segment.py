@@ -500,7 +500,41 @@ class ScatterPlan:
     block-diagonal batch -- cut into chunks of at most 64 messages over two windows of at most 32 rows, with one packed word per
     message (`pygho_seg_scatter_count` / `_write`).  Integer work on the device; two host reads per plan (block count; chunk count +
     eligibility), cached with the MessagePlan."""
-    __slots__ = ("n_blocks", "n_chunks", "chunk0", "blk_e", "chunks", "words", "max_edges", "covers")
+    __slots__ = ("n_blocks", "n_chunks", "chunk0", "blk_e", "chunks", "words", "max_edges", "covers", "cgap", "covers_c")
+
+
+DUAL_BWD = os.environ.get("PYGHO_DUAL_BWD", "1") != "0"         # A/B switch: both gradients of a layer's aggregation in one pass (csrc/seg_dual.hip)
+
+
+def scatter_plan_parts_aligned(a32: Tensor, c32: Tensor, d32: Tensor, block_m: Tensor, row_cut: Tensor, n_rhs: Optional[int] = None):
+    """the ALIGNED planner (csrc/seg_scatter.hip, for csrc/seg_dual.hip): chunks that hold every message of the c rows they touch, over
+    blocks whose c rows lie in [row_cut[b], row_cut[b + 1]).  Returns what `scatter_plan_parts` returns + (cgap (total), the number of
+    blocks that have rows but no message), or None when a group of messages is outside the chunk limits -- ONE host read"""
+    dev = d32.device
+    nb = block_m.numel() - 1
+    n_chunks = torch.empty(nb, dtype=_I32, device=dev)
+    blk_e = torch.empty((nb, 2), dtype=_I32, device=dev)
+    flags = torch.zeros(3, dtype=_I32, device=dev)
+    sufmin = torch.empty(max(d32.numel(), 1), dtype=_I32, device=dev)
+    row_cut = row_cut.contiguous()
+    check(lib().pygho_seg_scatter_count_aligned(ptr(n_chunks), ptr(blk_e), ptr(flags), ptr(sufmin), ptr(a32), ptr(c32), ptr(d32), ptr(block_m),
+                                                ptr(row_cut), nb, stream_ptr(dev)), "seg_scatter_count_aligned")
+    chunk0 = torch.zeros(nb + 1, dtype=_I32, device=dev)
+    torch.cumsum(n_chunks, 0, out=chunk0[1:])
+    covers = torch.ones((), dtype=torch.bool, device=dev)
+    if n_rhs is not None and nb > 0:
+        e0, ne = blk_e[:, 0], blk_e[:, 1]
+        covers = (e0[0] == 0) & (e0[-1] + ne[-1] == n_rhs) & (e0[1:] == e0[:-1] + ne[:-1]).all()
+    max_edges, bad, uncovered, total, covers = _fetch(torch.stack([flags[0], flags[1], flags[2], chunk0[-1], covers.to(_I32)]))
+    if bad or max_edges > 255 or total == 0:
+        return None
+    chunks = torch.empty((int(total), 4), dtype=_I32, device=dev)
+    cgap = torch.empty(int(total), dtype=_I32, device=dev)
+    words = torch.empty(d32.numel(), dtype=_I32, device=dev)
+    check(lib().pygho_seg_scatter_write_aligned(ptr(chunks), ptr(words), ptr(cgap), ptr(chunk0), ptr(blk_e), ptr(sufmin), ptr(a32), ptr(c32),
+                                                ptr(d32), ptr(block_m), ptr(row_cut), nb, int(total), d32.numel(), stream_ptr(dev)),
+          "seg_scatter_write_aligned")
+    return n_chunks, chunk0, blk_e, chunks, words, int(max_edges), bool(covers), cgap, int(uncovered)
 
 
 def scatter_plan_parts(a32: Tensor, c32: Tensor, d32: Tensor, block_m: Tensor, n_rhs: Optional[int] = None):
@@ -544,25 +578,47 @@ def block_cuts(d32: Tensor) -> Tensor:
     return block_m[:n_blocks + 1]
 
 
+def _block_row_cuts(plan: "MessagePlan", block_m: Tensor) -> Tensor:
+    """c-row ranges of the blocks for the aligned planner: block b owns [min c of block b, min c of block b + 1) (the first block from
+    row 0, the last to n_lhs).  Whether the blocks' c ranges really are disjoint and ascending is the planner's check."""
+    dev = block_m.device
+    nb = block_m.numel() - 1
+    lens = (block_m[1:] - block_m[:-1]).long()
+    blk = torch.repeat_interleave(torch.arange(nb, device=dev), lens)
+    cmin = torch.full((nb,), plan.n_lhs, dtype=_I32, device=dev).scatter_reduce_(0, blk, plan.c32, "amin", include_self=True)
+    cut = torch.empty(nb + 1, dtype=_I32, device=dev)
+    cut[:nb] = cmin
+    cut[0] = 0
+    cut[nb] = plan.n_lhs
+    return cut
+
+
 def _scatter_plan_build(plan: "MessagePlan") -> Optional[ScatterPlan]:
     block_m = block_cuts(plan.d32)                                                        # (host read 1: the number of blocks)
-    parts = scatter_plan_parts(plan.a32, plan.c32, plan.d32, block_m, plan.n_rhs)         # (host read 2: chunk total + verdicts)
+    parts = None
+    if DUAL_BWD and plan.n_lhs == plan.n_out and block_m.numel() > 1:
+        # chunks that also serve the fused backward (every message of a chunk's c rows inside the chunk); the plain chunks otherwise
+        parts = scatter_plan_parts_aligned(plan.a32, plan.c32, plan.d32, block_m, _block_row_cuts(plan, block_m), plan.n_rhs)
+    if parts is None:
+        parts = scatter_plan_parts(plan.a32, plan.c32, plan.d32, block_m, plan.n_rhs)     # (host read 2: chunk total + verdicts)
     if parts is None:
         return None
-    _, chunk0, blk_e, chunks, words, max_edges, covers = parts
+    _, chunk0, blk_e, chunks, words, max_edges, covers = parts[:7]
     sp = ScatterPlan()
     sp.n_blocks, sp.n_chunks, sp.chunk0, sp.blk_e, sp.max_edges = block_m.numel() - 1, chunks.shape[0], chunk0, blk_e, max_edges
     sp.chunks, sp.words, sp.covers = chunks, words, covers
+    sp.cgap, sp.covers_c = (parts[7], parts[8] == 0) if len(parts) > 7 else (None, False)
     return sp
 
 
 def install_scatter_plan(plan: "MessagePlan", chunk0: Tensor, blk_e: Tensor, chunks: Tensor, words: Tensor, max_edges: int,
-                         covers: bool) -> None:
+                         covers: bool, cgap: Optional[Tensor] = None, covers_c: bool = False) -> None:
     """a ScatterPlan that already exists (`collate.DeviceGraphStore`: the chunks of a block-diagonal batch are its graphs' precomputed
-    chunks with the message / row offsets added): no planner launch, no host read.  The caller guarantees the planner's contract."""
+    chunks with the message / row offsets added): no planner launch, no host read.  The caller guarantees the planner's contract.
+    `cgap`: the chunks are ALIGNED (they also serve the fused backward); `covers_c`: every first-operand row belongs to a chunk."""
     sp = ScatterPlan()
     sp.n_blocks, sp.n_chunks, sp.chunk0, sp.blk_e, sp.max_edges, sp.covers = chunk0.numel() - 1, chunks.shape[0], chunk0, blk_e, max_edges, covers
-    sp.chunks, sp.words = chunks, words
+    sp.chunks, sp.words, sp.cgap, sp.covers_c = chunks, words, cgap, covers_c
     plan._scatter = sp if sp.n_chunks > 0 else False
 
 
@@ -726,6 +782,50 @@ def by_edge_product(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], scale: 
         timer.records.append((f"seg_gmr[{str(g.dtype).split('.')[-1]},sum,both{',res' if addend is not None else ''},scatter]",
                               nbytes, e0, e1))
     return out
+
+
+def dual_eligible(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], table: Optional[Tensor], scale: Optional[Tensor]) -> bool:
+    """both gradients of the aggregation in one pass (csrc/seg_dual.hip): an aligned scatter plan, 16-bit rows, a lookup table of at most
+    32 rows as the second operand, sum"""
+    if not DUAL_BWD or table is None or h is None or scale is not None or not _scatter_eligible(plan, g, h, scale, None):
+        return False
+    sp = scatter_plan(plan, on_demand=True)
+    if sp is None or sp.cgap is None or sp.max_edges > 96 or table.dim() != 2 or table.shape[0] > 32 or table.dtype != g.dtype:
+        return False
+    if plan.n_lhs != h.shape[0] or table.shape[1] != g.shape[1] or h.shape[0] * g.shape[1] * g.element_size() >= (1 << 31):
+        return False
+    rb = g.shape[1] * g.element_size()
+    per_wave = (sp.max_edges + 7) // 8 * 8 * 144 + 65 * 80 + 512 + 160 + (table.shape[0] + 1) * 80
+    return (rb // 64) * per_wave <= 160 * 1024
+
+
+def dual_backward(plan: "MessagePlan", g: Tensor, h: Tensor, table: Tensor, look_byc: Tensor, addend: Optional[Tensor] = None):
+    """(gh, g_rhs) of out[a] = sum_{(a,c,d)} h[c] * table[look[d]]:  gh[c] = sum g[a] * table[look]  (n_lhs rows; the bits of
+    `seg_gmr` over the by-c plan) and g_rhs[d] = [addend[d] +] sum g[a] * h[c]  (n_rhs rows; the bits of `by_edge_product`), g and h
+    rows fetched once for both (autograd of pygho/backend/Spspmm.py:309-315)."""
+    sp = scatter_plan(plan, on_demand=True)
+    dev = require_device(g, h, table, look_byc, addend)
+    g, h, table = g.contiguous(), h.contiguous(), table.contiguous()
+    d = g.shape[1]
+    pc, a_byc, _ = plan.by_c()
+    if addend is not None:
+        addend = addend.contiguous()
+        assert addend.shape == (plan.n_rhs, d) and addend.dtype == g.dtype
+    if sp.covers:
+        out = torch.empty((plan.n_rhs, d), dtype=g.dtype, device=dev)
+    else:
+        out = torch.zeros((plan.n_rhs, d), dtype=g.dtype, device=dev) if addend is None else addend.clone()
+    gh = (torch.empty if sp.covers_c else torch.zeros)((plan.n_lhs, d), dtype=g.dtype, device=dev)
+    es = g.element_size()
+    # has-to-move bytes: g, h and gh rows once, the edge rows once (twice with the chained gradient), per message the packed word + two
+    # by-c indices, the by-c CSR pointers, the chunk records
+    nbytes = es * d * (g.shape[0] + h.shape[0] + plan.n_lhs + plan.n_rhs * (2 if addend is not None else 1)) + 12 * plan.m + 4 * (plan.n_lhs + 1) + 20 * sp.n_chunks
+    name = f"seg_dual[{str(g.dtype).split('.')[-1]},sum{',res' if addend is not None else ''}]"
+    _timed(name, nbytes, dev, lambda: check(lib().pygho_seg_dual(
+        ptr(out), ptr(gh), ptr(addend), ptr(g), ptr(h), ptr(table), table.shape[0], ptr(sp.chunks), ptr(sp.words), ptr(sp.cgap), ptr(sp.chunk0),
+        ptr(sp.blk_e), ptr(pc.seg_ptr), ptr(a_byc), ptr(look_byc), sp.n_blocks, sp.n_chunks, plan.m, sp.max_edges, plan.n_rhs, d, g.shape[0],
+        h.shape[0], dtype_code(g), stream_ptr(dev)), "seg_dual"))
+    return gh, out
 
 
 class _MessageReduce(torch.autograd.Function):
