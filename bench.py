@@ -171,7 +171,8 @@ def cpu_baseline(args, seed):
             "spspmm_fwd_msg_edges_per_sec": hb128.num_messages(KEY) / float(np.median(ts))}
 
 
-KERNEL_SOURCES = {"seg_gmr_fast_kernel": ("common.h", "seg_reduce.hip"), "seg_fused_fwd_kernel": ("common.h", "seg_fused.hip")}
+KERNEL_SOURCES = {"seg_gmr_fast_kernel": ("common.h", "seg_reduce.hip"), "seg_fused_fwd_kernel": ("common.h", "seg_fused.hip"),
+                  "seg_dual_kernel": ("common.h", "seg_dual.hip")}
 
 
 def kernel_source_hash(kernel: str = "seg_gmr_fast_kernel") -> str:
@@ -515,7 +516,10 @@ def main():
         # the other one is reported beside it under `roofline.other`)
         dom = f"seg_gmr[{'bfloat16' if act_dtype is not None else 'float32'},sum,both"
         fused = [v for k, v in summ.items() if k.startswith("seg_fused[")]
-        every = [v for k, v in summ.items() if k.startswith(dom)] + fused
+        # (round 6: with 16-bit activations BOTH gradients of a layer's aggregation come from one launch of seg_dual_kernel,
+        # csrc/seg_dual.hip -- g and H rows fetched once for the by-tuple and the by-edge sum; bytes = what has to move)
+        dual = [v for k, v in summ.items() if k.startswith("seg_dual[")]
+        every = [v for k, v in summ.items() if k.startswith(dom)] + fused + dual
         parts = [v for k, v in summ.items() if k.startswith(dom) and ",window" not in k and ",scatter" not in k]
 
         def agg(vs):
@@ -525,6 +529,9 @@ def main():
         cands = {f"seg_gmr_fast_kernel<{tname},SUM,BOTH>": parts}
         if fused:
             cands[f"seg_fused_fwd_kernel<{tname},SILU,SUM>"] = fused
+        if dual:
+            cands[f"seg_dual_kernel<{tname},SUM>"] = dual
+        cands = {k: v for k, v in cands.items() if v}
         dom_name = max(cands, key=lambda k: sum(v[0] * v[1] for v in cands[k]))
         launches, ms, nbytes = agg(cands[dom_name])
         achieved = nbytes / (ms * 1e-3) / 1e9

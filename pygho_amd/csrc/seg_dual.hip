@@ -34,8 +34,10 @@ constexpr int kDuTabRows = 32;
 
 typedef uint32_t du_u4_t __attribute__((ext_vector_type(4)));
 
-__host__ __device__ constexpr uint32_t du_wave_lds(int e_cap, int table_rows) {
-  return (uint32_t)e_cap * kDuAccPitch + (2u * kDuRows + 1u) * kDuStagePitch + 2u * kDuMsgs * 4u + 40u * 4u + (uint32_t)(table_rows + 1) * kDuStagePitch;
+// the table slice is staged as f32 (no conversion per message) when two workgroups per CU still fit, in the storage type otherwise
+__host__ __device__ constexpr uint32_t du_wave_lds(int e_cap, int table_rows, bool tab_f32) {
+  return (uint32_t)e_cap * kDuAccPitch + (2u * kDuRows + 1u) * kDuStagePitch + 2u * kDuMsgs * 4u + 40u * 4u +
+         (uint32_t)(table_rows + 1) * (tab_f32 ? kDuAccPitch : kDuStagePitch);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t du_rsrc(const void* base, uint32_t bytes) {
@@ -53,7 +55,20 @@ template <typename T> __device__ __forceinline__ du_u4_t du_pack(const float (&v
   return du_u4_t{u.x, u.y, u.z, u.w};
 }
 
-template <typename T, bool ADD, int ADL>
+// two channels of a 16-bit word as a float pair: the products and sums below are written on PAIRS so that they issue as packed f32
+// instructions (v_pk_fma_f32: two exact-product fmas per lane and issue slot); the kernel is bound by vector issue (PMC: 440 vector
+// instructions per chunk and wavefront, 60 % of them conversions of 16-bit rows)
+typedef float du_f2_t __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ du_f2_t du_pair(uint32_t w);
+template <> __device__ __forceinline__ du_f2_t du_pair<bf16>(uint32_t w) { return du_f2_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+template <> __device__ __forceinline__ du_f2_t du_pair<f16>(uint32_t w) {
+  union { uint32_t u; _Float16 h[2]; } c;
+  c.u = w;
+  return du_f2_t{(float)c.h[0], (float)c.h[1]};
+}
+__device__ __forceinline__ du_f2_t du_fma(du_f2_t a, du_f2_t b, du_f2_t c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <typename T, bool ADD, int ADL, bool TABF32>
 __global__ __launch_bounds__(512) void seg_dual_kernel(
     T* __restrict__ out, T* __restrict__ gh, const T* __restrict__ addend, const T* __restrict__ lhs, const T* __restrict__ rhs,
     const T* __restrict__ table, int table_rows, const int4* __restrict__ chunks, const uint32_t* __restrict__ words,
@@ -68,7 +83,7 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
   const uint32_t slice_off = (uint32_t)wv * kDuSlice + (uint32_t)p * 16u;
   // per-wavefront LDS: edge accumulators | g rows (+ an all-zero row) | H rows | forward words | by-c words | by-c row pointers | table
   // slice (+ an all-zero row): a message slot past its row's end multiplies the two zero rows instead of being predicated
-  char* s_acc = s_mem + (size_t)wv * du_wave_lds(e_cap, table_rows);
+  char* s_acc = s_mem + (size_t)wv * du_wave_lds(e_cap, table_rows, TABF32);
   char* s_g = s_acc + (size_t)e_cap * kDuAccPitch;
   char* s_x = s_g + (kDuRows + 1) * kDuStagePitch;
   uint32_t* s_w = reinterpret_cast<uint32_t*>(s_x + kDuRows * kDuStagePitch);
@@ -102,10 +117,17 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
 
   for (uint32_t off = (uint32_t)lane * 16u; off < (uint32_t)e_cap * kDuAccPitch; off += kWave * 16u)
     *reinterpret_cast<du_u4_t*>(s_acc + off) = zero4;
-  for (int r = q; r <= table_rows; r += 16) {             // the table slice in the storage type; the row behind the table is zeros
+  constexpr int kTabPitch = TABF32 ? kDuAccPitch : kDuStagePitch;
+  for (int r = q; r <= table_rows; r += 16) {             // the table slice (f32: pairs 0-1 | 2-3 at p * 32); the row behind the table is zeros
     du_u4_t tv = zero4;
     if (r < table_rows) tv = *reinterpret_cast<const du_u4_t*>(reinterpret_cast<const char*>(table) + (size_t)r * row_bytes + slice_off);
-    *reinterpret_cast<du_u4_t*>(s_tab + r * kDuStagePitch + p * 16) = tv;
+    if constexpr (TABF32) {
+      const du_f2_t t0 = du_pair<T>(tv[0]), t1 = du_pair<T>(tv[1]), t2 = du_pair<T>(tv[2]), t3 = du_pair<T>(tv[3]);
+      *reinterpret_cast<float4*>(s_tab + r * kTabPitch + p * 32) = make_float4(t0[0], t0[1], t1[0], t1[1]);
+      *reinterpret_cast<float4*>(s_tab + r * kTabPitch + p * 32 + 16) = make_float4(t2[0], t2[1], t3[0], t3[1]);
+    } else {
+      *reinterpret_cast<du_u4_t*>(s_tab + r * kTabPitch + p * 16) = tv;
+    }
   }
   if (lane < kDuLpm) *reinterpret_cast<du_u4_t*>(s_g + kDuRows * kDuStagePitch + lane * 16) = zero4;
 
@@ -155,17 +177,14 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
   int e0 = 0, ne = 0;
   auto rmw = [&](uint32_t dr, const du_u4_t& gv, const du_u4_t& xv) {
     char* row = s_acc + (dr * kDuAccPitch + (uint32_t)p * 16u);
-    du_u4_t a0 = *reinterpret_cast<du_u4_t*>(row), a1 = *reinterpret_cast<du_u4_t*>(row + kDuSlice);
-    float x[8], y[8];
-    du_unpack<T>(gv, x);
-    du_unpack<T>(xv, y);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      a0[i] = __float_as_uint(__builtin_fmaf(x[i], y[i], __uint_as_float(a0[i])));              // exact product: == mul then add
-      a1[i] = __float_as_uint(__builtin_fmaf(x[4 + i], y[4 + i], __uint_as_float(a1[i])));
-    }
-    *reinterpret_cast<du_u4_t*>(row) = a0;
-    *reinterpret_cast<du_u4_t*>(row + kDuSlice) = a1;
+    float4 a0 = *reinterpret_cast<float4*>(row), a1 = *reinterpret_cast<float4*>(row + kDuSlice);
+    // channels 0-3 in a0, 4-7 in a1 (as csrc/seg_scatter.hip); exact products: fma == mul then add
+    const du_f2_t r0 = du_fma(du_pair<T>(gv[0]), du_pair<T>(xv[0]), du_f2_t{a0.x, a0.y});
+    const du_f2_t r1 = du_fma(du_pair<T>(gv[1]), du_pair<T>(xv[1]), du_f2_t{a0.z, a0.w});
+    const du_f2_t r2 = du_fma(du_pair<T>(gv[2]), du_pair<T>(xv[2]), du_f2_t{a1.x, a1.y});
+    const du_f2_t r3 = du_fma(du_pair<T>(gv[3]), du_pair<T>(xv[3]), du_f2_t{a1.z, a1.w});
+    *reinterpret_cast<float4*>(row) = make_float4(r0[0], r0[1], r1[0], r1[1]);
+    *reinterpret_cast<float4*>(row + kDuSlice) = make_float4(r2[0], r2[1], r3[0], r3[1]);
   };
   auto trips_of = [&](int n) {                           // the by-edge half: csrc/seg_scatter.hip
     constexpr int TMAX = kDuMsgs / kDuMpt;
@@ -212,14 +231,27 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
       cnt[j] = valid ? s_cp[r + 1] - beg[j] : 0;
     }
     const uint32_t kNone = (uint32_t)kDuRows | ((uint32_t)table_rows << 8);
+    // a message's table row piece as four channel pairs
+    auto table_pairs = [&](uint32_t trow, du_f2_t (&t)[4]) {
+      if constexpr (TABF32) {
+        const float4 t0 = *reinterpret_cast<const float4*>(s_tab + trow * kTabPitch + (uint32_t)p * 32u);
+        const float4 t1 = *reinterpret_cast<const float4*>(s_tab + trow * kTabPitch + (uint32_t)p * 32u + 16u);
+        t[0] = du_f2_t{t0.x, t0.y}; t[1] = du_f2_t{t0.z, t0.w}; t[2] = du_f2_t{t1.x, t1.y}; t[3] = du_f2_t{t1.z, t1.w};
+      } else {
+        const du_u4_t tv = *reinterpret_cast<const du_u4_t*>(s_tab + trow * kTabPitch + (uint32_t)p * 16u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = du_pair<T>(tv[i]);
+      }
+    };
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = j * 16 + q;
-      float sum[8];
+      du_f2_t acc[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sum[i] = 0.f;
+      for (int i = 0; i < 4; ++i) acc[i] = du_f2_t{0.f, 0.f};
       uint32_t w[kBurst];
-      du_u4_t gv[kBurst], tv[kBurst];
+      du_u4_t gv[kBurst];
+      du_f2_t tv[kBurst][4];
 #pragma unroll
       for (int k = 0; k < kBurst; ++k) {
         const uint32_t ww = s_bw[min(beg[j] + k, kDuMsgs - 1)];
@@ -228,28 +260,24 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
 #pragma unroll
       for (int k = 0; k < kBurst; ++k) {
         gv[k] = *reinterpret_cast<const du_u4_t*>(s_g + (w[k] & 63u) * kDuStagePitch + (uint32_t)p * 16u);
-        tv[k] = *reinterpret_cast<const du_u4_t*>(s_tab + ((w[k] >> 8) & 63u) * kDuStagePitch + (uint32_t)p * 16u);
+        table_pairs((w[k] >> 8) & 63u, tv[k]);
       }
 #pragma unroll
       for (int k = 0; k < kBurst; ++k) {
-        float x[8], y[8];
-        du_unpack<T>(gv[k], x);
-        du_unpack<T>(tv[k], y);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sum[i] = __builtin_fmaf(x[i], y[i], sum[i]);
+        for (int i = 0; i < 4; ++i) acc[i] = du_fma(du_pair<T>(gv[k][i]), tv[k][i], acc[i]);
       }
       for (int m = beg[j] + kBurst; __builtin_amdgcn_ballot_w64(m < beg[j] + cnt[j]) != 0; ++m) {
         if (m < beg[j] + cnt[j]) {
           const uint32_t ww = s_bw[m];
           const du_u4_t g1 = *reinterpret_cast<const du_u4_t*>(s_g + (ww & 63u) * kDuStagePitch + (uint32_t)p * 16u);
-          const du_u4_t t1 = *reinterpret_cast<const du_u4_t*>(s_tab + ((ww >> 8) & 63u) * kDuStagePitch + (uint32_t)p * 16u);
-          float x[8], y[8];
-          du_unpack<T>(g1, x);
-          du_unpack<T>(t1, y);
+          du_f2_t t1[4];
+          table_pairs((ww >> 8) & 63u, t1);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) sum[i] = __builtin_fmaf(x[i], y[i], sum[i]);
+          for (int i = 0; i < 4; ++i) acc[i] = du_fma(du_pair<T>(g1[i]), t1[i], acc[i]);
         }
       }
+      const float sum[8] = {acc[0][0], acc[0][1], acc[1][0], acc[1][1], acc[2][0], acc[2][1], acc[3][0], acc[3][1]};
       if (r < c_rows) __builtin_amdgcn_raw_buffer_store_b128(du_pack<T>(sum), hres, (int)((uint32_t)(c_lo + r) * row_bytes + slice_off), 0, 0);
     }
     if (gap != 0) {                                      // rows without a message that this chunk owns (rare): zeros
@@ -271,9 +299,13 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
         ne = __builtin_amdgcn_readfirstlane(be.y);
       } while (ne == 0);
     }
+#ifndef PYGHO_DU_KO_TUPLE                               // (measurement switches: tools/dual_step_ab.sh)
     by_tuple(dsc.d.z, (dsc.d.w >> 16) & 0xff, dsc.gap);
+#endif
     if (!((dsc.d.w >> 25) & 1)) {
+#ifndef PYGHO_DU_KO_TRIPS
       trips_of(n);
+#endif
       return;
     }
     du_u4_t ad[ADL];
@@ -284,7 +316,9 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
         ad[j] = __builtin_amdgcn_raw_buffer_load_b128(ares, r < ne ? (int)((uint32_t)(e0 + r) * row_bytes + slice_off) : kOob, 0, 0);
       }
     }
+#ifndef PYGHO_DU_KO_TRIPS
     trips_of(n);
+#endif
 #pragma unroll
     for (int j = 0; j < ADL; ++j) {
       const int r = j * 16 + q;
@@ -352,30 +386,34 @@ int launch_dual(void* out, void* gh, const void* addend, const void* lhs, const 
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && n > 0) max_lds = n;
   }
-  const size_t lds = (size_t)waves * du_wave_lds(e_cap, (int)table_rows);
+  // the f32 table stage costs 64 bytes per table row and wavefront: taken when the workgroups per CU stay what they are without it
+  const size_t lds16 = (size_t)waves * du_wave_lds(e_cap, (int)table_rows, false), lds32 = (size_t)waves * du_wave_lds(e_cap, (int)table_rows, true);
+  const bool tab_f32 = lds32 <= (size_t)max_lds && (size_t)max_lds / lds32 == (size_t)max_lds / lds16;
+  const size_t lds = tab_f32 ? lds32 : lds16;
   if (lds > (size_t)max_lds) { set_error("seg_dual: %lld edges per block x %lld-byte rows need %zu bytes of LDS (the device offers %d)", (long long)max_edges, (long long)rb, lds, max_lds); return PYGHO_ERR_UNSUPPORTED; }
   int per_cu = (int)((size_t)max_lds / lds);
   if (per_cu * waves > 32) per_cu = 32 / waves;
   if (per_cu < 1) per_cu = 1;
   int gx = cus * per_cu;
   if (gx > n_blocks) gx = (int)n_blocks;
-#define PYGHO_DU(ADD, ADL)                                                                                                           \
+#define PYGHO_DU(ADD, ADL, TF)                                                                                                       \
   do {                                                                                                                                 \
     static bool attr_set_dev[64] = {};                                                                                                 \
     bool& attr_set = per_device_flag(attr_set_dev);                                                                                    \
     if (!attr_set) {                                                                                                                   \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_dual_kernel<T, ADD, ADL>),                                \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_dual_kernel<T, ADD, ADL, TF>),                            \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                                         \
       if (e != hipSuccess) { set_error("seg_dual: cannot reserve LDS: %s", hipGetErrorString(e)); return PYGHO_ERR_LAUNCH; }          \
       attr_set = true;                                                                                                                 \
     }                                                                                                                                  \
-    hipLaunchKernelGGL((seg_dual_kernel<T, ADD, ADL>), dim3(gx), dim3(waves * kWave), lds, st, (T*)out, (T*)gh, (const T*)addend,      \
+    hipLaunchKernelGGL((seg_dual_kernel<T, ADD, ADL, TF>), dim3(gx), dim3(waves * kWave), lds, st, (T*)out, (T*)gh, (const T*)addend,      \
                        (const T*)lhs, (const T*)rhs, (const T*)table, (int)table_rows, (const int4*)chunks, words, cgap, chunk0,      \
                        (const int2*)blk_e, ptr_c, a_byc, look_byc, (int)n_blocks, (int)n_chunks, e_cap, (uint32_t)rb,                 \
                        (uint32_t)(lhs_rows * rb), (uint32_t)(rhs_rows * rb), (uint32_t)(n_out * rb), (uint32_t)(n_msg * 4),           \
                        (uint32_t)((rhs_rows + 1) * 4));                                                                                \
   } while (0)
-  if (addend) PYGHO_DU(true, 6); else PYGHO_DU(false, 6);           // (blocks of up to 96 edges: the flush holds 6 x 16 addend rows in registers)
+  if (tab_f32) { if (addend) PYGHO_DU(true, 6, true); else PYGHO_DU(false, 6, true); }
+  else         { if (addend) PYGHO_DU(true, 6, false); else PYGHO_DU(false, 6, false); }           // (blocks of up to 96 edges: the flush holds 6 x 16 addend rows in registers)
 #undef PYGHO_DU
   return check_launch("seg_dual");
 }
