@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--ranks-share-gpu", action="store_true",
                     help="every rank computes on cuda:0 (RCCL refuses two ranks on one device: use --dist-backend gloo).  A functional run of "
                          "the N > 1 code path, not a scaling measurement")
+    ap.add_argument("--captured", action="store_true",
+                    help="the whole step of every rank -- collation of the new batch, forward, backward, the gradient all-reduce, AdamW -- as "
+                         "ONE captured HIP graph over a fixed-capacity batch slot (pygho_amd.graphs.SlotStep with the FlatGradSync inside; "
+                         "RCCL only).  BASELINE config 4's operating point: python bench.py --gpus 8 --graphs 1024 --global-stream --captured")
     ap.add_argument("--cpu-graphs", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=40.0, help="bound of the CPU baseline's four legs together (each stops early at a quarter of it)")
     return ap.parse_args()
@@ -307,7 +311,16 @@ def side_regimes(args, dev):
         torch.cuda.synchronize(dev)
         res["captured_fresh"] = (time.perf_counter() - t0) / (len(cids) - 10) * 1e3
         assert bool(torch.isfinite(loss))
+        # the same captured slot step with the data-parallel gradient exchange INSIDE the graph (parallel.FlatGradSync, two ranges issued on
+        # a side stream from backward hooks) over a ONE-rank RCCL group: what every rank of `--gpus N --graphs 1024 --captured` replays
+        # (BASELINE config 4's operating point; with one rank the collective's transport is trivial, its launch and stream joins are not)
+        res["captured_sync"] = res["captured_sync_note"] = None
+        try:
+            res["captured_sync"], res["captured_sync_note"] = captured_under_sync(args, dev, small_store, graphs, cids, act)
+        except Exception as e:
+            res["captured_sync_note"] = f"{type(e).__name__}: {e}"
         out[f"bs{graphs}"] = {"graphs": graphs, "eager_ms_per_step": res["eager"], "hipgraph_ms_per_step": res["hipgraph"],
+                              "captured_under_sync_ms_per_step": res["captured_sync"], "captured_under_sync_note": res["captured_sync_note"],
                               "eager_fresh_batch_ms_per_step": res["fresh"],
                               "captured_fresh_batch_ms_per_step": res["captured_fresh"],
                               "captured_fresh_batch_graphs_per_s": graphs / res["captured_fresh"] * 1e3,
@@ -321,6 +334,53 @@ def side_regimes(args, dev):
                                "captured_fresh_batch = ONE captured step over a fixed-capacity batch slot serving 200 different shuffled batches "
                                "(pygho_amd.graphs.SlotStep: a batch that would not fit the capacities runs eagerly and is counted)")
     return out
+
+
+def captured_under_sync(args, dev, store, graphs, id_batches, act):
+    """ms per step of ONE captured slot step that carries the FlatGradSync exchange (RCCL, this process as the only rank of a group
+    created for the measurement when none exists) over `id_batches` (the first 10 untimed)"""
+    import socket
+    from pygho_amd.graphs import SlotStep
+    from pygho_amd.ngnn import SpModel
+    from pygho_amd.parallel import FlatGradSync
+    own_group = not dist.is_initialized()
+    if own_group:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(0)
+        model = SpModel(1, args.layers, args.hidden, act_dtype=act).to(dev)
+        sync = FlatGradSync(model.parameters(), overlap=True, buckets=2)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True)
+
+        def step(dd):
+            sync.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=act is not None):
+                pred = model(dd)
+            loss = torch.nn.functional.l1_loss(dd["y"].unsqueeze(-1), pred.float())
+            loss.backward()
+            sync.sync()
+            opt.step()
+            return loss.detach()
+        ss = SlotStep(store, graphs, step, sync=sync)
+        for k, ids in enumerate(id_batches):
+            if k == 10:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            loss = ss.run(ids)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / (len(id_batches) - 10) * 1e3
+        assert bool(torch.isfinite(loss))
+        note = (f"{ss.replays} replays, {ss.eager_steps} eager fallbacks, {ss._calls_per_step} RCCL all-reduce ranges inside the graph per step, "
+                f"{sync.allreduce_calls} collectives in all; one-rank group ({dist.get_backend()})")
+        sync.close()
+        return ms, note
+    finally:
+        if own_group:
+            dist.destroy_process_group()
 
 
 def visible_gpu_count():
@@ -424,7 +484,12 @@ def main():
     resident_ids = id_rng.permutation(store.num_graphs)[:per_step]
     for _ in range(n_batches):
         ids = resident_ids if args.resident_batch else id_rng.permutation(store.num_graphs)[:per_step]
-        if global_stream:
+        if global_stream and args.captured:
+            # a captured step serves batches of ONE graph count: equal contiguous ranges (the mean of the ranks' mean losses is then the
+            # global mean loss, weight 1)
+            scales.append(1.0)
+            ids = ids[rank * args.graphs:(rank + 1) * args.graphs]
+        elif global_stream:
             # BASELINE config 4's wording: a fixed global stream, sharded by graph.  Every rank draws the same global batch and keeps
             # its contiguous range (balanced by message count); the loss is weighted so that the averaged gradient equals the
             # gradient of the global mean loss whatever the shard sizes are.
@@ -442,9 +507,12 @@ def main():
     # overlaps the rest of backward); a single process only packs
     sync = FlatGradSync(model.parameters(), overlap=use_dist, buckets=2)
     sync.broadcast_params(0)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=args.optimizer == "fused")
+    if args.captured and not sync.capturable:
+        sys.exit("bench.py: --captured needs the RCCL backend (a host-staged collective cannot be captured into a HIP graph)")
+    opt = (torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True) if args.captured        # device-side step counters
+           else torch.optim.AdamW(model.parameters(), lr=1e-3, fused=args.optimizer == "fused"))
 
-    def step(datadict, loss_scale):
+    def step(datadict, loss_scale=1.0):
         sync.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=act_dtype is not None):
             pred = model(datadict)
@@ -453,7 +521,7 @@ def main():
         sync.mark_backward_end()
         sync.sync()
         opt.step()
-        return loss
+        return loss.detach()
 
     def barrier():
         if use_dist:
@@ -470,15 +538,33 @@ def main():
 
     timer = _ops.LaunchTimer()
     t0 = None
-    for k, dd in enumerate(batches()):
-        if k == args.warmup:
-            barrier()
-            timer.__enter__()
-            t0 = time.perf_counter()
-        loss = step(dd, scales[k])
-    barrier()
-    elapsed = elapsed_own = time.perf_counter() - t0
-    timer.__exit__(None, None, None)
+    slot_step = None
+    if args.captured:
+        # ONE captured step per rank for every batch: the slot's collate kernel, the step and the collectives its backward hooks
+        # issue on the side stream are one HIP graph; per step the host uploads the batch's offsets and replays
+        from pygho_amd.graphs import SlotStep
+        slot_step = SlotStep(store, args.graphs, step, warmup=3, sync=sync)
+        for k, ids in enumerate(id_batches):
+            if k == args.warmup:
+                barrier()
+                t0 = time.perf_counter()
+            loss = slot_step.run(ids)
+        barrier()
+        elapsed = elapsed_own = time.perf_counter() - t0
+        with timer:                                   # per-kernel HIP-event times: three EAGER steps after the timed region
+            for ids in id_batches[:3]:               # (a replayed graph records no events)
+                step(store.collate(ids))
+        torch.cuda.synchronize(dev)
+    else:
+        for k, dd in enumerate(batches()):
+            if k == args.warmup:
+                barrier()
+                timer.__enter__()
+                t0 = time.perf_counter()
+            loss = step(dd, scales[k])
+        barrier()
+        elapsed = elapsed_own = time.perf_counter() - t0
+        timer.__exit__(None, None, None)
     timed = id_batches[args.warmup:]
     fam_total = lambda fam: float(sum(np.asarray(store.h_len[fam])[ids].sum() for ids in timed))
     own_graphs, own_msgs = float(sum(len(ids) for ids in timed)), fam_total(("acd", KEY))
@@ -563,6 +649,11 @@ def main():
                                       ", a NEW shuffled batch every step, collated on the device from a resident graph store "
                                       "(the reference's loop, example/minimal.py:141-149)"),
                        "batch": "resident" if args.resident_batch else "fresh every step",
+                       **({"captured": {"what": "every rank's whole step (collation of the new batch, forward, backward, gradient all-reduce, "
+                                                "AdamW) is ONE captured HIP graph over a fixed-capacity batch slot (graphs.SlotStep)",
+                                        "replays": slot_step.replays, "eager_fallbacks": slot_step.eager_steps,
+                                        "collectives_inside_the_graph_per_step": slot_step._calls_per_step,
+                                        "kernel_times": "from three eager steps after the timed region"}} if slot_step is not None else {}),
                        "graphs_per_gpu": mean["graphs"], "store_graphs": store.num_graphs, "store_distinct_graphs": distinct,
                        "nodes": mean["nodes"], "edges": mean["edges"], "tuples": mean["tuples"], "msg_edges": mean["msg_edges"],
                        "sizes": "means over the timed steps of rank 0", "hidden": args.hidden,
@@ -631,6 +722,8 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if use_dist:
+        slot_step = None                              # a captured step holds recorded collectives: gone before their communicator
+        torch.cuda.synchronize(dev)
         dist.barrier()
         dist.destroy_process_group()
 

@@ -84,13 +84,27 @@ class SlotStep:
     (all BatchNorm / weight-gradient / embedding-gradient folds are written that way; ``tests/test_gpu_slots.py`` pins it)."""
 
     def __init__(self, store, batch_graphs: int, step_fn: Callable[[dict], Any], warmup_ids=None, warmup: int = 3,
-                 capacities=None, capacity_sigmas: float = 4.5):
+                 capacities=None, capacity_sigmas: float = 4.5, sync=None):
+        """`sync`: the `parallel.FlatGradSync` that `step_fn` exchanges its gradient through (data-parallel training, BASELINE config
+        4).  With RCCL the collectives -- issued on a side stream from backward hooks -- are captured INSIDE the step, so a rank's
+        whole step incl. its share of the all-reduce is one graph launch; every rank must then run the same number of captured /
+        eager steps in the same order (a batch that does not fit falls back to an eager step, which exchanges too: the ranks stay
+        matched).  A host-staged backend (gloo) cannot be captured: the object then runs EVERY step eagerly (`captured` False,
+        `why_eager` says so) -- same results."""
         from . import _ops
         from .slots import BatchSlot
         assert torch.cuda.is_available(), "HIP graph capture needs the ROCm device"
-        self.store, self.step_fn = store, step_fn
-        self.slot = BatchSlot(store, batch_graphs, capacities, capacity_sigmas)
+        self.store, self.step_fn, self.sync = store, step_fn, sync
         self.eager_steps = self.replays = 0
+        self.captured, self.why_eager = True, None
+        if sync is not None and not sync.capturable:
+            import torch.distributed as dist
+            self.captured = False
+            self.why_eager = (f"process-group backend {dist.get_backend(sync.group)!r}: a host-staged collective cannot be captured into a "
+                              "HIP graph; every step runs eagerly")
+            self.slot, self.graph, self.output = None, None, None
+            return
+        self.slot = BatchSlot(store, batch_graphs, capacities, capacity_sigmas)
         if warmup_ids is None:
             warmup_ids = self._first_fitting()
         slot, dd = self.slot, self.slot.datadict
@@ -107,10 +121,12 @@ class SlotStep:
         # what the warm-up derived from the slot's arrays (narrowed copies, lookups, reciprocal counts ...) is dropped: the captured
         # step derives it again INSIDE the graph, so every replay derives it for the batch that is in the slot
         slot.reset_caches()
+        calls0 = sync.allreduce_calls if sync is not None else 0
         self.graph = torch.cuda.CUDAGraph()
         with slot.rows(), torch.cuda.graph(self.graph):
             slot.launch()
             self.output = step_fn(dd)
+        self._calls_per_step = (sync.allreduce_calls - calls0) if sync is not None else 0     # collectives inside ONE captured step
         _ops.invalidate_cast_arenas()
 
     def _first_fitting(self):
@@ -128,9 +144,11 @@ class SlotStep:
         from . import _ops
         slot = self.slot
         n = len(graph_ids)
-        if n == slot.g and slot.upload(graph_ids):
+        if self.captured and n == slot.g and slot.upload(graph_ids):
             self.graph.replay()
             self.replays += 1
+            if self.sync is not None:
+                self.sync.allreduce_calls += self._calls_per_step      # the replay issued them; no Python ran to count
             _ops.invalidate_cast_arenas()          # the captured optimizer step moved the parameters behind their version counters
             return self.output
         self.eager_steps += 1

@@ -83,6 +83,14 @@ class FlatGradSync:
                         me._on_grad(i)
                 self._handles.append(p.register_post_accumulate_grad_hook(hook))
 
+    @property
+    def capturable(self) -> bool:
+        """can a step that exchanges through this object be captured into a HIP graph?  Without a process group (packing only) and
+        with RCCL (stream-ordered collectives) yes; a host-staged backend (gloo) no."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return True
+        return self.flat.is_cuda and dist.get_backend(self.group) == "nccl"
+
     def close(self) -> None:
         """remove the backward hooks (a second FlatGradSync over the same parameters must not leave this one issuing collectives)"""
         self._closed = True
@@ -145,6 +153,10 @@ class FlatGradSync:
                                "per zero_grad() / sync() pair (a second pass would re-reduce an already exchanged range); run the "
                                "earlier passes of a gradient accumulation under `with sync.no_sync():`")
         if self._pending[b] == 0 and not self._launched[b]:
+            # under stream capture the hook (autograd's worker thread) leaves the range to sync(), which records the collective on the
+            # capturing stream from the capturing thread (see _launch)
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                return
             self._launch(b)
 
     def _launch(self, b: int) -> None:
@@ -157,6 +169,21 @@ class FlatGradSync:
             self._issue_log.append((time.perf_counter(), b, None))
         else:
             cur = torch.cuda.current_stream(self.flat.device)
+            # under stream capture (`graphs.SlotStep(..., sync=...)`: the whole step incl. this collective becomes ONE HIP graph) the
+            # collective is recorded on the CAPTURING stream itself, from sync(): on this stack (PyTorch 2.10 / ROCm 7.2 / RCCL 2.26) a
+            # collective issued on a second stream that joined the capture crashes hipStreamEndCapture, one on the capturing stream is
+            # recorded fine (tools/experiments/rccl_capture_repro.py: every variant).  Inside a captured step the exchange therefore
+            # follows backward instead of overlapping it: 0.7 MB over xGMI against a 2.5 ms step
+            capturing = torch.cuda.is_current_stream_capturing()
+            if capturing:
+                if not self._stream_ordered:
+                    raise RuntimeError("FlatGradSync: only the RCCL backend can be captured into a HIP graph (a host-staged collective has "
+                                       "no stream to be ordered on); run this step eagerly")
+                dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
+                self._issue_log.append((time.perf_counter(), b, None))
+                self._captured_on_current = True
+                self.allreduce_calls += 1
+                return
             self._side.wait_stream(cur)                # the packed range is complete on the side stream
             with torch.cuda.stream(self._side):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -176,7 +203,7 @@ class FlatGradSync:
         """call right after loss.backward() returns: host time + an event on the compute stream, against which overlap_report()
         places the moment the first range's collective was issued"""
         ev = None
-        if self.flat.is_cuda:
+        if self.flat.is_cuda and not torch.cuda.is_current_stream_capturing():
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(torch.cuda.current_stream(self.flat.device))
         self._bwd_end = (time.perf_counter(), ev)
@@ -218,7 +245,7 @@ class FlatGradSync:
                     w.wait()
                     e1.record(self._side)
         self._works = []
-        if self._side is not None:
+        if self._side is not None and not (torch.cuda.is_current_stream_capturing() and getattr(self, "_captured_on_current", False)):
             torch.cuda.current_stream(self.flat.device).wait_stream(self._side)
         if self.world > 1:
             self.flat.div_(self.world)

@@ -72,6 +72,35 @@ def test_bench_under_torchrun_one_rank_uses_rccl():
 
 
 @pytest.mark.gpu
+def test_bench_captured_under_torchrun_one_rank_has_the_collective_inside_the_graph():
+    """BASELINE config 4's operating point, on what one GPU allows: `bench.py --gpus 1 --captured` under torch.distributed.run -- the
+    rank's whole step (collation, forward, backward, the two RCCL all-reduce ranges issued from backward hooks on a side stream,
+    AdamW) is ONE captured HIP graph replayed per batch.  Checked: every timed and warm-up step was a replay, two collectives sit inside
+    the graph, the counted collectives are the replays' (+ warm-up, capture and the three eager steps that time the kernels)."""
+    steps, warmup = 4, 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), BENCH, "--gpus", "1", "--captured", "--steps", str(steps), "--warmup", str(warmup),
+           "--graphs", "256", "--distinct", "256", "--no-cpu-baseline", "--no-regimes", "--no-configs"]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = _line(r.stdout)
+    cap = line["config"]["captured"]
+    assert cap["replays"] + cap["eager_fallbacks"] == steps + warmup and cap["replays"] >= steps
+    assert cap["collectives_inside_the_graph_per_step"] == 2
+    c = line["collectives"]
+    # 3 warm-up runs + 1 capture inside SlotStep, then one pair per replay / fallback, then the 3 eager steps that time the kernels
+    assert c["backend"] == "nccl" and c["allreduce_calls"] == 2 * (4 + steps + warmup + 3)
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_captured_refuses_a_host_staged_backend():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--ranks-share-gpu", "--captured"] + SMALL,
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs")
 def test_bench_self_launches_two_ranks():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + SMALL, env=_env(PYGHO_BENCH_TRACE_COLLECTIVES="1"),
