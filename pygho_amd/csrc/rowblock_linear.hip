@@ -97,9 +97,11 @@ template <int D> struct RlFwdGeom {
   static constexpr int PITCH_S = NW + 8;                   // stage rows hold the workgroup's NW outputs
   static constexpr int CH = NW / 8;                        // 16-B chunks per (half) output row
   // widths 64 / 128: 4 wavefronts x 32 rows (two 16-row MFMA blocks per wavefront share every W fragment), 2 workgroups per CU.
-  // width 256: ONE workgroup per CU (105 KB of LDS) of 8 wavefronts x 16 rows -- two wavefronts per SIMD, so that a wavefront waiting
-  // for its rows / its LDS fragments leaves the SIMD to the other one (4 x 32 rows at one wavefront per SIMD: every load latency was
-  // exposed, 0.54 ms for the statistics pass over 1.2 GB); per wavefront 32 + 32 fragment registers and 32 accumulators
+  // width 256: ONE workgroup per CU of 8 wavefronts x (PYGHO_RL256_MB x 16) rows -- with the shipped MB = 2 a 256-row tile:
+  // 67 584 B of W + 69 632 B of stage + 4 096 B of constants = 141 312 B (138 KB) of LDS, checked against the CU's 160 KB below --
+  // two wavefronts per SIMD, so that a wavefront waiting for its rows / its LDS fragments leaves the SIMD to the other one (4 x 32
+  // rows at one wavefront per SIMD: every load latency was exposed, 0.54 ms for the statistics pass over 1.2 GB); per wavefront
+  // 32 + 32 fragment registers and 32 accumulators
 #ifndef PYGHO_RL256_MB
 #define PYGHO_RL256_MB 2
 #endif
@@ -118,6 +120,8 @@ template <int D> struct RlFwdGeom {
   static constexpr int WG_PER_CU = D > 128 ? 1 : 2;
 };
 static_assert(RlFwdGeom<128>::TILE == kRlTile && RlFwdGeom<64>::TILE == kRlTile, "row tile");
+static_assert(RlFwdGeom<256>::lds_bytes <= 160 * 1024 && 2 * RlFwdGeom<128>::lds_bytes <= 160 * 1024 && 2 * RlFwdGeom<64>::lds_bytes <= 160 * 1024,
+              "the row-block kernels' LDS (W + stage + constants) must fit a CU's 160 KB at the workgroups per CU they are launched for");
 
 template <typename T, int D, int EPI = RL_STORE, int ACT = 0>
 __global__ __launch_bounds__(RlFwdGeom<D>::THREADS, RlFwdGeom<D>::WG_PER_CU) void rowblock_linear_kernel(T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ wl,

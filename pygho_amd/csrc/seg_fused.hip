@@ -471,14 +471,16 @@ int launch_fused(void* out, void* hout, const void* x, const void* wl, const voi
                  const void* table, int table_rows, int residual, const int32_t* seg_ptr, const int32_t* c32, const int32_t* look,
                  const int32_t* chunks, const uint32_t* own, int64_t n_chunks, int64_t n_rows, int64_t n_msg, int act, int mean,
                  hipStream_t st) {
-  int cus = 256;
+  int cus = 256, max_lds = 160 * 1024;
   {
     int dev = 0, n = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && n > 0) max_lds = n;
   }
   const int lds = fu_lds_bytes(table_rows);
-  int per_cu = (160 * 1024) / lds;
+  if (lds > max_lds) { set_error("seg_fused_fwd: %d bytes of LDS per workgroup, the device offers %d", lds, max_lds); return PYGHO_ERR_UNSUPPORTED; }
+  int per_cu = max_lds / lds;
   if (per_cu > PYGHO_FU_WG_PER_CU) per_cu = PYGHO_FU_WG_PER_CU;
   int gx = cus * per_cu;
   if (gx > n_chunks) gx = (int)n_chunks;

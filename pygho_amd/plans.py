@@ -76,9 +76,17 @@ def narrow_i32(x: Tensor, checked: bool = False, bound: Optional[int] = None, bo
         return x.contiguous()
     cache = getattr(x, "_pygho_i32", None)
     if cache is not None and cache[0] == x._version:
-        if bound is not None and x.numel():                  # narrowed earlier without this bound: a check of its own
+        # the smallest bound this copy was already checked against rides in the cache entry: a repeated request with the same or a
+        # larger bound launches nothing and defers nothing (every MessagePlan over the same triples re-ran aminmax + three
+        # elementwise ops and grew the deferred-error list)
+        checked_bound = cache[2] if len(cache) > 2 else None
+        if bound is not None and x.numel() and (checked_bound is None or bound < checked_bound):
             lo, hi = torch.aminmax(cache[1])
             defer_error(((lo < 0) | (hi >= bound)).to(_I32).reshape(1), bound_msg or f"pygho_amd: index outside [0, {bound})")
+            try:
+                x._pygho_i32 = (cache[0], cache[1], bound)
+            except Exception:
+                pass
         return cache[1]
     dev = require_device(x)
     x = x.contiguous()
@@ -89,7 +97,7 @@ def narrow_i32(x: Tensor, checked: bool = False, bound: Optional[int] = None, bo
         if x.numel():
             defer_error(err, bound_msg or f"pygho_amd: index outside [0, {bound})")
         try:
-            x._pygho_i32 = (x._version, out)
+            x._pygho_i32 = (x._version, out, int(bound))
         except Exception:
             pass
         return out

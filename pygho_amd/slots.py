@@ -90,6 +90,16 @@ class BatchSlot:
         dev = self.device = store.device
         self.caps = dict(capacities) if capacities is not None else slot_capacities(store, n_graphs, capacity_sigmas)
         g, sd = self.g, store.sd
+        # the extent of dim 0 NAMES a row family (`plans.row_families`): capacities (and capacity + 1, the CSR pointer arrays) must be
+        # pairwise distinct and distinct from the graph count -- two families of one extent would silently share a row count
+        fams_ = [f for f in store.h_len if not (isinstance(f, tuple) and f[0] == "sc")]
+        missing = [f for f in fams_ if f not in self.caps]
+        if missing:
+            raise ValueError(f"BatchSlot: no capacity for the row families {missing}")
+        extents = [g, g + 1] + [v for f in fams_ for v in (int(self.caps[f]), int(self.caps[f]) + 1)]
+        if min(int(self.caps[f]) for f in fams_) < 1 or len(set(extents)) != len(extents):
+            raise ValueError("BatchSlot: capacities must be >= 1, pairwise distinct (also capacity + 1) and different from the number of "
+                             f"graphs and that + 1; got {self.caps} for {g} graphs (slot_capacities() builds a valid set)")
         fam_of = lambda role: "tup" if role[0] == "X" else "edge"
         # ---- the per-batch upload: rows of G + 1 int64 ------------------------------------------------------------------
         self.fams = [f for f in store.h_len if not (isinstance(f, tuple) and f[0] == "sc")]
