@@ -9,3 +9,4 @@ rocprofv3 --kernel-trace --output-format csv -d $out/fetch --pmc FETCH_SIZE -- p
 rocprofv3 --kernel-trace --output-format csv -d $out/write --pmc WRITE_SIZE -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-regimes --no-configs > $out/write.log 2>&1
 cd $R && python3 tools/collect_traffic.py $out/fetch $out/write $out/kernel_stats.csv $out/traffic.json 8192 128 bf16 fused > $out/traffic.log 2>&1
 python3 tools/collect_traffic.py $out/fetch $out/write $out/kernel_stats.csv $out/traffic_fast.json 8192 128 bf16 fast >> $out/traffic.log 2>&1
+python3 tools/collect_traffic.py $out/fetch $out/write $out/kernel_stats.csv $out/traffic_dual.json 8192 128 bf16 dual >> $out/traffic.log 2>&1
