@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--ranks-share-gpu", action="store_true",
                     help="every rank computes on cuda:0 (RCCL refuses two ranks on one device: use --dist-backend gloo).  A functional run of "
                          "the N > 1 code path, not a scaling measurement")
+    ap.add_argument("--collate-gate", default="none", choices=["readout", "none"],
+                    help="where the next batch's collate kernel may start: `none` = the moment it is queued (shipped), `readout` = from the "
+                         "first graph-level module of the step in flight (A/B, tools/gate_ab.sh: the window of small launches is shorter than "
+                         "the kernel, which then lands on the first backward launch -- 0.1-0.2 ms WORSE per step)")
     ap.add_argument("--captured", action="store_true",
                     help="the whole step of every rank -- collation of the new batch, forward, backward, the gradient all-reduce, AdamW -- as "
                          "ONE captured HIP graph over a fixed-capacity batch slot (pygho_amd.graphs.SlotStep with the FlatGradSync inside; "
@@ -534,7 +538,11 @@ def main():
             for _ in range(n_batches):
                 yield dd
         else:
-            yield from BatchPrefetcher(store, id_batches)
+            pf = BatchPrefetcher(store, id_batches, gated=args.collate_gate == "readout")
+            if pf.gated:
+                # the next batch's upload + collate kernel run under the readout / loss / first backward launches of the step in flight
+                model.lpool.register_forward_pre_hook(lambda _m, _a: pf.gate())
+            yield from pf
 
     timer = _ops.LaunchTimer()
     t0 = None

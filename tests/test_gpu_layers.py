@@ -1330,6 +1330,15 @@ def test_batch_prefetcher_with_plan_preparation(dev):
     pre = train(BatchPrefetcher(store, ids, m2.prepare), m2)
     for k in plain:
         assert torch.equal(plain[k], pre[k]), k
+    # gated (round 6): the next batch's upload + collate kernel start no earlier than the mark the consumer sets inside its step
+    # (bench.py: a forward pre-hook on the model's first graph-level module) -- same batches, same training
+    m3 = copy.deepcopy(base)
+    pf = BatchPrefetcher(store, ids, gated=True)
+    hook = m3.lpool.register_forward_pre_hook(lambda _m, _a: pf.gate())
+    gated = train(pf, m3)
+    hook.remove()
+    for k in plain:
+        assert torch.equal(plain[k], gated[k]), k
     # same batches, and no synchronisation left inside a prepared step
     for a, b in zip((store.collate(i) for i in ids), BatchPrefetcher(store, ids)):
         assert torch.equal(a["X"].indices, b["X"].indices) and torch.equal(a["A"].values, b["A"].values)
