@@ -689,6 +689,70 @@ def bn_bwd_linear(pre: Optional[Tensor], gh: Tensor, saved, training: bool, act:
     return gx, second, s1, s2, sdx
 
 
+class record_block_paths:
+    """``with record_block_paths() as log:`` -- every tuple block that runs inside appends what it dispatched and, where a faster
+    path was not taken, which of its conditions failed ("nothing reports which path ran except LaunchTimer"):
+    {"forward": "seg_fused" | "rowblock_linear + seg_gmr" | ..., "forward_not_fused_because": [...]} at forward time and
+    {"backward": "seg_dual" | "seg_gmr + by_edge", "backward_not_dual_because": [...]} at backward time."""
+    active = None
+
+    def __enter__(self):
+        self.log, self.prev = [], record_block_paths.active
+        record_block_paths.active = self.log
+        return self.log
+
+    def __exit__(self, *exc):
+        record_block_paths.active = self.prev
+
+
+def _why_not_fused(recompute, plan, rhs, rhs_lookup, aggr, x):
+    why = []
+    if not FUSED_FWD:
+        why.append("PYGHO_FUSED_FWD=0")
+    if not recompute:
+        why.append("the block keeps its pre-activation (fewer than 8192 rows, width other than 64 / 128, no weight gradient wanted, or a switch is off)")
+    if plan is None or rhs is None:
+        why.append("no aggregation in this block")
+        return why
+    if rhs_lookup is None:
+        why.append("the second operand is not known to be an embedding lookup (pass adj_lookup=(table, index) to forward_residual)")
+    elif rhs_lookup[0].shape[0] > 32 or rhs_lookup[0].dtype != x.dtype:
+        why.append("the lookup table has more than 32 rows or another dtype than the rows")
+    if aggr not in ("sum", "mean"):
+        why.append(f"aggregation {aggr!r}")
+    if x.shape[1] != 128 or x.dtype not in (torch.bfloat16, torch.float16):
+        why.append("rows are not 128 x 16-bit")
+    if plan is not None and fused_plan(plan, on_demand=True) is None:
+        why.append("the plan has no fused chunks (not planned: DeviceGraphStore.collate / SpModel.prepare / _ops.fused_plan; or a row outside the limits)")
+    return why
+
+
+def _why_not_dual(plan, g, h, table, scale, look, affine, wants_rhs):
+    why = []
+    if not wants_rhs:
+        return ["the second operand needs no gradient"]
+    if not DUAL_BWD:
+        why.append("PYGHO_DUAL_BWD=0")
+    if look is None or table is None:
+        why.append("the second operand is not an embedding lookup")
+    if affine is not None or h is None:
+        why.append("the activated rows were not stored (act-on-load path)")
+    if scale is not None:
+        why.append("mean aggregation")
+    if plan.m < SEG_SCATTER_MIN_MESSAGES:
+        why.append(f"fewer than {SEG_SCATTER_MIN_MESSAGES} messages")
+    sp = scatter_plan(plan, on_demand=True)
+    if sp is None:
+        why.append("no scatter plan (not planned, or blocks outside the limits)")
+    elif sp.cgap is None:
+        why.append("the scatter plan's chunks are not aligned (a group of messages outside the chunk limits)")
+    elif sp.max_edges > 96:
+        why.append("more than 96 second-operand rows in one block")
+    if g.dtype not in (torch.bfloat16, torch.float16):
+        why.append("rows are not 16-bit")
+    return why
+
+
 class _TupleBlock(torch.autograd.Function):
     """H = act(bn(x W^T + b));  out = H                                  (plan is None)
                                   out = [x +] (+)_{(a,c,d)} H[c] * rhs[d]   (plan given; `residual` adds x)
@@ -737,6 +801,11 @@ class _TupleBlock(torch.autograd.Function):
                 and x.shape[1] == 128 and x.dtype in (torch.bfloat16, torch.float16) and rhs_lookup[0].shape[0] <= 32
                 and rhs_lookup[0].dtype == x.dtype and x.shape[0] * 256 < (1 << 31) and plan.m * 4 < (1 << 31)):
             fp = fused_plan(plan, on_demand=True)
+        if record_block_paths.active is not None:
+            record_block_paths.active.append(
+                {"forward": "seg_fused"} if fp is not None else
+                {"forward": ("rowblock_linear" if skinny else "library GEMM") + (" + seg_gmr" if plan is not None else ""),
+                 "forward_not_fused_because": _why_not_fused(recompute, plan, rhs, rhs_lookup, aggr, x)})
         if fp is not None:
             (scale, shift), mean, var, saved = _bn_forward(None, gamma, beta, running_mean, running_var, training, eps, act, fold_momentum,
                                                            partial, apply=False, producer=(x, wc, bc))
@@ -815,8 +884,15 @@ class _TupleBlock(torch.autograd.Function):
             rhs_read = rhs
             if ctx.look is not None:
                 rhs_read, d_g = ctx.look[0], ctx.look[2]
-            if (rhs is not None and ctx.needs_input_grad[10] and ctx.look is not None and ctx.affine is None
-                    and dual_eligible(plan, g, h, rhs_read, scale)):
+            use_dual = (rhs is not None and ctx.needs_input_grad[10] and ctx.look is not None and ctx.affine is None
+                        and dual_eligible(plan, g, h, rhs_read, scale))
+            if record_block_paths.active is not None and rhs is not None:
+                record_block_paths.active.append(
+                    {"backward": "seg_dual"} if use_dual else
+                    {"backward": "seg_gmr + by_edge_product",
+                     "backward_not_dual_because": _why_not_dual(plan, g, h, rhs_read if ctx.look is not None else None, scale, ctx.look,
+                                                                ctx.affine, bool(ctx.needs_input_grad[10]))})
+            if use_dual:
                 # both gradients of the aggregation from ONE pass over the forward message order (csrc/seg_dual.hip): g and H rows are
                 # fetched once for the by-tuple sum gh and the by-edge sum g_rhs -- the bits of the two launches below
                 gh, g_rhs = dual_backward(plan, g, h, rhs_read, d_g, addend=g_chain)

@@ -353,11 +353,17 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
   issue(r1, d1);
   issue(r2, d2);
   issue(r3, d3);
+#ifdef PYGHO_DU_DESC_PREFETCH
+  Desc pre = next_desc();                               // the record of the chunk after next travels while this one is multiplied
+#define PYGHO_DU_NEXT() pre; pre = next_desc()
+#else
+#define PYGHO_DU_NEXT() next_desc()
+#endif
   while ((d0.d.w & 0xff) != 0) {
 #define PYGHO_DU_STEP(R, D)                    \
     {                                          \
       stage(R, D);                             \
-      const Desc dn = next_desc();             \
+      const Desc dn = PYGHO_DU_NEXT();         \
       issue(R, dn);                            \
       compute(D);                              \
       D = dn;                                  \

@@ -83,7 +83,10 @@ def _views(mode: str, pool: str):
 GRAD_CHAIN_KEY = "_pygho_grad_chain"      # datadict key a model loop sets to {} for one forward pass (see _residual_update)
 
 
-def _residual_update(layer, A: Rep, X: Rep, datadict: dict) -> Rep:
+ADJ_LOOKUP_KEY = "A_lookup"      # datadict key: (table, flat index) when A's values are table[index] (set by the input encoder)
+
+
+def _residual_update(layer, A: Rep, X: Rep, datadict: dict, adj_lookup=None) -> Rep:
     """X + aggr(lin(X), A) for the layers whose update is `tuple-wise MLP, then X A inside the subgraph`.  Fused
     path (sparse X and A on the device, single-block MLP with square weight, sum / mean, precomputed acd):
     GEMM -> BatchNorm+act kernels -> aggregation kernel with the residual row added in its epilogue, one
@@ -101,8 +104,20 @@ def _residual_update(layer, A: Rep, X: Rep, datadict: dict) -> Rep:
         return X.add(layer.forward(A, X, datadict), True)
     lin, bn, act = block
     plan = _ops.message_plan(acd, X.nnz, X.nnz, A.nnz)
-    # adjacency values that are an embedding lookup (a handful of distinct rows) are READ through the table
-    lookup = getattr(A.values, "_pygho_lookup", None) if _ops.USE_ADJ_TABLE else None
+    # adjacency values that are an embedding lookup (a handful of distinct rows) are READ through the table.  The provenance is an
+    # EXPLICIT argument -- `adj_lookup=(table, index)` with A.values == table[index] --, or the datadict entry the input encoder leaves
+    # (ADJ_LOOKUP_KEY); the attribute `IndexEmbedding` hangs on its output is the legacy route for callers that pass neither
+    lookup = None
+    if _ops.USE_ADJ_TABLE:
+        lookup = adj_lookup
+        if lookup is None and datadict is not None:
+            ent = datadict.get(ADJ_LOOKUP_KEY)           # (table, index, the values tensor it describes)
+            if ent is not None and ent[2] is A.values:
+                lookup = ent
+        if lookup is None:
+            lookup = getattr(A.values, "_pygho_lookup", None)
+        if lookup is not None:
+            lookup = (lookup[0], lookup[1])
     if lookup is not None and not (lookup[0].dim() == 2 and lookup[0].dtype == X.values.dtype and lookup[1].numel() == A.nnz
                                    and lookup[0].shape[1] == X.values.shape[1]):
         lookup = None
@@ -188,10 +203,13 @@ class NGNNConv(Module):
         H = X.tuplewiseapply(self.lin)
         return self.aggr.forward(A, H, datadict, H)
 
-    def forward_residual(self, A: Rep, X: Rep, datadict: dict) -> Rep:
+    def forward_residual(self, A: Rep, X: Rep, datadict: dict, adj_lookup=None) -> Rep:
         """``X.add(self.forward(A, X, datadict), True)`` (the model loop of example/minimal.py:76-79) as one fused
-        block when the layer is sparse with a single Linear -> BatchNorm -> act update; otherwise exactly that."""
-        return _residual_update(self, A, X, datadict)
+        block when the layer is sparse with a single Linear -> BatchNorm -> act update; otherwise exactly that.
+        `adj_lookup=(table, index)`: A.values == table[index] (an embedding lookup of the edge feature) -- the block then reads the
+        table instead of the gathered rows and, at width 128 in 16 bits, runs as the fused forward / fused backward kernels
+        (`_ops.record_block_paths()` reports which path ran and why)."""
+        return _residual_update(self, A, X, datadict, adj_lookup)
 
 
 class SSWLConv(Module):

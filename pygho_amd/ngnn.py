@@ -13,7 +13,7 @@ from torch import Tensor
 from . import _ops
 from .backend.SpTensor import SparseTensor
 from .backend.utils import torch_scatter_reduce
-from .honn.Conv import GRAD_CHAIN_KEY, NGNNConv
+from .honn.Conv import ADJ_LOOKUP_KEY, GRAD_CHAIN_KEY, NGNNConv
 from .honn.TensorOp import OpPoolingSubg2D
 from .honn.utils import MLP, Linear
 
@@ -67,6 +67,10 @@ class InputEncoderSp(nn.Module):
         out = dict(datadict)
         out["x"] = self._cast(self.x_encoder(datadict["x"].flatten()))
         out["A"] = datadict["A"].tuplewiseapply(lambda v: self._cast(self.ea_encoder(v)))
+        look = getattr(out["A"].values, "_pygho_lookup", None)
+        if look is not None:
+            # A's values are table[index]: said explicitly to the layers (honn.Conv.ADJ_LOOKUP_KEY) -- they read the table
+            out[ADJ_LOOKUP_KEY] = (look[0], look[1], out["A"].values)
         if defer_tuplefeat:
             w = self.tuplefeat_encoder.weight                 # the table itself: its 16-bit copy comes from the cast arena
             out["X_table"] = w if self.act_dtype is None else _ops.cast_param(w, self.act_dtype)

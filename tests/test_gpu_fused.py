@@ -338,3 +338,47 @@ def test_fused_forward_at_baseline_size_vs_host_oracle(dev, baseline_store, dtyp
         if not torch.equal(got, want):
             bad = got != want
             raise AssertionError(f"{aggr}: {int(bad.sum())} of {bad.numel()} output elements differ from the host oracle over the device's H")
+
+
+def test_explicit_lookup_argument_and_path_report(dev):
+    """the fused dispatch used to hang on a private tensor attribute and nothing said which path ran.  Now the
+    provenance of A's values is an EXPLICIT argument of `forward_residual` (`adj_lookup=(table, index)`), and
+    `_ops.record_block_paths()` reports per block what was dispatched and which condition kept a faster path out: a plain gathered
+    A (no attribute, no argument) takes the separate launches and says why; the same call with `adj_lookup` runs seg_fused forward and
+    seg_dual backward -- same output bits either way."""
+    from pygho_amd import SparseTensor, _ops, synth
+    from pygho_amd.collate import DeviceGraphStore
+    from pygho_amd.honn.Conv import NGNNConv
+    rng = np.random.default_rng(4)
+    store = DeviceGraphStore([synth.make_graph(rng, "zinc", 3, (KEY,)) for _ in range(128)], dev)
+    dd = store.collate(np.arange(128))
+    h = 128
+    torch.manual_seed(0)
+    layer = NGNNConv(h, h, "sum", "SS", {"numlayer": 1, "tailact": True, "norm": "bn", "act": "silu"}).to(dev).train()
+    table = torch.randn(16, h, device=dev).to(torch.bfloat16).requires_grad_(True)
+    idx = _ops.flat_index(dd["A"].values)
+    n = int(dd["num_nodes"])
+    xv = torch.randn(dd["X"].nnz, h, device=dev).to(torch.bfloat16)
+    old = _ops.SEG_SCATTER_MIN_MESSAGES
+    _ops.SEG_SCATTER_MIN_MESSAGES = 0
+    try:
+        outs = []
+        for explicit in (False, True):
+            av = table[dd["A"].values]                       # a plain gather: no provenance on the tensor
+            A = SparseTensor(dd["A"].indices, av, [n, n, h], True)
+            X = SparseTensor(dd["X"].indices, xv.clone().requires_grad_(True), [n, n, h], True)
+            with _ops.record_block_paths() as log:
+                out = layer.forward_residual(A, X, dd, adj_lookup=(table.detach(), idx) if explicit else None)
+                out.values.float().square().mean().backward()
+            torch.cuda.synchronize()
+            outs.append(out.values.detach().clone())
+            fwd = [e for e in log if "forward" in e][0]
+            bwd = [e for e in log if "backward" in e][0]
+            if explicit:
+                assert fwd == {"forward": "seg_fused"} and bwd == {"backward": "seg_dual"}, log
+            else:
+                assert fwd["forward"] == "rowblock_linear + seg_gmr" and any("adj_lookup" in w for w in fwd["forward_not_fused_because"]), log
+                assert bwd["backward"] == "seg_gmr + by_edge_product" and bwd["backward_not_dual_because"], log
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        _ops.SEG_SCATTER_MIN_MESSAGES = old
