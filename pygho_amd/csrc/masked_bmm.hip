@@ -35,6 +35,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
+#ifndef PYGHO_BMM_TILED_DEFAULT
+#define PYGHO_BMM_TILED_DEFAULT 0
+#endif
 constexpr int kTile = 48;     // max rows of an i- / j-tile (3 MFMA tiles of 16)
 constexpr int kKBlock = 64;   // k elements staged per pass
 constexpr int kOutPitch = 50; // dwords per row of an epilogue plane: a wavefront's 4 row groups land 8 banks apart (2-way =
@@ -178,6 +181,7 @@ __device__ __forceinline__ void stage_write_at(char* lds, const StageRegs<T>& re
 }  // namespace pygho
 
 #include "masked_bmm_blocks.h"      // the multi-block matrix-core form (no LDS): taken whenever d is a multiple of 16 pieces
+#include "masked_bmm_tiled.h"       // 16-bit rows: 16 x 16 workgroup tiles through LDS (round 6)
 
 namespace pygho {
 
@@ -407,11 +411,27 @@ __global__ __launch_bounds__(kBlock) void mask_extents_kernel(int32_t* __restric
   }
 }
 
+// PYGHO_BMM_TILED = 1 / 0: the LDS-tiled kernel for 16-bit rows (A/B switch; default set from the measurements in DESIGN.md 3)
+inline bool bmm_use_tiled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PYGHO_BMM_TILED");
+    v = e ? (strcmp(e, "0") != 0) : PYGHO_BMM_TILED_DEFAULT;
+  }
+  return v != 0;
+}
+
 template <typename T>
 int launch_bmm(const BmmArgs& p, int64_t nb, hipStream_t st) {
   using TR = BmmTraits<T>;
   if (p.d % TR::CH != 0) { set_error("masked_bmm: d must be a multiple of %d for this dtype", TR::CH); return PYGHO_ERR_UNSUPPORTED; }
-  if (bmm_blocks_eligible<T>(p)) return launch_bmm_blocks<T>(p, nb, st);
+  if (bmm_blocks_eligible<T>(p)) {
+    // 16-bit rows: the 16 x 16 workgroup tiles through LDS (masked_bmm_tiled.h, round 6) where PYGHO_BMM_TILED says so
+    if constexpr (sizeof(T) == 2) {
+      if (bmm_use_tiled() && bmm_tiled_eligible<T>(p)) return launch_bmm_tiled<T>(p, nb, st);
+    }
+    return launch_bmm_blocks<T>(p, nb, st);
+  }
   const int kmax = (int)(p.nk < kKBlock ? p.nk : kKBlock);
   const int kp = bmm_pitch(kmax, sizeof(T));
   const int ri = (int)(p.ni < kTile ? p.ni : kTile), rj = (int)(p.nj < kTile ? p.nj : kTile);

@@ -616,3 +616,46 @@ def test_masked_diag_over_more_than_two_dims(dev, shape, md, dims):
         sel = tuple(i if k in dims else slice(None) for k in range(md))
         gexp[sel] = mask[sel].reshape(mask[sel].shape + (1,) * (data.ndim - md))
     assert np.array_equal(x.grad.cpu().numpy(), gexp)
+
+
+def test_lds_tiled_contraction_variant_returns_the_same_bits():
+    """round 6: the 16 x 16 workgroup-tile kernel (`csrc/masked_bmm_tiled.h`, opt-in through PYGHO_BMM_TILED=1 -- it measured slower than the
+    multi-block kernel) stays correct: in a child process with the switch on, the contraction over ragged shapes, all
+    mask combinations and both operand layouts equals the default kernel's result bit for bit (the k order per output is the same)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    if not torch.cuda.is_available():
+        pytest.skip("needs the ROCm device")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from pygho_amd import _ops
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+outs = []
+for (nb, ni, nk, nj, d, dt) in ((3, 37, 37, 37, 128, torch.bfloat16), (2, 16, 5, 33, 128, torch.float16), (4, 9, 64, 20, 256, torch.bfloat16)):
+    for akf in (False, True):
+        for bkf in (True, False):
+            A = torch.randn((nb, nk, ni, d) if akf else (nb, ni, nk, d), device=dev).to(dt)
+            B = torch.randn((nb, nk, nj, d) if bkf else (nb, nj, nk, d), device=dev).to(dt)
+            am = (torch.rand(A.shape[:3], device=dev) < 0.6).to(torch.uint8)
+            bm = (torch.rand(B.shape[:3], device=dev) < 0.5).to(torch.uint8)
+            om = (torch.rand((nb, ni, nj), device=dev) < 0.7).to(torch.uint8)
+            for masks in ((am, bm, om), (None, bm, None), (am, None, om), (None, None, None)):
+                outs.append(_ops.masked_bmm(A, B, masks[0], masks[1], masks[2], nb, ni, nk, nj, d, akf, bkf).cpu())
+torch.save(outs, sys.argv[1])
+''' % repo
+    with tempfile.TemporaryDirectory() as tmp:
+        res = {}
+        for tiled in ("0", "1"):
+            path = os.path.join(tmp, f"out{tiled}.pt")
+            env = dict(os.environ, PYGHO_BMM_TILED=tiled)
+            r = subprocess.run([sys.executable, "-c", script, path], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-3000:]
+            res[tiled] = torch.load(path)
+        assert len(res["0"]) == len(res["1"]) == 48
+        for a, b in zip(res["0"], res["1"]):
+            assert torch.equal(a, b)
