@@ -264,6 +264,33 @@ class DeviceGraphStore:
             chunks[:, 1] -= base
             chunks[:, 2] = torch.where((chunks[:, 3] >> 16) > 0, chunks[:, 2] - base, torch.zeros_like(base))
             self.fused_parts[k] = {"chunk_ptr": chunk0.to(torch.int64), "chunks_t": chunks.t().contiguous(), "own": own.reshape(1, -1)}
+        # 3-tuple stores (I2GNN): the MERGED (i, j) pattern that pooling the last coordinate away produces (reference
+        # SpTensor.py:368-380 via OpPoolingSubg3D, SpOperator.py:496-522), per graph and ONCE: the tuples are sorted by (i, j, k), so
+        # the distinct (i, j) pairs are runs -- a batch's pooled pattern, its CSR pointers over the tuples, the tuple -> pair map and
+        # the pairs' grouping by root are the graphs' parts with offsets added (round 5: a sort + unique with host reads per fresh batch)
+        self.pair_parts = None
+        if self.sd == 3 and all(r.tupleid.shape[1] > 0 for r in records):
+            idx, ptr, inv, rptr, n_pairs, h_max, h_rmax, ok = [], [], [], [], [], [], [], True
+            for r in records:
+                t = r.tupleid.astype(np.int64)
+                key = t[0] * r.num_nodes + t[1]
+                if np.any(np.diff(key) < 0):
+                    ok = False
+                    break
+                start = np.concatenate(([0], np.nonzero(np.diff(key))[0] + 1))
+                cnt = np.diff(np.concatenate((start, [t.shape[1]])))
+                idx.append(t[:2, start])
+                ptr.append((np.cumsum(cnt) - cnt).reshape(1, -1))
+                inv.append(np.repeat(np.arange(start.size), cnt).reshape(1, -1))
+                rc = np.bincount(t[0, start], minlength=r.num_nodes)
+                rptr.append((np.cumsum(rc) - rc).reshape(1, -1))
+                n_pairs.append(start.size)
+                h_max.append(int(cnt.max()))
+                h_rmax.append(int(rc.max()))
+            if ok:
+                self.pair_parts = {"index": _cat32(idx, 1, d), "ptr": _cat32(ptr, 1, d), "inv": _cat32(inv, 1, d), "root_ptr": _cat32(rptr, 1, d),
+                                   "h_len": np.asarray(n_pairs, dtype=np.int64), "h_max": np.asarray(h_max, dtype=np.int64),
+                                   "h_root_max": np.asarray(h_rmax, dtype=np.int64)}
         self.y = torch.tensor([r.y for r in records], dtype=torch.float32, device=d)
         # largest integer feature of the store per array: a lookup into a table with more rows than that needs no range flag
         vmax = lambda f: max((int(np.max(f(r))) for r in records if np.size(f(r))), default=-1)
@@ -274,6 +301,8 @@ class DeviceGraphStore:
         self.h_len = {"node": ln(lambda r: r.num_nodes), "edge": ln(lambda r: r.edge_index.shape[1]), "tup": ln(lambda r: r.tupleid.shape[1])}
         for k in self.keys:
             self.h_len[("acd", k)] = ln(lambda r: r.acd[k].shape[1])
+        if self.pair_parts is not None:
+            self.h_len["pair"] = self.pair_parts["h_len"]
         for k, v in self.scatter_parts.items():
             self.h_len[("sc", k)] = np.diff(v["chunk_ptr"].cpu().numpy())
         for k, v in self.fused_parts.items():
@@ -371,6 +400,31 @@ class DeviceGraphStore:
             row32._pygho_mirror = (col32, vidx32, n, res, (row32._version, col32._version, vidx32._version))
         return finish
 
+    def _install_pair_plans(self, dd, lay: "_Layout", B: "_BatchBuilder"):
+        """3-tuple batches: the merged (i, j) pattern of `X.sum / max / mean(dims=[2], return_sparse=True)` (OpPoolingSubg3D) with its
+        plan, and the pooled pattern's grouping by root (the OpPoolingSubg2D that follows), where `SparseTensor._reduce_to_sparse` /
+        `_reduce_to_dense` look for them: no sort, no unique, no host read per fresh batch"""
+        pp = self.pair_parts
+        if pp is None or lay.g == 0 or lay.total["pair"] == 0 or lay.total["tup"] >= (1 << 31):
+            return lambda: None
+        X, n, ids_h = dd["X"], lay.total["node"], lay.ids_h
+        n_pairs, nnz = lay.total["pair"], lay.total["tup"]
+        new_ind = B.add(pp["index"], "pair", incs=(B.off("node"), B.off("node")))
+        pair_ptr = B.add(pp["ptr"], "pair", incs=(B.off("tup"),), pad=B.total("tup"), i32=True, extra=1).reshape(-1)
+        inv32 = B.add(pp["inv"], "tup", incs=(B.off("pair"),), i32=True).reshape(-1)
+        root_ptr = B.add(pp["root_ptr"], "node", incs=(B.off("pair"),), pad=B.total("pair"), i32=True, extra=1).reshape(-1)
+
+        def finish():
+            plan = _ops.SegPlan(pair_ptr, None, n_pairs, nnz)
+            plan._memo = {"max_len": int(pp["h_max"][ids_h].max())}
+            if n < (1 << 31):
+                new_ind._pygho_hash_ok = new_ind._version
+            X._cache()[("pool_sparse", (0, 1))] = (new_ind, plan, inv32)
+            row0 = _ops.unbased(new_ind[0])
+            new_ind._pygho_cache = {"_v": new_ind._version, ("row", 0): row0}
+            _ops.install_plan(row0, _ops.SegPlan(root_ptr, None, n, n_pairs), ("scatter",), max_len=int(pp["h_root_max"][ids_h].max()))
+        return finish
+
     def _group_factory(self, part, lay: "_Layout", fam):
         def build(n_seg: int):
             if n_seg != lay.total["node"] or lay.total[fam] >= (1 << 31):
@@ -426,7 +480,7 @@ class DeviceGraphStore:
         for t64, t32 in seeds:
             if t64.numel():
                 t64._pygho_i32 = (t64._version, t32)
-        finish = [self._install_node_plans(dd, lay, B)]
+        finish = [self._install_node_plans(dd, lay, B), self._install_pair_plans(dd, lay, B)]
         for k in self.keys:
             roles = parse_key(k)
             fm = ("acd", k)

@@ -193,6 +193,15 @@ class BatchSlot:
             self.diag_pos = desc(out(1, "node", False), store.diag_parts["pos"], "node", incs=(off("tup"),), pad=self._neg1.data_ptr()).reshape(-1)
             self.cnt_r = torch.ones((self.caps["node"], 1), dtype=_I64, device=dev)
             self.cnt_c = torch.ones((self.caps["node"], 1), dtype=_I64, device=dev)
+        # 3-tuple stores: the merged (i, j) pattern of pooling the last coordinate away, its CSR pointers over the tuples, the tuple ->
+        # pair map and the pairs' grouping by root (collate.DeviceGraphStore.pair_parts); pad pairs are (0, 0) with empty segments
+        self.pair = None
+        pp = getattr(store, "pair_parts", None)
+        if pp is not None:
+            self.pair = {"index": desc(out(2, "pair", False), pp["index"], "pair", incs=(node_off, node_off)),
+                         "ptr": desc(out(1, "pair", True, extra=1), pp["ptr"], "pair", incs=(off("tup"),), pad=total("tup")).reshape(-1),
+                         "inv": desc(out(1, "tup", True), pp["inv"], "tup", incs=(off("pair"),)).reshape(-1),
+                         "root_ptr": desc(out(1, "node", True, extra=1), pp["root_ptr"], "node", incs=(off("pair"),), pad=total("pair")).reshape(-1)}
         self.mirror = None
         if store.mirror_parts is not None and bool(store.mirror_parts["h_ok"].all()):
             self.mirror = desc(out(1, "tup", True), store.mirror_parts["pos"], "tup", incs=(off("tup"),)).reshape(-1)
@@ -237,6 +246,8 @@ class BatchSlot:
               self.y, self.graph_ptr, self.root_ptr, self.mirror, self.diag_pos, self.cnt_r, self.cnt_c]
         for gp, perm in self.group.values():
             ts += [gp, perm]
+        if self.pair is not None:
+            ts += list(self.pair.values())
         for ent in self.msg.values():
             ts += list(ent.values())
         return [t for t in ts if t is not None]
@@ -299,6 +310,18 @@ class BatchSlot:
             keys = (rows_x if which == "X" else rows_a)[dim]
             m = self.caps["tup" if which == "X" else "edge"]
             serve(keys, seg(gp, perm, n, m, h_max(st.group_parts[(which, dim)]["h_max"])))
+        if self.pair is not None:
+            pr, pp = self.pair, st.pair_parts
+            pr["index"]._pygho_slot = True
+            if n < (1 << 31):
+                pr["index"]._pygho_hash_ok = pr["index"]._version
+            self._X._cache()[("pool_sparse", (0, 1))] = (pr["index"], seg(pr["ptr"], None, self.caps["pair"], self.caps["tup"], h_max(pp["h_max"])),
+                                                        pr["inv"])
+            self._pair_row0 = getattr(self, "_pair_row0", None)
+            if self._pair_row0 is None:
+                self._pair_row0 = _ops.unbased(pr["index"][0])            # the SAME row object every time (plans hang on it)
+            pr["index"]._pygho_cache = {"_v": pr["index"]._version, ("row", 0): self._pair_row0}
+            serve(self._pair_row0, seg(pr["root_ptr"], None, n, self.caps["pair"], h_max(pp["h_root_max"])))
         if self.diag_pos is not None:
             self._X._cache()["sun_views"] = (self.diag_pos, self.cnt_r, self.cnt_c)
         if self.root_ptr is not None:
@@ -325,7 +348,7 @@ class BatchSlot:
         re-install the slot's own plans.  Needed after every eager `collate`; before a capture it makes the captured step recompute
         whatever it derives INSIDE the graph, so a replay recomputes it for the new batch."""
         keep = set()
-        objs = list(self._static) + list(self._rows32_x) + list(self._rows32_a)
+        objs = list(self._static) + list(self._rows32_x) + list(self._rows32_a) + ([self._pair_row0] if getattr(self, "_pair_row0", None) is not None else [])
         for sp in (self._A, self._X):
             c = sp._cache()
             objs += [v for v in c.values() if isinstance(v, torch.Tensor)]

@@ -1830,12 +1830,13 @@ def test_prefetched_training_with_deferred_flags_from_two_streams(dev):
         _ops._fetch(torch.zeros(1, dtype=torch.int64, device=dev))
 
 
-@pytest.mark.parametrize("conv", ["NGNN", "SSWL", "SUN", "GNNAK", "DSSGNN"])
+@pytest.mark.parametrize("conv", ["NGNN", "SSWL", "SUN", "GNNAK", "DSSGNN", "I2GNN"])
 def test_fresh_collated_batch_trains_without_host_reads(dev, conv):
-    """a training step of every 2-tuple sparse model family on a batch it has never seen, collated from the device graph store,
+    """a training step of every sparse model family on a batch it has never seen, collated from the device graph store,
     makes no device-to-host read (planner fetches, `.item()`, `.tolist()`): the batch arrives with its message / scatter plans, the
     groupings of its index rows are assembled from per-graph parts on demand, small-table gradients need no plan, and the store's
-    range checks stand in for the hash asserts.  (3-tuple models still plan their merged patterns: an inherent size read.)"""
+    range checks stand in for the hash asserts.  Round 6: I2GNN too -- the merged (i, j) pattern of pooling a 3-tuple representation's
+    last coordinate away (reference SpTensor.py:368-380) and its grouping by root come with the batch (`DeviceGraphStore.pair_parts`)."""
     from pygho_amd import _ops, synth
     from pygho_amd.collate import DeviceGraphStore
     from pygho_amd.honn.SpOperator import parse_precomputekey
@@ -1844,7 +1845,8 @@ def test_fresh_collated_batch_trains_without_host_reads(dev, conv):
     model = SpModel(conv, num_layer=2, hiddim=64, act_dtype=torch.bfloat16).to(dev)
     keys = tuple(parse_precomputekey(model))
     rng = np.random.default_rng(1)
-    store = DeviceGraphStore([synth.make_graph(rng, "zinc", 3, keys) for _ in range(24)], dev)
+    store = DeviceGraphStore([synth.make_graph(rng, "i2" if conv == "I2GNN" else "zinc", 3, keys) for _ in range(24)], dev)
+    assert (store.pair_parts is not None) == (conv == "I2GNN")
 
     def step(dd):
         model.zero_grad(set_to_none=True)
@@ -1867,6 +1869,37 @@ def test_fresh_collated_batch_trains_without_host_reads(dev, conv):
         torch.Tensor.item, torch.Tensor.tolist = oi, ol
     assert _ops.FETCHES[0] == f0 and not reads, (conv, _ops.FETCHES[0] - f0, reads)
     assert bool(torch.isfinite(loss))
+
+
+def test_collated_three_tuple_batch_brings_its_pooled_pattern(dev):
+    """the merged (i, j) pattern a collated I2-shape batch installs (per-graph runs of the sorted 3-tuples + offsets) == the one
+    `SparseTensor._reduce_to_sparse` plans by hash + sort + unique on the same indices (reference SpTensor.py:368-380): indices bit-exact,
+    pooled values and their gradient identical for sum / max / mean; the pooled pattern's grouping by root likewise (the 2-D pooling
+    that follows in OpPoolingSubg2D, SpOperator.py:496-522)"""
+    from pygho_amd import SparseTensor, synth
+    from pygho_amd.collate import DeviceGraphStore
+    key = "X___X___2___A___0"
+    rng = np.random.default_rng(2)
+    store = DeviceGraphStore([synth.make_graph(rng, "i2", 3, (key,)) for _ in range(20)], dev)
+    dd = store.collate([4, 11, 0, 19, 7, 7, 3])
+    X = dd["X"]
+    assert ("pool_sparse", (0, 1)) in X._cache()
+    n = int(dd["num_nodes"])
+    torch.manual_seed(0)
+    vals = torch.randn(X.nnz, 16, device=dev)
+    for op in ("sum", "max", "mean"):
+        got_in = vals.clone().requires_grad_(True)
+        ref_in = vals.clone().requires_grad_(True)
+        Xa = SparseTensor(X.indices, got_in, [n, n, n, 16], True)                      # the collated index object: installed plans
+        Xb = SparseTensor(X.indices.clone(), ref_in, [n, n, n, 16], True)              # a copy: planned by hash + sort + unique
+        pa, pb = getattr(Xa, op)([2], return_sparse=True), getattr(Xb, op)([2], return_sparse=True)
+        assert torch.equal(pa.indices, pb.indices) and torch.equal(pa.values, pb.values), op
+        da, db = getattr(pa, op)([1]), getattr(pb, op)([1])                              # (n, 16): pooled again over the second coordinate
+        assert torch.equal(da, db), op
+        w = torch.randn_like(da)
+        (da * w).sum().backward()
+        (db * w).sum().backward()
+        assert torch.equal(got_in.grad, ref_in.grad), op
 
 
 def _allocated_growth(make_and_use, warm=6, iters=24):

@@ -188,9 +188,10 @@ def test_row_reduction_without_a_device_count_form_refuses_slot_rows(dev, store)
     _ops.weight_grad_splitk(g, x, torch.float32)           # outside a slot context the capacity is just a row count
 
 
-@pytest.mark.parametrize("family", ["NGNN", "SSWL", "DSSGNN", "GNNAK", "SUN"])
+@pytest.mark.parametrize("family", ["NGNN", "SSWL", "DSSGNN", "GNNAK", "SUN", "I2GNN"])
 def test_captured_slot_step_serves_every_two_tuple_family(dev, family):
-    """the model of example/zinc.py:222-297 for each 2-tuple layer family (`pygho_amd.models.SpModel`: max subgraph pooling, mean graph
+    """(round 6: and the 3-tuple family I2GNN, whose merged (i, j) pooling pattern now comes with the slot)
+    the model of example/zinc.py:222-297 for each 2-tuple layer family (`pygho_amd.models.SpModel`: max subgraph pooling, mean graph
     pooling, cross-subgraph pooling / unpooling, GNNAK's and SUN's diagonal views): ONE captured step, 6 different batches, bit for bit
     against the eager loop on exactly sized batches -- loss, every gradient, the model state after AdamW.  (The diagonal positions and
     per-node tuple counts those two layers search by hash / bincount per batch come with the slot; hash-searching operators on a
@@ -207,7 +208,7 @@ def test_captured_slot_step_serves_every_two_tuple_family(dev, family):
         return SpModel(family, num_layer=2, hiddim=128, act_dtype=torch.bfloat16).to(dev)
     keys = tuple(parse_precomputekey(make()))
     rng = np.random.default_rng(9)
-    st = DeviceGraphStore([synth.make_graph(rng, "zinc", 3, keys) for _ in range(192)], dev)
+    st = DeviceGraphStore([synth.make_graph(rng, "i2" if family == "I2GNN" else "zinc", 3, keys) for _ in range(192)], dev)
     batches = _batches(st.num_graphs, g, 6, seed=13)
     warm = _batches(st.num_graphs, g, 1, seed=77)[0]
     ref_model = make()
