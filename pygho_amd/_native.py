@@ -55,7 +55,9 @@ PROTOTYPES = {
     "pygho_seg_scatter_mul_reduce": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, P]),
     "pygho_seg_scatter_count_aligned": (I, [P, P, P, P, P, P, P, P, P, L, P]),
     "pygho_seg_scatter_write_aligned": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, L, P]),
-    "pygho_seg_dual_limits": (I, [P, P]),
+    "pygho_seg_dual_limits": (I, [P, P, P]),
+    "pygho_seg_dual_tg_blocks": (I, [L, L, L, I]),
+    "pygho_seg_dual_tg": (I, [P, P, P, P, P, L, P, P, P, P, P, P, P, L, L, L, L, L, I, P]),
     "pygho_seg_dual": (I, [P, P, P, P, P, P, L, P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, P]),
     "pygho_seg_fused_limits": (I, [P, P, P, P]),
     "pygho_seg_fused_count": (I, [P, P, P, P, P, L, P]),

@@ -762,7 +762,11 @@ class _TupleBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, eps, act, rhs, plan, aggr, residual,
-                fold_momentum=None, rhs_lookup=None, chain=False, chain_x=False):
+                fold_momentum=None, rhs_lookup=None, chain=False, chain_x=False, table_master=None):
+        # `table_master`: the parameter behind the lookup table of `rhs_lookup` (rhs == cast(table_master)[index]).  When it is given
+        # and asks for a gradient, backward may hand the TABLE's gradient to it directly (the fused backward's table-gradient form)
+        # instead of the per-edge gradient of `rhs`, which then receives none from this block -- the same total for the leaf
+        ctx.has_master = table_master is not None
         require_device(x, w, rhs)
         x = x.contiguous()
         # master weights (usually f32) are cast to the activation dtype here, outside the autograd graph; their
@@ -812,6 +816,7 @@ class _TupleBlock(torch.autograd.Function):
             look = (rhs_lookup[0].detach(),) + plan.lookup(rhs_lookup[1])
             out, h = fused_forward(x, wc, bc, scale, shift, act, look[0], look[1], plan, fp, aggr, residual, bool(needs[10]))
             ctx.affine, ctx.look = None, look
+            ctx.look_index = rhs_lookup[1]
             ctx.save_for_backward(x, wc, None, h, rhs, bc, *saved)
             ctx.meta = (training, act, None if b is None else b.dtype, gamma is not None, beta is not None, plan, aggr, residual, w.dtype,
                         skinny)
@@ -843,6 +848,7 @@ class _TupleBlock(torch.autograd.Function):
         else:
             out = seg_gmr(plan.n_out, h, rhs_read, plan.fwd.seg_ptr, plan.c_fwd, d_idx, aggr, addend=x if residual else None)
         ctx.affine, ctx.look = affine, look
+        ctx.look_index = rhs_lookup[1] if rhs_lookup is not None else None
         ctx.save_for_backward(x, wc, pre, h if plan is not None else None, rhs, bc, *saved)
         ctx.meta = (training, act, None if b is None else b.dtype, gamma is not None, beta is not None, plan, aggr, residual, w.dtype,
                     skinny)
@@ -876,7 +882,7 @@ class _TupleBlock(torch.autograd.Function):
         res_g = g if residual else None
         if g_x is not None:
             res_g = g_x.contiguous() if res_g is None else res_g + g_x
-        g_rhs = None
+        g_rhs = g_master = None
         gh = g
         if plan is not None:
             scale = plan.fwd.inv_count if aggr == "mean" else None
@@ -884,21 +890,28 @@ class _TupleBlock(torch.autograd.Function):
             rhs_read = rhs
             if ctx.look is not None:
                 rhs_read, d_g = ctx.look[0], ctx.look[2]
-            use_dual = (rhs is not None and ctx.needs_input_grad[10] and ctx.look is not None and ctx.affine is None
+            use_tg = (rhs is not None and ctx.needs_input_grad[10] and ctx.look is not None and ctx.affine is None and ctx.has_master
+                      and ctx.needs_input_grad[18] and dual_tg_eligible(plan, g, h, rhs_read, scale, getattr(ctx, "look_index", None)))
+            use_dual = (not use_tg and rhs is not None and ctx.needs_input_grad[10] and ctx.look is not None and ctx.affine is None
                         and dual_eligible(plan, g, h, rhs_read, scale))
             if record_block_paths.active is not None and rhs is not None:
                 record_block_paths.active.append(
-                    {"backward": "seg_dual"} if use_dual else
+                    {"backward": "seg_dual (table gradient)"} if use_tg else {"backward": "seg_dual"} if use_dual else
                     {"backward": "seg_gmr + by_edge_product",
                      "backward_not_dual_because": _why_not_dual(plan, g, h, rhs_read if ctx.look is not None else None, scale, ctx.look,
                                                                 ctx.affine, bool(ctx.needs_input_grad[10]))})
-            if use_dual:
+            if use_tg:
+                # the same pass with the TABLE's gradient accumulated inside it: the per-edge gradient is never formed (what arrived
+                # for `rhs` from later blocks is passed on as it is)
+                gh, g_master = dual_backward_tg(plan, g, h, rhs_read, ctx.look[1], d_g)
+                g_rhs = g_chain
+            elif use_dual:
                 # both gradients of the aggregation from ONE pass over the forward message order (csrc/seg_dual.hip): g and H rows are
                 # fetched once for the by-tuple sum gh and the by-edge sum g_rhs -- the bits of the two launches below
                 gh, g_rhs = dual_backward(plan, g, h, rhs_read, d_g, addend=g_chain)
             else:
                 gh = seg_gmr(plan.n_lhs, g, rhs_read, p.seg_ptr, a_g, d_g if rhs is not None else None, "sum", scale)
-            if g_rhs is not None:
+            if g_rhs is not None or use_tg:
                 pass
             elif rhs is not None and ctx.needs_input_grad[10]:
                 p, a_g, c_g = plan.by_d()
@@ -940,12 +953,13 @@ class _TupleBlock(torch.autograd.Function):
         if gx is None and g_x is not None:
             gx = g_x
         return (gx, gw, gb, (s2 if has_gamma else None), (s1 if has_beta else None), None, None, None, None, None,
-                g_rhs, None, None, None, None, None, None, None)
+                g_rhs, None, None, None, None, None, None, None, g_master)
 
 
 def tuple_block(x: Tensor, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", act: str, rhs: Optional[Tensor] = None,
                 plan: Optional[MessagePlan] = None, aggr: str = "sum", residual: bool = False,
-                rhs_lookup: Optional[Tuple[Tensor, Tensor]] = None, chain: bool = False, chain_x: bool = False):
+                rhs_lookup: Optional[Tuple[Tensor, Tensor]] = None, chain: bool = False, chain_x: bool = False,
+                rhs_master: Optional[Tensor] = None):
     """fused Linear -> BatchNorm1d -> act (-> aggregation over `plan` with `rhs` (-> + x)); parameters are read
     from the stock modules (f32 master weights are cast to the activation dtype like autocast would)."""
     training = bn.training or bn.running_mean is None
@@ -954,8 +968,10 @@ def tuple_block(x: Tensor, lin: "torch.nn.Linear", bn: "torch.nn.BatchNorm1d", a
     if plan is None and rhs is not None:                # residual row operand (see _TupleBlock.forward)
         assert rhs.shape == (x.shape[0], lin.out_features) and rhs.dtype == x.dtype and rhs_lookup is None
     fold = _fold_momentum(bn)
+    if rhs_master is not None and (rhs_lookup is None or not rhs_master.requires_grad or tuple(rhs_master.shape) != tuple(rhs_lookup[0].shape)):
+        rhs_master = None
     res = _TupleBlock.apply(x, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                            bn.eps, act, rhs, plan, aggr, residual, fold, rhs_lookup, chain, chain_x)
+                            bn.eps, act, rhs, plan, aggr, residual, fold, rhs_lookup, chain, chain_x, rhs_master)
     out, mean, var = res[:3]
     _update_running(bn, mean, var, x.shape[0], folded=fold is not None)
     # (out[, rhs again when `chain`][, x again when `chain_x`]): see _TupleBlock.forward

@@ -68,13 +68,23 @@ template <> __device__ __forceinline__ du_f2_t du_pair<f16>(uint32_t w) {
 }
 __device__ __forceinline__ du_f2_t du_fma(du_f2_t a, du_f2_t b, du_f2_t c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <typename T, bool ADD, int ADL, bool TABF32>
-__global__ __launch_bounds__(512) void seg_dual_kernel(
+// TG ("table gradient"): the second operand is a lookup into a table whose looked-up rows are all < kDuTgRows (bond types): the by-edge
+// half does not form the per-edge gradient at all -- every lane group accumulates the gradient of the TABLE rows in registers
+// (kDuTgRows x 8 channels: g[a] * H[c] routed by a 0 / 1 factor per table row), the lane groups of a wavefront are summed by shuffles
+// once at the end, and every workgroup writes one f32 slab (`tg_out`, folded by pygho_sum_blocks).  No edge accumulators in LDS (8.3
+// instead of 19.8 KB per wavefront: three workgroups per CU instead of two), no read-modify-write per message, no edge rows written
+// and read back (0.2 GB per launch), no table_grad launch behind it.  The table gradient is then the f32 sum of exact products --
+// more accurate than, and therefore not bit-identical to, the per-edge route (which rounds every edge row to the storage type first).
+constexpr int kDuTgRows = 4;
+
+template <typename T, bool ADD, int ADL, bool TABF32, bool TG = false>
+__global__ __launch_bounds__(TG ? 256 : 512, TG ? 3 : 1) void seg_dual_kernel(
     T* __restrict__ out, T* __restrict__ gh, const T* __restrict__ addend, const T* __restrict__ lhs, const T* __restrict__ rhs,
     const T* __restrict__ table, int table_rows, const int4* __restrict__ chunks, const uint32_t* __restrict__ words,
     const int32_t* __restrict__ cgap, const int32_t* __restrict__ chunk0, const int2* __restrict__ blk_e,
     const int32_t* __restrict__ ptr_c, const int32_t* __restrict__ a_byc, const int32_t* __restrict__ look_byc, int n_blocks, int n_chunks,
-    int e_cap, uint32_t row_bytes, uint32_t lhs_bytes, uint32_t rhs_bytes, uint32_t out_bytes, uint32_t words_bytes, uint32_t ptr_bytes) {
+    int e_cap, uint32_t row_bytes, uint32_t lhs_bytes, uint32_t rhs_bytes, uint32_t out_bytes, uint32_t words_bytes, uint32_t ptr_bytes,
+    const int32_t* __restrict__ look_fwd = nullptr, float* __restrict__ tg_out = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char s_mem[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);            // channel slice of this wavefront
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
   const __amdgpu_buffer_rsrc_t lres = du_rsrc(lhs, lhs_bytes), rres = du_rsrc(rhs, rhs_bytes), ores = du_rsrc(out, out_bytes),
                                ares = du_rsrc(addend, ADD ? out_bytes : 0u), wres = du_rsrc(words, words_bytes),
                                hres = du_rsrc(gh, rhs_bytes), pres = du_rsrc(ptr_c, ptr_bytes), bares = du_rsrc(a_byc, words_bytes),
-                               blres = du_rsrc(look_byc, words_bytes);
+                               blres = du_rsrc(look_byc, words_bytes), lfres = du_rsrc(look_fwd, TG ? words_bytes : 0u);
   const du_u4_t zero4 = {0u, 0u, 0u, 0u};
   constexpr int kOob = (int)0x80000000;
 
@@ -108,12 +118,15 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
     }
     return l;
   };
-  int b = first_block_at(lo);
-  const int b_hi = first_block_at(hi);
-  if (b >= b_hi) return;
-  int pci = __builtin_amdgcn_readfirstlane(chunk0[b]);
-  const int ci_end = __builtin_amdgcn_readfirstlane(chunk0[b_hi]);
-  --b;
+  int b = 0, pci = lo, ci_end = hi;                      // TG: no per-block state, any contiguous share of the chunk list
+  if constexpr (!TG) {
+    b = first_block_at(lo);
+    const int b_hi = first_block_at(hi);
+    if (b >= b_hi) return;
+    pci = __builtin_amdgcn_readfirstlane(chunk0[b]);
+    ci_end = __builtin_amdgcn_readfirstlane(chunk0[b_hi]);
+    --b;
+  } else if (lo >= hi) return;
 
   for (uint32_t off = (uint32_t)lane * 16u; off < (uint32_t)e_cap * kDuAccPitch; off += kWave * 16u)
     *reinterpret_cast<du_u4_t*>(s_acc + off) = zero4;
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
   }
   if (lane < kDuLpm) *reinterpret_cast<du_u4_t*>(s_g + kDuRows * kDuStagePitch + lane * 16) = zero4;
 
-  struct Rows { du_u4_t g[2], x[2]; uint32_t w; int ba, bl, cp; };
+  struct Rows { du_u4_t g[2], x[2]; uint32_t w; int ba, bl, cp, lf; };
   struct Desc { int4 d; int gap; };
   auto issue = [&](Rows& rw, const Desc& dsc) {
     const int n = dsc.d.w & 0xff, a_rows = (dsc.d.w >> 8) & 0xff, c_rows = (dsc.d.w >> 16) & 0xff;
@@ -141,6 +154,8 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
     rw.ba = __builtin_amdgcn_raw_buffer_load_b32(bares, mo, 0, 0);
     rw.bl = __builtin_amdgcn_raw_buffer_load_b32(blres, mo, 0, 0);
     rw.cp = __builtin_amdgcn_raw_buffer_load_b32(pres, n > 0 && lane <= c_rows ? (int)((uint32_t)(dsc.d.z + lane) * 4u) : kOob, 0, 0);
+    if constexpr (TG) rw.lf = __builtin_amdgcn_raw_buffer_load_b32(lfres, mo, 0, 0);
+    else rw.lf = 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = j * 16 + q;
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
       *reinterpret_cast<du_u4_t*>(s_g + (uint32_t)(j * 16 + q) * kDuStagePitch + (uint32_t)p * 16u) = rw.g[j];
       *reinterpret_cast<du_u4_t*>(s_x + (uint32_t)(j * 16 + q) * kDuStagePitch + (uint32_t)p * 16u) = rw.x[j];
     }
-    s_w[lane] = rw.w;
+    s_w[lane] = TG ? ((rw.w & 0x3ffu) | ((uint32_t)rw.lf << 10)) : rw.w;        // TG: row offsets | table row of the message
     s_bw[lane] = (uint32_t)(rw.ba - dsc.d.y) | ((uint32_t)rw.bl << 8);      // row inside the g window | table row
     if (lane <= kDuRows) s_cp[lane] = rw.cp - dsc.d.x;                       // by-c positions relative to the chunk's first
   };
@@ -288,9 +303,53 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
         __builtin_amdgcn_raw_buffer_store_b128(zero4, hres, (int)((uint32_t)(c_lo + c_rows + r) * row_bytes + slice_off), 0, 0);
     }
   };
+  // TG: this lane group's share of the table gradient -- rows 0 .. kDuTgRows - 1 x its 8 channels, over all its messages
+  du_f2_t tg[kDuTgRows][4];
+#pragma unroll
+  for (int tt = 0; tt < kDuTgRows; ++tt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tg[tt][i] = du_f2_t{0.f, 0.f};
+  auto tg_trips = [&](int n) {
+    constexpr int TMAX = kDuMsgs / kDuMpt;
+    const int trips = (n + kDuMpt - 1) / kDuMpt;
+    uint32_t w[TMAX];
+    du_u4_t gv[TMAX], xv[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+      if (t < trips) w[t] = s_w[min(t * kDuMpt + q, n - 1)];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+      if (t < trips) {
+        gv[t] = *reinterpret_cast<const du_u4_t*>(s_g + (w[t] & 31u) * kDuStagePitch + (uint32_t)p * 16u);
+        xv[t] = *reinterpret_cast<const du_u4_t*>(s_x + ((w[t] >> 5) & 31u) * kDuStagePitch + (uint32_t)p * 16u);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+      if (t < trips) {
+        const bool valid = t * kDuMpt + q < n;
+        const uint32_t look = w[t] >> 10;
+        du_f2_t pr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pr[i] = du_pair<T>(gv[t][i]) * du_pair<T>(xv[t][i]);     // exact products
+#pragma unroll
+        for (int tt = 0; tt < kDuTgRows; ++tt) {
+          const float sel = (valid && look == (uint32_t)tt) ? 1.f : 0.f;
+          const du_f2_t s2 = du_f2_t{sel, sel};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) tg[tt][i] = du_fma(pr[i], s2, tg[tt][i]);
+        }
+      }
+    }
+  };
   auto compute = [&](const Desc& dsc) {
     const int n = dsc.d.w & 0xff;
     if (n == 0) return;
+    if constexpr (TG) {
+      by_tuple(dsc.d.z, (dsc.d.w >> 16) & 0xff, dsc.gap);
+      tg_trips(n);
+      return;
+    }
     if ((dsc.d.w >> 24) & 1) {
       do {
         ++b;
@@ -347,12 +406,14 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
     }
   };
 
+  // chunks of register prefetch: four (two wavefronts per SIMD: 256 registers each); TG: three (three wavefronts per SIMD: 168)
+  constexpr int DEPTH = TG ? 3 : 4;
   Rows r0, r1, r2, r3;
-  Desc d0 = next_desc(), d1 = next_desc(), d2 = next_desc(), d3 = next_desc();
+  Desc d0 = next_desc(), d1 = next_desc(), d2 = next_desc(), d3;
   issue(r0, d0);
   issue(r1, d1);
   issue(r2, d2);
-  issue(r3, d3);
+  if constexpr (DEPTH >= 4) { d3 = next_desc(); issue(r3, d3); }
 #ifdef PYGHO_DU_DESC_PREFETCH
   Desc pre = next_desc();                               // the record of the chunk after next travels while this one is multiplied
 #define PYGHO_DU_NEXT() pre; pre = next_desc()
@@ -371,8 +432,32 @@ __global__ __launch_bounds__(512) void seg_dual_kernel(
     PYGHO_DU_STEP(r0, d0)
     PYGHO_DU_STEP(r1, d1)
     PYGHO_DU_STEP(r2, d2)
-    PYGHO_DU_STEP(r3, d3)
+    if constexpr (DEPTH >= 4) PYGHO_DU_STEP(r3, d3)
 #undef PYGHO_DU_STEP
+  }
+  if constexpr (TG) {
+    // the 16 lane groups of the wavefront hold partial sums of the same (table row, channel) pairs: folded over the lane bits 2 .. 5 in
+    // a fixed order, then lane group 0 writes this wavefront's slice of the workgroup's slab [kDuTgRows][row elements]
+#pragma unroll
+    for (int tt = 0; tt < kDuTgRows; ++tt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float v = tg[tt][i][h];
+#pragma unroll
+          for (int step = 4; step < kWave; step <<= 1) v += __shfl_xor(v, step, kWave);
+          tg[tt][i][h] = v;
+        }
+    if (q == 0) {
+      const uint32_t elems = row_bytes / (uint32_t)sizeof(T);
+      float* dst = tg_out + ((size_t)blockIdx.x * kDuTgRows) * elems + (size_t)wv * (kDuSlice / sizeof(T)) + (size_t)p * 8u;
+#pragma unroll
+      for (int tt = 0; tt < kDuTgRows; ++tt) {
+        *reinterpret_cast<float4*>(dst + (size_t)tt * elems) = make_float4(tg[tt][0][0], tg[tt][0][1], tg[tt][1][0], tg[tt][1][1]);
+        *reinterpret_cast<float4*>(dst + (size_t)tt * elems + 4) = make_float4(tg[tt][2][0], tg[tt][2][1], tg[tt][3][0], tg[tt][3][1]);
+      }
+    }
   }
 }
 
@@ -424,13 +509,73 @@ int launch_dual(void* out, void* gh, const void* addend, const void* lhs, const 
   return check_launch("seg_dual");
 }
 
+// TG launch geometry: workgroups (= f32 slabs the caller allocates and folds)
+static int dual_tg_grid(int64_t n_chunks, int64_t rb, int64_t table_rows, size_t* lds_out) {
+  int cus = 256, max_lds = 160 * 1024;
+  {
+    int dev = 0, n = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && n > 0) max_lds = n;
+  }
+  const int waves = (int)(rb / kDuSlice);
+  const size_t lds = (size_t)waves * du_wave_lds(0, (int)table_rows, true);
+  if (lds_out) *lds_out = lds;
+  int per_cu = (int)((size_t)max_lds / lds);
+  if (per_cu > 3) per_cu = 3;                            // (launch bounds: three workgroups per CU)
+  if (per_cu < 1) per_cu = 1;
+  int64_t gx = (int64_t)cus * per_cu;
+  if (gx > n_chunks) gx = n_chunks;
+  return (int)(gx < 1 ? 1 : gx);
+}
+
+template <typename T>
+int launch_dual_tg(void* gh, float* tg_out, const void* lhs, const void* rhs, const void* table, int64_t table_rows, const int32_t* chunks,
+                   const uint32_t* words, const int32_t* cgap, const int32_t* ptr_c, const int32_t* a_byc, const int32_t* look_byc,
+                   const int32_t* look_fwd, int64_t n_chunks, int64_t n_msg, int64_t d, int64_t lhs_rows, int64_t rhs_rows, hipStream_t st) {
+  const int64_t rb = d * (int64_t)sizeof(T);
+  const int waves = (int)(rb / kDuSlice);
+  size_t lds = 0;
+  const int gx = dual_tg_grid(n_chunks, rb, table_rows, &lds);
+  hipLaunchKernelGGL((seg_dual_kernel<T, false, 1, true, true>), dim3(gx), dim3(waves * kWave), lds, st, (T*)nullptr, (T*)gh, (const T*)nullptr,
+                     (const T*)lhs, (const T*)rhs, (const T*)table, (int)table_rows, (const int4*)chunks, words, cgap, (const int32_t*)nullptr,
+                     (const int2*)nullptr, ptr_c, a_byc, look_byc, 0, (int)n_chunks, 0, (uint32_t)rb, (uint32_t)(lhs_rows * rb),
+                     (uint32_t)(rhs_rows * rb), 0u, (uint32_t)(n_msg * 4), (uint32_t)((rhs_rows + 1) * 4), look_fwd, tg_out);
+  return check_launch("seg_dual_tg");
+}
+
 }  // namespace pygho
 
 using namespace pygho;
 
-extern "C" int pygho_seg_dual_limits(int* max_edges_per_block, int* table_rows) {
+extern "C" int pygho_seg_dual_tg_blocks(int64_t n_chunks, int64_t d, int64_t table_rows, int dtype) {
+  if ((dtype != PYGHO_BF16 && dtype != PYGHO_F16) || d <= 0 || (d * 2) % kDuSlice != 0 || d * 2 > 256 || table_rows <= 0 || table_rows > kDuTabRows || n_chunks <= 0) return 0;
+  return dual_tg_grid(n_chunks, d * 2, table_rows, nullptr);
+}
+
+extern "C" int pygho_seg_dual_tg(void* gh, float* tg_out, const void* lhs, const void* rhs, const void* table, int64_t table_rows,
+                                 const int32_t* chunks, const uint32_t* words, const int32_t* cgap, const int32_t* ptr_c, const int32_t* a_byc,
+                                 const int32_t* look_byc, const int32_t* look_fwd, int64_t n_chunks, int64_t n_msg, int64_t d, int64_t lhs_rows,
+                                 int64_t rhs_rows, int dtype, void* stream) {
+  if (n_chunks < 0 || d <= 0 || lhs_rows <= 0 || rhs_rows <= 0 || table_rows <= 0) { set_error("seg_dual_tg: bad size"); return PYGHO_ERR_INVALID; }
+  if (n_chunks == 0) return PYGHO_OK;
+  if (!gh || !tg_out || !lhs || !rhs || !table || !chunks || !words || !cgap || !ptr_c || !a_byc || !look_byc || !look_fwd) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  if (dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("seg_dual_tg: bf16 / f16 only"); return PYGHO_ERR_UNSUPPORTED; }
+  const int64_t rb = d * 2;
+  if (rb % kDuSlice != 0 || rb > 256) { set_error("seg_dual_tg: row bytes %lld (multiples of 64 up to 256)", (long long)rb); return PYGHO_ERR_UNSUPPORTED; }
+  if (table_rows > kDuTabRows) { set_error("seg_dual_tg: %lld table rows (at most %d)", (long long)table_rows, kDuTabRows); return PYGHO_ERR_UNSUPPORTED; }
+  if ((((uintptr_t)gh | (uintptr_t)tg_out | (uintptr_t)lhs | (uintptr_t)rhs | (uintptr_t)table | (uintptr_t)chunks) % 16) != 0) { set_error("seg_dual_tg: operands must be 16-byte aligned"); return PYGHO_ERR_INVALID; }
+  const int64_t lim = (int64_t)1 << 31;
+  if (lhs_rows * rb >= lim || rhs_rows * rb >= lim || n_msg * 4 >= lim || n_msg < 0) { set_error("seg_dual_tg: operands of 2 GiB and more are not supported"); return PYGHO_ERR_UNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PYGHO_BF16) return launch_dual_tg<bf16>(gh, tg_out, lhs, rhs, table, table_rows, chunks, words, cgap, ptr_c, a_byc, look_byc, look_fwd, n_chunks, n_msg, d, lhs_rows, rhs_rows, st);
+  return launch_dual_tg<f16>(gh, tg_out, lhs, rhs, table, table_rows, chunks, words, cgap, ptr_c, a_byc, look_byc, look_fwd, n_chunks, n_msg, d, lhs_rows, rhs_rows, st);
+}
+
+extern "C" int pygho_seg_dual_limits(int* max_edges_per_block, int* table_rows, int* table_grad_rows) {
   if (max_edges_per_block) *max_edges_per_block = kDuMaxEdges;
   if (table_rows) *table_rows = kDuTabRows;
+  if (table_grad_rows) *table_grad_rows = kDuTgRows;
   return PYGHO_OK;
 }
 

@@ -83,7 +83,7 @@ def _views(mode: str, pool: str):
 GRAD_CHAIN_KEY = "_pygho_grad_chain"      # datadict key a model loop sets to {} for one forward pass (see _residual_update)
 
 
-ADJ_LOOKUP_KEY = "A_lookup"      # datadict key: (table, flat index) when A's values are table[index] (set by the input encoder)
+ADJ_LOOKUP_KEY = "A_lookup"      # datadict key: (table, flat index, the values tensor it describes, the table's master parameter or None)
 
 
 def _residual_update(layer, A: Rep, X: Rep, datadict: dict, adj_lookup=None) -> Rep:
@@ -116,8 +116,11 @@ def _residual_update(layer, A: Rep, X: Rep, datadict: dict, adj_lookup=None) -> 
                 lookup = ent
         if lookup is None:
             lookup = getattr(A.values, "_pygho_lookup", None)
-        if lookup is not None:
-            lookup = (lookup[0], lookup[1])
+    # (table, index[, .., the table's master parameter]): with the master the block may return the TABLE's gradient directly
+    master = None
+    if lookup is not None:
+        master = lookup[3] if len(lookup) > 3 else None
+        lookup = (lookup[0], lookup[1])
     if lookup is not None and not (lookup[0].dim() == 2 and lookup[0].dtype == X.values.dtype and lookup[1].numel() == A.nnz
                                    and lookup[0].shape[1] == X.values.shape[1]):
         lookup = None
@@ -132,7 +135,8 @@ def _residual_update(layer, A: Rep, X: Rep, datadict: dict, adj_lookup=None) -> 
         if link is not None and link[0] is A.values and link[1] == A.values._version:
             rhs = link[2]
     with torch.autocast("cuda", enabled=False):
-        vals = _ops.tuple_block(X.values, lin, bn, act, rhs=rhs, plan=plan, aggr=op.aggr, residual=True, rhs_lookup=lookup, chain=chain)
+        vals = _ops.tuple_block(X.values, lin, bn, act, rhs=rhs, plan=plan, aggr=op.aggr, residual=True, rhs_lookup=lookup, chain=chain,
+                                rhs_master=master if lookup is not None else None)
     if chain:
         vals, nxt = vals
         holder[id(A.values)] = (A.values, A.values._version, nxt)

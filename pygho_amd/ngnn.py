@@ -44,7 +44,8 @@ class IndexEmbedding(nn.Embedding):
         if idx.dim() == 1:
             # provenance for consumers that can index the (tiny, cache-resident) table themselves instead of streaming the
             # gathered rows: the fused layer block reads A's values this way (honn/Conv._residual_update)
-            out._pygho_lookup = (table, _flat_index(idx))
+            # (table, index, None, master): the master parameter lets a consumer return the TABLE's gradient directly
+            out._pygho_lookup = (table, _flat_index(idx), None, self.weight if self.padding_idx is None else None)
         return out
 
 
@@ -70,7 +71,7 @@ class InputEncoderSp(nn.Module):
         look = getattr(out["A"].values, "_pygho_lookup", None)
         if look is not None:
             # A's values are table[index]: said explicitly to the layers (honn.Conv.ADJ_LOOKUP_KEY) -- they read the table
-            out[ADJ_LOOKUP_KEY] = (look[0], look[1], out["A"].values)
+            out[ADJ_LOOKUP_KEY] = (look[0], look[1], out["A"].values, look[3] if len(look) > 3 else None)
         if defer_tuplefeat:
             w = self.tuplefeat_encoder.weight                 # the table itself: its 16-bit copy comes from the cast arena
             out["X_table"] = w if self.act_dtype is None else _ops.cast_param(w, self.act_dtype)

@@ -5,6 +5,7 @@ spspmm, scatter-reduce, row gather, spmm and the three-operand tuple initialisat
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import Optional, Tuple
 
@@ -784,19 +785,69 @@ def by_edge_product(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], scale: 
     return out
 
 
-def dual_eligible(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], table: Optional[Tensor], scale: Optional[Tensor]) -> bool:
+def dual_eligible(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], table: Optional[Tensor], scale: Optional[Tensor], tg: bool = False) -> bool:
     """both gradients of the aggregation in one pass (csrc/seg_dual.hip): an aligned scatter plan, 16-bit rows, a lookup table of at most
-    32 rows as the second operand, sum"""
+    32 rows as the second operand, sum.  `tg`: the table-gradient form (no edge accumulators: no limit on the edges per block)"""
     if not DUAL_BWD or table is None or h is None or scale is not None or not _scatter_eligible(plan, g, h, scale, None):
         return False
     sp = scatter_plan(plan, on_demand=True)
-    if sp is None or sp.cgap is None or sp.max_edges > 96 or table.dim() != 2 or table.shape[0] > 32 or table.dtype != g.dtype:
+    if sp is None or sp.cgap is None or table.dim() != 2 or table.shape[0] > 32 or table.dtype != g.dtype:
         return False
     if plan.n_lhs != h.shape[0] or table.shape[1] != g.shape[1] or h.shape[0] * g.shape[1] * g.element_size() >= (1 << 31):
+        return False
+    if tg:
+        return True
+    if sp.max_edges > 96:
         return False
     rb = g.shape[1] * g.element_size()
     per_wave = (sp.max_edges + 7) // 8 * 8 * 144 + 65 * 80 + 512 + 160 + (table.shape[0] + 1) * 80
     return (rb // 64) * per_wave <= 160 * 1024
+
+
+DUAL_TABLE_GRAD = os.environ.get("PYGHO_DUAL_TABLE_GRAD", "1") != "0"      # A/B switch: the table gradient straight from the fused backward
+
+
+def dual_tg_eligible(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], table: Optional[Tensor], scale: Optional[Tensor],
+                     index: Optional[Tensor]) -> bool:
+    """the fused backward in its table-gradient form (csrc/seg_dual.hip, TG): what `dual_eligible` asks for, rows of at most 256 bytes,
+    and an index tensor whose values are KNOWN to lie below the kernel's table-gradient rows (4: bond types) -- the bound the device
+    graph store attaches to the arrays it range-checked (`_pygho_value_bound`)"""
+    if not DUAL_TABLE_GRAD or index is None or not dual_eligible(plan, g, h, table, scale, tg=True):
+        return False
+    bound = getattr(index, "_pygho_value_bound", None)
+    if bound is None or bound[0] != index._version:
+        return False
+    rows = ctypes.c_int(0)
+    check(lib().pygho_seg_dual_limits(None, None, ctypes.byref(rows)), "seg_dual_limits")
+    return int(bound[1]) <= rows.value and g.shape[1] * g.element_size() <= 256
+
+
+def dual_backward_tg(plan: "MessagePlan", g: Tensor, h: Tensor, table: Tensor, look_fwd: Tensor, look_byc: Tensor):
+    """(gh, g_table) of out[a] = sum_{(a,c,d)} h[c] * table[look[d]]: gh as `dual_backward`; g_table (table rows, d) f32 = the gradient of
+    the TABLE, sum over the messages of g[a] * h[c] by looked-up row -- accumulated inside the kernel (exact products, f32 sums, one
+    slab per workgroup folded here), instead of the per-edge gradient + its chain of adds + `table_grad`"""
+    sp = scatter_plan(plan, on_demand=True)
+    dev = require_device(g, h, table, look_fwd, look_byc)
+    g, h, table = g.contiguous(), h.contiguous(), table.contiguous()
+    d = g.shape[1]
+    pc, a_byc, _ = plan.by_c()
+    gh = (torch.empty if sp.covers_c else torch.zeros)((plan.n_lhs, d), dtype=g.dtype, device=dev)
+    rows = ctypes.c_int(0)
+    check(lib().pygho_seg_dual_limits(None, None, ctypes.byref(rows)), "seg_dual_limits")
+    nblk = int(lib().pygho_seg_dual_tg_blocks(sp.n_chunks, d, table.shape[0], dtype_code(g)))
+    assert nblk > 0
+    slabs = torch.empty((nblk, rows.value * d), dtype=torch.float32, device=dev)      # (every workgroup has a chunk: nblk <= n_chunks)
+    es = g.element_size()
+    nbytes = es * d * (g.shape[0] + h.shape[0] + plan.n_lhs) + 16 * plan.m + 4 * (plan.n_lhs + 1) + 20 * sp.n_chunks
+    name = f"seg_dual[{str(g.dtype).split('.')[-1]},sum,table]"
+    _timed(name, nbytes, dev, lambda: check(lib().pygho_seg_dual_tg(
+        ptr(gh), ptr(slabs), ptr(g), ptr(h), ptr(table), table.shape[0], ptr(sp.chunks), ptr(sp.words), ptr(sp.cgap), ptr(pc.seg_ptr),
+        ptr(a_byc), ptr(look_byc), ptr(look_fwd), sp.n_chunks, plan.m, d, g.shape[0], h.shape[0], dtype_code(g), stream_ptr(dev)), "seg_dual_tg"))
+    from .blocks import sum_blocks
+    part = sum_blocks(slabs).reshape(rows.value, d)
+    t = table.shape[0]
+    g_table = part[:t] if t <= rows.value else torch.nn.functional.pad(part, (0, 0, 0, t - rows.value))
+    return gh, g_table
 
 
 def dual_backward(plan: "MessagePlan", g: Tensor, h: Tensor, table: Tensor, look_byc: Tensor, addend: Optional[Tensor] = None):

@@ -190,6 +190,16 @@ def test_dual_at_baseline_size_vs_host_oracle(dev, baseline_batch, dtype):
     b32 = th.float()[dd["A"].values.cpu().long()]
     want_gh = P.spspmm_values_chunked(gh_.float(), b32, acd_h[1], acd_h[0], acd_h[2], nt, "sum").to(dtype)
     sums = P.spspmm_values_chunked(gh_.float(), hh.float(), acd_h[2], acd_h[0], acd_h[1], ne, "sum")
+    # the table-gradient form: gh the same bits; the table's gradient against the port's f32 sums by looked-up row (another summation
+    # order: f32 accuracy)
+    idx = _ops.flat_index(dd["A"].values)
+    if _ops.dual_tg_eligible(plan, g, h, table, None, idx):
+        look_fwd = plan.lookup(idx)[0]
+        tg_gh, tg_gt = _ops.dual_backward_tg(plan, g, h, table, look_fwd, look_byc)
+        assert torch.equal(tg_gh.cpu(), want_gh), "table-gradient form: by-tuple gradient"
+        look_of_msg = dd["A"].values.cpu().long()[acd_h[2]]
+        want_gt = P.spspmm_values_chunked(gh_.float(), hh.float(), look_of_msg, acd_h[0], acd_h[1], 16, "sum")
+        torch.testing.assert_close(tg_gt.cpu(), want_gt, rtol=2e-4, atol=2e-4 * float(want_gt.abs().max()))
     for chained in (False, True):
         got_gh, got_gr = _ops.dual_backward(plan, g, h, table, look_byc, addend=addend if chained else None)
         want_gr = ((ah.float() + sums) if chained else sums).to(dtype)
@@ -211,6 +221,11 @@ def _train_step(model, dd):
 
 
 def test_training_step_with_and_without_the_dual_backward_is_bit_identical(dev, small_plans):
+    """three runs of the same two steps from the same state: the two launches (PYGHO_DUAL_BWD=0), the fused backward with the per-edge
+    gradient (PYGHO_DUAL_TABLE_GRAD=0) and the fused backward in its table-gradient form (shipped).  Loss and EVERY gradient of the first
+    two agree bit for bit; the third agrees bit for bit except for the edge-feature embedding table, whose gradient it accumulates
+    itself -- f32 sums of exact products instead of per-edge rows rounded to bf16 and chained through six layers: closer to an f64
+    evaluation, compared with a tolerance"""
     from pygho_amd import _ops, synth
     from pygho_amd.collate import DeviceGraphStore
     from pygho_amd.ngnn import SpModel
@@ -220,26 +235,72 @@ def test_training_step_with_and_without_the_dual_backward_is_bit_identical(dev, 
     torch.manual_seed(1)
     model = SpModel(1, 3, 128, act_dtype=torch.bfloat16).to(dev)
     model.train()
+    names_p = [k for k, _ in model.named_parameters()]
+    ea_name = "data_encoder.ea_encoder.weight"
+    assert ea_name in names_p
     state = {k: v.clone() for k, v in model.state_dict().items()}
     timer = _ops.LaunchTimer()
-    old = _ops.DUAL_BWD
+    old = (_ops.DUAL_BWD, _ops.DUAL_TABLE_GRAD)
     try:
         res = {}
-        for dual in (True, False):
-            _ops.DUAL_BWD = dual
+        for mode, (dual, tg) in (("two launches", (False, False)), ("dual", (True, False)), ("dual + table gradient", (True, True))):
+            _ops.DUAL_BWD, _ops.DUAL_TABLE_GRAD = dual, tg
             model.load_state_dict(state)
             out = []
             with timer:
                 for seed in (0, 1):
                     ids = np.random.default_rng(seed).permutation(160)[:96]
                     out.append(_train_step(model, store.collate(ids)))
-            res[dual] = out
+            res[mode] = out
     finally:
-        _ops.DUAL_BWD = old
+        _ops.DUAL_BWD, _ops.DUAL_TABLE_GRAD = old
     torch.cuda.synchronize()
     names = set(timer.summary())
-    assert any(k.startswith("seg_dual[") for k in names), names
-    for (l1, g1), (l0, g0) in zip(res[True], res[False]):
-        assert torch.equal(l1, l0)
-        for a, b in zip(g1, g0):
-            assert torch.equal(a, b)
+    assert any(k.startswith("seg_dual[") and "table" not in k for k in names) and any(k.endswith(",table]") for k in names), names
+    for step in range(2):
+        l0, g0 = res["two launches"][step]
+        for mode in ("dual", "dual + table gradient"):
+            l1, g1 = res[mode][step]
+            assert torch.equal(l1, l0), mode
+            for name, a, b in zip(names_p, g1, g0):
+                if name == ea_name and mode.endswith("table gradient"):
+                    scale = float(b.abs().max())
+                    torch.testing.assert_close(a, b, rtol=0, atol=2.0 ** -7 * scale, msg=f"{mode}: {name}")
+                    assert not torch.equal(a, b)                 # it IS another (more accurate) summation
+                else:
+                    assert torch.equal(a, b), (mode, name)
+
+
+def test_table_gradient_form_vs_f64_and_the_by_tuple_bits(dev, small_plans):
+    """`dual_backward_tg` on a store-collated batch (the index carries the store's value bound): gh has the bits of the by-tuple launch;
+    the table gradient equals sum_m [look_m = t] g[a_m] * h[c_m] evaluated in f64 to f32 accuracy -- and is CLOSER to it than the route it
+    replaces (per-edge gradient rounded to bf16, then `table_grad`)"""
+    from pygho_amd import _ops, synth
+    from pygho_amd.collate import DeviceGraphStore
+    rng = np.random.default_rng(3)
+    store = DeviceGraphStore([synth.make_graph(rng, "zinc", 3, (KEY,)) for _ in range(200)], dev)
+    dd = store.collate(np.arange(200))
+    acd = dd[KEY + "___acd"]
+    nt, ne, d = dd["X"].nnz, dd["A"].nnz, 128
+    plan = _ops.message_plan(acd, nt, nt, ne)
+    idx = _ops.flat_index(dd["A"].values)
+    torch.manual_seed(0)
+    g = torch.randn(nt, d, device=dev).to(torch.bfloat16)
+    h = torch.randn(nt, d, device=dev).to(torch.bfloat16)
+    table = torch.randn(16, d, device=dev).to(torch.bfloat16)
+    look_fwd, look_byc = plan.lookup(idx)
+    assert _ops.dual_tg_eligible(plan, g, h, table, None, idx)
+    gh, gt = _ops.dual_backward_tg(plan, g, h, table, look_fwd, look_byc)
+    pc, a_byc, _ = plan.by_c()
+    assert torch.equal(gh, _ops.seg_gmr(nt, g, table, pc.seg_ptr, a_byc, look_byc, "sum"))
+    prod = g.double()[acd[0]] * h.double()[acd[1]]
+    want = torch.zeros(16, d, dtype=torch.float64, device=dev).index_add_(0, dd["A"].values[acd[2]], prod)
+    scale = float(want.abs().max())
+    err_new = float((gt.double() - want).abs().max()) / scale
+    old_route = _ops.table_grad(_ops.by_edge_product(plan, g, h, None), idx, 16)
+    err_old = float((old_route.double() - want).abs().max()) / scale
+    print(f"table gradient: max error / max |value| new {err_new:.2e}, per-edge route {err_old:.2e}")
+    assert err_new < 1e-5 and err_new <= err_old
+    assert bool((gt[4:] == 0).all())
+    # an index without the store's bound keeps the per-edge form
+    assert not _ops.dual_tg_eligible(plan, g, h, table, None, idx.clone())

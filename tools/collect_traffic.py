@@ -30,7 +30,7 @@ def kernel_source_hash(files):
 KERNELS = {"fast": ("seg_gmr_fast_kernel<pygho::bf16, 0, 0, false, true, false, false, 0>",     # <T, SUM, BOTH, !SCALED, OFF32, !OUTF32, !THIRD, no act>
                     "seg_gmr_fast_kernel<bf16,SUM,BOTH>", ("common.h", "seg_reduce.hip")),
            "fused": ("seg_fused_fwd_kernel<pygho::bf16, 2, false", "seg_fused_fwd_kernel<bf16,SILU,SUM>", ("common.h", "seg_fused.hip")),
-           "dual": ("seg_dual_kernel<pygho::bf16, true", "seg_dual_kernel<bf16,SUM>", ("common.h", "seg_dual.hip"))}
+           "dual": ("seg_dual_kernel<pygho::bf16", "seg_dual_kernel<bf16,SUM>", ("common.h", "seg_dual.hip"))}
 WHICH = sys.argv[8] if len(sys.argv) > 8 else "fast"
 KERNEL, REPORTED, SOURCES = KERNELS[WHICH]
 FETCH_CORRECTION = 1.97
