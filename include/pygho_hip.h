@@ -682,6 +682,9 @@ int pygho_weight_grad(float* dw_ws, float* colsum_ws, const void* g, const void*
 /* out[j] = sum over b < n_blocks of in[b * n + j]: folds the per-workgroup partial results of the kernels above (weight
  * gradient slabs, column sums) deterministically. */
 int pygho_sum_blocks(float* out, const float* in, int64_t n_blocks, int64_t n, void* stream);
+/* the same fold into the head of a longer array: out[j] for n <= j < n_out is written as zero (the table gradient of
+ * pygho_seg_dual_tg covers the first table_grad_rows rows of a (rows, d) embedding gradient: fold + zero rows in one launch). */
+int pygho_sum_blocks_pad(float* out, const float* in, int64_t n_blocks, int64_t n, int64_t n_out, void* stream);
 /* the reduction half of pygho_bn_act_bwd alone: sum_dz, sum_dz_xhat (c floats each). */
 int pygho_bn_act_bwd_sums(float* sum_dz, float* sum_dz_xhat, const void* x, const void* gy, const float* mean,
                           const float* invstd, const float* w, const float* b, int64_t m, int64_t c, int act,

@@ -124,6 +124,7 @@ PROTOTYPES = {
     "pygho_bn_bwd_linear_dw": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, L, P]),
     "pygho_weight_grad": (I, [P, P, P, P, L, L, L, I, L, P]),
     "pygho_sum_blocks": (I, [P, P, L, L, P]),
+    "pygho_sum_blocks_pad": (I, [P, P, L, L, L, P]),
     "pygho_bn_act_bwd_sums": (I, [P, P, P, P, P, P, P, P, L, L, I, P, I, P]),
     "pygho_rowblock_linear_bn_act": (I, [P, P, P, P, P, P, P, L, L, I, I, P]),
     "pygho_rowblock_linear_bwd_sums": (I, [P, P, P, P, P, P, P, P, P, P, L, L, I, P, I, P]),

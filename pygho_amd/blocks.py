@@ -376,6 +376,7 @@ class _CastParam(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, dtype):
         ctx.src_dtype = p.dtype
+        ctx.set_materialize_grads(False)            # (no gradient for the copy = none for the parameter: not a zero tensor)
         # a NEW tensor object every call: autograd writes this node into the returned object, and the arena's own view object
         # would carry it -- and the AccumulateGrad node behind it, with the stream it was created on -- into the next iteration
         # (a HIP graph capture after eager steps then pulled the eager stream into the capture and crashed in hipStreamEndCapture)
@@ -383,7 +384,7 @@ class _CastParam(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(ctx.src_dtype), None
+        return (None if g is None else g.to(ctx.src_dtype)), None
 
 
 def cast_param(p: Tensor, dtype: torch.dtype) -> Tensor:
@@ -586,12 +587,19 @@ def rowblock_linear_bwd_apply(x: Tensor, wl: Tensor, bias: Optional[Tensor], gh:
     return gpre, cs
 
 
-def sum_blocks(partials: Tensor) -> Tensor:
-    """(n_blocks, ...) f32 per-workgroup partial results -> their sum over the first dim (one deterministic kernel)."""
+def sum_blocks(partials: Tensor, out_numel: Optional[int] = None) -> Tensor:
+    """(n_blocks, ...) f32 per-workgroup partial results -> their sum over the first dim (one deterministic kernel).  With
+    `out_numel` >= the slab size the result is a flat array of that length whose tail is zero (written by the same launch)."""
     dev = require_device(partials)
     assert partials.dtype == torch.float32 and partials.is_contiguous()
-    out = torch.empty(partials.shape[1:], dtype=torch.float32, device=dev)
-    check(lib().pygho_sum_blocks(ptr(out), ptr(partials), partials.shape[0], out.numel(), stream_ptr(dev)), "sum_blocks")
+    if out_numel is None:
+        out = torch.empty(partials.shape[1:], dtype=torch.float32, device=dev)
+        check(lib().pygho_sum_blocks(ptr(out), ptr(partials), partials.shape[0], out.numel(), stream_ptr(dev)), "sum_blocks")
+        return out
+    n = int(torch.Size(partials.shape[1:]).numel())
+    assert out_numel >= n
+    out = torch.empty((out_numel,), dtype=torch.float32, device=dev)
+    check(lib().pygho_sum_blocks_pad(ptr(out), ptr(partials), partials.shape[0], n, out_numel, stream_ptr(dev)), "sum_blocks_pad")
     return out
 
 

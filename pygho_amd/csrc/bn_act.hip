@@ -522,7 +522,7 @@ extern "C" int pygho_bn_bwd_fold_sums(float* sum_a, float* sum_b, const float* w
 #endif
 namespace pygho {
 __global__ __launch_bounds__(kBlock) void sum_blocks_kernel(float* __restrict__ out, const float* __restrict__ in, int64_t nblk,
-                                                            int64_t n) {
+                                                            int64_t n, int64_t n_out) {
   __shared__ float red[kBlock / kWave][kWave];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t j = (int64_t)blockIdx.x * kWave + lane;
@@ -551,6 +551,7 @@ __global__ __launch_bounds__(kBlock) void sum_blocks_kernel(float* __restrict__ 
   red[wave][lane] = acc[0];
   __syncthreads();
   if (wave == 0 && j < n) out[j] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  else if (wave == 0 && j < n_out) out[j] = 0.f;       // (pygho_sum_blocks_pad: the entries behind the sum)
 }
 }  // namespace pygho
 
@@ -558,6 +559,14 @@ extern "C" int pygho_sum_blocks(float* out, const float* in, int64_t n_blocks, i
   if (n_blocks < 0 || n < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
   if (n == 0) return PYGHO_OK;
   if (!out || (n_blocks > 0 && !in)) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
-  hipLaunchKernelGGL(pygho::sum_blocks_kernel, dim3((unsigned)ceil_div(n, kWave)), dim3(kBlock), 0, (hipStream_t)stream, out, in, n_blocks, n);
+  hipLaunchKernelGGL(pygho::sum_blocks_kernel, dim3((unsigned)ceil_div(n, kWave)), dim3(kBlock), 0, (hipStream_t)stream, out, in, n_blocks, n, n);
   return check_launch("sum_blocks");
+}
+
+extern "C" int pygho_sum_blocks_pad(float* out, const float* in, int64_t n_blocks, int64_t n, int64_t n_out, void* stream) {
+  if (n_blocks < 0 || n < 0 || n_out < n) { set_error("negative size, or n_out < n"); return PYGHO_ERR_INVALID; }
+  if (n_out == 0) return PYGHO_OK;
+  if (!out || (n_blocks > 0 && n > 0 && !in)) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  hipLaunchKernelGGL(pygho::sum_blocks_kernel, dim3((unsigned)ceil_div(n_out, kWave)), dim3(kBlock), 0, (hipStream_t)stream, out, in, n_blocks, n, n_out);
+  return check_launch("sum_blocks_pad");
 }

@@ -123,6 +123,16 @@ static_assert(RlFwdGeom<128>::TILE == kRlTile && RlFwdGeom<64>::TILE == kRlTile,
 static_assert(RlFwdGeom<256>::lds_bytes <= 160 * 1024 && 2 * RlFwdGeom<128>::lds_bytes <= 160 * 1024 && 2 * RlFwdGeom<64>::lds_bytes <= 160 * 1024,
               "the row-block kernels' LDS (W + stage + constants) must fit a CU's 160 KB at the workgroups per CU they are launched for");
 
+// sweep direction of the row tiles per epilogue (bit EPI of PYGHO_RL_REV set: the pass walks the tiles from the last to the first) and
+// of bn_bwd_linear_dw (PYGHO_DW_REV): a measurement switch -- whether a pass that follows an ascending sweep over the same rows finds
+// their tail in the memory-side cache (tools/probe_mall_order.hip, profiles/r06_mall_order_probe.txt)
+#ifndef PYGHO_RL_REV
+#define PYGHO_RL_REV 0
+#endif
+#ifndef PYGHO_DW_REV
+#define PYGHO_DW_REV 0
+#endif
+#define RL_PT(t) (((PYGHO_RL_REV >> EPI) & 1) ? n_tiles - 1 - (t) : (t))
 template <typename T, int D, int EPI = RL_STORE, int ACT = 0>
 __global__ __launch_bounds__(RlFwdGeom<D>::THREADS, RlFwdGeom<D>::WG_PER_CU) void rowblock_linear_kernel(T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ wl,
                                                                     const T* __restrict__ bias, const T* __restrict__ addend,
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(RlFwdGeom<D>::THREADS, RlFwdGeom<D>::WG_PER_CU) voi
 
   uint4 fb[G::MB][G::KS];                                    // `in` fragments of the current tile
   auto load_tile = [&](int64_t tile, uint4 (&dst)[G::MB][G::KS]) {
-    const int64_t base = tile * G::TILE + wave * G::RPW;
+    const int64_t base = RL_PT(tile) * G::TILE + wave * G::RPW;
 #pragma unroll
     for (int mb = 0; mb < G::MB; ++mb) {
       int64_t row = base + mb * 16 + r16;
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(RlFwdGeom<D>::THREADS, RlFwdGeom<D>::WG_PER_CU) voi
     if constexpr (G::REG_PREFETCH) load_tile(tn, nxt);                // prefetch: in flight during this tile's MFMAs and epilogue
     uint4 cgh[G::RPW / EROWS];  // RL_BWD_SUMS / _APPLY: this tile's gh chunks (row-contiguous), in flight during the MFMAs
     if constexpr (EPI == RL_BWD_SUMS || EPI == RL_BWD_APPLY) {
-      const int64_t b0 = tile * G::TILE + wave * G::RPW;
+      const int64_t b0 = RL_PT(tile) * G::TILE + wave * G::RPW;
 #pragma unroll
       for (int it = 0; it < G::RPW / EROWS; ++it) {
         int64_t row = b0 + it * EROWS + erow0;
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(RlFwdGeom<D>::THREADS, RlFwdGeom<D>::WG_PER_CU) voi
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- epilogue on row-contiguous 16-B chunks ----------------------------------------------------------------
-    const int64_t base = tile * G::TILE + wave * G::RPW;
+    const int64_t base = RL_PT(tile) * G::TILE + wave * G::RPW;
 #pragma unroll
     for (int it = 0; it < G::RPW / EROWS; ++it) {
       const int rl = it * EROWS + erow0;
@@ -631,6 +641,7 @@ __device__ __forceinline__ int rl_wt_row(int k) { return (k & ~12) | ((k & 4) <<
 // holds k = 32 ks + 8 q + 0..7 of row m = r16 / of output channel n = 16 nb + r16), so the result has the forward's bits.  W sits
 // in LDS as W^T (rows k) for the gx product: the 8 consecutive k of a fixed n are a COLUMN there, delivered by two transpose
 // reads (rows 8 q + 0..3 and 8 q + 4..7 of the 32-row step).  One HBM stream (pre) less per row: 4 instead of 5.
+#define DW_PT(t) (PYGHO_DW_REV ? n_tiles - 1 - (t) : (t))
 template <typename T, int D, int ACT, bool RECOMP = false>
 __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __restrict__ gx, const T* __restrict__ pre,
                                                                          const T* __restrict__ gh, const T* __restrict__ x,
@@ -701,7 +712,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
 
   uint4 cy[EIT], cg[EIT];
   auto load_tile = [&](int64_t tile, uint4 (&y)[EIT], uint4 (&g)[EIT]) {
-    const int64_t base = tile * kDwTile + wave * kDwRowsPerWave;
+    const int64_t base = DW_PT(tile) * kDwTile + wave * kDwRowsPerWave;
 #pragma unroll
     for (int it = 0; it < EIT; ++it) {
       int64_t row = base + it * EROWS + erow0;
@@ -718,7 +729,7 @@ __global__ __launch_bounds__(kDwThreads, 2) void bn_bwd_linear_dw_kernel(T* __re
   if (tile < n_tiles) load_tile(tile, cy, cg);
   __syncthreads();                                       // W^T staged
   for (; tile < n_tiles; tile += gridDim.x) {
-    const int64_t base = tile * kDwTile + wave * kDwRowsPerWave;
+    const int64_t base = DW_PT(tile) * kDwTile + wave * kDwRowsPerWave;
     uint4 cx[EIT];                                       // x rows of THIS tile
     if constexpr (RECOMP && PYGHO_DW_PREFETCH_X) {
 #pragma unroll

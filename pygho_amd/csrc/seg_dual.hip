@@ -28,6 +28,12 @@ constexpr int kDuStagePitch = kDuSlice + 16;
 constexpr int kDuMaxPhase = 3;
 constexpr int kDuMaxEdges = 96;                   // the flush of a block's edge rows keeps 6 x 16 addend rows in registers (255 edges: spills)
 constexpr int kDuTabRows = 32;
+#ifndef PYGHO_DU_LD_AUX      // cache policy bits of the g / H row loads and of the gH stores (0 default, 2 = nt: measurement switches)
+#define PYGHO_DU_LD_AUX 0
+#endif
+#ifndef PYGHO_DU_ST_AUX
+#define PYGHO_DU_ST_AUX 0
+#endif
 #ifndef PYGHO_DU_BURST
 #define PYGHO_DU_BURST 3
 #endif
@@ -159,8 +165,8 @@ __global__ __launch_bounds__(TG ? 256 : 512, TG ? 3 : 1) void seg_dual_kernel(
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = j * 16 + q;
-      rw.g[j] = __builtin_amdgcn_raw_buffer_load_b128(lres, r < a_rows ? (int)((uint32_t)(dsc.d.y + r) * row_bytes + slice_off) : kOob, 0, 0);
-      rw.x[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, r < c_rows ? (int)((uint32_t)(dsc.d.z + r) * row_bytes + slice_off) : kOob, 0, 0);
+      rw.g[j] = __builtin_amdgcn_raw_buffer_load_b128(lres, r < a_rows ? (int)((uint32_t)(dsc.d.y + r) * row_bytes + slice_off) : kOob, 0, PYGHO_DU_LD_AUX);
+      rw.x[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, r < c_rows ? (int)((uint32_t)(dsc.d.z + r) * row_bytes + slice_off) : kOob, 0, PYGHO_DU_LD_AUX);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(TG ? 256 : 512, TG ? 3 : 1) void seg_dual_kernel(
         }
       }
       const float sum[8] = {acc[0][0], acc[0][1], acc[1][0], acc[1][1], acc[2][0], acc[2][1], acc[3][0], acc[3][1]};
-      if (r < c_rows) __builtin_amdgcn_raw_buffer_store_b128(du_pack<T>(sum), hres, (int)((uint32_t)(c_lo + r) * row_bytes + slice_off), 0, 0);
+      if (r < c_rows) __builtin_amdgcn_raw_buffer_store_b128(du_pack<T>(sum), hres, (int)((uint32_t)(c_lo + r) * row_bytes + slice_off), 0, PYGHO_DU_ST_AUX);
     }
     if (gap != 0) {                                      // rows without a message that this chunk owns (rare): zeros
       const int before = gap & 0xffff, after = (gap >> 16) & 0xffff;

@@ -32,6 +32,15 @@ typedef __attribute__((ext_vector_type(8))) _Float16 fu_f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float fu_f32x4_t;
 typedef uint32_t fu_u4_t __attribute__((ext_vector_type(4)));
 
+#ifndef PYGHO_FU_LD_AUX      // cache policy bits of the row loads / the H stores / the out stores (0 default, 2 = nt: measurement switches)
+#define PYGHO_FU_LD_AUX 0
+#endif
+#ifndef PYGHO_FU_STH_AUX
+#define PYGHO_FU_STH_AUX 0
+#endif
+#ifndef PYGHO_FU_STO_AUX
+#define PYGHO_FU_STO_AUX 0
+#endif
 #ifndef PYGHO_FU_MSGS
 #define PYGHO_FU_MSGS 64
 #endif
@@ -284,8 +293,8 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
       // the window is staged cooperatively, so any partition does: this wavefront takes 8 WHOLE rows (16 lanes x 16 B = one row: full
       // cache lines per request instead of four wavefronts asking for a quarter of every row)
       const int xr = wv * 8 + j * 4 + (lane >> 4);
-      rw.xs[j] = __builtin_amdgcn_raw_buffer_load_b128(xres, xr < c_rows ? (int)((uint32_t)(dsc.d.z + xr) * kFuRowBytes + (uint32_t)(lane & 15) * 16u) : kOob, 0, 0);
-      rw.res[j] = __builtin_amdgcn_raw_buffer_load_b128(xres, residual && r < a_rows ? (int)((uint32_t)(dsc.d.y + r) * kFuRowBytes + slice_off) : kOob, 0, 0);
+      rw.xs[j] = __builtin_amdgcn_raw_buffer_load_b128(xres, xr < c_rows ? (int)((uint32_t)(dsc.d.z + xr) * kFuRowBytes + (uint32_t)(lane & 15) * 16u) : kOob, 0, PYGHO_FU_LD_AUX);
+      rw.res[j] = __builtin_amdgcn_raw_buffer_load_b128(xres, residual && r < a_rows ? (int)((uint32_t)(dsc.d.y + r) * kFuRowBytes + slice_off) : kOob, 0, PYGHO_FU_LD_AUX);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
           const float4 h1 = *reinterpret_cast<const float4*>(s_hf + r * kFuFPitch + p * 32 + 16);
           const float hv8[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
           const uint4 hp = V::pack(hv8);
-          __builtin_amdgcn_raw_buffer_store_b128(fu_u4_t{hp.x, hp.y, hp.z, hp.w}, hres, (int)((uint32_t)(c_lo + r) * kFuRowBytes + slice_off), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(fu_u4_t{hp.x, hp.y, hp.z, hp.w}, hres, (int)((uint32_t)(c_lo + r) * kFuRowBytes + slice_off), 0, PYGHO_FU_STH_AUX);
         }
       }
     }
@@ -450,7 +459,7 @@ __global__ __launch_bounds__(kBlock, PYGHO_FU_WG_PER_CU) void seg_fused_fwd_kern
       }
       if (r < a_rows) {
         const uint4 o = V::pack(sum);
-        __builtin_amdgcn_raw_buffer_store_b128(fu_u4_t{o.x, o.y, o.z, o.w}, ores, (int)((uint32_t)(a_lo + r) * kFuRowBytes + slice_off), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(fu_u4_t{o.x, o.y, o.z, o.w}, ores, (int)((uint32_t)(a_lo + r) * kFuRowBytes + slice_off), 0, PYGHO_FU_STO_AUX);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -844,10 +844,9 @@ def dual_backward_tg(plan: "MessagePlan", g: Tensor, h: Tensor, table: Tensor, l
         ptr(gh), ptr(slabs), ptr(g), ptr(h), ptr(table), table.shape[0], ptr(sp.chunks), ptr(sp.words), ptr(sp.cgap), ptr(pc.seg_ptr),
         ptr(a_byc), ptr(look_byc), ptr(look_fwd), sp.n_chunks, plan.m, d, g.shape[0], h.shape[0], dtype_code(g), stream_ptr(dev)), "seg_dual_tg"))
     from .blocks import sum_blocks
-    part = sum_blocks(slabs).reshape(rows.value, d)
     t = table.shape[0]
-    g_table = part[:t] if t <= rows.value else torch.nn.functional.pad(part, (0, 0, 0, t - rows.value))
-    return gh, g_table
+    part = sum_blocks(slabs, max(t, rows.value) * d).reshape(-1, d)          # fold + the zero rows behind the kernel's rows: one launch
+    return gh, part[:t]
 
 
 def dual_backward(plan: "MessagePlan", g: Tensor, h: Tensor, table: Tensor, look_byc: Tensor, addend: Optional[Tensor] = None):
@@ -1144,10 +1143,15 @@ class _RowGather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src: Tensor, ind: Tensor):
         ctx.ind, ctx.n = ind, src.shape[0]
+        # a consumer that returns the TABLE's gradient itself (`dual_backward_tg`) sends nothing here: without this the engine would
+        # hand over an all-zero (rows, d) gradient and the reduction below would run on it
+        ctx.set_materialize_grads(False)
         return row_gather(src, narrow_i32(ind))
 
     @staticmethod
-    def backward(ctx, gout: Tensor):
+    def backward(ctx, gout: Optional[Tensor]):
+        if gout is None:
+            return None, None
         ind = ctx.ind
         g2 = _as2d(gout) if gout.dim() > 1 else gout.contiguous().reshape(-1, 1)
         if _table_grad_now(g2, ind, ctx.n):

@@ -304,3 +304,40 @@ def test_table_gradient_form_vs_f64_and_the_by_tuple_bits(dev, small_plans):
     assert bool((gt[4:] == 0).all())
     # an index without the store's bound keeps the per-edge form
     assert not _ops.dual_tg_eligible(plan, g, h, table, None, idx.clone())
+
+
+def test_the_table_gradient_form_leaves_the_lookup_backward_alone(dev, small_plans):
+    """with the table's gradient returned by the layers themselves nothing travels back through A.values: the lookup's backward must
+    not run on an all-zero gradient (autograd materialises one for a custom function unless told otherwise) -- one small-table reduction
+    per step (the node features'), not two; and the fold of the kernel's 4-row slabs writes the table's other rows as zero itself"""
+    from pygho_amd import _ops, blocks, synth
+    from pygho_amd.collate import DeviceGraphStore
+    from pygho_amd.ngnn import SpModel
+    rng = np.random.default_rng(4)
+    store = DeviceGraphStore([synth.make_graph(rng, "zinc", 3, (KEY,)) for _ in range(128)], dev)
+    torch.manual_seed(2)
+    model = SpModel(1, 2, 128, act_dtype=torch.bfloat16).to(dev)
+    model.train()
+    dd = store.collate(np.arange(96))
+    counts = {}
+    for tg in (False, True):
+        old = _ops.DUAL_TABLE_GRAD
+        _ops.DUAL_TABLE_GRAD = tg
+        try:
+            timer = _ops.LaunchTimer()
+            with timer:
+                _train_step(model, dd)
+            torch.cuda.synchronize()
+            summ = timer.summary()
+            counts[tg] = sum(v[0] for k, v in summ.items() if k.startswith("table_grad["))
+            assert any(k.endswith(",table]") for k in summ) == tg
+        finally:
+            _ops.DUAL_TABLE_GRAD = old
+    assert counts == {False: 2, True: 1}, counts
+    g = model.data_encoder.ea_encoder.weight.grad
+    assert g is not None and bool((g[4:] == 0).all()) and float(g[:4].abs().max()) > 0
+    # the fold on its own: (blocks, n) -> n sums followed by zeros, the sums being sum_blocks' bits
+    parts = torch.randn(37, 512, device=dev)
+    padded = blocks.sum_blocks(parts, 2048)
+    assert padded.shape == (2048,) and torch.equal(padded[:512], blocks.sum_blocks(parts)) and bool((padded[512:] == 0).all())
+    assert torch.equal(blocks.sum_blocks(parts, 512), blocks.sum_blocks(parts))
