@@ -291,15 +291,18 @@ int pygho_seg_scatter_write_aligned(int32_t* chunks, uint32_t* words, int32_t* c
 int pygho_seg_dual_limits(int* max_edges_per_block, int* table_rows, int* table_grad_rows);
 /* The same pass when every looked-up table row is below `table_grad_rows` of pygho_seg_dual_limits (bond types): the by-edge half
  * accumulates the gradient of the TABLE rows directly -- per lane group in registers, summed per workgroup into one f32 slab
- * tg_out[block][table_grad_rows][d] (pygho_seg_dual_tg_blocks slabs, zero-initialised by the caller, folded with pygho_sum_blocks) --
+ * tg_out[block][table_grad_rows][d] (pygho_seg_dual_tg_blocks slabs, every one written by the launch, folded with pygho_sum_blocks) --
  * instead of forming the per-edge gradient: no edge accumulators, no edge rows written and read back, no table-gradient launch behind
  * it.  `look_fwd` / `look_byc`: the table row of every message in forward / by-c order.  gh as pygho_seg_dual (same bits); the table
- * gradient is the f32 sum of exact products (autograd of Spspmm.py:309-315 + the embedding lookup of example/minimal.py:22-34). */
+ * gradient is the f32 sum of exact products (autograd of Spspmm.py:309-315 + the embedding lookup of example/minimal.py:22-34).
+ * `n_chunks_dyn` (nullable, device): the TRUE chunk count of a fixed-capacity chunk list (a batch slot's; records behind it are
+ * all-zero): the workgroups' shares are cut from it exactly as a launch sized for that count cuts them, so the table gradient's
+ * bits do not depend on the capacity; workgroups without a share write all-zero slabs. */
 int pygho_seg_dual_tg_blocks(int64_t n_chunks, int64_t d, int64_t table_rows, int dtype);
 int pygho_seg_dual_tg(void* gh, float* tg_out, const void* lhs, const void* rhs, const void* table, int64_t table_rows,
                       const int32_t* chunks, const uint32_t* words, const int32_t* cgap, const int32_t* ptr_c, const int32_t* a_byc,
                       const int32_t* look_byc, const int32_t* look_fwd, int64_t n_chunks, int64_t n_msg, int64_t d, int64_t lhs_rows,
-                      int64_t rhs_rows, int dtype, void* stream);
+                      int64_t rhs_rows, int dtype, const int32_t* n_chunks_dyn, void* stream);
 int pygho_seg_dual(void* out, void* gh, const void* addend, const void* lhs, const void* rhs, const void* table, int64_t table_rows,
                    const int32_t* chunks, const uint32_t* words, const int32_t* cgap, const int32_t* chunk0, const int32_t* blk_e,
                    const int32_t* ptr_c, const int32_t* a_byc, const int32_t* look_byc, int64_t n_blocks, int64_t n_chunks,

@@ -57,7 +57,7 @@ PROTOTYPES = {
     "pygho_seg_scatter_write_aligned": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, L, P]),
     "pygho_seg_dual_limits": (I, [P, P, P]),
     "pygho_seg_dual_tg_blocks": (I, [L, L, L, I]),
-    "pygho_seg_dual_tg": (I, [P, P, P, P, P, L, P, P, P, P, P, P, P, L, L, L, L, L, I, P]),
+    "pygho_seg_dual_tg": (I, [P, P, P, P, P, L, P, P, P, P, P, P, P, L, L, L, L, L, I, P, P]),
     "pygho_seg_dual": (I, [P, P, P, P, P, P, L, P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, P]),
     "pygho_seg_fused_limits": (I, [P, P, P, P]),
     "pygho_seg_fused_count": (I, [P, P, P, P, P, L, P]),

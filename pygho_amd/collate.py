@@ -228,6 +228,8 @@ class DeviceGraphStore:
             if parts is None:
                 continue
             n_chunks, chunk0, blk_e, chunks, words, max_edges = parts[:6]
+            # a chunk's first message, graph-LOCAL like its row fields: a batch (or a batch slot) adds the graph's message offset
+            chunks[:, 0] -= self.acd_ptr[k].to(torch.int32)[torch.repeat_interleave(torch.arange(self.num_graphs, device=d), n_chunks.long())]
             rows3 = (self.tup_ptr if roles[3][0] == "X" else self.edge_ptr)
             n_rows3 = (rows3[1:] - rows3[:-1]).to(torch.int32)
             covers = bool(((blk_e[:, 0] == 0) & (blk_e[:, 1] == n_rows3)).all())        # every graph's triples reach all of its rows
@@ -562,8 +564,7 @@ class _Layout:
             roles = parse_key(k)
             pieces[("inc", "acd", k)] = np.stack([off[fam_of(roles[i])] for i in (0, 1, 3)])
             if k in store.scatter_parts:
-                first_m = off[("acd", k)] - pieces[("start", ("acd", k))]
-                pieces[("inc", "sc", k)] = np.stack([first_m, off[fam_of(roles[0])], off[fam_of(roles[1])], np.zeros(g, dtype=np.int64)])
+                pieces[("inc", "sc", k)] = np.stack([off[("acd", k)], off[fam_of(roles[0])], off[fam_of(roles[1])], np.zeros(g, dtype=np.int64)])
                 pieces[("inc", "blk", k)] = np.stack([off[fam_of(roles[3])], np.zeros(g, dtype=np.int64)])
         wide = [np.ascontiguousarray(p, dtype=np.int64).reshape(-1) for p in pieces.values()]
         # int32 copies of the pointers that ARE plan arrays (nodes by graph; the scatter plans' chunk pointers), behind the int64 part

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(TG ? 256 : 512, TG ? 3 : 1) void seg_dual_kernel(
     const int32_t* __restrict__ cgap, const int32_t* __restrict__ chunk0, const int2* __restrict__ blk_e,
     const int32_t* __restrict__ ptr_c, const int32_t* __restrict__ a_byc, const int32_t* __restrict__ look_byc, int n_blocks, int n_chunks,
     int e_cap, uint32_t row_bytes, uint32_t lhs_bytes, uint32_t rhs_bytes, uint32_t out_bytes, uint32_t words_bytes, uint32_t ptr_bytes,
-    const int32_t* __restrict__ look_fwd = nullptr, float* __restrict__ tg_out = nullptr) {
+    const int32_t* __restrict__ look_fwd = nullptr, float* __restrict__ tg_out = nullptr, const int32_t* __restrict__ n_dyn = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char s_mem[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);            // channel slice of this wavefront
@@ -114,8 +114,18 @@ __global__ __launch_bounds__(TG ? 256 : 512, TG ? 3 : 1) void seg_dual_kernel(
   constexpr int kOob = (int)0x80000000;
 
   // ---- this workgroup's blocks (as seg_scatter_kernel: equal chunk counts) --------------------------------------------------------------
-  const int G = (int)gridDim.x, g = (int)blockIdx.x;
-  const int lo = (int)((int64_t)n_chunks * g / G), hi = (int)((int64_t)n_chunks * (g + 1) / G);
+  int G = (int)gridDim.x;
+  const int g = (int)blockIdx.x;
+  if constexpr (TG) {
+    // a batch slot's chunk list has a fixed capacity and the batch's true chunk count on the device: the shares are cut from the TRUE
+    // count over min(workgroups, true count) workgroups -- the partition (hence the order of the table gradient's f32 sums) a launch
+    // sized for exactly that batch has; the workgroups beyond write all-zero slabs, which the fold ignores bit for bit
+    if (n_dyn) {
+      n_chunks = min(n_chunks, max(__builtin_amdgcn_readfirstlane(*n_dyn), 0));
+      G = max(min(G, n_chunks), 1);
+    }
+  }
+  const int lo = g < G ? (int)((int64_t)n_chunks * g / G) : 0, hi = g < G ? (int)((int64_t)n_chunks * (g + 1) / G) : 0;
   auto first_block_at = [&](int t) {
     int l = 0, r = n_blocks;
     while (l < r) {
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(TG ? 256 : 512, TG ? 3 : 1) void seg_dual_kernel(
     pci = __builtin_amdgcn_readfirstlane(chunk0[b]);
     ci_end = __builtin_amdgcn_readfirstlane(chunk0[b_hi]);
     --b;
-  } else if (lo >= hi) return;
+  }                                                      // (TG: a workgroup without chunks still writes its all-zero slab)
 
   for (uint32_t off = (uint32_t)lane * 16u; off < (uint32_t)e_cap * kDuAccPitch; off += kWave * 16u)
     *reinterpret_cast<du_u4_t*>(s_acc + off) = zero4;
@@ -538,7 +548,8 @@ static int dual_tg_grid(int64_t n_chunks, int64_t rb, int64_t table_rows, size_t
 template <typename T>
 int launch_dual_tg(void* gh, float* tg_out, const void* lhs, const void* rhs, const void* table, int64_t table_rows, const int32_t* chunks,
                    const uint32_t* words, const int32_t* cgap, const int32_t* ptr_c, const int32_t* a_byc, const int32_t* look_byc,
-                   const int32_t* look_fwd, int64_t n_chunks, int64_t n_msg, int64_t d, int64_t lhs_rows, int64_t rhs_rows, hipStream_t st) {
+                   const int32_t* look_fwd, int64_t n_chunks, int64_t n_msg, int64_t d, int64_t lhs_rows, int64_t rhs_rows, const int32_t* n_dyn,
+                   hipStream_t st) {
   const int64_t rb = d * (int64_t)sizeof(T);
   const int waves = (int)(rb / kDuSlice);
   size_t lds = 0;
@@ -546,7 +557,7 @@ int launch_dual_tg(void* gh, float* tg_out, const void* lhs, const void* rhs, co
   hipLaunchKernelGGL((seg_dual_kernel<T, false, 1, true, true>), dim3(gx), dim3(waves * kWave), lds, st, (T*)nullptr, (T*)gh, (const T*)nullptr,
                      (const T*)lhs, (const T*)rhs, (const T*)table, (int)table_rows, (const int4*)chunks, words, cgap, (const int32_t*)nullptr,
                      (const int2*)nullptr, ptr_c, a_byc, look_byc, 0, (int)n_chunks, 0, (uint32_t)rb, (uint32_t)(lhs_rows * rb),
-                     (uint32_t)(rhs_rows * rb), 0u, (uint32_t)(n_msg * 4), (uint32_t)((rhs_rows + 1) * 4), look_fwd, tg_out);
+                     (uint32_t)(rhs_rows * rb), 0u, (uint32_t)(n_msg * 4), (uint32_t)((rhs_rows + 1) * 4), look_fwd, tg_out, n_dyn);
   return check_launch("seg_dual_tg");
 }
 
@@ -562,7 +573,7 @@ extern "C" int pygho_seg_dual_tg_blocks(int64_t n_chunks, int64_t d, int64_t tab
 extern "C" int pygho_seg_dual_tg(void* gh, float* tg_out, const void* lhs, const void* rhs, const void* table, int64_t table_rows,
                                  const int32_t* chunks, const uint32_t* words, const int32_t* cgap, const int32_t* ptr_c, const int32_t* a_byc,
                                  const int32_t* look_byc, const int32_t* look_fwd, int64_t n_chunks, int64_t n_msg, int64_t d, int64_t lhs_rows,
-                                 int64_t rhs_rows, int dtype, void* stream) {
+                                 int64_t rhs_rows, int dtype, const int32_t* n_chunks_dyn, void* stream) {
   if (n_chunks < 0 || d <= 0 || lhs_rows <= 0 || rhs_rows <= 0 || table_rows <= 0) { set_error("seg_dual_tg: bad size"); return PYGHO_ERR_INVALID; }
   if (n_chunks == 0) return PYGHO_OK;
   if (!gh || !tg_out || !lhs || !rhs || !table || !chunks || !words || !cgap || !ptr_c || !a_byc || !look_byc || !look_fwd) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
@@ -574,8 +585,8 @@ extern "C" int pygho_seg_dual_tg(void* gh, float* tg_out, const void* lhs, const
   const int64_t lim = (int64_t)1 << 31;
   if (lhs_rows * rb >= lim || rhs_rows * rb >= lim || n_msg * 4 >= lim || n_msg < 0) { set_error("seg_dual_tg: operands of 2 GiB and more are not supported"); return PYGHO_ERR_UNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == PYGHO_BF16) return launch_dual_tg<bf16>(gh, tg_out, lhs, rhs, table, table_rows, chunks, words, cgap, ptr_c, a_byc, look_byc, look_fwd, n_chunks, n_msg, d, lhs_rows, rhs_rows, st);
-  return launch_dual_tg<f16>(gh, tg_out, lhs, rhs, table, table_rows, chunks, words, cgap, ptr_c, a_byc, look_byc, look_fwd, n_chunks, n_msg, d, lhs_rows, rhs_rows, st);
+  if (dtype == PYGHO_BF16) return launch_dual_tg<bf16>(gh, tg_out, lhs, rhs, table, table_rows, chunks, words, cgap, ptr_c, a_byc, look_byc, look_fwd, n_chunks, n_msg, d, lhs_rows, rhs_rows, n_chunks_dyn, st);
+  return launch_dual_tg<f16>(gh, tg_out, lhs, rhs, table, table_rows, chunks, words, cgap, ptr_c, a_byc, look_byc, look_fwd, n_chunks, n_msg, d, lhs_rows, rhs_rows, n_chunks_dyn, st);
 }
 
 extern "C" int pygho_seg_dual_limits(int* max_edges_per_block, int* table_rows, int* table_grad_rows) {

@@ -501,7 +501,7 @@ class ScatterPlan:
     block-diagonal batch -- cut into chunks of at most 64 messages over two windows of at most 32 rows, with one packed word per
     message (`pygho_seg_scatter_count` / `_write`).  Integer work on the device; two host reads per plan (block count; chunk count +
     eligibility), cached with the MessagePlan."""
-    __slots__ = ("n_blocks", "n_chunks", "chunk0", "blk_e", "chunks", "words", "max_edges", "covers", "cgap", "covers_c")
+    __slots__ = ("n_blocks", "n_chunks", "chunk0", "blk_e", "chunks", "words", "max_edges", "covers", "cgap", "covers_c", "n_dyn")
 
 
 DUAL_BWD = os.environ.get("PYGHO_DUAL_BWD", "1") != "0"         # A/B switch: both gradients of a layer's aggregation in one pass (csrc/seg_dual.hip)
@@ -609,17 +609,21 @@ def _scatter_plan_build(plan: "MessagePlan") -> Optional[ScatterPlan]:
     sp.n_blocks, sp.n_chunks, sp.chunk0, sp.blk_e, sp.max_edges = block_m.numel() - 1, chunks.shape[0], chunk0, blk_e, max_edges
     sp.chunks, sp.words, sp.covers = chunks, words, covers
     sp.cgap, sp.covers_c = (parts[7], parts[8] == 0) if len(parts) > 7 else (None, False)
+    sp.n_dyn = None
     return sp
 
 
-def install_scatter_plan(plan: "MessagePlan", chunk0: Tensor, blk_e: Tensor, chunks: Tensor, words: Tensor, max_edges: int,
-                         covers: bool, cgap: Optional[Tensor] = None, covers_c: bool = False) -> None:
+def install_scatter_plan(plan: "MessagePlan", chunk0: Optional[Tensor], blk_e: Optional[Tensor], chunks: Tensor, words: Tensor, max_edges: int,
+                         covers: bool, cgap: Optional[Tensor] = None, covers_c: bool = False, n_dyn: Optional[Tensor] = None) -> None:
     """a ScatterPlan that already exists (`collate.DeviceGraphStore`: the chunks of a block-diagonal batch are its graphs' precomputed
     chunks with the message / row offsets added): no planner launch, no host read.  The caller guarantees the planner's contract.
-    `cgap`: the chunks are ALIGNED (they also serve the fused backward); `covers_c`: every first-operand row belongs to a chunk."""
+    `cgap`: the chunks are ALIGNED (they also serve the fused backward); `covers_c`: every first-operand row belongs to a chunk.
+    Without `chunk0` / `blk_e` (the per-block arrays) the plan serves the fused backward's table-gradient form only, which walks the
+    chunk list alone (`slots.BatchSlot`: a list of fixed capacity, all-zero records behind the batch's chunks, the true count in
+    `n_dyn` on the device)."""
     sp = ScatterPlan()
-    sp.n_blocks, sp.n_chunks, sp.chunk0, sp.blk_e, sp.max_edges, sp.covers = chunk0.numel() - 1, chunks.shape[0], chunk0, blk_e, max_edges, covers
-    sp.chunks, sp.words, sp.cgap, sp.covers_c = chunks, words, cgap, covers_c
+    sp.n_blocks, sp.n_chunks, sp.chunk0, sp.blk_e, sp.max_edges, sp.covers = (chunk0.numel() - 1 if chunk0 is not None else 0), chunks.shape[0], chunk0, blk_e, max_edges, covers
+    sp.chunks, sp.words, sp.cgap, sp.covers_c, sp.n_dyn = chunks, words, cgap, covers_c, n_dyn
     plan._scatter = sp if sp.n_chunks > 0 else False
 
 
@@ -731,17 +735,21 @@ def _fused_launch(out, h, x, wl, bias, scale, shift, act, table, look_fwd, plan,
                                     stream_ptr(dev)), "seg_fused_fwd")
 
 
-def _scatter_eligible(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], scale, addend) -> bool:
+def _scatter_eligible(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], scale, addend, tg: bool = False) -> bool:
+    """`tg`: asked for the fused backward's table-gradient form (its own size threshold; a chunk list without per-block arrays will do)"""
     if SEG_SCATTER == "0" or h is None or scale is not None or g.dtype not in (torch.bfloat16, torch.float16) or h.dtype != g.dtype:
         return False
     rb = g.shape[1] * g.element_size() if g.dim() == 2 else 0
-    if rb == 0 or rb % 64 != 0 or rb > 512 or h.dim() != 2 or h.shape[1] != g.shape[1] or plan.m < SEG_SCATTER_MIN_MESSAGES:
+    if (rb == 0 or rb % 64 != 0 or rb > 512 or h.dim() != 2 or h.shape[1] != g.shape[1]
+            or plan.m < (min(DUAL_TG_MIN_MESSAGES, SEG_SCATTER_MIN_MESSAGES) if tg else SEG_SCATTER_MIN_MESSAGES)):
         return False
     if max(g.shape[0], h.shape[0], plan.n_rhs) * rb >= (1 << 31) or g.shape[0] != plan.n_out or h.shape[0] != plan.n_lhs:
         return False
     sp = scatter_plan(plan, on_demand=True)
-    if sp is None:
+    if sp is None or (sp.chunk0 is None and not tg):
         return False
+    if tg:
+        return True
     per_wave = (sp.max_edges + 7) // 8 * 8 * 144 + 2 * 32 * 80 + 256
     return (rb // 64) * per_wave <= 160 * 1024
 
@@ -788,7 +796,7 @@ def by_edge_product(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], scale: 
 def dual_eligible(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], table: Optional[Tensor], scale: Optional[Tensor], tg: bool = False) -> bool:
     """both gradients of the aggregation in one pass (csrc/seg_dual.hip): an aligned scatter plan, 16-bit rows, a lookup table of at most
     32 rows as the second operand, sum.  `tg`: the table-gradient form (no edge accumulators: no limit on the edges per block)"""
-    if not DUAL_BWD or table is None or h is None or scale is not None or not _scatter_eligible(plan, g, h, scale, None):
+    if not DUAL_BWD or table is None or h is None or scale is not None or not _scatter_eligible(plan, g, h, scale, None, tg):
         return False
     sp = scatter_plan(plan, on_demand=True)
     if sp is None or sp.cgap is None or table.dim() != 2 or table.shape[0] > 32 or table.dtype != g.dtype:
@@ -805,6 +813,10 @@ def dual_eligible(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], table: Op
 
 
 DUAL_TABLE_GRAD = os.environ.get("PYGHO_DUAL_TABLE_GRAD", "1") != "0"      # A/B switch: the table gradient straight from the fused backward
+# the table-gradient form replaces by-tuple launch + by-edge launch + table reduction + the chain adds by ONE launch and a fold: it
+# pays from far fewer messages than the scatter form does against the gather form (captured 1024-graph step, 440 k messages: 2.43 ->
+# 2.20 ms; 128 graphs, 55 k messages: 1.165 -> 1.16 ms, i.e. nothing)
+DUAL_TG_MIN_MESSAGES = int(os.environ.get("PYGHO_DUAL_TG_MIN_MESSAGES", str(1 << 17)))
 
 
 def dual_tg_eligible(plan: "MessagePlan", g: Tensor, h: Optional[Tensor], table: Optional[Tensor], scale: Optional[Tensor],
@@ -842,7 +854,8 @@ def dual_backward_tg(plan: "MessagePlan", g: Tensor, h: Tensor, table: Tensor, l
     name = f"seg_dual[{str(g.dtype).split('.')[-1]},sum,table]"
     _timed(name, nbytes, dev, lambda: check(lib().pygho_seg_dual_tg(
         ptr(gh), ptr(slabs), ptr(g), ptr(h), ptr(table), table.shape[0], ptr(sp.chunks), ptr(sp.words), ptr(sp.cgap), ptr(pc.seg_ptr),
-        ptr(a_byc), ptr(look_byc), ptr(look_fwd), sp.n_chunks, plan.m, d, g.shape[0], h.shape[0], dtype_code(g), stream_ptr(dev)), "seg_dual_tg"))
+        ptr(a_byc), ptr(look_byc), ptr(look_fwd), sp.n_chunks, plan.m, d, g.shape[0], h.shape[0], dtype_code(g), ptr(sp.n_dyn),
+        stream_ptr(dev)), "seg_dual_tg"))
     from .blocks import sum_blocks
     t = table.shape[0]
     part = sum_blocks(slabs, max(t, rows.value) * d).reshape(-1, d)          # fold + the zero rows behind the kernel's rows: one launch

@@ -36,13 +36,21 @@ from .synth import KEYSEP, parse_key
 _I32, _I64 = torch.int32, torch.int64
 
 
+def _slotted_family(store: DeviceGraphStore, fam) -> bool:
+    """row families a slot holds: all but the by-edge scatter chunk lists, of which only ALIGNED ones are kept (they serve the fused
+    backward's table-gradient form, csrc/seg_dual.hip; the scatter kernel itself needs per-block arrays a slot does not collate)"""
+    if isinstance(fam, tuple) and fam[0] == "sc":
+        return "cgap" in store.scatter_parts.get(fam[1], {})
+    return True
+
+
 def slot_capacities(store: DeviceGraphStore, n_graphs: int, sigmas: float = 4.5, align: int = 64) -> Dict:
     """capacity per row family for batches of `n_graphs` graphs drawn at random from the store: mean + `sigmas` standard deviations
     of the batch total (a sum of n_graphs draws), never more than the n_graphs largest graphs together, rounded up to `align`, and
     made pairwise distinct and distinct from n_graphs (the extent of dim 0 names the family, `plans.row_families`)."""
     caps, used = {}, {n_graphs, n_graphs + 1}
     for fam, lens in store.h_len.items():
-        if isinstance(fam, tuple) and fam[0] == "sc":
+        if not _slotted_family(store, fam):
             continue
         lens = np.asarray(lens, dtype=np.float64)
         worst = float(np.sort(lens)[::-1][:n_graphs].sum()) if lens.size else 0.0
@@ -92,7 +100,7 @@ class BatchSlot:
         g, sd = self.g, store.sd
         # the extent of dim 0 NAMES a row family (`plans.row_families`): capacities (and capacity + 1, the CSR pointer arrays) must be
         # pairwise distinct and distinct from the graph count -- two families of one extent would silently share a row count
-        fams_ = [f for f in store.h_len if not (isinstance(f, tuple) and f[0] == "sc")]
+        fams_ = [f for f in store.h_len if _slotted_family(store, f) and not (isinstance(f, tuple) and f[0] == "sc" and f not in self.caps)]
         missing = [f for f in fams_ if f not in self.caps]
         if missing:
             raise ValueError(f"BatchSlot: no capacity for the row families {missing}")
@@ -102,7 +110,7 @@ class BatchSlot:
                              f"graphs and that + 1; got {self.caps} for {g} graphs (slot_capacities() builds a valid set)")
         fam_of = lambda role: "tup" if role[0] == "X" else "edge"
         # ---- the per-batch upload: rows of G + 1 int64 ------------------------------------------------------------------
-        self.fams = [f for f in store.h_len if not (isinstance(f, tuple) and f[0] == "sc")]
+        self.fams = list(fams_)
         names = ["ids", "arange"] + [("optr", f) for f in self.fams] + [("start", f) for f in self.fams]
         self.row_of = {n: i for i, n in enumerate(names)}
         self.lay_dev = torch.zeros((len(names), g + 1), dtype=_I64, device=dev)
@@ -230,6 +238,16 @@ class BatchSlot:
                     ent["fu_chunks"] = desc(out(4, ff, True, transposed=True), fu["chunks_t"], ff, incs=(off(fm), off("tup"), off("tup")),
                                             transposed=True)
                     ent["fu_own"] = desc(out(1, ff, True), fu["own"], ff).reshape(-1)
+                sc = store.scatter_parts.get(k)
+                fs = ("sc", k)
+                if sc is not None and "cgap" in sc and fs in self.caps and "look" in parts and fa == fc == "tup":
+                    # the fused backward's chunk list (csrc/seg_dual.hip, table-gradient form): records {first message, first output row,
+                    # first first-operand row, packed} + the graph's offsets, one packed word per message, the rows without messages a
+                    # chunk owns; records beyond the batch's chunk count stay all-zero (they end a workgroup's share), the true count
+                    # stays on the device (`counts`)
+                    ent["sc_chunks"] = desc(out(4, fs, True, transposed=True), sc["chunks_t"], fs, incs=(off(fm), off(fa), off(fc)), transposed=True)
+                    ent["sc_words"] = desc(out(1, fm, True), sc["words"], fm).reshape(-1)
+                    ent["sc_cgap"] = desc(out(1, fs, True), sc["cgap"], fs).reshape(-1)
             self.msg[k] = ent
         assert int(lib().pygho_collate_desc_bytes()) == ctypes.sizeof(_Desc)
         table = (_Desc * len(self._descs))(*self._descs)
@@ -341,6 +359,12 @@ class BatchSlot:
                 plan._lookup = (self.ea, (ent["look"][0], ent["look"][1]))      # A's values as a lookup of the edge feature
             if "fu_chunks" in ent:
                 _ops.install_fused_plan(plan, ent["fu_chunks"], ent["fu_own"])
+            if "sc_chunks" in ent:
+                # covers_c: every first-operand row of every graph of the STORE belongs to a chunk (then the by-tuple gradient needs no
+                # pre-fill; the slot's pad rows are don't-care rows like those of every row-wise result)
+                sc = st.scatter_parts[k]
+                _ops.install_scatter_plan(plan, None, None, ent["sc_chunks"], ent["sc_words"], int(sc["max_edges"]), False, ent["sc_cgap"],
+                                          bool(np.all(sc["h_cok"])), n_dyn=self.counts[("sc", k)])
             _ops.install_message_plan(ent["acd"], plan)
 
     def reset_caches(self) -> None:

@@ -235,3 +235,80 @@ def test_hash_searching_operators_refuse_a_padded_pattern(dev, store):
     dd = slot.collate(_batches(store.num_graphs, 48, 1)[0])
     with pytest.raises(RuntimeError, match="matches index tuples by hash"):
         dd["X"].diag([0, 1])
+
+
+@pytest.fixture()
+def dual_everywhere(dev):
+    """the size thresholds of the fused backward off for the duration of a test (the slot tests run 48-graph batches)"""
+    from pygho_amd import _ops
+    old = (_ops.SEG_SCATTER_MIN_MESSAGES, _ops.DUAL_TG_MIN_MESSAGES)
+    _ops.SEG_SCATTER_MIN_MESSAGES = _ops.DUAL_TG_MIN_MESSAGES = 0
+    yield
+    _ops.SEG_SCATTER_MIN_MESSAGES, _ops.DUAL_TG_MIN_MESSAGES = old
+
+
+def test_the_slot_holds_the_fused_backward_chunk_list(dev, store, dual_everywhere):
+    """the aligned chunk list of the by-edge plan in a slot: the exact batch's records on the true extent, all-zero records behind;
+    one eager step through the fused backward's table-gradient form on the slot == on the exactly sized batch, bit for bit INCLUDING
+    the embedding table's gradient (the workgroups' shares are cut from the true chunk count on the device, not from the capacity)"""
+    from pygho_amd import _ops
+    from pygho_amd.slots import BatchSlot
+    assert "cgap" in store.scatter_parts[KEY]
+    g = 48
+    slot = BatchSlot(store, g)
+    assert ("sc", KEY) in slot.caps and "sc_chunks" in slot.msg[KEY]
+    for ids in _batches(store.num_graphs, g, 3, seed=21):
+        dd_s = slot.collate(ids)
+        dd_e = store.collate(ids)
+        t, e = dd_e["X"].nnz, dd_e["A"].nnz
+        sp_e = _ops.scatter_plan(_ops.message_plan(dd_e[KEY + "___acd"], t, t, e), on_demand=True)
+        ent, n = slot.msg[KEY], slot.true_sizes()[("sc", KEY)]
+        assert n == sp_e.n_chunks and int(slot.counts[("sc", KEY)]) == n
+        assert torch.equal(ent["sc_chunks"][:n], sp_e.chunks) and int(ent["sc_chunks"][n:].abs().sum()) == 0
+        assert torch.equal(ent["sc_words"][:sp_e.words.numel()], sp_e.words) and torch.equal(ent["sc_cgap"][:n], sp_e.cgap)
+        res = []
+        for mode in ("slot", "exact"):
+            model = _model(dev)
+            step = _make_step(model, torch.optim.SGD(model.parameters(), lr=0.0))
+            timer = _ops.LaunchTimer()
+            with timer:
+                if mode == "slot":
+                    with slot.rows():
+                        loss = step(slot.collate(ids))
+                else:
+                    loss = step(store.collate(ids))
+            torch.cuda.synchronize()
+            assert any(k.endswith(",table]") for k in timer.summary()), (mode, sorted(timer.summary()))
+            res.append((loss.clone(), _grads(model)))
+        assert torch.equal(res[0][0], res[1][0])
+        _assert_same(res[0][1], res[1][1], "gradients through the fused backward (slot vs exact batch)")
+
+
+def test_captured_slot_step_through_the_fused_backward(dev, store, dual_everywhere):
+    """ONE capture with the fused forward AND the fused backward (table-gradient form) inside, 8 different batches == the eager loop on
+    `store.collate` batches bit for bit (loss, every gradient, every parameter after AdamW)"""
+    from pygho_amd import _ops
+    from pygho_amd.graphs import SlotStep
+    g, n_steps = 64, 8
+    batches = _batches(store.num_graphs, g, n_steps, seed=17)
+    warm = _batches(store.num_graphs, g, 1, seed=98)[0]
+    ref_model = _model(dev)
+    ref_step = _make_step(ref_model, torch.optim.AdamW(ref_model.parameters(), lr=1e-3, capturable=True))
+    timer = _ops.LaunchTimer()
+    with timer:
+        for _ in range(3):
+            ref_step(store.collate(warm))
+    torch.cuda.synchronize()
+    assert any(k.endswith(",table]") for k in timer.summary())
+    ref = []
+    for ids in batches:
+        loss = ref_step(store.collate(ids))
+        ref.append((loss.clone(), _grads(ref_model), {k: v.detach().clone() for k, v in ref_model.state_dict().items()}))
+    model = _model(dev)
+    ss = SlotStep(store, g, _make_step(model, torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True)), warmup_ids=warm, warmup=3)
+    for k, ids in enumerate(batches):
+        loss = ss.run(ids)
+        assert torch.equal(loss, ref[k][0]), (k, float(loss), float(ref[k][0]))
+        _assert_same(_grads(model), ref[k][1], f"gradients at step {k}")
+        _assert_same({kk: v.detach() for kk, v in model.state_dict().items()}, ref[k][2], f"model state after step {k}")
+    assert ss.replays == n_steps and ss.eager_steps == 0

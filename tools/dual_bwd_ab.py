@@ -28,7 +28,7 @@ g = torch.randn(nt, d, device=dev).to(torch.bfloat16)
 h = torch.randn(nt, d, device=dev).to(torch.bfloat16)
 table = torch.randn(16, d, device=dev).to(torch.bfloat16)
 addend = torch.randn(ne, d, device=dev).to(torch.bfloat16)
-look_byc = plan.lookup(_ops.flat_index(ea))[1]
+look_fwd, look_byc = plan.lookup(_ops.flat_index(ea))[:2]
 sp = S.scatter_plan(plan)
 assert sp is not None and sp.cgap is not None, "no aligned plan"
 pc, a_byc, _ = plan.by_c()
@@ -72,6 +72,15 @@ res["by_edge_ms"] = timed(lambda: by_edge(False))
 res["by_edge_chained_ms"] = timed(lambda: by_edge(True))
 res["dual_ms"] = timed(lambda: dual(False))
 res["dual_chained_ms"] = timed(lambda: dual(True))
+# the table-gradient form (what the training step runs): gh bit for bit, the table's gradient against the per-edge gradient summed in f64
+gh_tg, g_tab = S.dual_backward_tg(plan, g, h, table, look_fwd, look_byc)
+res["tg_gh_bit_identical"] = bool(torch.equal(gh_tg, by_tuple()))
+ref_tab = torch.zeros(16, d, dtype=torch.float64, device=dev).index_add_(0, ea, by_edge(False).double())
+res["tg_table_grad_max_rel_err_vs_summed_per_edge_rows"] = float((g_tab.double() - ref_tab).abs().max() / ref_tab.abs().max())
+res["dual_tg_ms"] = timed(lambda: S.dual_backward_tg(plan, g, h, table, look_fwd, look_byc))
+nb_tg = 2 * d * 3 * nt + 16 * plan.m + 4 * (nt + 1) + 20 * sp.n_chunks
+res["dual_tg_has_to_move_GB"] = nb_tg / 1e9
+res["dual_tg_frac_of_8TBs"] = nb_tg / res["dual_tg_ms"] / 1e6 / 8000
 nbytes = 2 * d * (3 * nt + 2 * ne) + 12 * plan.m + 4 * (nt + 1) + 20 * sp.n_chunks
 res["dual_chained_has_to_move_GB"] = nbytes / 1e9
 res["dual_chained_frac_of_8TBs"] = nbytes / res["dual_chained_ms"] / 1e6 / 8000
