@@ -88,6 +88,10 @@ def parse():
                     help="the whole step of every rank -- collation of the new batch, forward, backward, the gradient all-reduce, AdamW -- as "
                          "ONE captured HIP graph over a fixed-capacity batch slot (pygho_amd.graphs.SlotStep with the FlatGradSync inside; "
                          "RCCL only).  BASELINE config 4's operating point: python bench.py --gpus 8 --graphs 1024 --global-stream --captured")
+    ap.add_argument("--event-steps", type=int, default=4,
+                    help="HIP events around every aggregation launch (the `roofline` / `kernels` figures) in every N-th step of the timed "
+                         "region: an event pair costs the timeline ~12 us per launch (the kernel behind a record starts ~6 us late: "
+                         "profiles/r06_event_overhead_ab.txt), 0.2 ms per step with all ~18 timed launches of every step (1 = rounds 1-5)")
     ap.add_argument("--cpu-graphs", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=40.0, help="bound of the CPU baseline's four legs together (each stops early at a quarter of it)")
     return ap.parse_args()
@@ -564,15 +568,19 @@ def main():
                 step(store.collate(ids))
         torch.cuda.synchronize(dev)
     else:
+        every_n = max(1, args.event_steps)
         for k, dd in enumerate(batches()):
             if k == args.warmup:
                 barrier()
-                timer.__enter__()
                 t0 = time.perf_counter()
+            on = k >= args.warmup and (k - args.warmup) % every_n == 0
+            if on:
+                timer.__enter__()
             loss = step(dd, scales[k])
+            if on:
+                timer.__exit__(None, None, None)
         barrier()
         elapsed = elapsed_own = time.perf_counter() - t0
-        timer.__exit__(None, None, None)
     timed = id_batches[args.warmup:]
     fam_total = lambda fam: float(sum(np.asarray(store.h_len[fam])[ids].sum() for ids in timed))
     own_graphs, own_msgs = float(sum(len(ids) for ids in timed)), fam_total(("acd", KEY))
@@ -671,6 +679,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": dom_name, "other": others,
                          "launches": launches, "avg_ms": ms, "algorithmic_bytes_per_launch": nbytes,
+                         "timed_with": ("HIP events on the launch stream around every launch of "
+                                        + ("every" if max(1, args.event_steps) == 1 else f"every {max(1, args.event_steps)}th") + " step of the timed region"
+                                        if slot_step is None else "HIP events around every launch of three eager steps after the timed region"),
                          **({"replaced_launches": {
                              "what": "the two launches the fused forward kernel replaces (rounds 1-4): Linear+BatchNorm+act over the tuples "
                                      "(x in, H out) and the spspmm forward with the residual row (H, x in, out; edge rows; indices)",
