@@ -271,9 +271,10 @@ def side_regimes(args, dev):
         for mode in ("eager", "hipgraph"):
             torch.manual_seed(0)
             model = SpModel(1, args.layers, args.hidden, act_dtype=act).to(dev)
-            # eager: the fused multi-tensor AdamW (one launch); captured: its capturable form (device-side step counters)
+            # the fused multi-tensor AdamW both times; captured: its capturable form (device-side step counters).  (Rounds 4-5 captured
+            # the foreach implementation: ~0.2 ms of small launches per replay, 1.24 -> 1.05 ms at 128 graphs, profiles/r06_captured_adamw_ab.txt)
             optim = (torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True) if mode == "eager"
-                     else torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True))
+                     else torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True, fused=True))
             step = make_step(model, optim, lambda: dd)
             if mode == "eager":
                 run = step
@@ -309,7 +310,7 @@ def side_regimes(args, dev):
         # and the step in one HIP graph, row counts read on the device; per batch one small upload + one replay)
         torch.manual_seed(0)
         model = SpModel(1, args.layers, args.hidden, act_dtype=act).to(dev)
-        ss = SlotStep(small_store, graphs, make_step(model, torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True), None))
+        ss = SlotStep(small_store, graphs, make_step(model, torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True, fused=True), None))
         cids = [torch.randperm(small_store.num_graphs, generator=gen)[:graphs].numpy() for _ in range(210)]
         for k, ids in enumerate(cids):
             if k == 10:
@@ -362,7 +363,7 @@ def captured_under_sync(args, dev, store, graphs, id_batches, act):
         torch.manual_seed(0)
         model = SpModel(1, args.layers, args.hidden, act_dtype=act).to(dev)
         sync = FlatGradSync(model.parameters(), overlap=True, buckets=2)
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True, fused=True)
 
         def step(dd):
             sync.zero_grad()
@@ -517,7 +518,7 @@ def main():
     sync.broadcast_params(0)
     if args.captured and not sync.capturable:
         sys.exit("bench.py: --captured needs the RCCL backend (a host-staged collective cannot be captured into a HIP graph)")
-    opt = (torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True) if args.captured        # device-side step counters
+    opt = (torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True, fused=True) if args.captured        # device-side step counters
            else torch.optim.AdamW(model.parameters(), lr=1e-3, fused=args.optimizer == "fused"))
 
     def step(datadict, loss_scale=1.0):

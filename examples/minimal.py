@@ -79,7 +79,7 @@ def main():
 
 def train_captured(args, model, store, dev):
     """ONE captured training step for every mini-batch: fresh shuffled batches each epoch, as the reference's loader draws them"""
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True, fused=True)
 
     def step(dd):
         opt.zero_grad(set_to_none=True)

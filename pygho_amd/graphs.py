@@ -12,7 +12,8 @@ through the C ABI and no entry point synchronises or allocates, so a step on sta
   raises if one of them was written to since capture.  A NEW batch every step -- the reference's loop, example/minimal.py:141-149 --
   is served by ``SlotStep`` below: one capture over a fixed-capacity ``slots.BatchSlot`` whose sizes are read on the device;
 * the plans are built before capture (the warm-up steps below do that: plan construction reads sizes back to the host);
-* the optimizer is created with ``capturable=True``; gradients are reset with ``set_to_none=True`` inside the step;
+* the optimizer is created with ``capturable=True`` (and ``fused=True``: the foreach implementation is ~20 small launches per replay,
+  0.2 ms of a 1.2 ms step); gradients are reset with ``set_to_none=True`` inside the step;
 * no host read-back (``.item()``, ``print(loss)``) inside the step -- return tensors and read them after ``replay()``.
 
 Several captured steps (one per fixed mini-batch, ``examples/minimal.py``) may share one model and one capturable optimizer, with

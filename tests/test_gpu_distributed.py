@@ -93,7 +93,7 @@ def test_two_ranks_on_one_gpu_equal_single_process_on_the_hip_path():
 
 
 def _stepper(model, sync, capturable):
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=capturable)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=capturable, fused=True)
 
     def step(dd):
         sync.zero_grad()

@@ -284,6 +284,32 @@ def test_the_slot_holds_the_fused_backward_chunk_list(dev, store, dual_everywher
         _assert_same(res[0][1], res[1][1], "gradients through the fused backward (slot vs exact batch)")
 
 
+def test_captured_slot_step_with_the_fused_capturable_optimizer(dev, store):
+    """torch's fused multi-tensor AdamW in its capturable form inside the captured step (what bench.py and examples/minimal.py use:
+    one launch per replay instead of the foreach implementation's ~20): 10 replayed batches == the eager loop with the same optimizer,
+    bit for bit"""
+    from pygho_amd.graphs import SlotStep
+    g, n_steps = 48, 10
+    batches = _batches(store.num_graphs, g, n_steps, seed=31)
+    warm = _batches(store.num_graphs, g, 1, seed=97)[0]
+    mk = lambda m: torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True, fused=True)
+    ref_model = _model(dev)
+    ref_step = _make_step(ref_model, mk(ref_model))
+    for _ in range(3):
+        ref_step(store.collate(warm))
+    ref = []
+    for ids in batches:
+        loss = ref_step(store.collate(ids))
+        ref.append((loss.clone(), {k: v.detach().clone() for k, v in ref_model.state_dict().items()}))
+    model = _model(dev)
+    ss = SlotStep(store, g, _make_step(model, mk(model)), warmup_ids=warm, warmup=3)
+    for k, ids in enumerate(batches):
+        loss = ss.run(ids)
+        assert torch.equal(loss, ref[k][0]), (k, float(loss), float(ref[k][0]))
+        _assert_same({kk: v.detach() for kk, v in model.state_dict().items()}, ref[k][1], f"model state after step {k}")
+    assert ss.replays == n_steps and ss.eager_steps == 0
+
+
 def test_captured_slot_step_through_the_fused_backward(dev, store, dual_everywhere):
     """ONE capture with the fused forward AND the fused backward (table-gradient form) inside, 8 different batches == the eager loop on
     `store.collate` batches bit for bit (loss, every gradient, every parameter after AdamW)"""

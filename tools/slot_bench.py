@@ -49,7 +49,7 @@ def main():
         ids = [gen.permutation(store.num_graphs)[:graphs] for _ in range(args.steps + 10)]
         torch.manual_seed(0)
         model = SpModel(1, args.layers, args.hidden, act_dtype=torch.bfloat16).to(dev)
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True, fused=True)
         t0 = time.perf_counter()
         ss = SlotStep(store, graphs, make_step(model, opt))
         torch.cuda.synchronize()
