@@ -350,6 +350,12 @@ int pygho_seg_sum_f32out(float* out, const void* src, const int32_t* seg_ptr, co
  */
 int pygho_row_gather(void* out, const void* src, const int32_t* idx, const int32_t* valid,
                      int64_t n_rows, int64_t d, int dtype, void* stream);
+/* out[r] = src[idx[r]] * inv(idx[r]) with inv(i) = 1 / max(seg_ptr[i + 1] - seg_ptr[i], 1) rounded to the row type: the gradient
+ * of a segment MEAN w.r.t. its rows (torch_scatter_reduce(.., "mean"), pygho/backend/utils.py:44-56; the subgraph pooling of
+ * example/minimal.py:81) -- the bits of torch's `(gout * inv.to(dtype))[idx]`, one pass instead of six small launches and the gather.
+ * f32 / bf16 / f16 rows of a multiple of 16 bytes. */
+int pygho_row_gather_mean(void* out, const void* src, const int32_t* idx, const int32_t* seg_ptr, int64_t n_rows, int64_t d, int dtype,
+                          void* stream);
 
 /* ------------------------------------------------------------------------
  * Planner (integer, bit-exact)

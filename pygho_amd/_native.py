@@ -67,6 +67,7 @@ PROTOTYPES = {
     "pygho_seg_extremum_share": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, I, P]),
     "pygho_seg_extremum_bwd_shared": (I, [P, P, P, P, P, P, P, P, L, L, L, L, L, I, P]),
     "pygho_row_gather": (I, [P, P, P, P, L, L, I, P]),
+    "pygho_row_gather_mean": (I, [P, P, P, P, L, L, I, P]),
     "pygho_xcc_ids": (I, [P, L, P]),
     "pygho_narrow_i64_i32": (I, [P, P, L, P, P]),
     "pygho_csr_from_sorted": (I, [P, P, L, L, P, P]),

@@ -601,6 +601,36 @@ __global__ __launch_bounds__(kBlock) void row_gather_fast_kernel(
     *reinterpret_cast<uint4*>(out + r * d + (int64_t)c * N) = v;
   }
 }
+// out[r] = src[idx[r]] * inv(idx[r]),  inv(i) = 1 / max(seg_ptr[i + 1] - seg_ptr[i], 1) rounded to T: the gradient of a segment MEAN
+// w.r.t. its rows (autograd of pygho/backend/utils.py:44-56 with reduce = "mean"), i.e. torch's `(gout * inv.to(T))[idx]` in one pass --
+// f32 reciprocal (correctly rounded division), rounded to T, product formed in f32 and rounded to T: the same bits as the ATen sequence
+// (difference of the pointers, clamp, cast, reciprocal, cast, multiply: six launches) followed by the row gather.  16-byte pieces.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void row_gather_mean_kernel(T* __restrict__ out, const T* __restrict__ src, const int32_t* __restrict__ idx,
+                                                                const int32_t* __restrict__ seg_ptr, int64_t n_rows, int64_t d, int chunks) {
+  constexpr int N = Vec16<T>::N;
+  const int64_t total = n_rows * chunks;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / chunks;
+    const int c = (int)(t - r * chunks);
+    const int32_t i = idx[r];
+    const int cnt = max(seg_ptr[i + 1] - seg_ptr[i], 1);
+    float inv = 1.0f / (float)cnt;
+    if constexpr (!std::is_same<T, float>::value) {        // the factor in the storage type, as `inv.to(T)` rounds it
+      float tmp[N], back[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) tmp[j] = inv;
+      Vec16<T>::unpack(Vec16<T>::pack(tmp), back);
+      inv = back[0];
+    }
+    float v[N];
+    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(src + (int64_t)i * d + (int64_t)c * N), v);
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = v[j] * inv;
+    *reinterpret_cast<uint4*>(out + r * d + (int64_t)c * N) = Vec16<T>::pack(v);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void row_gather_generic_kernel(
     T* __restrict__ out, const T* __restrict__ src, const int32_t* __restrict__ idx,
@@ -1015,6 +1045,23 @@ extern "C" int pygho_row_gather(void* out, const void* src, const int32_t* idx, 
                        (uint64_t*)out, (const uint64_t*)src, idx, valid, n_rows, d);
   }
   return check_launch("row_gather");
+}
+
+extern "C" int pygho_row_gather_mean(void* out, const void* src, const int32_t* idx, const int32_t* seg_ptr, int64_t n_rows, int64_t d,
+                                     int dtype, void* stream) {
+  if (n_rows < 0 || d < 0) { set_error("negative size"); return PYGHO_ERR_INVALID; }
+  if (n_rows == 0 || d == 0) return PYGHO_OK;
+  if (!out || !src || !idx || !seg_ptr) { set_error("null pointer"); return PYGHO_ERR_INVALID; }
+  const int64_t es = dtype == PYGHO_F32 ? 4 : 2;
+  if (dtype != PYGHO_F32 && dtype != PYGHO_BF16 && dtype != PYGHO_F16) { set_error("row_gather_mean: dtype %d (f32, bf16, f16)", dtype); return PYGHO_ERR_UNSUPPORTED; }
+  if ((d * es) % 16 != 0 || (uintptr_t)out % 16 != 0 || (uintptr_t)src % 16 != 0) { set_error("row_gather_mean: rows must be multiples of 16 bytes, 16-byte aligned"); return PYGHO_ERR_UNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = (int)(d * es / 16);
+  const dim3 grid(grid_for(n_rows * chunks, kBlock));
+  if (dtype == PYGHO_F32) hipLaunchKernelGGL((row_gather_mean_kernel<float>), grid, dim3(kBlock), 0, st, (float*)out, (const float*)src, idx, seg_ptr, n_rows, d, chunks);
+  else if (dtype == PYGHO_BF16) hipLaunchKernelGGL((row_gather_mean_kernel<bf16>), grid, dim3(kBlock), 0, st, (bf16*)out, (const bf16*)src, idx, seg_ptr, n_rows, d, chunks);
+  else hipLaunchKernelGGL((row_gather_mean_kernel<f16>), grid, dim3(kBlock), 0, st, (f16*)out, (const f16*)src, idx, seg_ptr, n_rows, d, chunks);
+  return check_launch("row_gather_mean");
 }
 
 // f32 row sums of a 16-bit (or f32) operand: out_f32[s, :] = sum_{m in seg s} src[idx ? idx[m] : m, :]

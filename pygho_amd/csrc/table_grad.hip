@@ -22,6 +22,9 @@ namespace pygho {
 #ifndef PYGHO_TG_ROWS
 #define PYGHO_TG_ROWS 512
 #endif
+#ifndef PYGHO_TG_MIN_ROWS
+#define PYGHO_TG_MIN_ROWS 16
+#endif
 constexpr int kTgRows = PYGHO_TG_ROWS;          // rows of g per workgroup (upper bound on the grid: kTgMaxBlocks)
 constexpr int kTgMaxBlocks = 2048;
 constexpr int kTgLds = 64 * 1024;     // bytes of bins per workgroup
@@ -106,6 +109,20 @@ template <> struct TgPair<f16> {
   }
 };
 
+// slabs of the register form: enough wavefronts to keep ~2 MB of loads in flight, few enough that the slabs (n_table * d floats each)
+// stay a fraction of the input.  Small inputs: 16 rows per wavefront below kTgSmall rows, 32 above (a flat minimum of 64 made a
+// 3000-row call -- the node features of a 128-graph batch -- 50 wavefronts walking 8 dependent load rounds each: 41 -> 20 us for the
+// whole path; a flat minimum of 16 gave a 52 000-row call 3250 slabs to fold: 38 -> 48 us).  Host AND device: with the row count on
+// the device (a batch slot) every wavefront derives the partition from the TRUE count, so the f32 sums have the bits of a launch
+// sized for exactly that batch whatever the capacity is.
+constexpr int64_t kTgSmall = 16384;
+__host__ __device__ inline int64_t tg_rows_per_wave(int64_t m, int64_t n_table) {
+  const int64_t target = (n_table <= 16 ? 2048 : 1024) * PYGHO_TG_WAVES_X;
+  const int64_t mm = m > 0 ? m : 1;
+  const int64_t rpw = (mm + target - 1) / target;
+  const int64_t lo = mm < kTgSmall ? PYGHO_TG_MIN_ROWS : 2 * PYGHO_TG_MIN_ROWS;
+  return rpw < lo ? lo : rpw;
+}
 template <typename T, int NT, int CP>
 __global__ __launch_bounds__(kBlock) void table_grad_reg_kernel(float* __restrict__ ws, const T* __restrict__ g,
                                                                 const int32_t* __restrict__ idx, int64_t m, int d, int n_table,
@@ -115,9 +132,12 @@ __global__ __launch_bounds__(kBlock) void table_grad_reg_kernel(float* __restric
   constexpr int U = PYGHO_TG_UNROLL;
   const int lane = threadIdx.x & 63;
   const int64_t slab = (int64_t)blockIdx.x * (kBlock / kWave) + PYGHO_WAVE_INDEX((int)(threadIdx.x >> 6));
+  if (m_dyn) {                                           // device count: the partition of a launch sized for exactly that many rows;
+    m = *m_dyn;                                          // a slab past the last row is written as zeros below
+    rows_per_wave = tg_rows_per_wave(m, n_table);
+  }
   const int64_t r0 = slab * rows_per_wave;
   if (m_dyn == nullptr && r0 >= m) return;               // (static count: the host zeroes the slabs past the last row)
-  if (m_dyn) m = *m_dyn;                                 // device count: a slab past the last row is written as zeros below
   const int64_t r1 = r0 + rows_per_wave < m ? r0 + rows_per_wave : (m > r0 ? m : r0);
   float acc[NT][CP][2];
 #pragma unroll
@@ -170,12 +190,15 @@ __global__ __launch_bounds__(kBlock) void table_grad_reg_kernel(float* __restric
 
 static bool tg_reg_ok(int64_t d, int64_t n_table) { return n_table <= 32 && d % 2 == 0 && d <= 256; }
 
-// slabs of the register form: enough wavefronts to keep ~2 MB of loads in flight, few enough that the slabs (n_table * d floats each)
-// stay a fraction of the input
-static int64_t tg_rows_per_wave(int64_t m, int64_t n_table) {
-  const int64_t target = (n_table <= 16 ? 2048 : 1024) * PYGHO_TG_WAVES_X;
-  int64_t rpw = ceil_div(m > 0 ? m : 1, target);
-  return rpw < 64 ? 64 : rpw;
+// the most wavefronts any row count <= m asks for (the count is not monotonic across kTgSmall)
+static int64_t tg_waves_bound(int64_t m, int64_t n_table) {
+  const int64_t mm = m > 0 ? m : 1;
+  int64_t w = ceil_div(mm, tg_rows_per_wave(mm, n_table));
+  if (mm >= kTgSmall) {
+    const int64_t w0 = ceil_div(kTgSmall - 1, tg_rows_per_wave(kTgSmall - 1, n_table));
+    if (w0 > w) w = w0;
+  }
+  return w;
 }
 
 static int tg_lanes(int64_t d, int64_t n_table) {
@@ -194,7 +217,7 @@ extern "C" int pygho_table_grad_supported(int64_t d, int64_t n_table) {
 }
 
 extern "C" int pygho_table_grad_blocks(int64_t m, int64_t d, int64_t n_table) {
-  if (tg_reg_ok(d, n_table)) return (int)(ceil_div(ceil_div(m > 0 ? m : 1, tg_rows_per_wave(m, n_table)), kBlock / kWave) * (kBlock / kWave));
+  if (tg_reg_ok(d, n_table)) return (int)(ceil_div(tg_waves_bound(m, n_table), kBlock / kWave) * (kBlock / kWave));
   int64_t b = ceil_div(m, kTgRows);
   if (b < 1) b = 1;
   if (b > kTgMaxBlocks) b = kTgMaxBlocks;

@@ -415,6 +415,22 @@ def row_gather(src: Tensor, idx32: Tensor, valid: Optional[Tensor] = None) -> Te
     return out
 
 
+def row_gather_mean_ok(src: Tensor) -> bool:
+    return (src.is_cuda and src.dim() == 2 and src.dtype in (torch.float32, torch.bfloat16, torch.float16)
+            and (src.shape[1] * src.element_size()) % 16 == 0 and src.shape[1] > 0)
+
+
+def row_gather_mean(src: Tensor, idx32: Tensor, seg_ptr: Tensor) -> Tensor:
+    """src[idx] * (1 / max(segment length, 1)).to(src.dtype)[idx]: the gradient of a segment mean w.r.t. its rows in one pass -- the bits
+    of `row_gather(src * plan.inv_count.to(src.dtype).unsqueeze(-1), idx)`"""
+    dev = require_device(src, idx32, seg_ptr)
+    src = src.contiguous()
+    n, d = idx32.numel(), src.shape[1]
+    out = torch.empty((n, d), dtype=src.dtype, device=dev)
+    check(lib().pygho_row_gather_mean(ptr(out), ptr(src), ptr(idx32), ptr(seg_ptr), n, d, dtype_code(src), stream_ptr(dev)), "row_gather_mean")
+    return out
+
+
 def hash_pack(ind: Tensor, validate: bool = True) -> Tensor:
     """indicehash (SpTensor.py:10-44) on the device."""
     dev = require_device(ind)

@@ -1000,6 +1000,8 @@ class _ScatterReduce(torch.autograd.Function):
         if aggr == "sum":
             return row_gather(gout, ind32), None, None, None
         if aggr == "mean":
+            if row_gather_mean_ok(gout) and gout.data_ptr() % 16 == 0:
+                return row_gather_mean(gout, ind32, plan.seg_ptr), None, None, None       # scale and gather in one pass, same bits
             scaled = gout * plan.inv_count.to(gout.dtype).unsqueeze(-1)
             return row_gather(scaled, ind32), None, None, None
         src, fwd = ctx.saved_tensors

@@ -199,8 +199,13 @@ class BatchSlot:
             # node-level products of SUNConv are plain GEMMs over all capacity rows, which zero gradient rows leave alone)
             self._neg1 = torch.full((1,), -1, dtype=_I64, device=dev)
             self.diag_pos = desc(out(1, "node", False), store.diag_parts["pos"], "node", incs=(off("tup"),), pad=self._neg1.data_ptr()).reshape(-1)
-            self.cnt_r = torch.ones((self.caps["node"], 1), dtype=_I64, device=dev)
-            self.cnt_c = torch.ones((self.caps["node"], 1), dtype=_I64, device=dev)
+            # tuples per root / per second coordinate, clamped like honn/Conv.py's bincounts: the store's per-node counts (clamped once,
+            # here) travel with the batch in the collate kernel; pad nodes count 1  (round 5 derived them from the collated pointers
+            # with six small launches per batch)
+            self._one = torch.ones((1,), dtype=_I64, device=dev)
+            self._cnt1 = [store.root_parts["cnt"].clamp_min(1), store.group_parts[("X", 1)]["cnt"].clamp_min(1)]
+            self.cnt_r = desc(out(1, "node", False), self._cnt1[0], "node", pad=self._one.data_ptr()).reshape(-1, 1)
+            self.cnt_c = desc(out(1, "node", False), self._cnt1[1], "node", pad=self._one.data_ptr()).reshape(-1, 1)
         # 3-tuple stores: the merged (i, j) pattern of pooling the last coordinate away, its CSR pointers over the tuples, the tuple ->
         # pair map and the pairs' grouping by root (collate.DeviceGraphStore.pair_parts); pad pairs are (0, 0) with empty segments
         self.pair = None
@@ -418,9 +423,6 @@ class BatchSlot:
         check(lib().pygho_collate_batch(self.desc_dev.data_ptr(), len(self._descs), self.g, self.max_cols, stream_ptr(self.device)),
               "collate_batch")
         torch.index_select(self.store.y, 0, self.ids_dev, out=self.y)
-        if self.diag_pos is not None:              # tuples per root / per second coordinate (clamped like honn/Conv.py's bincounts)
-            for cnt, ptr in ((self.cnt_r, self.root_ptr), (self.cnt_c, self.group[("X", 1)][0])):
-                cnt.copy_((ptr[1:] - ptr[:-1]).clamp_min_(1).unsqueeze(-1))
 
     def collate(self, graph_ids) -> Dict:
         """eager use of the slot: write the batch, drop what earlier batches left in the caches; returns `.datadict`"""

@@ -1866,3 +1866,27 @@ def test_table_grad_keeps_non_finite_rows_in_their_table_row(dev, dtype):
     mask = torch.ones_like(got, dtype=torch.bool)
     mask[3, 7] = mask[9, 100] = False
     assert torch.equal(got[mask], ref[mask])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_mean_backward_in_one_pass_has_the_bits_of_the_aten_sequence(dev, dtype):
+    """the gradient of a segment mean w.r.t. its rows (`pygho_row_gather_mean`): scale by 1 / max(count, 1) rounded to the row type and
+    gather, one launch == torch's (gout * inv.to(dtype))[idx] bit for bit; segments of every length incl. empty ones and one of 1000
+    rows; through `torch_scatter_reduce(..., "mean")` the input gradient equals the plain-torch formula"""
+    from pygho_amd import _ops
+    from pygho_amd.backend.utils import torch_scatter_reduce
+    g = torch.Generator(device="cpu").manual_seed(3)
+    lens = torch.cat([torch.randint(0, 40, (300,), generator=g), torch.tensor([1000, 0, 1, 3, 7])])
+    n_seg = lens.numel()
+    idx = torch.repeat_interleave(torch.arange(n_seg), lens)
+    idx = idx[torch.randperm(idx.numel(), generator=g)].to(dev)
+    seg_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)]).to(torch.int32).to(dev)
+    gout = torch.randn(n_seg, 128, generator=g).to(dev).to(dtype)
+    inv = lens.clamp_min(1).to(torch.float32).reciprocal().to(dev)
+    want = (gout * inv.to(dtype).unsqueeze(-1))[idx]
+    got = _ops.row_gather_mean(gout, idx.to(torch.int32), seg_ptr)
+    assert torch.equal(got, want)
+    src = torch.randn(idx.numel(), 128, generator=g).to(dev).to(dtype).requires_grad_(True)
+    out = torch_scatter_reduce(0, src, idx, n_seg, "mean")
+    out.backward(gout)
+    assert torch.equal(src.grad, want)

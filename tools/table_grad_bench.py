@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygho_amd import _ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-for m, n_table in ((410_000, 16), (190_000, 32), (6_400, 16), (3_000, 32)):
+for m, n_table in ((410_000, 16), (190_000, 32), (52_000, 16), (24_000, 32), (6_400, 16), (3_000, 32)):
     g = torch.randn(m, 128, device=dev).to(torch.bfloat16)
     idx = torch.randint(0, min(n_table, 28), (m,), device=dev)
     plan = _ops.cached_plan(idx, n_table, "scatter")
