@@ -382,8 +382,8 @@ class GNNAKConv(Module):
             b = None if lin.bias is None else _ops.cast_param(lin.bias, cdt)
 
             def node_lin(x, w, bias):            # x @ w^T (+ bias); tall inputs take the split-K weight gradient (honn/utils.py)
-                if x.shape[0] >= 8192:
-                    return _SplitKLinearFn.apply(x.contiguous(), w, bias)
+                if x.shape[0] >= 8192 or (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)):
+                    return _SplitKLinearFn.apply(x.contiguous(), w, bias, True)      # (16-bit rows: the tiled weight-gradient kernel at any height)
                 return torch.nn.functional.linear(x, w, bias)
             u = node_lin(torch.cat((s_r, dg), dim=-1), W[:, :2 * d], b)           # indexed by i: pooled and centroid views
             v = node_lin(s_c, W[:, 2 * d:3 * d], None) if self.ctx else None      # indexed by j: context view
@@ -605,8 +605,8 @@ class SUNConv(Module):
             split-K kernel once instead of k times on a single-tile library GEMM."""
             x = torch.cat(parts, dim=-1).reshape(-1, len(parts) * d_)
             wt = torch.cat(blocks, dim=0).to(dt)                    # (k d, d)
-            if x.shape[0] >= 8192:
-                y = _SplitKLinearFn.apply(x, wt.t(), None)
+            if x.shape[0] >= 8192 or (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)):
+                y = _SplitKLinearFn.apply(x.contiguous(), wt.t(), None, True)
             else:
                 y = x @ wt
             return y.reshape(parts[0].shape[:-1] + (wt.shape[1],))

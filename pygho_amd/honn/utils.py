@@ -41,9 +41,13 @@ class _SplitKLinearFn(torch.autograd.Function):
     GEMM whose reduction dim is the long one (``_ops.weight_grad_splitk``)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, any_height=False):
+        # `any_height`: the weight-gradient KERNEL for short inputs too (node-level rows): its sum over the rows is cut into 64-row tiles
+        # folded in tile order, the same for an exactly sized batch and for a batch slot's capacity rows -- a library GEMM / `sum(0)` picks
+        # its split by the row count, so the two differ in the last bits
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.any_height = bool(any_height)
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
@@ -55,13 +59,13 @@ class _SplitKLinearFn(torch.autograd.Function):
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if want_b:
-                gw, gb = _ops.weight_grad_splitk(g, x, w.dtype, want_colsum=True)
+                gw, gb = _ops.weight_grad_splitk(g, x, w.dtype, want_colsum=True, any_height=ctx.any_height)
                 gb = gb.to(g.dtype)
             else:
-                gw = _ops.weight_grad_splitk(g, x, w.dtype)
+                gw = _ops.weight_grad_splitk(g, x, w.dtype, any_height=ctx.any_height)
         elif want_b:
             gb = g.sum(0)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 class _ArenaLinearFn(torch.autograd.Function):

@@ -34,12 +34,17 @@ class IndexEmbedding(nn.Embedding):
     def forward(self, idx: Tensor) -> Tensor:
         if not idx.is_cuda:
             return super().forward(idx)
-        table = self.weight if self.out_dtype is None else _ops.cast_param(self.weight, self.out_dtype)
-        if self.padding_idx is not None:            # nn.Embedding semantics: that row reads as stored (zero) and gets no gradient
-            keep = torch.ones((self.num_embeddings, 1), dtype=table.dtype, device=table.device)
-            keep[self.padding_idx] = 0
-            table = table * keep + (table * (1 - keep)).detach()
-        out = _ops.gather_rows(table, _flat_index(idx))              # persistent index object: the gather plan is cached on it
+        if self.out_dtype is not None and self.out_dtype != self.weight.dtype and self.padding_idx is None and self.weight.requires_grad:
+            # the table = the cast arena's copy of the parameter; the lookup's gradient returns to the PARAMETER in f32
+            table = _ops.param_as(self.weight, self.out_dtype)
+            out = _ops.gather_rows_master(self.weight, table, _flat_index(idx))
+        else:
+            table = self.weight if self.out_dtype is None else _ops.cast_param(self.weight, self.out_dtype)
+            if self.padding_idx is not None:            # nn.Embedding semantics: that row reads as stored (zero) and gets no gradient
+                keep = torch.ones((self.num_embeddings, 1), dtype=table.dtype, device=table.device)
+                keep[self.padding_idx] = 0
+                table = table * keep + (table * (1 - keep)).detach()
+            out = _ops.gather_rows(table, _flat_index(idx))              # persistent index object: the gather plan is cached on it
         out = out.reshape(tuple(idx.shape) + (self.embedding_dim,))
         if idx.dim() == 1:
             # provenance for consumers that can index the (tiny, cache-resident) table themselves instead of streaming the
@@ -74,7 +79,12 @@ class InputEncoderSp(nn.Module):
             out[ADJ_LOOKUP_KEY] = (look[0], look[1], out["A"].values, look[3] if len(look) > 3 else None)
         if defer_tuplefeat:
             w = self.tuplefeat_encoder.weight                 # the table itself: its 16-bit copy comes from the cast arena
-            out["X_table"] = w if self.act_dtype is None else _ops.cast_param(w, self.act_dtype)
+            if self.act_dtype is None or self.act_dtype == w.dtype:
+                out["X_table"] = w
+            else:
+                # (table copy without an autograd node, the parameter beside it: the consumer returns the table's gradient to the
+                # parameter in f32 -- `_ops.pair_product(val_master=)`)
+                out["X_table"], out["X_table_master"] = _ops.param_as(w, self.act_dtype), w
         else:
             out["X"] = datadict["X"].tuplewiseapply(lambda v: self._cast(self.tuplefeat_encoder(v)))
         return out
@@ -97,13 +107,13 @@ class SpModel(nn.Module):
         conv_mlp = dict(mlp, numlayer=1, tailact=True)
         self.subggnns = nn.ModuleList([NGNNConv(hiddim, hiddim, "sum", "SS", conv_mlp) for _ in range(num_layer)])
 
-    def tupleinit(self, X: SparseTensor, x: Tensor, table: Optional[Tensor] = None) -> SparseTensor:
+    def tupleinit(self, X: SparseTensor, x: Tensor, table: Optional[Tensor] = None, table_master: Optional[Tensor] = None) -> SparseTensor:
         """X.values * lin0(x)[root] * lin1(x)[node] (example/minimal.py:62-67); with `table`, X.values are still the
         integer tuple features and the embedding lookup table[X.values] happens inside the same kernel."""
         left, right = self.lin_tupleinit0(x), self.lin_tupleinit1(x)
         if table is not None:
             feat = _flat_index(X.values)                                            # persistent object: plans are cached on it
-            return X.tuplewiseapply(lambda _: _ops.pair_product(left, right, table, X._row(0), X._row(1), feat))
+            return X.tuplewiseapply(lambda _: _ops.pair_product(left, right, table, X._row(0), X._row(1), feat, val_master=table_master))
         val = X.values
         if val.is_cuda and val.dim() == 2 and left.dtype == right.dtype == val.dtype:
             return X.tuplewiseapply(lambda v: _ops.pair_product(left, right, v, X._row(0), X._row(1)))
@@ -162,7 +172,7 @@ class SpModel(nn.Module):
         datadict[GRAD_CHAIN_KEY] = {}           # the layers share A: its gradient is summed inside their by-edge aggregations
         A, X, x = datadict["A"], datadict["X"], datadict["x"]
         with _ops.deferred_batch_counters():               # the BatchNorm step counters of the pass: one launch instead of one per layer
-            X = self.tupleinit(X, x, datadict.get("X_table"))
+            X = self.tupleinit(X, x, datadict.get("X_table"), datadict.get("X_table_master"))
             for conv in self.subggnns:
                 X = conv.forward_residual(A, X, datadict)  # == X.add(conv.forward(A, X, datadict), True), fused
             x = self.lpool(X)

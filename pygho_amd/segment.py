@@ -1110,8 +1110,8 @@ def _table_grad_now(g2: Tensor, ind: Tensor, n_table: int) -> bool:
     return True
 
 
-def table_grad(g2: Tensor, ind: Tensor, n_table: int) -> Tensor:
-    """sum of the rows of `g2` per value of `ind` (values in [0, n_table)) as an (n_table, d) tensor of g2's dtype: the
+def table_grad(g2: Tensor, ind: Tensor, n_table: int, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    """sum of the rows of `g2` per value of `ind` (values in [0, n_table)) as an (n_table, d) tensor of g2's dtype (or `out_dtype`): the
     gradient of ``table[ind]`` for a small table (csrc/table_grad.hip: LDS bins per workgroup + a deterministic fold), accumulated
     in f32.  An index outside the table is skipped here and reported by the deferred range check of its first use."""
     dev = require_device(g2, ind)
@@ -1151,7 +1151,39 @@ def table_grad(g2: Tensor, ind: Tensor, n_table: int) -> Tensor:
     else:
         tot = torch.empty((n_table * d,), dtype=torch.float32, device=dev)
         check(lib().pygho_sum_blocks(ptr(tot), ptr(ws), nblk, n_table * d, stream_ptr(dev)), "sum_blocks")
-    return tot.view(n_table, d).to(g2.dtype)
+    return tot.view(n_table, d).to(out_dtype or g2.dtype)
+
+
+class _RowGatherMaster(torch.autograd.Function):
+    """table[ind] where `table` is the 16-bit copy (cast arena) of the f32 parameter `master`: the gradient goes to the MASTER, in its
+    dtype, straight from the f32 accumulators of the reduction -- not rounded to the table's 16 bits and cast back (two launches per
+    embedding and step, and 8 bits of every gradient entry)."""
+
+    @staticmethod
+    def forward(ctx, master: Tensor, table: Tensor, ind: Tensor):
+        ctx.ind, ctx.n, ctx.mdt = ind, table.shape[0], master.dtype
+        ctx.set_materialize_grads(False)
+        return row_gather(table, narrow_i32(ind))
+
+    @staticmethod
+    def backward(ctx, gout: Optional[Tensor]):
+        if gout is None:
+            return None, None, None
+        ind = ctx.ind
+        g2 = _as2d(gout) if gout.dim() > 1 else gout.contiguous().reshape(-1, 1)
+        if _table_grad_now(g2, ind, ctx.n):
+            g = table_grad(g2, ind, ctx.n, out_dtype=ctx.mdt)
+        else:
+            g = seg_reduce_rows(g2, cached_plan(ind, ctx.n, "scatter"), "sum").to(ctx.mdt)
+        return g.reshape((ctx.n,) + tuple(gout.shape[1:])), None, None
+
+
+def gather_rows_master(master: Tensor, table: Tensor, ind: Tensor) -> Tensor:
+    """`table[ind]` along dim 0 for `table` = a detached lower-precision copy of the parameter `master` (same shape): the gradient is
+    returned to `master`"""
+    require_device(master, table, ind)
+    assert table.shape == master.shape and not table.requires_grad
+    return _RowGatherMaster.apply(master, table, ind)
 
 
 class _RowGather(torch.autograd.Function):
@@ -1309,8 +1341,10 @@ def pair_mirror(row32: Tensor, col32: Tensor, vidx32: Tensor, n_nodes: int) -> O
     return res
 
 
-def pair_bwd(g: Tensor, left: Tensor, right: Tensor, tab: Tensor, seg_ptr: Tensor, col32: Tensor, vidx32: Tensor, mirror: Tensor):
-    """(g_left, g_right, g_tab) of `pair_product` with a table operand in one pass over g (`pygho_pair_bwd`)."""
+def pair_bwd(g: Tensor, left: Tensor, right: Tensor, tab: Tensor, seg_ptr: Tensor, col32: Tensor, vidx32: Tensor, mirror: Tensor,
+             tab_f32: bool = False):
+    """(g_left, g_right, g_tab) of `pair_product` with a table operand in one pass over g (`pygho_pair_bwd`).  `tab_f32`: the table's
+    gradient as the f32 fold of the workgroups' slabs (for the table's f32 master parameter) instead of rounded to the table's dtype."""
     dev = require_device(g, left, right, tab, seg_ptr, col32, vidx32, mirror)
     n_nodes, d = left.shape[0], left.shape[1]
     g_left, g_right = torch.empty_like(left), torch.empty_like(right)
@@ -1334,6 +1368,12 @@ def pair_bwd(g: Tensor, left: Tensor, right: Tensor, tab: Tensor, seg_ptr: Tenso
         mid = torch.empty((fan * width,), dtype=torch.float32, device=dev)
         check(lib().pygho_sum_blocks(ptr(mid), ptr(ws), nblk // fan, fan * width, stream_ptr(dev)), "sum_blocks")
         ws, nblk = mid, fan
+    if tab_f32:
+        # the fold writes the rows behind the kernel's `nt` as zeros itself (table rows without a tuple get no gradient)
+        rows = max(nt, tab.shape[0])
+        tot = torch.empty((rows * d,), dtype=torch.float32, device=dev)
+        check(lib().pygho_sum_blocks_pad(ptr(tot), ptr(ws), nblk, width, rows * d, stream_ptr(dev)), "sum_blocks_pad")
+        return g_left, g_right, tot.view(rows, d)[:tab.shape[0]]
     tot = torch.empty((width,), dtype=torch.float32, device=dev)
     check(lib().pygho_sum_blocks(ptr(tot), ptr(ws), nblk, width, stream_ptr(dev)), "sum_blocks")
     g_tab = torch.zeros((tab.shape[0], d), dtype=tab.dtype, device=dev)          # table rows without a tuple get no gradient
@@ -1349,9 +1389,11 @@ class _PairProduct(torch.autograd.Function):
     gradients are the same three-operand kernel over the unit / by-row / by-col / by-feature groupings of the tuples."""
 
     @staticmethod
-    def forward(ctx, left, right, val, row32, col32, vidx32, by_row, by_col, by_val, mirror, groupings=None):
+    def forward(ctx, left, right, val, row32, col32, vidx32, by_row, by_col, by_val, mirror, groupings=None, val_master=None):
+        # `val_master`: `val` is a (detached) 16-bit copy of this f32 parameter -- the table's gradient is returned to IT, in f32
         n = row32.numel()
         ctx.mirror, ctx.groupings = mirror, groupings
+        ctx.master_dtype = None if val_master is None else val_master.dtype
         unit_ok = USE_UNIT_TRIPLE and (left.shape[1] * left.element_size()) % 16 == 0 and left.shape[1] * left.element_size() <= 1024 \
             and left.dtype in (torch.float32, torch.bfloat16, torch.float16)
         out = seg_triple(n, left, right, val, None if unit_ok else unit_ptr(n, val.device), row32, col32, vidx32)
@@ -1367,11 +1409,15 @@ class _PairProduct(torch.autograd.Function):
         n = row32.numel()
         g_left = g_right = g_val = None
         mirror = ctx.mirror
+        mdt = ctx.master_dtype
+        to_master = mdt is not None and ctx.needs_input_grad[11]
         if (mirror is not None and g.dtype == left.dtype and g.shape[1] == left.shape[1] and left.is_contiguous()
                 and right.is_contiguous() and val.is_contiguous()):
-            g_left, g_right, g_val = pair_bwd(g, left, right, val, by_row[0].seg_ptr, col32, vidx32, mirror)
+            g_left, g_right, g_val = pair_bwd(g, left, right, val, by_row[0].seg_ptr, col32, vidx32, mirror,
+                                              tab_f32=to_master and mdt == torch.float32)
             return (g_left if ctx.needs_input_grad[0] else None, g_right if ctx.needs_input_grad[1] else None,
-                    g_val if ctx.needs_input_grad[2] else None, None, None, None, None, None, None, None, None)
+                    g_val if ctx.needs_input_grad[2] else None, None, None, None, None, None, None, None, None,
+                    g_val.to(mdt) if to_master else None)
         if by_col is None and ctx.groupings is not None:
             by_col, by_val = ctx.groupings()          # the gradient arrived in another dtype / layout than the forward promised
         if ctx.needs_input_grad[0]:
@@ -1380,7 +1426,7 @@ class _PairProduct(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             p, row_p, v_p = by_col
             g_right = seg_triple(p.n_seg, g, val, left, p.seg_ptr, p.perm, v_p if vidx32 is not None else p.perm, row_p)
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[2] or to_master:
             if vidx32 is None:
                 g_val = seg_triple(n, g, left, right, unit_ptr(n, g.device), None, row32, col32)
             else:
@@ -1390,8 +1436,9 @@ class _PairProduct(torch.autograd.Function):
                 cur = seg_triple(levels[0].numel() - 1, g, left, right, levels[0], p.perm, row_p, col_p, out_f32=len(levels) > 1)
                 for lv in levels[1:]:
                     cur = seg_gmr(lv.numel() - 1, cur, None, lv, None, None, "sum")
-                g_val = cur.to(val.dtype)
-        return g_left, g_right, g_val, None, None, None, None, None, None, None, None
+                g_val = cur.to(mdt if to_master else val.dtype)
+        return (g_left, g_right, g_val if ctx.needs_input_grad[2] else None, None, None, None, None, None, None, None, None,
+                (g_val.to(mdt) if to_master else None))
 
 
 def _grouped(plan: SegPlan, key, *idx32):
@@ -1403,11 +1450,17 @@ def _grouped(plan: SegPlan, key, *idx32):
     return memo[1]
 
 
-def pair_product(left: Tensor, right: Tensor, val: Tensor, row: Tensor, col: Tensor, val_index: Optional[Tensor] = None) -> Tensor:
+def pair_product(left: Tensor, right: Tensor, val: Tensor, row: Tensor, col: Tensor, val_index: Optional[Tensor] = None,
+                 val_master: Optional[Tensor] = None) -> Tensor:
     """``left[row] * right[col] * val`` for (n_rows, d) / (n_cols, d) node features and (nnz, d) tuple values -- or, with
     `val_index`, ``... * val[val_index]`` for a small (n_types, d) table.  `row` / `col` / `val_index` are persistent
-    int64 index arrays of the tuple pattern (plans are cached on them)."""
+    int64 index arrays of the tuple pattern (plans are cached on them).  `val_master`: the table `val` is a detached 16-bit copy of
+    this parameter (cast arena); the table's gradient is returned to the parameter in its own dtype, from f32 accumulators."""
     require_device(left, right, val, row, col, val_index)
+    if val_master is not None:
+        assert val_index is not None and val_master.shape == val.shape and not val.requires_grad
+        if not val_master.requires_grad:
+            val_master = None
     assert left.dim() == right.dim() == val.dim() == 2
     row32, col32 = narrow_i32(row), narrow_i32(col)
     vidx32 = None if val_index is None else narrow_i32(val_index)
@@ -1417,7 +1470,7 @@ def pair_product(left: Tensor, right: Tensor, val: Tensor, row: Tensor, col: Ten
     # the one-pass backward needs the tuple set's mirror permutation: decided HERE (one host read per pattern, memoised -- or
     # installed by `collate.DeviceGraphStore`), where the plans are built, so that backward never synchronises
     mirror = None
-    if (USE_PAIR_BWD and vidx32 is not None and torch.is_grad_enabled() and (left.requires_grad or right.requires_grad or val.requires_grad)
+    if (USE_PAIR_BWD and vidx32 is not None and torch.is_grad_enabled() and (left.requires_grad or right.requires_grad or val.requires_grad or val_master is not None)
             and p_row.perm is None and left.dtype in (torch.bfloat16, torch.float16) and left.dtype == right.dtype == val.dtype
             and left.shape == right.shape and (left.shape[1] * 2) % 16 == 0 and left.shape[1] * 2 <= 1024
             and left.is_contiguous() and right.is_contiguous() and val.is_contiguous()):
@@ -1436,4 +1489,4 @@ def pair_product(left: Tensor, right: Tensor, val: Tensor, row: Tensor, col: Ten
             by_val = (p_val,) + _grouped(p_val, key, row32, col32)
         return by_col, by_val
     by_col, by_val = (None, None) if mirror is not None else groupings()
-    return _PairProduct.apply(left, right, val, row32, col32, vidx32, by_row, by_col, by_val, mirror, groupings)
+    return _PairProduct.apply(left, right, val, row32, col32, vidx32, by_row, by_col, by_val, mirror, groupings, val_master)
