@@ -40,7 +40,7 @@ def _slotted_family(store: DeviceGraphStore, fam) -> bool:
     """row families a slot holds: all but the by-edge scatter chunk lists, of which only ALIGNED ones are kept (they serve the fused
     backward's table-gradient form, csrc/seg_dual.hip; the scatter kernel itself needs per-block arrays a slot does not collate)"""
     if isinstance(fam, tuple) and fam[0] == "sc":
-        return "cgap" in store.scatter_parts.get(fam[1], {})
+        return "cgap" in getattr(store, "scatter_parts", {}).get(fam[1], {})
     return True
 
 
