@@ -27,7 +27,7 @@ if CAPTURED:
         store = DeviceGraphStore(recs * 2, dev)
         torch.manual_seed(0)
         model = SpModel(1, 6, 128, act_dtype=torch.bfloat16).to(dev)
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True, fused=True)
 
         def step(dd):
             opt.zero_grad(set_to_none=True)
