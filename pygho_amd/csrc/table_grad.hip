@@ -190,15 +190,17 @@ __global__ __launch_bounds__(kBlock) void table_grad_reg_kernel(float* __restric
 
 static bool tg_reg_ok(int64_t d, int64_t n_table) { return n_table <= 32 && d % 2 == 0 && d <= 256; }
 
-// the most wavefronts any row count <= m asks for (the count is not monotonic across kTgSmall)
+// the most wavefronts any row count <= m asks for (what a launch sized for a CAPACITY must provide: the kernel cuts the partition from
+// the true count).  The count is not monotonic: it drops at kTgSmall (16 -> 32 rows per wavefront) and, once rows / target exceeds the
+// minimum, wobbles just below `target` (ceil(m / ceil(m / target)))
 static int64_t tg_waves_bound(int64_t m, int64_t n_table) {
+  const int64_t target = (n_table <= 16 ? 2048 : 1024) * PYGHO_TG_WAVES_X;
   const int64_t mm = m > 0 ? m : 1;
-  int64_t w = ceil_div(mm, tg_rows_per_wave(mm, n_table));
-  if (mm >= kTgSmall) {
-    const int64_t w0 = ceil_div(kTgSmall - 1, tg_rows_per_wave(kTgSmall - 1, n_table));
-    if (w0 > w) w = w0;
-  }
-  return w;
+  if (mm < kTgSmall) return ceil_div(mm, (int64_t)PYGHO_TG_MIN_ROWS);
+  const int64_t lo2 = 2 * PYGHO_TG_MIN_ROWS;
+  int64_t w = mm <= lo2 * target ? ceil_div(mm, lo2) : target;
+  const int64_t w0 = ceil_div(kTgSmall - 1, (int64_t)PYGHO_TG_MIN_ROWS);
+  return w > w0 ? w : w0;
 }
 
 static int tg_lanes(int64_t d, int64_t n_table) {

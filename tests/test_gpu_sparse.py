@@ -1890,3 +1890,23 @@ def test_mean_backward_in_one_pass_has_the_bits_of_the_aten_sequence(dev, dtype)
     out = torch_scatter_reduce(0, src, idx, n_seg, "mean")
     out.backward(gout)
     assert torch.equal(src.grad, want)
+
+
+@pytest.mark.parametrize("n_table,true_rows,capacity", [(16, 33 * 4096, 33 * 4096 + 1), (32, 17 * 2048, 17 * 2048 + 3), (16, 16383, 16640),
+                                                        (32, 3000, 3200), (16, 140_000, 150_016)])
+def test_small_table_gradient_with_the_row_count_on_the_device_covers_every_row(dev, n_table, true_rows, capacity):
+    """`pygho_table_grad_dyn`: the launch is sized for a CAPACITY, the kernel cuts the rows into wavefront shares from the TRUE count --
+    the partition of a launch sized for exactly that count (same bits), for which the capacity-sized launch must offer enough
+    wavefronts although their number is not monotonic in the row count (it drops where the rows per wavefront step up): true counts
+    just below such a step under capacities just above it"""
+    from pygho_amd import _ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rows = (torch.randn(capacity, 128, generator=g) * 0.1).to(dev).to(torch.bfloat16)
+    idx = torch.randint(0, min(n_table, 28), (capacity,), generator=g).to(dev)
+    want = _ops.table_grad(rows[:true_rows].contiguous(), idx[:true_rows].contiguous(), n_table, out_dtype=torch.float32)
+    cnt = torch.tensor([true_rows], dtype=torch.int32, device=dev)
+    with _ops.row_families({capacity: cnt}):
+        got = _ops.table_grad(rows, idx, n_table, out_dtype=torch.float32)
+    assert torch.equal(got, want)
+    ref = torch.zeros(n_table, 128, dtype=torch.float64, device=dev).index_add_(0, idx[:true_rows], rows[:true_rows].double())
+    torch.testing.assert_close(got.double(), ref, rtol=1e-5, atol=1e-4)
